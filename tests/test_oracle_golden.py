@@ -356,7 +356,7 @@ def test_roi_pool_interpolation_bounds():
 
 
 # ---- A14 RCNNProposal -----------------------------------------------------
-CFG14 = dict(num_classes=3, class_max_detections=100, class_nms_threshold=0.6,
+CFG14 = dict(num_classes=3, variances=None, class_max_detections=100, class_nms_threshold=0.6,
              total_max_detections=300, min_prob_threshold=0.0)
 
 
@@ -398,7 +398,7 @@ def test_rcnn_proposal_clipping_bboxpred_limits():
     prob = [(0., 1., 0.), (0., .2, .8), (0., .45, .55), (0., .55, .45), (1., 0., 0.), (1., 0., 0.),
             (0., .95, .05), (1., 0., 0.), (0., .495, .505)]
     r = of.rcnn_proposal(props, np.zeros((9, 8), F), prob, (900, 1440), num_classes=2,
-                         class_max_detections=2, class_nms_threshold=0.6, total_max_detections=3,
+                         variances=None, class_max_detections=2, class_nms_threshold=0.6, total_max_detections=3,
                          min_prob_threshold=0.0)
     lab = r['proposal_label']
     assert (lab == 0).sum() <= 2 and (lab == 1).sum() <= 2 and lab.shape[0] <= 3
