@@ -1,0 +1,240 @@
+/* luminoth_hip.h — C ABI of libluminoth_hip.so (gfx950 / MI355X).
+ *
+ * The reference (tryolabs/luminoth) has NO FFI: its hot path is a Python
+ * module protocol (luminoth/models/models.py:6-17 get_model -> FasterRCNN /
+ * SSD Sonnet modules) whose "kernels" are TensorFlow ops.  This header is the
+ * flat C boundary placed BELOW that protocol: one entry point per group of TF
+ * ops the reference calls on the path.  Each declaration
+ * cites the reference call site(s) it replaces (paths relative to
+ * /root/reference/luminoth/).
+ *
+ * Conventions
+ *  - extern "C", plain device pointers + sizes; no allocation inside; no
+ *    global state; every launch goes to the caller's `stream` (hipStream_t
+ *    passed as void*); returns 0 or a negative lmh_status, message via
+ *    lmh_last_error() (thread local).
+ *  - boxes are (x1,y1,x2,y2) fp32, inclusive-pixel convention; gt boxes are
+ *    (G,5) with the 0-based class in column 4; image shape is (H, W).
+ *  - Batched: leading B dimension, ragged per-image counts in int32 device
+ *    arrays, fixed-capacity outputs (no host synchronisation anywhere).
+ *  - "ws" = caller-provided scratch, size from the matching *_workspace_bytes.
+ */
+#ifndef LUMINOTH_HIP_H_
+#define LUMINOTH_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* lmh_stream_t; /* hipStream_t */
+
+enum lmh_status {
+  LMH_OK = 0,
+  LMH_ERR_INVALID = -1,   /* bad argument */
+  LMH_ERR_LAUNCH = -2,    /* HIP launch / runtime error */
+  LMH_ERR_WORKSPACE = -3, /* workspace too small */
+  LMH_ERR_UNSUPPORTED = -4
+};
+
+int lmh_version(void);
+const char* lmh_last_error(void);
+/* Number of HIP devices visible (used by the host side to fail loudly). */
+int lmh_device_count(void);
+
+/* ------------------------------------------------------------------ conv --
+ * Implicit-GEMM NHWC fp32 convolution on v_mfma_f32_32x32x2_f32 with a fused
+ * epilogue  y = act(conv(x,w) * scale[k] + shift[k] + residual).
+ * Replaces: tf.contrib.slim conv2d / conv2d_same + frozen batch_norm + relu of
+ * resnet_v1 (models/base/base_network.py:82-93, truncated_base_network.py:
+ * 39-95), slim vgg conv (base_network.py:70-80, truncated_vgg.py:99-121),
+ * sonnet Conv2D of the RPN (models/fasterrcnn/rpn.py:69-90,148-153) and the
+ * SSD extra layers / heads (models/ssd/feature_extractor.py:27-37,
+ * ssd.py:83-96), sonnet Linear of RCNN (models/fasterrcnn/rcnn.py:73-98) as a
+ * 1x1 convolution.
+ *   x (N,H,W,C)  w (R,S,C,K) [TF HWIO]  y (N,OH,OW,K);  pad_* = leading pads
+ *   (TF SAME / conv2d_same pads are computed by the host), OH/OW given.
+ *   scale/shift/residual may be NULL.  act: 0 none, 1 relu, 2 relu6.
+ *   in_sub (3 floats or NULL) is subtracted from in-bounds x (channel means,
+ *   base_network.py:14-16,159-177) — padding stays exactly 0.
+ */
+typedef struct lmh_conv_desc {
+  int32_t N, H, W, C;      /* input  */
+  int32_t K, R, S;         /* filter */
+  int32_t OH, OW;          /* output */
+  int32_t stride, dilation;
+  int32_t pad_top, pad_left;
+  int32_t act;
+} lmh_conv_desc;
+
+int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const float* w,
+                   const float* scale, const float* shift, const float* residual,
+                   const float* in_sub, float* y, lmh_stream_t stream);
+/* dx (N,H,W,C) = sum_{r,s,k} dy[..] * kscale[k] * w[r,s,c,k] + addend
+ * (kscale, addend may be NULL; addend may alias dx: residual-branch accumulate). */
+int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, const float* w,
+                        const float* kscale, const float* addend, float* dx,
+                        lmh_stream_t stream);
+/* dw (R,S,C,K) = sum_{n,oh,ow} x[..] * dy[..]; split-K partials are reduced
+ * deterministically through `ws`. */
+size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d);
+int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* dy,
+                          float* dw, void* ws, size_t ws_bytes, lmh_stream_t stream);
+/* g = dy * (y > 0 [&& y < 6 for relu6]); optional colsum[k] += sum_rows g
+ * (colsum must be zeroed by the caller; K = innermost dim). */
+int lmh_act_bwd(const float* dy, const float* y, int act, int64_t rows, int K,
+                float* g, float* colsum, lmh_stream_t stream);
+/* BN (frozen) parameter gradients from the raw weight gradient:
+ * dgamma[k] = rstd[k]*(sum_{rsc} w*dw_raw - mean[k]*dbeta[k]); dw = dw_raw*scale[k]. */
+int lmh_bn_param_grads(const float* w, float* dw_raw_inout, const float* dbeta,
+                       const float* mean, const float* rstd, const float* scale,
+                       int64_t rsc, int K, float* dgamma, lmh_stream_t stream);
+/* tf.nn.max_pool NHWC (slim resnet pool1 3x3/2 SAME; vgg 2x2/2 VALID; SSD 3x3/1 SAME). */
+int lmh_maxpool_fwd(const float* x, int N, int H, int W, int C, int ksize, int stride,
+                    int pad_top, int pad_left, int OH, int OW, float* y, lmh_stream_t stream);
+int lmh_maxpool_bwd(const float* x, const float* y, const float* dy, int N, int H, int W, int C,
+                    int ksize, int stride, int pad_top, int pad_left, int OH, int OW, float* dx,
+                    lmh_stream_t stream);
+
+/* ------------------------------------------------------------ proposals --
+ * RPNProposal._build (models/fasterrcnn/rpn_proposal.py:41-197) for a batch:
+ * softmax(2) (rpn.py:163) -> anchors generated on the fly with the int32
+ * truncation quirk (fasterrcnn.py:261-308) -> decode (utils/
+ * bbox_transform_tf.py:41-66) -> area>0 & score>=min_prob filter -> clip ->
+ * top_k(pre_nms_top_n) (stable: score desc, index asc) -> NMS(thr, strict >,
+ * TF continuous-area IoU) -> gather.
+ *   cls_score (B,N,2)  bbox_pred (B,N,4)  anchor_ref (A,4) int32
+ *   out: cls_prob (B,N,2), proposals (B,post_nms_top_n,4), scores (B,post),
+ *        num_proposals (B) int32.  Rows beyond num_proposals[b] are zero.
+ */
+typedef struct lmh_rpn_proposal_desc {
+  int32_t B, feat_h, feat_w, A, anchor_stride;
+  float im_h, im_w;
+  int32_t pre_nms_top_n, post_nms_top_n;
+  float nms_threshold, min_prob_threshold;
+  int32_t apply_nms, clip_after_nms, filter_outside_anchors;
+} lmh_rpn_proposal_desc;
+
+size_t lmh_rpn_proposal_workspace_bytes(const lmh_rpn_proposal_desc* d);
+int lmh_rpn_proposal(const lmh_rpn_proposal_desc* d, const float* cls_score,
+                     const float* bbox_pred, const int32_t* anchor_ref,
+                     float* cls_prob, float* proposals, float* scores,
+                     int32_t* num_proposals, void* ws, size_t ws_bytes,
+                     lmh_stream_t stream);
+
+/* Batched in-place ascending sort of u64 keys, n_pad a power of two (LDS
+ * bitonic).  Building block of top_k (tf.nn.top_k call sites:
+ * rpn_proposal.py:140, rcnn_proposal.py:152, ssd/target.py:143, ssd/proposal.py:159). */
+int lmh_sort_u64(uint64_t* keys, int B, int n_pad, lmh_stream_t stream);
+
+/* tf.image.non_max_suppression (rpn_proposal.py:152-157, rcnn_proposal.py:
+ * 114-117, ssd/proposal.py:123-126) on boxes ALREADY sorted by descending
+ * score: boxes (B,K,4) xyxy, counts (B).  keep_idx (B,max_out) indices into
+ * the sorted order (-1 padded), keep_count (B). */
+size_t lmh_nms_workspace_bytes(int B, int K);
+int lmh_nms(const float* boxes, const int32_t* counts, int B, int K, float iou_threshold,
+            int max_out, int32_t* keep_idx, int32_t* keep_count, void* ws, size_t ws_bytes,
+            lmh_stream_t stream);
+
+/* -------------------------------------------------------------- targets --
+ * RPNTarget._build (models/fasterrcnn/rpn_target.py:73-335) for a batch.
+ *   gt (B,Gmax,5), gt_count (B); seeds (B) per-image u32 for the shared
+ *   counter-based sampler (oracle/rng.py).
+ *   out: labels (B,N) f32 in {-1,0,1}; bbox_targets (B,N,4); max_overlaps
+ *   (B,N); labels_pre (B,N) labels before subsampling (may be NULL).
+ */
+typedef struct lmh_rpn_target_desc {
+  int32_t B, feat_h, feat_w, A, anchor_stride, Gmax;
+  int32_t im_h, im_w;
+  int32_t allowed_border, clobber_positives;
+  float foreground_threshold, background_threshold_high, foreground_fraction;
+  int32_t minibatch_size;
+} lmh_rpn_target_desc;
+
+size_t lmh_rpn_target_workspace_bytes(const lmh_rpn_target_desc* d);
+int lmh_rpn_target(const lmh_rpn_target_desc* d, const int32_t* anchor_ref, const float* gt,
+                   const int32_t* gt_count, const uint32_t* seeds, float* labels,
+                   float* bbox_targets, float* max_overlaps, float* labels_pre, void* ws,
+                   size_t ws_bytes, lmh_stream_t stream);
+
+/* RCNNTarget._build (models/fasterrcnn/rcnn_target.py:48-299) + the
+ * is_training batch compaction of RCNN._build (rcnn.py:156-167).
+ *   proposals (B,P,4), prop_count (B), gt (B,Gmax,5), gt_count (B)
+ *   out: labels (B,P), bbox_targets (B,P,4) [full, as the reference returns];
+ *   compacted rows with label >= 0, proposal order preserved:
+ *   rois (B,R,4), roi_labels (B,R), roi_targets (B,R,4), roi_count (B)
+ *   with R = minibatch_size (rows beyond roi_count: boxes 0, label -1).
+ */
+typedef struct lmh_rcnn_target_desc {
+  int32_t B, P, Gmax, minibatch_size;
+  float foreground_fraction, foreground_threshold, background_threshold_high,
+      background_threshold_low;
+  float variance_xy, variance_wh;
+} lmh_rcnn_target_desc;
+
+int lmh_rcnn_target(const lmh_rcnn_target_desc* d, const float* proposals,
+                    const int32_t* prop_count, const float* gt, const int32_t* gt_count,
+                    const uint32_t* seeds, float* labels, float* bbox_targets, float* labels_pre,
+                    float* rois, float* roi_labels, float* roi_targets, int32_t* roi_count,
+                    lmh_stream_t stream);
+
+/* ------------------------------------------------------------------ ROI --
+ * ROIPoolingLayer._roi_crop (models/fasterrcnn/roi_pool.py:37-95):
+ * tf.image.crop_and_resize(2ph x 2pw, bilinear, extrapolation 0) fused with
+ * the 2x2/2 VALID max pool.  feat (B,FH,FW,C); rois (B,R,4) image coords;
+ * roi_count (B) (rows beyond -> zeros).  out (B*R,ph,pw,C); argmax (same
+ * shape, u8: which of the 4 samples) for the backward.
+ */
+int lmh_roi_pool_fwd(const float* feat, const float* rois, const int32_t* roi_count, int B, int R,
+                     int FH, int FW, int C, float im_h, float im_w, int ph, int pw, float* out,
+                     uint8_t* argmax, lmh_stream_t stream);
+/* dfeat must be zeroed by the caller (scatter-add, CropAndResizeGradImage order). */
+int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const float* rois,
+                     const int32_t* roi_count, int B, int R, int FH, int FW, int C, float im_h,
+                     float im_w, int ph, int pw, float* dfeat, lmh_stream_t stream);
+/* tf.reduce_mean(features, [1,2]) (rcnn.py:185-188): x (M,S,C) -> y (M,C). */
+int lmh_spatial_mean_fwd(const float* x, int64_t M, int S, int C, float* y, lmh_stream_t stream);
+int lmh_spatial_mean_bwd(const float* dy, int64_t M, int S, int C, float* dx, lmh_stream_t stream);
+
+/* --------------------------------------------------------------- losses --
+ * RPN.loss (models/fasterrcnn/rpn.py:219-309) + smooth_l1_loss
+ * (utils/losses.py:4-32): per image  cls = mean_{label!=-1} CE,
+ * reg = mean_{label==1} sum_4 SL1_sigma; batch loss = mean over images.
+ * losses (2) = {w_cls*rpn_cls_loss, w_reg*rpn_reg_loss}; per_image (B,4) =
+ * {cls, reg, #labelled, #positive} per image (required scratch/output);
+ * gradients of (w_cls*cls + w_reg*reg) wrt cls_score / bbox_pred.
+ */
+int lmh_rpn_loss(const float* cls_score, const float* bbox_pred, const float* labels,
+                 const float* bbox_targets, int B, int N, float sigma, float w_cls, float w_reg,
+                 float* losses, float* per_image, float* d_cls_score, float* d_bbox_pred,
+                 lmh_stream_t stream);
+/* RCNN.loss (models/fasterrcnn/rcnn.py:255-411): rows (B,R), num_classes C:
+ * cls_score (B,R,C+1), bbox_offsets (B,R,4C), labels (B,R), targets (B,R,4). */
+int lmh_rcnn_loss(const float* cls_score, const float* bbox_offsets, const float* labels,
+                  const float* targets, int B, int R, int C, float sigma, float w_cls, float w_reg,
+                  float* losses, float* per_image, float* d_cls_score, float* d_bbox_offsets,
+                  lmh_stream_t stream);
+/* tf.nn.softmax over the last axis (rcnn.py:206, ssd.py:109). */
+int lmh_softmax(const float* x, int64_t rows, int C, float* y, lmh_stream_t stream);
+
+/* ------------------------------------------------------------ optimizer --
+ * tf.train.MomentumOptimizer (utils/training.py:64-81, train.py:79-91) over a
+ * flat parameter buffer split in `nseg` segments, with the L2 regulariser
+ * (rpn.py:54-56, rcnn.py:59-60, slim weight_decay) folded in:
+ *   g' = g*gscale + wd[s]*w ; [per-tensor clip_by_norm, training.py:84-120, if clip>0]
+ *   v = momentum*v + g' ; w -= lr*v
+ * seg_offset (nseg+1) int64, seg_wd (nseg) float: device arrays.
+ */
+int lmh_sgd_momentum(float* w, const float* g, float* v, int64_t n, const int64_t* seg_offset,
+                     const float* seg_wd, int nseg, float lr, float momentum, float gscale,
+                     lmh_stream_t stream);
+/* regularization_loss = sum_s wd[s] * sum(w_s^2)/2 (tf l2_regularizer), out (1) zeroed by caller. */
+int lmh_l2_reg_loss(const float* w, int64_t n, const int64_t* seg_offset, const float* seg_wd,
+                    int nseg, float* out, lmh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUMINOTH_HIP_H_ */

@@ -1,0 +1,125 @@
+"""ctypes loader for libluminoth_hip.so (the C ABI in include/luminoth_hip.h).
+
+cffi (named by BASELINE.json north_star) is not installed in this image; ctypes
+plays the same thin-FFI role.  There is NO fallback: if the library is missing
+or a call fails, the product path raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libluminoth_hip.so')
+_lib = None
+
+c_f = ctypes.c_void_p   # device pointers travel as void*
+c_i = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_fl = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        'N', 'H', 'W', 'C', 'K', 'R', 'S', 'OH', 'OW', 'stride', 'dilation',
+        'pad_top', 'pad_left', 'act')]
+
+
+class RpnProposalDesc(ctypes.Structure):
+    _fields_ = [('B', ctypes.c_int32), ('feat_h', ctypes.c_int32), ('feat_w', ctypes.c_int32),
+                ('A', ctypes.c_int32), ('anchor_stride', ctypes.c_int32),
+                ('im_h', ctypes.c_float), ('im_w', ctypes.c_float),
+                ('pre_nms_top_n', ctypes.c_int32), ('post_nms_top_n', ctypes.c_int32),
+                ('nms_threshold', ctypes.c_float), ('min_prob_threshold', ctypes.c_float),
+                ('apply_nms', ctypes.c_int32), ('clip_after_nms', ctypes.c_int32),
+                ('filter_outside_anchors', ctypes.c_int32)]
+
+
+class RpnTargetDesc(ctypes.Structure):
+    _fields_ = [('B', ctypes.c_int32), ('feat_h', ctypes.c_int32), ('feat_w', ctypes.c_int32),
+                ('A', ctypes.c_int32), ('anchor_stride', ctypes.c_int32), ('Gmax', ctypes.c_int32),
+                ('im_h', ctypes.c_int32), ('im_w', ctypes.c_int32),
+                ('allowed_border', ctypes.c_int32), ('clobber_positives', ctypes.c_int32),
+                ('foreground_threshold', ctypes.c_float), ('background_threshold_high', ctypes.c_float),
+                ('foreground_fraction', ctypes.c_float), ('minibatch_size', ctypes.c_int32)]
+
+
+class RcnnTargetDesc(ctypes.Structure):
+    _fields_ = [('B', ctypes.c_int32), ('P', ctypes.c_int32), ('Gmax', ctypes.c_int32),
+                ('minibatch_size', ctypes.c_int32),
+                ('foreground_fraction', ctypes.c_float), ('foreground_threshold', ctypes.c_float),
+                ('background_threshold_high', ctypes.c_float), ('background_threshold_low', ctypes.c_float),
+                ('variance_xy', ctypes.c_float), ('variance_wh', ctypes.c_float)]
+
+
+P = ctypes.POINTER
+SIGNATURES = {
+    # name: (restype, argtypes)   -- lists EVERY symbol include/luminoth_hip.h declares
+    'lmh_version': (c_i, []),
+    'lmh_last_error': (ctypes.c_char_p, []),
+    'lmh_device_count': (c_i, []),
+    'lmh_conv2d_fwd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_conv2d_bwd_data': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_conv2d_bwd_weight_workspace_bytes': (c_sz, [P(ConvDesc)]),
+    'lmh_conv2d_bwd_weight': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_act_bwd': (c_i, [c_f, c_f, c_i, c_i64, c_i, c_f, c_f, c_f]),
+    'lmh_bn_param_grads': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i, c_f, c_f]),
+    'lmh_maxpool_fwd': (c_i, [c_f] + [c_i] * 10 + [c_f, c_f]),
+    'lmh_maxpool_bwd': (c_i, [c_f, c_f, c_f] + [c_i] * 10 + [c_f, c_f]),
+    'lmh_rpn_proposal_workspace_bytes': (c_sz, [P(RpnProposalDesc)]),
+    'lmh_rpn_proposal': (c_i, [P(RpnProposalDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_sort_u64': (c_i, [c_f, c_i, c_i, c_f]),
+    'lmh_nms_workspace_bytes': (c_sz, [c_i, c_i]),
+    'lmh_nms': (c_i, [c_f, c_f, c_i, c_i, c_fl, c_i, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_rpn_target_workspace_bytes': (c_sz, [P(RpnTargetDesc)]),
+    'lmh_rpn_target': (c_i, [P(RpnTargetDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_rcnn_target': (c_i, [P(RcnnTargetDesc)] + [c_f] * 13),
+    'lmh_roi_pool_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_f]),
+    'lmh_roi_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
+    'lmh_spatial_mean_fwd': (c_i, [c_f, c_i64, c_i, c_i, c_f, c_f]),
+    'lmh_spatial_mean_bwd': (c_i, [c_f, c_i64, c_i, c_i, c_f, c_f]),
+    'lmh_rpn_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_rcnn_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_softmax': (c_i, [c_f, c_i64, c_i, c_f, c_f]),
+    'lmh_sgd_momentum': (c_i, [c_f, c_f, c_f, c_i64, c_f, c_f, c_i, c_fl, c_fl, c_fl, c_f]),
+    'lmh_l2_reg_loss': (c_i, [c_f, c_i64, c_f, c_f, c_i, c_f, c_f]),
+}
+
+
+class LuminothHipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into csrc/libluminoth_hip.so (in-tree)."""
+    script = os.path.join(_HERE, 'csrc', 'build.sh')
+    if force:
+        for f in os.listdir(os.path.join(_HERE, 'csrc')):
+            if f.endswith('.o'):
+                os.remove(os.path.join(_HERE, 'csrc', f))
+    subprocess.check_call(['bash', script])
+    return LIB_PATH
+
+
+def load():
+    """Load the library and bind every declared symbol.  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LuminothHipError(
+            'libluminoth_hip.so not found at %s — run `python -c "import __graft_entry__ as g; '
+            'g.build()"` (there is no CPU fallback on the product path)' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().lmh_last_error()
+        raise LuminothHipError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))

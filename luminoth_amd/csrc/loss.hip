@@ -1,0 +1,246 @@
+// Fused loss forward + gradient kernels (gfx950).
+//
+// RPN.loss   luminoth/models/fasterrcnn/rpn.py:219-309
+// RCNN.loss  luminoth/models/fasterrcnn/rcnn.py:255-411
+// smooth_l1  luminoth/utils/losses.py:4-32
+// One block per image: deterministic in-block tree reductions (no float
+// atomics), gradients written in the same launch.
+#include "lmh_common.h"
+
+#define LOSS_THREADS 1024
+
+__device__ __forceinline__ float sl1_val(float d, float sigma2) {
+  const float a = fabsf(d);
+  return (a < 1.0f / sigma2) ? 0.5f * sigma2 * (a * a) : a - 0.5f / sigma2;
+}
+__device__ __forceinline__ float sl1_grad(float d, float sigma2) {
+  const float a = fabsf(d);
+  return (a < 1.0f / sigma2) ? sigma2 * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+}
+
+// deterministic block sum of up to 4 values per thread
+__device__ void block_sum4(float v[4], float* sh /* 4 * LOSS_THREADS/64 */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float x = v[q];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+    if (lane == 0) sh[q * 16 + wave] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += sh[threadIdx.x * 16 + w];
+    sh[64 + threadIdx.x] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = sh[64 + q];
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(LOSS_THREADS)
+k_rpn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_pred,
+           const float* __restrict__ labels, const float* __restrict__ bbox_targets, int B, int N,
+           float sigma2, float w_cls, float w_reg, float* __restrict__ per_image,
+           float* __restrict__ d_cls, float* __restrict__ d_bbox) {
+  __shared__ float sh[72];
+  const int b = blockIdx.x;
+  const float2* cs = reinterpret_cast<const float2*>(cls_score) + (size_t)b * N;
+  const float4* bp = reinterpret_cast<const float4*>(bbox_pred) + (size_t)b * N;
+  const float4* bt = reinterpret_cast<const float4*>(bbox_targets) + (size_t)b * N;
+  const float* lab = labels + (size_t)b * N;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // ce_sum, n_cls, reg_sum, n_pos
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const float l = lab[n];
+    if (l != -1.f) {
+      const float2 s = cs[n];
+      const float m = fmaxf(s.x, s.y);
+      const float lse = logf(expf(s.x - m) + expf(s.y - m));
+      const float z = ((l == 1.f) ? s.y : s.x) - m;
+      acc[0] += lse - z;
+      acc[1] += 1.f;
+    }
+    if (l == 1.f) {
+      const float4 p = bp[n], t = bt[n];
+      acc[2] += ((sl1_val(p.x - t.x, sigma2) + sl1_val(p.y - t.y, sigma2)) + sl1_val(p.z - t.z, sigma2)) +
+                sl1_val(p.w - t.w, sigma2);
+      acc[3] += 1.f;
+    }
+  }
+  block_sum4(acc, sh);
+  if (threadIdx.x == 0) {
+    per_image[b * 4 + 0] = acc[0] / acc[1];  // mean of empty -> NaN, as tf.reduce_mean
+    per_image[b * 4 + 1] = acc[2] / acc[3];
+    per_image[b * 4 + 2] = acc[1];
+    per_image[b * 4 + 3] = acc[3];
+  }
+  if (!d_cls && !d_bbox) return;
+  const float gc = w_cls / (acc[1] * (float)B);
+  const float gr = w_reg / (acc[3] * (float)B);
+  float2* dc = reinterpret_cast<float2*>(d_cls) + (size_t)b * N;
+  float4* db = reinterpret_cast<float4*>(d_bbox) + (size_t)b * N;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const float l = lab[n];
+    float2 g = make_float2(0.f, 0.f);
+    float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (l != -1.f) {
+      const float2 s = cs[n];
+      const float m = fmaxf(s.x, s.y);
+      const float e0 = expf(s.x - m), e1 = expf(s.y - m);
+      const float den = e0 + e1;
+      const float p0 = e0 / den, p1 = e1 / den;
+      g.x = (p0 - ((l == 1.f) ? 0.f : 1.f)) * gc;
+      g.y = (p1 - ((l == 1.f) ? 1.f : 0.f)) * gc;
+    }
+    if (l == 1.f) {
+      const float4 p = bp[n], t = bt[n];
+      gb.x = sl1_grad(p.x - t.x, sigma2) * gr;
+      gb.y = sl1_grad(p.y - t.y, sigma2) * gr;
+      gb.z = sl1_grad(p.z - t.z, sigma2) * gr;
+      gb.w = sl1_grad(p.w - t.w, sigma2) * gr;
+    }
+    if (d_cls) dc[n] = g;
+    if (d_bbox) db[n] = gb;
+  }
+}
+
+// losses[q] = mean_b per_image[b*4 + q], q in {0,1}
+__global__ void k_loss_mean(const float* __restrict__ per_image, int B, float w0, float w1,
+                            float* __restrict__ losses) {
+  if (threadIdx.x < 2) {
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) t += per_image[b * 4 + threadIdx.x];
+    losses[threadIdx.x] = (t / (float)B) * (threadIdx.x == 0 ? w0 : w1);
+  }
+}
+
+extern "C" int lmh_rpn_loss(const float* cls_score, const float* bbox_pred, const float* labels,
+                            const float* bbox_targets, int B, int N, float sigma, float w_cls,
+                            float w_reg, float* losses, float* per_image, float* d_cls_score,
+                            float* d_bbox_pred, lmh_stream_t stream) {
+  LMH_CHECK_ARG(cls_score && bbox_pred && labels && bbox_targets && losses && per_image);
+  LMH_CHECK_ARG(B > 0 && N > 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rpn_loss, dim3(B), dim3(LOSS_THREADS), 0, st, cls_score, bbox_pred, labels,
+                     bbox_targets, B, N, sigma * sigma, w_cls, w_reg, per_image, d_cls_score, d_bbox_pred);
+  hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, w_cls, w_reg, losses);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// RCNN loss: rows (B,R); a wave per row, lanes over classes.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(LOSS_THREADS)
+k_rcnn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_offsets,
+            const float* __restrict__ labels, const float* __restrict__ targets, int B, int R, int C,
+            float sigma2, float w_cls, float w_reg, float* __restrict__ per_image,
+            float* __restrict__ d_cls, float* __restrict__ d_off) {
+  __shared__ float sh[72];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int C1 = C + 1;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = wave; r < R; r += nw) {
+    const size_t row = (size_t)b * R + r;
+    const float l = labels[row];
+    if (l >= 0.f) {
+      const float* s = cls_score + row * C1;
+      float m = -INFINITY;
+      for (int c = lane; c < C1; c += 64) m = fmaxf(m, s[c]);
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      float se = 0.f;
+      for (int c = lane; c < C1; c += 64) se += expf(s[c] - m);
+      for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+      if (lane == 0) {
+        acc[0] += logf(se) - (s[(int)l] - m);
+        acc[1] += 1.f;
+        if (l > 0.f) {
+          const float* p = bbox_offsets + row * 4 * C + 4 * ((int)l - 1);
+          const float* t = targets + row * 4;
+          acc[2] += ((sl1_val(p[0] - t[0], sigma2) + sl1_val(p[1] - t[1], sigma2)) +
+                     sl1_val(p[2] - t[2], sigma2)) + sl1_val(p[3] - t[3], sigma2);
+          acc[3] += 1.f;
+        }
+      }
+    }
+  }
+  block_sum4(acc, sh);
+  if (threadIdx.x == 0) {
+    per_image[b * 4 + 0] = acc[0] / acc[1];
+    per_image[b * 4 + 1] = acc[2] / acc[3];
+    per_image[b * 4 + 2] = acc[1];
+    per_image[b * 4 + 3] = acc[3];
+  }
+  if (!d_cls && !d_off) return;
+  const float gc = w_cls / (acc[1] * (float)B);
+  const float gr = w_reg / (acc[3] * (float)B);
+  for (int r = wave; r < R; r += nw) {
+    const size_t row = (size_t)b * R + r;
+    const float l = labels[row];
+    if (d_cls) {
+      const float* s = cls_score + row * C1;
+      float* g = d_cls + row * C1;
+      if (l >= 0.f) {
+        float m = -INFINITY;
+        for (int c = lane; c < C1; c += 64) m = fmaxf(m, s[c]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float se = 0.f;
+        for (int c = lane; c < C1; c += 64) se += expf(s[c] - m);
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+        for (int c = lane; c < C1; c += 64)
+          g[c] = (expf(s[c] - m) / se - ((c == (int)l) ? 1.f : 0.f)) * gc;
+      } else {
+        for (int c = lane; c < C1; c += 64) g[c] = 0.f;
+      }
+    }
+    if (d_off) {
+      float* g = d_off + row * 4 * C;
+      const int lo = (l > 0.f) ? 4 * ((int)l - 1) : -1;
+      for (int c = lane; c < 4 * C; c += 64) {
+        float v = 0.f;
+        if (lo >= 0 && c >= lo && c < lo + 4)
+          v = sl1_grad(bbox_offsets[row * 4 * C + c] - targets[row * 4 + (c - lo)], sigma2) * gr;
+        g[c] = v;
+      }
+    }
+  }
+}
+
+extern "C" int lmh_rcnn_loss(const float* cls_score, const float* bbox_offsets, const float* labels,
+                             const float* targets, int B, int R, int C, float sigma, float w_cls,
+                             float w_reg, float* losses, float* per_image, float* d_cls_score,
+                             float* d_bbox_offsets, lmh_stream_t stream) {
+  LMH_CHECK_ARG(cls_score && bbox_offsets && labels && targets && losses && per_image);
+  LMH_CHECK_ARG(B > 0 && R > 0 && C > 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rcnn_loss, dim3(B), dim3(LOSS_THREADS), 0, st, cls_score, bbox_offsets, labels,
+                     targets, B, R, C, sigma * sigma, w_cls, w_reg, per_image, d_cls_score, d_bbox_offsets);
+  hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, w_cls, w_reg, losses);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+// tf.nn.softmax over the last axis: one wave per row.
+__global__ void __launch_bounds__(256)
+k_softmax(const float* __restrict__ x, int64_t rows, int C, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* s = x + r * C;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, s[c]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += expf(s[c] - m);
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+  for (int c = lane; c < C; c += 64) y[r * C + c] = expf(s[c] - m) / se;
+}
+extern "C" int lmh_softmax(const float* x, int64_t rows, int C, float* y, lmh_stream_t stream) {
+  LMH_CHECK_ARG(x && y && rows > 0 && C > 0);
+  hipLaunchKernelGGL(k_softmax, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                     rows, C, y);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}

@@ -1,0 +1,428 @@
+// RPN proposal pipeline + batched sort + NMS (gfx950).
+//
+// Reference semantics: luminoth/models/fasterrcnn/rpn_proposal.py:41-197,
+// tf.nn.top_k, tf.image.non_max_suppression (TF 1.x CPU kernels, restated in
+// oracle/tfops.py).  All kernels are HBM/latency-bound integer + fp32 scalar
+// work: coalesced SoA-free float4 box loads, LDS bitonic sort, 64x64 IoU
+// bit-mask tiles (one u64 word per lane) and a wave-serial greedy reduce.
+#include "lmh_common.h"
+
+// ----------------------------------------------------------------------------
+// 1. decode + clip + validity + sort key   (one thread per anchor)
+// ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_rpn_decode(lmh_rpn_proposal_desc d, int N, int Npad, const float* __restrict__ cls_score,
+             const float* __restrict__ bbox_pred, const int32_t* __restrict__ anchor_ref,
+             float* __restrict__ cls_prob, float4* __restrict__ boxes, uint64_t* __restrict__ keys,
+             int32_t* __restrict__ n_valid) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= Npad) return;
+  uint64_t key = ~0ull;
+  if (n < N) {
+    const size_t row = (size_t)b * N + n;
+    // tf.nn.softmax over 2 logits (rpn.py:163): max-subtracted exp / sum.
+    const float2 s = reinterpret_cast<const float2*>(cls_score)[row];
+    const float m = fmaxf(s.x, s.y);
+    const float e0 = expf(s.x - m), e1 = expf(s.y - m);
+    const float den = e0 + e1;
+    const float p0 = e0 / den, p1 = e1 / den;
+    reinterpret_cast<float2*>(cls_prob)[row] = make_float2(p0, p1);
+
+    int32_t a4[4];
+    lmh_anchor(anchor_ref, n, d.A, d.feat_w, d.anchor_stride, a4);
+    bool ok = true;
+    if (d.filter_outside_anchors) {  // rpn_proposal.py:69-90 (int32 compares)
+      ok = a4[0] >= 0 && a4[1] >= 0 && a4[2] < (int)d.im_w && a4[3] < (int)d.im_h;
+    }
+    lmh_box roi = {(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+    const float4 dl = reinterpret_cast<const float4*>(bbox_pred)[row];
+    lmh_box p = lmh_decode(roi, dl.x, dl.y, dl.z, dl.w, 1.f, 1.f);
+    // zero/negative area filter has NO +1 (rpn_proposal.py:101-105)
+    const bool area_ok = fmaxf(p.x2 - p.x1, 0.f) * fmaxf(p.y2 - p.y1, 0.f) > 0.f;
+    ok = ok && area_ok && (p1 >= d.min_prob_threshold);
+    if (!d.clip_after_nms) p = lmh_clip(p, d.im_h, d.im_w);
+    boxes[row] = make_float4(p.x1, p.y1, p.x2, p.y2);
+    if (ok) {
+      // ascending u64 sort == (score desc, index asc): tf.nn.top_k order.
+      key = ((uint64_t)(~lmh_float_orderable(p1)) << 32) | (uint32_t)n;
+    }
+  }
+  keys[(size_t)b * Npad + n] = key;
+  // per-image valid count: one atomic per wave
+  const unsigned long long bal = __ballot(key != ~0ull);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&n_valid[b], __popcll(bal));
+}
+
+// ----------------------------------------------------------------------------
+// 2. batched bitonic sort of u64 keys (ascending).  Chunks of SORT_CHUNK keys
+//    are sorted / merged in LDS; strides >= SORT_CHUNK go through global.
+// ----------------------------------------------------------------------------
+#define SORT_CHUNK 4096
+#define SORT_THREADS 512
+
+__device__ __forceinline__ void cmp_swap(uint64_t& a, uint64_t& b, bool asc) {
+  if ((a > b) == asc) { uint64_t t = a; a = b; b = t; }
+}
+
+// Sort (full network up to k = min(n_pad, SORT_CHUNK)) each chunk in LDS.
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_local(uint64_t* __restrict__ keys, int n_pad, int chunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
+  const size_t base = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * chunk;
+  for (int i = threadIdx.x; i < chunk; i += blockDim.x) s[i] = keys[base + i];
+  __syncthreads();
+  const int gbase = blockIdx.x * chunk;
+  for (int k = 2; k <= chunk; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < chunk / 2; t += blockDim.x) {
+        const int i = 2 * t - (t & (j - 1));  // index with bit j clear
+        const bool asc = (((gbase + i) & k) == 0);
+        cmp_swap(s[i], s[i + j], asc);
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < chunk; i += blockDim.x) keys[base + i] = s[i];
+}
+
+// One global compare-exchange pass (stride j >= chunk) of merge step k.
+__global__ void __launch_bounds__(256)
+k_sort_global(uint64_t* __restrict__ keys, int n_pad, int k, int j) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_pad / 2) return;
+  uint64_t* kb = keys + (size_t)blockIdx.y * n_pad;
+  const int i = 2 * t - (t & (j - 1));
+  uint64_t a = kb[i], b = kb[i + j];
+  const bool asc = ((i & k) == 0);
+  if ((a > b) == asc) { kb[i] = b; kb[i + j] = a; }
+}
+
+// Finish merge step k inside each chunk (strides chunk/2 .. 1) in LDS.
+__global__ void __launch_bounds__(SORT_THREADS)
+k_sort_merge_local(uint64_t* __restrict__ keys, int n_pad, int chunk, int k) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
+  const size_t base = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * chunk;
+  for (int i = threadIdx.x; i < chunk; i += blockDim.x) s[i] = keys[base + i];
+  __syncthreads();
+  const bool asc = (((blockIdx.x * chunk) & k) == 0);
+  for (int j = chunk >> 1; j > 0; j >>= 1) {
+    for (int t = threadIdx.x; t < chunk / 2; t += blockDim.x) {
+      const int i = 2 * t - (t & (j - 1));
+      cmp_swap(s[i], s[i + j], asc);
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < chunk; i += blockDim.x) keys[base + i] = s[i];
+}
+
+static int sort_u64_impl(uint64_t* keys, int B, int n_pad, hipStream_t st) {
+  if (n_pad <= 1) return LMH_OK;
+  const int chunk = n_pad < SORT_CHUNK ? n_pad : SORT_CHUNK;
+  const size_t lds = (size_t)chunk * sizeof(uint64_t);
+  dim3 gl(n_pad / chunk, B);
+  hipLaunchKernelGGL(k_sort_local, gl, dim3(SORT_THREADS), lds, st, keys, n_pad, chunk);
+  for (int k = chunk * 2; k <= n_pad; k <<= 1) {
+    for (int j = k >> 1; j >= chunk; j >>= 1) {
+      dim3 gg((n_pad / 2 + 255) / 256, B);
+      hipLaunchKernelGGL(k_sort_global, gg, dim3(256), 0, st, keys, n_pad, k, j);
+    }
+    hipLaunchKernelGGL(k_sort_merge_local, gl, dim3(SORT_THREADS), lds, st, keys, n_pad, chunk, k);
+  }
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+extern "C" int lmh_sort_u64(uint64_t* keys, int B, int n_pad, lmh_stream_t stream) {
+  LMH_CHECK_ARG(keys != nullptr && B > 0 && n_pad > 0);
+  LMH_CHECK_ARG((n_pad & (n_pad - 1)) == 0);
+  return sort_u64_impl(keys, B, n_pad, (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------
+// 3. gather the top-k (sorted) boxes + scores
+// ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gather_topk(const uint64_t* __restrict__ keys, const float4* __restrict__ boxes,
+              const float* __restrict__ cls_prob, const int32_t* __restrict__ n_valid, int N,
+              int Npad, int K, float4* __restrict__ top_boxes, float* __restrict__ top_scores,
+              int32_t* __restrict__ top_count) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cnt = min(n_valid[b], K);
+  if (i == 0) top_count[b] = cnt;
+  if (i >= K) return;
+  float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sc = 0.f;
+  if (i < cnt) {
+    const uint32_t n = (uint32_t)(keys[(size_t)b * Npad + i] & 0xFFFFFFFFull);
+    bx = boxes[(size_t)b * N + n];
+    sc = cls_prob[((size_t)b * N + n) * 2 + 1];
+  }
+  top_boxes[(size_t)b * K + i] = bx;
+  top_scores[(size_t)b * K + i] = sc;
+}
+
+// ----------------------------------------------------------------------------
+// 4. NMS.  Phase 1: 64x64 suppression bit tiles (upper triangle).
+//    TF IOUGreaterThanThreshold: min/max-normalised corners, continuous areas
+//    (no +1), IoU := inter/(a_i+a_j-inter), suppressed iff IoU > thr (strict),
+//    never when either area <= 0.
+// ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts, int K, int W,
+           float thr, uint64_t* __restrict__ mask) {
+  const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  const int cnt = counts[b];
+  if (rb * 64 >= cnt || cb * 64 >= cnt) return;
+  __shared__ float4 cbox[64];
+  __shared__ float carea[64];
+  const int lane = threadIdx.x;
+  const float4* bb = boxes + (size_t)b * K;
+  {
+    const int c = cb * 64 + lane;
+    float4 v = (c < cnt) ? bb[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 nrm = make_float4(fminf(v.x, v.z), fminf(v.y, v.w), fmaxf(v.x, v.z), fmaxf(v.y, v.w));
+    cbox[lane] = nrm;
+    carea[lane] = (c < cnt) ? (nrm.w - nrm.y) * (nrm.z - nrm.x) : 0.f;
+  }
+  __syncthreads();
+  const int r = rb * 64 + lane;
+  uint64_t word = 0;
+  if (r < cnt) {
+    const float4 v = bb[r];
+    const float x1 = fminf(v.x, v.z), y1 = fminf(v.y, v.w), x2 = fmaxf(v.x, v.z), y2 = fmaxf(v.y, v.w);
+    const float area_r = (y2 - y1) * (x2 - x1);
+    if (area_r > 0.f) {
+      const int jstart = (cb == rb) ? lane + 1 : 0;
+      for (int j = jstart; j < 64; ++j) {
+        const float area_c = carea[j];
+        if (!(area_c > 0.f)) continue;
+        const float4 c = cbox[j];
+        const float iy1 = fmaxf(y1, c.y), ix1 = fmaxf(x1, c.x);
+        const float iy2 = fminf(y2, c.w), ix2 = fminf(x2, c.z);
+        const float inter = fmaxf(iy2 - iy1, 0.f) * fmaxf(ix2 - ix1, 0.f);
+        const float iou = inter / ((area_r + area_c) - inter);
+        if (iou > thr) word |= (1ull << j);
+      }
+    }
+  }
+  if (r < K) mask[((size_t)b * K + r) * W + cb] = word;
+}
+
+//    Phase 2: greedy reduce, one 256-thread block per image.  Wave 0 resolves
+//    the 64 candidates of a chunk serially in registers (diagonal word per
+//    lane), then all waves OR the kept rows into the LDS `removed` bitmap.
+#define NMS_RED_THREADS 256
+__global__ void __launch_bounds__(NMS_RED_THREADS)
+k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts, int K, int W,
+             int max_out, int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* removed = reinterpret_cast<unsigned long long*>(smem_raw);  // W words
+  __shared__ unsigned long long s_kept;
+  __shared__ int s_total;
+  const int b = blockIdx.x;
+  const int cnt = counts[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t* mb = mask + (size_t)b * K * W;
+  int32_t* kidx = keep_idx + (size_t)b * max_out;
+  for (int w = tid; w < W; w += blockDim.x) removed[w] = 0ull;
+  for (int i = tid; i < max_out; i += blockDim.x) kidx[i] = -1;
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  const int nchunks = (cnt + 63) / 64;
+  for (int c = 0; c < nchunks; ++c) {
+    if (wave == 0) {
+      const int r = c * 64 + lane;
+      const uint64_t diag = (r < cnt) ? mb[(size_t)r * W + c] : 0ull;
+      const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+      const int nin = min(64, cnt - c * 64);
+      uint64_t alive = ~removed[c];
+      if (nin < 64) alive &= ((1ull << nin) - 1ull);
+      uint64_t kept = 0;
+      int total = s_total;
+      while (alive && total < max_out) {
+        const int j = __builtin_ctzll(alive);
+        kept |= (1ull << j);
+        ++total;
+        const uint64_t dj = ((uint64_t)__builtin_amdgcn_readlane(dhi, j) << 32) |
+                            (uint64_t)__builtin_amdgcn_readlane(dlo, j);
+        alive &= ~dj;
+        alive &= ~(1ull << j);
+      }
+      // write kept indices in order
+      if ((kept >> lane) & 1ull) {
+        const int pos = s_total + __popcll(kept & ((1ull << lane) - 1ull));
+        kidx[pos] = c * 64 + lane;
+      }
+      if (lane == 0) { s_kept = kept; s_total = total; }
+    }
+    __syncthreads();
+    const uint64_t kept = s_kept;
+    const bool done = (s_total >= max_out);
+    if (done) break;
+    // OR rows of kept candidates into removed[c+1 .. W)
+    const int nk = __popcll(kept);
+    for (int q = wave; q < nk; q += NMS_RED_THREADS / 64) {
+      // q-th set bit of kept
+      uint64_t kk = kept;
+      for (int s = 0; s < q; ++s) kk &= kk - 1;
+      const int j = __builtin_ctzll(kk);
+      const uint64_t* row = mb + (size_t)(c * 64 + j) * W;
+      for (int w = c + 1 + lane; w < nchunks; w += 64) {  // words >= nchunks are never written
+        const uint64_t v = row[w];
+        if (v) atomicOr(&removed[w], (unsigned long long)v);
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) keep_count[b] = s_total;
+}
+
+extern "C" size_t lmh_nms_workspace_bytes(int B, int K) {
+  const size_t W = (size_t)(K + 63) / 64;
+  return lmh_align_up((size_t)B * K * W * sizeof(uint64_t), 256);
+}
+
+static int nms_impl(const float* boxes, const int32_t* counts, int B, int K, float thr, int max_out,
+                    int32_t* keep_idx, int32_t* keep_count, void* ws, hipStream_t st) {
+  const int W = (K + 63) / 64;
+  uint64_t* mask = reinterpret_cast<uint64_t*>(ws);
+  dim3 g(W, W, B);
+  hipLaunchKernelGGL(k_nms_mask, g, dim3(64), 0, st, reinterpret_cast<const float4*>(boxes), counts,
+                     K, W, thr, mask);
+  hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), (size_t)W * 8, st, mask, counts,
+                     K, W, max_out, keep_idx, keep_count);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+extern "C" int lmh_nms(const float* boxes, const int32_t* counts, int B, int K, float iou_threshold,
+                       int max_out, int32_t* keep_idx, int32_t* keep_count, void* ws,
+                       size_t ws_bytes, lmh_stream_t stream) {
+  LMH_CHECK_ARG(boxes && counts && keep_idx && keep_count && ws);
+  LMH_CHECK_ARG(B > 0 && K > 0 && max_out > 0);
+  if (ws_bytes < lmh_nms_workspace_bytes(B, K)) {
+    lmh_set_error("lmh_nms: workspace %zu < %zu", ws_bytes, lmh_nms_workspace_bytes(B, K));
+    return LMH_ERR_WORKSPACE;
+  }
+  return nms_impl(boxes, counts, B, K, iou_threshold, max_out, keep_idx, keep_count, ws,
+                  (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------
+// 5. final gather of kept proposals (+ optional clip after NMS)
+// ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gather_keep(const float4* __restrict__ top_boxes, const float* __restrict__ top_scores,
+              const int32_t* __restrict__ keep_idx, const int32_t* __restrict__ keep_count, int K,
+              int max_out, int clip_after, float im_h, float im_w, float4* __restrict__ proposals,
+              float* __restrict__ scores, int32_t* __restrict__ num) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) num[b] = keep_count[b];
+  if (i >= max_out) return;
+  float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sc = 0.f;
+  if (i < keep_count[b]) {
+    const int k = keep_idx[(size_t)b * max_out + i];
+    bx = top_boxes[(size_t)b * K + k];
+    sc = top_scores[(size_t)b * K + k];
+    if (clip_after) {
+      lmh_box c = lmh_clip(lmh_box{bx.x, bx.y, bx.z, bx.w}, im_h, im_w);
+      bx = make_float4(c.x1, c.y1, c.x2, c.y2);
+    }
+  }
+  proposals[(size_t)b * max_out + i] = bx;
+  scores[(size_t)b * max_out + i] = sc;
+}
+
+__global__ void k_iota_keep(const int32_t* __restrict__ top_count, int max_out,
+                            int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = min(top_count[b], max_out);
+  if (i == 0) keep_count[b] = c;
+  if (i < max_out) keep_idx[(size_t)b * max_out + i] = (i < c) ? i : -1;
+}
+
+struct rpn_prop_ws {
+  float4* boxes;      // B*N
+  uint64_t* keys;     // B*Npad
+  int32_t* n_valid;   // B
+  float4* top_boxes;  // B*K
+  float* top_scores;  // B*K
+  int32_t* top_count; // B
+  int32_t* keep_idx;  // B*post
+  int32_t* keep_count;// B
+  void* nms_ws;
+  size_t total;
+};
+
+static rpn_prop_ws rpn_prop_layout(const lmh_rpn_proposal_desc* d, void* base) {
+  const size_t B = d->B, N = (size_t)d->feat_h * d->feat_w * d->A;
+  const size_t Npad = lmh_next_pow2((int)N), K = d->pre_nms_top_n, P = d->post_nms_top_n;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += lmh_align_up(bytes, 256); return o; };
+  rpn_prop_ws w;
+  char* p = reinterpret_cast<char*>(base);
+  w.boxes = reinterpret_cast<float4*>(p + take(B * N * 16));
+  w.keys = reinterpret_cast<uint64_t*>(p + take(B * Npad * 8));
+  w.n_valid = reinterpret_cast<int32_t*>(p + take(B * 4));
+  w.top_boxes = reinterpret_cast<float4*>(p + take(B * K * 16));
+  w.top_scores = reinterpret_cast<float*>(p + take(B * K * 4));
+  w.top_count = reinterpret_cast<int32_t*>(p + take(B * 4));
+  w.keep_idx = reinterpret_cast<int32_t*>(p + take(B * P * 4));
+  w.keep_count = reinterpret_cast<int32_t*>(p + take(B * 4));
+  w.nms_ws = p + take(lmh_nms_workspace_bytes((int)B, (int)K));
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t lmh_rpn_proposal_workspace_bytes(const lmh_rpn_proposal_desc* d) {
+  if (!d) return 0;
+  return rpn_prop_layout(d, nullptr).total;
+}
+
+extern "C" int lmh_rpn_proposal(const lmh_rpn_proposal_desc* d, const float* cls_score,
+                                const float* bbox_pred, const int32_t* anchor_ref, float* cls_prob,
+                                float* proposals, float* scores, int32_t* num_proposals, void* ws,
+                                size_t ws_bytes, lmh_stream_t stream) {
+  LMH_CHECK_ARG(d && cls_score && bbox_pred && anchor_ref && cls_prob && proposals && scores &&
+                num_proposals && ws);
+  LMH_CHECK_ARG(d->B > 0 && d->feat_h > 0 && d->feat_w > 0 && d->A > 0);
+  LMH_CHECK_ARG(d->pre_nms_top_n > 0 && d->post_nms_top_n > 0);
+  const int N = d->feat_h * d->feat_w * d->A;
+  const int Npad = lmh_next_pow2(N);
+  rpn_prop_ws w = rpn_prop_layout(d, ws);
+  if (ws_bytes < w.total) {
+    lmh_set_error("lmh_rpn_proposal: workspace %zu < %zu", ws_bytes, w.total);
+    return LMH_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int B = d->B, K = d->pre_nms_top_n, P = d->post_nms_top_n;
+  LMH_CHECK_HIP(hipMemsetAsync(w.n_valid, 0, sizeof(int32_t) * B, st));
+  hipLaunchKernelGGL(k_rpn_decode, dim3((Npad + 255) / 256, B), dim3(256), 0, st, *d, N, Npad,
+                     cls_score, bbox_pred, anchor_ref, cls_prob, w.boxes, w.keys, w.n_valid);
+  int rc = sort_u64_impl(w.keys, B, Npad, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_gather_topk, dim3((K + 255) / 256, B), dim3(256), 0, st, w.keys, w.boxes,
+                     cls_prob, w.n_valid, N, Npad, K, w.top_boxes, w.top_scores, w.top_count);
+  if (d->apply_nms) {
+    rc = nms_impl(reinterpret_cast<const float*>(w.top_boxes), w.top_count, B, K, d->nms_threshold,
+                  P, w.keep_idx, w.keep_count, w.nms_ws, st);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(k_iota_keep, dim3((P + 255) / 256, B), dim3(256), 0, st, w.top_count, P,
+                       w.keep_idx, w.keep_count);
+  }
+  hipLaunchKernelGGL(k_gather_keep, dim3((P + 255) / 256, B), dim3(256), 0, st, w.top_boxes,
+                     w.top_scores, w.keep_idx, w.keep_count, K, P, d->clip_after_nms, d->im_h,
+                     d->im_w, reinterpret_cast<float4*>(proposals), scores, num_proposals);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}

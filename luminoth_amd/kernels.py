@@ -1,0 +1,335 @@
+"""Tensor-level launchers: torch device tensors in, C-ABI calls out.
+
+Every function here enqueues hand-written gfx950 kernels from
+libluminoth_hip.so on the caller's current HIP stream and returns torch tensors
+that merely own the memory.  Nothing in this file computes with torch ops, and
+nothing falls back to the CPU: tensors must live on a ROCm device.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ConvDesc, RpnProposalDesc, RpnTargetDesc, RcnnTargetDesc, check)
+
+ACT = {None: 0, 'none': 0, 'relu': 1, 'relu6': 2}
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.LuminothHipError('luminoth_amd kernels need ROCm device tensors (got %s); '
+                                    'there is no CPU fallback' % t.device)
+    if not t.is_contiguous():
+        raise _lib.LuminothHipError('non-contiguous tensor passed to a HIP kernel')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    assert t.dtype == torch.float32, t.dtype
+    return t
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag):
+    """Persistent scratch per (tag, device): no allocation in the steady state."""
+    key = (tag, device)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------ conv ----
+def same_pads(in_size, k, stride, dilation=1):
+    """TF 'SAME' padding: out = ceil(in/stride); leading pad = total // 2."""
+    out = -(-in_size // stride)
+    eff = (k - 1) * dilation + 1
+    total = max((out - 1) * stride + eff - in_size, 0)
+    return out, total // 2
+
+
+def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding='SAME', act=None):
+    """padding: 'SAME' | 'VALID' | 'SAME_EXPLICIT' (slim conv2d_same: pad
+    (k_eff-1)//2 before, VALID after) | (pad_top, pad_left, OH, OW)."""
+    N, H, W, C = x_shape
+    R, S, C2, K = w_shape
+    assert C == C2, (x_shape, w_shape)
+    if padding == 'SAME':
+        OH, pt = same_pads(H, R, stride, dilation)
+        OW, pl = same_pads(W, S, stride, dilation)
+    elif padding == 'VALID':
+        OH = (H - ((R - 1) * dilation + 1)) // stride + 1
+        OW = (W - ((S - 1) * dilation + 1)) // stride + 1
+        pt = pl = 0
+    elif padding == 'SAME_EXPLICIT':
+        keh, kew = (R - 1) * dilation + 1, (S - 1) * dilation + 1
+        pt, pl = (keh - 1) // 2, (kew - 1) // 2
+        OH = (H + keh - 1 - keh) // stride + 1
+        OW = (W + kew - 1 - kew) // stride + 1
+    else:
+        pt, pl, OH, OW = padding
+    return ConvDesc(N, H, W, C, K, R, S, OH, OW, stride, dilation, pt, pl, ACT[act])
+
+
+def conv2d_fwd(d, x, w, scale=None, shift=None, residual=None, in_sub=None, out=None):
+    lib = _lib.load()
+    y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
+    check(lib.lmh_conv2d_fwd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(scale), _p(shift), _p(residual),
+                             _p(in_sub), _p(y), _stream()), 'lmh_conv2d_fwd')
+    return y
+
+
+def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None):
+    lib = _lib.load()
+    dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
+    check(lib.lmh_conv2d_bwd_data(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(kscale), _p(addend), _p(dx),
+                                  _stream()), 'lmh_conv2d_bwd_data')
+    return dx
+
+
+def conv2d_bwd_weight(d, x, dy, out=None):
+    lib = _lib.load()
+    dw = out if out is not None else torch.empty((d.R, d.S, d.C, d.K), dtype=torch.float32, device=x.device)
+    nbytes = lib.lmh_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
+    ws = _workspace(nbytes, x.device, 'bwd_weight')
+    check(lib.lmh_conv2d_bwd_weight(ctypes.byref(d), _p(_f32(x)), _p(_f32(dy)), _p(dw), _p(ws),
+                                    ctypes.c_size_t(ws.numel()), _stream()), 'lmh_conv2d_bwd_weight')
+    return dw
+
+
+def act_bwd(dy, y, act, want_g=True, colsum=None):
+    lib = _lib.load()
+    K = dy.shape[-1]
+    rows = dy.numel() // K
+    g = torch.empty_like(dy) if want_g else None
+    check(lib.lmh_act_bwd(_p(dy), _p(y), ACT[act], rows, K, _p(g), _p(colsum), _stream()), 'lmh_act_bwd')
+    return g
+
+
+def bn_param_grads(w, dw_raw, dbeta, mean, rstd, scale):
+    lib = _lib.load()
+    K = w.shape[-1]
+    rsc = w.numel() // K
+    dgamma = torch.empty_like(dbeta)
+    check(lib.lmh_bn_param_grads(_p(w), _p(dw_raw), _p(dbeta), _p(mean), _p(rstd), _p(scale), rsc, K,
+                                 _p(dgamma), _stream()), 'lmh_bn_param_grads')
+    return dgamma
+
+
+def maxpool_fwd(x, ksize, stride, padding='SAME'):
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    if padding == 'SAME':
+        OH, pt = same_pads(H, ksize, stride)
+        OW, pl = same_pads(W, ksize, stride)
+    else:
+        OH, OW, pt, pl = (H - ksize) // stride + 1, (W - ksize) // stride + 1, 0, 0
+    y = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
+    check(lib.lmh_maxpool_fwd(_p(x), N, H, W, C, ksize, stride, pt, pl, OH, OW, _p(y), _stream()),
+          'lmh_maxpool_fwd')
+    return y, (pt, pl, OH, OW)
+
+
+def maxpool_bwd(x, y, dy, ksize, stride, geom):
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    pt, pl, OH, OW = geom
+    dx = torch.zeros_like(x)
+    check(lib.lmh_maxpool_bwd(_p(x), _p(y), _p(dy), N, H, W, C, ksize, stride, pt, pl, OH, OW, _p(dx),
+                              _stream()), 'lmh_maxpool_bwd')
+    return dx
+
+
+# ------------------------------------------------------------- proposals ----
+def rpn_proposal(cls_score, bbox_pred, anchor_ref_i32, feat_h, feat_w, stride, im_shape,
+                 pre_nms_top_n=12000, post_nms_top_n=2000, nms_threshold=0.7, min_prob_threshold=0.0,
+                 apply_nms=True, clip_after_nms=False, filter_outside_anchors=False):
+    """cls_score (B,N,2), bbox_pred (B,N,4) -> cls_prob (B,N,2), proposals (B,post,4), scores, count (B)."""
+    lib = _lib.load()
+    B, N, _ = cls_score.shape
+    A = anchor_ref_i32.shape[0]
+    assert N == feat_h * feat_w * A
+    d = RpnProposalDesc(B, feat_h, feat_w, A, stride, float(im_shape[0]), float(im_shape[1]),
+                        int(pre_nms_top_n), int(post_nms_top_n), float(nms_threshold),
+                        float(min_prob_threshold), int(bool(apply_nms)), int(bool(clip_after_nms)),
+                        int(bool(filter_outside_anchors)))
+    dev = cls_score.device
+    cls_prob = torch.empty_like(cls_score)
+    proposals = torch.empty((B, post_nms_top_n, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, post_nms_top_n), dtype=torch.float32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = _workspace(lib.lmh_rpn_proposal_workspace_bytes(ctypes.byref(d)), dev, 'rpn_proposal')
+    check(lib.lmh_rpn_proposal(ctypes.byref(d), _p(cls_score), _p(bbox_pred), _p(anchor_ref_i32), _p(cls_prob),
+                               _p(proposals), _p(scores), _p(count), _p(ws), ctypes.c_size_t(ws.numel()),
+                               _stream()), 'lmh_rpn_proposal')
+    return cls_prob, proposals, scores, count
+
+
+def sort_u64(keys):
+    lib = _lib.load()
+    B, n = keys.shape
+    assert keys.dtype == torch.int64 and (n & (n - 1)) == 0
+    check(lib.lmh_sort_u64(_p(keys), B, n, _stream()), 'lmh_sort_u64')
+    return keys
+
+
+def nms(boxes, counts, iou_threshold, max_out):
+    """boxes (B,K,4) sorted by descending score; counts (B) int32."""
+    lib = _lib.load()
+    B, K, _ = boxes.shape
+    keep_idx = torch.empty((B, max_out), dtype=torch.int32, device=boxes.device)
+    keep_count = torch.empty((B,), dtype=torch.int32, device=boxes.device)
+    ws = _workspace(lib.lmh_nms_workspace_bytes(B, K), boxes.device, 'nms')
+    check(lib.lmh_nms(_p(boxes), _p(counts), B, K, float(iou_threshold), int(max_out), _p(keep_idx),
+                      _p(keep_count), _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_nms')
+    return keep_idx, keep_count
+
+
+# --------------------------------------------------------------- targets ----
+def rpn_target(anchor_ref_i32, feat_h, feat_w, stride, gt, gt_count, seeds, im_shape, allowed_border=0,
+               clobber_positives=False, foreground_threshold=0.7, background_threshold_high=0.3,
+               foreground_fraction=0.5, minibatch_size=256, want_pre=False):
+    lib = _lib.load()
+    B, Gmax, _ = gt.shape
+    A = anchor_ref_i32.shape[0]
+    N = feat_h * feat_w * A
+    d = RpnTargetDesc(B, feat_h, feat_w, A, stride, Gmax, int(im_shape[0]), int(im_shape[1]),
+                      int(allowed_border), int(bool(clobber_positives)), float(foreground_threshold),
+                      float(background_threshold_high), float(foreground_fraction), int(minibatch_size))
+    dev = gt.device
+    labels = torch.empty((B, N), dtype=torch.float32, device=dev)
+    targets = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+    max_ov = torch.empty((B, N), dtype=torch.float32, device=dev)
+    pre = torch.empty((B, N), dtype=torch.float32, device=dev) if want_pre else None
+    ws = _workspace(lib.lmh_rpn_target_workspace_bytes(ctypes.byref(d)), dev, 'rpn_target')
+    check(lib.lmh_rpn_target(ctypes.byref(d), _p(anchor_ref_i32), _p(gt), _p(gt_count), _p(seeds), _p(labels),
+                             _p(targets), _p(max_ov), _p(pre), _p(ws), ctypes.c_size_t(ws.numel()),
+                             _stream()), 'lmh_rpn_target')
+    return labels, targets, max_ov, pre
+
+
+def rcnn_target(proposals, prop_count, gt, gt_count, seeds, minibatch_size=256, foreground_fraction=0.25,
+                foreground_threshold=0.5, background_threshold_high=0.5, background_threshold_low=0.0,
+                variances=(0.1, 0.2), want_pre=False):
+    lib = _lib.load()
+    B, Pn, _ = proposals.shape
+    Gmax = gt.shape[1]
+    v = (1.0, 1.0) if variances is None else variances
+    d = RcnnTargetDesc(B, Pn, Gmax, int(minibatch_size), float(foreground_fraction),
+                       float(foreground_threshold), float(background_threshold_high),
+                       float(background_threshold_low), float(v[0]), float(v[1]))
+    dev = proposals.device
+    R = int(minibatch_size)
+    labels = torch.empty((B, Pn), dtype=torch.float32, device=dev)
+    targets = torch.empty((B, Pn, 4), dtype=torch.float32, device=dev)
+    pre = torch.empty((B, Pn), dtype=torch.float32, device=dev) if want_pre else None
+    rois = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
+    roi_labels = torch.empty((B, R), dtype=torch.float32, device=dev)
+    roi_targets = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
+    roi_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    check(lib.lmh_rcnn_target(ctypes.byref(d), _p(proposals), _p(prop_count), _p(gt), _p(gt_count), _p(seeds),
+                              _p(labels), _p(targets), _p(pre), _p(rois), _p(roi_labels), _p(roi_targets),
+                              _p(roi_count), _stream()), 'lmh_rcnn_target')
+    return dict(labels=labels, bbox_targets=targets, labels_pre=pre, rois=rois, roi_labels=roi_labels,
+                roi_targets=roi_targets, roi_count=roi_count)
+
+
+# ------------------------------------------------------------------- ROI ----
+def roi_pool_fwd(feat, rois, roi_count, im_shape, ph=7, pw=7):
+    lib = _lib.load()
+    B, FH, FW, C = feat.shape
+    R = rois.shape[1]
+    out = torch.empty((B * R, ph, pw, C), dtype=torch.float32, device=feat.device)
+    argmax = torch.empty((B * R, ph, pw, C), dtype=torch.uint8, device=feat.device)
+    check(lib.lmh_roi_pool_fwd(_p(feat), _p(rois), _p(roi_count), B, R, FH, FW, C, float(im_shape[0]),
+                               float(im_shape[1]), ph, pw, _p(out), _p(argmax), _stream()), 'lmh_roi_pool_fwd')
+    return out, argmax
+
+
+def roi_pool_bwd(dout, argmax, rois, roi_count, feat_shape, im_shape, ph=7, pw=7, out=None):
+    lib = _lib.load()
+    B, FH, FW, C = feat_shape
+    R = rois.shape[1]
+    dfeat = out if out is not None else torch.zeros(feat_shape, dtype=torch.float32, device=dout.device)
+    check(lib.lmh_roi_pool_bwd(_p(dout), _p(argmax), _p(rois), _p(roi_count), B, R, FH, FW, C,
+                               float(im_shape[0]), float(im_shape[1]), ph, pw, _p(dfeat), _stream()),
+          'lmh_roi_pool_bwd')
+    return dfeat
+
+
+def spatial_mean_fwd(x):
+    lib = _lib.load()
+    M, S, C = x.shape[0], x.shape[1] * x.shape[2], x.shape[3]
+    y = torch.empty((M, C), dtype=torch.float32, device=x.device)
+    check(lib.lmh_spatial_mean_fwd(_p(x), M, S, C, _p(y), _stream()), 'lmh_spatial_mean_fwd')
+    return y
+
+
+def spatial_mean_bwd(dy, shape):
+    lib = _lib.load()
+    M, S, C = shape[0], shape[1] * shape[2], shape[3]
+    dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+    check(lib.lmh_spatial_mean_bwd(_p(dy), M, S, C, _p(dx), _stream()), 'lmh_spatial_mean_bwd')
+    return dx
+
+
+# ---------------------------------------------------------------- losses ----
+def rpn_loss(cls_score, bbox_pred, labels, bbox_targets, sigma=3.0, w_cls=1.0, w_reg=1.0, want_grad=True):
+    lib = _lib.load()
+    B, N, _ = cls_score.shape
+    dev = cls_score.device
+    losses = torch.empty((2,), dtype=torch.float32, device=dev)
+    per_image = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    d_cls = torch.empty_like(cls_score) if want_grad else None
+    d_bbox = torch.empty_like(bbox_pred) if want_grad else None
+    check(lib.lmh_rpn_loss(_p(cls_score), _p(bbox_pred), _p(labels), _p(bbox_targets), B, N, float(sigma),
+                           float(w_cls), float(w_reg), _p(losses), _p(per_image), _p(d_cls), _p(d_bbox),
+                           _stream()), 'lmh_rpn_loss')
+    return losses, per_image, d_cls, d_bbox
+
+
+def rcnn_loss(cls_score, bbox_offsets, labels, targets, num_classes, sigma=1.0, w_cls=1.0, w_reg=1.0,
+              want_grad=True):
+    lib = _lib.load()
+    B, R = labels.shape
+    dev = cls_score.device
+    losses = torch.empty((2,), dtype=torch.float32, device=dev)
+    per_image = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    d_cls = torch.empty_like(cls_score) if want_grad else None
+    d_off = torch.empty_like(bbox_offsets) if want_grad else None
+    check(lib.lmh_rcnn_loss(_p(cls_score), _p(bbox_offsets), _p(labels), _p(targets), B, R, int(num_classes),
+                            float(sigma), float(w_cls), float(w_reg), _p(losses), _p(per_image), _p(d_cls),
+                            _p(d_off), _stream()), 'lmh_rcnn_loss')
+    return losses, per_image, d_cls, d_off
+
+
+def softmax(x):
+    lib = _lib.load()
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.lmh_softmax(_p(x), x.numel() // C, C, _p(y), _stream()), 'lmh_softmax')
+    return y
+
+
+# ------------------------------------------------------------- optimizer ----
+def sgd_momentum(w, g, v, seg_offset, seg_wd, lr, momentum, gscale=1.0):
+    lib = _lib.load()
+    check(lib.lmh_sgd_momentum(_p(w), _p(g), _p(v), w.numel(), _p(seg_offset), _p(seg_wd), seg_wd.numel(),
+                               float(lr), float(momentum), float(gscale), _stream()), 'lmh_sgd_momentum')
+
+
+def l2_reg_loss(w, seg_offset, seg_wd):
+    lib = _lib.load()
+    out = torch.zeros((1,), dtype=torch.float32, device=w.device)
+    check(lib.lmh_l2_reg_loss(_p(w), w.numel(), _p(seg_offset), _p(seg_wd), seg_wd.numel(), _p(out),
+                              _stream()), 'lmh_l2_reg_loss')
+    return out

@@ -1,0 +1,156 @@
+"""Config surface of the drop-in boundary: same YAML schema, merge and override
+semantics as luminoth/utils/config.py:14-232 (`get_config(files, overrides)`),
+restated without TensorFlow / easydict (neither is installed here).
+
+ * per-model defaults (the reference keeps them in models/<type>/base_config.yml;
+   here `luminoth_amd/models/<type>/defaults.py`) are deep-merged with the user
+   files left to right, then with `-o a.b=c` overrides;
+ * a sub-dict carrying `_replace: True` replaces instead of merging
+   (config.py:93-110); incompatible types raise ValueError (config.py:73-90);
+   `_replace` keys are stripped at the end (config.py:199-210).
+"""
+import copy
+
+import yaml
+
+REPLACE_KEY = '_replace'
+
+
+class Config(dict):
+    """dict with attribute access, recursively (EasyDict stand-in)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = dict(d or {}, **kw)
+        for k, v in d.items():
+            self[k] = v
+
+    @staticmethod
+    def _wrap(v):
+        if isinstance(v, dict) and not isinstance(v, Config):
+            return Config(v)
+        if isinstance(v, (list, tuple)):
+            return type(v)(Config._wrap(x) for x in v)
+        return v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, Config._wrap(v))
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def copy(self):
+        return Config(copy.deepcopy(dict(self)))
+
+
+def _is_str(v):
+    return isinstance(v, str)
+
+
+def types_compatible(new, base):
+    if base is None or new is None or new is False:
+        return True
+    if _is_str(new) and _is_str(base):
+        return True
+    return isinstance(new, type(base))
+
+
+def should_replace(new_config, base_config, key):
+    def flag(cfg):
+        try:
+            return cfg[key][REPLACE_KEY]
+        except (KeyError, TypeError):
+            return None
+    new_r, base_r = flag(new_config), flag(base_config)
+    return bool(new_r) or (new_r is None and bool(base_r))
+
+
+def merge_into(new_config, base_config, overwrite=False):
+    if not isinstance(new_config, dict):
+        return base_config
+    for key, value in new_config.items():
+        if not types_compatible(value, base_config.get(key)):
+            raise ValueError('Incorrect type "{}" for key "{}". Must be "{}"'.format(
+                type(value), key, type(base_config.get(key))))
+        if isinstance(value, dict):
+            if should_replace(new_config, base_config, key):
+                base_config[key] = value
+            else:
+                base_config[key] = merge_into(value, base_config.get(key) or Config(), overwrite)
+        elif base_config.get(key) is None or overwrite:
+            base_config[key] = value
+    return base_config
+
+
+def parse_config_value(value):
+    low = value.lower()
+    if low == 'none':
+        return None
+    if low == 'true':
+        return True
+    if low == 'false':
+        return False
+    for cast in (int, float):
+        try:
+            return cast(value)
+        except ValueError:
+            pass
+    return value
+
+
+def parse_override(options):
+    out = {}
+    for option in options or []:
+        kv = option.split('=')
+        if len(kv) != 2:
+            raise ValueError('Invalid override option "{}"'.format(option))
+        keys = kv[0].split('.')
+        d = out
+        for k in keys[:-1]:
+            d = d.setdefault(k, {})
+        d[keys[-1]] = parse_config_value(kv[1])
+    return out
+
+
+def cleanup_config(config):
+    config.pop(REPLACE_KEY, None)
+    for v in config.values():
+        if isinstance(v, dict):
+            cleanup_config(v)
+    return config
+
+
+def load_config_files(files):
+    if not isinstance(files, (list, tuple)):
+        files = [files]
+    config = Config()
+    for f in files:
+        if isinstance(f, dict):
+            new = Config(f)
+        else:
+            with open(f) as fh:
+                new = Config(yaml.safe_load(fh) or {})
+        config = merge_into(new, config, overwrite=True)
+    return config
+
+
+def get_base_config(model_type):
+    from luminoth_amd.models import get_model_defaults
+    return Config(copy.deepcopy(get_model_defaults(model_type)))
+
+
+def get_config(config_files, override_params=None):
+    """config_files: path(s) to YAML or dict(s) with the reference's schema."""
+    custom = load_config_files(config_files) if config_files else Config()
+    model_type = (custom.get('model') or {}).get('type', 'fasterrcnn')
+    config = get_base_config(model_type)
+    config = merge_into(custom, config, overwrite=True)
+    if override_params:
+        config = merge_into(Config(parse_override(override_params)), config, overwrite=True)
+    return cleanup_config(config)

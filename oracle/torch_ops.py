@@ -1,0 +1,116 @@
+"""Oracle (test infrastructure): differentiable torch-CPU fp32 restatements of
+the dense / gather stages, so `torch.autograd` provides reference gradients for
+the HIP backward kernels and the CPU-baseline train step.
+
+Citations relative to /root/reference/luminoth/.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def tf_same_pad(in_size, k, stride, dilation=1):
+    out = -(-in_size // stride)
+    eff = (k - 1) * dilation + 1
+    total = max((out - 1) * stride + eff - in_size, 0)
+    return total // 2, total - total // 2
+
+
+def conv2d_nhwc(x, w_hwio, stride=1, dilation=1, padding='SAME', bias=None):
+    """tf.nn.conv2d / slim conv2d / conv2d_same on NHWC input with HWIO weights."""
+    R, S = w_hwio.shape[0], w_hwio.shape[1]
+    xt = x.permute(0, 3, 1, 2)
+    if padding == 'SAME':
+        pt, pb = tf_same_pad(x.shape[1], R, stride, dilation)
+        pl, pr = tf_same_pad(x.shape[2], S, stride, dilation)
+    elif padding == 'SAME_EXPLICIT':  # slim resnet_utils.conv2d_same
+        ke_h, ke_w = (R - 1) * dilation + 1, (S - 1) * dilation + 1
+        pt, pl = (ke_h - 1) // 2, (ke_w - 1) // 2
+        pb, pr = ke_h - 1 - pt, ke_w - 1 - pl
+    else:
+        pt = pb = pl = pr = 0
+    if pt or pb or pl or pr:
+        xt = F.pad(xt, (pl, pr, pt, pb))
+    y = F.conv2d(xt, w_hwio.permute(3, 2, 0, 1), bias=bias, stride=stride, dilation=dilation)
+    return y.permute(0, 2, 3, 1)
+
+
+def max_pool_nhwc(x, k, stride, padding='SAME'):
+    xt = x.permute(0, 3, 1, 2)
+    if padding == 'SAME':
+        pt, pb = tf_same_pad(x.shape[1], k, stride)
+        pl, pr = tf_same_pad(x.shape[2], k, stride)
+        xt = F.pad(xt, (pl, pr, pt, pb), value=float('-inf'))
+    return F.max_pool2d(xt, k, stride).permute(0, 2, 3, 1)
+
+
+def frozen_batch_norm(x, gamma, beta, mean, var, eps=1e-5):
+    """slim batch_norm in inference mode (base_network.py:84-89: is_training False)."""
+    return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
+def crop_and_resize(feat, boxes_norm, box_ind, crop_h, crop_w):
+    """tf.image.crop_and_resize, bilinear, extrapolation 0 (vectorised; same
+    arithmetic as oracle/tfops.py::crop_and_resize).  feat (B,H,W,C)."""
+    B, H, W, C = feat.shape
+    R = boxes_norm.shape[0]
+    y1, x1, y2, x2 = boxes_norm[:, 0], boxes_norm[:, 1], boxes_norm[:, 2], boxes_norm[:, 3]
+    hs = (y2 - y1) * float(H - 1) / float(crop_h - 1)
+    ws = (x2 - x1) * float(W - 1) / float(crop_w - 1)
+    ys = torch.arange(crop_h, dtype=torch.float32)
+    xs = torch.arange(crop_w, dtype=torch.float32)
+    in_y = (y1 * float(H - 1))[:, None] + ys[None, :] * hs[:, None]      # (R, ch)
+    in_x = (x1 * float(W - 1))[:, None] + xs[None, :] * ws[:, None]      # (R, cw)
+    vy = ~((in_y < 0) | (in_y > H - 1))
+    vx = ~((in_x < 0) | (in_x > W - 1))
+    top = torch.floor(in_y).clamp(0, H - 1).long()
+    bot = torch.ceil(in_y).clamp(0, H - 1).long()
+    left = torch.floor(in_x).clamp(0, W - 1).long()
+    right = torch.ceil(in_x).clamp(0, W - 1).long()
+    yl = (in_y - torch.floor(in_y))[:, :, None, None]
+    xl = (in_x - torch.floor(in_x))[:, None, :, None]
+    bi = box_ind.long()[:, None, None]
+
+    def g(yy, xx):
+        return feat[bi, yy[:, :, None], xx[:, None, :]]                  # (R, ch, cw, C)
+    tl, tr, bl, br = g(top, left), g(top, right), g(bot, left), g(bot, right)
+    t = tl + (tr - tl) * xl
+    b = bl + (br - bl) * xl
+    out = t + (b - t) * yl
+    valid = (vy[:, :, None] & vx[:, None, :])[..., None]
+    return torch.where(valid, out, torch.zeros_like(out))
+
+
+def roi_pool(feat, rois, box_ind, im_shape, pooled_h=7, pooled_w=7):
+    """models/fasterrcnn/roi_pool.py:37-95: normalise by (H, W), crop 2x, 2x2 max pool."""
+    H, W = float(im_shape[0]), float(im_shape[1])
+    bn = torch.stack([rois[:, 1] / H, rois[:, 0] / W, rois[:, 3] / H, rois[:, 2] / W], dim=1)
+    crops = crop_and_resize(feat, bn, box_ind, pooled_h * 2, pooled_w * 2)
+    p = F.max_pool2d(crops.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    return p
+
+
+def smooth_l1(pred, target, sigma):
+    s2 = sigma ** 2
+    a = (pred - target).abs()
+    return torch.where(a < 1.0 / s2, 0.5 * s2 * a * a, a - 0.5 / s2).sum(dim=1)
+
+
+def rpn_loss(cls_score, bbox_pred, labels, bbox_targets, sigma=3.0):
+    """models/fasterrcnn/rpn.py:219-309 for one image (tensors (N,2),(N,4),(N,),(N,4))."""
+    ni = labels != -1
+    ce = F.cross_entropy(cls_score[ni], labels[ni].long(), reduction='none')
+    pos = labels == 1
+    reg = smooth_l1(bbox_pred[pos], bbox_targets[pos], sigma)
+    return ce.mean(), reg.mean()
+
+
+def rcnn_loss(cls_score, bbox_offsets, labels, targets, num_classes, sigma=1.0):
+    """models/fasterrcnn/rcnn.py:255-411 for one image."""
+    ni = labels >= 0
+    ce = F.cross_entropy(cls_score[ni], labels[ni].long(), reduction='none')
+    fg = labels > 0
+    cls = labels[fg].long() - 1
+    bo = bbox_offsets[fg].reshape(-1, num_classes, 4)
+    cleaned = bo[torch.arange(bo.shape[0]), cls]
+    reg = smooth_l1(cleaned, targets[fg], sigma)
+    return ce.mean(), reg.mean()

@@ -1,0 +1,447 @@
+"""GPU parity tests: every HIP kernel (through the C ABI) vs the CPU oracle on
+identical seeded inputs.  Bit-exact for index / label / keep-mask work,
+1e-4..1e-5 for fp32 (tolerances written at each assert).  Run with `-m gpu`.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as obx
+from oracle import frcnn as of
+from oracle import rng as orng
+from oracle import tfops
+from oracle import torch_ops as ot
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def T(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev()).contiguous()
+
+
+def rand_boxes(rs, n, lim=1024, smin=16, smax=400):
+    wh = rs.randint(smin, smax, size=(n, 2))
+    xy = np.stack([rs.randint(0, lim - wh[:, 0]), rs.randint(0, lim - wh[:, 1])], 1)
+    return np.concatenate([xy, xy + wh - 1], 1).astype(F)
+
+
+@pytest.fixture(scope='module')
+def K():
+    from luminoth_amd import kernels
+    return kernels
+
+
+# ------------------------------------------------------------------ sort ----
+@pytest.mark.parametrize('n', [2, 64, 4096, 8192, 65536])
+def test_sort_u64(K, n):
+    rs = np.random.RandomState(n)
+    keys = rs.randint(0, 2 ** 62, size=(3, n), dtype=np.int64)
+    keys[1, : n // 2] = keys[1, n // 2:][: n // 2]       # duplicates
+    out = K.sort_u64(T(keys)).cpu().numpy()
+    np.testing.assert_array_equal(out.view(np.uint64), np.sort(keys.view(np.uint64), axis=1))
+
+
+# ------------------------------------------------------------------- NMS ----
+def test_nms_matches_oracle_bit_exact(K):
+    rs = np.random.RandomState(0)
+    B, Kn = 3, 3000
+    boxes = np.zeros((B, Kn, 4), F)
+    counts = np.array([3000, 1777, 64], np.int32)
+    for b in range(B):
+        base = rand_boxes(rs, 60, 600, 40, 200)
+        jit = base[rs.randint(0, 60, size=Kn)] + rs.randint(-12, 13, size=(Kn, 4))
+        boxes[b] = jit.astype(F)
+    boxes[0, 5] = [10, 10, 10, 50]        # zero-area box
+    boxes[0, 7] = [50, 60, 20, 30]        # inverted corners (TF normalises them)
+    for thr, max_out in ((0.7, 300), (0.3, 2000), (0.0, 50)):
+        keep, kc = K.nms(T(boxes), T(counts), thr, max_out)
+        keep, kc = keep.cpu().numpy(), kc.cpu().numpy()
+        for b in range(B):
+            scores = np.arange(counts[b], 0, -1).astype(F)      # already sorted, descending
+            ref = tfops.non_max_suppression(boxes[b, :counts[b]][:, [1, 0, 3, 2]], scores, max_out, thr)
+            assert kc[b] == ref.shape[0]
+            np.testing.assert_array_equal(keep[b, :kc[b]], ref)
+            assert (keep[b, kc[b]:] == -1).all()
+
+
+# ---------------------------------------------------------- RPN proposal ----
+def _proposal_case(K, feat, A, stride, im, pre, post, thr, zero_wh, seed, **kw):
+    rs = np.random.RandomState(seed)
+    B = 2
+    ref = obx.generate_anchors_reference(256, np.array([.5, 1, 2]), np.array([.25, .5, 1, 2]))[:A]
+    ref_i32 = np.trunc(ref).astype(np.int32)
+    N = feat * feat * A
+    score = (rs.randn(B, N, 2) * 2).astype(F)
+    pred = (rs.randn(B, N, 4) * 0.2).astype(F)
+    if zero_wh:
+        pred[..., 2:] = 0           # exp(0) == 1 exactly: the whole chain is IEEE-exact
+    prob, props, scores, cnt = K.rpn_proposal(T(score), T(pred), T(ref_i32), feat, feat, stride, im,
+                                              pre_nms_top_n=pre, post_nms_top_n=post, nms_threshold=thr, **kw)
+    prob, props, scores, cnt = [t.cpu().numpy() for t in (prob, props, scores, cnt)]
+    np.testing.assert_allclose(prob, tfops.softmax(score), rtol=2e-6, atol=1e-7)   # fp32 softmax
+    anchors = obx.generate_anchors(ref, feat, feat, stride)
+    for b in range(B):
+        # the oracle consumes the kernel's own probabilities so ordering decisions are comparable
+        r = of.rpn_proposal(prob[b], pred[b], anchors, im, pre_nms_top_n=pre, post_nms_top_n=post,
+                            nms_threshold=thr, **kw)
+        assert cnt[b] == r['proposals'].shape[0]
+        if zero_wh:
+            np.testing.assert_array_equal(props[b, :cnt[b]], r['proposals'])       # bit-exact
+        else:
+            np.testing.assert_allclose(props[b, :cnt[b]], r['proposals'], rtol=1e-6, atol=1e-4)
+        np.testing.assert_array_equal(scores[b, :cnt[b]], r['scores'])
+        assert (props[b, cnt[b]:] == 0).all()
+
+
+def test_rpn_proposal_small_exact(K):
+    _proposal_case(K, 16, 12, 16, (256, 256), 600, 100, 0.7, True, 1)
+    _proposal_case(K, 16, 12, 16, (256, 256), 6000, 3072, 0.7, True, 2)          # k > n_valid
+    _proposal_case(K, 16, 12, 16, (256, 256), 600, 100, 0.7, True, 3, clip_after_nms=True)
+    _proposal_case(K, 16, 12, 16, (256, 256), 600, 100, 0.7, True, 4, filter_outside_anchors=True)
+    _proposal_case(K, 16, 12, 16, (256, 256), 600, 100, 0.7, True, 5, apply_nms=False)
+    _proposal_case(K, 16, 12, 16, (256, 256), 600, 100, 0.7, True, 6, min_prob_threshold=0.4)
+
+
+def test_rpn_proposal_full_size(K):
+    # BASELINE config 2 geometry: 1024x1024 image, 64x64x12 = 49152 anchors, 12000 -> 2000
+    _proposal_case(K, 64, 12, 16, (1024, 1024), 12000, 2000, 0.7, True, 7)
+    _proposal_case(K, 64, 12, 16, (1024, 1024), 12000, 2000, 0.7, False, 8)
+
+
+def test_rpn_proposal_reference_vectors(K):
+    # luminoth/models/fasterrcnn/rpn_proposal_test.py:61-170 through the kernel: arbitrary anchors
+    # are expressed as a 1x1 grid whose "reference" IS the anchor list (stride 0).
+    gt = np.array([[10, 10, 26, 36], [10, 10, 20, 22], [10, 11, 20, 21], [19, 30, 33, 38]], F)
+    anchors = np.array([[11, 13, 34, 31], [10, 10, 20, 22], [11, 13, 34, 28], [21, 29, 34, 37]], np.int32)
+    prob = np.array([[.8, .2], [.1, .9], [.4, .6], [.2, .8]], F)
+    score = np.log(prob)[None]
+    pred = obx.encode(anchors, gt)[None]
+    for thr, n in ((0.0, 2), (0.3, 3), (0.6, 3), (0.8, 3), (1.0, 4)):
+        _, props, scores, cnt = K.rpn_proposal(T(score), T(pred), T(anchors), 1, 1, 0, (40, 40),
+                                               pre_nms_top_n=4, post_nms_top_n=4, nms_threshold=thr)
+        assert int(cnt[0]) == n
+        np.testing.assert_allclose(scores[0, :n].cpu().numpy(), [.9, .8, .2, .1][:n] if n < 4 else
+                                   [.9, .8, .6, .2], rtol=1e-5)
+
+
+# ------------------------------------------------------------ RPN target ----
+def test_rpn_target_full_size_bit_exact(K):
+    rs = np.random.RandomState(11)
+    B, Gmax, feat, A, stride = 2, 16, 64, 12, 16
+    ref = obx.generate_anchors_reference(256, np.array([.5, 1, 2]), np.array([.25, .5, 1, 2]))
+    ref_i32 = np.trunc(ref).astype(np.int32)
+    gt = np.zeros((B, Gmax, 5), F)
+    counts = np.array([8, 3], np.int32)
+    for b in range(B):
+        gt[b, :counts[b], :4] = rand_boxes(rs, counts[b], 1024, 32, 512)
+        gt[b, :counts[b], 4] = rs.randint(0, 80, size=counts[b])
+    seeds = np.array([orng.image_seed(0, 5, b) for b in range(B)], np.uint32)
+    labels, targets, mo, pre = K.rpn_target(T(ref_i32), feat, feat, stride, T(gt), T(counts),
+                                            T(seeds.view(np.int32)), (1024, 1024), want_pre=True)
+    labels, targets, mo, pre = [t.cpu().numpy() for t in (labels, targets, mo, pre)]
+    anchors = obx.generate_anchors(ref, feat, feat, stride)
+    for b in range(B):
+        ol, ot_, om, opre, _ = of.rpn_target(anchors, gt[b, :counts[b]], (1024, 1024), seed=int(seeds[b]),
+                                             return_pre_subsample=True)
+        np.testing.assert_array_equal(pre[b], opre)          # labels before subsampling: bit-exact
+        np.testing.assert_array_equal(mo[b], om)             # IoU: bit-exact fp32
+        np.testing.assert_array_equal(labels[b], ol)         # shared counter RNG: bit-exact
+        np.testing.assert_allclose(targets[b], ot_, rtol=1e-5, atol=1e-6)   # logf: 1e-5
+        assert (labels[b] == 1).sum() <= 128 and (labels[b] >= 0).sum() == 256
+
+
+def test_rpn_target_reference_vectors(K):
+    # luminoth/models/fasterrcnn/rpn_target_test.py:94-152,154-190 via the 1x1-grid trick
+    gt = np.array([[[200, 0, 400, 400, 0]]], F)
+    cnt = np.array([1], np.int32)
+    seeds = np.array([7], np.int32)
+    anchors = np.array([[200, 100, 400, 400], [300, 300, 400, 400], [200, 380, 300, 500],
+                        [500, 500, 600, 650], [200, 100, 400, 400]], np.int32)
+    labels, targets, _, _ = K.rpn_target(T(anchors), 1, 1, 0, T(gt), T(cnt), T(seeds), (600, 600),
+                                         minibatch_size=5)
+    np.testing.assert_array_equal(labels[0].cpu().numpy(), [1, 0, 0, -1, 1])
+    t = targets[0].cpu().numpy()
+    assert t[0][0] == 0 and t[0][2] == 0 and t[0][1] != 0 and t[0][3] != 0
+    np.testing.assert_array_equal(t[1:4], np.zeros((3, 4)))
+    anchors = np.array([[300, 300, 400, 400], [200, 380, 300, 500]], np.int32)
+    labels, _, _, _ = K.rpn_target(T(anchors), 1, 1, 0, T(gt), T(cnt), T(seeds), (600, 600), minibatch_size=2)
+    np.testing.assert_array_equal(labels[0].cpu().numpy(), [1, 0])
+    labels, _, _, _ = K.rpn_target(T(anchors), 1, 1, 0, T(gt), T(cnt), T(seeds), (600, 600), minibatch_size=2,
+                                   clobber_positives=True)
+    np.testing.assert_array_equal(labels[0].cpu().numpy(), [0, 0])
+
+
+# ----------------------------------------------------------- RCNN target ----
+def test_rcnn_target_bit_exact(K):
+    rs = np.random.RandomState(21)
+    B, Pn, Gmax = 3, 2000, 16
+    props = np.zeros((B, Pn, 4), F)
+    pc = np.array([2000, 700, 40], np.int32)
+    gt = np.zeros((B, Gmax, 5), F)
+    gc = np.array([8, 2, 1], np.int32)
+    for b in range(B):
+        gt[b, :gc[b], :4] = rand_boxes(rs, gc[b], 1024, 32, 512)
+        gt[b, :gc[b], 4] = rs.randint(0, 80, size=gc[b])
+        p = rand_boxes(rs, pc[b], 1024, 8, 600)
+        near = gt[b, rs.randint(0, gc[b], size=pc[b] // 3), :4] + rs.randint(-20, 21, size=(pc[b] // 3, 4))
+        p[: pc[b] // 3] = near
+        props[b, :pc[b]] = p
+    seeds = np.array([orng.image_seed(1, 9, b) for b in range(B)], np.uint32)
+    r = K.rcnn_target(T(props), T(pc), T(gt), T(gc), T(seeds.view(np.int32)), want_pre=True)
+    r = {k: v.cpu().numpy() for k, v in r.items()}
+    for b in range(B):
+        ol, ot_, opre, _, _ = of.rcnn_target(props[b, :pc[b]], gt[b, :gc[b]], seed=int(seeds[b]),
+                                             return_pre_subsample=True)
+        np.testing.assert_array_equal(r['labels_pre'][b, :pc[b]], opre)
+        np.testing.assert_array_equal(r['labels'][b, :pc[b]], ol)
+        assert (r['labels'][b, pc[b]:] == -1).all()
+        np.testing.assert_allclose(r['bbox_targets'][b, :pc[b]], ot_, rtol=1e-5, atol=1e-6)
+        keep = ol >= 0                                      # rcnn.py:156-167 compaction
+        n = int(keep.sum())
+        assert r['roi_count'][b] == n and n <= 256
+        np.testing.assert_array_equal(r['rois'][b, :n], props[b, :pc[b]][keep])
+        np.testing.assert_array_equal(r['roi_labels'][b, :n], ol[keep])
+        np.testing.assert_allclose(r['roi_targets'][b, :n], ot_[keep], rtol=1e-5, atol=1e-6)
+        assert (r['roi_labels'][b, n:] == -1).all() and (r['rois'][b, n:] == 0).all()
+
+
+def test_rcnn_target_reference_vectors(K):
+    # luminoth/models/fasterrcnn/rcnn_target_test.py:349-398 (labels) and :475-524 (priority)
+    gt = np.array([[(10, 0, 398, 399, 0), (200, 300, 250, 390, 1), (185, 305, 235, 372, 2)]], F)
+    props = np.array([[(12, 70, 350, 540), (190, 310, 240, 370), (197, 300, 252, 389), (196, 300, 252, 389),
+                       (197, 303, 252, 394), (180, 310, 235, 370), (0, 0, 400, 400), (197, 302, 252, 389),
+                       (0, 0, 400, 400)]], F)
+    r = K.rcnn_target(T(props), T(np.array([9], np.int32)), T(gt), T(np.array([3], np.int32)),
+                      T(np.array([0], np.int32)), minibatch_size=18, foreground_fraction=0.5,
+                      background_threshold_low=0.1)
+    np.testing.assert_array_equal(r['labels'][0, 1:].cpu().numpy(), np.add([2., 1., 1., 1., 2., 0., 1., 0.], 1))
+    gt = np.array([[[10, 10, 20, 20, 3.], [10, 10, 30, 30, 4.]]], F)
+    props = np.array([[[10, 10, 20, 20], [12, 10, 20, 20]]], F)
+    r = K.rcnn_target(T(props), T(np.array([2], np.int32)), T(gt), T(np.array([2], np.int32)),
+                      T(np.array([0], np.int32)), minibatch_size=64, foreground_fraction=0.5)
+    lab = r['labels'][0].cpu().numpy()
+    assert (lab == 4.).sum() == 1 and (lab == 5.).sum() == 1
+
+
+# -------------------------------------------------------------- ROI pool ----
+def test_roi_pool_fwd_bwd(K):
+    rs = np.random.RandomState(31)
+    B, FH, FW, C, R = 2, 20, 24, 64, 24
+    feat = rs.randn(B, FH, FW, C).astype(F)
+    rois = np.zeros((B, R, 4), F)
+    cnt = np.array([24, 10], np.int32)
+    for b in range(B):
+        rois[b] = rand_boxes(rs, R, 320, 8, 200)
+    rois[0, 0] = [-30, -20, 100, 90]        # partly outside: extrapolation 0
+    rois[0, 1] = [300, 200, 420, 380]       # beyond the image
+    im = (320, 384)
+    out, am = K.roi_pool_fwd(T(feat), T(rois), T(cnt), im)
+    out = out.cpu().numpy().reshape(B, R, 7, 7, C)
+    for b in range(B):
+        ref, _ = of.roi_pool(rois[b, :cnt[b]], feat[b:b + 1], im, 7, 7)
+        np.testing.assert_array_equal(out[b, :cnt[b]], ref)          # bit-exact bilinear + max
+        assert (out[b, cnt[b]:] == 0).all()
+    # backward vs torch autograd of the torch restatement
+    ft = torch.tensor(feat, requires_grad=True)
+    sel = [(b, r) for b in range(B) for r in range(cnt[b])]
+    rr = torch.tensor(np.stack([rois[b, r] for b, r in sel]))
+    bi = torch.tensor([b for b, _ in sel])
+    pooled = ot.roi_pool(ft, rr, bi, im)
+    g = rs.randn(B, R, 7, 7, C).astype(F)
+    gsel = torch.tensor(np.stack([g[b, r] for b, r in sel]))
+    pooled.backward(gsel)
+    dfeat = K.roi_pool_bwd(T(g.reshape(B * R, 7, 7, C)), am, T(rois), T(cnt), (B, FH, FW, C), im)
+    np.testing.assert_allclose(dfeat.cpu().numpy(), ft.grad.numpy(), rtol=1e-4, atol=1e-5)  # atomics order
+    # reference quadrant vectors, roi_pool_test.py:56-175
+    m = np.block([[np.ones((5, 5)) * 1, np.ones((5, 5)) * 2], [np.ones((5, 5)) * 3, np.ones((5, 5)) * 4]])
+    fm = np.repeat(m[None, :, :, None], 4, axis=3).astype(F)
+    rq = np.array([[[3, 1, 6, 4], [1, 3, 4, 7], [5, 3, 9, 7], [3, 6, 6, 9]]], F)
+    o, _ = K.roi_pool_fwd(T(fm), T(rq), T(np.array([4], np.int32)), (10, 10), ph=2, pw=2)
+    o = o.cpu().numpy()[..., 0]
+    np.testing.assert_array_equal(o[0], [[1, 2], [1, 2]])
+    np.testing.assert_array_equal(o[1], [[1, 1], [3, 3]])
+    np.testing.assert_array_equal(o[2], [[2, 2], [4, 4]])
+    np.testing.assert_array_equal(o[3], [[3, 4], [3, 4]])
+
+
+def test_spatial_mean(K):
+    x = torch.randn(37, 7, 7, 128, device=dev())
+    np.testing.assert_allclose(K.spatial_mean_fwd(x).cpu().numpy(), x.cpu().mean(dim=(1, 2)).numpy(),
+                               rtol=1e-5, atol=1e-6)
+    dy = torch.randn(37, 128, device=dev())
+    dx = K.spatial_mean_bwd(dy, x.shape).cpu().numpy()
+    np.testing.assert_allclose(dx, np.broadcast_to(dy.cpu().numpy()[:, None, None, :] / 49, x.shape), rtol=1e-6)
+
+
+# ---------------------------------------------------------------- losses ----
+def test_rpn_loss(K):
+    rs = np.random.RandomState(41)
+    B, N = 2, 49152
+    score = rs.randn(B, N, 2).astype(F)
+    pred = (rs.randn(B, N, 4) * 0.5).astype(F)
+    labels = np.full((B, N), -1, F)
+    tg = np.zeros((B, N, 4), F)
+    for b in range(B):
+        idx = rs.choice(N, 256, replace=False)
+        labels[b, idx[:100 + 20 * b]] = 1
+        labels[b, idx[100 + 20 * b:]] = 0
+        tg[b, idx[:100 + 20 * b]] = (rs.randn(100 + 20 * b, 4) * 0.5).astype(F)
+    losses, per, dc, db = K.rpn_loss(T(score), T(pred), T(labels), T(tg), sigma=3.0)
+    st, pt = torch.tensor(score, requires_grad=True), torch.tensor(pred, requires_grad=True)
+    tot = 0
+    for b in range(B):
+        o = of.rpn_loss(score[b], labels[b], pred[b], tg[b], 3.0)
+        np.testing.assert_allclose(per[b, :2].cpu().numpy(), [o['rpn_cls_loss'], o['rpn_reg_loss']], rtol=1e-5)
+        c, r = ot.rpn_loss(st[b], pt[b], torch.tensor(labels[b]), torch.tensor(tg[b]), 3.0)
+        tot = tot + (c + r) / B
+    tot.backward()
+    np.testing.assert_allclose(float(losses.sum()), float(tot), rtol=1e-5)       # loss: 1e-5 rel
+    np.testing.assert_allclose(dc.cpu().numpy(), st.grad.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(db.cpu().numpy(), pt.grad.numpy(), rtol=1e-4, atol=1e-8)
+
+
+def test_rcnn_loss(K):
+    rs = np.random.RandomState(43)
+    B, R, C = 2, 256, 80
+    score = rs.randn(B, R, C + 1).astype(F)
+    off = (rs.randn(B, R, 4 * C) * 0.5).astype(F)
+    labels = np.full((B, R), -1, F)
+    tg = np.zeros((B, R, 4), F)
+    for b in range(B):
+        n = 200 + 30 * b
+        labels[b, :n] = 0
+        fg = rs.choice(n, 50, replace=False)
+        labels[b, fg] = rs.randint(1, C + 1, size=50)
+        tg[b, fg] = rs.randn(50, 4).astype(F)
+    losses, per, dc, do = K.rcnn_loss(T(score), T(off), T(labels), T(tg), C, sigma=1.0)
+    st, ot_ = torch.tensor(score, requires_grad=True), torch.tensor(off, requires_grad=True)
+    tot = 0
+    for b in range(B):
+        o = of.rcnn_loss(score[b], off[b], labels[b], tg[b], C, 1.0)
+        np.testing.assert_allclose(per[b, :2].cpu().numpy(), [o['rcnn_cls_loss'], o['rcnn_reg_loss']], rtol=1e-5)
+        c, r = ot.rcnn_loss(st[b], ot_[b], torch.tensor(labels[b]), torch.tensor(tg[b]), C, 1.0)
+        tot = tot + (c + r) / B
+    tot.backward()
+    np.testing.assert_allclose(float(losses.sum()), float(tot), rtol=1e-5)
+    np.testing.assert_allclose(dc.cpu().numpy(), st.grad.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(do.cpu().numpy(), ot_.grad.numpy(), rtol=1e-4, atol=1e-8)
+    y = K.softmax(T(score)).cpu().numpy()
+    np.testing.assert_allclose(y, tfops.softmax(score), rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------ conv ----
+CONV_CASES = [
+    # N, H, W, C, K, R, stride, dil, padding, act
+    (2, 32, 32, 64, 256, 1, 1, 1, 'SAME', 'relu'),
+    (2, 32, 32, 256, 64, 3, 1, 1, 'SAME', 'relu'),
+    (1, 33, 47, 128, 128, 3, 2, 1, 'SAME_EXPLICIT', 'relu'),
+    (1, 64, 64, 3, 64, 7, 2, 1, 'SAME_EXPLICIT', 'relu'),
+    (2, 19, 19, 512, 1024, 3, 1, 6, 'SAME', 'relu'),
+    (1, 16, 16, 512, 72, 1, 1, 1, 'VALID', None),
+    (1, 16, 32, 1024, 404, 1, 1, 1, 'VALID', None),
+    (1, 64, 64, 1024, 512, 3, 1, 1, 'SAME', 'relu6'),
+    (1, 10, 10, 256, 256, 3, 2, 1, 'SAME', 'relu'),
+    (1, 5, 5, 128, 256, 3, 1, 1, 'VALID', 'relu'),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_bwd(K, case):
+    N, H, W, C, Kc, R, stride, dil, padding, act = case
+    rs = np.random.RandomState(hash(case) % 2 ** 31)
+    x = rs.randn(N, H, W, C).astype(F)
+    w = (rs.randn(R, R, C, Kc) * np.sqrt(2.0 / (R * R * C))).astype(F)
+    scale = (1 + 0.1 * rs.randn(Kc)).astype(F)
+    shift = (0.1 * rs.randn(Kc)).astype(F)
+    in_sub = np.array([.3, -.2, .1], F) if C == 3 else None
+    d = K.conv_desc(x.shape, w.shape, stride, dil, padding, act)
+    res = rs.randn(N, d.OH, d.OW, Kc).astype(F)
+    y = K.conv2d_fwd(d, T(x), T(w), T(scale), T(shift), T(res), None if in_sub is None else T(in_sub))
+    xt = torch.tensor(x, requires_grad=True)
+    wt = torch.tensor(w, requires_grad=True)
+    xin = xt - torch.tensor(in_sub) if in_sub is not None else xt
+    conv = ot.conv2d_nhwc(xin, wt, stride, dil, padding)
+    yt = conv * torch.tensor(scale) + torch.tensor(shift) + torch.tensor(res)
+    if act == 'relu':
+        yt = torch.relu(yt)
+    elif act == 'relu6':
+        yt = torch.clamp(yt, 0, 6)
+    assert tuple(y.shape) == tuple(yt.shape)
+    # fp32 MFMA == fmaf chain; reference sums in another order: 2e-5 of the output scale
+    tol = 2e-5 * max(1.0, float(yt.abs().max()))
+    np.testing.assert_allclose(y.cpu().numpy(), yt.detach().numpy(), rtol=1e-4, atol=tol)
+    if C == 3:
+        return
+    # backward through the fused layer
+    gy = rs.randn(*yt.shape).astype(F)
+    yt.backward(torch.tensor(gy))
+    g = K.act_bwd(T(gy), y, act) if act else T(gy)
+    colsum = torch.zeros(Kc, device=dev())
+    K.act_bwd(T(gy), y, act, want_g=False, colsum=colsum)
+    gref = gy * ((yt.detach().numpy() > 0) & ((yt.detach().numpy() < 6) if act == 'relu6' else True)) if act else gy
+    np.testing.assert_allclose(colsum.cpu().numpy(), gref.reshape(-1, Kc).sum(0), rtol=1e-3, atol=1e-3)
+    dx = K.conv2d_bwd_data(d, g, T(w), T(scale))
+    tolx = 2e-5 * max(1.0, float(xt.grad.abs().max()))
+    np.testing.assert_allclose(dx.cpu().numpy(), xt.grad.numpy(), rtol=1e-4, atol=tolx)
+    add = rs.randn(*x.shape).astype(F)
+    dx2 = K.conv2d_bwd_data(d, g, T(w), T(scale), addend=T(add))
+    np.testing.assert_allclose(dx2.cpu().numpy(), xt.grad.numpy() + add, rtol=1e-4, atol=tolx)
+    dw = K.conv2d_bwd_weight(d, T(x), g)            # raw: w.r.t. the un-scaled conv output
+    dw_ref = wt.grad.numpy()
+    dws = dw.cpu().numpy() * scale[None, None, None, :]
+    tolw = 5e-5 * max(1.0, float(np.abs(dw_ref).max()))
+    np.testing.assert_allclose(dws, dw_ref, rtol=1e-3, atol=tolw)
+
+
+def test_bn_param_grads(K):
+    rs = np.random.RandomState(5)
+    rsc, Kc = 9 * 64, 96
+    w = rs.randn(rsc, Kc).astype(F)
+    dwr = rs.randn(rsc, Kc).astype(F)
+    dbeta, mean = rs.randn(Kc).astype(F), rs.randn(Kc).astype(F)
+    rstd, scale = rs.rand(Kc).astype(F) + .5, rs.rand(Kc).astype(F) + .5
+    dwt = T(dwr.copy())
+    dg = K.bn_param_grads(T(w), dwt, T(dbeta), T(mean), T(rstd), T(scale))
+    np.testing.assert_allclose(dg.cpu().numpy(), rstd * ((w * dwr).sum(0) - mean * dbeta), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dwt.cpu().numpy(), dwr * scale, rtol=1e-6)
+
+
+def test_maxpool(K):
+    rs = np.random.RandomState(6)
+    for (H, W, k, s, pad) in ((33, 31, 3, 2, 'SAME'), (20, 20, 2, 2, 'VALID'), (18, 18, 3, 1, 'SAME')):
+        x = rs.randn(2, H, W, 64).astype(F)
+        y, geom = K.maxpool_fwd(T(x), k, s, pad)
+        xt = torch.tensor(x, requires_grad=True)
+        yt = ot.max_pool_nhwc(xt, k, s, pad)
+        np.testing.assert_array_equal(y.cpu().numpy(), yt.detach().numpy())
+        gy = rs.randn(*yt.shape).astype(F)
+        yt.backward(torch.tensor(gy))
+        dx = K.maxpool_bwd(T(x), y, T(gy), k, s, geom)
+        np.testing.assert_allclose(dx.cpu().numpy(), xt.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------- optimizer ----
+def test_sgd_momentum_and_l2(K):
+    rs = np.random.RandomState(8)
+    sizes = [1000, 37, 4096, 5]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    wd = np.array([5e-4, 0.0, 1e-3, 0.0], F)
+    n = int(off[-1])
+    w, g, v = rs.randn(n).astype(F), rs.randn(n).astype(F), rs.randn(n).astype(F)
+    wt, gt_, vt = T(w.copy()), T(g), T(v.copy())
+    reg = K.l2_reg_loss(wt, T(off), T(wd))
+    wde = np.repeat(wd, sizes)
+    np.testing.assert_allclose(float(reg), float((wde * w.astype(np.float64) ** 2 / 2).sum()), rtol=1e-5)
+    K.sgd_momentum(wt, gt_, vt, T(off), T(wd), lr=3e-4, momentum=0.9, gscale=0.5)
+    gg = g * F(0.5) + wde * w
+    vv = F(0.9) * v + gg
+    np.testing.assert_allclose(vt.cpu().numpy(), vv, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(wt.cpu().numpy(), w - F(3e-4) * vv, rtol=1e-6, atol=1e-7)
