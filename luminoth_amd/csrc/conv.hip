@@ -253,6 +253,7 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int kq = tid & 7;
+  const bool vecK = (K & 3) == 0;
   int a_n[AJ], a_h[AJ], a_w[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
@@ -268,9 +269,14 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
   auto load_tile = [&](int kt) {
     const int rs = kt / KTk, k0 = (kt - rs * KTk) * BK + 4 * kq;
     const int r = rs / d.S, s = rs - r * d.S;
-    const bool kok = k0 < K;  // K % 4 == 0 guaranteed by the host
+    const bool kok = k0 < K;
     float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (kscale && kok) ks = *reinterpret_cast<const float4*>(kscale + k0);
+    if (kscale && kok) {
+      ks.x = kscale[k0];
+      if (k0 + 1 < K) ks.y = kscale[k0 + 1];
+      if (k0 + 2 < K) ks.z = kscale[k0 + 2];
+      if (k0 + 3 < K) ks.w = kscale[k0 + 3];
+    }
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const int th = a_h[j] - r * d.dilation, tw = a_w[j] - s * d.dilation;
@@ -283,7 +289,15 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
       ok = ok && oh < d.OH && ow < d.OW;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) {
-        v = *reinterpret_cast<const float4*>(dy + ((size_t)(a_n[j] * d.OH + oh) * d.OW + ow) * K + k0);
+        const float* src = dy + ((size_t)(a_n[j] * d.OH + oh) * d.OW + ow) * K + k0;
+        if (vecK) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (k0 + 1 < K) v.y = src[1];
+          if (k0 + 2 < K) v.z = src[2];
+          if (k0 + 3 < K) v.w = src[3];
+        }
         v.x *= ks.x; v.y *= ks.y; v.z *= ks.z; v.w *= ks.w;
       }
       ra[j] = v;
@@ -291,8 +305,19 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       const int c = n0 + (tid >> 3) + 32 * j;
-      rb[j] = (c < C && kok) ? *reinterpret_cast<const float4*>(w + ((size_t)rs * C + c) * K + k0)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C && kok) {
+        const float* src = w + ((size_t)rs * C + c) * K + k0;
+        if (vecK) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (k0 + 1 < K) v.y = src[1];
+          if (k0 + 2 < K) v.z = src[2];
+          if (k0 + 3 < K) v.w = src[3];
+        }
+      }
+      rb[j] = v;
     }
   };
   auto store_tile = [&]() {
@@ -363,6 +388,7 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
   constexpr int BROW_T = BN / 4, BROW_STEP = 256 / BROW_T;
   const int ax4 = tid % AROW_T, ak = tid / AROW_T;
   const int bx4 = tid % BROW_T, bk = tid / BROW_T;
+  const bool vecK = (K & 3) == 0;
   float4 ra[AJ], rb[BJ];
   auto load_tile = [&](int kt) {
     const int p0 = kt * BK;
@@ -385,8 +411,19 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
     for (int j = 0; j < BJ; ++j) {
       const int p = p0 + bk + BROW_STEP * j;
       const int n = n0 + 4 * bx4;
-      rb[j] = (p < P && n < K) ? *reinterpret_cast<const float4*>(dy + (size_t)p * K + n)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < P && n < K) {
+        const float* src = dy + (size_t)p * K + n;
+        if (vecK && n + 3 < K) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (n + 1 < K) v.y = src[1];
+          if (n + 2 < K) v.z = src[2];
+          if (n + 3 < K) v.w = src[3];
+        }
+      }
+      rb[j] = v;
     }
   };
   auto store_tile = [&]() {
@@ -506,7 +543,6 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(dy && w && dx);
-  LMH_CHECK_ARG((d->K & 3) == 0);
   LMH_CHECK_ARG(d->R * d->S == 1 || (d->K % BK) == 0);
   const int64_t M = (int64_t)d->N * d->H * d->W;
   int bm, bn;
@@ -550,7 +586,7 @@ extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, con
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(x && dy && dw);
-  LMH_CHECK_ARG((d->C & 3) == 0 && (d->K & 3) == 0);
+  LMH_CHECK_ARG((d->C & 3) == 0);
   int bm, bn, splits, kps;
   bwd_weight_plan(d, &bm, &bn, &splits, &kps);
   if (ws_bytes < lmh_conv2d_bwd_weight_workspace_bytes(d) || (splits > 1 && !ws)) {

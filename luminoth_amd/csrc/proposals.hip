@@ -217,12 +217,14 @@ k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts,
 //    the 64 candidates of a chunk serially in registers (diagonal word per
 //    lane), then all waves OR the kept rows into the LDS `removed` bitmap.
 #define NMS_RED_THREADS 256
+#define NMS_MAX_W 512  // K <= 32768 candidates
 __global__ void __launch_bounds__(NMS_RED_THREADS)
 k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts, int K, int W,
              int max_out, int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned long long* removed = reinterpret_cast<unsigned long long*>(smem_raw);  // W words
-  __shared__ unsigned long long s_kept;
+  // all LDS static: a static object in front of a dynamic region would leave the u64 bitmap
+  // 4-byte aligned (64-bit LDS atomics then misbehave) — guide §6 G17.
+  __shared__ __attribute__((aligned(16))) unsigned long long removed[NMS_MAX_W];
+  __shared__ __attribute__((aligned(16))) unsigned long long s_kept;
   __shared__ int s_total;
   const int b = blockIdx.x;
   const int cnt = counts[b];
@@ -295,7 +297,7 @@ static int nms_impl(const float* boxes, const int32_t* counts, int B, int K, flo
   dim3 g(W, W, B);
   hipLaunchKernelGGL(k_nms_mask, g, dim3(64), 0, st, reinterpret_cast<const float4*>(boxes), counts,
                      K, W, thr, mask);
-  hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), (size_t)W * 8, st, mask, counts,
+  hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts,
                      K, W, max_out, keep_idx, keep_count);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -305,7 +307,7 @@ extern "C" int lmh_nms(const float* boxes, const int32_t* counts, int B, int K, 
                        int max_out, int32_t* keep_idx, int32_t* keep_count, void* ws,
                        size_t ws_bytes, lmh_stream_t stream) {
   LMH_CHECK_ARG(boxes && counts && keep_idx && keep_count && ws);
-  LMH_CHECK_ARG(B > 0 && K > 0 && max_out > 0);
+  LMH_CHECK_ARG(B > 0 && K > 0 && max_out > 0 && K <= 64 * NMS_MAX_W);
   if (ws_bytes < lmh_nms_workspace_bytes(B, K)) {
     lmh_set_error("lmh_nms: workspace %zu < %zu", ws_bytes, lmh_nms_workspace_bytes(B, K));
     return LMH_ERR_WORKSPACE;
@@ -395,7 +397,7 @@ extern "C" int lmh_rpn_proposal(const lmh_rpn_proposal_desc* d, const float* cls
   LMH_CHECK_ARG(d && cls_score && bbox_pred && anchor_ref && cls_prob && proposals && scores &&
                 num_proposals && ws);
   LMH_CHECK_ARG(d->B > 0 && d->feat_h > 0 && d->feat_w > 0 && d->A > 0);
-  LMH_CHECK_ARG(d->pre_nms_top_n > 0 && d->post_nms_top_n > 0);
+  LMH_CHECK_ARG(d->pre_nms_top_n > 0 && d->post_nms_top_n > 0 && d->pre_nms_top_n <= 64 * NMS_MAX_W);
   const int N = d->feat_h * d->feat_w * d->A;
   const int Npad = lmh_next_pow2(N);
   rpn_prop_ws w = rpn_prop_layout(d, ws);

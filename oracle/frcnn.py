@@ -83,21 +83,22 @@ def rpn_target(all_anchors, gt_boxes, im_shape, seed=0, allowed_border=0,
         labels[neg] = 0                                              # :191-202
     labels_pre = labels.copy()
     # Subsample positives (:203-241) then negatives (:243-284).
+    # The random choice is keyed on the anchor's index in the FULL grid (oracle/rng.py).
+    inds = np.where(anchor_filter)[0]
     num_fg = int(foreground_fraction * minibatch_size)
     fg_inds = np.where(labels == 1)[0]
     if fg_inds.size > num_fg:
-        keep = rng.keep_k_smallest(fg_inds, num_fg, seed, rng.STREAM_RPN_FG)
+        keep = rng.keep_k_smallest(inds[fg_inds], num_fg, seed, rng.STREAM_RPN_FG)
         labels[fg_inds[~keep]] = -1
     num_bg = int(minibatch_size - np.sum(labels == 1))
     bg_inds = np.where(labels == 0)[0]
     if bg_inds.size > num_bg:
-        keep = rng.keep_k_smallest(bg_inds, num_bg, seed, rng.STREAM_RPN_BG)
+        keep = rng.keep_k_smallest(inds[bg_inds], num_bg, seed, rng.STREAM_RPN_BG)
         labels[bg_inds[~keep]] = -1
     argmax_overlaps = overlaps.argmax(axis=1)                        # :289
     bbox_targets = bx.encode(anchors, gt[argmax_overlaps])           # :295-297
     bbox_targets = np.where((labels == 1)[:, None], bbox_targets, F(0)).astype(F)  # :299-304
     # Scatter back to all anchors (:311-333).
-    inds = np.where(anchor_filter)[0]
     out_t = np.zeros((N, 4), dtype=F)
     out_t[inds] = bbox_targets
     out_l = np.full((N,), -1, dtype=F)
