@@ -106,8 +106,9 @@ int lmh_maxpool_bwd(const float* x, const float* y, const float* dy, int N, int 
  * top_k(pre_nms_top_n) (stable: score desc, index asc) -> NMS(thr, strict >,
  * TF continuous-area IoU) -> gather.
  *   cls_score (B,N,2)  bbox_pred (B,N,4)  anchor_ref (A,4) int32
- *   out: cls_prob (B,N,2), proposals (B,post_nms_top_n,4), scores (B,post),
- *        num_proposals (B) int32.  Rows beyond num_proposals[b] are zero.
+ *   out: cls_prob (B,N,2), proposals (B,cap,4), scores (B,cap), num_proposals
+ *        (B) int32, cap = apply_nms ? post_nms_top_n : pre_nms_top_n.  Rows
+ *        beyond num_proposals[b] are zero.
  */
 typedef struct lmh_rpn_proposal_desc {
   int32_t B, feat_h, feat_w, A, anchor_stride;
@@ -179,6 +180,32 @@ int lmh_rcnn_target(const lmh_rcnn_target_desc* d, const float* proposals,
                     const uint32_t* seeds, float* labels, float* bbox_targets, float* labels_pre,
                     float* rois, float* roi_labels, float* roi_targets, int32_t* roi_count,
                     lmh_stream_t stream);
+
+/* RCNNProposal._build (models/fasterrcnn/rcnn_proposal.py:46-164): per class
+ * decode(variances) -> clip -> (prob >= min_prob & area > 0) -> NMS(thr, <=
+ * class_max) ; concat in class order ; top_k(total_max) by prob.  One batched
+ * launch sequence over (image, class).  Also SSDProposal
+ * (models/ssd/proposal.py:41-171) with class_agnostic_boxes = 1.
+ *   proposals (B,R,4), prop_count (B), bbox_pred (B,R,4C) [(B,R,4) if
+ *   class_agnostic_boxes], cls_prob (B,R,C+1)
+ *   out: objects (B,T,4), labels (B,T) int32 (-1 padded), probs (B,T), num (B).
+ */
+typedef struct lmh_rcnn_proposal_desc {
+  int32_t B, R, C;
+  float im_h, im_w;
+  float variance_xy, variance_wh;
+  int32_t class_max_detections;
+  float class_nms_threshold;
+  int32_t total_max_detections;
+  float min_prob_threshold;
+  int32_t class_agnostic_boxes;
+} lmh_rcnn_proposal_desc;
+
+size_t lmh_rcnn_proposal_workspace_bytes(const lmh_rcnn_proposal_desc* d);
+int lmh_rcnn_proposal(const lmh_rcnn_proposal_desc* d, const float* proposals,
+                      const int32_t* prop_count, const float* bbox_pred, const float* cls_prob,
+                      float* objects, int32_t* labels, float* probs, int32_t* num_objects,
+                      void* ws, size_t ws_bytes, lmh_stream_t stream);
 
 /* ------------------------------------------------------------------ ROI --
  * ROIPoolingLayer._roi_crop (models/fasterrcnn/roi_pool.py:37-95):

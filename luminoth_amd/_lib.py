@@ -52,6 +52,15 @@ class RcnnTargetDesc(ctypes.Structure):
                 ('variance_xy', ctypes.c_float), ('variance_wh', ctypes.c_float)]
 
 
+class RcnnProposalDesc(ctypes.Structure):
+    _fields_ = [('B', ctypes.c_int32), ('R', ctypes.c_int32), ('C', ctypes.c_int32),
+                ('im_h', ctypes.c_float), ('im_w', ctypes.c_float),
+                ('variance_xy', ctypes.c_float), ('variance_wh', ctypes.c_float),
+                ('class_max_detections', ctypes.c_int32), ('class_nms_threshold', ctypes.c_float),
+                ('total_max_detections', ctypes.c_int32), ('min_prob_threshold', ctypes.c_float),
+                ('class_agnostic_boxes', ctypes.c_int32)]
+
+
 P = ctypes.POINTER
 SIGNATURES = {
     # name: (restype, argtypes)   -- lists EVERY symbol include/luminoth_hip.h declares
@@ -74,6 +83,8 @@ SIGNATURES = {
     'lmh_rpn_target_workspace_bytes': (c_sz, [P(RpnTargetDesc)]),
     'lmh_rpn_target': (c_i, [P(RpnTargetDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_rcnn_target': (c_i, [P(RcnnTargetDesc)] + [c_f] * 13),
+    'lmh_rcnn_proposal_workspace_bytes': (c_sz, [P(RcnnProposalDesc)]),
+    'lmh_rcnn_proposal': (c_i, [P(RcnnProposalDesc)] + [c_f] * 9 + [c_sz, c_f]),
     'lmh_roi_pool_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_f]),
     'lmh_roi_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
     'lmh_spatial_mean_fwd': (c_i, [c_f, c_i64, c_i, c_i, c_f, c_f]),

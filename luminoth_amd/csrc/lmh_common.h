@@ -10,6 +10,10 @@
 #define LMH_WAVE 64
 
 void lmh_set_error(const char* fmt, ...);
+// shared building blocks (proposals.hip)
+int lmh_sort_u64_impl(uint64_t* keys, int B, int n_pad, hipStream_t st);
+int lmh_nms_impl(const float* boxes, const int32_t* counts, int B, int K, float thr, int max_out,
+                 int32_t* keep_idx, int32_t* keep_count, void* ws, hipStream_t st);
 
 #define LMH_CHECK_ARG(cond)                                                 \
   do {                                                                      \

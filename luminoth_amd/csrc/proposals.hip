@@ -118,7 +118,7 @@ k_sort_merge_local(uint64_t* __restrict__ keys, int n_pad, int chunk, int k) {
   for (int i = threadIdx.x; i < chunk; i += blockDim.x) keys[base + i] = s[i];
 }
 
-static int sort_u64_impl(uint64_t* keys, int B, int n_pad, hipStream_t st) {
+int lmh_sort_u64_impl(uint64_t* keys, int B, int n_pad, hipStream_t st) {
   if (n_pad <= 1) return LMH_OK;
   const int chunk = n_pad < SORT_CHUNK ? n_pad : SORT_CHUNK;
   const size_t lds = (size_t)chunk * sizeof(uint64_t);
@@ -138,7 +138,7 @@ static int sort_u64_impl(uint64_t* keys, int B, int n_pad, hipStream_t st) {
 extern "C" int lmh_sort_u64(uint64_t* keys, int B, int n_pad, lmh_stream_t stream) {
   LMH_CHECK_ARG(keys != nullptr && B > 0 && n_pad > 0);
   LMH_CHECK_ARG((n_pad & (n_pad - 1)) == 0);
-  return sort_u64_impl(keys, B, n_pad, (hipStream_t)stream);
+  return lmh_sort_u64_impl(keys, B, n_pad, (hipStream_t)stream);
 }
 
 // ----------------------------------------------------------------------------
@@ -250,8 +250,9 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
         const int j = __builtin_ctzll(alive);
         kept |= (1ull << j);
         ++total;
-        const uint64_t dj = ((uint64_t)__builtin_amdgcn_readlane(dhi, j) << 32) |
-                            (uint64_t)__builtin_amdgcn_readlane(dlo, j);
+        // readlane returns a signed int: go through uint32_t or bit 31 sign-extends into the high word
+        const uint64_t dj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dlo, j);
         alive &= ~dj;
         alive &= ~(1ull << j);
       }
@@ -290,7 +291,7 @@ extern "C" size_t lmh_nms_workspace_bytes(int B, int K) {
   return lmh_align_up((size_t)B * K * W * sizeof(uint64_t), 256);
 }
 
-static int nms_impl(const float* boxes, const int32_t* counts, int B, int K, float thr, int max_out,
+int lmh_nms_impl(const float* boxes, const int32_t* counts, int B, int K, float thr, int max_out,
                     int32_t* keep_idx, int32_t* keep_count, void* ws, hipStream_t st) {
   const int W = (K + 63) / 64;
   uint64_t* mask = reinterpret_cast<uint64_t*>(ws);
@@ -312,7 +313,7 @@ extern "C" int lmh_nms(const float* boxes, const int32_t* counts, int B, int K, 
     lmh_set_error("lmh_nms: workspace %zu < %zu", ws_bytes, lmh_nms_workspace_bytes(B, K));
     return LMH_ERR_WORKSPACE;
   }
-  return nms_impl(boxes, counts, B, K, iou_threshold, max_out, keep_idx, keep_count, ws,
+  return lmh_nms_impl(boxes, counts, B, K, iou_threshold, max_out, keep_idx, keep_count, ws,
                   (hipStream_t)stream);
 }
 
@@ -367,7 +368,8 @@ struct rpn_prop_ws {
 
 static rpn_prop_ws rpn_prop_layout(const lmh_rpn_proposal_desc* d, void* base) {
   const size_t B = d->B, N = (size_t)d->feat_h * d->feat_w * d->A;
-  const size_t Npad = lmh_next_pow2((int)N), K = d->pre_nms_top_n, P = d->post_nms_top_n;
+  const size_t Npad = lmh_next_pow2((int)N), K = d->pre_nms_top_n;
+  const size_t P = d->apply_nms ? d->post_nms_top_n : d->pre_nms_top_n;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += lmh_align_up(bytes, 256); return o; };
   rpn_prop_ws w;
@@ -406,16 +408,17 @@ extern "C" int lmh_rpn_proposal(const lmh_rpn_proposal_desc* d, const float* cls
     return LMH_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int B = d->B, K = d->pre_nms_top_n, P = d->post_nms_top_n;
+  const int B = d->B, K = d->pre_nms_top_n;
+  const int P = d->apply_nms ? d->post_nms_top_n : d->pre_nms_top_n;  // no post cap without NMS (rpn_proposal.py:172-174)
   LMH_CHECK_HIP(hipMemsetAsync(w.n_valid, 0, sizeof(int32_t) * B, st));
   hipLaunchKernelGGL(k_rpn_decode, dim3((Npad + 255) / 256, B), dim3(256), 0, st, *d, N, Npad,
                      cls_score, bbox_pred, anchor_ref, cls_prob, w.boxes, w.keys, w.n_valid);
-  int rc = sort_u64_impl(w.keys, B, Npad, st);
+  int rc = lmh_sort_u64_impl(w.keys, B, Npad, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_gather_topk, dim3((K + 255) / 256, B), dim3(256), 0, st, w.keys, w.boxes,
                      cls_prob, w.n_valid, N, Npad, K, w.top_boxes, w.top_scores, w.top_count);
   if (d->apply_nms) {
-    rc = nms_impl(reinterpret_cast<const float*>(w.top_boxes), w.top_count, B, K, d->nms_threshold,
+    rc = lmh_nms_impl(reinterpret_cast<const float*>(w.top_boxes), w.top_count, B, K, d->nms_threshold,
                   P, w.keep_idx, w.keep_count, w.nms_ws, st);
     if (rc) return rc;
   } else {

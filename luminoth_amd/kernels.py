@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ConvDesc, RpnProposalDesc, RpnTargetDesc, RcnnTargetDesc, check)
+from ._lib import (ConvDesc, RpnProposalDesc, RpnTargetDesc, RcnnTargetDesc, RcnnProposalDesc, check)
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'relu6': 2}
 
@@ -115,11 +115,11 @@ def act_bwd(dy, y, act, want_g=True, colsum=None):
     return g
 
 
-def bn_param_grads(w, dw_raw, dbeta, mean, rstd, scale):
+def bn_param_grads(w, dw_raw, dbeta, mean, rstd, scale, out=None):
     lib = _lib.load()
     K = w.shape[-1]
     rsc = w.numel() // K
-    dgamma = torch.empty_like(dbeta)
+    dgamma = out if out is not None else torch.empty_like(dbeta)
     check(lib.lmh_bn_param_grads(_p(w), _p(dw_raw), _p(dbeta), _p(mean), _p(rstd), _p(scale), rsc, K,
                                  _p(dgamma), _stream()), 'lmh_bn_param_grads')
     return dgamma
@@ -164,8 +164,9 @@ def rpn_proposal(cls_score, bbox_pred, anchor_ref_i32, feat_h, feat_w, stride, i
                         int(bool(filter_outside_anchors)))
     dev = cls_score.device
     cls_prob = torch.empty_like(cls_score)
-    proposals = torch.empty((B, post_nms_top_n, 4), dtype=torch.float32, device=dev)
-    scores = torch.empty((B, post_nms_top_n), dtype=torch.float32, device=dev)
+    cap = int(post_nms_top_n if apply_nms else pre_nms_top_n)
+    proposals = torch.empty((B, cap, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, cap), dtype=torch.float32, device=dev)
     count = torch.empty((B,), dtype=torch.int32, device=dev)
     ws = _workspace(lib.lmh_rpn_proposal_workspace_bytes(ctypes.byref(d)), dev, 'rpn_proposal')
     check(lib.lmh_rpn_proposal(ctypes.byref(d), _p(cls_score), _p(bbox_pred), _p(anchor_ref_i32), _p(cls_prob),
@@ -241,6 +242,30 @@ def rcnn_target(proposals, prop_count, gt, gt_count, seeds, minibatch_size=256, 
                               _p(roi_count), _stream()), 'lmh_rcnn_target')
     return dict(labels=labels, bbox_targets=targets, labels_pre=pre, rois=rois, roi_labels=roi_labels,
                 roi_targets=roi_targets, roi_count=roi_count)
+
+
+def rcnn_proposal(proposals, prop_count, bbox_pred, cls_prob, im_shape, num_classes, variances=(0.1, 0.2),
+                  class_max_detections=100, class_nms_threshold=0.5, total_max_detections=300,
+                  min_prob_threshold=0.5, class_agnostic_boxes=False):
+    """proposals (B,R,4), bbox_pred (B,R,4C), cls_prob (B,R,C+1) -> objects (B,T,4), labels, probs, num."""
+    lib = _lib.load()
+    B, R, _ = proposals.shape
+    v = (1.0, 1.0) if variances is None else variances
+    d = RcnnProposalDesc(B, R, int(num_classes), float(im_shape[0]), float(im_shape[1]), float(v[0]),
+                         float(v[1]), int(class_max_detections), float(class_nms_threshold),
+                         int(total_max_detections), float(min_prob_threshold or 0.0),
+                         int(bool(class_agnostic_boxes)))
+    dev = proposals.device
+    T = int(total_max_detections)
+    objects = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, T), dtype=torch.int32, device=dev)
+    probs = torch.empty((B, T), dtype=torch.float32, device=dev)
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = _workspace(lib.lmh_rcnn_proposal_workspace_bytes(ctypes.byref(d)), dev, 'rcnn_proposal')
+    check(lib.lmh_rcnn_proposal(ctypes.byref(d), _p(proposals), _p(prop_count), _p(bbox_pred), _p(cls_prob),
+                                _p(objects), _p(labels), _p(probs), _p(num), _p(ws),
+                                ctypes.c_size_t(ws.numel()), _stream()), 'lmh_rcnn_proposal')
+    return objects, labels, probs, num
 
 
 # ------------------------------------------------------------------- ROI ----

@@ -1,0 +1,279 @@
+"""Layer executors of the backbone / heads: each node knows how to run its
+forward and its hand-derived backward through the HIP kernels
+(luminoth_amd/kernels.py).  No torch compute ops are used on activations.
+
+The nodes restate what tf.contrib.slim builds for the reference
+(models/base/base_network.py:70-101): conv2d [+ frozen BatchNorm | + bias]
+[+ ReLU], conv2d_same, max_pool2d, resnet_v1 bottleneck units.
+"""
+import torch
+
+from luminoth_amd import kernels as K
+
+BN_EPS = 1e-5  # slim resnet_arg_scope batch_norm_epsilon (truncated_base_network.py:69-73)
+
+
+class ConvLayer(object):
+    """conv2d (HWIO weights `<scope>/weights`) followed by either a frozen
+    BatchNorm (`<scope>/BatchNorm/{gamma,beta,moving_mean,moving_variance}`:
+    inference statistics, gamma/beta trainable — base_network.py:84-89) or a
+    bias (`<scope>/biases`), an optional residual add and an activation."""
+
+    def __init__(self, scope, cin, cout, ksize, stride=1, rate=1, padding='SAME', act='relu',
+                 norm='bn', wd=0.0, init=None, bias_name='biases', weight_name='weights'):
+        self.scope, self.cin, self.cout, self.k = scope, cin, cout, ksize
+        self.stride, self.rate, self.padding, self.act = stride, rate, padding, act
+        self.norm = norm          # 'bn' | 'bias' | None
+        self.wd, self.init = wd, init
+        self.trainable = True
+        self.w_name = '%s/%s' % (scope, weight_name)
+        self.b_name = '%s/%s' % (scope, bias_name)
+        self._desc = {}
+
+    # ---- variable names in TF creation order (drives fine_tune_from) --------
+    def var_names(self):
+        names = [self.w_name]
+        if self.norm == 'bn':
+            names += ['%s/BatchNorm/beta' % self.scope, '%s/BatchNorm/gamma' % self.scope]
+        elif self.norm == 'bias':
+            names += [self.b_name]
+        return names
+
+    def bind(self, store, bn_table):
+        self.store = store
+        self.w = store[self.w_name]
+        self.gw = store.grads.get(self.w_name)
+        self.scale = self.shift = None
+        if self.norm == 'bn':
+            self.bn = bn_table.views(self.scope)
+            self.scale, self.shift = self.bn['scale'], self.bn['shift']
+        elif self.norm == 'bias':
+            self.shift = store[self.b_name]
+            self.gb = store.grads.get(self.b_name)
+
+    def desc(self, x_shape):
+        key = tuple(x_shape)
+        d = self._desc.get(key)
+        if d is None:
+            d = K.conv_desc(x_shape, (self.k, self.k, self.cin, self.cout), self.stride, self.rate,
+                            self.padding, self.act)
+            self._desc[key] = d
+        return d
+
+    def forward(self, x, residual=None, in_sub=None):
+        d = self.desc(x.shape)
+        return K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub)
+
+    def backward(self, x, y, dy, need_dx=True, addend=None):
+        """dy: gradient w.r.t. the layer output (after residual add + act).
+        Returns (dx or None, g) with g = gradient w.r.t. the pre-activation sum
+        (== gradient of the residual branch)."""
+        d = self.desc(x.shape)
+        colsum = None
+        if self.trainable:
+            if self.norm == 'bn':
+                colsum = self.bn['gbeta']
+            elif self.norm == 'bias':
+                colsum = self.gb
+        if self.act:
+            g = K.act_bwd(dy, y, self.act, want_g=True, colsum=colsum)
+        else:
+            g = dy
+            if colsum is not None:
+                K.act_bwd(dy, None, None, want_g=False, colsum=colsum)
+        if self.trainable:
+            K.conv2d_bwd_weight(d, x, g, out=self.gw)
+            if self.norm == 'bn':
+                K.bn_param_grads(self.w, self.gw, self.bn['gbeta'], self.bn['mean'], self.bn['rstd'],
+                                 self.scale, out=self.bn['ggamma'])
+        dx = None
+        if need_dx:
+            dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
+                                   addend=addend)
+        return dx, g
+
+
+class BNTable(object):
+    """All BatchNorm vectors of a network, grouped so that scale = gamma*rstd and
+    shift = beta - mean*scale are refreshed for EVERY layer with three
+    elementwise launches per step (gamma/beta are trained, statistics frozen)."""
+
+    def __init__(self):
+        self.layers = []   # (scope, K, trainable)
+
+    def add(self, scope, k, trainable):
+        self.layers.append((scope, k, trainable))
+
+    def register(self, store, ones, zeros):
+        # grouped registration keeps each kind contiguous inside the flat buffers
+        for scope, k, tr in self.layers:
+            store.add('%s/BatchNorm/gamma' % scope, (k,), ones, trainable=tr)
+        for scope, k, tr in self.layers:
+            store.add('%s/BatchNorm/beta' % scope, (k,), zeros, trainable=tr)
+        for scope, k, tr in self.layers:
+            store.add('%s/BatchNorm/moving_mean' % scope, (k,), zeros, trainable=False)
+        for scope, k, tr in self.layers:
+            store.add('%s/BatchNorm/moving_variance' % scope, (k,), ones, trainable=False)
+
+    def bind(self, store):
+        self.store = store
+        dev = store.flat.device
+        self._views = {}
+        self.groups = []
+        for tr in (True, False):
+            ls = [(s, k) for s, k, t in self.layers if t == tr]
+            if not ls:
+                continue
+            total = sum(k for _, k in ls)
+
+            def region(kind):
+                first = '%s/BatchNorm/%s' % (ls[0][0], kind)
+                is_tr, o, _ = store.offsets[first]
+                buf = store.flat if is_tr else store.frozen
+                return buf[o:o + total], (store.grad[o:o + total] if is_tr else None)
+            gamma, ggamma = region('gamma')
+            beta, gbeta = region('beta')
+            mean = torch.cat([store['%s/BatchNorm/moving_mean' % s].reshape(-1) for s, _ in ls])
+            var = torch.cat([store['%s/BatchNorm/moving_variance' % s].reshape(-1) for s, _ in ls])
+            rstd = torch.rsqrt(var + BN_EPS)
+            scale = torch.empty(total, dtype=torch.float32, device=dev)
+            shift = torch.empty(total, dtype=torch.float32, device=dev)
+            grp = dict(gamma=gamma, beta=beta, mean=mean, rstd=rstd, scale=scale, shift=shift,
+                       trainable=tr, tmp=torch.empty_like(scale))
+            self.groups.append(grp)
+            o = 0
+            for s, k in ls:
+                self._views[s] = dict(
+                    scale=scale[o:o + k], shift=shift[o:o + k], mean=mean[o:o + k], rstd=rstd[o:o + k],
+                    ggamma=None if ggamma is None else ggamma[o:o + k],
+                    gbeta=None if gbeta is None else gbeta[o:o + k])
+                o += k
+        self.refresh(force=True)
+
+    def reload_statistics(self):
+        """Call after loading a checkpoint: moving statistics changed."""
+        for grp in self.groups:
+            ls = [(s, k) for s, k, t in self.layers if t == grp['trainable']]
+            var = torch.cat([self.store['%s/BatchNorm/moving_variance' % s].reshape(-1) for s, _ in ls])
+            grp['mean'].copy_(torch.cat([self.store['%s/BatchNorm/moving_mean' % s].reshape(-1) for s, _ in ls]))
+            grp['rstd'].copy_(torch.rsqrt(var + BN_EPS))
+        self.refresh(force=True)
+
+    def refresh(self, force=False):
+        for grp in self.groups:
+            if grp['trainable'] or force:
+                torch.mul(grp['gamma'], grp['rstd'], out=grp['scale'])
+                torch.mul(grp['mean'], grp['scale'], out=grp['tmp'])
+                torch.sub(grp['beta'], grp['tmp'], out=grp['shift'])
+
+    def views(self, scope):
+        return self._views[scope]
+
+
+# ---------------------------------------------------------------- nodes -----
+class ConvNode(object):
+    def __init__(self, layer, in_sub=None):
+        self.layer, self.in_sub = layer, in_sub
+        self.layers = [layer]
+
+    def forward(self, x, save):
+        y = self.layer.forward(x, in_sub=self.in_sub)
+        return y, ((x, y) if save else None)
+
+    def backward(self, saved, dy, need_dx):
+        x, y = saved
+        dx, _ = self.layer.backward(x, y, dy, need_dx=need_dx)
+        return dx
+
+
+class MaxPoolNode(object):
+    layers = []
+
+    def __init__(self, ksize, stride, padding):
+        self.k, self.s, self.p = ksize, stride, padding
+
+    def forward(self, x, save):
+        y, geom = K.maxpool_fwd(x, self.k, self.s, self.p)
+        return y, ((x, y, geom) if save else None)
+
+    def backward(self, saved, dy, need_dx):
+        if not need_dx:
+            return None
+        x, y, geom = saved
+        return K.maxpool_bwd(x, y, dy, self.k, self.s, geom)
+
+
+class BottleneckNode(object):
+    """slim resnet_v1.bottleneck: shortcut (identity | 1x1 max-pool subsample |
+    1x1 conv+BN) + [1x1 -> 3x3 conv2d_same(stride, rate) -> 1x1], relu(sum)."""
+
+    def __init__(self, scope, cin, depth, depth_bottleneck, stride, rate, wd, init):
+        p = scope + '/bottleneck_v1'
+        self.stride = stride
+        self.shortcut = None
+        if depth != cin:
+            self.shortcut = ConvLayer(p + '/shortcut', cin, depth, 1, stride=stride, act=None, wd=wd, init=init)
+        self.conv1 = ConvLayer(p + '/conv1', cin, depth_bottleneck, 1, act='relu', wd=wd, init=init)
+        self.conv2 = ConvLayer(p + '/conv2', depth_bottleneck, depth_bottleneck, 3, stride=stride, rate=rate,
+                               padding='SAME' if stride == 1 else 'SAME_EXPLICIT', act='relu', wd=wd, init=init)
+        self.conv3 = ConvLayer(p + '/conv3', depth_bottleneck, depth, 1, act='relu', wd=wd, init=init)
+        # TF creation order inside a unit: shortcut, conv1, conv2, conv3
+        self.layers = ([self.shortcut] if self.shortcut else []) + [self.conv1, self.conv2, self.conv3]
+
+    def forward(self, x, save):
+        geom = None
+        if self.shortcut is not None:
+            sc = self.shortcut.forward(x)
+        elif self.stride > 1:
+            sc, geom = K.maxpool_fwd(x, 1, self.stride, 'VALID')   # resnet_utils.subsample
+        else:
+            sc = x
+        a = self.conv1.forward(x)
+        b = self.conv2.forward(a)
+        y = self.conv3.forward(b, residual=sc)
+        return y, ((x, sc, a, b, y, geom) if save else None)
+
+    def backward(self, saved, dy, need_dx):
+        x, sc, a, b, y, geom = saved
+        d_b, g = self.conv3.backward(b, y, dy)
+        d_a, _ = self.conv2.backward(a, b, d_b)
+        if self.shortcut is not None:
+            d_sc, _ = self.shortcut.backward(x, sc, g, need_dx=need_dx)
+        elif self.stride > 1:
+            d_sc = K.maxpool_bwd(x, sc, g, 1, self.stride, geom) if need_dx else None
+        else:
+            d_sc = g
+        dx, _ = self.conv1.backward(x, a, d_a, need_dx=need_dx, addend=d_sc)
+        return dx
+
+
+class Trunk(object):
+    """Ordered nodes; nodes before `first_trainable` run forward-only."""
+
+    def __init__(self, nodes):
+        self.nodes = nodes
+
+    def all_layers(self):
+        return [l for n in self.nodes for l in n.layers]
+
+    def first_trainable(self):
+        for i, n in enumerate(self.nodes):
+            if any(l.trainable for l in n.layers):
+                return i
+        return len(self.nodes)
+
+    def forward(self, x, save_from=None):
+        saved = []
+        for i, n in enumerate(self.nodes):
+            save = save_from is not None and i >= save_from
+            x, s = n.forward(x, save)
+            if save:
+                saved.append(s)
+        return x, saved
+
+    def backward(self, saved, dy, save_from, need_dx_first=False):
+        nodes = self.nodes[save_from:]
+        for j in range(len(nodes) - 1, -1, -1):
+            need_dx = (j > 0) or need_dx_first
+            dy = nodes[j].backward(saved[j], dy, need_dx)
+        return dy

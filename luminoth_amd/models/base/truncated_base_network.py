@@ -1,0 +1,161 @@
+"""TruncatedBaseNetwork — feature extractor truncated at an endpoint, with the
+ResNet-101 `block4` tail for pooled ROIs.  Mirrors the public surface of
+luminoth/models/base/truncated_base_network.py:19-169:
+`__call__(inputs, is_training)`, `_build_tail(inputs, is_training)`,
+`get_trainable_vars()`; default endpoints from :8-16.
+"""
+import torch
+
+from luminoth_amd.models.base import layers as L
+from luminoth_amd.models.base import networks
+from luminoth_amd.models.base.base_network import BaseNetwork, he_normal, ones, zeros
+
+DEFAULT_ENDPOINTS = {
+    'resnet_v1_50': 'block3', 'resnet_v1_101': 'block3', 'resnet_v1_152': 'block3',
+    'resnet_v2_50': 'block3', 'resnet_v2_101': 'block3', 'resnet_v2_152': 'block3',
+    'vgg_16': 'conv5/conv5_3',
+}
+
+
+class _TrunkFn(torch.autograd.Function):
+    """Autograd boundary around the trainable part of a Trunk.  Parameter
+    gradients are written straight into the flat gradient buffer by the node
+    backward passes; autograd only routes the activation gradient."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, trunk, start, need_dx):
+        y, saved = trunk.forward(x, save_from=0)
+        ctx.trunk, ctx.saved, ctx.need_dx = trunk, saved, need_dx
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = ctx.trunk.backward(ctx.saved, dy.contiguous(), 0, need_dx_first=ctx.need_dx)
+        ctx.saved = None
+        return dx, None, None, None, None
+
+
+class TruncatedBaseNetwork(BaseNetwork):
+    def __init__(self, config, name='truncated_base_network', build_unused_tail_vars=True):
+        super(TruncatedBaseNetwork, self).__init__(config, name=name)
+        self._endpoint = config.get('endpoint') or DEFAULT_ENDPOINTS[config.get('architecture')]
+        self._freeze_tail = config.get('freeze_tail')
+        self._use_tail = config.get('use_tail')
+        wd = self._weight_decay()
+        arch = self._architecture
+        in_sub = self._in_sub()
+        self._in_sub_vals = in_sub
+        if self.resnet_v1_type:
+            # slim builds the whole net (block4 included) even though only the
+            # endpoint is used: its variables exist and are regularised.
+            nodes, endpoints = networks.resnet_v1_nodes(arch, name, wd, he_normal,
+                                                        output_stride=config.get('output_stride'))
+            if self._endpoint not in endpoints:
+                raise ValueError('"{}" is an invalid value of endpoint for this architecture.'.format(
+                    '%s/%s/%s' % (name, arch, self._endpoint)))
+            cut = endpoints[self._endpoint] + 1
+            self._all_nodes = nodes
+            self.trunk = L.Trunk(nodes[:cut])
+            self._unused_nodes = nodes[cut:]
+            self.tail = None
+            if arch == 'resnet_v1_101':
+                # same variables as the (unused) trunk block4, applied at stride 1 / rate 1
+                self.tail = L.Trunk(networks.resnet_v1_tail_nodes(arch, name, wd, he_normal))
+            self.feat_channels = self.trunk.nodes[-1].conv3.cout
+            self.tail_channels = 2048 if (self.tail is not None and self._use_tail) else self.feat_channels
+        elif self.vgg_type or self.truncated_vgg_type:
+            nodes, endpoints = networks.vgg16_nodes(name, arch, wd, he_normal, zeros, in_sub=None)
+            if self._endpoint not in endpoints:
+                raise ValueError('"{}" is an invalid value of endpoint for this architecture.'.format(
+                    '%s/%s/%s' % (name, arch, self._endpoint)))
+            cut = endpoints[self._endpoint] + 1
+            self._all_nodes = nodes[:cut]        # fc layers are not instantiated (unused, un-regularised here)
+            self.trunk = L.Trunk(nodes[:cut])
+            self._unused_nodes = []
+            self.tail = None
+            self.feat_channels = self.trunk.nodes[-1].layer.cout
+            self.tail_channels = self.feat_channels
+        self.bn_table = L.BNTable()
+        self._in_sub = None
+
+    # ---- variables --------------------------------------------------------------
+    def _creation_order_layers(self):
+        return [l for n in self._all_nodes for l in n.layers]
+
+    def get_trainable_var_names(self):
+        """truncated_base_network.py:97-144: fine-tune range cut at the last
+        variable containing the endpoint, plus block4 for the R101 tail."""
+        all_tr = super(TruncatedBaseNetwork, self).get_trainable_var_names()
+        idx = None
+        for i, n in enumerate(all_tr):
+            if self._endpoint in n:
+                idx = i
+        names = [] if idx is None else all_tr[:idx + 1]
+        if self._use_tail and not self._freeze_tail and self._architecture == 'resnet_v1_101':
+            for i, n in enumerate(all_tr):
+                if 'block4' in n:
+                    names += all_tr[i:]
+                    break
+            else:
+                raise ValueError('"block4" not present in the trainable vars retrieved from base network.')
+        return names
+
+    def register(self, store, base_trainable=True):
+        """Declare every variable; decides trainability like the reference."""
+        tr = set(self.get_trainable_var_names()) if base_trainable else set()
+        self._trainable_names = tr
+        tail_layers = {l.scope: l for l in (self.tail.all_layers() if self.tail else [])}
+        for layer in self._creation_order_layers():
+            layer.trainable = layer.w_name in tr
+            store.add(layer.w_name, (layer.k, layer.k, layer.cin, layer.cout), layer.init or he_normal,
+                      trainable=layer.trainable, wd=layer.wd)
+            if layer.norm == 'bn':
+                self.bn_table.add(layer.scope, layer.cout, ('%s/BatchNorm/gamma' % layer.scope) in tr)
+            elif layer.norm == 'bias':
+                store.add(layer.b_name, (layer.cout,), zeros, trainable=layer.b_name in tr)
+            if layer.scope in tail_layers:
+                tail_layers[layer.scope].trainable = layer.trainable
+        self.bn_table.register(store, ones, zeros)
+
+    def bind(self, store):
+        self.store = store
+        self.bn_table.bind(store)
+        for layer in self._creation_order_layers():
+            layer.bind(store, self.bn_table)
+        if self.tail is not None:
+            for layer in self.tail.all_layers():
+                layer.bind(store, self.bn_table)
+        if self._in_sub_vals is not None:
+            self._in_sub = torch.tensor(self._in_sub_vals, dtype=torch.float32, device=store.flat.device)
+            first = self.trunk.nodes[0]
+            if hasattr(first, 'in_sub'):
+                first.in_sub = self._in_sub
+        self._anchor = torch.zeros(1, device=store.flat.device, requires_grad=True)
+
+    # ---- forward ------------------------------------------------------------------
+    def _run(self, trunk, x, is_training):
+        if is_training and self._config.get('train_batch_norm'):
+            raise NotImplementedError('train_batch_norm: True (BatchNorm in training mode) is not implemented; '
+                                      'the reference default is False (base_config.yml:147)')
+        start = trunk.first_trainable()
+        needs_grad = torch.is_grad_enabled() and (start < len(trunk.nodes) or x.requires_grad)
+        if not needs_grad:
+            y, _ = trunk.forward(x, save_from=None)
+            return y
+        if not x.requires_grad:
+            # frozen prefix: forward only, nothing saved
+            pre = L.Trunk(trunk.nodes[:start])
+            x, _ = pre.forward(x, save_from=None)
+            sub = L.Trunk(trunk.nodes[start:])
+            return _TrunkFn.apply(x, self._anchor, sub, 0, False)
+        return _TrunkFn.apply(x, self._anchor, trunk, 0, True)
+
+    def __call__(self, inputs, is_training=False):
+        """inputs (B,H,W,3) fp32 RGB 0..255 -> feature map (B,fh,fw,C)."""
+        self.bn_table.refresh()
+        return self._run(self.trunk, inputs.contiguous(), is_training)
+
+    def _build_tail(self, inputs, is_training=False):
+        if not self._use_tail or self.tail is None:
+            return inputs
+        return self._run(self.tail, inputs, is_training)

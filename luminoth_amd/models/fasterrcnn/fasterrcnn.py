@@ -1,0 +1,235 @@
+"""FasterRCNN — the drop-in model module of the hot path.
+
+Same protocol as the reference Sonnet module (luminoth/models/fasterrcnn/
+fasterrcnn.py:12-364):
+
+    model = get_model('fasterrcnn')(config)
+    prediction_dict = model(image, gt_boxes=None, is_training=False)
+    total_loss = model.loss(prediction_dict)            # or return_all=True
+    model.get_trainable_vars(); model.get_base_network_checkpoint_vars(); model.summary
+
+with the same `prediction_dict` keys.  Differences, all
+extensions: `image` may be a batch `(B,H,W,3)` (the reference is batch-1:
+fasterrcnn.py:101-103) with `gt_boxes` a list / padded `(B,G,5)` tensor, tensors
+are torch ROCm tensors, and ragged results are fixed-capacity buffers plus
+per-image counts (`num_proposals`, `num_objects`) so that the train step never
+synchronises with the host.  For un-batched inference calls the results are
+truncated to the reference's exact shapes.
+"""
+import numpy as np
+import torch
+
+from luminoth_amd import _lib
+from luminoth_amd import kernels as K
+from luminoth_amd.models.base.truncated_base_network import TruncatedBaseNetwork
+from luminoth_amd.models.fasterrcnn.rcnn import RCNN
+from luminoth_amd.models.fasterrcnn.rpn import RPN
+from luminoth_amd.params import ParamStore
+from luminoth_amd.utils import rng
+from luminoth_amd.utils.anchors import generate_anchors_reference, truncate_reference, all_anchors_numpy
+
+
+class FasterRCNN(object):
+    def __init__(self, config, name='fasterrcnn', device=None):
+        self._config = config
+        self._name = name
+        self._num_classes = config.model.network.num_classes
+        self._with_rcnn = config.model.network.with_rcnn
+        self._debug = config.train.debug
+        self._seed = config.train.seed
+        self._anchor_base_size = config.model.anchors.base_size
+        self._anchor_scales = np.array(config.model.anchors.scales)
+        self._anchor_ratios = np.array(config.model.anchors.ratios)
+        self._anchor_stride = config.model.anchors.stride
+        self._anchor_reference = generate_anchors_reference(
+            self._anchor_base_size, self._anchor_ratios, self._anchor_scales)
+        self._num_anchors = self._anchor_reference.shape[0]
+        self._rpn_cls_loss_weight = config.model.loss.rpn_cls_loss_weight
+        self._rpn_reg_loss_weight = config.model.loss.rpn_reg_loss_weights
+        self._rcnn_cls_loss_weight = config.model.loss.rcnn_cls_loss_weight
+        self._rcnn_reg_loss_weight = config.model.loss.rcnn_reg_loss_weights
+        self._losses_collections = ['fastercnn_losses']
+
+        if device is None:
+            if not torch.cuda.is_available():
+                raise _lib.LuminothHipError('FasterRCNN needs a ROCm device (no CPU fallback on the product path)')
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(device)
+        _lib.load()   # fail loudly, now, if the HIP library is missing
+
+        self.base_network = TruncatedBaseNetwork(config.model.base_network)
+        self._rpn = RPN(self._num_anchors, config.model.rpn, self.base_network.feat_channels,
+                        debug=self._debug, seed=self._seed, scope=name)
+        self._rcnn = None
+        if self._with_rcnn:
+            self._rcnn = RCNN(self._num_classes, config.model.rcnn, self.base_network.tail_channels,
+                              debug=self._debug, seed=self._seed, scope=name)
+        self.store = ParamStore()
+        self.base_network.register(self.store, base_trainable=bool(config.model.base_network.trainable))
+        self._rpn.register(self.store)
+        if self._rcnn is not None:
+            self._rcnn.register(self.store)
+        self.store.build(self.device, seed=self._seed)
+        self.base_network.bind(self.store)
+        self._rpn.bind(self.store)
+        if self._rcnn is not None:
+            self._rcnn.bind(self.store)
+        self._anchor_ref_i32 = torch.tensor(truncate_reference(self._anchor_reference), dtype=torch.int32,
+                                            device=self.device)
+        self._step = 0
+        self._frozen_reg = None
+
+    # ------------------------------------------------------------------ inputs --
+    def _pack_gt(self, gt_boxes, B):
+        """-> (gt (B,Gmax,5) fp32 device, gt_count (B) int32 device)."""
+        if gt_boxes is None:
+            return None, None
+        if isinstance(gt_boxes, (tuple, list)) and len(gt_boxes) == 2 and torch.is_tensor(gt_boxes[0]) \
+                and gt_boxes[0].dim() == 3:
+            return gt_boxes[0].to(self.device, torch.float32).contiguous(), \
+                gt_boxes[1].to(self.device, torch.int32).contiguous()
+        if torch.is_tensor(gt_boxes) and gt_boxes.dim() == 3:
+            cnt = torch.full((B,), gt_boxes.shape[1], dtype=torch.int32, device=self.device)
+            return gt_boxes.to(self.device, torch.float32).contiguous(), cnt
+        if torch.is_tensor(gt_boxes) or isinstance(gt_boxes, np.ndarray):
+            gt_boxes = [gt_boxes]
+        gts = [torch.as_tensor(g, dtype=torch.float32).reshape(-1, 5) for g in gt_boxes]
+        gmax = max(1, max(g.shape[0] for g in gts))
+        packed = torch.zeros((B, gmax, 5), dtype=torch.float32)
+        for b, g in enumerate(gts):
+            packed[b, :g.shape[0]] = g
+        cnt = torch.tensor([g.shape[0] for g in gts], dtype=torch.int32)
+        return packed.to(self.device), cnt.to(self.device)
+
+    # ----------------------------------------------------------------- forward --
+    def __call__(self, image, gt_boxes=None, is_training=False):
+        """image (H,W,3) or (B,H,W,3) fp32 RGB in [0,255]; gt_boxes (G,5) / list / (B,G,5)."""
+        image = torch.as_tensor(image)
+        unbatched = image.dim() == 3
+        if unbatched:
+            image = image.unsqueeze(0)
+        image = image.to(self.device, torch.float32).contiguous()
+        B, H, W, _ = image.shape
+        gt, gt_count = self._pack_gt(gt_boxes, B)
+        seeds = None
+        if gt is not None:
+            seeds = torch.from_numpy(np.array(
+                [rng.image_seed(self._seed, self._step, b) for b in range(B)],
+                dtype=np.uint32).view(np.int32)).to(self.device)
+            if is_training:
+                self._step += 1
+        with torch.set_grad_enabled(bool(is_training)):
+            conv_feature_map = self.base_network(image, is_training=is_training)
+            im_shape = (H, W)
+            rpn_prediction = self._rpn(conv_feature_map, im_shape, self._anchor_ref_i32, self._anchor_stride,
+                                       gt_boxes=gt, gt_count=gt_count, seeds=seeds, is_training=is_training)
+            prediction_dict = {'rpn_prediction': rpn_prediction}
+            if self._debug:
+                prediction_dict['image'] = image
+                prediction_dict['image_shape'] = im_shape
+                prediction_dict['all_anchors'] = torch.from_numpy(all_anchors_numpy(
+                    self._anchor_reference, conv_feature_map.shape[1], conv_feature_map.shape[2],
+                    self._anchor_stride))
+                prediction_dict['anchor_reference'] = torch.from_numpy(self._anchor_reference)
+                if gt is not None:
+                    prediction_dict['gt_boxes'] = gt
+                prediction_dict['conv_feature_map'] = conv_feature_map
+            if self._with_rcnn:
+                proposals = rpn_prediction['proposals'].detach()        # stop_gradient, fasterrcnn.py:147
+                prediction_dict['classification_prediction'] = self._rcnn(
+                    conv_feature_map, proposals, rpn_prediction['num_proposals'], im_shape, self.base_network,
+                    gt_boxes=gt, gt_count=gt_count, seeds=seeds, is_training=is_training)
+        prediction_dict['_batch'] = {'B': B, 'unbatched': unbatched}
+        if unbatched and not is_training:
+            self._truncate_unbatched(prediction_dict)
+        return prediction_dict
+
+    def _truncate_unbatched(self, pd):
+        """Reference shapes for a single image: drop the batch dim and the padding (host sync)."""
+        rp = pd['rpn_prediction']
+        n = int(rp['num_proposals'][0])
+        rp['proposals'], rp['scores'] = rp['proposals'][0, :n], rp['scores'][0, :n]
+        for k in ('rpn_cls_prob', 'rpn_cls_score', 'rpn_bbox_pred', 'rpn_cls_target', 'rpn_bbox_target'):
+            if k in rp:
+                rp[k] = rp[k][0]
+        cp = pd.get('classification_prediction')
+        if cp is not None:
+            m = int(cp['num_proposals'][0])
+            for k in ('cls_score', 'cls_prob', 'bbox_offsets'):
+                cp['rcnn'][k] = cp['rcnn'][k][0, :m]
+            if 'objects' in cp:
+                d = int(cp['num_objects'][0])
+                cp['objects'], cp['labels'], cp['probs'] = cp['objects'][0, :d], cp['labels'][0, :d], cp['probs'][0, :d]
+            if 'target' in cp:
+                cp['target'] = {k: v[0, :m] for k, v in cp['target'].items()}
+
+    # -------------------------------------------------------------------- loss --
+    def regularization_loss(self):
+        """tf.losses.get_regularization_loss(): sum_w scale * sum(w^2)/2 over every
+        regularised weight, frozen ones included (fasterrcnn.py:223)."""
+        if self._frozen_reg is None:
+            st = self.store
+            self._frozen_reg = K.l2_reg_loss(st.frozen, st.frozen_seg_offset, st.frozen_seg_wd)
+        st = self.store
+        return (K.l2_reg_loss(st.flat, st.seg_offset, st.seg_wd) + self._frozen_reg)[0]
+
+    def loss(self, prediction_dict, return_all=False):
+        """fasterrcnn.py:158-259.  Mutates prediction_dict (adds rpn_loss_dict / rcnn_loss_dict)."""
+        rpn_loss_dict = self._rpn.loss(prediction_dict['rpn_prediction'], self._rpn_cls_loss_weight,
+                                       self._rpn_reg_loss_weight)
+        prediction_dict['rpn_loss_dict'] = rpn_loss_dict
+        rcnn_loss_dict = {}
+        if self._with_rcnn:
+            rcnn_loss_dict = self._rcnn.loss(prediction_dict['classification_prediction'],
+                                             self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
+            prediction_dict['rcnn_loss_dict'] = rcnn_loss_dict
+        items = list(rpn_loss_dict.items()) + list(rcnn_loss_dict.items())
+        no_reg_loss = items[0][1]
+        for _, t in items[1:]:
+            no_reg_loss = no_reg_loss + t
+        regularization_loss = self.regularization_loss()
+        total_loss = no_reg_loss + regularization_loss
+        self._last_losses = dict(items, total_loss=total_loss, no_reg_loss=no_reg_loss,
+                                 regularization_loss=regularization_loss)
+        if return_all:
+            out = {'total_loss': total_loss, 'no_reg_loss': no_reg_loss,
+                   'regularization_loss': regularization_loss}
+            out.update(items)
+            return out
+        return total_loss
+
+    def backward(self, total_loss):
+        """Gradients of the data loss flow through the HIP backward kernels into the flat
+        gradient buffer; the L2 term's gradient (wd*w) is folded into the optimizer kernel."""
+        self.store.grad.zero_()
+        total_loss.backward()
+
+    # --------------------------------------------------------------- variables --
+    @property
+    def summary(self):
+        """Scalar summaries (the reference merges TensorBoard summaries here: fasterrcnn.py:310-327)."""
+        return {k: float(v) for k, v in getattr(self, '_last_losses', {}).items()}
+
+    @property
+    def vars_summary(self):
+        return {}
+
+    def get_trainable_vars(self):
+        """Module variables + the fine-tuned base-network variables (fasterrcnn.py:337-358):
+        OrderedDict name -> tensor view (with `.grad` views in `self.store.grads`)."""
+        st = self.store
+        return {n: st.params[n] for n in st.trainable_names()}
+
+    def get_base_network_checkpoint_vars(self):
+        return self.base_network.get_base_network_checkpoint_vars(self.store)
+
+    def get_checkpoint_file(self):
+        return self.base_network.get_checkpoint_file()
+
+    def state_dict(self):
+        return self.store.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.store.load_state_dict(sd, strict=strict)
+        self.base_network.bn_table.reload_statistics()
+        self._frozen_reg = None

@@ -1,0 +1,81 @@
+"""RPN — Region Proposal Network head (reference:
+luminoth/models/fasterrcnn/rpn.py:19-309): 3x3 conv + activation, 1x1 cls /
+bbox convs (Sonnet Conv2D: SAME / VALID, bias), proposals, anchor targets and
+the RPN loss.  Variable names follow Sonnet: `<scope>/rpn/{conv,cls_conv,bbox_conv}/{w,b}`."""
+import torch
+
+from luminoth_amd import autograd as A
+from luminoth_amd.models.base.layers import ConvLayer
+from luminoth_amd.models.fasterrcnn.rpn_proposal import RPNProposal
+from luminoth_amd.models.fasterrcnn.rpn_target import RPNTarget
+from luminoth_amd.utils.vars import get_activation_function, get_initializer
+
+
+class RPN(object):
+    def __init__(self, num_anchors, config, in_channels, debug=False, seed=None, name='rpn', scope='fasterrcnn'):
+        self._num_anchors = num_anchors
+        self._num_channels = config.num_channels
+        self._kernel_shape = config.kernel_shape
+        self._debug, self._seed, self._config = debug, seed, config
+        self._l1_sigma = config.l1_sigma
+        act = get_activation_function(config.activation_function)
+        wd = float(config.l2_regularization_scale or 0.0)
+        p = '%s/%s' % (scope, name)
+        k = self._kernel_shape[0]
+        self._rpn = ConvLayer(p + '/conv', in_channels, self._num_channels, k, act=act, norm='bias', wd=wd,
+                              init=get_initializer(config.rpn_initializer, seed), weight_name='w', bias_name='b')
+        self._rpn_cls = ConvLayer(p + '/cls_conv', self._num_channels, num_anchors * 2, 1, padding='VALID',
+                                  act=None, norm='bias', wd=wd,
+                                  init=get_initializer(config.cls_initializer, seed), weight_name='w', bias_name='b')
+        self._rpn_bbox = ConvLayer(p + '/bbox_conv', self._num_channels, num_anchors * 4, 1, padding='VALID',
+                                   act=None, norm='bias', wd=wd,
+                                   init=get_initializer(config.bbox_initializer, seed), weight_name='w', bias_name='b')
+        self.layers = [self._rpn, self._rpn_cls, self._rpn_bbox]
+        self._proposal = RPNProposal(num_anchors, config.proposals, debug=debug)
+        self._anchor_target = RPNTarget(num_anchors, config.target, seed=seed)
+
+    def register(self, store):
+        zeros = lambda shape, gen: torch.zeros(shape)
+        for l in self.layers:
+            store.add(l.w_name, (l.k, l.k, l.cin, l.cout), l.init, trainable=True, wd=l.wd)
+            store.add(l.b_name, (l.cout,), zeros, trainable=True)
+
+    def bind(self, store):
+        for l in self.layers:
+            l.bind(store, None)
+        self._anchor = torch.zeros(1, device=store.flat.device, requires_grad=True)
+
+    def __call__(self, conv_feature_map, im_shape, anchor_ref_i32, stride, gt_boxes=None, gt_count=None,
+                 seeds=None, is_training=False):
+        B, fh, fw, _ = conv_feature_map.shape
+        rpn_feature = A.conv(self._rpn, conv_feature_map, self._anchor)
+        cls_orig = A.conv(self._rpn_cls, rpn_feature, self._anchor)      # (B,fh,fw,2A)
+        bbox_orig = A.conv(self._rpn_bbox, rpn_feature, self._anchor)    # (B,fh,fw,4A)
+        rpn_cls_score = cls_orig.reshape(B, -1, 2)                       # rpn.py:160
+        rpn_bbox_pred = bbox_orig.reshape(B, -1, 4)                      # rpn.py:169
+        pred = {'rpn_cls_score': rpn_cls_score, 'rpn_bbox_pred': rpn_bbox_pred}
+        prop = self._proposal(rpn_cls_score.detach(), rpn_bbox_pred.detach(), anchor_ref_i32, (fh, fw), stride,
+                              im_shape)
+        pred['rpn_cls_prob'] = prop['rpn_cls_prob']
+        pred['proposals'] = prop['proposals']
+        pred['scores'] = prop['scores']
+        pred['num_proposals'] = prop['num_proposals']
+        if self._debug:
+            pred['proposal_prediction'] = prop
+            pred['rpn_feature'] = rpn_feature
+        if gt_boxes is not None:
+            labels, targets, max_ov = self._anchor_target(anchor_ref_i32, (fh, fw), stride, gt_boxes, gt_count,
+                                                          seeds, im_shape)
+            pred['rpn_cls_target'] = labels
+            pred['rpn_bbox_target'] = targets
+            if self._debug:
+                pred['rpn_max_overlap'] = max_ov
+        return pred
+
+    def loss(self, prediction_dict, w_cls=1.0, w_reg=1.0):
+        """rpn.py:219-309.  Returns {'rpn_cls_loss','rpn_reg_loss'} already multiplied by
+        the loss weights (fasterrcnn.py:183-186), batch mean over images."""
+        losses = A.RpnLossFn.apply(prediction_dict['rpn_cls_score'], prediction_dict['rpn_bbox_pred'],
+                                   prediction_dict['rpn_cls_target'], prediction_dict['rpn_bbox_target'],
+                                   float(self._l1_sigma), float(w_cls), float(w_reg))
+        return {'rpn_cls_loss': losses[0], 'rpn_reg_loss': losses[1]}

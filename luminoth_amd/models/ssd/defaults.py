@@ -1,0 +1,37 @@
+"""Default configuration of the SSD model: schema and values of the reference's
+luminoth/models/ssd/base_config.yml (line numbers cited per group)."""
+
+DEFAULTS = {
+    'train': {                                           # ssd/base_config.yml:1-66
+        'debug': True, 'seed': None, 'batch_size': 1, 'job_dir': 'jobs/', 'ignore_scope': None,
+        'tf_debug': False, 'run_name': None, 'no_log': False, 'display_every_steps': None,
+        'display_every_secs': 300, 'random_shuffle': True, 'save_timeline': False,
+        'save_checkpoint_secs': 600, 'checkpoints_max_keep': 1, 'save_summaries_steps': None,
+        'save_summaries_secs': 30, 'full_trace': False, 'clip_by_norm': False,
+        'learning_rate': {'_replace': True, 'decay_method': None, 'learning_rate': 0.0003},
+        'optimizer': {'_replace': True, 'type': 'momentum', 'momentum': 0.5},
+        'num_epochs': 1000, 'image_vis': 'train', 'var_vis': None,
+    },
+    'eval': {'image_vis': 'eval'},
+    'dataset': {                                         # :68-102
+        'type': 'object_detection', 'dir': 'datasets/voc/tf', 'split': 'train',
+        'image_preprocessing': {'fixed_height': 300, 'fixed_width': 300},
+        'data_augmentation': [],
+    },
+    'model': {
+        'type': 'ssd',
+        'network': {'num_classes': 20},                  # :108
+        'base_network': {'architecture': 'truncated_vgg_16', 'trainable': True, 'weights': None,
+                         'download': True, 'endpoints': ['conv4/conv4_3', 'conv5/conv5_3'],
+                         'hook_endpoint': 'conv4/conv4_3', 'fine_tune_from': None,
+                         'arg_scope': {'weight_decay': 0.0005}},
+        'loss': {'localization_loss_weight': 1.0},       # :126
+        'anchors': {'anchors_per_point': [4, 6, 6, 6, 4, 4], 'ratios': [1, 0.5, 2, 0.333, 3],
+                    'min_scale': 0.1, 'max_scale': 0.88},      # :128-138 (linspace .10-.88)
+        'target': {'hard_negative_ratio': 3.0, 'foreground_threshold': 0.5,
+                   'background_threshold_high': 0.2, 'background_threshold_low': 0.0},
+        'proposals': {'total_max_detections': 100, 'class_max_detections': 100,
+                      'class_nms_threshold': 0.45, 'min_prob_threshold': 0.5, 'filter_outside_anchors': False},
+        'target_normalization_variances': [0.1, 0.2],    # :166
+    },
+}

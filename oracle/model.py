@@ -1,0 +1,207 @@
+"""Oracle (test infrastructure): the Faster R-CNN train step restated end to end
+on the CPU — torch fp32 for the dense differentiable parts (backbone, heads,
+ROI pooling, losses; `torch.autograd` supplies the reference gradients), numpy
+(oracle/frcnn.py) for proposals and targets.  One image at a time, exactly like
+the reference (batch 1: luminoth/models/fasterrcnn/fasterrcnn.py:101-103);
+the batch loss is the mean over images.
+
+Variables come in as a {tf_name: tensor} dict (same names as the reference's
+checkpoints).  PARITY UNPINNED: the slim ResNet arithmetic is third-party
+(tf.contrib.slim, not in /root/reference); structure per SURVEY.md §8a-A2.
+Citations relative to /root/reference/luminoth/.
+"""
+import numpy as np
+import torch
+
+from . import boxes as bx
+from . import frcnn as of
+from . import rng
+from . import torch_ops as ot
+
+RESNET_UNITS = {'resnet_v1_50': (3, 4, 6, 3), 'resnet_v1_101': (3, 4, 23, 3), 'resnet_v1_152': (3, 8, 36, 3)}
+MEANS = torch.tensor([123.68, 116.78, 103.94])   # models/base/base_network.py:14-16
+
+
+def _act(x, name):
+    if name == 'relu':
+        return torch.relu(x)
+    if name == 'relu6':
+        return torch.clamp(x, 0, 6)
+    return x
+
+
+class OracleFasterRCNN(object):
+    def __init__(self, variables, arch='resnet_v1_50', num_classes=80, scope='fasterrcnn',
+                 base_scope='truncated_base_network', anchors=None, rpn=None, rcnn=None, weight_decay=5e-4,
+                 l2_rpn=5e-4, l2_rcnn=5e-4, fine_tune_from='block2', seed=None):
+        self.v = {k: torch.as_tensor(v).clone().float() for k, v in variables.items()}
+        self.arch, self.C, self.scope, self.base = arch, num_classes, scope, '%s/%s' % (base_scope, arch)
+        a = anchors or {}
+        self.anchor_ref = bx.generate_anchors_reference(a.get('base_size', 256), np.array(a.get('ratios', [.5, 1, 2])),
+                                                        np.array(a.get('scales', [.25, .5, 1, 2])))
+        self.stride = a.get('stride', 16)
+        self.rpn_cfg = dict(pre_nms_top_n=12000, post_nms_top_n=2000, nms_threshold=0.7)
+        self.rpn_cfg.update(rpn or {})
+        self.rcnn_cfg = dict(minibatch_size=256)
+        self.rcnn_cfg.update(rcnn or {})
+        self.wd, self.l2_rpn, self.l2_rcnn = weight_decay, l2_rpn, l2_rcnn
+        self.fine_tune_from, self.seed = fine_tune_from, seed
+        self.step = 0
+
+    # ---- backbone: slim resnet_v1 up to block3, output_stride 16 ----------------
+    def _conv_bn(self, x, scope, stride=1, rate=1, padding='SAME', act='relu'):
+        v = self.v
+        y = ot.conv2d_nhwc(x, v[scope + '/weights'], stride, rate, padding)
+        y = ot.frozen_batch_norm(y, v[scope + '/BatchNorm/gamma'], v[scope + '/BatchNorm/beta'],
+                                 v[scope + '/BatchNorm/moving_mean'], v[scope + '/BatchNorm/moving_variance'])
+        return _act(y, act)
+
+    def _bottleneck(self, x, scope, depth, stride, rate):
+        p = scope + '/bottleneck_v1'
+        if x.shape[-1] == depth:
+            sc = x if stride == 1 else x[:, ::stride, ::stride, :]      # resnet_utils.subsample
+        else:
+            sc = self._conv_bn(x, p + '/shortcut', stride=stride, act=None)
+        r = self._conv_bn(x, p + '/conv1')
+        r = self._conv_bn(r, p + '/conv2', stride=stride, rate=rate,
+                          padding='SAME' if stride == 1 else 'SAME_EXPLICIT')
+        r = self._conv_bn(r, p + '/conv3', act=None)
+        return torch.relu(sc + r)
+
+    def backbone(self, image, upto=3, output_stride=16):
+        x = image - MEANS
+        x = self._conv_bn(x, self.base + '/conv1', stride=2, padding='SAME_EXPLICIT')
+        x = ot.max_pool_nhwc(x, 3, 2, 'SAME')
+        current, rate = 4, 1
+        for bi, (depth, n) in enumerate(zip((256, 512, 1024, 2048), RESNET_UNITS[self.arch])):
+            if bi + 1 > upto:
+                break
+            for u in range(n):
+                ustride = (2 if bi < 3 else 1) if u == n - 1 else 1
+                if current == output_stride:
+                    s, r = 1, rate
+                    rate *= ustride
+                else:
+                    s, r = ustride, 1
+                    current *= ustride
+                x = self._bottleneck(x, '%s/block%d/unit_%d' % (self.base, bi + 1, u + 1), depth, s, r)
+        return x
+
+    def tail(self, pooled):
+        """truncated_base_network.py:56-95: block4 on pooled ROIs, ResNet-101 only."""
+        if self.arch != 'resnet_v1_101':
+            return pooled
+        x = pooled
+        for u in range(3):
+            x = self._bottleneck(x, '%s/block4/unit_%d' % (self.base, u + 1), 2048, 1, 1)
+        return x
+
+    # ---- heads --------------------------------------------------------------------
+    def rpn_head(self, feat):
+        v, p = self.v, self.scope + '/rpn'
+        f = _act(ot.conv2d_nhwc(feat, v[p + '/conv/w'], padding='SAME', bias=v[p + '/conv/b']), 'relu6')
+        cls = ot.conv2d_nhwc(f, v[p + '/cls_conv/w'], padding='VALID', bias=v[p + '/cls_conv/b'])
+        box = ot.conv2d_nhwc(f, v[p + '/bbox_conv/w'], padding='VALID', bias=v[p + '/bbox_conv/b'])
+        return cls.reshape(-1, 2), box.reshape(-1, 4)
+
+    def rcnn_head(self, feat, rois, im_shape):
+        v, p = self.v, self.scope + '/rcnn'
+        pooled = ot.roi_pool(feat, rois, torch.zeros(rois.shape[0], dtype=torch.long), im_shape)
+        net = self.tail(pooled).mean(dim=(1, 2))
+        cls = net @ v[p + '/fc_classifier/w'] + v[p + '/fc_classifier/b']
+        box = net @ v[p + '/fc_bbox/w'] + v[p + '/fc_bbox/b']
+        return cls, box, pooled
+
+    # ---- regularisation -------------------------------------------------------------
+    def regularization_loss(self):
+        tot = 0.0
+        for k, t in self.v.items():
+            if k.endswith('/weights'):
+                tot = tot + self.wd * (t.double() ** 2).sum() / 2
+            elif k.endswith('/w'):
+                wd = self.l2_rpn if '/rpn/' in k else self.l2_rcnn
+                tot = tot + wd * (t.double() ** 2).sum() / 2
+        return tot
+
+    # ---- one image ------------------------------------------------------------------
+    def forward_image(self, image, gt, seed, overrides=None):
+        """image (H,W,3) tensor, gt (G,5) numpy.  Returns dict of stage outputs and the
+        four losses (torch scalars with graph).  `overrides` may pin 'proposals' / 'rois' etc.
+        to values produced elsewhere (identical-input comparisons)."""
+        ov = overrides or {}
+        H, W = image.shape[0], image.shape[1]
+        feat = self.backbone(image[None])
+        fh, fw = feat.shape[1], feat.shape[2]
+        cls_score, bbox_pred = self.rpn_head(feat)
+        anchors = bx.generate_anchors(self.anchor_ref, fh, fw, self.stride)
+        out = dict(feat=feat, rpn_cls_score=cls_score, rpn_bbox_pred=bbox_pred)
+        labels, targets, _ = of.rpn_target(anchors, gt, (H, W), seed=seed)
+        out['rpn_labels'], out['rpn_targets'] = labels, targets
+        l_cls, l_reg = ot.rpn_loss(cls_score, bbox_pred, torch.tensor(labels), torch.tensor(targets), 3.0)
+        out['rpn_cls_loss'], out['rpn_reg_loss'] = l_cls, l_reg
+        if 'rois' in ov:
+            rois, roi_labels, roi_targets = ov['rois'], ov['roi_labels'], ov['roi_targets']
+        else:
+            if 'proposals' in ov:
+                proposals = ov['proposals']
+            else:
+                prob = torch.softmax(cls_score.detach(), dim=1).numpy()
+                proposals = of.rpn_proposal(prob, bbox_pred.detach().numpy(), anchors, (H, W),
+                                            **self.rpn_cfg)['proposals']
+            out['proposals'] = proposals
+            lab, tg = of.rcnn_target(proposals, gt, seed=seed, **self.rcnn_cfg)
+            keep = lab >= 0                                               # rcnn.py:156-167
+            rois, roi_labels, roi_targets = proposals[keep], lab[keep], tg[keep]
+        out['rois'], out['roi_labels'], out['roi_targets'] = rois, roi_labels, roi_targets
+        cls, box, pooled = self.rcnn_head(feat, torch.tensor(np.asarray(rois)), (H, W))
+        out['rcnn_cls_score'], out['rcnn_bbox_offsets'], out['pooled'] = cls, box, pooled
+        c_cls, c_reg = ot.rcnn_loss(cls, box, torch.tensor(np.asarray(roi_labels)),
+                                    torch.tensor(np.asarray(roi_targets)), self.C, 1.0)
+        out['rcnn_cls_loss'], out['rcnn_reg_loss'] = c_cls, c_reg
+        return out
+
+    # ---- trainable set (base_network.py:211-241, truncated_base_network.py:97-144) ---
+    def trainable_names(self):
+        names = []
+        for k in self.v:
+            if k.startswith(self.base):
+                if 'moving_' in k:
+                    continue
+                blk = [b for b in ('block2', 'block3') if '/%s/' % b in k]
+                if blk or (self.arch == 'resnet_v1_101' and '/block4/' in k):
+                    names.append(k)
+            else:
+                names.append(k)
+        return names
+
+    def train_step(self, images, gts, lr=3e-4, momentum=0.9, mom_state=None):
+        """One full CPU train step (forward, loss, backward, momentum-SGD with the L2 term)."""
+        names = self.trainable_names()
+        for n in names:
+            self.v[n].requires_grad_(True)
+            self.v[n].grad = None
+        B = len(images)
+        total = 0.0
+        parts = []
+        for b in range(B):
+            o = self.forward_image(images[b], gts[b], rng.image_seed(self.seed, self.step, b))
+            loss_b = o['rpn_cls_loss'] + o['rpn_reg_loss'] + o['rcnn_cls_loss'] + o['rcnn_reg_loss']
+            total = total + loss_b / B
+            parts.append(o)
+        reg = self.regularization_loss()
+        total_loss = total + reg.float()
+        total_loss.backward()
+        mom_state = mom_state if mom_state is not None else {}
+        with torch.no_grad():
+            for n in names:
+                g = self.v[n].grad
+                if g is None:
+                    continue
+                vbuf = mom_state.get(n)
+                vbuf = g.clone() if vbuf is None else vbuf.mul_(momentum).add_(g)
+                mom_state[n] = vbuf
+                self.v[n].sub_(lr * vbuf)
+        for n in names:
+            self.v[n].requires_grad_(False)
+        self.step += 1
+        return float(total_loss), parts, mom_state
