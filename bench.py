@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the Faster R-CNN ResNet-50 train step (BASELINE.json
+metric) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = forward + loss + backward + (gradient all-reduce) + momentum-SGD
+update of BASELINE config[1]: Faster R-CNN ResNet-50 (no FPN), batch 2 per GPU,
+1024x1024 synthetic images (U[0,255), 8 gt boxes/image, 80 classes, 49 152
+anchors/image, RPN minibatch 256, RCNN minibatch 256), fp32, random-init
+weights.  Inputs are resident in HBM before the timed region.  Weak scaling:
+per-GPU batch fixed, one RCCL all-reduce of the flat gradient buffer per step.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline     — dominant MFMA conv kernel: algorithmic FLOPs per launch / mean
+                 launch time (HIP events on the launch stream, instrumented
+                 steps run right after the timed region) vs the 157.3 TFLOP/s
+                 fp32 matrix peak of gfx950;
+  cpu_baseline — the CPU oracle (oracle/model.py, kind "port": the TF reference
+                 cannot run here) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def synth_batch(B, H, W, G, num_classes, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    images = (torch.rand((B, H, W, 3), generator=g) * 255.0).to(device)
+    gt = torch.zeros((B, G, 5), dtype=torch.float32)
+    for b in range(B):
+        wh = torch.randint(32, 513, (G, 2), generator=g)
+        x = (torch.rand((G,), generator=g) * (W - wh[:, 0]).float()).floor()
+        y = (torch.rand((G,), generator=g) * (H - wh[:, 1]).float()).floor()
+        gt[b, :, 0], gt[b, :, 1] = x, y
+        gt[b, :, 2], gt[b, :, 3] = x + wh[:, 0] - 1, y + wh[:, 1] - 1
+        gt[b, :, 4] = torch.randint(0, num_classes, (G,), generator=g).float()
+    cnt = torch.full((B,), G, dtype=torch.int32)
+    return images, (gt.to(device), cnt.to(device))
+
+
+def cpu_baseline(cfg_kwargs, sd, H, W, G, num_classes, n_images):
+    from oracle.model import OracleFasterRCNN
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    oracle = OracleFasterRCNN(sd, num_classes=num_classes, seed=0, **cfg_kwargs)
+    images, (gt, _) = synth_batch(n_images, H, W, G, num_classes, 1234, 'cpu')
+    t0 = time.time()
+    oracle.train_step([images[i] for i in range(n_images)], [gt[i].numpy() for i in range(n_images)])
+    dt = time.time() - t0
+    return {'value': n_images / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d image(s) %dx%d, one full oracle train step (torch-CPU fp32 + numpy), %.1fs'
+                      % (n_images, H, W, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=2, help='images per GPU')
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--arch', default='resnet_v1_50')
+    ap.add_argument('--classes', type=int, default=80)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=device)
+    assert world == args.gpus or world == 1, (world, args.gpus)
+
+    from luminoth_amd import kernels as K
+    from luminoth_amd.models import get_model
+    from luminoth_amd.utils.config import get_config
+    from luminoth_amd.utils.training import broadcast_parameters, get_optimizer, train_step
+
+    cfg = get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': args.classes},
+                                'base_network': {'architecture': args.arch}},
+                      'train': {'seed': 0, 'debug': False}})
+    model = get_model('fasterrcnn')(cfg, device=device)
+    broadcast_parameters(model)
+    sd0 = model.state_dict() if (rank == 0 and not args.no_cpu_baseline) else None
+    opt = get_optimizer(cfg.train, model)
+    H = W = args.size
+    images, gts = synth_batch(args.batch, H, W, 8, args.classes, 100 + rank, device)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step(model, opt, images, gts)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total, _ = train_step(model, opt, images, gts)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    loss_val = float(total)
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        K._Profile.start()
+        nprof = min(args.steps, 3)
+        for _ in range(nprof):
+            train_step(model, opt, images, gts)
+        prof = K._Profile.stop()
+        mfma = {k: v for k, v in prof.items() if 'bwd_weight' not in k}   # bwd_weight span includes its reduce
+        name = max(mfma, key=lambda k: mfma[k]['ms'])
+        r = prof[name]
+        fl = r['flops'] / r['launches']
+        ms = r['ms'] / r['launches']
+        achieved = fl / (ms * 1e-3) / 1e12
+        roofline = {'bound': 'mfma', 'kernel': name, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                    'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
+                    'all_conv_kernels': {k: {'launches_per_step': v['launches'] / nprof,
+                                             'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
+                                             'ms_per_step': v['ms'] / nprof} for k, v in prof.items()}}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        gb = args.batch * world
+        out = {
+            'metric': 'images/sec (1024x1024) Faster R-CNN ResNet-50 train step',
+            'value': gb * args.steps / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: Faster R-CNN %s FPN-off, %dx%d synthetic, batch %d/GPU, '
+                                   '80 classes, 8 gt/image, 49152 anchors/image, fwd+loss+bwd+momentum-SGD'
+                                   % (args.arch, H, W, args.batch),
+                       'global_batch': gb, 'parallelism': 'dp%d' % world, 'final_total_loss': loss_val},
+            'roofline': roofline,
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline({'arch': args.arch}, sd0, H, W, 8, args.classes, args.cpu_images)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -82,6 +82,10 @@ int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, const float* w,
 size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d);
 int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* dy,
                           float* dw, void* ws, size_t ws_bytes, lmh_stream_t stream);
+/* Which kernel instantiation a launch will use: op 0 fwd, 1 bwd_data, 2 bwd_weight.
+ * Returns BM*1000 + BN (+1000000 for the generic C%32 != 0 forward gather).  Used by
+ * bench.py to attribute per-kernel time / algorithmic FLOPs (roofline). */
+int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op);
 /* g = dy * (y > 0 [&& y < 6 for relu6]); optional colsum[k] += sum_rows g
  * (colsum must be zeroed by the caller; K = innermost dim). */
 int lmh_act_bwd(const float* dy, const float* y, int act, int64_t rows, int K,

@@ -573,6 +573,22 @@ static void bwd_weight_plan(const lmh_conv_desc* d, int* bm, int* bn, int* split
   *splits = (KT + *kt_per_split - 1) / *kt_per_split;
 }
 
+extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
+  if (!d) return -1;
+  int bm = 0, bn = 0;
+  if (op == 0) {
+    pick_tile((int64_t)d->N * d->OH * d->OW, d->K, &bm, &bn);
+    return bm * 1000 + bn + ((d->C % BK) != 0 ? 1000000 : 0);
+  }
+  if (op == 1) {
+    pick_tile((int64_t)d->N * d->H * d->W, d->C, &bm, &bn);
+    return bm * 1000 + bn;
+  }
+  int splits, kps;
+  bwd_weight_plan(d, &bm, &bn, &splits, &kps);
+  return bm * 1000 + bn;
+}
+
 extern "C" size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d) {
   if (!d) return 0;
   int bm, bn, splits, kps;
@@ -654,16 +670,43 @@ k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act, in
   }
 }
 
+// scalar variant for K % 4 != 0 (e.g. the 81-way classifier): thread per column
+__global__ void __launch_bounds__(256)
+k_act_bwd_scalar(const float* __restrict__ dy, const float* __restrict__ y, int act, int64_t rows, int K,
+                 float* __restrict__ g, float* __restrict__ colsum, int rows_per_block) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < K; c += blockDim.x) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      const size_t o = (size_t)r * K + c;
+      float d = dy[o];
+      if (act) {
+        const float yv = y[o];
+        const float hi = (act == 2) ? 6.f : INFINITY;
+        d = (yv > 0.f && yv < hi) ? d : 0.f;
+      }
+      if (g) g[o] = d;
+      s += d;
+    }
+    if (colsum) unsafeAtomicAdd(colsum + c, s);
+  }
+}
+
 extern "C" int lmh_act_bwd(const float* dy, const float* y, int act, int64_t rows, int K, float* g,
                            float* colsum, lmh_stream_t stream) {
-  LMH_CHECK_ARG(dy && rows > 0 && K > 0 && (K & 3) == 0);
+  LMH_CHECK_ARG(dy && rows > 0 && K > 0);
   LMH_CHECK_ARG(act == 0 || y != nullptr);
   LMH_CHECK_ARG(g || colsum);
   int rpb = (int)((rows + 2047) / 2048);
   if (rpb < 8) rpb = 8;
   const int blocks = (int)((rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(k_act_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, y, act, rows, K, g,
-                     colsum, rpb);
+  if ((K & 3) != 0)
+    hipLaunchKernelGGL(k_act_bwd_scalar, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, y, act, rows,
+                       K, g, colsum, rpb);
+  else
+    hipLaunchKernelGGL(k_act_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, y, act, rows, K, g,
+                       colsum, rpb);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

@@ -48,6 +48,60 @@ def _workspace(nbytes, device, tag):
     return ws
 
 
+# ------------------------------------------------------------- profiling ----
+class _Profile(object):
+    """Optional per-launch HIP-event timing of the conv kernels (bench.py roofline leg).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+    enabled = False
+    records = []   # (kernel_name, algorithmic_flops, start_event, end_event)
+
+    @classmethod
+    def start(cls):
+        cls.enabled, cls.records = True, []
+
+    @classmethod
+    def stop(cls):
+        cls.enabled = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in cls.records:
+            r = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
+            r['launches'] += 1
+            r['flops'] += flops
+            r['ms'] += e0.elapsed_time(e1)
+        cls.records = []
+        return out
+
+
+_OPN = {0: 'k_conv_fwd', 1: 'k_conv_bwd_data', 2: 'k_conv_bwd_weight'}
+
+
+def _conv_flops(d):
+    return 2.0 * d.N * d.OH * d.OW * d.K * d.R * d.S * d.C
+
+
+class _timed(object):
+    def __init__(self, d, op):
+        self.on = _Profile.enabled
+        if self.on:
+            kid = _lib.load().lmh_conv2d_kernel_id(ctypes.byref(d), op)
+            gen = ',generic' if kid >= 1000000 else ''
+            kid %= 1000000
+            self.name = '%s<%d,%d%s>' % (_OPN[op], kid // 1000, kid % 1000, gen)
+            self.flops = _conv_flops(d)
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            _Profile.records.append((self.name, self.flops, self.e0, self.e1))
+
+
 # ------------------------------------------------------------------ conv ----
 def same_pads(in_size, k, stride, dilation=1):
     """TF 'SAME' padding: out = ceil(in/stride); leading pad = total // 2."""
@@ -83,16 +137,18 @@ def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding='SAME', act=None):
 def conv2d_fwd(d, x, w, scale=None, shift=None, residual=None, in_sub=None, out=None):
     lib = _lib.load()
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
-    check(lib.lmh_conv2d_fwd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(scale), _p(shift), _p(residual),
-                             _p(in_sub), _p(y), _stream()), 'lmh_conv2d_fwd')
+    with _timed(d, 0):
+        check(lib.lmh_conv2d_fwd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(scale), _p(shift), _p(residual),
+                                 _p(in_sub), _p(y), _stream()), 'lmh_conv2d_fwd')
     return y
 
 
 def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None):
     lib = _lib.load()
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
-    check(lib.lmh_conv2d_bwd_data(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(kscale), _p(addend), _p(dx),
-                                  _stream()), 'lmh_conv2d_bwd_data')
+    with _timed(d, 1):
+        check(lib.lmh_conv2d_bwd_data(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(kscale), _p(addend), _p(dx),
+                                      _stream()), 'lmh_conv2d_bwd_data')
     return dx
 
 
@@ -101,8 +157,9 @@ def conv2d_bwd_weight(d, x, dy, out=None):
     dw = out if out is not None else torch.empty((d.R, d.S, d.C, d.K), dtype=torch.float32, device=x.device)
     nbytes = lib.lmh_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
     ws = _workspace(nbytes, x.device, 'bwd_weight')
-    check(lib.lmh_conv2d_bwd_weight(ctypes.byref(d), _p(_f32(x)), _p(_f32(dy)), _p(dw), _p(ws),
-                                    ctypes.c_size_t(ws.numel()), _stream()), 'lmh_conv2d_bwd_weight')
+    with _timed(d, 2):
+        check(lib.lmh_conv2d_bwd_weight(ctypes.byref(d), _p(_f32(x)), _p(_f32(dy)), _p(dw), _p(ws),
+                                        ctypes.c_size_t(ws.numel()), _stream()), 'lmh_conv2d_bwd_weight')
     return dw
 
 

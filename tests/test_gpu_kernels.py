@@ -350,6 +350,8 @@ CONV_CASES = [
     (1, 64, 64, 1024, 512, 3, 1, 1, 'SAME', 'relu6'),
     (1, 10, 10, 256, 256, 3, 2, 1, 'SAME', 'relu'),
     (1, 5, 5, 128, 256, 3, 1, 1, 'VALID', 'relu'),
+    (1, 1, 512, 1024, 81, 1, 1, 1, 'VALID', None),      # fc_classifier: K % 4 != 0 scalar paths
+    (1, 1, 500, 1024, 320, 1, 1, 1, 'VALID', 'relu'),
 ]
 
 
