@@ -49,12 +49,18 @@ class MomentumOptimizer(object):
         self.momentum = float(momentum)
         self.global_step = 0
 
-    def step(self):
+    def reduce_gradients(self):
+        """Sum the flat gradient buffer over the data-parallel replicas (one collective);
+        returns the factor that turns the sum into the mean (applied inside the update kernel)."""
         st = self.store
-        gscale = 1.0
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(st.grad)                 # ONE bucket: the flat gradient buffer
-            gscale = 1.0 / dist.get_world_size()
+            return 1.0 / dist.get_world_size()
+        return 1.0
+
+    def step(self):
+        st = self.store
+        gscale = self.reduce_gradients()
         lr = get_learning_rate(self.cfg, self.global_step)
         K.sgd_momentum(st.flat, st.grad, st.mom, st.seg_offset, st.seg_wd, lr, self.momentum, gscale)
         self.global_step += 1

@@ -1,0 +1,94 @@
+"""CPU, world_size 2, gloo: the N>1 host logic of the train step — ONE all-reduce of the
+flat gradient buffer, mean folded into the update, replicas stay bit-identical.  The HIP
+update kernel itself needs a GPU; here a numpy twin of `k_sgd_momentum` stands in for it so the
+collective plumbing is what is under test."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Store(object):
+    def __init__(self, n, rank):
+        g = torch.Generator().manual_seed(0)
+        self.flat = torch.randn(n, generator=g)            # identical on every rank (seeded init)
+        self.mom = torch.zeros(n)
+        gr = torch.Generator().manual_seed(100 + rank)
+        self.grad = torch.randn(n, generator=gr)           # per-rank gradients
+        self.seg_offset = torch.tensor([0, n // 2, n], dtype=torch.int64)
+        self.seg_wd = torch.tensor([5e-4, 0.0])
+
+
+class _Model(object):
+    pass
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from luminoth_amd.utils import training
+    from luminoth_amd.utils.config import Config
+
+    def sgd_twin(w, g, v, seg_offset, seg_wd, lr, momentum, gscale):     # numpy twin of k_sgd_momentum
+        wd = torch.zeros_like(w)
+        for s in range(seg_wd.numel()):
+            wd[int(seg_offset[s]):int(seg_offset[s + 1])] = seg_wd[s]
+        gi = g * gscale + wd * w
+        v.mul_(momentum).add_(gi)
+        w.sub_(lr * v)
+    training.K.sgd_momentum = sgd_twin
+    m = _Model()
+    m.store = _Store(1000, rank)
+    local_grad = m.store.grad.clone()
+    cfg = Config({'learning_rate': {'decay_method': None, 'learning_rate': 0.01},
+                  'optimizer': {'type': 'momentum', 'momentum': 0.9}, 'clip_by_norm': False})
+    opt = training.get_optimizer(cfg, m)
+    w0 = m.store.flat.clone()
+    opt.step()
+    q.put((rank, local_grad.numpy(), m.store.grad.numpy().copy(), m.store.flat.numpy().copy(), w0.numpy()))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, g0, s0, w0_new, w0), (_, g1, s1, w1_new, _) = res
+    np.testing.assert_allclose(s0, g0 + g1, rtol=1e-6)       # gradients were summed once
+    np.testing.assert_array_equal(s0, s1)
+    np.testing.assert_array_equal(w0_new, w1_new)             # replicas stay bit-identical
+    wd = np.concatenate([np.full(500, 5e-4, np.float32), np.zeros(500, np.float32)])
+    exp = w0 - 0.01 * ((g0 + g1) * 0.5 + wd * w0)
+    np.testing.assert_allclose(w0_new, exp, rtol=1e-5, atol=1e-7)
+
+
+def test_learning_rate_schedules():
+    sys.path.insert(0, ROOT)
+    from luminoth_amd.utils.config import Config
+    from luminoth_amd.utils.training import get_learning_rate, get_optimizer
+    import pytest
+    c = Config({'learning_rate': {'decay_method': None, 'learning_rate': 3e-4}})
+    assert get_learning_rate(c, 10) == 3e-4
+    c = Config({'learning_rate': {'decay_method': 'piecewise_constant', 'boundaries': [10, 20],
+                                  'values': [1.0, 0.1, 0.01]}})
+    assert [get_learning_rate(c, s) for s in (0, 10, 11, 20, 21)] == [1.0, 1.0, 0.1, 0.1, 0.01]
+    c = Config({'learning_rate': {'decay_method': 'exponential_decay', 'learning_rate': 1.0, 'decay_steps': 10,
+                                  'decay_rate': 0.5, 'staircase': True}})
+    assert get_learning_rate(c, 25) == 0.25
+    with pytest.raises(ValueError):
+        get_learning_rate(Config({'learning_rate': {'decay_method': 'bogus', 'learning_rate': 1.0}}), 0)
+    with pytest.raises(ValueError):
+        get_optimizer(Config({'optimizer': {'type': 'bogus'}, 'learning_rate': {}}), None)

@@ -1,0 +1,108 @@
+"""CPU-only tests of the host side of the boundary: config merge semantics, registry, anchors,
+initialisers, variable naming / trainable-set logic (no kernels launched)."""
+import numpy as np
+import pytest
+import torch
+
+from luminoth_amd.utils import config as C
+from luminoth_amd.utils.anchors import generate_anchors_reference, truncate_reference, all_anchors_numpy
+from oracle import boxes as obx
+
+
+def test_get_model_registry():
+    # luminoth/models/models.py:11-17
+    from luminoth_amd.models import get_model
+    from luminoth_amd.models.fasterrcnn.fasterrcnn import FasterRCNN
+    assert get_model('FasterRCNN') is FasterRCNN
+    with pytest.raises(ValueError):
+        get_model('yolo')
+
+
+def test_config_merge_replace_override_and_types():
+    # luminoth/utils/config.py:73-196
+    cfg = C.get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': 80}},
+                        'train': {'learning_rate': {'decay_method': 'piecewise_constant', 'boundaries': [1],
+                                                    'values': [1., .1]}}},
+                       ['model.rpn.proposals.post_nms_top_n=300', 'train.seed=7', 'train.debug=True',
+                        'model.base_network.fine_tune_from=None'])
+    assert cfg.model.network.num_classes == 80 and cfg.model.network.with_rcnn is True
+    assert cfg.model.rpn.proposals.post_nms_top_n == 300 and cfg.model.rpn.proposals.pre_nms_top_n == 12000
+    assert cfg.train.seed == 7 and cfg.train.debug is True and cfg.model.base_network.fine_tune_from is None
+    # `_replace: True` on learning_rate: the default's `learning_rate: 0.0003` key is gone
+    assert 'learning_rate' not in cfg.train.learning_rate and '_replace' not in cfg.train.learning_rate
+    with pytest.raises(ValueError):
+        C.get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': 'many'}}})
+    with pytest.raises(ValueError):
+        C.parse_override(['a=b=c'])
+    assert C.parse_override(['a.b=1', 'a.c=0.5', 'd=None', 'e=true', 'f=x']) == \
+        {'a': {'b': 1, 'c': .5}, 'd': None, 'e': True, 'f': 'x'}
+
+
+def test_anchor_reference_matches_oracle_and_quirk():
+    ref = generate_anchors_reference(256, [.5, 1, 2], [.25, .5, 1, 2])
+    np.testing.assert_allclose(ref, obx.generate_anchors_reference(256, np.array([.5, 1, 2]),
+                                                                   np.array([.25, .5, 1, 2])), rtol=1e-12)
+    with pytest.raises(ValueError):
+        generate_anchors_reference(1, [.5], [.5])
+    np.testing.assert_array_equal(all_anchors_numpy(ref, 5, 7, 16), obx.generate_anchors(ref, 5, 7, 16))
+    assert truncate_reference(np.array([[-22.13, 29.9, -0.5, 0.5]])).tolist() == [[-22, 29, 0, 0]]
+
+
+def test_initializers_and_activations():
+    from luminoth_amd.utils.vars import get_initializer, get_activation_function
+    g = torch.Generator().manual_seed(0)
+    w = get_initializer({'type': 'random_normal_initializer', 'mean': 0., 'stddev': 0.01})((3, 3, 64, 128), g)
+    assert abs(float(w.std()) - 0.01) < 5e-4
+    u = get_initializer({'type': 'variance_scaling_initializer', 'factor': 1.0, 'uniform': True,
+                         'mode': 'FAN_AVG'})((1024, 81), g)
+    assert float(u.abs().max()) <= np.sqrt(3.0 / ((1024 + 81) / 2)) + 1e-6
+    with pytest.raises(ValueError):
+        get_initializer({'type': 'nope'})
+    assert get_activation_function('relu6') == 'relu6' and get_activation_function(None) is None
+    with pytest.raises(ValueError):
+        get_activation_function('swish')
+
+
+def test_trainable_variable_selection_resnet():
+    # base_network.py:211-241 + truncated_base_network.py:97-144
+    from luminoth_amd.models.base.truncated_base_network import TruncatedBaseNetwork
+    cfg = C.get_config({'model': {'type': 'fasterrcnn', 'base_network': {'architecture': 'resnet_v1_50'}}})
+    net = TruncatedBaseNetwork(cfg.model.base_network)
+    names = net.get_trainable_var_names()
+    assert names[0].endswith('resnet_v1_50/block2/unit_1/bottleneck_v1/shortcut/weights')
+    assert names[-1].endswith('resnet_v1_50/block3/unit_6/bottleneck_v1/conv3/BatchNorm/gamma')
+    assert not any('/block1/' in n or '/block4/' in n or n.endswith('conv1/weights') and '/block' not in n
+                   for n in names)
+    # R50 to block4/unit_3: 156 trainable vars in total (truncated_base_network_test.py:61-133);
+    # block2+block3 = (4+6) units * 9 vars + 2 shortcuts * 3 = 96
+    assert len(names) == 96
+    cfg101 = C.get_config({'model': {'type': 'fasterrcnn'}})
+    net101 = TruncatedBaseNetwork(cfg101.model.base_network)
+    n101 = net101.get_trainable_var_names()
+    assert any('/block4/' in n for n in n101) and net101.tail is not None     # tail only for R101
+    all_vars = net._ordered_var_names()
+    assert len(all_vars) == 3 + 16 * 9 + 4 * 3                                 # conv1 + 16 units + 4 shortcuts
+    bad = C.get_config({'model': {'type': 'fasterrcnn', 'base_network': {'architecture': 'resnet_v1_50',
+                                                                          'fine_tune_from': 'nope'}}})
+    with pytest.raises(ValueError):
+        TruncatedBaseNetwork(bad.model.base_network).get_trainable_var_names()
+    with pytest.raises(ValueError):
+        TruncatedBaseNetwork(C.Config({'architecture': 'lenet'}))
+
+
+def test_param_store_layout_cpu():
+    from luminoth_amd.params import ParamStore
+    st = ParamStore()
+    ones = lambda s, g: torch.ones(s)
+    st.add('a/weights', (3, 5), ones, trainable=True, wd=1e-3)
+    st.add('f/weights', (7,), ones, trainable=False, wd=5e-4)
+    st.add('a/biases', (5,), ones, trainable=True)
+    st.build(torch.device('cpu'), seed=0)
+    assert st.flat.numel() == 16 + 8 and st.frozen.numel() == 8           # 4-float segment padding
+    assert st.seg_offset.tolist() == [0, 16, 24] and st.seg_wd.tolist() == pytest.approx([1e-3, 0.0])
+    st.grads['a/biases'].fill_(2.)
+    assert float(st.grad[16:21].sum()) == 10.
+    sd = st.state_dict()
+    sd['a/weights'] = torch.zeros(3, 5)
+    st.load_state_dict(sd)
+    assert float(st.flat[:15].abs().sum()) == 0.
