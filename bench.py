@@ -55,7 +55,7 @@ def synth_batch(B, H, W, G, num_classes, seed, device):
 
 def cpu_baseline(cfg_kwargs, sd, H, W, G, num_classes, n_images):
     from oracle.model import OracleFasterRCNN
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)      # torch-CPU conv scaling flattens well before 256 threads
     torch.set_num_threads(cores)
     oracle = OracleFasterRCNN(sd, num_classes=num_classes, seed=0, **cfg_kwargs)
     images, (gt, _) = synth_batch(n_images, H, W, G, num_classes, 1234, 'cpu')
@@ -103,6 +103,12 @@ def main():
                                 'base_network': {'architecture': args.arch}},
                       'train': {'seed': 0, 'debug': False}})
     model = get_model('fasterrcnn')(cfg, device=device)
+    # Random-init stand-in for pretrained BatchNorm statistics: without them raw 0..255 pixels drive the
+    # activations to O(1e3) and the momentum-SGD run diverges to NaN within a few steps.  Only the frozen
+    # conv1 moving variance is set (pixel variance x fan-in gain); architecture and work are unchanged.
+    sd = model.state_dict()
+    sd['truncated_base_network/%s/conv1/BatchNorm/moving_variance' % args.arch].fill_(73.6 ** 2 * 2)
+    model.load_state_dict(sd)
     broadcast_parameters(model)
     sd0 = model.state_dict() if (rank == 0 and not args.no_cpu_baseline) else None
     opt = get_optimizer(cfg.train, model)
@@ -126,7 +132,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-    loss_val = float(total)
+    loss_val = float(total.detach())
 
     roofline = None
     if rank == 0 and not args.no_roofline:

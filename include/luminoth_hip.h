@@ -86,15 +86,18 @@ int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* d
  * Returns BM*1000 + BN (+1000000 for the generic C%32 != 0 forward gather).  Used by
  * bench.py to attribute per-kernel time / algorithmic FLOPs (roofline). */
 int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op);
-/* g = dy * (y > 0 [&& y < 6 for relu6]); optional colsum[k] += sum_rows g
- * (colsum must be zeroed by the caller; K = innermost dim). */
+/* g = dy * (y > 0 [&& y < 6 for relu6]) (g may be NULL); colsum[k] = sum_rows g
+ * (may be NULL; written, not accumulated; two-stage deterministic reduction through ws). */
+size_t lmh_act_bwd_workspace_bytes(int64_t rows, int K);
 int lmh_act_bwd(const float* dy, const float* y, int act, int64_t rows, int K,
-                float* g, float* colsum, lmh_stream_t stream);
+                float* g, float* colsum, void* ws, size_t ws_bytes, lmh_stream_t stream);
 /* BN (frozen) parameter gradients from the raw weight gradient:
- * dgamma[k] = rstd[k]*(sum_{rsc} w*dw_raw - mean[k]*dbeta[k]); dw = dw_raw*scale[k]. */
+ * dgamma[k] = rstd[k]*(sum_{rsc} w*dw_raw - mean[k]*dbeta[k]); dw = dw_raw*scale[k] (in place). */
+size_t lmh_bn_param_grads_workspace_bytes(int64_t rsc, int K);
 int lmh_bn_param_grads(const float* w, float* dw_raw_inout, const float* dbeta,
                        const float* mean, const float* rstd, const float* scale,
-                       int64_t rsc, int K, float* dgamma, lmh_stream_t stream);
+                       int64_t rsc, int K, float* dgamma, void* ws, size_t ws_bytes,
+                       lmh_stream_t stream);
 /* tf.nn.max_pool NHWC (slim resnet pool1 3x3/2 SAME; vgg 2x2/2 VALID; SSD 3x3/1 SAME). */
 int lmh_maxpool_fwd(const float* x, int N, int H, int W, int C, int ksize, int stride,
                     int pad_top, int pad_left, int OH, int OW, float* y, lmh_stream_t stream);

@@ -164,11 +164,17 @@ def conv2d_bwd_weight(d, x, dy, out=None):
 
 
 def act_bwd(dy, y, act, want_g=True, colsum=None):
+    """g = dy * act'(y); colsum (K,) is WRITTEN with the per-channel sums of g."""
     lib = _lib.load()
     K = dy.shape[-1]
     rows = dy.numel() // K
     g = torch.empty_like(dy) if want_g else None
-    check(lib.lmh_act_bwd(_p(dy), _p(y), ACT[act], rows, K, _p(g), _p(colsum), _stream()), 'lmh_act_bwd')
+    ws, nbytes = None, 0
+    if colsum is not None:
+        nbytes = lib.lmh_act_bwd_workspace_bytes(rows, K)
+        ws = _workspace(nbytes, dy.device, 'colsum')
+    check(lib.lmh_act_bwd(_p(dy), _p(y), ACT[act], rows, K, _p(g), _p(colsum), _p(ws),
+                          ctypes.c_size_t(0 if ws is None else ws.numel()), _stream()), 'lmh_act_bwd')
     return g
 
 
@@ -177,8 +183,10 @@ def bn_param_grads(w, dw_raw, dbeta, mean, rstd, scale, out=None):
     K = w.shape[-1]
     rsc = w.numel() // K
     dgamma = out if out is not None else torch.empty_like(dbeta)
+    ws = _workspace(lib.lmh_bn_param_grads_workspace_bytes(rsc, K), w.device, 'bn_wdot')
     check(lib.lmh_bn_param_grads(_p(w), _p(dw_raw), _p(dbeta), _p(mean), _p(rstd), _p(scale), rsc, K,
-                                 _p(dgamma), _stream()), 'lmh_bn_param_grads')
+                                 _p(dgamma), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
+          'lmh_bn_param_grads')
     return dgamma
 
 
