@@ -1,0 +1,62 @@
+// Shared pieces of the implicit-GEMM convolution kernels (gfx950).
+#pragma once
+#include "lmh_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+#define LDK (BK + 4)  // row stride (floats) of K-contiguous LDS tiles: 9*m mod 16 slots, conflict-free b128
+
+// bijective XCD remap: hardware places block b on XCD b % 8
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+// ---- MFMA stage: A tile (BM x 32), B tile (32 x BN) from LDS -----------------
+template <int TM, int TN, bool A_KC, bool B_KC, int LDA, int LDB>
+__device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const float* __restrict__ Bs,
+                                           f32x16 (&acc)[TM][TN], int a_off, int b_off, int lane) {
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int kb = 16 * h + 4 * g;
+    float a[TM][4], b[TN][4];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      if (A_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(&As[(a_off + tm * 32 + l31) * LDA + kb]);
+        a[tm][0] = v.x; a[tm][1] = v.y; a[tm][2] = v.z; a[tm][3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[tm][i] = As[(kb + i) * LDA + a_off + tm * 32 + l31];
+      }
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      if (B_KC) {
+        const float4 v = *reinterpret_cast<const float4*>(&Bs[(b_off + tn * 32 + l31) * LDB + kb]);
+        b[tn][0] = v.x; b[tn][1] = v.y; b[tn][2] = v.z; b[tn][3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[tn][i] = Bs[(kb + i) * LDB + b_off + tn * 32 + l31];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][i], b[tn][i], acc[tm][tn], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return fminf(fmaxf(v, 0.f), 6.f);
+  return v;
+}
+

@@ -1,0 +1,410 @@
+// General-shape (predicated, single-buffered) implicit-GEMM kernels: any C / K, used when the
+// fast-path alignment conditions of conv.hip do not hold (conv1 C=3, 24/48/81-wide heads, ...).
+#pragma once
+#include "conv_common.h"
+
+// ============================================================================
+// forward:  y[p, k] = act( sum_{r,s,c} x[pix(p,r,s), c] * w[r,s,c,k] * scale[k] + shift[k] + res[p,k] )
+// GEMM M = N*OH*OW, N = K, Kg = R*S*C.   A: gather, K-contiguous.  B: HWIO, K-major.
+// ============================================================================
+template <int BM, int BN, bool GENERIC_A>
+__global__ void __launch_bounds__(256)
+k_conv_fwd_gen(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
+           const float* __restrict__ scale, const float* __restrict__ shift,
+           const float* __restrict__ residual, const float* __restrict__ in_sub, float* __restrict__ y) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32;  // A float4 per thread per stage
+  constexpr int BJ = BN / 32;  // B float4 per thread per stage
+  __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = d.N * d.OH * d.OW, Kg = d.R * d.S * d.C, K = d.K;
+  const int tiles_n = (K + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  // per-thread A rows
+  const int kq = tid & 7;
+  int a_n[AJ], a_ih0[AJ], a_iw0[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int p = m0 + (tid >> 3) + 32 * j;
+    if (p < M) {
+      const int ow = p % d.OW, t = p / d.OW;
+      const int oh = t % d.OH;
+      a_n[j] = t / d.OH;
+      a_ih0[j] = oh * d.stride - d.pad_top;
+      a_iw0[j] = ow * d.stride - d.pad_left;
+    } else {
+      a_n[j] = -1; a_ih0[j] = 0; a_iw0[j] = 0;
+    }
+  }
+  // per-thread B slots
+  constexpr int BROW_T = BN / 4;         // threads per K-major row
+  constexpr int BROW_STEP = 256 / BROW_T;  // rows per pass
+  const int bx4 = tid % BROW_T, bk = tid / BROW_T;
+  const bool vecB = (K & 3) == 0;
+
+  float4 ra[AJ], rb[BJ];
+  auto load_tile = [&](int kt) {
+    const int kg0 = kt * BK;
+    if (!GENERIC_A) {
+      const int rs = kg0 / d.C, c0 = kg0 - rs * d.C;
+      const int r = rs / d.S, s = rs - r * d.S;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int ih = a_ih0[j] + r * d.dilation, iw = a_iw0[j] + s * d.dilation;
+        const bool ok = a_n[j] >= 0 && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W && kg0 < Kg;
+        ra[j] = ok ? *reinterpret_cast<const float4*>(
+                         x + ((size_t)(a_n[j] * d.H + ih) * d.W + iw) * d.C + c0 + 4 * kq)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kg = kg0 + 4 * kq + e;
+          float val = 0.f;
+          if (kg < Kg && a_n[j] >= 0) {
+            const int rs = kg / d.C, c = kg - rs * d.C;
+            const int r = rs / d.S, s = rs - r * d.S;
+            const int ih = a_ih0[j] + r * d.dilation, iw = a_iw0[j] + s * d.dilation;
+            if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W) {
+              val = x[((size_t)(a_n[j] * d.H + ih) * d.W + iw) * d.C + c];
+              if (in_sub) val -= in_sub[c];
+            }
+          }
+          v[e] = val;
+        }
+        ra[j] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int kg = kg0 + bk + BROW_STEP * j;
+      const int n = n0 + 4 * bx4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kg < Kg) {
+        const float* wp = w + (size_t)kg * K + n;
+        if (vecB && n + 3 < K) {
+          v = *reinterpret_cast<const float4*>(wp);
+        } else {
+          if (n < K) v.x = wp[0];
+          if (n + 1 < K) v.y = wp[1];
+          if (n + 2 < K) v.z = wp[2];
+          if (n + 3 < K) v.w = wp[3];
+        }
+      }
+      rb[j] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)
+      *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * j) * LDK + 4 * kq]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j)
+      *reinterpret_cast<float4*>(&Bs[(bk + BROW_STEP * j) * BN + 4 * bx4]) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
+
+  const int KT = (Kg + BK - 1) / BK;
+  load_tile(0);
+  for (int kt = 0; kt < KT; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < KT) load_tile(kt + 1);
+    mfma_stage<TM, TN, true, false, LDK, BN>(As, Bs, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    __syncthreads();
+  }
+
+  // epilogue
+  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * (BN / 2) + tn * 32 + col_l;
+    if (col >= K) continue;
+    const float sc = scale ? scale[col] : 1.f;
+    const float sh = shift ? shift[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase;
+        if (row < M) {
+          float v = acc[tm][tn][i];
+          if (scale) v = v * sc;
+          v = v + sh;
+          if (residual) v += residual[(size_t)row * K + col];
+          y[(size_t)row * K + col] = apply_act(v, d.act);
+        }
+      }
+    }
+  }
+}
+
+// ============================================================================
+// backward data: dx[p, c] = sum_{r,s,k} dy[opix(p,r,s), k] * kscale[k] * w[r,s,c,k]   (+ addend)
+// GEMM M = N*H*W, N = C, Kg = R*S*K.  A: dy gather (K-contiguous).  B: w[rs][c][k] (K-contiguous).
+// ============================================================================
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+k_conv_bwd_data_gen(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
+                const float* __restrict__ kscale, const float* __restrict__ addend,
+                float* __restrict__ dx) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32, BJ = BN / 32;
+  __shared__ __attribute__((aligned(16))) float As[BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = d.N * d.H * d.W, K = d.K, C = d.C;
+  const int KTk = (K + BK - 1) / BK;  // k-tiles per (r,s)
+  const int KT = d.R * d.S * KTk;
+  const int tiles_n = (C + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int kq = tid & 7;
+  const bool vecK = (K & 3) == 0;
+  int a_n[AJ], a_h[AJ], a_w[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int p = m0 + (tid >> 3) + 32 * j;
+    if (p < M) {
+      const int ww = p % d.W, t = p / d.W;
+      a_w[j] = ww + d.pad_left;
+      a_h[j] = (t % d.H) + d.pad_top;
+      a_n[j] = t / d.H;
+    } else { a_n[j] = -1; a_h[j] = 0; a_w[j] = 0; }
+  }
+  float4 ra[AJ], rb[BJ];
+  auto load_tile = [&](int kt) {
+    const int rs = kt / KTk, k0 = (kt - rs * KTk) * BK + 4 * kq;
+    const int r = rs / d.S, s = rs - r * d.S;
+    const bool kok = k0 < K;
+    float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (kscale && kok) {
+      ks.x = kscale[k0];
+      if (k0 + 1 < K) ks.y = kscale[k0 + 1];
+      if (k0 + 2 < K) ks.z = kscale[k0 + 2];
+      if (k0 + 3 < K) ks.w = kscale[k0 + 3];
+    }
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int th = a_h[j] - r * d.dilation, tw = a_w[j] - s * d.dilation;
+      int oh = th, ow = tw;
+      bool ok = a_n[j] >= 0 && kok && th >= 0 && tw >= 0;
+      if (d.stride > 1) {
+        oh = th / d.stride; ow = tw / d.stride;
+        ok = ok && (oh * d.stride == th) && (ow * d.stride == tw);
+      }
+      ok = ok && oh < d.OH && ow < d.OW;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const float* src = dy + ((size_t)(a_n[j] * d.OH + oh) * d.OW + ow) * K + k0;
+        if (vecK) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (k0 + 1 < K) v.y = src[1];
+          if (k0 + 2 < K) v.z = src[2];
+          if (k0 + 3 < K) v.w = src[3];
+        }
+        v.x *= ks.x; v.y *= ks.y; v.z *= ks.z; v.w *= ks.w;
+      }
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int c = n0 + (tid >> 3) + 32 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C && kok) {
+        const float* src = w + ((size_t)rs * C + c) * K + k0;
+        if (vecK) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (k0 + 1 < K) v.y = src[1];
+          if (k0 + 2 < K) v.z = src[2];
+          if (k0 + 3 < K) v.w = src[3];
+        }
+      }
+      rb[j] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)
+      *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * j) * LDK + 4 * kq]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j)
+      *reinterpret_cast<float4*>(&Bs[((tid >> 3) + 32 * j) * LDK + 4 * kq]) = rb[j];
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
+  load_tile(0);
+  for (int kt = 0; kt < KT; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < KT) load_tile(kt + 1);
+    mfma_stage<TM, TN, true, true, LDK, LDK>(As, Bs, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    __syncthreads();
+  }
+  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * (BN / 2) + tn * 32 + col_l;
+    if (col >= C) continue;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase;
+        if (row < M) {
+          float v = acc[tm][tn][i];
+          if (addend) v += addend[(size_t)row * C + col];
+          dx[(size_t)row * C + col] = v;
+        }
+      }
+  }
+}
+
+// ============================================================================
+// backward weight: dw[rs, c, k] = sum_p x[pix(p,r,s), c] * dy[p, k]
+// GEMM (per r,s) M = C, N = K, Kg = N*OH*OW (split over gridDim.z).  Both K-major.
+// ============================================================================
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+k_conv_bwd_weight_gen(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ dy,
+                  float* __restrict__ out, int kt_per_split) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32, BJ = BN / 32;
+  __shared__ __attribute__((aligned(16))) float As[BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int P = d.N * d.OH * d.OW, K = d.K, C = d.C;
+  const int tiles_c = (C + BM - 1) / BM;
+  const int rs = blockIdx.x / tiles_c, m0 = (blockIdx.x % tiles_c) * BM;
+  const int n0 = blockIdx.y * BN;
+  const int r = rs / d.S, s = rs - r * d.S;
+  const int KT_all = (P + BK - 1) / BK;
+  const int kt_begin = blockIdx.z * kt_per_split;
+  const int kt_end = min(KT_all, kt_begin + kt_per_split);
+  constexpr int AROW_T = BM / 4, AROW_STEP = 256 / AROW_T;
+  constexpr int BROW_T = BN / 4, BROW_STEP = 256 / BROW_T;
+  const int ax4 = tid % AROW_T, ak = tid / AROW_T;
+  const int bx4 = tid % BROW_T, bk = tid / BROW_T;
+  const bool vecK = (K & 3) == 0;
+  float4 ra[AJ], rb[BJ];
+  auto load_tile = [&](int kt) {
+    const int p0 = kt * BK;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int p = p0 + ak + AROW_STEP * j;
+      const int c = m0 + 4 * ax4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < P && c < C) {
+        const int ow = p % d.OW, t = p / d.OW;
+        const int oh = t % d.OH, n = t / d.OH;
+        const int ih = oh * d.stride - d.pad_top + r * d.dilation;
+        const int iw = ow * d.stride - d.pad_left + s * d.dilation;
+        if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
+          v = *reinterpret_cast<const float4*>(x + ((size_t)(n * d.H + ih) * d.W + iw) * C + c);
+      }
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int p = p0 + bk + BROW_STEP * j;
+      const int n = n0 + 4 * bx4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < P && n < K) {
+        const float* src = dy + (size_t)p * K + n;
+        if (vecK && n + 3 < K) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (n + 1 < K) v.y = src[1];
+          if (n + 2 < K) v.z = src[2];
+          if (n + 3 < K) v.w = src[3];
+        }
+      }
+      rb[j] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)
+      *reinterpret_cast<float4*>(&As[(ak + AROW_STEP * j) * BM + 4 * ax4]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j)
+      *reinterpret_cast<float4*>(&Bs[(bk + BROW_STEP * j) * BN + 4 * bx4]) = rb[j];
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
+  if (kt_begin < kt_end) load_tile(kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < kt_end) load_tile(kt + 1);
+    mfma_stage<TM, TN, false, false, BM, BN>(As, Bs, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    __syncthreads();
+  }
+  float* o = out + (size_t)blockIdx.z * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;
+  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * (BN / 2) + tn * 32 + col_l;
+    if (col >= K) continue;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase;
+        if (row < C) o[(size_t)row * K + col] = acc[tm][tn][i];
+      }
+  }
+}
+
+// deterministic split-K reduction: dw[i] = sum_s part[s][i]
+__global__ void __launch_bounds__(256)
+k_splitk_reduce(const float* __restrict__ part, int64_t n, int splits, float* __restrict__ out) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n) {
+    float4 a = *reinterpret_cast<const float4*>(part + i);
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(part + (size_t)s * n + i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = a;
+  } else {
+    for (int64_t e = i; e < n; ++e) {
+      float a = part[e];
+      for (int s = 1; s < splits; ++s) a += part[(size_t)s * n + e];
+      out[e] = a;
+    }
+  }
+}
+

@@ -1,0 +1,289 @@
+// Streaming helpers around the convolutions (gfx950, HBM-bound): activation backward + column
+// sums, BatchNorm parameter gradients, max pooling.
+#include "lmh_common.h"
+
+// ============================================================================
+// elementwise helpers
+// ============================================================================
+// ---------------------------------------------------------------------------
+// g = dy * act'(y) and per-channel column sums (dbeta / dbias), two stages,
+// deterministic: every block reduces its row slab into LDS and writes ONE
+// partial row [K]; k_colsum_finish adds the partial rows per column.
+// ---------------------------------------------------------------------------
+#define ACT_MAX_K 4096
+template <bool VEC>
+__global__ void __launch_bounds__(256)
+k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act, int64_t rows, int K,
+          float* __restrict__ g, float* __restrict__ partial, int rows_per_block) {
+  __shared__ float scol[ACT_MAX_K];
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  const float hi = (act == 2) ? 6.f : INFINITY;
+  if (partial) {
+    for (int c = threadIdx.x; c < K; c += 256) scol[c] = 0.f;
+    __syncthreads();
+  }
+  if (VEC) {
+    const int K4 = K >> 2;
+    const int tpr = min(K4, 256), rstep = 256 / tpr;
+    const int c4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    if (rsub < rstep) {
+      for (int cc = c4; cc < K4; cc += tpr) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t r = r0 + rsub; r < r1; r += rstep) {
+          const size_t o = (size_t)r * K + 4 * cc;
+          float4 d4 = *reinterpret_cast<const float4*>(dy + o);
+          if (act) {
+            const float4 y4 = *reinterpret_cast<const float4*>(y + o);
+            d4.x = (y4.x > 0.f && y4.x < hi) ? d4.x : 0.f;
+            d4.y = (y4.y > 0.f && y4.y < hi) ? d4.y : 0.f;
+            d4.z = (y4.z > 0.f && y4.z < hi) ? d4.z : 0.f;
+            d4.w = (y4.w > 0.f && y4.w < hi) ? d4.w : 0.f;
+          }
+          if (g) *reinterpret_cast<float4*>(g + o) = d4;
+          s.x += d4.x; s.y += d4.y; s.z += d4.z; s.w += d4.w;
+        }
+        if (partial) {
+          atomicAdd(&scol[4 * cc + 0], s.x);
+          atomicAdd(&scol[4 * cc + 1], s.y);
+          atomicAdd(&scol[4 * cc + 2], s.z);
+          atomicAdd(&scol[4 * cc + 3], s.w);
+        }
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < K; c += 256) {
+      float sacc = 0.f;
+      for (int64_t r = r0; r < r1; ++r) {
+        const size_t o = (size_t)r * K + c;
+        float d = dy[o];
+        if (act) { const float yv = y[o]; d = (yv > 0.f && yv < hi) ? d : 0.f; }
+        if (g) g[o] = d;
+        sacc += d;
+      }
+      if (partial) scol[c] = sacc;
+    }
+  }
+  if (partial) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < K; c += 256) partial[(size_t)blockIdx.x * K + c] = scol[c];
+  }
+}
+
+// out[c] = sum_b partial[b][c]  (sequential over b: deterministic)
+__global__ void __launch_bounds__(256)
+k_colsum_finish(const float* __restrict__ partial, int nb, int K, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= K) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nb; b += 4) {
+    s0 += partial[(size_t)b * K + c];
+    s1 += partial[(size_t)(b + 1) * K + c];
+    s2 += partial[(size_t)(b + 2) * K + c];
+    s3 += partial[(size_t)(b + 3) * K + c];
+  }
+  for (; b < nb; ++b) s0 += partial[(size_t)b * K + c];
+  out[c] = (s0 + s1) + (s2 + s3);
+}
+
+static int act_bwd_blocks(int64_t rows, int K, int* rpb_out) {
+  int rpb = (int)((rows + 511) / 512);
+  const int k4 = (K & 3) ? K : (K >> 2);
+  const int rstep = k4 >= 256 ? 1 : 256 / k4;
+  if (rpb < 4 * rstep) rpb = 4 * rstep;
+  *rpb_out = rpb;
+  return (int)((rows + rpb - 1) / rpb);
+}
+
+extern "C" size_t lmh_act_bwd_workspace_bytes(int64_t rows, int K) {
+  int rpb;
+  const int nb = act_bwd_blocks(rows, K, &rpb);
+  return lmh_align_up((size_t)nb * K * sizeof(float), 256);
+}
+
+extern "C" int lmh_act_bwd(const float* dy, const float* y, int act, int64_t rows, int K, float* g,
+                           float* colsum, void* ws, size_t ws_bytes, lmh_stream_t stream) {
+  LMH_CHECK_ARG(dy && rows > 0 && K > 0 && K <= ACT_MAX_K);
+  LMH_CHECK_ARG(act == 0 || y != nullptr);
+  LMH_CHECK_ARG(g || colsum);
+  int rpb;
+  const int nb = act_bwd_blocks(rows, K, &rpb);
+  float* partial = nullptr;
+  if (colsum) {
+    if (!ws || ws_bytes < lmh_act_bwd_workspace_bytes(rows, K)) {
+      lmh_set_error("lmh_act_bwd: workspace too small");
+      return LMH_ERR_WORKSPACE;
+    }
+    partial = reinterpret_cast<float*>(ws);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if ((K & 3) != 0)
+    hipLaunchKernelGGL((k_act_bwd<false>), dim3(nb), dim3(256), 0, st, dy, y, act, rows, K, g, partial, rpb);
+  else
+    hipLaunchKernelGGL((k_act_bwd<true>), dim3(nb), dim3(256), 0, st, dy, y, act, rows, K, g, partial, rpb);
+  if (colsum)
+    hipLaunchKernelGGL(k_colsum_finish, dim3((K + 255) / 256), dim3(256), 0, st, partial, nb, K, colsum);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+// BN (frozen) parameter gradients from the raw weight gradient, two stages:
+//   partial[b][k] = sum_{i in slab b} w[i,k]*dw_raw[i,k];  dw[i,k] = dw_raw[i,k]*scale[k]
+//   dgamma[k] = rstd[k]*(sum_b partial[b][k] - mean[k]*dbeta[k])
+__global__ void __launch_bounds__(256)
+k_bn_wdot(const float* __restrict__ w, float* __restrict__ dw, const float* __restrict__ scale, int64_t rsc,
+          int K, float* __restrict__ partial, int rows_per_block) {
+  __shared__ float scol[ACT_MAX_K];
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(rsc, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < K; c += 256) scol[c] = 0.f;
+  __syncthreads();
+  const int K4 = K >> 2;
+  const int tpr = min(K4, 256), rstep = 256 / tpr;
+  const int c4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+  if (rsub < rstep) {
+    for (int cc = c4; cc < K4; cc += tpr) {
+      const float4 sc = *reinterpret_cast<const float4*>(scale + 4 * cc);
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int64_t r = r0 + rsub; r < r1; r += rstep) {
+        const size_t o = (size_t)r * K + 4 * cc;
+        const float4 wv = *reinterpret_cast<const float4*>(w + o);
+        float4 d = *reinterpret_cast<const float4*>(dw + o);
+        s.x += wv.x * d.x; s.y += wv.y * d.y; s.z += wv.z * d.z; s.w += wv.w * d.w;
+        d.x *= sc.x; d.y *= sc.y; d.z *= sc.z; d.w *= sc.w;
+        *reinterpret_cast<float4*>(dw + o) = d;
+      }
+      atomicAdd(&scol[4 * cc + 0], s.x);
+      atomicAdd(&scol[4 * cc + 1], s.y);
+      atomicAdd(&scol[4 * cc + 2], s.z);
+      atomicAdd(&scol[4 * cc + 3], s.w);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < K; c += 256) partial[(size_t)blockIdx.x * K + c] = scol[c];
+}
+
+__global__ void __launch_bounds__(256)
+k_bn_finish(const float* __restrict__ partial, int nb, int K, const float* __restrict__ dbeta,
+            const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dgamma) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= K) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += partial[(size_t)b * K + c];
+  dgamma[c] = rstd[c] * (s - mean[c] * dbeta[c]);
+}
+
+static int bn_blocks(int64_t rsc, int K, int* rpb_out) {
+  int rpb = (int)((rsc + 255) / 256);
+  const int k4 = K >> 2;
+  const int rstep = k4 >= 256 ? 1 : 256 / k4;
+  if (rpb < 2 * rstep) rpb = 2 * rstep;
+  *rpb_out = rpb;
+  return (int)((rsc + rpb - 1) / rpb);
+}
+
+extern "C" size_t lmh_bn_param_grads_workspace_bytes(int64_t rsc, int K) {
+  int rpb;
+  return lmh_align_up((size_t)bn_blocks(rsc, K, &rpb) * K * sizeof(float), 256);
+}
+
+extern "C" int lmh_bn_param_grads(const float* w, float* dw_raw_inout, const float* dbeta,
+                                  const float* mean, const float* rstd, const float* scale, int64_t rsc,
+                                  int K, float* dgamma, void* ws, size_t ws_bytes, lmh_stream_t stream) {
+  LMH_CHECK_ARG(w && dw_raw_inout && dbeta && mean && rstd && scale && dgamma && rsc > 0 && K > 0);
+  LMH_CHECK_ARG((K & 3) == 0 && K <= ACT_MAX_K);
+  if (!ws || ws_bytes < lmh_bn_param_grads_workspace_bytes(rsc, K)) {
+    lmh_set_error("lmh_bn_param_grads: workspace too small");
+    return LMH_ERR_WORKSPACE;
+  }
+  int rpb;
+  const int nb = bn_blocks(rsc, K, &rpb);
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(k_bn_wdot, dim3(nb), dim3(256), 0, st, w, dw_raw_inout, scale, rsc, K, partial, rpb);
+  hipLaunchKernelGGL(k_bn_finish, dim3((K + 255) / 256), dim3(256), 0, st, partial, nb, K, dbeta, mean, rstd,
+                     dgamma);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+// ---- max pool (NHWC) --------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_maxpool_fwd(const float* __restrict__ x, int N, int H, int W, int C, int ks, int stride, int pt, int pl,
+              int OH, int OW, float* __restrict__ y) {
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)N * OH * OW * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    int64_t t = i / C4;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int r = 0; r < ks; ++r) {
+      const int ih = oh * stride - pt + r;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int s = 0; s < ks; ++s) {
+        const int iw = ow * stride - pl + s;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)(n * H + ih) * W + iw) * C + 4 * c4);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    *reinterpret_cast<float4*>(y + (size_t)i * 4) = m;
+  }
+}
+
+// dx must be zeroed by the caller; gradient goes to the first max in (r,s) scan order.
+__global__ void __launch_bounds__(256)
+k_maxpool_bwd(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, int N,
+              int H, int W, int C, int ks, int stride, int pt, int pl, int OH, int OW,
+              float* __restrict__ dx) {
+  const int64_t total = (int64_t)N * OH * OW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    const float yv = y[i], g = dy[i];
+    bool done = false;
+    for (int r = 0; r < ks && !done; ++r) {
+      const int ih = oh * stride - pt + r;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int s = 0; s < ks && !done; ++s) {
+        const int iw = ow * stride - pl + s;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const size_t o = ((size_t)(n * H + ih) * W + iw) * C + c;
+        if (x[o] == yv) { unsafeAtomicAdd(dx + o, g); done = true; }
+      }
+    }
+  }
+}
+
+extern "C" int lmh_maxpool_fwd(const float* x, int N, int H, int W, int C, int ksize, int stride,
+                               int pad_top, int pad_left, int OH, int OW, float* y, lmh_stream_t stream) {
+  LMH_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && ksize > 0 && stride > 0);
+  const int64_t total = (int64_t)N * OH * OW * (C / 4);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_maxpool_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ksize,
+                     stride, pad_top, pad_left, OH, OW, y);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+extern "C" int lmh_maxpool_bwd(const float* x, const float* y, const float* dy, int N, int H, int W, int C,
+                               int ksize, int stride, int pad_top, int pad_left, int OH, int OW, float* dx,
+                               lmh_stream_t stream) {
+  LMH_CHECK_ARG(x && y && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && ksize > 0 && stride > 0);
+  const int64_t total = (int64_t)N * OH * OW * C;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, dy, N, H, W, C,
+                     ksize, stride, pad_top, pad_left, OH, OW, dx);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+

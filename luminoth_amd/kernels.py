@@ -85,9 +85,9 @@ class _timed(object):
         self.on = _Profile.enabled
         if self.on:
             kid = _lib.load().lmh_conv2d_kernel_id(ctypes.byref(d), op)
-            gen = ',generic' if kid >= 1000000 else ''
+            gen = '_gen' if kid >= 1000000 else ''
             kid %= 1000000
-            self.name = '%s<%d,%d%s>' % (_OPN[op], kid // 1000, kid % 1000, gen)
+            self.name = '%s%s<%d,%d>' % (_OPN[op], gen, kid // 1000, kid % 1000)
             self.flops = _conv_flops(d)
 
     def __enter__(self):
