@@ -31,355 +31,7 @@
 
 __device__ __attribute__((aligned(64))) float lmh_zero_page[16];  // zero-initialised: padding source
 
-// ============================================================================
-// forward (fast path: C % 32 == 0, K % 4 == 0)
-// ============================================================================
-template <int BM, int BN>
-__global__ void __launch_bounds__(256)
-k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
-           const float* __restrict__ scale, const float* __restrict__ shift,
-           const float* __restrict__ residual, float* __restrict__ y) {
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AJ = BM / 32, BJ = BN / 32;
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int M = d.N * d.OH * d.OW, K = d.K, C = d.C;
-  const int tiles_n = (K + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int CC = C / BK, KT = d.R * d.S * CC;
-
-  const int kq = tid & 7;
-  int a_n[AJ], a_ih0[AJ], a_iw0[AJ];
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) {
-    const int p = m0 + (tid >> 3) + 32 * j;
-    if (p < M) {
-      const int ow = p % d.OW, t = p / d.OW;
-      a_n[j] = t / d.OH;
-      a_ih0[j] = (t % d.OH) * d.stride - d.pad_top;
-      a_iw0[j] = ow * d.stride - d.pad_left;
-    } else { a_n[j] = -1; a_ih0[j] = 0; a_iw0[j] = 0; }
-  }
-  const float* pa[AJ];
-  int inca[AJ];
-  auto setup_rs = [&](int rs) {
-    const int r = rs / d.S, s = rs - r * d.S;
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const int ih = a_ih0[j] + r * d.dilation, iw = a_iw0[j] + s * d.dilation;
-      const bool ok = a_n[j] >= 0 && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-      pa[j] = ok ? x + ((size_t)(a_n[j] * d.H + ih) * d.W + iw) * C + 4 * kq : lmh_zero_page;
-      inca[j] = ok ? BK : 0;
-    }
-  };
-  constexpr int BROW_T = BN / 4, BROW_STEP = 256 / BROW_T;
-  const int bx4 = tid % BROW_T, bk = tid / BROW_T;
-  const bool b_ok = (n0 + 4 * bx4) < K;
-  const float* pb[BJ];
-  const size_t incb = b_ok ? (size_t)BK * K : 0;
-#pragma unroll
-  for (int j = 0; j < BJ; ++j)
-    pb[j] = b_ok ? w + (size_t)(bk + BROW_STEP * j) * K + n0 + 4 * bx4 : lmh_zero_page;
-
-  float4 ra[AJ], rb[BJ];
-  auto load_tile = [&]() {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) { ra[j] = *reinterpret_cast<const float4*>(pa[j]); pa[j] += inca[j]; }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) { rb[j] = *reinterpret_cast<const float4*>(pb[j]); pb[j] += incb; }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j)
-      *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * j) * LDK + 4 * kq]) = ra[j];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j)
-      *reinterpret_cast<float4*>(&Bs[buf][(bk + BROW_STEP * j) * BN + 4 * bx4]) = rb[j];
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
-
-  int rs = 0, cc = 0;
-  setup_rs(0);
-  load_tile();
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) {
-      if (++cc == CC) { cc = 0; setup_rs(++rs); }
-      load_tile();
-    }
-    mfma_stage<TM, TN, true, false, LDK, BN>(As[cur], Bs[cur], acc, wm * (BM / 2), wn * (BN / 2), lane);
-    if (more) store_tile(cur ^ 1);
-    __syncthreads();
-  }
-
-  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int col = n0 + wn * (BN / 2) + tn * 32 + col_l;
-    if (col >= K) continue;
-    const float sc = scale ? scale[col] : 1.f;
-    const float sh = shift ? shift[col] : 0.f;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase;
-        if (row < M) {
-          float v = acc[tm][tn][i];
-          if (scale) v = v * sc;
-          v = v + sh;
-          if (residual) v += residual[(size_t)row * K + col];
-          y[(size_t)row * K + col] = apply_act(v, d.act);
-        }
-      }
-    }
-  }
-}
-
-// ============================================================================
-// backward data (fast path: K % 32 == 0)
-// dx[p, c] = sum_{r,s,k} dy[opix(p,r,s), k] * kscale[k] * w[r,s,c,k]   (+ addend)
-// ============================================================================
-template <int BM, int BN>
-__global__ void __launch_bounds__(256)
-k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
-                const float* __restrict__ kscale, const float* __restrict__ addend,
-                float* __restrict__ dx) {
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AJ = BM / 32, BJ = BN / 32;
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int M = d.N * d.H * d.W, K = d.K, C = d.C;
-  const int KC = K / BK, KT = d.R * d.S * KC;
-  const int tiles_n = (C + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int kq = tid & 7;
-  int a_n[AJ], a_h[AJ], a_w[AJ];
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) {
-    const int p = m0 + (tid >> 3) + 32 * j;
-    if (p < M) {
-      const int ww = p % d.W, t = p / d.W;
-      a_w[j] = ww + d.pad_left;
-      a_h[j] = (t % d.H) + d.pad_top;
-      a_n[j] = t / d.H;
-    } else { a_n[j] = -1; a_h[j] = 0; a_w[j] = 0; }
-  }
-  const float* pa[AJ];
-  int inca[AJ];
-  const float* pb[BJ];
-  int incb[BJ];
-  auto setup_rs = [&](int rs) {
-    const int r = rs / d.S, s = rs - r * d.S;
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const int th = a_h[j] - r * d.dilation, tw = a_w[j] - s * d.dilation;
-      int oh = th, ow = tw;
-      bool ok = a_n[j] >= 0 && th >= 0 && tw >= 0;
-      if (d.stride > 1) {
-        oh = th / d.stride; ow = tw / d.stride;
-        ok = ok && (oh * d.stride == th) && (ow * d.stride == tw);
-      }
-      ok = ok && oh < d.OH && ow < d.OW;
-      pa[j] = ok ? dy + ((size_t)(a_n[j] * d.OH + oh) * d.OW + ow) * K + 4 * kq : lmh_zero_page;
-      inca[j] = ok ? BK : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-      const int c = n0 + (tid >> 3) + 32 * j;
-      const bool ok = c < C;
-      pb[j] = ok ? w + ((size_t)rs * C + c) * K + 4 * kq : lmh_zero_page;
-      incb[j] = ok ? BK : 0;
-    }
-  };
-  float4 ra[AJ], rb[BJ];
-  int kcur = 0;  // k offset of the tile being loaded (for kscale)
-  auto load_tile = [&]() {
-    float4 ks = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (kscale) ks = *reinterpret_cast<const float4*>(kscale + kcur + 4 * kq);
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      float4 v = *reinterpret_cast<const float4*>(pa[j]);
-      pa[j] += inca[j];
-      v.x *= ks.x; v.y *= ks.y; v.z *= ks.z; v.w *= ks.w;
-      ra[j] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) { rb[j] = *reinterpret_cast<const float4*>(pb[j]); pb[j] += incb[j]; }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j)
-      *reinterpret_cast<float4*>(&As[buf][((tid >> 3) + 32 * j) * LDK + 4 * kq]) = ra[j];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j)
-      *reinterpret_cast<float4*>(&Bs[buf][((tid >> 3) + 32 * j) * LDK + 4 * kq]) = rb[j];
-  };
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
-  int rs = 0, kc = 0;
-  setup_rs(0);
-  load_tile();
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) {
-      if (++kc == KC) { kc = 0; setup_rs(++rs); }
-      kcur = kc * BK;
-      load_tile();
-    }
-    mfma_stage<TM, TN, true, true, LDK, LDK>(As[cur], Bs[cur], acc, wm * (BM / 2), wn * (BN / 2), lane);
-    if (more) store_tile(cur ^ 1);
-    __syncthreads();
-  }
-  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int col = n0 + wn * (BN / 2) + tn * 32 + col_l;
-    if (col >= C) continue;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase;
-        if (row < M) {
-          float v = acc[tm][tn][i];
-          if (addend) v += addend[(size_t)row * C + col];
-          dx[(size_t)row * C + col] = v;
-        }
-      }
-  }
-}
-
-// ============================================================================
-// backward weight (fast path: C % 4 == 0, K % 4 == 0)
-// dw[rs, c, k] = sum_p x[pix(p,r,s), c] * dy[p, k];  split over gridDim.z
-// ============================================================================
-template <int BM, int BN>
-__global__ void __launch_bounds__(256)
-k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ dy,
-                  float* __restrict__ out, int kt_per_split) {
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AJ = BM / 32, BJ = BN / 32;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int P = d.N * d.OH * d.OW, K = d.K, C = d.C;
-  const int tiles_c = (C + BM - 1) / BM;
-  const int rs = blockIdx.x / tiles_c, m0 = (blockIdx.x % tiles_c) * BM;
-  const int n0 = blockIdx.y * BN;
-  const int r = rs / d.S, s = rs - r * d.S;
-  const int KT_all = (P + BK - 1) / BK;
-  const int kt_begin = blockIdx.z * kt_per_split;
-  const int kt_end = min(KT_all, kt_begin + kt_per_split);
-  constexpr int AROW_T = BM / 4, AROW_STEP = 256 / AROW_T;
-  constexpr int BROW_T = BN / 4, BROW_STEP = 256 / BROW_T;
-  const int ax4 = tid % AROW_T, ak = tid / AROW_T;
-  const int bx4 = tid % BROW_T, bk = tid / BROW_T;
-  const bool a_col_ok = (m0 + 4 * ax4) < C, b_col_ok = (n0 + 4 * bx4) < K;
-  // incremental pixel decode for the A rows of this thread
-  int pn[AJ], poh[AJ], pow_[AJ];
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) {
-    const int p = kt_begin * BK + ak + AROW_STEP * j;
-    pow_[j] = p % d.OW;
-    const int t = p / d.OW;
-    poh[j] = t % d.OH;
-    pn[j] = t / d.OH;
-  }
-  int bp[BJ];
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) bp[j] = kt_begin * BK + bk + BROW_STEP * j;
-  const float* xb = x + m0 + 4 * ax4;
-  const float* dyb = dy + n0 + 4 * bx4;
-  float4 ra[AJ], rb[BJ];
-  auto load_tile = [&]() {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const int ih = poh[j] * d.stride - d.pad_top + r * d.dilation;
-      const int iw = pow_[j] * d.stride - d.pad_left + s * d.dilation;
-      const bool ok = a_col_ok && pn[j] < d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-      const float* p = ok ? xb + ((size_t)(pn[j] * d.H + ih) * d.W + iw) * C : lmh_zero_page;
-      ra[j] = *reinterpret_cast<const float4*>(p);
-      pow_[j] += BK;
-      while (pow_[j] >= d.OW) { pow_[j] -= d.OW; ++poh[j]; }
-      while (poh[j] >= d.OH) { poh[j] -= d.OH; ++pn[j]; }
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-      const bool ok = b_col_ok && bp[j] < P;
-      const float* p = ok ? dyb + (size_t)bp[j] * K : lmh_zero_page;
-      rb[j] = *reinterpret_cast<const float4*>(p);
-      bp[j] += BK;
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j)
-      *reinterpret_cast<float4*>(&As[buf][(ak + AROW_STEP * j) * BM + 4 * ax4]) = ra[j];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j)
-      *reinterpret_cast<float4*>(&Bs[buf][(bk + BROW_STEP * j) * BN + 4 * bx4]) = rb[j];
-  };
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
-  if (kt_begin < kt_end) {
-    load_tile();
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    const bool more = kt + 1 < kt_end;
-    if (more) load_tile();
-    mfma_stage<TM, TN, false, false, BM, BN>(As[cur], Bs[cur], acc, wm * (BM / 2), wn * (BN / 2), lane);
-    if (more) store_tile(cur ^ 1);
-    __syncthreads();
-  }
-  float* o = out + (size_t)blockIdx.z * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;
-  const int col_l = lane & 31, rbase = 4 * (lane >> 5);
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int col = n0 + wn * (BN / 2) + tn * 32 + col_l;
-    if (col >= K) continue;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase;
-        if (row < C) o[(size_t)row * K + col] = acc[tm][tn][i];
-      }
-  }
-}
+#include "conv_fast.h"
 
 // ============================================================================
 // host dispatch
@@ -403,7 +55,7 @@ static void pick_tile(int64_t M, int64_t Ncols, int* bm, int* bn) {
 }
 
 static bool fwd_fast(const lmh_conv_desc* d) { return (d->C % BK) == 0 && (d->K & 3) == 0; }
-static bool bwd_data_fast(const lmh_conv_desc* d) { return (d->K % BK) == 0; }
+static bool bwd_data_fast(const lmh_conv_desc* d) { return (d->K % BK) == 0 && (d->C & 3) == 0; }
 static bool bwd_weight_fast(const lmh_conv_desc* d) { return (d->C & 3) == 0 && (d->K & 3) == 0; }
 
 extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,

@@ -3,6 +3,9 @@
 #include "lmh_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: loads stay loads (float4 struct copies
+                                                            // through address-space-ambiguous pointers become memcpy -> scratch)
+extern __device__ float lmh_zero_page[16];
 
 #define BK 32
 #define LDK (BK + 4)  // row stride (floats) of K-contiguous LDS tiles: 9*m mod 16 slots, conflict-free b128

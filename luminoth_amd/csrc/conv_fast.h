@@ -1,0 +1,493 @@
+// Fast-path implicit-GEMM convolution kernels (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// Structure shared by forward / backward-data / backward-weight:
+//   * 256 threads = 4 waves (2x2), block tile BM x BN in {128x128, 128x64, 64x128, 64x64}, BK = 32;
+//   * global -> VGPR prefetch of stage t+1 is issued (unconditionally: the last
+//     iteration re-reads a valid address and drops the data) before the MFMAs
+//     of stage t and written to the OTHER LDS buffer after them: one barrier
+//     per stage, HBM/L2 latency hidden under 64 MFMAs (4096 matrix cycles);
+//   * LDS -> VGPR operand fragments are software pipelined in 4 groups of 4
+//     k-pairs: group g+1 is read while the MFMAs of group g issue, so one wave
+//     per SIMD is enough to keep the matrix pipe busy;
+//   * K-contiguous operands sit in LDS as [row][BK+4] and are read with
+//     conflict-free ds_read_b128; K-major operands sit as [BK][cols] and are
+//     read with conflict-free ds_read_b32;
+//   * the epilogue goes through LDS (the operand buffers are dead by then):
+//     accumulators are transposed into a row-major tile and leave the CU as
+//     float4 rows (512 contiguous bytes per 32 lanes) with scale / shift /
+//     residual / activation fused in.
+// No lambdas here on purpose: the prefetch registers must stay in VGPRs (an
+// earlier lambda-based version was demoted to scratch by the compiler).
+#pragma once
+#include "conv_common.h"
+
+template <int T, bool KC, int LD>
+__device__ __forceinline__ void load_frag(const float* __restrict__ S, int off, int g, int h, int l31,
+                                          float (&f)[T][4]) {
+  const int kb = 16 * h + 4 * g;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    if (KC) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&S[(off + t * 32 + l31) * LD + kb]);
+      f[t][0] = v.x; f[t][1] = v.y; f[t][2] = v.z; f[t][3] = v.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[t][i] = S[(kb + i) * LD + off + t * 32 + l31];
+    }
+  }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void mfma_group(const float (&a)[TM][4], const float (&b)[TN][4],
+                                           f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][i], b[tn][i], acc[tm][tn], 0, 0, 0);
+}
+
+// One BK=32 stage out of LDS, fragment reads pipelined one group ahead.
+template <int TM, int TN, bool A_KC, bool B_KC, int LDA, int LDB>
+__device__ __forceinline__ void mfma_stage_pipelined(const float* __restrict__ As, const float* __restrict__ Bs,
+                                                     f32x16 (&acc)[TM][TN], int a_off, int b_off, int lane) {
+  const int h = lane >> 5, l31 = lane & 31;
+  float a0[TM][4], b0[TN][4], a1[TM][4], b1[TN][4];
+  // sched_barrier(0): nothing moves across — keeps the reads of group g+1 AHEAD of the MFMAs of group g
+  // (left alone, the scheduler sinks every read to just before its first use and the wave stalls on LDS).
+  load_frag<TM, A_KC, LDA>(As, a_off, 0, h, l31, a0);
+  load_frag<TN, B_KC, LDB>(Bs, b_off, 0, h, l31, b0);
+  load_frag<TM, A_KC, LDA>(As, a_off, 1, h, l31, a1);
+  load_frag<TN, B_KC, LDB>(Bs, b_off, 1, h, l31, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_group<TM, TN>(a0, b0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  load_frag<TM, A_KC, LDA>(As, a_off, 2, h, l31, a0);
+  load_frag<TN, B_KC, LDB>(Bs, b_off, 2, h, l31, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_group<TM, TN>(a1, b1, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  load_frag<TM, A_KC, LDA>(As, a_off, 3, h, l31, a1);
+  load_frag<TN, B_KC, LDB>(Bs, b_off, 3, h, l31, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_group<TM, TN>(a0, b0, acc);
+  mfma_group<TM, TN>(a1, b1, acc);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
+}
+
+// accumulators -> row-major LDS tile Cs[BM][BN + 4]
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void acc_to_lds(float* __restrict__ Cs, const f32x16 (&acc)[TM][TN], int wm, int wn,
+                                           int lane) {
+  constexpr int LDC = BN + 4;
+  const int l31 = lane & 31, rbase = 4 * (lane >> 5);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase;
+        Cs[row * LDC + wn * (BN / 2) + tn * 32 + l31] = acc[tm][tn][i];
+      }
+}
+
+// ============================================================================
+// forward (fast path: C % 32 == 0, K % 4 == 0)
+//   y[p, k] = act( sum_{r,s,c} x[pix(p,r,s), c] * w[r,s,c,k] * scale[k] + shift[k] + res[p,k] )
+//   GEMM M = N*OH*OW, N = K, Kg = R*S*C.  A: gather, K-contiguous.  B: HWIO, K-major.
+// ============================================================================
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
+           const float* __restrict__ scale, const float* __restrict__ shift,
+           const float* __restrict__ residual, float* __restrict__ y) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32, BJ = BN / 32;
+  constexpr int A_SZ = BM * LDK, B_SZ = BK * BN;
+  constexpr int LDC = BN + 4;
+  constexpr int SMEM = (2 * (A_SZ + B_SZ) > BM * LDC) ? 2 * (A_SZ + B_SZ) : BM * LDC;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float* const As = smem;               // [2][BM][LDK]
+  float* const Bs = smem + 2 * A_SZ;    // [2][BK][BN]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = d.N * d.OH * d.OW, K = d.K, C = d.C;
+  const int tiles_n = (K + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int CC = C / BK, KT = d.R * d.S * CC;
+
+  // ---- A gather state: AJ rows (output pixels) per thread, 4 channels each
+  const int kq = tid & 7, arow = tid >> 3;
+  int a_n[AJ], a_ih0[AJ], a_iw0[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int p = m0 + arow + 32 * j;
+    if (p < M) {
+      const int ow = p % d.OW, t = p / d.OW;
+      a_n[j] = t / d.OH;
+      a_ih0[j] = (t % d.OH) * d.stride - d.pad_top;
+      a_iw0[j] = ow * d.stride - d.pad_left;
+    } else { a_n[j] = -1; a_ih0[j] = 0; a_iw0[j] = 0; }
+  }
+  const float* pa[AJ];
+  int inca[AJ];
+#define FWD_SETUP_RS(rs_)                                                                         \
+  do {                                                                                            \
+    const int r_ = (rs_) / d.S, s_ = (rs_) - r_ * d.S;                                            \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                              \
+      const int ih = a_ih0[j] + r_ * d.dilation, iw = a_iw0[j] + s_ * d.dilation;                 \
+      const bool ok = a_n[j] >= 0 && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W; \
+      pa[j] = ok ? x + ((size_t)(a_n[j] * d.H + ih) * d.W + iw) * C + 4 * kq : lmh_zero_page;     \
+      inca[j] = ok ? BK : 0;                                                                      \
+    }                                                                                             \
+  } while (0)
+  // ---- B (weights, [Kg][K]) state
+  constexpr int BROW_T = BN / 4, BROW_STEP = 256 / BROW_T;
+  const int bx4 = tid % BROW_T, bk = tid / BROW_T;
+  const bool b_ok = (n0 + 4 * bx4) < K;
+  const float* pb = b_ok ? w + (size_t)bk * K + n0 + 4 * bx4 : lmh_zero_page;
+  const size_t incb = b_ok ? (size_t)BK * K : 0;          // one stage
+  const size_t rowb = b_ok ? (size_t)BROW_STEP * K : 0;   // next row slot of this thread
+
+  f32x4 ra[AJ], rb[BJ];
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+
+  int rs = 0, cc = 0;
+  FWD_SETUP_RS(0);
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb + j * rowb);
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(&As[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(&Bs[(bk + BROW_STEP * j) * BN + 4 * bx4]) = rb[j];
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < KT;
+    if (more) {   // advance to stage kt+1 (block-uniform branch); otherwise re-read stage kt, unused
+      if (++cc == CC) { cc = 0; ++rs; FWD_SETUP_RS(rs); }
+      else {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) pa[j] += inca[j];
+      }
+      pb += incb;
+    }
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb + j * rowb);
+    __builtin_amdgcn_sched_barrier(0);   // the prefetch is issued BEFORE the MFMAs (the scheduler would sink it)
+    mfma_stage_pipelined<TM, TN, true, false, LDK, BN>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2),
+                                                       wn * (BN / 2), lane);
+    if (more) {
+      float* Ad = As + (cur ^ 1) * A_SZ;
+      float* Bd = Bs + (cur ^ 1) * B_SZ;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(&Ad[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(&Bd[(bk + BROW_STEP * j) * BN + 4 * bx4]) = rb[j];
+    }
+    __syncthreads();
+  }
+#undef FWD_SETUP_RS
+
+  // ---- epilogue through LDS: float4 rows
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  const int c4 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 4 * c4;
+  if (col < K) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) sc = *reinterpret_cast<const float4*>(scale + col);
+    if (shift) sh = *reinterpret_cast<const float4*>(shift + col);
+    const int act = d.act;
+#pragma unroll 4
+    for (int r = r0; r < BM; r += RSTEP) {
+      const int row = m0 + r;
+      if (row >= M) break;
+      float4 v = *reinterpret_cast<const float4*>(&smem[r * LDC + 4 * c4]);
+      if (scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+      v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
+      if (residual) {
+        const float4 rr = *reinterpret_cast<const float4*>(residual + (size_t)row * K + col);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+      *reinterpret_cast<float4*>(y + (size_t)row * K + col) = v;
+    }
+  }
+}
+
+// ============================================================================
+// backward data (fast path: K % 32 == 0, C % 4 == 0)
+//   dx[p, c] = sum_{r,s,k} dy[opix(p,r,s), k] * kscale[k] * w[r,s,c,k]   (+ addend)
+//   GEMM M = N*H*W, N = C, Kg = R*S*K.  A: dy gather (K-contiguous).  B: w[rs][c][k] (K-contiguous).
+// ============================================================================
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
+                const float* __restrict__ kscale, const float* __restrict__ addend,
+                float* __restrict__ dx) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32, BJ = BN / 32;
+  constexpr int A_SZ = BM * LDK, B_SZ = BN * LDK;
+  constexpr int LDC = BN + 4;
+  constexpr int SMEM = (2 * (A_SZ + B_SZ) > BM * LDC) ? 2 * (A_SZ + B_SZ) : BM * LDC;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float* const As = smem;               // [2][BM][LDK]
+  float* const Bs = smem + 2 * A_SZ;    // [2][BN][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = d.N * d.H * d.W, K = d.K, C = d.C;
+  const int KC = K / BK, KT = d.R * d.S * KC;
+  const int tiles_n = (C + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int kq = tid & 7, arow = tid >> 3;
+  int a_n[AJ], a_h[AJ], a_w[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int p = m0 + arow + 32 * j;
+    if (p < M) {
+      const int ww = p % d.W, t = p / d.W;
+      a_w[j] = ww + d.pad_left;
+      a_h[j] = (t % d.H) + d.pad_top;
+      a_n[j] = t / d.H;
+    } else { a_n[j] = -1; a_h[j] = 0; a_w[j] = 0; }
+  }
+  const float* pa[AJ];
+  int inca[AJ];
+#define BD_SETUP_RS(rs_)                                                                                \
+  do {                                                                                                  \
+    const int r_ = (rs_) / d.S, s_ = (rs_) - r_ * d.S;                                                  \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                    \
+      const int th = a_h[j] - r_ * d.dilation, tw = a_w[j] - s_ * d.dilation;                           \
+      int oh = th, ow = tw;                                                                             \
+      bool ok = a_n[j] >= 0 && th >= 0 && tw >= 0;                                                      \
+      if (d.stride > 1) {                                                                               \
+        oh = th / d.stride; ow = tw / d.stride;                                                         \
+        ok = ok && (oh * d.stride == th) && (ow * d.stride == tw);                                      \
+      }                                                                                                 \
+      ok = ok && oh < d.OH && ow < d.OW;                                                                \
+      pa[j] = ok ? dy + ((size_t)(a_n[j] * d.OH + oh) * d.OW + ow) * K + 4 * kq : lmh_zero_page;        \
+      inca[j] = ok ? BK : 0;                                                                            \
+    }                                                                                                   \
+  } while (0)
+  // B rows = input channels c; pointer walks k within a tap, then jumps to the next tap
+  const float* pb[BJ];
+  int incb[BJ];
+  size_t tapb[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int c = n0 + arow + 32 * j;
+    const bool ok = c < C;
+    pb[j] = ok ? w + (size_t)c * K + 4 * kq : lmh_zero_page;
+    incb[j] = ok ? BK : 0;
+    tapb[j] = ok ? (size_t)C * K - K + BK : 0;
+  }
+  const float* pks = kscale ? kscale + 4 * kq : lmh_zero_page;
+  const int incks = kscale ? BK : 0;
+
+  f32x4 ra[AJ], rb[BJ], ks;
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  int rs = 0, kc = 0;
+  BD_SETUP_RS(0);
+  ks = *reinterpret_cast<const f32x4*>(pks);
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb[j]);
+  if (kscale) {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) ra[j] *= ks;
+  }
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(&As[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(&Bs[(arow + 32 * j) * LDK + 4 * kq]) = rb[j];
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < KT;
+    if (more) {
+      if (++kc == KC) {
+        kc = 0; ++rs;
+        BD_SETUP_RS(rs);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) pb[j] += tapb[j];
+        pks -= (KC - 1) * incks;
+      } else {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) pa[j] += inca[j];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) pb[j] += incb[j];
+        pks += incks;
+      }
+    }
+    ks = *reinterpret_cast<const f32x4*>(pks);
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_stage_pipelined<TM, TN, true, true, LDK, LDK>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2),
+                                                       wn * (BN / 2), lane);
+    if (more) {
+      float* Ad = As + (cur ^ 1) * A_SZ;
+      float* Bd = Bs + (cur ^ 1) * B_SZ;
+      if (kscale) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) ra[j] *= ks;
+      }
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(&Ad[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(&Bd[(arow + 32 * j) * LDK + 4 * kq]) = rb[j];
+    }
+    __syncthreads();
+  }
+#undef BD_SETUP_RS
+
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  const int c4 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 4 * c4;
+  if (col < C) {
+#pragma unroll 4
+    for (int r = r0; r < BM; r += RSTEP) {
+      const int row = m0 + r;
+      if (row >= M) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
+      if (addend) v += *reinterpret_cast<const f32x4*>(addend + (size_t)row * C + col);
+      *reinterpret_cast<f32x4*>(dx + (size_t)row * C + col) = v;
+    }
+  }
+}
+
+// ============================================================================
+// backward weight (fast path: C % 4 == 0, K % 4 == 0)
+//   dw[rs, c, k] = sum_p x[pix(p,r,s), c] * dy[p, k];  reduction split over gridDim.z
+//   GEMM M = C (per tap), N = K, Kg = P = N*OH*OW.  Both operands K-major ([pixel][channel]).
+// ============================================================================
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ dy,
+                  float* __restrict__ out, int kt_per_split) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32, BJ = BN / 32;
+  constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
+  constexpr int LDC = BN + 4;
+  constexpr int SMEM = (2 * (A_SZ + B_SZ) > BM * LDC) ? 2 * (A_SZ + B_SZ) : BM * LDC;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float* const As = smem;               // [2][BK][BM]
+  float* const Bs = smem + 2 * A_SZ;    // [2][BK][BN]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int P = d.N * d.OH * d.OW, K = d.K, C = d.C;
+  const int tiles_c = (C + BM - 1) / BM;
+  const int rs = blockIdx.x / tiles_c, m0 = (blockIdx.x % tiles_c) * BM;
+  const int n0 = blockIdx.y * BN;
+  const int r = rs / d.S, s = rs - r * d.S;
+  const int KT_all = (P + BK - 1) / BK;
+  const int kt_begin = blockIdx.z * kt_per_split;
+  const int kt_end = min(KT_all, kt_begin + kt_per_split);
+  constexpr int AROW_T = BM / 4, AROW_STEP = 256 / AROW_T;
+  constexpr int BROW_T = BN / 4, BROW_STEP = 256 / BROW_T;
+  const int ax4 = tid % AROW_T, ak = tid / AROW_T;
+  const int bx4 = tid % BROW_T, bk = tid / BROW_T;
+  const bool a_col_ok = (m0 + 4 * ax4) < C, b_col_ok = (n0 + 4 * bx4) < K;
+  const int dh0 = r * d.dilation - d.pad_top, dw0 = s * d.dilation - d.pad_left;
+  // incremental pixel decode for the A rows of this thread
+  int pn[AJ], poh[AJ], pow_[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int p = kt_begin * BK + ak + AROW_STEP * j;
+    pow_[j] = p % d.OW;
+    const int t = p / d.OW;
+    poh[j] = t % d.OH;
+    pn[j] = t / d.OH;
+  }
+  int bp = kt_begin * BK + bk;
+  const float* xb = x + m0 + 4 * ax4;
+  const float* pdy = dy + (size_t)bp * K + n0 + 4 * bx4;
+  const size_t dy_row = (size_t)BROW_STEP * K, dy_stage = (size_t)BK * K;
+  f32x4 ra[AJ], rb[BJ];
+#define BW_LOAD()                                                                                          \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                       \
+      const int ih = poh[j] * d.stride + dh0, iw = pow_[j] * d.stride + dw0;                               \
+      const bool ok = a_col_ok && pn[j] < d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W; \
+      const float* p_ = ok ? xb + ((size_t)(pn[j] * d.H + ih) * d.W + iw) * C : lmh_zero_page;             \
+      ra[j] = *reinterpret_cast<const f32x4*>(p_);                                                         \
+      pow_[j] += BK;                                                                                       \
+      while (pow_[j] >= d.OW) { pow_[j] -= d.OW; ++poh[j]; }                                               \
+      while (poh[j] >= d.OH) { poh[j] -= d.OH; ++pn[j]; }                                                  \
+    }                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                                       \
+      const bool ok = b_col_ok && (bp + BROW_STEP * j) < P;                                                \
+      const float* p_ = ok ? pdy + j * dy_row : lmh_zero_page;                                             \
+      rb[j] = *reinterpret_cast<const f32x4*>(p_);                                                         \
+    }                                                                                                      \
+    bp += BK; pdy += dy_stage;                                                                             \
+  } while (0)
+#define BW_STORE(buf_)                                                                                     \
+  do {                                                                                                     \
+    float* Ad = As + (buf_) * A_SZ;                                                                        \
+    float* Bd = Bs + (buf_) * B_SZ;                                                                        \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                         \
+        *reinterpret_cast<f32x4*>(&Ad[(ak + AROW_STEP * j) * BM + 4 * ax4]) = ra[j];                       \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j)                                                         \
+        *reinterpret_cast<f32x4*>(&Bd[(bk + BROW_STEP * j) * BN + 4 * bx4]) = rb[j];                       \
+  } while (0)
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  BW_LOAD();
+  BW_STORE(0);
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    BW_LOAD();   // stage kt+1; past the end of this split the rows are still valid pixels (or the zero page)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_stage_pipelined<TM, TN, false, false, BM, BN>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2),
+                                                       wn * (BN / 2), lane);
+    if (kt + 1 < kt_end) BW_STORE(cur ^ 1);
+    __syncthreads();
+  }
+#undef BW_LOAD
+#undef BW_STORE
+
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  float* o = out + (size_t)blockIdx.z * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;
+  constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  const int c4 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 4 * c4;
+  if (col < K) {
+#pragma unroll 4
+    for (int rr = r0; rr < BM; rr += RSTEP) {
+      const int row = m0 + rr;
+      if (row >= C) break;
+      *reinterpret_cast<f32x4*>(o + (size_t)row * K + col) = *reinterpret_cast<const f32x4*>(&smem[rr * LDC + 4 * c4]);
+    }
+  }
+}

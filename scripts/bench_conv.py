@@ -32,7 +32,7 @@ flt = sys.argv[1] if len(sys.argv) > 1 else ''
 dev = torch.device('cuda:0')
 
 
-def timeit(fn, iters=10):
+def timeit(fn, iters=40):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
