@@ -224,7 +224,7 @@ int lmh_rcnn_proposal(const lmh_rcnn_proposal_desc* d, const float* proposals,
 int lmh_roi_pool_fwd(const float* feat, const float* rois, const int32_t* roi_count, int B, int R,
                      int FH, int FW, int C, float im_h, float im_w, int ph, int pw, float* out,
                      uint8_t* argmax, lmh_stream_t stream);
-/* dfeat must be zeroed by the caller (scatter-add, CropAndResizeGradImage order). */
+/* dfeat is OVERWRITTEN with the full gradient (CropAndResizeGradImage scatter-add, done in LDS slabs). */
 int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const float* rois,
                      const int32_t* roi_count, int B, int R, int FH, int FW, int C, float im_h,
                      float im_w, int ph, int pw, float* dfeat, lmh_stream_t stream);

@@ -19,10 +19,6 @@ k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act, in
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(rows, r0 + rows_per_block);
   const float hi = (act == 2) ? 6.f : INFINITY;
-  if (partial) {
-    for (int c = threadIdx.x; c < K; c += 256) scol[c] = 0.f;
-    __syncthreads();
-  }
   if (VEC) {
     const int K4 = K >> 2;
     const int tpr = min(K4, 256), rstep = 256 / tpr;
@@ -43,12 +39,15 @@ k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act, in
           if (g) *reinterpret_cast<float4*>(g + o) = d4;
           s.x += d4.x; s.y += d4.y; s.z += d4.z; s.w += d4.w;
         }
-        if (partial) {
-          atomicAdd(&scol[4 * cc + 0], s.x);
-          atomicAdd(&scol[4 * cc + 1], s.y);
-          atomicAdd(&scol[4 * cc + 2], s.z);
-          atomicAdd(&scol[4 * cc + 3], s.w);
-        }
+        if (partial) *reinterpret_cast<float4*>(&scol[rsub * K + 4 * cc]) = s;   // rstep * K <= 4096 floats
+      }
+    }
+    if (partial && rstep > 1) {   // fold the rstep row-groups in a fixed order
+      __syncthreads();
+      for (int c = threadIdx.x; c < K; c += 256) {
+        float t = scol[c];
+        for (int g2 = 1; g2 < rstep; ++g2) t += scol[g2 * K + c];
+        scol[c] = t;
       }
     }
   } else {
@@ -70,25 +69,37 @@ k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act, in
   }
 }
 
-// out[c] = sum_b partial[b][c]  (sequential over b: deterministic)
+// out[c] = sum_b partial[b][c]: 32 columns x 8 row-groups per block, fixed summation tree (deterministic)
+__device__ __forceinline__ float colsum_partial(const float* __restrict__ partial, int nb, int K, int c, int g) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = g;
+  for (; b + 24 < nb; b += 32) {
+    s0 += partial[(size_t)b * K + c];
+    s1 += partial[(size_t)(b + 8) * K + c];
+    s2 += partial[(size_t)(b + 16) * K + c];
+    s3 += partial[(size_t)(b + 24) * K + c];
+  }
+  for (; b < nb; b += 8) s0 += partial[(size_t)b * K + c];
+  return (s0 + s1) + (s2 + s3);
+}
+
 __global__ void __launch_bounds__(256)
 k_colsum_finish(const float* __restrict__ partial, int nb, int K, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= K) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nb; b += 4) {
-    s0 += partial[(size_t)b * K + c];
-    s1 += partial[(size_t)(b + 1) * K + c];
-    s2 += partial[(size_t)(b + 2) * K + c];
-    s3 += partial[(size_t)(b + 3) * K + c];
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  red[g][cl] = (c < K) ? colsum_partial(partial, nb, K, c, g) : 0.f;
+  __syncthreads();
+  if (g == 0 && c < K) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += red[i][cl];
+    out[c] = t;
   }
-  for (; b < nb; ++b) s0 += partial[(size_t)b * K + c];
-  out[c] = (s0 + s1) + (s2 + s3);
 }
 
 static int act_bwd_blocks(int64_t rows, int K, int* rpb_out) {
-  int rpb = (int)((rows + 511) / 512);
+  int rpb = (int)((rows + 1023) / 1024);   // ~4 slabs per CU
   const int k4 = (K & 3) ? K : (K >> 2);
   const int rstep = k4 >= 256 ? 1 : 256 / k4;
   if (rpb < 4 * rstep) rpb = 4 * rstep;
@@ -123,7 +134,7 @@ extern "C" int lmh_act_bwd(const float* dy, const float* y, int act, int64_t row
   else
     hipLaunchKernelGGL((k_act_bwd<true>), dim3(nb), dim3(256), 0, st, dy, y, act, rows, K, g, partial, rpb);
   if (colsum)
-    hipLaunchKernelGGL(k_colsum_finish, dim3((K + 255) / 256), dim3(256), 0, st, partial, nb, K, colsum);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, partial, nb, K, colsum);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -137,8 +148,6 @@ k_bn_wdot(const float* __restrict__ w, float* __restrict__ dw, const float* __re
   __shared__ float scol[ACT_MAX_K];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(rsc, r0 + rows_per_block);
-  for (int c = threadIdx.x; c < K; c += 256) scol[c] = 0.f;
-  __syncthreads();
   const int K4 = K >> 2;
   const int tpr = min(K4, 256), rstep = 256 / tpr;
   const int c4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
@@ -154,24 +163,31 @@ k_bn_wdot(const float* __restrict__ w, float* __restrict__ dw, const float* __re
         d.x *= sc.x; d.y *= sc.y; d.z *= sc.z; d.w *= sc.w;
         *reinterpret_cast<float4*>(dw + o) = d;
       }
-      atomicAdd(&scol[4 * cc + 0], s.x);
-      atomicAdd(&scol[4 * cc + 1], s.y);
-      atomicAdd(&scol[4 * cc + 2], s.z);
-      atomicAdd(&scol[4 * cc + 3], s.w);
+      *reinterpret_cast<float4*>(&scol[rsub * K + 4 * cc]) = s;
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < K; c += 256) partial[(size_t)blockIdx.x * K + c] = scol[c];
+  for (int c = threadIdx.x; c < K; c += 256) {
+    float t = scol[c];
+    for (int g2 = 1; g2 < rstep; ++g2) t += scol[g2 * K + c];
+    partial[(size_t)blockIdx.x * K + c] = t;
+  }
 }
 
 __global__ void __launch_bounds__(256)
 k_bn_finish(const float* __restrict__ partial, int nb, int K, const float* __restrict__ dbeta,
             const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dgamma) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= K) return;
-  float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += partial[(size_t)b * K + c];
-  dgamma[c] = rstd[c] * (s - mean[c] * dbeta[c]);
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  red[g][cl] = (c < K) ? colsum_partial(partial, nb, K, c, g) : 0.f;
+  __syncthreads();
+  if (g == 0 && c < K) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += red[i][cl];
+    dgamma[c] = rstd[c] * (t - mean[c] * dbeta[c]);
+  }
 }
 
 static int bn_blocks(int64_t rsc, int K, int* rpb_out) {
@@ -202,7 +218,7 @@ extern "C" int lmh_bn_param_grads(const float* w, float* dw_raw_inout, const flo
   hipStream_t st = (hipStream_t)stream;
   float* partial = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(k_bn_wdot, dim3(nb), dim3(256), 0, st, w, dw_raw_inout, scale, rsc, K, partial, rpb);
-  hipLaunchKernelGGL(k_bn_finish, dim3((K + 255) / 256), dim3(256), 0, st, partial, nb, K, dbeta, mean, rstd,
+  hipLaunchKernelGGL(k_bn_finish, dim3((K + 31) / 32), dim3(256), 0, st, partial, nb, K, dbeta, mean, rstd,
                      dgamma);
   LMH_CHECK_LAUNCH();
   return LMH_OK;

@@ -349,7 +349,7 @@ def roi_pool_bwd(dout, argmax, rois, roi_count, feat_shape, im_shape, ph=7, pw=7
     lib = _lib.load()
     B, FH, FW, C = feat_shape
     R = rois.shape[1]
-    dfeat = out if out is not None else torch.zeros(feat_shape, dtype=torch.float32, device=dout.device)
+    dfeat = out if out is not None else torch.empty(feat_shape, dtype=torch.float32, device=dout.device)   # overwritten
     check(lib.lmh_roi_pool_bwd(_p(dout), _p(argmax), _p(rois), _p(roi_count), B, R, FH, FW, C,
                                float(im_shape[0]), float(im_shape[1]), ph, pw, _p(dfeat), _stream()),
           'lmh_roi_pool_bwd')
