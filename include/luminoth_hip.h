@@ -86,6 +86,8 @@ int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* d
  * Returns BM*1000 + BN (+1000000 for the generic C%32 != 0 forward gather).  Used by
  * bench.py to attribute per-kernel time / algorithmic FLOPs (roofline). */
 int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op);
+/* Diagnostics: force the block tile (bm,bn in {64,128}) and the bwd-weight split count; 0 = automatic. */
+void lmh_conv2d_force_config(int bm, int bn, int splits);
 /* g = dy * (y > 0 [&& y < 6 for relu6]) (g may be NULL); colsum[k] = sum_rows g
  * (may be NULL; written, not accumulated; two-stage deterministic reduction through ws). */
 size_t lmh_act_bwd_workspace_bytes(int64_t rows, int K);

@@ -45,13 +45,23 @@ static int check_desc(const lmh_conv_desc* d) {
   return LMH_OK;
 }
 
-// pick the block tile so the grid covers the chip at least ~2x when possible
+// Tuning override (diagnostics only: scripts/bench_conv.py sweeps tile shapes / split counts with it).
+static int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
+extern "C" void lmh_conv2d_force_config(int bm, int bn, int splits) {
+  g_force_bm = bm; g_force_bn = bn; g_force_splits = splits;
+}
+
+// Block tile: minimise (tile rounds over the 256 CUs) x (tile area), i.e. the matrix-pipe time of the
+// busiest CU; ties go to the larger tile (less L2 traffic).  Fitted to scripts/sweep_conv.py on MI355X.
 static void pick_tile(int64_t M, int64_t Ncols, int* bm, int* bn) {
-  const int64_t t128 = ((M + 127) / 128) * ((Ncols + 127) / 128);
-  if (Ncols > 64 && t128 >= 512) { *bm = 128; *bn = 128; return; }
-  const int64_t t12864 = ((M + 127) / 128) * ((Ncols + 63) / 64);
-  if (t12864 >= 512) { *bm = 128; *bn = 64; return; }
-  *bm = 64; *bn = 64;
+  if (g_force_bm && g_force_bn) { *bm = g_force_bm; *bn = g_force_bn; return; }
+  static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+  int64_t best = -1;
+  for (int i = 0; i < 3; ++i) {
+    const int64_t tiles = ((M + cand[i][0] - 1) / cand[i][0]) * ((Ncols + cand[i][1] - 1) / cand[i][1]);
+    const int64_t cost = ((tiles + 255) / 256) * cand[i][0] * cand[i][1];
+    if (best < 0 || cost < best) { best = cost; *bm = cand[i][0]; *bn = cand[i][1]; }
+  }
 }
 
 static bool fwd_fast(const lmh_conv_desc* d) { return (d->C % BK) == 0 && (d->K & 3) == 0; }
@@ -121,17 +131,29 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   return LMH_OK;
 }
 
+// Backward-weight plan: output tiles x split-K over the pixels.  128x128 tiles when there are >= 128 of
+// them, else 64x64 (4x the tiles, fewer splits => less partial-slab traffic); the split count is the
+// smallest one (>= 16 stages per block) that fills the 512 resident-block slots to >= 90 %.
 static void bwd_weight_plan(const lmh_conv_desc* d, int* bm, int* bn, int* splits, int* kt_per_split) {
-  *bm = (d->C >= 128) ? 128 : 64;
-  *bn = (d->K >= 128) ? 128 : 64;
+  const int64_t t128 = (int64_t)d->R * d->S * ((d->C + 127) / 128) * ((d->K + 127) / 128);
+  if (t128 >= 128 && d->C >= 128 && d->K >= 128) { *bm = 128; *bn = 128; }
+  else { *bm = 64; *bn = 64; }
+  if (g_force_bm && g_force_bn) { *bm = g_force_bm; *bn = g_force_bn; }
   const int64_t tiles = (int64_t)d->R * d->S * ((d->C + *bm - 1) / *bm) * ((d->K + *bn - 1) / *bn);
   const int64_t P = (int64_t)d->N * d->OH * d->OW;
   const int KT = (int)((P + BK - 1) / BK);
-  int64_t want = (768 + tiles - 1) / tiles;  // ~3 blocks per CU
-  int64_t max_split = KT / 8 > 0 ? KT / 8 : 1;  // >= 8 K-steps per block
-  if (want > max_split) want = max_split;
-  if (want < 1) want = 1;
-  *kt_per_split = (int)((KT + want - 1) / want);
+  int max_split = KT / 16 > 0 ? KT / 16 : 1;
+  if (max_split > 64) max_split = 64;
+  int want = 1;
+  double best_eff = -1.0;
+  for (int s = 1; s <= max_split; ++s) {
+    const double rounds = (double)(tiles * s) / 512.0;
+    const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
+    if (eff >= 0.9) { want = s; best_eff = eff; break; }
+    if (eff > best_eff + 1e-9) { best_eff = eff; want = s; }
+  }
+  if (g_force_splits) want = g_force_splits < KT ? g_force_splits : KT;
+  *kt_per_split = (KT + want - 1) / want;
   *splits = (KT + *kt_per_split - 1) / *kt_per_split;
 }
 
@@ -178,7 +200,8 @@ extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, con
 #define LAUNCH_BW(BM_, BN_)                                                                              \
   do {                                                                                                   \
     if (fast)                                                                                            \
-      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_>), grid, dim3(256), 0, st, *d, x, dy, out, kps);    \
+      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_>), grid, dim3(256), 0, st, *d, x, dy, out, kps,    \
+                         lmh_make_fastdiv((uint32_t)d->OW), lmh_make_fastdiv((uint32_t)d->OH));           \
     else                                                                                                 \
       hipLaunchKernelGGL((k_conv_bwd_weight_gen<BM_, BN_>), grid, dim3(256), 0, st, *d, x, dy, out, kps); \
   } while (0)

@@ -7,6 +7,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: loa
                                                             // through address-space-ambiguous pointers become memcpy -> scratch)
 extern __device__ float lmh_zero_page[16];
 
+// Unsigned division by a launch-time constant: q = (mulhi(n, m) + n) >> s, exact for n < 2^31.
+struct lmh_fastdiv { uint32_t m, s; };
+static inline lmh_fastdiv lmh_make_fastdiv(uint32_t dv) {
+  lmh_fastdiv f;
+  uint32_t s = 0;
+  while ((1ull << s) < dv) ++s;
+  f.s = s;
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - dv)) / dv + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned lmh_div(unsigned n, lmh_fastdiv f) { return (__umulhi(n, f.m) + n) >> f.s; }
+
 #define BK 32
 #define LDK (BK + 4)  // row stride (floats) of K-contiguous LDS tiles: 9*m mod 16 slots, conflict-free b128
 

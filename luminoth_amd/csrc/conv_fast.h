@@ -77,6 +77,59 @@ __device__ __forceinline__ void mfma_stage_pipelined(const float* __restrict__ A
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// Full pipeline stage (the "split write / re-issue" schedule): on entry the staging registers hold tile
+// t+1 (loaded during the previous stage).  Its ds_writes into the OTHER LDS buffer are interleaved with the
+// MFMAs of fragment group 0, the global loads of tile t+2 (same registers) with the MFMAs of group 1, so
+// neither the LDS-write pass nor the VMEM issue ever runs with the matrix pipe idle; fragment reads stay
+// one group ahead.  sched_group_barrier pins the MFMA : DS_WRITE / VMEM interleave inside each region,
+// sched_barrier(0) pins the regions.
+template <int TM, int TN, bool A_KC, bool B_KC, int LDA, int LDB, int NWR, int NLD, class WriteF, class LoadF>
+__device__ __forceinline__ void mfma_stage_split(const float* __restrict__ As, const float* __restrict__ Bs,
+                                                 f32x16 (&acc)[TM][TN], int a_off, int b_off, int lane,
+                                                 WriteF&& do_writes, LoadF&& do_loads) {
+  constexpr int NM = 4 * TM * TN;   // MFMAs per fragment group
+  const int h = lane >> 5, l31 = lane & 31;
+  float a0[TM][4], b0[TN][4], a1[TM][4], b1[TN][4];
+  load_frag<TM, A_KC, LDA>(As, a_off, 0, h, l31, a0);
+  load_frag<TN, B_KC, LDB>(Bs, b_off, 0, h, l31, b0);
+  load_frag<TM, A_KC, LDA>(As, a_off, 1, h, l31, a1);
+  load_frag<TN, B_KC, LDB>(Bs, b_off, 1, h, l31, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- group 0 MFMAs || ds_write of tile t+1
+  mfma_group<TM, TN>(a0, b0, acc);
+  do_writes();
+  {
+    constexpr int PER = (NM / NWR) > 0 ? (NM / NWR) : 1;
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- group 1 MFMAs || fragment reads of group 2 || global loads of tile t+2
+  load_frag<TM, A_KC, LDA>(As, a_off, 2, h, l31, a0);
+  load_frag<TN, B_KC, LDB>(Bs, b_off, 2, h, l31, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_group<TM, TN>(a1, b1, acc);
+  do_loads();
+  {
+    constexpr int PER = (NM / NLD) > 0 ? (NM / NLD) : 1;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_frag<TM, A_KC, LDA>(As, a_off, 3, h, l31, a1);
+  load_frag<TN, B_KC, LDB>(Bs, b_off, 3, h, l31, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_group<TM, TN>(a0, b0, acc);
+  mfma_group<TM, TN>(a1, b1, acc);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
 #pragma unroll
@@ -169,43 +222,44 @@ k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict
 
   int rs = 0, cc = 0;
   FWD_SETUP_RS(0);
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb + j * rowb);
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(&As[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(&Bs[(bk + BROW_STEP * j) * BN + 4 * bx4]) = rb[j];
+  // block-uniform pointer advance to the next BK slice (tap change re-derives the gather pointers)
+#define FWD_ADVANCE()                                                          \
+  do {                                                                         \
+    if (++cc == CC) { cc = 0; ++rs; FWD_SETUP_RS(rs); }                        \
+    else { _Pragma("unroll") for (int j = 0; j < AJ; ++j) pa[j] += inca[j]; }  \
+    pb += incb;                                                                \
+  } while (0)
+#define FWD_LOAD()                                                                                     \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);     \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb + j * rowb); \
+  } while (0)
+#define FWD_STORE(buf_)                                                                                \
+  do {                                                                                                 \
+    float* Ad = As + (buf_) * A_SZ;                                                                    \
+    float* Bd = Bs + (buf_) * B_SZ;                                                                    \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                     \
+        *reinterpret_cast<f32x4*>(&Ad[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];                        \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j)                                                     \
+        *reinterpret_cast<f32x4*>(&Bd[(bk + BROW_STEP * j) * BN + 4 * bx4]) = rb[j];                   \
+  } while (0)
+  FWD_LOAD();                       // tile 0
+  FWD_STORE(0);
+  if (KT > 1) FWD_ADVANCE();
+  FWD_LOAD();                       // tile 1 (or tile 0 again: never stored)
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) {   // advance to stage kt+1 (block-uniform branch); otherwise re-read stage kt, unused
-      if (++cc == CC) { cc = 0; ++rs; FWD_SETUP_RS(rs); }
-      else {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) pa[j] += inca[j];
-      }
-      pb += incb;
-    }
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb + j * rowb);
-    __builtin_amdgcn_sched_barrier(0);   // the prefetch is issued BEFORE the MFMAs (the scheduler would sink it)
-    mfma_stage_pipelined<TM, TN, true, false, LDK, BN>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2),
-                                                       wn * (BN / 2), lane);
-    if (more) {
-      float* Ad = As + (cur ^ 1) * A_SZ;
-      float* Bd = Bs + (cur ^ 1) * B_SZ;
-#pragma unroll
-      for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(&Ad[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];
-#pragma unroll
-      for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(&Bd[(bk + BROW_STEP * j) * BN + 4 * bx4]) = rb[j];
-    }
+    if (kt + 2 < KT) FWD_ADVANCE();   // pointers -> tile kt+2 (else they stay on a valid tile; data unused)
+    mfma_stage_split<TM, TN, true, false, LDK, BN, AJ + BJ, AJ + BJ>(
+        As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane,
+        [&]() { FWD_STORE(cur ^ 1); },   // tile kt+1 (harmless duplicate after the last tile)
+        [&]() { FWD_LOAD(); });          // tile kt+2
     __syncthreads();
   }
+#undef FWD_ADVANCE
+#undef FWD_LOAD
+#undef FWD_STORE
 #undef FWD_SETUP_RS
 
   // ---- epilogue through LDS: float4 rows
@@ -311,60 +365,51 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
   zero_acc<TM, TN>(acc);
   int rs = 0, kc = 0;
   BD_SETUP_RS(0);
-  ks = *reinterpret_cast<const f32x4*>(pks);
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb[j]);
-  if (kscale) {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) ra[j] *= ks;
-  }
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(&As[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(&Bs[(arow + 32 * j) * LDK + 4 * kq]) = rb[j];
+#define BD_ADVANCE()                                                              \
+  do {                                                                            \
+    if (++kc == KC) {                                                             \
+      kc = 0; ++rs;                                                               \
+      BD_SETUP_RS(rs);                                                            \
+      _Pragma("unroll") for (int j = 0; j < BJ; ++j) pb[j] += tapb[j];            \
+      pks -= (KC - 1) * incks;                                                    \
+    } else {                                                                      \
+      _Pragma("unroll") for (int j = 0; j < AJ; ++j) pa[j] += inca[j];            \
+      _Pragma("unroll") for (int j = 0; j < BJ; ++j) pb[j] += incb[j];            \
+      pks += incks;                                                               \
+    }                                                                             \
+  } while (0)
+#define BD_LOAD()                                                                                  \
+  do {                                                                                             \
+    ks = *reinterpret_cast<const f32x4*>(pks);                                                     \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]); \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb[j]); \
+  } while (0)
+#define BD_STORE(buf_)                                                                             \
+  do {                                                                                             \
+    float* Ad = As + (buf_) * A_SZ;                                                                \
+    float* Bd = Bs + (buf_) * B_SZ;                                                                \
+    if (kscale) { _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[j] *= ks; }                    \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                 \
+        *reinterpret_cast<f32x4*>(&Ad[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];                    \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j)                                                 \
+        *reinterpret_cast<f32x4*>(&Bd[(arow + 32 * j) * LDK + 4 * kq]) = rb[j];                    \
+  } while (0)
+  BD_LOAD();
+  BD_STORE(0);
+  if (KT > 1) BD_ADVANCE();
+  BD_LOAD();
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
-    const bool more = kt + 1 < KT;
-    if (more) {
-      if (++kc == KC) {
-        kc = 0; ++rs;
-        BD_SETUP_RS(rs);
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) pb[j] += tapb[j];
-        pks -= (KC - 1) * incks;
-      } else {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) pa[j] += inca[j];
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) pb[j] += incb[j];
-        pks += incks;
-      }
-    }
-    ks = *reinterpret_cast<const f32x4*>(pks);
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb[j]);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_stage_pipelined<TM, TN, true, true, LDK, LDK>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2),
-                                                       wn * (BN / 2), lane);
-    if (more) {
-      float* Ad = As + (cur ^ 1) * A_SZ;
-      float* Bd = Bs + (cur ^ 1) * B_SZ;
-      if (kscale) {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) ra[j] *= ks;
-      }
-#pragma unroll
-      for (int j = 0; j < AJ; ++j) *reinterpret_cast<f32x4*>(&Ad[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];
-#pragma unroll
-      for (int j = 0; j < BJ; ++j) *reinterpret_cast<f32x4*>(&Bd[(arow + 32 * j) * LDK + 4 * kq]) = rb[j];
-    }
+    if (kt + 2 < KT) BD_ADVANCE();
+    mfma_stage_split<TM, TN, true, true, LDK, LDK, AJ + BJ, AJ + BJ + 1>(
+        As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane,
+        [&]() { BD_STORE(cur ^ 1); }, [&]() { BD_LOAD(); });
     __syncthreads();
   }
+#undef BD_ADVANCE
+#undef BD_LOAD
+#undef BD_STORE
 #undef BD_SETUP_RS
 
   acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
@@ -392,7 +437,7 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
 template <int BM, int BN>
 __global__ void __launch_bounds__(256)
 k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ dy,
-                  float* __restrict__ out, int kt_per_split) {
+                  float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
@@ -417,16 +462,9 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
   const int bx4 = tid % BROW_T, bk = tid / BROW_T;
   const bool a_col_ok = (m0 + 4 * ax4) < C, b_col_ok = (n0 + 4 * bx4) < K;
   const int dh0 = r * d.dilation - d.pad_top, dw0 = s * d.dilation - d.pad_left;
-  // incremental pixel decode for the A rows of this thread
-  int pn[AJ], poh[AJ], pow_[AJ];
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) {
-    const int p = kt_begin * BK + ak + AROW_STEP * j;
-    pow_[j] = p % d.OW;
-    const int t = p / d.OW;
-    poh[j] = t % d.OH;
-    pn[j] = t / d.OH;
-  }
+  // A rows of this thread = output pixels pa0 + AROW_STEP*j (+BK per stage), decoded with magic-number
+  // division (branch-free: the whole stage stays one basic block for the MFMA/VMEM interleave)
+  int pa0 = kt_begin * BK + ak;
   int bp = kt_begin * BK + bk;
   const float* xb = x + m0 + 4 * ax4;
   const float* pdy = dy + (size_t)bp * K + n0 + 4 * bx4;
@@ -435,21 +473,21 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
 #define BW_LOAD()                                                                                          \
   do {                                                                                                     \
     _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                       \
-      const int ih = poh[j] * d.stride + dh0, iw = pow_[j] * d.stride + dw0;                               \
-      const bool ok = a_col_ok && pn[j] < d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W; \
-      const float* p_ = ok ? xb + ((size_t)(pn[j] * d.H + ih) * d.W + iw) * C : lmh_zero_page;             \
+      const unsigned p = (unsigned)(pa0 + AROW_STEP * j);                                                  \
+      const unsigned t = lmh_div(p, div_ow), ow = p - t * (unsigned)d.OW;                                  \
+      const unsigned n = lmh_div(t, div_oh), oh = t - n * (unsigned)d.OH;                                  \
+      const int ih = (int)oh * d.stride + dh0, iw = (int)ow * d.stride + dw0;                              \
+      const bool ok = a_col_ok && n < (unsigned)d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W; \
+      const float* p_ = ok ? xb + ((size_t)((int)n * d.H + ih) * d.W + iw) * C : lmh_zero_page;            \
       ra[j] = *reinterpret_cast<const f32x4*>(p_);                                                         \
-      pow_[j] += BK;                                                                                       \
-      while (pow_[j] >= d.OW) { pow_[j] -= d.OW; ++poh[j]; }                                               \
-      while (poh[j] >= d.OH) { poh[j] -= d.OH; ++pn[j]; }                                                  \
     }                                                                                                      \
     _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                                       \
       const bool ok = b_col_ok && (bp + BROW_STEP * j) < P;                                                \
       const float* p_ = ok ? pdy + j * dy_row : lmh_zero_page;                                             \
       rb[j] = *reinterpret_cast<const f32x4*>(p_);                                                         \
     }                                                                                                      \
-    bp += BK; pdy += dy_stage;                                                                             \
   } while (0)
+#define BW_ADVANCE() do { pa0 += BK; bp += BK; pdy += dy_stage; } while (0)
 #define BW_STORE(buf_)                                                                                     \
   do {                                                                                                     \
     float* Ad = As + (buf_) * A_SZ;                                                                        \
@@ -461,18 +499,20 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
   } while (0)
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  BW_LOAD();
+  BW_LOAD();          // tile 0 of this split
   BW_STORE(0);
+  BW_ADVANCE();
+  BW_LOAD();          // tile 1 (past the split's end the rows are still valid pixels, or the zero page)
   __syncthreads();
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
-    BW_LOAD();   // stage kt+1; past the end of this split the rows are still valid pixels (or the zero page)
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_stage_pipelined<TM, TN, false, false, BM, BN>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2),
-                                                       wn * (BN / 2), lane);
-    if (kt + 1 < kt_end) BW_STORE(cur ^ 1);
+    BW_ADVANCE();
+    mfma_stage_split<TM, TN, false, false, BM, BN, AJ + BJ, AJ + BJ>(
+        As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane,
+        [&]() { BW_STORE(cur ^ 1); }, [&]() { BW_LOAD(); });
     __syncthreads();
   }
+#undef BW_ADVANCE
 #undef BW_LOAD
 #undef BW_STORE
 

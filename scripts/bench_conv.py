@@ -1,7 +1,7 @@
 """Per-layer micro-benchmark of the conv kernels on the ResNet-50 @1024^2, B=2 shapes
 (fwd / bwd_data / bwd_weight), HIP-event timed.  python scripts/bench_conv.py [filter]"""
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from luminoth_amd import kernels as K
 
@@ -28,7 +28,7 @@ LAYERS = [
     ('rpn 3x3 1024->512', 64, 1024, 512, 3, 1, 'SAME'),
     ('rpn 1x1 512->48', 64, 512, 48, 1, 1, 'VALID'),
 ]
-flt = sys.argv[1] if len(sys.argv) > 1 else ''
+flt = sys.argv[1] if len(sys.argv) > 1 and __name__ == "__main__" else ""
 dev = torch.device('cuda:0')
 
 
@@ -45,32 +45,37 @@ def timeit(fn, iters=40):
     return e0.elapsed_time(e1) / iters
 
 
-tot = {'fwd': 0.0, 'bwd_data': 0.0, 'bwd_weight': 0.0}
-print('%-22s %8s | %-22s | %-22s | %-22s' % ('layer', 'GFLOP', 'fwd us / TF', 'bwd_data us / TF', 'bwd_weight us / TF'))
-for name, H, C, Kc, R, stride, pad in LAYERS:
-    if flt and flt not in name:
-        continue
-    x = torch.randn(B, H, H, C, device=dev)
-    w = torch.randn(R, R, C, Kc, device=dev) * 0.05
-    d = K.conv_desc(x.shape, w.shape, stride, 1, pad, 'relu')
-    scale = torch.ones(Kc, device=dev)
-    shift = torch.zeros(Kc, device=dev)
-    y = K.conv2d_fwd(d, x, w, scale, shift)
-    gy = torch.randn_like(y)
-    fl = 2.0 * B * d.OH * d.OW * Kc * R * R * C
-    t_f = timeit(lambda: K.conv2d_fwd(d, x, w, scale, shift, out=y))
-    row = '%-22s %8.2f | %8.1f %6.1f (%s)' % (name, fl / 1e9, t_f * 1e3, fl / t_f / 1e9,
-                                              K._lib.load().lmh_conv2d_kernel_id(d, 0) % 1000000)
-    tot['fwd'] += t_f
-    if C % 4 == 0:
-        dx = torch.empty_like(x)
-        t_d = timeit(lambda: K.conv2d_bwd_data(d, gy, w, scale, out=dx))
-        dw = torch.empty_like(w)
-        t_w = timeit(lambda: K.conv2d_bwd_weight(d, x, gy, out=dw))
-        row += ' | %8.1f %6.1f (%s) | %8.1f %6.1f (%s)' % (
-            t_d * 1e3, fl / t_d / 1e9, K._lib.load().lmh_conv2d_kernel_id(d, 1),
-            t_w * 1e3, fl / t_w / 1e9, K._lib.load().lmh_conv2d_kernel_id(d, 2))
-        tot['bwd_data'] += t_d
-        tot['bwd_weight'] += t_w
-    print(row)
-print('sum ms:', {k: round(v, 3) for k, v in tot.items()})
+def main():
+    tot = {'fwd': 0.0, 'bwd_data': 0.0, 'bwd_weight': 0.0}
+    print('%-22s %8s | %-22s | %-22s | %-22s' % ('layer', 'GFLOP', 'fwd us / TF', 'bwd_data us / TF', 'bwd_weight us / TF'))
+    for name, H, C, Kc, R, stride, pad in LAYERS:
+        if flt and flt not in name:
+            continue
+        x = torch.randn(B, H, H, C, device=dev)
+        w = torch.randn(R, R, C, Kc, device=dev) * 0.05
+        d = K.conv_desc(x.shape, w.shape, stride, 1, pad, 'relu')
+        scale = torch.ones(Kc, device=dev)
+        shift = torch.zeros(Kc, device=dev)
+        y = K.conv2d_fwd(d, x, w, scale, shift)
+        gy = torch.randn_like(y)
+        fl = 2.0 * B * d.OH * d.OW * Kc * R * R * C
+        t_f = timeit(lambda: K.conv2d_fwd(d, x, w, scale, shift, out=y))
+        row = '%-22s %8.2f | %8.1f %6.1f (%s)' % (name, fl / 1e9, t_f * 1e3, fl / t_f / 1e9,
+                                                  K._lib.load().lmh_conv2d_kernel_id(d, 0) % 1000000)
+        tot['fwd'] += t_f
+        if C % 4 == 0:
+            dx = torch.empty_like(x)
+            t_d = timeit(lambda: K.conv2d_bwd_data(d, gy, w, scale, out=dx))
+            dw = torch.empty_like(w)
+            t_w = timeit(lambda: K.conv2d_bwd_weight(d, x, gy, out=dw))
+            row += ' | %8.1f %6.1f (%s) | %8.1f %6.1f (%s)' % (
+                t_d * 1e3, fl / t_d / 1e9, K._lib.load().lmh_conv2d_kernel_id(d, 1),
+                t_w * 1e3, fl / t_w / 1e9, K._lib.load().lmh_conv2d_kernel_id(d, 2))
+            tot['bwd_data'] += t_d
+            tot['bwd_weight'] += t_w
+        print(row)
+    print('sum ms:', {k: round(v, 3) for k, v in tot.items()})
+
+
+if __name__ == '__main__':
+    main()
