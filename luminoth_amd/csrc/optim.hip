@@ -7,7 +7,11 @@
 // gradient, as wd*w.
 #include "lmh_common.h"
 
-__device__ __forceinline__ int seg_find(const int64_t* __restrict__ off, int nseg, int64_t i) {
+// The segment table is staged in LDS; every thread walks float4s with a fixed stride, so its segment
+// index only moves forward: one binary search, then a short linear advance per element (segments may
+// start anywhere; params.py happens to pad them to 16 bytes).
+#define OPT_MAX_SEG 2048
+__device__ __forceinline__ int seg_find(const int64_t* off, int nseg, int64_t i) {
   int lo = 0, hi = nseg;  // off[lo] <= i < off[hi]
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -20,22 +24,49 @@ __global__ void __launch_bounds__(256)
 k_sgd_momentum(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, int64_t n,
                const int64_t* __restrict__ seg_offset, const float* __restrict__ seg_wd, int nseg,
                float lr, float momentum, float gscale) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float wd = seg_wd[seg_find(seg_offset, nseg, i)];
+  __shared__ int64_t s_off[OPT_MAX_SEG + 1];
+  __shared__ float s_wd[OPT_MAX_SEG];
+  for (int i = threadIdx.x; i <= nseg; i += 256) s_off[i] = seg_offset[i];
+  for (int i = threadIdx.x; i < nseg; i += 256) s_wd[i] = seg_wd[i];
+  __syncthreads();
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+  int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // scalar tail
+    const int64_t i = 4 * n4 + threadIdx.x;
+    const float wdt = s_wd[seg_find(s_off, nseg, i)];
     const float wi = w[i];
-    const float gi = g[i] * gscale + wd * wi;
-    const float vi = momentum * v[i] + gi;
+    const float vi = momentum * v[i] + (g[i] * gscale + wdt * wi);
     v[i] = vi;
     w[i] = wi - lr * vi;
+  }
+  if (i4 >= n4) return;
+  int seg = seg_find(s_off, nseg, 4 * i4);
+  for (; i4 < n4; i4 += stride) {
+    float wd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      while (s_off[seg + 1] <= 4 * i4 + e) ++seg;
+      wd[e] = s_wd[seg];
+    }
+    float4 wi = reinterpret_cast<const float4*>(w)[i4];
+    const float4 gi = reinterpret_cast<const float4*>(g)[i4];
+    float4 vi = reinterpret_cast<const float4*>(v)[i4];
+    vi.x = momentum * vi.x + (gi.x * gscale + wd[0] * wi.x);
+    vi.y = momentum * vi.y + (gi.y * gscale + wd[1] * wi.y);
+    vi.z = momentum * vi.z + (gi.z * gscale + wd[2] * wi.z);
+    vi.w = momentum * vi.w + (gi.w * gscale + wd[3] * wi.w);
+    wi.x -= lr * vi.x; wi.y -= lr * vi.y; wi.z -= lr * vi.z; wi.w -= lr * vi.w;
+    reinterpret_cast<float4*>(v)[i4] = vi;
+    reinterpret_cast<float4*>(w)[i4] = wi;
   }
 }
 
 extern "C" int lmh_sgd_momentum(float* w, const float* g, float* v, int64_t n, const int64_t* seg_offset,
                                 const float* seg_wd, int nseg, float lr, float momentum, float gscale,
                                 lmh_stream_t stream) {
-  LMH_CHECK_ARG(w && g && v && seg_offset && seg_wd && n > 0 && nseg > 0);
-  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  LMH_CHECK_ARG(w && g && v && seg_offset && seg_wd && n > 0 && nseg > 0 && nseg <= OPT_MAX_SEG);
+  const int64_t n4 = n >> 2;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 + 1 : 2048);
   hipLaunchKernelGGL(k_sgd_momentum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, v, n,
                      seg_offset, seg_wd, nseg, lr, momentum, gscale);
   LMH_CHECK_LAUNCH();
@@ -45,13 +76,31 @@ extern "C" int lmh_sgd_momentum(float* w, const float* g, float* v, int64_t n, c
 __global__ void __launch_bounds__(256)
 k_l2_reg(const float* __restrict__ w, int64_t n, const int64_t* __restrict__ seg_offset,
          const float* __restrict__ seg_wd, int nseg, float* __restrict__ out) {
+  __shared__ int64_t s_off[OPT_MAX_SEG + 1];
+  __shared__ float s_wd[OPT_MAX_SEG];
   __shared__ float sh[4];
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int i = threadIdx.x; i <= nseg; i += 256) s_off[i] = seg_offset[i];
+  for (int i = threadIdx.x; i < nseg; i += 256) s_wd[i] = seg_wd[i];
+  __syncthreads();
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+  int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float acc = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float wd = seg_wd[seg_find(seg_offset, nseg, i)];
+  if (i4 < n4) {
+    int seg = seg_find(s_off, nseg, 4 * i4);
+    for (; i4 < n4; i4 += stride) {
+      const float4 wi = reinterpret_cast<const float4*>(w)[i4];
+      const float we[4] = {wi.x, wi.y, wi.z, wi.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        while (s_off[seg + 1] <= 4 * i4 + e) ++seg;
+        acc += s_wd[seg] * (we[e] * we[e]) * 0.5f;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // scalar tail
+    const int64_t i = 4 * n4 + threadIdx.x;
     const float wi = w[i];
-    acc += wd * (wi * wi) * 0.5f;
+    acc += s_wd[seg_find(s_off, nseg, i)] * (wi * wi) * 0.5f;
   }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
@@ -61,8 +110,9 @@ k_l2_reg(const float* __restrict__ w, int64_t n, const int64_t* __restrict__ seg
 
 extern "C" int lmh_l2_reg_loss(const float* w, int64_t n, const int64_t* seg_offset, const float* seg_wd,
                                int nseg, float* out, lmh_stream_t stream) {
-  LMH_CHECK_ARG(w && seg_offset && seg_wd && out && n > 0 && nseg > 0);
-  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  LMH_CHECK_ARG(w && seg_offset && seg_wd && out && n > 0 && nseg > 0 && nseg <= OPT_MAX_SEG);
+  const int64_t n4 = n >> 2;
+  const int blocks = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 + 1 : 1024);
   hipLaunchKernelGGL(k_l2_reg, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, n, seg_offset,
                      seg_wd, nseg, out);
   LMH_CHECK_LAUNCH();

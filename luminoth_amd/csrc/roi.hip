@@ -155,11 +155,11 @@ extern "C" int lmh_roi_pool_fwd(const float* feat, const float* rois, const int3
 }
 
 // Slab variant (default): one 1024-thread block owns CS channels of one image's whole feature map in
-// LDS (FH*FW*CS floats, 128 KiB at 64x64x8), loops over every (roi, cell) of that image and scatter-adds
+// LDS (CS channel planes of FH*FW floats, 128 KiB at 64x64x8), loops over every (roi, cell) of that image and scatter-adds
 // with LDS atomics, then writes its slab once.  No global atomics, no pre-zeroing, and the 4-way corner
 // contention of overlapping ROIs stays inside the CU (the global-atomic kernel above took 1.1 ms at
 // R=256, C=1024 because clustered foreground ROIs serialise in L2).
-template <int CS>
+template <int CS, int DBG = 0>
 __global__ void __launch_bounds__(1024)
 k_roi_pool_bwd_slab(const float* __restrict__ dout, const uint8_t* __restrict__ argmax,
                     const float4* __restrict__ rois, const int32_t* __restrict__ roi_count, int R, int FH,
@@ -201,20 +201,26 @@ k_roi_pool_bwd_slab(const float* __restrict__ dout, const uint8_t* __restrict__ 
       if (!sq.valid || go[cc] == 0.f) continue;
       const float dtop = (1.f - sq.ylerp) * go[cc];
       const float dbot = sq.ylerp * go[cc];
-      atomicAdd(&slab[(sq.top * FW + sq.left) * CS + cc], (1.f - sq.xlerp) * dtop);
-      atomicAdd(&slab[(sq.top * FW + sq.right) * CS + cc], sq.xlerp * dtop);
-      atomicAdd(&slab[(sq.bot * FW + sq.left) * CS + cc], (1.f - sq.xlerp) * dbot);
-      atomicAdd(&slab[(sq.bot * FW + sq.right) * CS + cc], sq.xlerp * dbot);
+      if (DBG == 1) continue;
+      float* pl = slab + cc * npix;   // channel-major planes: lanes (different pixels) hit different banks
+      atomicAdd(&pl[sq.top * FW + sq.left], (1.f - sq.xlerp) * dtop);
+      atomicAdd(&pl[sq.top * FW + sq.right], sq.xlerp * dtop);
+      atomicAdd(&pl[sq.bot * FW + sq.left], (1.f - sq.xlerp) * dbot);
+      atomicAdd(&pl[sq.bot * FW + sq.right], sq.xlerp * dbot);
     }
   }
   __syncthreads();
   float* fb = dfeat + (size_t)b * npix * C + c0;
-  for (int i = threadIdx.x; i < npix * CS / 4; i += 1024) {
-    const int pix = i / (CS / 4), part = i - pix * (CS / 4);
-    *reinterpret_cast<float4*>(fb + (size_t)pix * C + 4 * part) = reinterpret_cast<const float4*>(slab)[i];
+  if (DBG == 2) return;
+  for (int i = threadIdx.x; i < npix * (CS / 4); i += 1024) {
+    const int part = i / npix, pix = i - part * npix;   // consecutive lanes = consecutive pixels (conflict-free)
+    const float* pl = slab + 4 * part * npix + pix;
+    *reinterpret_cast<float4*>(fb + (size_t)pix * C + 4 * part) = make_float4(pl[0], pl[npix], pl[2 * npix], pl[3 * npix]);
   }
 }
 
+static int g_roi_dbg = 0;
+extern "C" void lmh_roi_dbg(int v) { g_roi_dbg = v; }
 // dfeat is OVERWRITTEN (it does not need to be zeroed by the caller).
 extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const float* rois,
                                 const int32_t* roi_count, int B, int R, int FH, int FW, int C,
@@ -232,6 +238,15 @@ extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
       attr8 = true;
     }
+    if (g_roi_dbg == 1) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
+      hipLaunchKernelGGL((k_roi_pool_bwd_slab<8, 1>), dim3(C / 8, B), dim3(1024), npix * 8 * sizeof(float), st, dout,
+                       argmax, reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, dfeat);
+    } else if (g_roi_dbg == 2) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
+      hipLaunchKernelGGL((k_roi_pool_bwd_slab<8, 2>), dim3(C / 8, B), dim3(1024), npix * 8 * sizeof(float), st, dout,
+                       argmax, reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, dfeat);
+    } else
     hipLaunchKernelGGL((k_roi_pool_bwd_slab<8>), dim3(C / 8, B), dim3(1024), npix * 8 * sizeof(float), st, dout,
                        argmax, reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw,
                        dfeat);

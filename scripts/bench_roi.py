@@ -1,0 +1,28 @@
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from luminoth_amd import kernels as K
+from scripts.bench_conv import timeit
+lib = ctypes.CDLL(K._lib.LIB_PATH)
+dev = 'cuda:0'
+B, R, FH, FW, C = 2, 256, 64, 64, 1024
+rs = np.random.RandomState(0)
+# clustered ROIs around 8 gt boxes (what training produces)
+rois = np.zeros((B, R, 4), np.float32)
+for b in range(B):
+    for r in range(R):
+        cx, cy = rs.choice([200, 500, 800]), rs.choice([300, 700])
+        w, h = rs.randint(60, 400), rs.randint(60, 400)
+        x1 = np.clip(cx - w / 2 + rs.randn() * 20, 0, 1023); y1 = np.clip(cy - h / 2 + rs.randn() * 20, 0, 1023)
+        rois[b, r] = [x1, y1, min(x1 + w, 1023), min(y1 + h, 1023)]
+feat = torch.randn(B, FH, FW, C, device=dev)
+roist = torch.tensor(rois, device=dev); cnt = torch.full((B,), R, dtype=torch.int32, device=dev)
+out, am = K.roi_pool_fwd(feat, roist, cnt, (1024, 1024))
+g = torch.randn_like(out)
+for dbg in (0, 1, 2):
+    lib.lmh_roi_dbg(dbg)
+    t = timeit(lambda: K.roi_pool_bwd(g, am, roist, cnt, (B, FH, FW, C), (1024, 1024)), 10)
+    print('roi_pool_bwd dbg=%d: %.1f us' % (dbg, t * 1e3))
+lib.lmh_roi_dbg(0)
+t = timeit(lambda: K.roi_pool_fwd(feat, roist, cnt, (1024, 1024)), 10)
+print('roi_pool_fwd: %.1f us' % (t * 1e3))
