@@ -6,11 +6,35 @@ The nodes restate what tf.contrib.slim builds for the reference
 (models/base/base_network.py:70-101): conv2d [+ frozen BatchNorm | + bias]
 [+ ReLU], conv2d_same, max_pool2d, resnet_v1 bottleneck units.
 """
+import os
+
 import torch
 
 from luminoth_amd import kernels as K
 
 BN_EPS = 1e-5  # slim resnet_arg_scope batch_norm_epsilon (truncated_base_network.py:69-73)
+
+
+class SideStream(object):
+    """Second HIP stream for the weight-gradient chain of every layer (bwd_weight -> split-K reduce ->
+    BN parameter gradients).  It is independent of the data-gradient chain once g = dy*act'(y) exists,
+    so running it beside bwd_data fills the CUs each kernel leaves idle in its prologue / tail.
+    `join()` makes the caller's stream wait for everything enqueued here (before all-reduce / update)."""
+    enabled = os.environ.get('LUMINOTH_AMD_SIDE_STREAM', '1') != '0'
+    _streams = {}
+
+    @classmethod
+    def get(cls, device):
+        st = cls._streams.get(device)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            cls._streams[device] = st
+        return st
+
+    @classmethod
+    def join(cls):
+        for st in cls._streams.values():
+            torch.cuda.current_stream(st.device).wait_stream(st)
 
 
 class ConvLayer(object):
@@ -64,6 +88,12 @@ class ConvLayer(object):
         d = self.desc(x.shape)
         return K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub)
 
+    def _weight_grads(self, d, x, g):
+        K.conv2d_bwd_weight(d, x, g, out=self.gw)
+        if self.norm == 'bn':
+            K.bn_param_grads(self.w, self.gw, self.bn['gbeta'], self.bn['mean'], self.bn['rstd'],
+                             self.scale, out=self.bn['ggamma'])
+
     def backward(self, x, y, dy, need_dx=True, addend=None):
         """dy: gradient w.r.t. the layer output (after residual add + act).
         Returns (dx or None, g) with g = gradient w.r.t. the pre-activation sum
@@ -82,10 +112,16 @@ class ConvLayer(object):
             if colsum is not None:
                 K.act_bwd(dy, None, None, want_g=False, colsum=colsum)
         if self.trainable:
-            K.conv2d_bwd_weight(d, x, g, out=self.gw)
-            if self.norm == 'bn':
-                K.bn_param_grads(self.w, self.gw, self.bn['gbeta'], self.bn['mean'], self.bn['rstd'],
-                                 self.scale, out=self.bn['ggamma'])
+            if SideStream.enabled:
+                main = torch.cuda.current_stream(x.device)
+                side = SideStream.get(x.device)
+                side.wait_stream(main)                  # g (and dbeta) are ready once `main` gets here
+                with torch.cuda.stream(side):
+                    self._weight_grads(d, x, g)
+                x.record_stream(side)                   # keep the buffers alive for the side stream
+                g.record_stream(side)
+            else:
+                self._weight_grads(d, x, g)
         dx = None
         if need_dx:
             dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,

@@ -21,6 +21,7 @@ import torch
 
 from luminoth_amd import _lib
 from luminoth_amd import kernels as K
+from luminoth_amd.models.base.layers import SideStream
 from luminoth_amd.models.base.truncated_base_network import TruncatedBaseNetwork
 from luminoth_amd.models.fasterrcnn.rcnn import RCNN
 from luminoth_amd.models.fasterrcnn.rpn import RPN
@@ -203,6 +204,7 @@ class FasterRCNN(object):
         gradient buffer; the L2 term's gradient (wd*w) is folded into the optimizer kernel."""
         self.store.grad.zero_()
         total_loss.backward()
+        SideStream.join()      # weight-gradient chain runs on a second stream (models/base/layers.py)
 
     # --------------------------------------------------------------- variables --
     @property
