@@ -39,8 +39,9 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device, tag):
-    """Persistent scratch per (tag, device): no allocation in the steady state."""
-    key = (tag, device)
+    """Persistent scratch per (tag, device, stream): no allocation in the steady state, and two
+    streams never share a scratch buffer."""
+    key = (tag, device, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

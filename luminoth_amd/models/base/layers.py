@@ -21,14 +21,15 @@ class SideStream(object):
     so running it beside bwd_data fills the CUs each kernel leaves idle in its prologue / tail.
     `join()` makes the caller's stream wait for everything enqueued here (before all-reduce / update)."""
     enabled = os.environ.get('LUMINOTH_AMD_SIDE_STREAM', '1') != '0'
-    _streams = {}
+    _streams = {}      # one side stream per issuing stream (the fused train step issues from two)
 
     @classmethod
     def get(cls, device):
-        st = cls._streams.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        st = cls._streams.get(key)
         if st is None:
             st = torch.cuda.Stream(device=device)
-            cls._streams[device] = st
+            cls._streams[key] = st
         return st
 
     @classmethod

@@ -206,6 +206,83 @@ class FasterRCNN(object):
         total_loss.backward()
         SideStream.join()      # weight-gradient chain runs on a second stream (models/base/layers.py)
 
+    # ------------------------------------------------------------ fused step --
+    def train_step(self, image, gt_boxes):
+        """forward + loss + backward of ONE train step (train.py:66-91), same arithmetic as
+        `__call__(is_training=True)` -> `loss()` -> `backward()`, scheduled on two HIP streams:
+
+            main: trunk fwd -> RPN convs -> RPN targets -> RPN loss -> RPN backward ------> trunk backward
+            aux :               '-> proposals (sort + NMS) -> RCNN targets -> ROI pool -> FCs
+                                    -> RCNN loss -> RCNN backward -> ROI-pool backward ----'
+
+        The proposal chain is a sequence of latency-bound launches that occupy a handful of CUs; it now
+        runs beside the RPN backward (the largest MFMA kernels of the step) instead of in front of it.
+        Returns (total_loss, prediction_dict); gradients are complete in `self.store.grad` when the
+        caller's stream reaches this point."""
+        if not self._with_rcnn:
+            pred = self(image, gt_boxes, is_training=True)
+            total = self.loss(pred)
+            self.backward(total)
+            return total, pred
+        image = torch.as_tensor(image)
+        if image.dim() == 3:
+            image = image.unsqueeze(0)
+        image = image.to(self.device, torch.float32).contiguous()
+        B, H, W, _ = image.shape
+        gt, gt_count = self._pack_gt(gt_boxes, B)
+        seeds = torch.from_numpy(np.array([rng.image_seed(self._seed, self._step, b) for b in range(B)],
+                                          dtype=np.uint32).view(np.int32)).to(self.device)
+        self._step += 1
+        im_shape = (H, W)
+        main = torch.cuda.current_stream(self.device)
+        aux = self._aux_stream()
+        self.store.grad.zero_()
+        with torch.enable_grad():
+            feat = self.base_network(image, is_training=True)
+            f_rpn = feat.detach().requires_grad_(True)
+            f_rcnn = feat.detach().requires_grad_(True)
+            rpn = self._rpn
+            fh, fw = feat.shape[1], feat.shape[2]
+            rpn_pred = rpn.heads(f_rpn)
+            # ---- aux stream: proposals -> RCNN forward -> RCNN loss -> RCNN backward
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                prop = rpn._proposal(rpn_pred['rpn_cls_score'].detach(), rpn_pred['rpn_bbox_pred'].detach(),
+                                     self._anchor_ref_i32, (fh, fw), self._anchor_stride, im_shape)
+                cp = self._rcnn(f_rcnn, prop['proposals'], prop['num_proposals'], im_shape, self.base_network,
+                                gt_boxes=gt, gt_count=gt_count, seeds=seeds, is_training=True)
+                rcnn_losses = self._rcnn.loss(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
+                (rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).backward()
+            for t in (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred'], feat, gt, gt_count, seeds):
+                t.record_stream(aux)
+            # ---- main stream: RPN targets -> RPN loss -> RPN backward
+            rpn.targets(rpn_pred, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape)
+            rpn_losses = rpn.loss(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
+            (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss']).backward()
+            # ---- join, trunk backward
+            main.wait_stream(aux)
+            for t in (f_rcnn.grad, rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']):
+                t.record_stream(main)
+            feat.backward(f_rpn.grad + f_rcnn.grad)
+        SideStream.join()
+        rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})
+        rpn_pred['num_proposals'] = prop['num_proposals']
+        no_reg_loss = (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss'] +
+                       rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).detach()
+        regularization_loss = self.regularization_loss()
+        total_loss = no_reg_loss + regularization_loss
+        self._last_losses = dict(rpn_losses, total_loss=total_loss, no_reg_loss=no_reg_loss,
+                                 regularization_loss=regularization_loss, **rcnn_losses)
+        pred = {'rpn_prediction': rpn_pred, 'classification_prediction': cp, 'rpn_loss_dict': rpn_losses,
+                'rcnn_loss_dict': rcnn_losses, '_batch': {'B': B, 'unbatched': False}}
+        return total_loss, pred
+
+    def _aux_stream(self):
+        st = getattr(self, '_aux', None)
+        if st is None:
+            st = self._aux = torch.cuda.Stream(device=self.device)
+        return st
+
     # --------------------------------------------------------------- variables --
     @property
     def summary(self):

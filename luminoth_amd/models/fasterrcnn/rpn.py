@@ -45,31 +45,40 @@ class RPN(object):
             l.bind(store, None)
         self._anchor = torch.zeros(1, device=store.flat.device, requires_grad=True)
 
-    def __call__(self, conv_feature_map, im_shape, anchor_ref_i32, stride, gt_boxes=None, gt_count=None,
-                 seeds=None, is_training=False):
-        B, fh, fw, _ = conv_feature_map.shape
+    def heads(self, conv_feature_map):
+        """3x3 conv + activation, then the 1x1 cls / bbox convs (rpn.py:148-172)."""
+        B = conv_feature_map.shape[0]
         rpn_feature = A.conv(self._rpn, conv_feature_map, self._anchor)
         cls_orig = A.conv(self._rpn_cls, rpn_feature, self._anchor)      # (B,fh,fw,2A)
         bbox_orig = A.conv(self._rpn_bbox, rpn_feature, self._anchor)    # (B,fh,fw,4A)
-        rpn_cls_score = cls_orig.reshape(B, -1, 2)                       # rpn.py:160
-        rpn_bbox_pred = bbox_orig.reshape(B, -1, 4)                      # rpn.py:169
-        pred = {'rpn_cls_score': rpn_cls_score, 'rpn_bbox_pred': rpn_bbox_pred}
-        prop = self._proposal(rpn_cls_score.detach(), rpn_bbox_pred.detach(), anchor_ref_i32, (fh, fw), stride,
-                              im_shape)
+        pred = {'rpn_cls_score': cls_orig.reshape(B, -1, 2),             # rpn.py:160
+                'rpn_bbox_pred': bbox_orig.reshape(B, -1, 4)}            # rpn.py:169
+        if self._debug:
+            pred['rpn_feature'] = rpn_feature
+        return pred
+
+    def targets(self, pred, anchor_ref_i32, feat_hw, stride, gt_boxes, gt_count, seeds, im_shape):
+        labels, targets, max_ov = self._anchor_target(anchor_ref_i32, feat_hw, stride, gt_boxes, gt_count,
+                                                      seeds, im_shape)
+        pred['rpn_cls_target'] = labels
+        pred['rpn_bbox_target'] = targets
+        if self._debug:
+            pred['rpn_max_overlap'] = max_ov
+
+    def __call__(self, conv_feature_map, im_shape, anchor_ref_i32, stride, gt_boxes=None, gt_count=None,
+                 seeds=None, is_training=False):
+        fh, fw = conv_feature_map.shape[1], conv_feature_map.shape[2]
+        pred = self.heads(conv_feature_map)
+        prop = self._proposal(pred['rpn_cls_score'].detach(), pred['rpn_bbox_pred'].detach(), anchor_ref_i32,
+                              (fh, fw), stride, im_shape)
         pred['rpn_cls_prob'] = prop['rpn_cls_prob']
         pred['proposals'] = prop['proposals']
         pred['scores'] = prop['scores']
         pred['num_proposals'] = prop['num_proposals']
         if self._debug:
             pred['proposal_prediction'] = prop
-            pred['rpn_feature'] = rpn_feature
         if gt_boxes is not None:
-            labels, targets, max_ov = self._anchor_target(anchor_ref_i32, (fh, fw), stride, gt_boxes, gt_count,
-                                                          seeds, im_shape)
-            pred['rpn_cls_target'] = labels
-            pred['rpn_bbox_target'] = targets
-            if self._debug:
-                pred['rpn_max_overlap'] = max_ov
+            self.targets(pred, anchor_ref_i32, (fh, fw), stride, gt_boxes, gt_count, seeds, im_shape)
         return pred
 
     def loss(self, prediction_dict, w_cls=1.0, w_reg=1.0):

@@ -8,11 +8,14 @@ The optimizer is ONE fused kernel over the flat parameter buffer
 all-reduced with one collective before the update (replaces the reference's
 asynchronous parameter-server exchange, train.py:46,282-326).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from luminoth_amd import kernels as K
 
+FUSED_STEP = os.environ.get('LUMINOTH_AMD_FUSED_STEP', '1') != '0'
 OPTIMIZERS = {'momentum', 'gradient_descent', 'adam', 'rmsprop'}
 LEARNING_RATE_DECAY_METHODS = {'piecewise_constant', 'exponential_decay'}
 
@@ -92,8 +95,11 @@ def broadcast_parameters(model, src=0):
 
 def train_step(model, optimizer, image, gt_boxes):
     """One step of train.py:66-91: forward, loss, backward, (all-reduce), update."""
-    pred = model(image, gt_boxes, is_training=True)
-    total = model.loss(pred)
-    model.backward(total)
+    if FUSED_STEP and hasattr(model, 'train_step'):
+        total, pred = model.train_step(image, gt_boxes)     # same arithmetic, two-stream schedule
+    else:
+        pred = model(image, gt_boxes, is_training=True)
+        total = model.loss(pred)
+        model.backward(total)
     optimizer.step()
     return total, pred

@@ -203,3 +203,30 @@ def test_optimizer_step_changes_weights_like_oracle(setup):
     frozen = 'truncated_base_network/resnet_v1_50/block1/unit_1/bottleneck_v1/conv1/weights'
     np.testing.assert_array_equal(after[frozen].numpy(), before[frozen].numpy())
     model.load_state_dict(before)
+
+
+def test_fused_two_stream_step_equals_plain_step(setup):
+    """FasterRCNN.train_step (two-stream schedule) == __call__ + loss + backward: same losses, same
+    targets, same gradients (ROI-pool backward adds in LDS-atomic order: 1e-5 of the gradient scale)."""
+    cfg, model, images, gts = setup
+    model._step = 0
+    pred = model(images, gts, is_training=True)
+    losses = model.loss(pred, return_all=True)
+    model.backward(losses['total_loss'])
+    torch.cuda.synchronize()
+    g_plain = model.store.grad.clone()
+    model._step = 0
+    total, pred2 = model.train_step(images, gts)
+    torch.cuda.synchronize()
+    g_fused = model.store.grad.clone()
+    np.testing.assert_allclose(float(total), float(losses['total_loss']), rtol=1e-6)
+    for k in ('rpn_cls_loss', 'rpn_reg_loss', 'rcnn_cls_loss', 'rcnn_reg_loss'):
+        np.testing.assert_allclose(float(model._last_losses[k]), float(losses[k]), rtol=1e-6)
+    a, b = pred['rpn_prediction'], pred2['rpn_prediction']
+    for k in ('rpn_cls_target', 'rpn_bbox_target', 'proposals', 'scores', 'num_proposals'):
+        assert torch.equal(a[k], b[k]), k
+    ca, cb = pred['classification_prediction'], pred2['classification_prediction']
+    assert torch.equal(ca['target']['cls'], cb['target']['cls'])
+    assert torch.equal(ca['proposals'], cb['proposals'])
+    scale = float(g_plain.abs().max())
+    np.testing.assert_allclose(g_fused.cpu().numpy(), g_plain.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
