@@ -81,6 +81,20 @@ class FasterRCNN(object):
         self._frozen_reg = None
 
     # ------------------------------------------------------------------ inputs --
+    _SEED_BLOCK = 1024
+
+    def _image_seeds(self, B):
+        """Per-image RNG seeds of the current step as a device tensor (B,) int32.  Seeds for the next
+        _SEED_BLOCK steps are generated and uploaded in one go: a per-step host->device copy from
+        pageable memory would re-synchronise the host with the GPU every step."""
+        c = getattr(self, '_seed_cache', None)
+        if c is None or c[0] != B or not (c[1] <= self._step < c[1] + self._SEED_BLOCK):
+            base = self._step
+            tab = np.array([[rng.image_seed(self._seed, base + s, b) for b in range(B)]
+                            for s in range(self._SEED_BLOCK)], dtype=np.uint32).view(np.int32)
+            c = self._seed_cache = (B, base, torch.from_numpy(tab).to(self.device))
+        return c[2][self._step - c[1]]
+
     def _pack_gt(self, gt_boxes, B):
         """-> (gt (B,Gmax,5) fp32 device, gt_count (B) int32 device)."""
         if gt_boxes is None:
@@ -114,9 +128,7 @@ class FasterRCNN(object):
         gt, gt_count = self._pack_gt(gt_boxes, B)
         seeds = None
         if gt is not None:
-            seeds = torch.from_numpy(np.array(
-                [rng.image_seed(self._seed, self._step, b) for b in range(B)],
-                dtype=np.uint32).view(np.int32)).to(self.device)
+            seeds = self._image_seeds(B)
             if is_training:
                 self._step += 1
         with torch.set_grad_enabled(bool(is_training)):
@@ -230,8 +242,7 @@ class FasterRCNN(object):
         image = image.to(self.device, torch.float32).contiguous()
         B, H, W, _ = image.shape
         gt, gt_count = self._pack_gt(gt_boxes, B)
-        seeds = torch.from_numpy(np.array([rng.image_seed(self._seed, self._step, b) for b in range(B)],
-                                          dtype=np.uint32).view(np.int32)).to(self.device)
+        seeds = self._image_seeds(B)
         self._step += 1
         im_shape = (H, W)
         main = torch.cuda.current_stream(self.device)
