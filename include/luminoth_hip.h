@@ -227,9 +227,11 @@ int lmh_roi_pool_fwd(const float* feat, const float* rois, const int32_t* roi_co
                      int FH, int FW, int C, float im_h, float im_w, int ph, int pw, float* out,
                      uint8_t* argmax, lmh_stream_t stream);
 /* dfeat is OVERWRITTEN with the full gradient (CropAndResizeGradImage scatter-add, done in LDS slabs). */
+size_t lmh_roi_pool_bwd_workspace_bytes(int B, int R, int ph, int pw);
 int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const float* rois,
                      const int32_t* roi_count, int B, int R, int FH, int FW, int C, float im_h,
-                     float im_w, int ph, int pw, float* dfeat, lmh_stream_t stream);
+                     float im_w, int ph, int pw, float* dfeat, void* ws, size_t ws_bytes,
+                     lmh_stream_t stream);
 /* tf.reduce_mean(features, [1,2]) (rcnn.py:185-188): x (M,S,C) -> y (M,C). */
 int lmh_spatial_mean_fwd(const float* x, int64_t M, int S, int C, float* y, lmh_stream_t stream);
 int lmh_spatial_mean_bwd(const float* dy, int64_t M, int S, int C, float* dx, lmh_stream_t stream);

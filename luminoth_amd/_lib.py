@@ -90,7 +90,8 @@ SIGNATURES = {
     'lmh_rcnn_proposal_workspace_bytes': (c_sz, [P(RcnnProposalDesc)]),
     'lmh_rcnn_proposal': (c_i, [P(RcnnProposalDesc)] + [c_f] * 9 + [c_sz, c_f]),
     'lmh_roi_pool_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_f]),
-    'lmh_roi_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f]),
+    'lmh_roi_pool_bwd_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
+    'lmh_roi_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_sz, c_f]),
     'lmh_spatial_mean_fwd': (c_i, [c_f, c_i64, c_i, c_i, c_f, c_f]),
     'lmh_spatial_mean_bwd': (c_i, [c_f, c_i64, c_i, c_i, c_f, c_f]),
     'lmh_rpn_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),

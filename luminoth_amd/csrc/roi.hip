@@ -9,6 +9,7 @@
 // every corner fetch is a fully coalesced 1 KiB wave request and the backward's
 // scatter-add atomics hit distinct addresses per lane.
 #include "lmh_common.h"
+#include <stdlib.h>
 
 struct roi_geom {
   float y1n, x1n, hs, ws;  // normalised top-left * (dim-1), per-sample scale
@@ -154,112 +155,127 @@ extern "C" int lmh_roi_pool_fwd(const float* feat, const float* rois, const int3
   return LMH_OK;
 }
 
-// Slab variant (default): one 1024-thread block owns CS channels of one image's whole feature map in
-// LDS (CS channel planes of FH*FW floats, 128 KiB at 64x64x8), loops over every (roi, cell) of that image and scatter-adds
-// with LDS atomics, then writes its slab once.  No global atomics, no pre-zeroing, and the 4-way corner
-// contention of overlapping ROIs stays inside the CU (the global-atomic kernel above took 1.1 ms at
-// R=256, C=1024 because clustered foreground ROIs serialise in L2).
-template <int CS, int DBG = 0>
+// ---- backward, slab variant (default) --------------------------------------------------------------
+// Step 1 (k_roi_sample_table): the four bilinear samples of every (roi, cell) are evaluated ONCE.
+// Step 2 (k_roi_pool_bwd_slab): one 1024-thread block owns CS channels of one image's whole feature map
+// in LDS ([pixel][CS] floats, 128 KiB at 64x64x8).  A thread is one (roi-cell, channel): consecutive
+// lanes are the CS channels of a pair (distinct, bank-consecutive addresses), so an LDS atomic
+// instruction only serialises when two of its 64/CS pairs hit the same pixel — with a pair per lane
+// (the first version) overlapping cells of one ROI serialised 10x and the kernel took 0.55 ms.  No
+// global atomics, no pre-zeroing: the slab is written once as float4s.
+struct __attribute__((aligned(16))) roi_sample_rec {
+  int16_t top, left, bot, right;   // top < 0: sample outside the feature map (contributes nothing)
+  float ylerp, xlerp;
+};
+
+__global__ void __launch_bounds__(256)
+k_roi_sample_table(const float4* __restrict__ rois, const int32_t* __restrict__ roi_count, int B, int R, int FH,
+                   int FW, float im_h, float im_w, int ph, int pw, roi_sample_rec* __restrict__ table) {
+  const int cells = ph * pw;
+  const int i = blockIdx.x * 256 + threadIdx.x;      // (b, r, cell)
+  if (i >= B * R * cells) return;
+  const int rr = i / cells, cell = i - rr * cells;
+  const int b = rr / R, r = rr - b * R;
+  const int py = cell / pw, px = cell - py * pw;
+  roi_sample_rec rec[4];
+  if (r < roi_count[b]) {
+    const roi_geom g = roi_geometry(rois[rr], im_h, im_w, FH, FW, 2 * ph, 2 * pw);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const roi_sample sq = roi_sample_at(g, 2 * py + (q >> 1), 2 * px + (q & 1), FH, FW, 2 * ph, 2 * pw);
+      rec[q].top = sq.valid ? (int16_t)sq.top : (int16_t)-1;
+      rec[q].left = (int16_t)sq.left; rec[q].bot = (int16_t)sq.bot; rec[q].right = (int16_t)sq.right;
+      rec[q].ylerp = sq.ylerp; rec[q].xlerp = sq.xlerp;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { rec[q].top = -1; rec[q].left = rec[q].bot = rec[q].right = 0; rec[q].ylerp = rec[q].xlerp = 0.f; }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) table[(size_t)i * 4 + q] = rec[q];
+}
+
+template <int CS>
 __global__ void __launch_bounds__(1024)
 k_roi_pool_bwd_slab(const float* __restrict__ dout, const uint8_t* __restrict__ argmax,
-                    const float4* __restrict__ rois, const int32_t* __restrict__ roi_count, int R, int FH,
-                    int FW, int C, float im_h, float im_w, int ph, int pw, float* __restrict__ dfeat) {
-  extern __shared__ __attribute__((aligned(16))) float slab[];
+                    const roi_sample_rec* __restrict__ table, const int32_t* __restrict__ roi_count, int R,
+                    int FH, int FW, int C, int cells, float* __restrict__ dfeat) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];   // [npix][CS]
   const int b = blockIdx.y, c0 = blockIdx.x * CS;
   const int npix = FH * FW;
   for (int i = threadIdx.x; i < npix * CS / 4; i += 1024)
     reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  const int cells = ph * pw, ch = 2 * ph, cw = 2 * pw;
   const int nroi = min(roi_count[b], R);
   const int pairs = nroi * cells;
-  for (int pair = threadIdx.x; pair < pairs; pair += 1024) {
-    const int r = pair / cells, cell = pair - r * cells;
-    const int py = cell / pw, px = cell - py * pw;
-    const int rr = b * R + r;
-    const roi_geom g = roi_geometry(rois[rr], im_h, im_w, FH, FW, ch, cw);
-    roi_sample s[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s[q] = roi_sample_at(g, 2 * py + (q >> 1), 2 * px + (q & 1), FH, FW, ch, cw);
-    const size_t obase = ((size_t)rr * cells + cell) * C + c0;
-    float go[CS];
-    uint8_t am[CS];
-#pragma unroll
-    for (int v = 0; v < CS / 4; ++v) {
-      const float4 t = reinterpret_cast<const float4*>(dout + obase)[v];
-      go[4 * v] = t.x; go[4 * v + 1] = t.y; go[4 * v + 2] = t.z; go[4 * v + 3] = t.w;
-      const uint32_t a = reinterpret_cast<const uint32_t*>(argmax + obase)[v];
-      am[4 * v] = a & 3; am[4 * v + 1] = (a >> 8) & 3; am[4 * v + 2] = (a >> 16) & 3; am[4 * v + 3] = (a >> 24) & 3;
-    }
-#pragma unroll
-    for (int cc = 0; cc < CS; ++cc) {
-      const int q = am[cc];
-      roi_sample sq = s[0];
-      if (q == 1) sq = s[1];
-      if (q == 2) sq = s[2];
-      if (q == 3) sq = s[3];
-      if (!sq.valid || go[cc] == 0.f) continue;
-      const float dtop = (1.f - sq.ylerp) * go[cc];
-      const float dbot = sq.ylerp * go[cc];
-      if (DBG == 1) continue;
-      float* pl = slab + cc * npix;   // channel-major planes: lanes (different pixels) hit different banks
-      atomicAdd(&pl[sq.top * FW + sq.left], (1.f - sq.xlerp) * dtop);
-      atomicAdd(&pl[sq.top * FW + sq.right], sq.xlerp * dtop);
-      atomicAdd(&pl[sq.bot * FW + sq.left], (1.f - sq.xlerp) * dbot);
-      atomicAdd(&pl[sq.bot * FW + sq.right], sq.xlerp * dbot);
-    }
+  const int cc = threadIdx.x % CS;
+  for (int pair = threadIdx.x / CS; pair < pairs; pair += 1024 / CS) {
+    const size_t gp = (size_t)b * R * cells + pair;
+    const size_t o = gp * C + c0 + cc;
+    const float go = dout[o];
+    const int q = argmax[o] & 3;
+    const roi_sample_rec s = table[gp * 4 + q];
+    if (s.top < 0 || go == 0.f) continue;
+    const float dtop = (1.f - s.ylerp) * go;
+    const float dbot = s.ylerp * go;
+    atomicAdd(&slab[(s.top * FW + s.left) * CS + cc], (1.f - s.xlerp) * dtop);
+    atomicAdd(&slab[(s.top * FW + s.right) * CS + cc], s.xlerp * dtop);
+    atomicAdd(&slab[(s.bot * FW + s.left) * CS + cc], (1.f - s.xlerp) * dbot);
+    atomicAdd(&slab[(s.bot * FW + s.right) * CS + cc], s.xlerp * dbot);
   }
   __syncthreads();
   float* fb = dfeat + (size_t)b * npix * C + c0;
-  if (DBG == 2) return;
-  for (int i = threadIdx.x; i < npix * (CS / 4); i += 1024) {
-    const int part = i / npix, pix = i - part * npix;   // consecutive lanes = consecutive pixels (conflict-free)
-    const float* pl = slab + 4 * part * npix + pix;
-    *reinterpret_cast<float4*>(fb + (size_t)pix * C + 4 * part) = make_float4(pl[0], pl[npix], pl[2 * npix], pl[3 * npix]);
+  for (int i = threadIdx.x; i < npix * CS / 4; i += 1024) {
+    const int pix = i / (CS / 4), part = i - pix * (CS / 4);
+    *reinterpret_cast<float4*>(fb + (size_t)pix * C + 4 * part) = reinterpret_cast<const float4*>(slab)[i];
   }
 }
 
-static int g_roi_dbg = 0;
-extern "C" void lmh_roi_dbg(int v) { g_roi_dbg = v; }
+extern "C" size_t lmh_roi_pool_bwd_workspace_bytes(int B, int R, int ph, int pw) {
+  return lmh_align_up((size_t)B * R * ph * pw * 4 * sizeof(roi_sample_rec), 256);
+}
+
 // dfeat is OVERWRITTEN (it does not need to be zeroed by the caller).
 extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const float* rois,
                                 const int32_t* roi_count, int B, int R, int FH, int FW, int C,
-                                float im_h, float im_w, int ph, int pw, float* dfeat,
+                                float im_h, float im_w, int ph, int pw, float* dfeat, void* ws, size_t ws_bytes,
                                 lmh_stream_t stream) {
   LMH_CHECK_ARG(dout && argmax && rois && roi_count && dfeat);
   LMH_CHECK_ARG(B > 0 && R > 0 && FH > 0 && FW > 0 && C > 0 && ph > 0 && pw > 0);
   hipStream_t st = (hipStream_t)stream;
   const size_t npix = (size_t)FH * FW;
   const size_t lds_cap = 160 * 1024;
-  if ((C % 8) == 0 && npix * 8 * sizeof(float) <= lds_cap) {
-    static bool attr8 = false;
-    if (!attr8) {
-      LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<8>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-      attr8 = true;
+  static const int force_cs = getenv("LMH_ROI_CS") ? atoi(getenv("LMH_ROI_CS")) : 0;   // diagnostics
+  const bool slab8 = force_cs != 4 && (C % 8) == 0 && npix * 8 * sizeof(float) <= lds_cap;
+  const bool slab4 = (C % 4) == 0 && npix * 4 * sizeof(float) <= lds_cap;
+  if ((slab8 || slab4) && FH < 32768 && FW < 32768) {
+    if (!ws || ws_bytes < lmh_roi_pool_bwd_workspace_bytes(B, R, ph, pw)) {
+      lmh_set_error("lmh_roi_pool_bwd: workspace too small");
+      return LMH_ERR_WORKSPACE;
     }
-    if (g_roi_dbg == 1) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
-      hipLaunchKernelGGL((k_roi_pool_bwd_slab<8, 1>), dim3(C / 8, B), dim3(1024), npix * 8 * sizeof(float), st, dout,
-                       argmax, reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, dfeat);
-    } else if (g_roi_dbg == 2) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
-      hipLaunchKernelGGL((k_roi_pool_bwd_slab<8, 2>), dim3(C / 8, B), dim3(1024), npix * 8 * sizeof(float), st, dout,
-                       argmax, reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, dfeat);
-    } else
-    hipLaunchKernelGGL((k_roi_pool_bwd_slab<8>), dim3(C / 8, B), dim3(1024), npix * 8 * sizeof(float), st, dout,
-                       argmax, reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw,
-                       dfeat);
-  } else if ((C % 4) == 0 && npix * 4 * sizeof(float) <= lds_cap) {
-    static bool attr4 = false;
-    if (!attr4) {
-      LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<4>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-      attr4 = true;
+    roi_sample_rec* table = reinterpret_cast<roi_sample_rec*>(ws);
+    const int cells = ph * pw;
+    hipLaunchKernelGGL(k_roi_sample_table, dim3((B * R * cells + 255) / 256), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(rois), roi_count, B, R, FH, FW, im_h, im_w, ph, pw, table);
+    if (slab8) {
+      static bool attr8 = false;
+      if (!attr8) {
+        LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<8>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        attr8 = true;
+      }
+      hipLaunchKernelGGL((k_roi_pool_bwd_slab<8>), dim3(C / 8, B), dim3(1024), npix * 8 * sizeof(float), st, dout,
+                         argmax, table, roi_count, R, FH, FW, C, cells, dfeat);
+    } else {
+      static bool attr4 = false;
+      if (!attr4) {
+        LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        attr4 = true;
+      }
+      hipLaunchKernelGGL((k_roi_pool_bwd_slab<4>), dim3(C / 4, B), dim3(1024), npix * 4 * sizeof(float), st, dout,
+                         argmax, table, roi_count, R, FH, FW, C, cells, dfeat);
     }
-    hipLaunchKernelGGL((k_roi_pool_bwd_slab<4>), dim3(C / 4, B), dim3(1024), npix * 4 * sizeof(float), st, dout,
-                       argmax, reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw,
-                       dfeat);
   } else {   // very large feature maps: global scatter-add
     LMH_CHECK_HIP(hipMemsetAsync(dfeat, 0, (size_t)B * npix * C * sizeof(float), st));
     const int threads = C < 256 ? ((C + 63) / 64 * 64) : 256;

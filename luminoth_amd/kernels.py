@@ -26,8 +26,19 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)   # ~10x cheaper than current_stream()
+
+
+def _stream_id(device=None):
+    """Raw hipStream_t (int) of torch's CURRENT stream on `device` (default: current device)."""
+    if _raw_stream is not None:
+        idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_stream_id())
 
 
 def _f32(t):
@@ -41,7 +52,7 @@ _ws_cache = {}
 def _workspace(nbytes, device, tag):
     """Persistent scratch per (tag, device, stream): no allocation in the steady state, and two
     streams never share a scratch buffer."""
-    key = (tag, device, torch.cuda.current_stream(device).cuda_stream)
+    key = (tag, device, _stream_id(device))
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -351,9 +362,10 @@ def roi_pool_bwd(dout, argmax, rois, roi_count, feat_shape, im_shape, ph=7, pw=7
     B, FH, FW, C = feat_shape
     R = rois.shape[1]
     dfeat = out if out is not None else torch.empty(feat_shape, dtype=torch.float32, device=dout.device)   # overwritten
+    ws = _workspace(lib.lmh_roi_pool_bwd_workspace_bytes(B, R, ph, pw), dout.device, 'roi_bwd')
     check(lib.lmh_roi_pool_bwd(_p(dout), _p(argmax), _p(rois), _p(roi_count), B, R, FH, FW, C,
-                               float(im_shape[0]), float(im_shape[1]), ph, pw, _p(dfeat), _stream()),
-          'lmh_roi_pool_bwd')
+                               float(im_shape[0]), float(im_shape[1]), ph, pw, _p(dfeat), _p(ws),
+                               ctypes.c_size_t(ws.numel()), _stream()), 'lmh_roi_pool_bwd')
     return dfeat
 
 

@@ -25,7 +25,7 @@ class SideStream(object):
 
     @classmethod
     def get(cls, device):
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, K._stream_id(device))
         st = cls._streams.get(key)
         if st is None:
             st = torch.cuda.Stream(device=device)

@@ -255,21 +255,26 @@ class FasterRCNN(object):
             rpn = self._rpn
             fh, fw = feat.shape[1], feat.shape[2]
             rpn_pred = rpn.heads(f_rpn)
-            # ---- aux stream: proposals -> RCNN forward -> RCNN loss -> RCNN backward
+            # Host enqueue order matters while the host is not far ahead of the GPU: the proposal chain is
+            # ONE C call (cheap to enqueue, long to run), so it goes first; then the RPN branch of the main
+            # stream; the RCNN part of the aux stream last (it cannot start before the NMS finishes anyway).
+            # ---- aux stream: proposals
             aux.wait_stream(main)
             with torch.cuda.stream(aux):
                 prop = rpn._proposal(rpn_pred['rpn_cls_score'].detach(), rpn_pred['rpn_bbox_pred'].detach(),
                                      self._anchor_ref_i32, (fh, fw), self._anchor_stride, im_shape)
-                cp = self._rcnn(f_rcnn, prop['proposals'], prop['num_proposals'], im_shape, self.base_network,
-                                gt_boxes=gt, gt_count=gt_count, seeds=seeds, is_training=True)
-                rcnn_losses = self._rcnn.loss(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
-                (rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).backward()
             for t in (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred'], feat, gt, gt_count, seeds):
                 t.record_stream(aux)
             # ---- main stream: RPN targets -> RPN loss -> RPN backward
             rpn.targets(rpn_pred, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape)
             rpn_losses = rpn.loss(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
             (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss']).backward()
+            # ---- aux stream: RCNN forward -> RCNN loss -> RCNN backward
+            with torch.cuda.stream(aux):
+                cp = self._rcnn(f_rcnn, prop['proposals'], prop['num_proposals'], im_shape, self.base_network,
+                                gt_boxes=gt, gt_count=gt_count, seeds=seeds, is_training=True)
+                rcnn_losses = self._rcnn.loss(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
+                (rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).backward()
             # ---- join, trunk backward
             main.wait_stream(aux)
             for t in (f_rcnn.grad, rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']):
