@@ -158,11 +158,9 @@ extern "C" int lmh_roi_pool_fwd(const float* feat, const float* rois, const int3
 // ---- backward, slab variant (default) --------------------------------------------------------------
 // Step 1 (k_roi_sample_table): the four bilinear samples of every (roi, cell) are evaluated ONCE.
 // Step 2 (k_roi_pool_bwd_slab): one 1024-thread block owns CS channels of one image's whole feature map
-// in LDS ([pixel][CS] floats, 128 KiB at 64x64x8).  A thread is one (roi-cell, channel): consecutive
-// lanes are the CS channels of a pair (distinct, bank-consecutive addresses), so an LDS atomic
-// instruction only serialises when two of its 64/CS pairs hit the same pixel — with a pair per lane
-// (the first version) overlapping cells of one ROI serialised 10x and the kernel took 0.55 ms.  No
-// global atomics, no pre-zeroing: the slab is written once as float4s.
+// in LDS ([pixel][CS] 64-bit cells, 128 KiB at 64x64x4).  A thread is one (roi-cell, channel):
+// consecutive lanes are the CS channels of a pair (distinct, bank-consecutive addresses).  No global
+// atomics, no pre-zeroing: the slab is written once as float4s.
 struct __attribute__((aligned(16))) roi_sample_rec {
   int16_t top, left, bot, right;   // top < 0: sample outside the feature map (contributes nothing)
   float ylerp, xlerp;
@@ -195,16 +193,26 @@ k_roi_sample_table(const float4* __restrict__ rois, const int32_t* __restrict__ 
   for (int q = 0; q < 4; ++q) table[(size_t)i * 4 + q] = rec[q];
 }
 
+// Accumulation is 64-bit FIXED POINT (value * 2^38, ds_add_u64): on gfx950 an LDS float atomic retires
+// ~0.33 lane-ops/clk/CU while the integer ones retire >3.5 (scripts/probes/lds_atomic_rate.hip), and integer
+// addition is associative, so the result is the exactly-rounded sum of the fp32 terms, bit-identical run to
+// run (the float-atomic version depended on arrival order).  Range: |sum| < 2^25, resolution 2^-38.
+#define ROI_FX_SCALE 274877906944.0f          /* 2^38 */
+#define ROI_FX_INV (1.0 / 274877906944.0)
+
+__device__ __forceinline__ void roi_fx_add(unsigned long long* cell, float v) {
+  atomicAdd(cell, (unsigned long long)(long long)__float2ll_rn(v * ROI_FX_SCALE));
+}
+
 template <int CS>
 __global__ void __launch_bounds__(1024)
 k_roi_pool_bwd_slab(const float* __restrict__ dout, const uint8_t* __restrict__ argmax,
                     const roi_sample_rec* __restrict__ table, const int32_t* __restrict__ roi_count, int R,
                     int FH, int FW, int C, int cells, float* __restrict__ dfeat) {
-  extern __shared__ __attribute__((aligned(16))) float slab[];   // [npix][CS]
+  extern __shared__ __attribute__((aligned(16))) unsigned long long slab[];   // [npix][CS] fixed point
   const int b = blockIdx.y, c0 = blockIdx.x * CS;
   const int npix = FH * FW;
-  for (int i = threadIdx.x; i < npix * CS / 4; i += 1024)
-    reinterpret_cast<float4*>(slab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = threadIdx.x; i < npix * CS; i += 1024) slab[i] = 0ull;
   __syncthreads();
   const int nroi = min(roi_count[b], R);
   const int pairs = nroi * cells;
@@ -218,16 +226,22 @@ k_roi_pool_bwd_slab(const float* __restrict__ dout, const uint8_t* __restrict__ 
     if (s.top < 0 || go == 0.f) continue;
     const float dtop = (1.f - s.ylerp) * go;
     const float dbot = s.ylerp * go;
-    atomicAdd(&slab[(s.top * FW + s.left) * CS + cc], (1.f - s.xlerp) * dtop);
-    atomicAdd(&slab[(s.top * FW + s.right) * CS + cc], s.xlerp * dtop);
-    atomicAdd(&slab[(s.bot * FW + s.left) * CS + cc], (1.f - s.xlerp) * dbot);
-    atomicAdd(&slab[(s.bot * FW + s.right) * CS + cc], s.xlerp * dbot);
+    roi_fx_add(&slab[(s.top * FW + s.left) * CS + cc], (1.f - s.xlerp) * dtop);
+    roi_fx_add(&slab[(s.top * FW + s.right) * CS + cc], s.xlerp * dtop);
+    roi_fx_add(&slab[(s.bot * FW + s.left) * CS + cc], (1.f - s.xlerp) * dbot);
+    roi_fx_add(&slab[(s.bot * FW + s.right) * CS + cc], s.xlerp * dbot);
   }
   __syncthreads();
   float* fb = dfeat + (size_t)b * npix * C + c0;
   for (int i = threadIdx.x; i < npix * CS / 4; i += 1024) {
     const int pix = i / (CS / 4), part = i - pix * (CS / 4);
-    *reinterpret_cast<float4*>(fb + (size_t)pix * C + 4 * part) = reinterpret_cast<const float4*>(slab)[i];
+    const unsigned long long* p4 = slab + (size_t)pix * CS + 4 * part;
+    float4 v;
+    v.x = (float)((double)(long long)p4[0] * ROI_FX_INV);
+    v.y = (float)((double)(long long)p4[1] * ROI_FX_INV);
+    v.z = (float)((double)(long long)p4[2] * ROI_FX_INV);
+    v.w = (float)((double)(long long)p4[3] * ROI_FX_INV);
+    *reinterpret_cast<float4*>(fb + (size_t)pix * C + 4 * part) = v;
   }
 }
 
@@ -246,8 +260,8 @@ extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const 
   const size_t npix = (size_t)FH * FW;
   const size_t lds_cap = 160 * 1024;
   static const int force_cs = getenv("LMH_ROI_CS") ? atoi(getenv("LMH_ROI_CS")) : 0;   // diagnostics
-  const bool slab8 = force_cs != 4 && (C % 8) == 0 && npix * 8 * sizeof(float) <= lds_cap;
-  const bool slab4 = (C % 4) == 0 && npix * 4 * sizeof(float) <= lds_cap;
+  const bool slab8 = force_cs != 4 && (C % 8) == 0 && npix * 8 * sizeof(unsigned long long) <= lds_cap;
+  const bool slab4 = (C % 4) == 0 && npix * 4 * sizeof(unsigned long long) <= lds_cap;
   if ((slab8 || slab4) && FH < 32768 && FW < 32768) {
     if (!ws || ws_bytes < lmh_roi_pool_bwd_workspace_bytes(B, R, ph, pw)) {
       lmh_set_error("lmh_roi_pool_bwd: workspace too small");
@@ -264,7 +278,7 @@ extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const 
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         attr8 = true;
       }
-      hipLaunchKernelGGL((k_roi_pool_bwd_slab<8>), dim3(C / 8, B), dim3(1024), npix * 8 * sizeof(float), st, dout,
+      hipLaunchKernelGGL((k_roi_pool_bwd_slab<8>), dim3(C / 8, B), dim3(1024), npix * 8 * sizeof(unsigned long long), st, dout,
                          argmax, table, roi_count, R, FH, FW, C, cells, dfeat);
     } else {
       static bool attr4 = false;
@@ -273,7 +287,7 @@ extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const 
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         attr4 = true;
       }
-      hipLaunchKernelGGL((k_roi_pool_bwd_slab<4>), dim3(C / 4, B), dim3(1024), npix * 4 * sizeof(float), st, dout,
+      hipLaunchKernelGGL((k_roi_pool_bwd_slab<4>), dim3(C / 4, B), dim3(1024), npix * 4 * sizeof(unsigned long long), st, dout,
                          argmax, table, roi_count, R, FH, FW, C, cells, dfeat);
     }
   } else {   // very large feature maps: global scatter-add
