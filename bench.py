@@ -54,8 +54,11 @@ def synth_batch(B, H, W, G, num_classes, seed, device):
 
 
 def cpu_baseline(cfg_kwargs, sd, H, W, G, num_classes, n_images):
+    """The CPU oracle (oracle/model.py: torch-CPU fp32 convs + numpy box/NMS stages — a port, the TF
+    reference cannot run here) timed on this host for ONE full train step over `n_images` images of the
+    benchmark shape.  32 threads: the oracle's scaling peaks there on the 256-thread GPU hosts."""
     from oracle.model import OracleFasterRCNN
-    cores = min(os.cpu_count() or 1, 64)      # torch-CPU conv scaling flattens well before 256 threads
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     oracle = OracleFasterRCNN(sd, num_classes=num_classes, seed=0, **cfg_kwargs)
     images, (gt, _) = synth_batch(n_images, H, W, G, num_classes, 1234, 'cpu')
@@ -65,6 +68,21 @@ def cpu_baseline(cfg_kwargs, sd, H, W, G, num_classes, n_images):
     return {'value': n_images / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
             'sample': '%d image(s) %dx%d, one full oracle train step (torch-CPU fp32 + numpy), %.1fs'
                       % (n_images, H, W, dt)}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_traffic.json,
+    produced by scripts/gpu_pmc_bench.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+    same bench command; counters cannot be read from inside the process).  (None, None) if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))['kernels'].get(kernel.replace(' ', ''))
+        return (k['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)) if k else (None, None)
+    except Exception:
+        return None, None
 
 
 def main():
@@ -78,7 +96,7 @@ def main():
     ap.add_argument('--classes', type=int, default=80)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=1)
+    ap.add_argument('--cpu-images', type=int, default=6)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -153,8 +171,11 @@ def main():
         fl = r['flops'] / r['launches']
         ms = r['ms'] / r['launches']
         achieved = fl / (ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(name)
         roofline = {'bound': 'mfma', 'kernel': name, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                    'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                    'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes)',
+                    'traffic_source': traffic_src,
                     'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
                     'all_conv_kernels': {k: {'launches_per_step': v['launches'] / nprof,
                                              'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
