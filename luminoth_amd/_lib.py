@@ -68,9 +68,9 @@ SIGNATURES = {
     'lmh_last_error': (ctypes.c_char_p, []),
     'lmh_device_count': (c_i, []),
     'lmh_conv2d_fwd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
-    'lmh_conv2d_bwd_data': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_conv2d_bwd_data': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     'lmh_conv2d_bwd_weight_workspace_bytes': (c_sz, [P(ConvDesc)]),
-    'lmh_conv2d_bwd_weight': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_conv2d_bwd_weight': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_kernel_id': (c_i, [P(ConvDesc), c_i]),
     'lmh_conv2d_force_config': (None, [c_i, c_i, c_i]),
     'lmh_act_bwd_workspace_bytes': (c_sz, [c_i64, c_i]),

@@ -102,12 +102,13 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
 }
 
 extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, const float* w,
-                                   const float* kscale, const float* addend, float* dx,
+                                   const float* kscale, const float* addend, const float* yact, float* dx,
                                    lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(dy && w && dx);
   LMH_CHECK_ARG(d->R * d->S == 1 || (d->K % BK) == 0);
+  LMH_CHECK_ARG(yact == nullptr || (bwd_data_fast(d) && d->act != 0));   // fused act'(y) only on the fast path
   const int64_t M = (int64_t)d->N * d->H * d->W;
   const bool fast = bwd_data_fast(d);
   int bm, bn;
@@ -116,9 +117,12 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   const int grid = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
 #define LAUNCH_BD(BM_, BN_)                                                                                 \
   do {                                                                                                      \
-    if (fast)                                                                                               \
-      hipLaunchKernelGGL((k_conv_bwd_data<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale,      \
-                         addend, dx);                                                                       \
+    if (fast && yact)                                                                                       \
+      hipLaunchKernelGGL((k_conv_bwd_data<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, \
+                         addend, yact, dx);                                                                 \
+    else if (fast)                                                                                          \
+      hipLaunchKernelGGL((k_conv_bwd_data<BM_, BN_, false>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, \
+                         addend, yact, dx);                                                                 \
     else                                                                                                    \
       hipLaunchKernelGGL((k_conv_bwd_data_gen<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale,  \
                          addend, dx);                                                                       \
@@ -177,12 +181,14 @@ extern "C" size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d) 
   if (!d) return 0;
   int bm, bn, splits, kps;
   bwd_weight_plan(d, &bm, &bn, &splits, &kps);
-  if (splits <= 1) return 256;
-  return lmh_align_up((size_t)splits * d->R * d->S * d->C * d->K * sizeof(float), 256);
+  // split-K slabs, then [splits][K] column-sum partials (fused dbeta / dbias)
+  const size_t slabs = splits <= 1 ? 256 : lmh_align_up((size_t)splits * d->R * d->S * d->C * d->K * sizeof(float), 256);
+  return slabs + lmh_align_up((size_t)splits * d->K * sizeof(float), 256);
 }
 
-extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* dy, float* dw,
-                                     void* ws, size_t ws_bytes, lmh_stream_t stream) {
+extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* dy, const float* yact,
+                                     float* dw, float* colsum, void* ws, size_t ws_bytes,
+                                     lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(x && dy && dw);
@@ -193,15 +199,23 @@ extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, con
     lmh_set_error("lmh_conv2d_bwd_weight: workspace too small");
     return LMH_ERR_WORKSPACE;
   }
+  LMH_CHECK_ARG((yact == nullptr && colsum == nullptr) || bwd_weight_fast(d));   // fused paths: fast kernels only
+  LMH_CHECK_ARG(yact == nullptr || d->act != 0);
   hipStream_t st = (hipStream_t)stream;
+  const size_t slab_bytes = splits > 1 ? lmh_align_up((size_t)splits * d->R * d->S * d->C * d->K * sizeof(float), 256) : 256;
   float* out = splits > 1 ? reinterpret_cast<float*>(ws) : dw;
+  float* cpart = colsum ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + slab_bytes) : nullptr;
   const bool fast = bwd_weight_fast(d);
   dim3 grid(d->R * d->S * ((d->C + bm - 1) / bm), (d->K + bn - 1) / bn, splits);
+  const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
 #define LAUNCH_BW(BM_, BN_)                                                                              \
   do {                                                                                                   \
-    if (fast)                                                                                            \
-      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_>), grid, dim3(256), 0, st, *d, x, dy, out, kps,    \
-                         lmh_make_fastdiv((uint32_t)d->OW), lmh_make_fastdiv((uint32_t)d->OH));           \
+    if (fast && yact)                                                                                    \
+      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, true>), grid, dim3(256), 0, st, *d, x, dy, out, kps, \
+                         dvw, dvh, yact, cpart);                                                         \
+    else if (fast)                                                                                       \
+      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, false>), grid, dim3(256), 0, st, *d, x, dy, out, kps, \
+                         dvw, dvh, yact, cpart);                                                         \
     else                                                                                                 \
       hipLaunchKernelGGL((k_conv_bwd_weight_gen<BM_, BN_>), grid, dim3(256), 0, st, *d, x, dy, out, kps); \
   } while (0)
@@ -210,10 +224,12 @@ extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, con
   else if (bn == 128) LAUNCH_BW(64, 128);
   else LAUNCH_BW(64, 64);
 #undef LAUNCH_BW
-  if (splits > 1) {
-    const int64_t n = (int64_t)d->R * d->S * d->C * d->K;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, st,
-                       reinterpret_cast<const float*>(ws), n, splits, dw);
+  if (splits > 1 || colsum) {
+    const int64_t n = splits > 1 ? (int64_t)d->R * d->S * d->C * d->K : 0;
+    const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;
+    const int nb_col = colsum ? (d->K + 31) / 32 : 0;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, st, reinterpret_cast<const float*>(ws),
+                       n, splits, dw, cpart, colsum, d->K, nb_slab);
   }
   LMH_CHECK_LAUNCH();
   return LMH_OK;

@@ -130,6 +130,16 @@ __device__ __forceinline__ void mfma_stage_split(const float* __restrict__ As, c
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// g = dy * act'(y): act 1 = relu (y > 0), 2 = relu6 (0 < y < 6); y is the layer OUTPUT (post-activation)
+__device__ __forceinline__ f32x4 act_mask(f32x4 dy, f32x4 y, float hi) {
+  f32x4 g;
+  g.x = (y.x > 0.f && y.x < hi) ? dy.x : 0.f;
+  g.y = (y.y > 0.f && y.y < hi) ? dy.y : 0.f;
+  g.z = (y.z > 0.f && y.z < hi) ? dy.z : 0.f;
+  g.w = (y.w > 0.f && y.w < hi) ? dy.w : 0.f;
+  return g;
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
 #pragma unroll
@@ -295,11 +305,11 @@ k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict
 //   dx[p, c] = sum_{r,s,k} dy[opix(p,r,s), k] * kscale[k] * w[r,s,c,k]   (+ addend)
 //   GEMM M = N*H*W, N = C, Kg = R*S*K.  A: dy gather (K-contiguous).  B: w[rs][c][k] (K-contiguous).
 // ============================================================================
-template <int BM, int BN>
+template <int BM, int BN, bool YACT>   // YACT: A operand is dy * act'(yact) (fused activation backward)
 __global__ void __launch_bounds__(256)
 k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
                 const float* __restrict__ kscale, const float* __restrict__ addend,
-                float* __restrict__ dx) {
+                const float* __restrict__ yact, float* __restrict__ dx) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BM * LDK, B_SZ = BN * LDK;
@@ -328,7 +338,9 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
     } else { a_n[j] = -1; a_h[j] = 0; a_w[j] = 0; }
   }
   const float* pa[AJ];
+  const float* py[AJ];   // activation output at the same positions (fused g = dy*act'(y)); zero page if unused
   int inca[AJ];
+  const float act_hi = (d.act == 2) ? 6.f : INFINITY;
 #define BD_SETUP_RS(rs_)                                                                                \
   do {                                                                                                  \
     const int r_ = (rs_) / d.S, s_ = (rs_) - r_ * d.S;                                                  \
@@ -341,7 +353,9 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
         ok = ok && (oh * d.stride == th) && (ow * d.stride == tw);                                      \
       }                                                                                                 \
       ok = ok && oh < d.OH && ow < d.OW;                                                                \
-      pa[j] = ok ? dy + ((size_t)(a_n[j] * d.OH + oh) * d.OW + ow) * K + 4 * kq : lmh_zero_page;        \
+      const size_t off_ = ((size_t)(a_n[j] * d.OH + oh) * d.OW + ow) * K + 4 * kq;                      \
+      pa[j] = ok ? dy + off_ : lmh_zero_page;                                                           \
+      py[j] = (ok && YACT) ? yact + off_ : lmh_zero_page;                                               \
       inca[j] = ok ? BK : 0;                                                                            \
     }                                                                                                   \
   } while (0)
@@ -360,7 +374,7 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
   const float* pks = kscale ? kscale + 4 * kq : lmh_zero_page;
   const int incks = kscale ? BK : 0;
 
-  f32x4 ra[AJ], rb[BJ], ks;
+  f32x4 ra[AJ], ry[AJ], rb[BJ], ks;
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   int rs = 0, kc = 0;
@@ -373,7 +387,7 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
       _Pragma("unroll") for (int j = 0; j < BJ; ++j) pb[j] += tapb[j];            \
       pks -= (KC - 1) * incks;                                                    \
     } else {                                                                      \
-      _Pragma("unroll") for (int j = 0; j < AJ; ++j) pa[j] += inca[j];            \
+      _Pragma("unroll") for (int j = 0; j < AJ; ++j) { pa[j] += inca[j]; if (YACT) py[j] += inca[j]; } \
       _Pragma("unroll") for (int j = 0; j < BJ; ++j) pb[j] += incb[j];            \
       pks += incks;                                                               \
     }                                                                             \
@@ -382,12 +396,14 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
   do {                                                                                             \
     ks = *reinterpret_cast<const f32x4*>(pks);                                                     \
     _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]); \
+    if (YACT) { _Pragma("unroll") for (int j = 0; j < AJ; ++j) ry[j] = *reinterpret_cast<const f32x4*>(py[j]); } \
     _Pragma("unroll") for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb[j]); \
   } while (0)
 #define BD_STORE(buf_)                                                                             \
   do {                                                                                             \
     float* Ad = As + (buf_) * A_SZ;                                                                \
     float* Bd = Bs + (buf_) * B_SZ;                                                                \
+    if (YACT) { _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[j] = act_mask(ra[j], ry[j], act_hi); } \
     if (kscale) { _Pragma("unroll") for (int j = 0; j < AJ; ++j) ra[j] *= ks; }                    \
     _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                 \
         *reinterpret_cast<f32x4*>(&Ad[(arow + 32 * j) * LDK + 4 * kq]) = ra[j];                    \
@@ -402,7 +418,7 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
     if (kt + 2 < KT) BD_ADVANCE();
-    mfma_stage_split<TM, TN, true, true, LDK, LDK, AJ + BJ, AJ + BJ + 1>(
+    mfma_stage_split<TM, TN, true, true, LDK, LDK, AJ + BJ, (YACT ? 2 : 1) * AJ + BJ + 1>(
         As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane,
         [&]() { BD_STORE(cur ^ 1); }, [&]() { BD_LOAD(); });
     __syncthreads();
@@ -434,10 +450,11 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
 //   dw[rs, c, k] = sum_p x[pix(p,r,s), c] * dy[p, k];  reduction split over gridDim.z
 //   GEMM M = C (per tap), N = K, Kg = P = N*OH*OW.  Both operands K-major ([pixel][channel]).
 // ============================================================================
-template <int BM, int BN>
+template <int BM, int BN, bool YACT>   // YACT: B operand is dy * act'(yact) (fused activation backward)
 __global__ void __launch_bounds__(256)
 k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ dy,
-                  float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh) {
+                  float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh,
+                  const float* __restrict__ yact, float* __restrict__ colsum_part) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
@@ -467,9 +484,15 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
   int pa0 = kt_begin * BK + ak;
   int bp = kt_begin * BK + bk;
   const float* xb = x + m0 + 4 * ax4;
-  const float* pdy = dy + (size_t)bp * K + n0 + 4 * bx4;
+  const size_t dy_off0 = (size_t)bp * K + n0 + 4 * bx4;
+  const float* pdy = dy + dy_off0;
+  const float* pyy = YACT ? yact + dy_off0 : lmh_zero_page;
   const size_t dy_row = (size_t)BROW_STEP * K, dy_stage = (size_t)BK * K;
-  f32x4 ra[AJ], rb[BJ];
+  const float act_hi = (d.act == 2) ? 6.f : INFINITY;
+  // per-channel sums of g (= dbeta / dbias) ride along in the blocks of the first (tap, c-tile) column
+  const bool do_colsum = colsum_part != nullptr && blockIdx.x == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[AJ], rb[BJ], ryb[BJ];
 #define BW_LOAD()                                                                                          \
   do {                                                                                                     \
     _Pragma("unroll") for (int j = 0; j < AJ; ++j) {                                                       \
@@ -485,13 +508,16 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
       const bool ok = b_col_ok && (bp + BROW_STEP * j) < P;                                                \
       const float* p_ = ok ? pdy + j * dy_row : lmh_zero_page;                                             \
       rb[j] = *reinterpret_cast<const f32x4*>(p_);                                                         \
+      if (YACT) ryb[j] = *reinterpret_cast<const f32x4*>((ok ? pyy + j * dy_row : lmh_zero_page));         \
     }                                                                                                      \
   } while (0)
-#define BW_ADVANCE() do { pa0 += BK; bp += BK; pdy += dy_stage; } while (0)
+#define BW_ADVANCE() do { pa0 += BK; bp += BK; pdy += dy_stage; if (YACT) pyy += dy_stage; } while (0)
 #define BW_STORE(buf_)                                                                                     \
   do {                                                                                                     \
     float* Ad = As + (buf_) * A_SZ;                                                                        \
     float* Bd = Bs + (buf_) * B_SZ;                                                                        \
+    if (YACT) { _Pragma("unroll") for (int j = 0; j < BJ; ++j) rb[j] = act_mask(rb[j], ryb[j], act_hi); }  \
+    if (do_colsum) { _Pragma("unroll") for (int j = 0; j < BJ; ++j) csum += rb[j]; }                       \
     _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                         \
         *reinterpret_cast<f32x4*>(&Ad[(ak + AROW_STEP * j) * BM + 4 * ax4]) = ra[j];                       \
     _Pragma("unroll") for (int j = 0; j < BJ; ++j)                                                         \
@@ -507,9 +533,11 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
     BW_ADVANCE();
-    mfma_stage_split<TM, TN, false, false, BM, BN, AJ + BJ, AJ + BJ>(
+    const f32x4 csum_before = csum;
+    mfma_stage_split<TM, TN, false, false, BM, BN, AJ + BJ, AJ + (YACT ? 2 : 1) * BJ>(
         As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane,
         [&]() { BW_STORE(cur ^ 1); }, [&]() { BW_LOAD(); });
+    if (kt + 1 >= kt_end) csum = csum_before;   // the tile stored in the last stage belongs to the next split
     __syncthreads();
   }
 #undef BW_ADVANCE
@@ -528,6 +556,18 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
       const int row = m0 + rr;
       if (row >= C) break;
       *reinterpret_cast<f32x4*>(o + (size_t)row * K + col) = *reinterpret_cast<const f32x4*>(&smem[rr * LDC + 4 * c4]);
+    }
+  }
+  if (do_colsum) {   // fold the BROW_STEP row-groups of every column group in a fixed order (deterministic)
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem);          // [BROW_STEP][BROW_T]
+    red[bk * BROW_T + bx4] = csum;
+    __syncthreads();
+    if (tid < BROW_T && (n0 + 4 * tid) < K) {
+      f32x4 t = red[tid];
+#pragma unroll
+      for (int g2 = 1; g2 < BROW_STEP; ++g2) t += red[g2 * BROW_T + tid];
+      *reinterpret_cast<f32x4*>(colsum_part + (size_t)blockIdx.z * K + n0 + 4 * tid) = t;
     }
   }
 }

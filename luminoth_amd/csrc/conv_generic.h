@@ -387,9 +387,29 @@ k_conv_bwd_weight_gen(lmh_conv_desc d, const float* __restrict__ x, const float*
   }
 }
 
-// deterministic split-K reduction: dw[i] = sum_s part[s][i]
+// deterministic split-K reduction: dw[i] = sum_s part[s][i] (blocks [0, nb_slab)); the remaining blocks fold
+// the fused column-sum partials colsum[k] = sum_s cpart[s][k] (dbeta / dbias from k_conv_bwd_weight), 32
+// columns x 8 split-groups per block with a fixed summation tree
 __global__ void __launch_bounds__(256)
-k_splitk_reduce(const float* __restrict__ part, int64_t n, int splits, float* __restrict__ out) {
+k_splitk_reduce(const float* __restrict__ part, int64_t n, int splits, float* __restrict__ out,
+                const float* __restrict__ cpart, float* __restrict__ colsum, int K, int nb_slab) {
+  if ((int)blockIdx.x >= nb_slab) {
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = ((int)blockIdx.x - nb_slab) * 32 + cl;
+    float s = 0.f;
+    if (c < K)
+      for (int b = g; b < splits; b += 8) s += cpart[(size_t)b * K + c];
+    red[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < K) {
+      float t = red[0][cl];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) t += red[i][cl];
+      colsum[c] = t;
+    }
+    return;
+  }
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   if (i + 3 < n) {
@@ -407,4 +427,3 @@ k_splitk_reduce(const float* __restrict__ part, int64_t n, int splits, float* __
     }
   }
 }
-

@@ -155,23 +155,37 @@ def conv2d_fwd(d, x, w, scale=None, shift=None, residual=None, in_sub=None, out=
     return y
 
 
-def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None):
+def conv_fused_act_ok(d):
+    """True when both backward kernels of `d` take the fused `yact` / `colsum` operands (fast paths)."""
+    lib = _lib.load()
+    return d.act != 0 and lib.lmh_conv2d_kernel_id(ctypes.byref(d), 1) < 1000000 and \
+        lib.lmh_conv2d_kernel_id(ctypes.byref(d), 2) < 1000000
+
+
+def conv_fused_colsum_ok(d):
+    """True when bwd_weight of `d` can emit the per-channel sums of its dy operand (fast path)."""
+    return _lib.load().lmh_conv2d_kernel_id(ctypes.byref(d), 2) < 1000000
+
+
+def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None, yact=None):
+    """yact: layer output y -> the kernel applies g = dy*act'(y) on load (fused activation backward)."""
     lib = _lib.load()
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
     with _timed(d, 1):
-        check(lib.lmh_conv2d_bwd_data(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(kscale), _p(addend), _p(dx),
-                                      _stream()), 'lmh_conv2d_bwd_data')
+        check(lib.lmh_conv2d_bwd_data(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(kscale), _p(addend), _p(yact),
+                                      _p(dx), _stream()), 'lmh_conv2d_bwd_data')
     return dx
 
 
-def conv2d_bwd_weight(d, x, dy, out=None):
+def conv2d_bwd_weight(d, x, dy, out=None, yact=None, colsum=None):
+    """yact: fused g = dy*act'(y); colsum (K,): WRITTEN with the per-channel sums of g."""
     lib = _lib.load()
     dw = out if out is not None else torch.empty((d.R, d.S, d.C, d.K), dtype=torch.float32, device=x.device)
     nbytes = lib.lmh_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
     ws = _workspace(nbytes, x.device, 'bwd_weight')
     with _timed(d, 2):
-        check(lib.lmh_conv2d_bwd_weight(ctypes.byref(d), _p(_f32(x)), _p(_f32(dy)), _p(dw), _p(ws),
-                                        ctypes.c_size_t(ws.numel()), _stream()), 'lmh_conv2d_bwd_weight')
+        check(lib.lmh_conv2d_bwd_weight(ctypes.byref(d), _p(_f32(x)), _p(_f32(dy)), _p(yact), _p(dw), _p(colsum),
+                                        _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_conv2d_bwd_weight')
     return dw
 
 

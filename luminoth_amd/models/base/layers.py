@@ -12,6 +12,7 @@ import torch
 
 from luminoth_amd import kernels as K
 
+FUSE_ACT = os.environ.get('LUMINOTH_AMD_FUSE_ACT', '0') == '1'
 BN_EPS = 1e-5  # slim resnet_arg_scope batch_norm_epsilon (truncated_base_network.py:69-73)
 
 
@@ -54,6 +55,7 @@ class ConvLayer(object):
         self.w_name = '%s/%s' % (scope, weight_name)
         self.b_name = '%s/%s' % (scope, bias_name)
         self._desc = {}
+        self._fused = {}
 
     # ---- variable names in TF creation order (drives fine_tune_from) --------
     def var_names(self):
@@ -89,45 +91,63 @@ class ConvLayer(object):
         d = self.desc(x.shape)
         return K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub)
 
-    def _weight_grads(self, d, x, g):
-        K.conv2d_bwd_weight(d, x, g, out=self.gw)
+    def _weight_grads(self, d, x, g, yact, colsum):
+        K.conv2d_bwd_weight(d, x, g, out=self.gw, yact=yact, colsum=colsum)
         if self.norm == 'bn':
             K.bn_param_grads(self.w, self.gw, self.bn['gbeta'], self.bn['mean'], self.bn['rstd'],
                              self.scale, out=self.bn['ggamma'])
 
-    def backward(self, x, y, dy, need_dx=True, addend=None):
+    def _fused_ok(self, d, key):
+        ok = self._fused.get(key)
+        if ok is None:
+            # Fusing act'(y) into the operand loads is supported by the kernels but OFF by default: it doubles
+            # the gather traffic of the (tap-repeated) A operand and measured slower than one streaming
+            # lmh_act_bwd pass (bwd_data 128x64: 167 us fused vs 75 + 20 us); the column sums stay fused.
+            ok = self._fused[key] = (FUSE_ACT and K.conv_fused_act_ok(d), K.conv_fused_colsum_ok(d))
+        return ok
+
+    def backward(self, x, y, dy, need_dx=True, addend=None, want_g=False):
         """dy: gradient w.r.t. the layer output (after residual add + act).
-        Returns (dx or None, g) with g = gradient w.r.t. the pre-activation sum
-        (== gradient of the residual branch)."""
+        Returns (dx or None, g) with g = dy * act'(y) = gradient w.r.t. the pre-activation sum (== gradient
+        of the residual branch); g is only materialised when `want_g` (the bottleneck's shortcut needs
+        it) or when the fast kernels cannot take it fused — otherwise both backward convolutions apply
+        act'(y) while they load dy, and the per-channel sums (dbeta / dbias) come out of bwd_weight."""
         d = self.desc(x.shape)
+        act_fused, colsum_fused = self._fused_ok(d, tuple(x.shape))
         colsum = None
         if self.trainable:
             if self.norm == 'bn':
                 colsum = self.bn['gbeta']
             elif self.norm == 'bias':
                 colsum = self.gb
-        if self.act:
-            g = K.act_bwd(dy, y, self.act, want_g=True, colsum=colsum)
+        colsum_in_wgrad = colsum is not None and colsum_fused
+        yact = None
+        if self.act and act_fused and not want_g:
+            g, yact = dy, y                               # fused: kernels mask on load
+        elif self.act:
+            g = K.act_bwd(dy, y, self.act, want_g=True, colsum=None if colsum_in_wgrad else colsum)
         else:
             g = dy
-            if colsum is not None:
+            if colsum is not None and not colsum_in_wgrad:
                 K.act_bwd(dy, None, None, want_g=False, colsum=colsum)
         if self.trainable:
+            cs = colsum if colsum_in_wgrad else None
             if SideStream.enabled:
                 main = torch.cuda.current_stream(x.device)
                 side = SideStream.get(x.device)
-                side.wait_stream(main)                  # g (and dbeta) are ready once `main` gets here
+                side.wait_stream(main)                  # dy / g are ready once `main` gets here
                 with torch.cuda.stream(side):
-                    self._weight_grads(d, x, g)
-                x.record_stream(side)                   # keep the buffers alive for the side stream
-                g.record_stream(side)
+                    self._weight_grads(d, x, g, yact, cs)
+                for t in (x, g, yact):                  # keep the buffers alive for the side stream
+                    if t is not None:
+                        t.record_stream(side)
             else:
-                self._weight_grads(d, x, g)
+                self._weight_grads(d, x, g, yact, cs)
         dx = None
         if need_dx:
             dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
-                                   addend=addend)
-        return dx, g
+                                   addend=addend, yact=yact)
+        return dx, (g if yact is None else None)
 
 
 class BNTable(object):
@@ -272,7 +292,7 @@ class BottleneckNode(object):
 
     def backward(self, saved, dy, need_dx):
         x, sc, a, b, y, geom = saved
-        d_b, g = self.conv3.backward(b, y, dy)
+        d_b, g = self.conv3.backward(b, y, dy, want_g=True)
         d_a, _ = self.conv2.backward(a, b, d_b)
         if self.shortcut is not None:
             d_sc, _ = self.shortcut.backward(x, sc, g, need_dx=need_dx)

@@ -403,6 +403,18 @@ def test_conv_fwd_bwd(K, case):
     dws = dw.cpu().numpy() * scale[None, None, None, :]
     tolw = 5e-5 * max(1.0, float(np.abs(dw_ref).max()))
     np.testing.assert_allclose(dws, dw_ref, rtol=1e-3, atol=tolw)
+    # fused activation backward: the kernels apply act'(y) while loading dy -> bit-identical results,
+    # and bwd_weight emits the per-channel sums of g (dbeta / dbias)
+    if K.conv_fused_colsum_ok(d):
+        cs = torch.full((Kc,), 7.0, device=dev())
+        if act and K.conv_fused_act_ok(d):
+            dx_f = K.conv2d_bwd_data(d, T(gy), T(w), T(scale), yact=y)
+            assert torch.equal(dx_f, dx)
+            dw_f = K.conv2d_bwd_weight(d, T(x), T(gy), yact=y, colsum=cs)
+        else:
+            dw_f = K.conv2d_bwd_weight(d, T(x), g, colsum=cs)
+        assert torch.equal(dw_f, dw)
+        np.testing.assert_allclose(cs.cpu().numpy(), gref.reshape(-1, Kc).sum(0), rtol=1e-3, atol=1e-3)
 
 
 def test_bn_param_grads(K):
