@@ -211,11 +211,11 @@ extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, con
 #define LAUNCH_BW(BM_, BN_)                                                                              \
   do {                                                                                                   \
     if (fast && yact)                                                                                    \
-      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, true>), grid, dim3(256), 0, st, *d, x, dy, out, kps, \
-                         dvw, dvh, yact, cpart);                                                         \
+      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, true>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, st, \
+                         *d, x, dy, out, kps, dvw, dvh, yact, cpart, (int)grid.x, (int)grid.y, (int)grid.z); \
     else if (fast)                                                                                       \
-      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, false>), grid, dim3(256), 0, st, *d, x, dy, out, kps, \
-                         dvw, dvh, yact, cpart);                                                         \
+      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, false>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, st, \
+                         *d, x, dy, out, kps, dvw, dvh, yact, cpart, (int)grid.x, (int)grid.y, (int)grid.z); \
     else                                                                                                 \
       hipLaunchKernelGGL((k_conv_bwd_weight_gen<BM_, BN_>), grid, dim3(256), 0, st, *d, x, dy, out, kps); \
   } while (0)

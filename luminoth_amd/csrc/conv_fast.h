@@ -454,7 +454,8 @@ template <int BM, int BN, bool YACT>   // YACT: B operand is dy * act'(yact) (fu
 __global__ void __launch_bounds__(256)
 k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ dy,
                   float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh,
-                  const float* __restrict__ yact, float* __restrict__ colsum_part) {
+                  const float* __restrict__ yact, float* __restrict__ colsum_part, int tiles_x, int tiles_y,
+                  int splits) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
@@ -466,12 +467,19 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int P = d.N * d.OH * d.OW, K = d.K, C = d.C;
+  // 1-D grid, XCD-aware: the blocks of one XCD (bid % 8) cover a contiguous range of (split, k-tile,
+  // tap x c-tile) ids with the SPLIT slowest, so the pixel range of a split — the x rows and dy rows every
+  // one of its tiles re-reads — is fetched into that XCD's private L2 once (PMC before: 144 MB fetched
+  // per launch for ~42 MB of operands, every XCD streaming all of x).
+  const int lin = xcd_remap(blockIdx.x, tiles_x * tiles_y * splits);
+  const int bz = lin / (tiles_x * tiles_y), rem = lin - bz * (tiles_x * tiles_y);
+  const int by = rem / tiles_x, bx = rem - by * tiles_x;
   const int tiles_c = (C + BM - 1) / BM;
-  const int rs = blockIdx.x / tiles_c, m0 = (blockIdx.x % tiles_c) * BM;
-  const int n0 = blockIdx.y * BN;
+  const int rs = bx / tiles_c, m0 = (bx % tiles_c) * BM;
+  const int n0 = by * BN;
   const int r = rs / d.S, s = rs - r * d.S;
   const int KT_all = (P + BK - 1) / BK;
-  const int kt_begin = blockIdx.z * kt_per_split;
+  const int kt_begin = bz * kt_per_split;
   const int kt_end = min(KT_all, kt_begin + kt_per_split);
   constexpr int AROW_T = BM / 4, AROW_STEP = 256 / AROW_T;
   constexpr int BROW_T = BN / 4, BROW_STEP = 256 / BROW_T;
@@ -490,7 +498,7 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
   const size_t dy_row = (size_t)BROW_STEP * K, dy_stage = (size_t)BK * K;
   const float act_hi = (d.act == 2) ? 6.f : INFINITY;
   // per-channel sums of g (= dbeta / dbias) ride along in the blocks of the first (tap, c-tile) column
-  const bool do_colsum = colsum_part != nullptr && blockIdx.x == 0;
+  const bool do_colsum = colsum_part != nullptr && bx == 0;
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   f32x4 ra[AJ], rb[BJ], ryb[BJ];
 #define BW_LOAD()                                                                                          \
@@ -546,7 +554,7 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
 
   acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
   __syncthreads();
-  float* o = out + (size_t)blockIdx.z * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;
+  float* o = out + (size_t)bz * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;
   constexpr int CT = BN / 4, RSTEP = 256 / CT;
   const int c4 = tid % CT, r0 = tid / CT;
   const int col = n0 + 4 * c4;
@@ -567,7 +575,7 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
       f32x4 t = red[tid];
 #pragma unroll
       for (int g2 = 1; g2 < BROW_STEP; ++g2) t += red[g2 * BROW_T + tid];
-      *reinterpret_cast<f32x4*>(colsum_part + (size_t)blockIdx.z * K + n0 + 4 * tid) = t;
+      *reinterpret_cast<f32x4*>(colsum_part + (size_t)bz * K + n0 + 4 * tid) = t;
     }
   }
 }
