@@ -75,12 +75,15 @@ int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const float* w,
 /* dx (N,H,W,C) = sum_{r,s,k} dy[..] * kscale[k] * w[r,s,c,k] + addend
  * (kscale, addend may be NULL; addend may alias dx: residual-branch accumulate). */
 int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, const float* w,
-                        const float* kscale, const float* addend, const float* yact, float* dx,
-                        lmh_stream_t stream);
+                        const float* kscale, const float* addend, const float* yact,
+                        const float* xmask, int xmask_act, float* dx, lmh_stream_t stream);
 /* dw (R,S,C,K) = sum_{n,oh,ow} x[..] * g[..]; split-K partials are reduced deterministically through `ws`.
  * Fused activation backward (both bwd entry points): when `yact` (the layer output y, same shape as dy) is
  * given, g = dy * act'(y) with act = d->act is applied while the operand is loaded (replaces a separate
- * lmh_act_bwd pass); otherwise g = dy.  `colsum` (K floats, may be NULL) receives sum_rows g (dbeta/dbias). */
+ * lmh_act_bwd pass); otherwise g = dy.  `colsum` (K floats, may be NULL) receives sum_rows g (dbeta/dbias).
+ * bwd_data only: `xmask` (the layer INPUT x = post-activation output of the layer below, may be NULL) makes
+ * the epilogue emit dx * act'(x) with act = xmask_act (1 relu, 2 relu6): the layer below then receives its
+ * pre-activation gradient and needs no lmh_act_bwd pass. */
 size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d);
 int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* dy, const float* yact,
                           float* dw, float* colsum, void* ws, size_t ws_bytes, lmh_stream_t stream);

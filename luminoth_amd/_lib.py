@@ -68,7 +68,7 @@ SIGNATURES = {
     'lmh_last_error': (ctypes.c_char_p, []),
     'lmh_device_count': (c_i, []),
     'lmh_conv2d_fwd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
-    'lmh_conv2d_bwd_data': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_conv2d_bwd_data': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f]),
     'lmh_conv2d_bwd_weight_workspace_bytes': (c_sz, [P(ConvDesc)]),
     'lmh_conv2d_bwd_weight': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_kernel_id': (c_i, [P(ConvDesc), c_i]),

@@ -102,13 +102,14 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
 }
 
 extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, const float* w,
-                                   const float* kscale, const float* addend, const float* yact, float* dx,
-                                   lmh_stream_t stream) {
+                                   const float* kscale, const float* addend, const float* yact,
+                                   const float* xmask, int xmask_act, float* dx, lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(dy && w && dx);
   LMH_CHECK_ARG(d->R * d->S == 1 || (d->K % BK) == 0);
   LMH_CHECK_ARG(yact == nullptr || (bwd_data_fast(d) && d->act != 0));   // fused act'(y) only on the fast path
+  LMH_CHECK_ARG(xmask == nullptr || (bwd_data_fast(d) && (xmask_act == 1 || xmask_act == 2)));
   const int64_t M = (int64_t)d->N * d->H * d->W;
   const bool fast = bwd_data_fast(d);
   int bm, bn;
@@ -119,10 +120,10 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   do {                                                                                                      \
     if (fast && yact)                                                                                       \
       hipLaunchKernelGGL((k_conv_bwd_data<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, \
-                         addend, yact, dx);                                                                 \
+                         addend, yact, xmask, xmask_act, dx);                                               \
     else if (fast)                                                                                          \
       hipLaunchKernelGGL((k_conv_bwd_data<BM_, BN_, false>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, \
-                         addend, yact, dx);                                                                 \
+                         addend, yact, xmask, xmask_act, dx);                                               \
     else                                                                                                    \
       hipLaunchKernelGGL((k_conv_bwd_data_gen<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale,  \
                          addend, dx);                                                                       \

@@ -309,7 +309,8 @@ template <int BM, int BN, bool YACT>   // YACT: A operand is dy * act'(yact) (fu
 __global__ void __launch_bounds__(256)
 k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
                 const float* __restrict__ kscale, const float* __restrict__ addend,
-                const float* __restrict__ yact, float* __restrict__ dx) {
+                const float* __restrict__ yact, const float* __restrict__ xmask, int xmask_act,
+                float* __restrict__ dx) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BM * LDK, B_SZ = BN * LDK;
@@ -433,6 +434,7 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
   constexpr int CT = BN / 4, RSTEP = 256 / CT;
   const int c4 = tid % CT, r0 = tid / CT;
   const int col = n0 + 4 * c4;
+  const float xm_hi = (xmask_act == 2) ? 6.f : INFINITY;
   if (col < C) {
 #pragma unroll 4
     for (int r = r0; r < BM; r += RSTEP) {
@@ -440,6 +442,9 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
       if (row >= M) break;
       f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
       if (addend) v += *reinterpret_cast<const f32x4*>(addend + (size_t)row * C + col);
+      // x is the (post-activation) output of the layer below: emitting dx * act'(x) hands that layer its
+      // pre-activation gradient directly — no separate lmh_act_bwd pass over dx
+      if (xmask) v = act_mask(v, *reinterpret_cast<const f32x4*>(xmask + (size_t)row * C + col), xm_hi);
       *reinterpret_cast<f32x4*>(dx + (size_t)row * C + col) = v;
     }
   }

@@ -167,13 +167,23 @@ def conv_fused_colsum_ok(d):
     return _lib.load().lmh_conv2d_kernel_id(ctypes.byref(d), 2) < 1000000
 
 
-def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None, yact=None):
-    """yact: layer output y -> the kernel applies g = dy*act'(y) on load (fused activation backward)."""
+def conv_bwd_data_fast(d):
+    return _lib.load().lmh_conv2d_kernel_id(ctypes.byref(d), 1) < 1000000
+
+
+def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None, yact=None, xmask=None, xmask_act=None):
+    """yact: layer output y -> the kernel applies g = dy*act'(y) on load (fused activation backward).
+    xmask (= the layer input x) + xmask_act: the result is dx * act'(x), i.e. the pre-activation gradient
+    of the layer that produced x (fused in the epilogue on the fast path, one extra pass otherwise)."""
     lib = _lib.load()
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
+    fuse_mask = xmask is not None and conv_bwd_data_fast(d)
     with _timed(d, 1):
         check(lib.lmh_conv2d_bwd_data(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(kscale), _p(addend), _p(yact),
+                                      _p(xmask if fuse_mask else None), ACT[xmask_act] if fuse_mask else 0,
                                       _p(dx), _stream()), 'lmh_conv2d_bwd_data')
+    if xmask is not None and not fuse_mask:
+        dx = act_bwd(dx, xmask, xmask_act)
     return dx
 
 

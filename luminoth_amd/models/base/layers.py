@@ -13,6 +13,10 @@ import torch
 from luminoth_amd import kernels as K
 
 FUSE_ACT = os.environ.get('LUMINOTH_AMD_FUSE_ACT', '0') == '1'
+# act'(x) in the bwd_data epilogue (removes ~30 lmh_act_bwd launches per step).  OFF by default: the mask tensor
+# is a cold forward activation and reading it in the epilogue of a 1-block-per-CU tile is latency-exposed —
+# measured 10.96 ms/step fused vs 10.77 unfused (the streaming lmh_act_bwd pass hides that latency).
+FUSE_MASK = os.environ.get('LUMINOTH_AMD_FUSE_MASK', '0') == '1'
 BN_EPS = 1e-5  # slim resnet_arg_scope batch_norm_epsilon (truncated_base_network.py:69-73)
 
 
@@ -106,12 +110,15 @@ class ConvLayer(object):
             ok = self._fused[key] = (FUSE_ACT and K.conv_fused_act_ok(d), K.conv_fused_colsum_ok(d))
         return ok
 
-    def backward(self, x, y, dy, need_dx=True, addend=None, want_g=False):
+    def backward(self, x, y, dy, need_dx=True, addend=None, want_g=False, dy_is_g=False, mask_input=None):
         """dy: gradient w.r.t. the layer output (after residual add + act).
         Returns (dx or None, g) with g = dy * act'(y) = gradient w.r.t. the pre-activation sum (== gradient
         of the residual branch); g is only materialised when `want_g` (the bottleneck's shortcut needs
         it) or when the fast kernels cannot take it fused — otherwise both backward convolutions apply
-        act'(y) while they load dy, and the per-channel sums (dbeta / dbias) come out of bwd_weight."""
+        act'(y) while they load dy, and the per-channel sums (dbeta / dbias) come out of bwd_weight.
+        dy_is_g: the incoming gradient already is g (the producer applied act'(y) in its epilogue).
+        mask_input: activation of the layer that produced x ('relu' / 'relu6'): the returned dx is then
+        dx * act'(x), i.e. THAT layer's g (fused into the bwd_data epilogue)."""
         d = self.desc(x.shape)
         act_fused, colsum_fused = self._fused_ok(d, tuple(x.shape))
         colsum = None
@@ -122,14 +129,14 @@ class ConvLayer(object):
                 colsum = self.gb
         colsum_in_wgrad = colsum is not None and colsum_fused
         yact = None
-        if self.act and act_fused and not want_g:
-            g, yact = dy, y                               # fused: kernels mask on load
-        elif self.act:
-            g = K.act_bwd(dy, y, self.act, want_g=True, colsum=None if colsum_in_wgrad else colsum)
-        else:
+        if dy_is_g or not self.act:
             g = dy
             if colsum is not None and not colsum_in_wgrad:
                 K.act_bwd(dy, None, None, want_g=False, colsum=colsum)
+        elif self.act and act_fused and not want_g:
+            g, yact = dy, y                               # fused: kernels mask on load
+        else:
+            g = K.act_bwd(dy, y, self.act, want_g=True, colsum=None if colsum_in_wgrad else colsum)
         if self.trainable:
             cs = colsum if colsum_in_wgrad else None
             if SideStream.enabled:
@@ -146,7 +153,8 @@ class ConvLayer(object):
         dx = None
         if need_dx:
             dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
-                                   addend=addend, yact=yact)
+                                   addend=addend, yact=yact, xmask=x if mask_input else None,
+                                   xmask_act=mask_input)
         return dx, (g if yact is None else None)
 
 
@@ -237,14 +245,17 @@ class ConvNode(object):
         y = self.layer.forward(x, in_sub=self.in_sub)
         return y, ((x, y) if save else None)
 
-    def backward(self, saved, dy, need_dx):
+    out_act = property(lambda self: self.layer.act)
+
+    def backward(self, saved, dy, need_dx, dy_is_g=False, mask_input=None):
         x, y = saved
-        dx, _ = self.layer.backward(x, y, dy, need_dx=need_dx)
+        dx, _ = self.layer.backward(x, y, dy, need_dx=need_dx, dy_is_g=dy_is_g, mask_input=mask_input)
         return dx
 
 
 class MaxPoolNode(object):
     layers = []
+    out_act = None
 
     def __init__(self, ksize, stride, padding):
         self.k, self.s, self.p = ksize, stride, padding
@@ -253,11 +264,12 @@ class MaxPoolNode(object):
         y, geom = K.maxpool_fwd(x, self.k, self.s, self.p)
         return y, ((x, y, geom) if save else None)
 
-    def backward(self, saved, dy, need_dx):
+    def backward(self, saved, dy, need_dx, dy_is_g=False, mask_input=None):
         if not need_dx:
             return None
         x, y, geom = saved
-        return K.maxpool_bwd(x, y, dy, self.k, self.s, geom)
+        dx = K.maxpool_bwd(x, y, dy, self.k, self.s, geom)
+        return K.act_bwd(dx, x, mask_input) if mask_input else dx
 
 
 class BottleneckNode(object):
@@ -290,17 +302,23 @@ class BottleneckNode(object):
         y = self.conv3.forward(b, residual=sc)
         return y, ((x, sc, a, b, y, geom) if save else None)
 
-    def backward(self, saved, dy, need_dx):
+    out_act = 'relu'
+
+    def backward(self, saved, dy, need_dx, dy_is_g=False, mask_input=None):
+        """Every bwd_data epilogue multiplies by relu'(its own input), so the gradient that reaches the
+        layer below already is that layer's g: no lmh_act_bwd passes inside the unit (and none for the
+        unit below when `mask_input` asks this unit to do the same for its input x)."""
         x, sc, a, b, y, geom = saved
-        d_b, g = self.conv3.backward(b, y, dy, want_g=True)
-        d_a, _ = self.conv2.backward(a, b, d_b)
+        m = 'relu' if FUSE_MASK else None
+        d_b, g = self.conv3.backward(b, y, dy, want_g=True, dy_is_g=dy_is_g, mask_input=m)
+        d_a, _ = self.conv2.backward(a, b, d_b, dy_is_g=FUSE_MASK, mask_input=m)
         if self.shortcut is not None:
             d_sc, _ = self.shortcut.backward(x, sc, g, need_dx=need_dx)
         elif self.stride > 1:
             d_sc = K.maxpool_bwd(x, sc, g, 1, self.stride, geom) if need_dx else None
         else:
             d_sc = g
-        dx, _ = self.conv1.backward(x, a, d_a, need_dx=need_dx, addend=d_sc)
+        dx, _ = self.conv1.backward(x, a, d_a, need_dx=need_dx, addend=d_sc, dy_is_g=FUSE_MASK, mask_input=mask_input)
         return dx
 
 
@@ -330,7 +348,11 @@ class Trunk(object):
 
     def backward(self, saved, dy, save_from, need_dx_first=False):
         nodes = self.nodes[save_from:]
+        dy_is_g = False
         for j in range(len(nodes) - 1, -1, -1):
             need_dx = (j > 0) or need_dx_first
-            dy = nodes[j].backward(saved[j], dy, need_dx)
+            # node j-1's output activation is folded into node j's data gradient (fused epilogue mask)
+            below = nodes[j - 1].out_act if (j > 0 and FUSE_MASK) else None
+            dy = nodes[j].backward(saved[j], dy, need_dx, dy_is_g=dy_is_g, mask_input=below)
+            dy_is_g = below is not None
         return dy
