@@ -247,6 +247,11 @@ class ConvNode(object):
 
     out_act = property(lambda self: self.layer.act)
 
+    def out_hw(self, h, w):
+        l = self.layer
+        d = K.conv_desc((1, h, w, l.cin), (l.k, l.k, l.cin, l.cout), l.stride, l.rate, l.padding, l.act)
+        return d.OH, d.OW
+
     def backward(self, saved, dy, need_dx, dy_is_g=False, mask_input=None):
         x, y = saved
         dx, _ = self.layer.backward(x, y, dy, need_dx=need_dx, dy_is_g=dy_is_g, mask_input=mask_input)
@@ -259,6 +264,11 @@ class MaxPoolNode(object):
 
     def __init__(self, ksize, stride, padding):
         self.k, self.s, self.p = ksize, stride, padding
+
+    def out_hw(self, h, w):
+        if self.p == 'SAME':
+            return -(-h // self.s), -(-w // self.s)
+        return (h - self.k) // self.s + 1, (w - self.k) // self.s + 1
 
     def forward(self, x, save):
         y, geom = K.maxpool_fwd(x, self.k, self.s, self.p)
@@ -304,6 +314,9 @@ class BottleneckNode(object):
 
     out_act = 'relu'
 
+    def out_hw(self, h, w):
+        return -(-h // self.stride), -(-w // self.stride)
+
     def backward(self, saved, dy, need_dx, dy_is_g=False, mask_input=None):
         """Every bwd_data epilogue multiplies by relu'(its own input), so the gradient that reaches the
         layer below already is that layer's g: no lmh_act_bwd passes inside the unit (and none for the
@@ -330,6 +343,11 @@ class Trunk(object):
 
     def all_layers(self):
         return [l for n in self.nodes for l in n.layers]
+
+    def out_hw(self, h, w):
+        for n in self.nodes:
+            h, w = n.out_hw(h, w)
+        return h, w
 
     def first_trainable(self):
         for i, n in enumerate(self.nodes):

@@ -150,6 +150,10 @@ class TruncatedBaseNetwork(BaseNetwork):
             return _TrunkFn.apply(x, self._anchor, sub, 0, False)
         return _TrunkFn.apply(x, self._anchor, trunk, 0, True)
 
+    def feature_hw(self, H, W):
+        """Spatial size of the feature map for an (H, W) input (no launch)."""
+        return self.trunk.out_hw(H, W)
+
     def __call__(self, inputs, is_training=False):
         """inputs (B,H,W,3) fp32 RGB 0..255 -> feature map (B,fh,fw,C)."""
         self.bn_table.refresh()
