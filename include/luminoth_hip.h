@@ -262,6 +262,38 @@ int lmh_rcnn_loss(const float* cls_score, const float* bbox_offsets, const float
 /* tf.nn.softmax over the last axis (rcnn.py:206, ssd.py:109). */
 int lmh_softmax(const float* x, int64_t rows, int C, float* y, lmh_stream_t stream);
 
+/* ------------------------------------------------------------------ SSD --
+ * conv4_3 normalisation (models/ssd/feature_extractor.py:75-89):
+ * y = tf.nn.l2_normalize(x, axis=3, epsilon) * gamma;  x (P, C) NHWC rows, gamma (C). */
+int lmh_l2norm_scale_fwd(const float* x, const float* gamma, int64_t P, int C, float eps, float* y,
+                         lmh_stream_t stream);
+size_t lmh_l2norm_scale_bwd_workspace_bytes(int64_t P, int C);
+int lmh_l2norm_scale_bwd(const float* x, const float* dy, const float* gamma, int64_t P, int C, float eps,
+                         float* dx, float* dgamma, void* ws, size_t ws_bytes, lmh_stream_t stream);
+
+/* SSDTarget._build (models/ssd/target.py:35-200) for a batch: IoU(+1) labels (>= fg threshold -> gt
+ * label + 1), best anchor per gt (override, last gt wins on duplicates), hard-negative mining
+ * (top_k(int(#fg * ratio)) of max_c>=1 prob over rows with max IoU <= bg_high and label <= 0; those rows
+ * become 0 — whatever they were), encode(variances) targets for label > 0.
+ *   anchors (N,4) shared by all images; gt (B,Gmax,5), gt_count (B); probs (B,N,C+1) softmax
+ *   out: labels (B,N) f32 in {-1,0,1..C}; bbox_targets (B,N,4); max_overlaps (B,N). */
+typedef struct lmh_ssd_target_desc {
+  int32_t B, N, C, Gmax;
+  float foreground_threshold, background_threshold_high, hard_negative_ratio;
+  float variance_xy, variance_wh;
+} lmh_ssd_target_desc;
+size_t lmh_ssd_target_workspace_bytes(const lmh_ssd_target_desc* d);
+int lmh_ssd_target(const lmh_ssd_target_desc* d, const float* anchors, const float* gt,
+                   const int32_t* gt_count, const float* probs, float* labels, float* bbox_targets,
+                   float* max_overlaps, void* ws, size_t ws_bytes, lmh_stream_t stream);
+
+/* SSD.loss (models/ssd/ssd.py:197-300) + smooth_l1 (utils/losses.py:4-32, sigma 3): rows with label -1 are
+ * ignored.  losses (3) = mean over images of [final, cls_sum, bbox_sum]; per_image (B,4) =
+ * [cls_sum, bbox_sum, #pos, final]; gradients of losses[0] (may be NULL). */
+int lmh_ssd_loss(const float* cls_pred, const float* loc_pred, const float* labels, const float* targets,
+                 int B, int N, int C, float sigma, float w_loc, float* losses, float* per_image,
+                 float* d_cls_pred, float* d_loc_pred, lmh_stream_t stream);
+
 /* ------------------------------------------------------------ optimizer --
  * tf.train.MomentumOptimizer (utils/training.py:64-81, train.py:79-91) over a
  * flat parameter buffer split in `nseg` segments, with the L2 regulariser

@@ -61,6 +61,13 @@ class RcnnProposalDesc(ctypes.Structure):
                 ('class_agnostic_boxes', ctypes.c_int32)]
 
 
+class SsdTargetDesc(ctypes.Structure):
+    _fields_ = [('B', ctypes.c_int32), ('N', ctypes.c_int32), ('C', ctypes.c_int32), ('Gmax', ctypes.c_int32),
+                ('foreground_threshold', ctypes.c_float), ('background_threshold_high', ctypes.c_float),
+                ('hard_negative_ratio', ctypes.c_float), ('variance_xy', ctypes.c_float),
+                ('variance_wh', ctypes.c_float)]
+
+
 P = ctypes.POINTER
 SIGNATURES = {
     # name: (restype, argtypes)   -- lists EVERY symbol include/luminoth_hip.h declares
@@ -97,6 +104,12 @@ SIGNATURES = {
     'lmh_rpn_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
     'lmh_rcnn_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
     'lmh_softmax': (c_i, [c_f, c_i64, c_i, c_f, c_f]),
+    'lmh_l2norm_scale_fwd': (c_i, [c_f, c_f, c_i64, c_i, c_fl, c_f, c_f]),
+    'lmh_l2norm_scale_bwd_workspace_bytes': (c_sz, [c_i64, c_i]),
+    'lmh_l2norm_scale_bwd': (c_i, [c_f, c_f, c_f, c_i64, c_i, c_fl, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_ssd_target_workspace_bytes': (c_sz, [P(SsdTargetDesc)]),
+    'lmh_ssd_target': (c_i, [P(SsdTargetDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_ssd_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
     'lmh_sgd_momentum': (c_i, [c_f, c_f, c_f, c_i64, c_f, c_f, c_i, c_fl, c_fl, c_fl, c_f]),
     'lmh_l2_reg_loss': (c_i, [c_f, c_i64, c_f, c_f, c_i, c_f, c_f]),
 }

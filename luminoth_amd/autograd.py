@@ -98,3 +98,57 @@ class RcnnLossFn(torch.autograd.Function):
     def backward(ctx, g):
         d_cls, d_off = ctx.saved_tensors
         return d_cls * g[0], d_off * g[1], None, None, None, None, None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    """tf.nn.max_pool NHWC (SSD: 2x2/2 VALID, 3x3/1 SAME)."""
+
+    @staticmethod
+    def forward(ctx, x, ksize, stride, padding):
+        x = x.contiguous()
+        y, geom = K.maxpool_fwd(x, ksize, stride, padding)
+        ctx.save_for_backward(x, y)
+        ctx.meta = (ksize, stride, geom)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        ksize, stride, geom = ctx.meta
+        return K.maxpool_bwd(x, y, dy.contiguous(), ksize, stride, geom), None, None, None
+
+
+class L2NormScaleFn(torch.autograd.Function):
+    """tf.nn.l2_normalize(x, 3, eps) * gamma (ssd/feature_extractor.py:75-89); dgamma goes straight into
+    the flat gradient buffer view `ggamma`."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, gamma, ggamma, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.gamma, ctx.ggamma, ctx.eps = gamma, ggamma, eps
+        return K.l2norm_scale_fwd(x, gamma, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dx, _ = K.l2norm_scale_bwd(x, dy.contiguous(), ctx.gamma, ctx.eps, dgamma=ctx.ggamma)
+        return dx, None, None, None, None
+
+
+class SsdLossFn(torch.autograd.Function):
+    """SSD.loss (ssd/ssd.py:197-300): returns (3,) = [final, cls_sum, bbox_sum] (batch means);
+    only losses[0] carries gradient."""
+
+    @staticmethod
+    def forward(ctx, cls_pred, loc_pred, labels, targets, num_classes, sigma, w_loc):
+        losses, per_image, d_cls, d_loc = K.ssd_loss(cls_pred.contiguous(), loc_pred.contiguous(), labels, targets,
+                                                     num_classes, sigma, w_loc, want_grad=True)
+        ctx.save_for_backward(d_cls, d_loc)
+        ctx.per_image = per_image
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        d_cls, d_loc = ctx.saved_tensors
+        return d_cls * g[0], d_loc * g[0], None, None, None, None, None

@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-result"
 OBJS=""
 pids=""
-for f in api proposals detect targets roi loss optim elementwise conv; do
+for f in api proposals detect targets roi loss optim elementwise ssd conv; do
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ lmh_common.h -nt "$f.o" ] || [ conv_common.h -nt "$f.o" ] || [ conv_generic.h -nt "$f.o" ] || [ ../../include/luminoth_hip.h -nt "$f.o" ]; then
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
     pids="$pids $!"

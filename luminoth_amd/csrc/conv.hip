@@ -107,7 +107,6 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(dy && w && dx);
-  LMH_CHECK_ARG(d->R * d->S == 1 || (d->K % BK) == 0);
   LMH_CHECK_ARG(yact == nullptr || (bwd_data_fast(d) && d->act != 0));   // fused act'(y) only on the fast path
   LMH_CHECK_ARG(xmask == nullptr || (bwd_data_fast(d) && (xmask_act == 1 || xmask_act == 2)));
   const int64_t M = (int64_t)d->N * d->H * d->W;
@@ -193,7 +192,6 @@ extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, con
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(x && dy && dw);
-  LMH_CHECK_ARG((d->C & 3) == 0);
   int bm, bn, splits, kps;
   bwd_weight_plan(d, &bm, &bn, &splits, &kps);
   if (ws_bytes < lmh_conv2d_bwd_weight_workspace_bytes(d) || (splits > 1 && !ws)) {

@@ -324,8 +324,17 @@ k_conv_bwd_weight_gen(lmh_conv_desc d, const float* __restrict__ x, const float*
         const int oh = t % d.OH, n = t / d.OH;
         const int ih = oh * d.stride - d.pad_top + r * d.dilation;
         const int iw = ow * d.stride - d.pad_left + s * d.dilation;
-        if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)
-          v = *reinterpret_cast<const float4*>(x + ((size_t)(n * d.H + ih) * d.W + iw) * C + c);
+        if ((unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W) {
+          const float* src = x + ((size_t)(n * d.H + ih) * d.W + iw) * C + c;
+          if ((C & 3) == 0) {
+            v = *reinterpret_cast<const float4*>(src);
+          } else {                                   // C = 3 image input (SSD trains conv1_1), odd widths
+            v.x = src[0];
+            if (c + 1 < C) v.y = src[1];
+            if (c + 2 < C) v.z = src[2];
+            if (c + 3 < C) v.w = src[3];
+          }
+        }
       }
       ra[j] = v;
     }

@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ConvDesc, RpnProposalDesc, RpnTargetDesc, RcnnTargetDesc, RcnnProposalDesc, check)
+from ._lib import (ConvDesc, RpnProposalDesc, RpnTargetDesc, RcnnTargetDesc, RcnnProposalDesc, SsdTargetDesc, check)
 
 ACT = {None: 0, 'none': 0, 'relu': 1, 'relu6': 2}
 
@@ -460,3 +460,58 @@ def l2_reg_loss(w, seg_offset, seg_wd):
     check(lib.lmh_l2_reg_loss(_p(w), w.numel(), _p(seg_offset), _p(seg_wd), seg_wd.numel(), _p(out),
                               _stream()), 'lmh_l2_reg_loss')
     return out
+
+
+# ------------------------------------------------------------------- SSD ----
+def l2norm_scale_fwd(x, gamma, eps=1e-12):
+    """tf.nn.l2_normalize(x, axis=-1, epsilon) * gamma (ssd/feature_extractor.py:75-89)."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.lmh_l2norm_scale_fwd(_p(x), _p(gamma), x.numel() // C, C, float(eps), _p(y), _stream()),
+          'lmh_l2norm_scale_fwd')
+    return y
+
+
+def l2norm_scale_bwd(x, dy, gamma, eps=1e-12, dgamma=None):
+    lib = _lib.load()
+    C = x.shape[-1]
+    P = x.numel() // C
+    dx = torch.empty_like(x)
+    dgamma = dgamma if dgamma is not None else torch.empty((C,), dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.lmh_l2norm_scale_bwd_workspace_bytes(P, C), x.device, 'l2norm')
+    check(lib.lmh_l2norm_scale_bwd(_p(x), _p(dy), _p(gamma), P, C, float(eps), _p(dx), _p(dgamma), _p(ws),
+                                   ctypes.c_size_t(ws.numel()), _stream()), 'lmh_l2norm_scale_bwd')
+    return dx, dgamma
+
+
+def ssd_target(anchors, gt, gt_count, probs, num_classes, foreground_threshold=0.5, background_threshold_high=0.2,
+               hard_negative_ratio=3.0, variances=(0.1, 0.2)):
+    """anchors (N,4), gt (B,Gmax,5), gt_count (B), probs (B,N,C+1) -> labels (B,N), bbox_targets (B,N,4), max_ov."""
+    lib = _lib.load()
+    B, N, K = probs.shape
+    assert K == num_classes + 1 and anchors.shape == (N, 4)
+    v = (1.0, 1.0) if variances is None else variances
+    d = SsdTargetDesc(B, N, int(num_classes), gt.shape[1], float(foreground_threshold),
+                      float(background_threshold_high), float(hard_negative_ratio), float(v[0]), float(v[1]))
+    dev = probs.device
+    labels = torch.empty((B, N), dtype=torch.float32, device=dev)
+    targets = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+    max_ov = torch.empty((B, N), dtype=torch.float32, device=dev)
+    ws = _workspace(lib.lmh_ssd_target_workspace_bytes(ctypes.byref(d)), dev, 'ssd_target')
+    check(lib.lmh_ssd_target(ctypes.byref(d), _p(anchors), _p(gt), _p(gt_count), _p(probs), _p(labels), _p(targets),
+                             _p(max_ov), _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_ssd_target')
+    return labels, targets, max_ov
+
+
+def ssd_loss(cls_pred, loc_pred, labels, targets, num_classes, sigma=3.0, w_loc=1.0, want_grad=True):
+    lib = _lib.load()
+    B, N, K = cls_pred.shape
+    dev = cls_pred.device
+    losses = torch.empty((3,), dtype=torch.float32, device=dev)
+    per_image = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    d_cls = torch.empty_like(cls_pred) if want_grad else None
+    d_loc = torch.empty_like(loc_pred) if want_grad else None
+    check(lib.lmh_ssd_loss(_p(cls_pred), _p(loc_pred), _p(labels), _p(targets), B, N, int(num_classes), float(sigma),
+                           float(w_loc), _p(losses), _p(per_image), _p(d_cls), _p(d_loc), _stream()), 'lmh_ssd_loss')
+    return losses, per_image, d_cls, d_loc

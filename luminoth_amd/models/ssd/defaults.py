@@ -24,14 +24,14 @@ DEFAULTS = {
         'base_network': {'architecture': 'truncated_vgg_16', 'trainable': True, 'weights': None,
                          'download': True, 'endpoints': ['conv4/conv4_3', 'conv5/conv5_3'],
                          'hook_endpoint': 'conv4/conv4_3', 'fine_tune_from': None,
-                         'arg_scope': {'weight_decay': 0.0005}},
+                         'arg_scope': {'weight_decay': 0.0005}, 'dropout_keep_prob': 1.0},
         'loss': {'localization_loss_weight': 1.0},       # :126
         'anchors': {'anchors_per_point': [4, 6, 6, 6, 4, 4], 'ratios': [1, 0.5, 2, 0.333, 3],
                     'min_scale': 0.1, 'max_scale': 0.88},      # :128-138 (linspace .10-.88)
         'target': {'hard_negative_ratio': 3.0, 'foreground_threshold': 0.5,
                    'background_threshold_high': 0.2, 'background_threshold_low': 0.0},
         'proposals': {'total_max_detections': 100, 'class_max_detections': 100,
-                      'class_nms_threshold': 0.45, 'min_prob_threshold': 0.5, 'filter_outside_anchors': False},
-        'target_normalization_variances': [0.1, 0.2],    # :166
+                      'class_nms_threshold': 0.45, 'min_prob_threshold': 0.5, 'filter_outside_anchors': True},
+        'variances': [0.1, 0.2],                         # :166
     },
 }

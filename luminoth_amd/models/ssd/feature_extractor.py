@@ -1,0 +1,120 @@
+"""SSDFeatureExtractor — truncated VGG-16 + the SSD extra layers (reference:
+luminoth/models/ssd/feature_extractor.py:15-141, luminoth/models/base/truncated_vgg.py:60-121).
+
+conv1_1..conv5_3 (3x3 SAME + bias + ReLU, 2x2/2 VALID pools: 300 -> 150 -> 75 -> 37 -> 18), conv4_3 ->
+l2_normalize * gamma (init 20), conv5_3 -> 3x3/1 SAME max-pool -> conv6 (3x3 rate 6) -> conv7 (1x1) ->
+conv8_1/8_2(stride 2) -> conv9_1/9_2(stride 2) -> conv10_1/10_2(VALID) -> conv11_1/11_2(VALID), ReLU after
+each.  The input is NOT mean-subtracted: 'truncated_vgg_16'.startswith('vgg') is False
+(base_network.py:103-113,153-157).  Returns the six feature maps in the reference's order."""
+import math
+from collections import OrderedDict
+
+import torch
+
+from luminoth_amd import autograd as A
+from luminoth_amd.models.base.base_network import BaseNetwork, zeros
+from luminoth_amd.models.base.layers import ConvLayer
+from luminoth_amd.models.base.networks import VGG16_CFG
+
+VALID_SSD_ARCHITECTURES = set(['truncated_vgg_16'])
+
+EXTRA_LAYERS = [   # name, cout, ksize, stride, rate, padding   (feature_extractor.py:27-37)
+    ('conv6', 1024, 3, 1, 6, 'SAME'), ('conv7', 1024, 1, 1, 1, 'SAME'),
+    ('conv8_1', 256, 1, 1, 1, 'SAME'), ('conv8_2', 512, 3, 2, 1, 'SAME'),
+    ('conv9_1', 128, 1, 1, 1, 'SAME'), ('conv9_2', 256, 3, 2, 1, 'SAME'),
+    ('conv10_1', 128, 1, 1, 1, 'SAME'), ('conv10_2', 256, 3, 1, 1, 'VALID'),
+    ('conv11_1', 128, 1, 1, 1, 'SAME'), ('conv11_2', 256, 3, 1, 1, 'VALID'),
+]
+FEATURE_MAP_AFTER = ('conv7', 'conv8_2', 'conv9_2', 'conv10_2', 'conv11_2')
+
+
+def xavier_uniform(shape, gen):
+    """slim conv2d default weights_initializer (tf.contrib.layers.xavier_initializer, uniform)."""
+    rf = shape[0] * shape[1]
+    lim = math.sqrt(6.0 / (shape[2] * rf + shape[3] * rf))
+    return (torch.rand(shape, generator=gen) * 2 - 1) * lim
+
+
+def sonnet_default(shape, gen):
+    """Sonnet Conv2D default w initializer: truncated normal, stddev 1/sqrt(fan_in)."""
+    fan_in = shape[0] * shape[1] * shape[2]
+    return torch.randn(shape, generator=gen).clamp_(-2, 2) / math.sqrt(fan_in)
+
+
+class SSDFeatureExtractor(BaseNetwork):
+    def __init__(self, config, parent_name=None, name='ssd_feature_extractor'):
+        super(SSDFeatureExtractor, self).__init__(config, name=name)
+        if self._architecture not in VALID_SSD_ARCHITECTURES:
+            raise ValueError('Invalid architecture "{}"'.format(self._architecture))
+        self.scope = (parent_name + '/' + name) if parent_name else name
+        wd = self._weight_decay()
+        self.vgg = []      # ('conv', layer) | ('pool', None)
+        cin = 3
+        p = self.scope + '/vgg_16'
+        for bi, (bname, reps, depth) in enumerate(VGG16_CFG):
+            for r in range(reps):
+                l = ConvLayer('%s/%s/%s_%d' % (p, bname, bname, r + 1), cin, depth, 3, act='relu', norm='bias', wd=wd,
+                              init=xavier_uniform)
+                self.vgg.append(('conv', l))
+                cin = depth
+            if bi < 4:
+                self.vgg.append(('pool', None))
+        self.extra = []
+        e = self.scope + '/extra_feature_layers'
+        for lname, cout, k, stride, rate, pad in EXTRA_LAYERS:
+            self.extra.append(ConvLayer('%s/%s' % (e, lname), cin, cout, k, stride=stride, rate=rate, padding=pad,
+                                        act='relu', norm='bias', wd=0.0, init=sonnet_default, weight_name='w',
+                                        bias_name='b'))
+            cin = cout
+        self.gamma_name = self.scope + '/conv_4_3_norm/gamma'
+        self.layers = [l for kind, l in self.vgg if kind == 'conv'] + self.extra
+        self.pretrained_weights_scope = p
+        self.feature_channels = [512, 1024, 512, 256, 256, 256]
+
+    def register(self, store, trainable=True):
+        for l in self.layers:
+            l.trainable = trainable
+            store.add(l.w_name, (l.k, l.k, l.cin, l.cout), l.init, trainable=trainable, wd=l.wd)
+            store.add(l.b_name, (l.cout,), zeros, trainable=trainable)
+        store.add(self.gamma_name, (512,), lambda shape, gen: torch.full(shape, 20.0), trainable=trainable)
+
+    def bind(self, store):
+        for l in self.layers:
+            l.bind(store, None)
+        self.gamma = store[self.gamma_name]
+        self.ggamma = store.grads.get(self.gamma_name)
+        self._anchor = torch.zeros(1, device=store.flat.device, requires_grad=True)
+
+    def get_base_network_checkpoint_vars(self, store):
+        """{slim checkpoint name: tensor}: the vgg_16 variables with the module scope stripped."""
+        prefix = self.scope + '/'
+        return {n[len(prefix):]: t for n, t in store.params.items() if n.startswith(prefix + 'vgg_16/')}
+
+    def get_trainable_var_names(self):
+        names = []
+        for l in self.layers:
+            names += [l.w_name, l.b_name]
+        return names + [self.gamma_name]
+
+    def __call__(self, inputs, is_training=False):
+        """inputs (B,H,W,3) -> OrderedDict name -> feature map, in FEATURE_MAPS collection order."""
+        net = inputs.contiguous()
+        maps = OrderedDict()
+        for kind, l in self.vgg:
+            if kind == 'pool':
+                net = A.MaxPoolFn.apply(net, 2, 2, 'VALID')
+            else:
+                net = A.conv(l, net, self._anchor)
+                if l.scope.endswith('conv4/conv4_3'):
+                    if torch.is_grad_enabled() and l.trainable:
+                        maps['conv4_3_norm'] = A.L2NormScaleFn.apply(net, self._anchor, self.gamma, self.ggamma, 1e-12)
+                    else:
+                        from luminoth_amd import kernels as K
+                        maps['conv4_3_norm'] = K.l2norm_scale_fwd(net, self.gamma, 1e-12)
+        net = A.MaxPoolFn.apply(net, 3, 1, 'SAME')          # pool5
+        for l in self.extra:
+            net = A.conv(l, net, self._anchor)
+            lname = l.scope.rsplit('/', 1)[1]
+            if lname in FEATURE_MAP_AFTER:
+                maps[lname] = net
+        return maps

@@ -1,14 +1,220 @@
-"""SSD model module (reference: luminoth/models/ssd/ssd.py:17-334).
+"""SSD — the drop-in model module of the SSD hot path.
 
-Round 1 status: the HIP kernels SSD needs (3x3/dilated/VALID convs with bias,
-2x2 and 3x3 max-pools, IoU targets, per-class NMS `lmh_rcnn_proposal` with
-class_agnostic_boxes=1, smooth-L1 / CE) exist in libluminoth_hip.so; the module
-wiring (multibox heads, hard-negative mining target, SSD loss) is the next §8
-row (S1-S6) and is not built yet.  Constructing it raises instead of silently
-falling back to anything else."""
+Same protocol as the reference Sonnet module (luminoth/models/ssd/ssd.py:17-334):
+
+    model = get_model('ssd')(config)
+    prediction_dict = model(image, gt_boxes=None, is_training=False)
+    total_loss = model.loss(prediction_dict)            # or return_all=True
+
+with the same `prediction_dict` keys (`cls_pred`, `loc_pred`, `target{cls,bbox_offsets,anchors}`,
+`classification_prediction{objects,labels,probs,anchors}`, `all_anchors`, `cls_prob`).  Extensions, as for
+Faster R-CNN: `image` may be a batch `(B,H,W,3)` (the reference hard-codes batch 1: ssd.py:62-64) and ragged
+results are fixed-capacity buffers plus counts.  The hard-negative-mining filter (ssd.py:146-161,
+`boolean_mask` on target >= 0) is expressed by keeping the -1 rows and letting the loss kernel skip them —
+identical loss and gradients, no data-dependent shapes; un-batched calls return the compacted rows exactly
+like the reference.
+"""
+import numpy as np
+import torch
+
+from luminoth_amd import _lib
+from luminoth_amd import autograd as A
+from luminoth_amd import kernels as K
+from luminoth_amd.models.base.base_network import zeros
+from luminoth_amd.models.base.layers import ConvLayer, SideStream
+from luminoth_amd.models.ssd.feature_extractor import SSDFeatureExtractor, sonnet_default
+from luminoth_amd.models.ssd.utils import generate_all_anchors
+from luminoth_amd.params import ParamStore
 
 
 class SSD(object):
     def __init__(self, config, name='ssd', device=None):
-        raise NotImplementedError(
-            'luminoth_amd: SSD (SURVEY.md §8 rows S1-S6) is not wired yet; Faster R-CNN is the round-1 path')
+        self._config = config.model
+        self._name = name
+        self._num_classes = config.model.network.num_classes
+        self._debug = config.train.debug
+        self._seed = config.train.seed
+        self._anchor_max_scale = config.model.anchors.max_scale
+        self._anchor_min_scale = config.model.anchors.min_scale
+        self._anchor_ratios = np.array(config.model.anchors.ratios)
+        self.image_shape = [config.dataset.image_preprocessing.fixed_height,
+                            config.dataset.image_preprocessing.fixed_width]
+        self._anchors_per_point = list(config.model.anchors.anchors_per_point)
+        self._loc_loss_weight = config.model.loss.localization_loss_weight
+        self._variances = list(config.model.variances)
+        self._losses_collections = ['ssd_losses']
+        if device is None:
+            if not torch.cuda.is_available():
+                raise _lib.LuminothHipError('SSD needs a ROCm device (no CPU fallback on the product path)')
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(device)
+        _lib.load()
+
+        self.feature_extractor = SSDFeatureExtractor(config.model.base_network, parent_name=name)
+        self.heads = []   # (offsets_layer, classes_layer) per feature map (ssd.py:73-100: Sonnet Conv2D 3x3 SAME)
+        for i, cin in enumerate(self.feature_extractor.feature_channels):
+            a = self._anchors_per_point[i]
+            off = ConvLayer('%s/MultiBox_%d_offsets_conv' % (name, i), cin, a * 4, 3, act=None, norm='bias', wd=0.0,
+                            init=sonnet_default, weight_name='w', bias_name='b')
+            cls = ConvLayer('%s/MultiBox_%d_classes_conv' % (name, i), cin, a * (self._num_classes + 1), 3, act=None,
+                            norm='bias', wd=0.0, init=sonnet_default, weight_name='w', bias_name='b')
+            self.heads.append((off, cls))
+        self.store = ParamStore()
+        self.feature_extractor.register(self.store, trainable=bool(config.model.base_network.trainable))
+        for off, cls in self.heads:
+            for l in (off, cls):
+                self.store.add(l.w_name, (l.k, l.k, l.cin, l.cout), l.init, trainable=True, wd=0.0)
+                self.store.add(l.b_name, (l.cout,), zeros, trainable=True)
+        self.store.build(self.device, seed=self._seed)
+        self.feature_extractor.bind(self.store)
+        for off, cls in self.heads:
+            off.bind(self.store, None)
+            cls.bind(self.store, None)
+        self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
+        self._anchors_cache = {}
+        self._frozen_reg = None
+
+    # ----------------------------------------------------------------- inputs --
+    def _pack_gt(self, gt_boxes, B):
+        if gt_boxes is None:
+            return None, None
+        if isinstance(gt_boxes, (tuple, list)) and len(gt_boxes) == 2 and torch.is_tensor(gt_boxes[0]) \
+                and gt_boxes[0].dim() == 3:
+            return gt_boxes[0].to(self.device, torch.float32).contiguous(), \
+                gt_boxes[1].to(self.device, torch.int32).contiguous()
+        if torch.is_tensor(gt_boxes) and gt_boxes.dim() == 3:
+            cnt = torch.full((B,), gt_boxes.shape[1], dtype=torch.int32, device=self.device)
+            return gt_boxes.to(self.device, torch.float32).contiguous(), cnt
+        if torch.is_tensor(gt_boxes) or isinstance(gt_boxes, np.ndarray):
+            gt_boxes = [gt_boxes]
+        gts = [torch.as_tensor(g, dtype=torch.float32).reshape(-1, 5) for g in gt_boxes]
+        gmax = max(1, max(g.shape[0] for g in gts))
+        packed = torch.zeros((B, gmax, 5), dtype=torch.float32)
+        for b, g in enumerate(gts):
+            packed[b, :g.shape[0]] = g
+        cnt = torch.tensor([g.shape[0] for g in gts], dtype=torch.int32)
+        return packed.to(self.device), cnt.to(self.device)
+
+    def _anchors_for(self, feat_shapes, im_hw):
+        """ssd.py:111-129: numpy anchors, generated once per geometry."""
+        key = (tuple(feat_shapes), tuple(im_hw))
+        a = self._anchors_cache.get(key)
+        if a is None:
+            a = torch.from_numpy(generate_all_anchors(feat_shapes, im_hw, self._anchor_min_scale,
+                                                      self._anchor_max_scale, self._anchor_ratios,
+                                                      self._anchors_per_point)).to(self.device)
+            self._anchors_cache[key] = a
+        return a
+
+    # ---------------------------------------------------------------- forward --
+    def __call__(self, image, gt_boxes=None, is_training=False):
+        image = torch.as_tensor(image)
+        unbatched = image.dim() == 3
+        if unbatched:
+            image = image.unsqueeze(0)
+        image = image.to(self.device, torch.float32).contiguous()
+        B, H, W, _ = image.shape
+        gt, gt_count = self._pack_gt(gt_boxes, B)
+        C = self._num_classes
+        with torch.set_grad_enabled(bool(is_training)):
+            feature_maps = self.feature_extractor(image, is_training=is_training)
+            offs, scores, shapes = [], [], []
+            for (off_l, cls_l), fm in zip(self.heads, feature_maps.values()):
+                shapes.append((fm.shape[1], fm.shape[2]))
+                offs.append(A.conv(off_l, fm, self._anchor).reshape(B, -1, 4))          # ssd.py:83-89
+                scores.append(A.conv(cls_l, fm, self._anchor).reshape(B, -1, C + 1))    # ssd.py:92-99
+            bbox_offsets = torch.cat(offs, dim=1)                                       # ssd.py:101-106
+            class_scores = torch.cat(scores, dim=1)
+        N = bbox_offsets.shape[1]
+        class_probabilities = K.softmax(class_scores.detach().reshape(B * N, C + 1)).reshape(B, N, C + 1)
+        anchors = self._anchors_for(shapes, (H, W))
+        assert anchors.shape[0] == N, (anchors.shape, N)
+        pd = {'cls_pred': class_scores, 'loc_pred': bbox_offsets}
+        if gt is not None:
+            t = self._config.target
+            labels, targets, _ = K.ssd_target(
+                anchors, gt, gt_count, class_probabilities, C, foreground_threshold=t.foreground_threshold,
+                background_threshold_high=t.background_threshold_high, hard_negative_ratio=t.hard_negative_ratio,
+                variances=self._variances)
+            pd['target'] = {'cls': labels, 'bbox_offsets': targets, 'anchors': anchors}
+        if not is_training or self._debug:
+            p = self._config.proposals
+            props = anchors.unsqueeze(0).expand(B, N, 4).contiguous()
+            cnt = torch.full((B,), N, dtype=torch.int32, device=self.device)
+            objects, olabels, probs, num = K.rcnn_proposal(
+                props, cnt, bbox_offsets.detach().contiguous(), class_probabilities, (H, W), C,
+                variances=self._variances, class_max_detections=p.class_max_detections,
+                class_nms_threshold=p.class_nms_threshold, total_max_detections=p.total_max_detections,
+                min_prob_threshold=p.min_prob_threshold, class_agnostic_boxes=True)
+            pd['classification_prediction'] = {'objects': objects, 'labels': olabels, 'probs': probs,
+                                               'num_objects': num}
+        if self._debug:
+            pd['all_anchors'] = anchors
+            pd['cls_prob'] = class_probabilities
+        pd['_batch'] = {'B': B, 'unbatched': unbatched}
+        if unbatched and not is_training:
+            self._truncate_unbatched(pd)
+        return pd
+
+    def _truncate_unbatched(self, pd):
+        """Reference shapes for a single image (host sync): hard-negative filter applied as boolean_mask."""
+        keep = None
+        if 'target' in pd:
+            keep = pd['target']['cls'][0] >= 0
+            pd['target'] = {'cls': pd['target']['cls'][0][keep], 'bbox_offsets': pd['target']['bbox_offsets'][0][keep],
+                            'anchors': pd['target']['anchors'][keep]}
+        for k in ('cls_pred', 'loc_pred', 'cls_prob'):
+            if k in pd:
+                pd[k] = pd[k][0] if keep is None else pd[k][0][keep]
+        if keep is not None and 'all_anchors' in pd:
+            pd['all_anchors'] = pd['all_anchors'][keep]
+        cp = pd.get('classification_prediction')
+        if cp is not None:
+            d = int(cp['num_objects'][0])
+            for k in ('objects', 'labels', 'probs'):
+                cp[k] = cp[k][0, :d]
+
+    # ------------------------------------------------------------------- loss --
+    def regularization_loss(self):
+        st = self.store
+        if self._frozen_reg is None:
+            self._frozen_reg = K.l2_reg_loss(st.frozen, st.frozen_seg_offset, st.frozen_seg_wd)
+        return (K.l2_reg_loss(st.flat, st.seg_offset, st.seg_wd) + self._frozen_reg)[0]
+
+    def loss(self, prediction_dict, return_all=False):
+        """ssd.py:197-300 (+ the L2 regularisers of the slim VGG scope through get_total_loss)."""
+        losses = A.SsdLossFn.apply(prediction_dict['cls_pred'], prediction_dict['loc_pred'],
+                                   prediction_dict['target']['cls'], prediction_dict['target']['bbox_offsets'],
+                                   self._num_classes, 3.0, float(self._loc_loss_weight))
+        total_loss = losses[0] + self.regularization_loss()
+        self._last_losses = {'total_loss': total_loss, 'cls_loss': losses[1], 'bbox_loss': losses[2]}
+        if return_all:
+            return dict(self._last_losses)
+        return total_loss
+
+    def backward(self, total_loss):
+        self.store.grad.zero_()
+        total_loss.backward()
+        SideStream.join()
+
+    # -------------------------------------------------------------- variables --
+    @property
+    def summary(self):
+        return {k: float(v) for k, v in getattr(self, '_last_losses', {}).items()}
+
+    def get_trainable_vars(self):
+        st = self.store
+        return {n: st.params[n] for n in st.trainable_names()}
+
+    def get_base_network_checkpoint_vars(self):
+        return self.feature_extractor.get_base_network_checkpoint_vars(self.store)
+
+    def get_checkpoint_file(self):
+        return self.feature_extractor.get_checkpoint_file()
+
+    def state_dict(self):
+        return self.store.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.store.load_state_dict(sd, strict=strict)
+        self._frozen_reg = None

@@ -352,6 +352,10 @@ CONV_CASES = [
     (1, 5, 5, 128, 256, 3, 1, 1, 'VALID', 'relu'),
     (1, 1, 512, 1024, 81, 1, 1, 1, 'VALID', None),      # fc_classifier: K % 4 != 0 scalar paths
     (1, 1, 500, 1024, 320, 1, 1, 1, 'VALID', 'relu'),
+    (2, 18, 18, 1024, 24, 3, 1, 1, 'SAME', None),       # SSD multibox offsets head: 3x3, K % 32 != 0
+    (2, 9, 9, 512, 126, 3, 1, 1, 'SAME', None),         # SSD multibox classes head: 3x3, K % 4 != 0
+    (1, 19, 19, 512, 1024, 3, 1, 6, 'SAME', 'relu'),    # SSD conv6: rate 6
+    (2, 5, 5, 128, 256, 3, 1, 1, 'VALID', 'relu'),      # SSD conv10_2
 ]
 
 
@@ -380,8 +384,6 @@ def test_conv_fwd_bwd(K, case):
     # fp32 MFMA == fmaf chain; reference sums in another order: 2e-5 of the output scale
     tol = 2e-5 * max(1.0, float(yt.abs().max()))
     np.testing.assert_allclose(y.cpu().numpy(), yt.detach().numpy(), rtol=1e-4, atol=tol)
-    if C == 3:
-        return
     # backward through the fused layer
     gy = rs.randn(*yt.shape).astype(F)
     g = K.act_bwd(T(gy), y, act) if act else T(gy)
@@ -398,7 +400,8 @@ def test_conv_fwd_bwd(K, case):
     add = rs.randn(*x.shape).astype(F)
     dx2 = K.conv2d_bwd_data(d, g, T(w), T(scale), addend=T(add))
     np.testing.assert_allclose(dx2.cpu().numpy(), xt.grad.numpy() + add, rtol=1e-4, atol=tolx)
-    dw = K.conv2d_bwd_weight(d, T(x), g)            # raw: w.r.t. the un-scaled conv output
+    xw = x - in_sub if in_sub is not None else x     # (the mean subtraction is part of the forward gather only)
+    dw = K.conv2d_bwd_weight(d, T(xw), g)           # raw: w.r.t. the un-scaled conv output
     dw_ref = wt.grad.numpy()
     dws = dw.cpu().numpy() * scale[None, None, None, :]
     tolw = 5e-5 * max(1.0, float(np.abs(dw_ref).max()))
@@ -410,9 +413,9 @@ def test_conv_fwd_bwd(K, case):
         if act and K.conv_fused_act_ok(d):
             dx_f = K.conv2d_bwd_data(d, T(gy), T(w), T(scale), yact=y)
             assert torch.equal(dx_f, dx)
-            dw_f = K.conv2d_bwd_weight(d, T(x), T(gy), yact=y, colsum=cs)
+            dw_f = K.conv2d_bwd_weight(d, T(xw), T(gy), yact=y, colsum=cs)
         else:
-            dw_f = K.conv2d_bwd_weight(d, T(x), g, colsum=cs)
+            dw_f = K.conv2d_bwd_weight(d, T(xw), g, colsum=cs)
         assert torch.equal(dw_f, dw)
         np.testing.assert_allclose(cs.cpu().numpy(), gref.reshape(-1, Kc).sum(0), rtol=1e-3, atol=1e-3)
 
