@@ -1,0 +1,89 @@
+"""CPU: the `lumi train` re-host (luminoth_amd/train.py) with a mock model — the port of the reference's
+luminoth/train_test.py:19-157 (MockFasterRCNN with one weight, loop runs, checkpoint is written and holds the
+trained value, resume continues from the saved global step)."""
+import os
+
+import numpy as np
+import torch
+
+from luminoth_amd import train as T
+from luminoth_amd.utils.config import get_config
+
+
+class MockModel(object):
+    """train_test.py:19-52: loss = reduce_sum(w * 0) ... here a weight that every step moves by +0.5."""
+
+    def __init__(self, config):
+        self.w = torch.tensor([2.0, 2.5])
+        self.steps = 0
+
+    def state_dict(self):
+        return {'mockfasterrcnn/w': self.w.clone()}
+
+    def load_state_dict(self, sd, strict=True):
+        self.w = torch.as_tensor(np.asarray(sd['mockfasterrcnn/w'])).clone()
+
+
+class MockOptimizer(object):
+    global_step = 0
+
+
+def mock_train_step(model, optimizer, image, gt_boxes):
+    assert image.shape[-1] == 3 and len(gt_boxes) == image.shape[0]
+    model.w = model.w + 0.5
+    model.steps += 1
+    optimizer.global_step += 1
+    return torch.tensor(float(model.w.sum())), {}
+
+
+def make_config(tmpdir, **over):
+    ov = ['train.num_epochs=1', 'dataset.type=synthetic', 'dataset.num_images=3', 'dataset.height=64',
+          'dataset.width=96', 'dataset.image_preprocessing.max_size=96', 'train.save_checkpoint_secs=0']
+    ov += ['%s=%s' % kv for kv in over.items()]
+    if tmpdir is not None:
+        ov += ['train.job_dir=%s' % tmpdir, 'train.run_name=test_runname']
+    else:
+        ov += ['train.job_dir=']
+    return get_config({'model': {'type': 'fasterrcnn'}}, ov)
+
+
+def patched_run(config, monkeypatch, **kw):
+    from luminoth_amd.utils import training
+    monkeypatch.setattr(training, 'get_optimizer', lambda cfg, model: MockOptimizer())
+    monkeypatch.setattr(training, 'broadcast_parameters', lambda model: None)
+    return T.run(config, get_model_fn=lambda t: MockModel, train_step_fn=mock_train_step, **kw)
+
+
+def test_train_runs_without_job_dir(monkeypatch):
+    assert patched_run(make_config(None), monkeypatch) == 3          # train_test.py:108-122: "This should not fail"
+
+
+def test_train_saves_checkpoint_and_resumes(tmp_path, monkeypatch):
+    cfg = make_config(str(tmp_path))
+    assert patched_run(cfg, monkeypatch) == 3
+    ckpt = tmp_path / 'test_runname' / 'model.ckpt-3.npz'
+    assert ckpt.exists() and (tmp_path / 'test_runname' / 'checkpoint').read_text().strip().endswith('model.ckpt-3.npz"')
+    data = np.load(str(ckpt))
+    np.testing.assert_allclose(data['mockfasterrcnn/w'], [3.5, 4.0])  # 3 steps of +0.5 (train_test.py:155-157 analogue)
+    assert int(data['global_step']) == 3
+    # resume: continues from step 3 with the saved weights; old checkpoints beyond max_to_keep are dropped
+    assert patched_run(cfg, monkeypatch) == 6
+    files = sorted(os.listdir(str(tmp_path / 'test_runname')))
+    assert 'model.ckpt-6.npz' in files and 'model.ckpt-3.npz' not in files
+    np.testing.assert_allclose(np.load(str(tmp_path / 'test_runname' / 'model.ckpt-6.npz'))['mockfasterrcnn/w'], [5.0, 5.5])
+
+
+def test_checkpoint_rotation_and_dataset_registry(tmp_path):
+    m = MockModel(None)
+    for s in (1, 2, 3, 4):
+        T.save_checkpoint(m, s, str(tmp_path), max_to_keep=2)
+    assert [s for s, _ in T.list_checkpoints(str(tmp_path))] == [3, 4]
+    from luminoth_amd.datasets import get_dataset
+    import pytest
+    with pytest.raises(ValueError):
+        get_dataset('nope')
+    ds = get_dataset('synthetic')(make_config(None, **{'train.batch_size': 2, 'dataset.num_images': 4}))
+    batches = list(ds)
+    assert len(batches) == 2 and batches[0]['image'].shape == (2, 64, 96, 3) and batches[0]['bboxes'][0].shape == (8, 5)
+    b = batches[0]['bboxes'][0]
+    assert (b[:, 2] < 96).all() and (b[:, 3] < 64).all() and (b[:, 0] <= b[:, 2]).all()
