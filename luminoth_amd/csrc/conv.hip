@@ -26,6 +26,7 @@
 //     range of tiles so operand panels stay in its private L2).
 // Shapes that break the alignment rules (C % 32, K % 4 ...) go through the
 // predicated kernels in conv_generic.h.
+#include <stdlib.h>
 #include "conv_common.h"
 #include "conv_generic.h"
 
@@ -64,6 +65,9 @@ static void pick_tile(int64_t M, int64_t Ncols, int* bm, int* bn) {
   }
 }
 
+static bool stem_fast(const lmh_conv_desc* d) {
+  return d->R == 7 && d->S == 7 && d->C == 3 && d->K == 64 && d->stride == 2 && d->dilation == 1;
+}
 static bool fwd_fast(const lmh_conv_desc* d) { return (d->C % BK) == 0 && (d->K & 3) == 0; }
 static bool bwd_data_fast(const lmh_conv_desc* d) { return (d->K % BK) == 0 && (d->C & 3) == 0; }
 static bool bwd_weight_fast(const lmh_conv_desc* d) { return (d->C & 3) == 0 && (d->K & 3) == 0; }
@@ -80,6 +84,15 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
   int bm, bn;
   pick_tile(M, d->K, &bm, &bn);
   hipStream_t st = (hipStream_t)stream;
+  if (stem_fast(d) && residual == nullptr && !g_force_bm) {   // ResNet conv1: dedicated persistent kernel
+    const int tiles_h = (d->OH + STEM_TH - 1) / STEM_TH, tiles_w = (d->OW + STEM_TW - 1) / STEM_TW;
+    const int ntiles = d->N * tiles_h * tiles_w;
+    const int grid1 = ntiles < 512 ? ntiles : 512;   // 2 resident blocks per CU (61 KB LDS each)
+    hipLaunchKernelGGL(k_conv_stem7x7s2<0>, dim3(grid1), dim3(256), 0, st, *d, x, w, scale, shift, in_sub, y, tiles_h,
+                       tiles_w);
+    LMH_CHECK_LAUNCH();
+    return LMH_OK;
+  }
   const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
 #define LAUNCH_FWD(BM_, BN_)                                                                              \
   do {                                                                                                    \
@@ -165,6 +178,7 @@ extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
   if (!d) return -1;
   int bm = 0, bn = 0;
   if (op == 0) {
+    if (stem_fast(d) && !g_force_bm) return 7007;   // k_conv_stem7x7s2
     pick_tile((int64_t)d->N * d->OH * d->OW, d->K, &bm, &bn);
     return bm * 1000 + bn + (fwd_fast(d) ? 0 : 1000000);
   }

@@ -584,3 +584,151 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
     }
   }
 }
+
+// ============================================================================
+// ResNet stem: 7x7 / stride 2, C = 3 -> K = 64 (slim resnet_v1 conv1, conv2d_same: pad 3, VALID), fused
+// channel-mean subtraction (base_network.py:153-177), frozen BN and ReLU.
+//
+// Kg = 147 is far too shallow for the staged pipeline above (5 BK stages, each gathering 3-channel pixels
+// element by element: the generic kernel ran at 42 TF/s).  Here a persistent block keeps the WHOLE weight
+// matrix (147 -> 160 rows x 64) in LDS and, per tile of 8 x 16 output pixels, the 21 x 37 x 3 input patch
+// (mean-subtracted, zero outside the image).  The im2col never exists: lane (pixel i, k) reads
+// patch[pixbase(i) + koff(k)] with koff(k) = k + 90*(k / 21) — for a fully unrolled k loop that is a
+// compile-time immediate off one of two per-lane base registers.  No global traffic and no barrier inside
+// the 160-MFMA tile loop; the next tile's patch is prefetched into registers under it.  Measured: 232 -> 134 us
+// (74 TF/s); the MFMA phase runs at 87 % of peak, the rest is the 134 MB output write (2.4 TB/s with every
+// block storing in lockstep) which does not yet overlap the next tile's MFMAs.
+// ============================================================================
+#define STEM_TH 8
+#define STEM_TW 16
+#define STEM_PH ((STEM_TH - 1) * 2 + 7)   // 21
+#define STEM_PW ((STEM_TW - 1) * 2 + 7)   // 37
+#define STEM_ROWF (STEM_PW * 3)           // 111 floats per patch row
+#define STEM_PATCH (STEM_PH * STEM_ROWF)  // 2331
+#define STEM_KP 160                       // 147 padded to a multiple of 32 (zero weight rows)
+#define STEM_NLD ((STEM_PATCH + 255) / 256)
+
+template <int dbg>   // dbg: compile-time ablation switches (1 no stores, 2 10% of the MFMAs, 4 no patch fetch); product = 0
+__global__ void __launch_bounds__(256)
+k_conv_stem7x7s2(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
+                 const float* __restrict__ scale, const float* __restrict__ shift,
+                 const float* __restrict__ in_sub, float* __restrict__ y, int tiles_h, int tiles_w) {
+  __shared__ __attribute__((aligned(16))) float Ws[STEM_KP * 64];
+  __shared__ __attribute__((aligned(16))) float Ps[2][STEM_PATCH + 64 * 3 + 32];   // slack: k in [147,160) reads
+  __shared__ __attribute__((aligned(16))) float Sc[64], Sh[64];                     // BN scale / shift (epilogue)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  for (int i = tid; i < STEM_KP * 64; i += 256) Ws[i] = (i < 147 * 64) ? w[i] : 0.f;
+  if (tid < 64) { Sc[tid] = scale ? scale[tid] : 1.f; Sh[tid] = shift ? shift[tid] : 0.f; }
+  const float act_lo = d.act ? 0.f : -INFINITY, act_hi = (d.act == 2) ? 6.f : INFINITY;   // branch-free activation
+  for (int i = tid; i < 2 * (STEM_PATCH + 64 * 3 + 32); i += 256) (&Ps[0][0])[i] = 0.f;
+  const float sub[3] = {in_sub ? in_sub[0] : 0.f, in_sub ? in_sub[1] : 0.f, in_sub ? in_sub[2] : 0.f};
+  const int ntiles = d.N * tiles_h * tiles_w;
+  // per-thread patch element slots (fixed across tiles): e = tid + 256*q -> (row, col3)
+  int prow[STEM_NLD], pcol[STEM_NLD];
+#pragma unroll
+  for (int q = 0; q < STEM_NLD; ++q) {
+    const int e = tid + 256 * q;
+    prow[q] = e / STEM_ROWF;
+    pcol[q] = e - prow[q] * STEM_ROWF;
+  }
+  float pre[STEM_NLD];
+#define STEM_FETCH(t_)                                                                       \
+  do {                                                                                       \
+    const int tw_ = (t_) % tiles_w, tq_ = (t_) / tiles_w;                                    \
+    const int th_ = tq_ % tiles_h, n_ = tq_ / tiles_h;                                       \
+    const int ih0 = th_ * STEM_TH * 2 - d.pad_top, iw0 = tw_ * STEM_TW * 2 - d.pad_left;     \
+    _Pragma("unroll") for (int q = 0; q < STEM_NLD; ++q) {                                   \
+      const int e = tid + 256 * q;                                                           \
+      const int ih = ih0 + prow[q], iwc = iw0 * 3 + pcol[q];                                 \
+      const bool ok = e < STEM_PATCH && (unsigned)ih < (unsigned)d.H && iwc >= 0 && iwc < d.W * 3; \
+      const int ch = pcol[q] % 3;                                                            \
+      pre[q] = ok ? x[((size_t)n_ * d.H + ih) * d.W * 3 + iwc] - sub[ch] : 0.f;              \
+    }                                                                                        \
+  } while (0)
+#define STEM_COMMIT(buf_)                                                                    \
+  do {                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < STEM_NLD; ++q) {                                   \
+      const int e = tid + 256 * q;                                                           \
+      if (e < STEM_PATCH) Ps[buf_][e] = pre[q];                                              \
+    }                                                                                        \
+  } while (0)
+  // this wave's 32 pixels: rows 2*wave, 2*wave+1 of the 8 x 16 tile
+  const int py = 2 * wave + (l31 >> 4), px = l31 & 15;
+  const int pixbase = py * 2 * STEM_ROWF + px * 6;
+  int t = blockIdx.x;
+  if (t < ntiles) STEM_FETCH(t);
+  __syncthreads();                      // Ws / zeroed patches visible
+  if (t < ntiles) STEM_COMMIT(0);
+  __syncthreads();
+  int buf = 0;
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    if (tn < ntiles && !(dbg & 4)) STEM_FETCH(tn);    // next patch: global -> registers, under the MFMAs below
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const float* P = &Ps[buf][pixbase + h];          // k even/odd split: lane half h takes k = 2s + h
+    const float* P91 = &Ps[buf][pixbase + 91 * h];   // steps where 2s+1 starts a new filter row
+    const float* Wl = &Ws[h * 64 + l31];
+    // operands of k-pair group g+1 are read while the MFMAs of group g issue (4 k-pairs per group,
+    // sched_barrier-pinned: left alone the scheduler puts every ds_read right before its MFMA)
+    float fa[2][4], fb0[2][4], fb1[2][4];
+#define STEM_LOAD(g_, set_)                                                              \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                        \
+    const int k0 = 2 * (4 * (g_) + u);                                                   \
+    const int koff0 = k0 + 90 * (k0 / 21);                                               \
+    fa[set_][u] = (((k0 + 1) % 21) == 0) ? P91[koff0] : P[koff0];                        \
+    fb0[set_][u] = Wl[k0 * 64];                                                          \
+    fb1[set_][u] = Wl[k0 * 64 + 32];                                                     \
+  }
+    STEM_LOAD(0, 0)
+#pragma unroll
+    for (int g = 0; g < ((dbg & 2) ? 2 : STEM_KP / 8); ++g) {
+      const int cur = g & 1;
+      if (g + 1 < STEM_KP / 8) { STEM_LOAD(g + 1, cur ^ 1) }
+      __builtin_amdgcn_sched_barrier(0);
+      // transposed product D[channel][pixel]: a lane then owns 4 CONSECUTIVE channels of one pixel per
+      // accumulator quad -> float4 stores (4x fewer store instructions than D[pixel][channel])
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fb0[cur][u], fa[cur][u], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fb1[cur][u], fa[cur][u], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef STEM_LOAD
+    // next patch -> LDS BEFORE this tile's stores: the vmcnt wait for the prefetch loads then covers no store of
+    // this tile (memory ops retire in order; the previous tile's stores finished under the MFMAs above)
+    if (tn < ntiles) STEM_COMMIT(buf ^ 1);
+    // epilogue: lane = pixel l31 of this wave; accumulator quad g = channels 8g + 4h .. +3 (+32 for acc1)
+    const int tw_ = t % tiles_w, tq_ = t / tiles_w;
+    const int th_ = tq_ % tiles_h, n_ = tq_ / tiles_h;
+    const int oh = th_ * STEM_TH + py, ow = tw_ * STEM_TW + px;
+    if (oh < d.OH && ow < d.OW) {
+      float* o = y + (((size_t)n_ * d.OH + oh) * d.OW + ow) * 64 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int c0 = 8 * g + 4 * h + 32 * half;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(&Sc[c0]);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(&Sh[c0]);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a_ = half ? acc1[4 * g + e] : acc0[4 * g + e];
+            v[e] = fminf(fmaxf(a_ * sc[e] + sh[e], act_lo), act_hi);
+          }
+          if (!(dbg & 1)) *reinterpret_cast<f32x4*>(o + 8 * g + 32 * half) = v;
+        }
+      }
+    }
+    // raw barrier: __syncthreads() would also drain vmcnt(0), i.e. wait for this tile's output stores to be
+    // acknowledged (PMC: 47 % of the wave cycles sat in that wait); only the LDS patch writes must be complete
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    buf ^= 1;
+  }
+#undef STEM_FETCH
+#undef STEM_COMMIT
+}

@@ -420,6 +420,25 @@ def test_conv_fwd_bwd(K, case):
         np.testing.assert_allclose(cs.cpu().numpy(), gref.reshape(-1, Kc).sum(0), rtol=1e-3, atol=1e-3)
 
 
+def test_conv_stem_kernel(K):
+    """ResNet conv1 (7x7/2, 3 -> 64, conv2d_same + mean subtraction + BN + ReLU): the dedicated persistent
+    kernel (k_conv_stem7x7s2) vs the oracle, incl. ragged tile edges."""
+    rs = np.random.RandomState(21)
+    for (N, H, W) in ((2, 64, 96), (1, 70, 45), (1, 256, 256)):
+        x = (rs.rand(N, H, W, 3) * 255).astype(F)
+        w = (rs.randn(7, 7, 3, 64) * np.sqrt(2.0 / 147)).astype(F)
+        scale = (0.01 * (1 + 0.1 * rs.randn(64))).astype(F)
+        shift = (0.1 * rs.randn(64)).astype(F)
+        in_sub = np.array([123.68, 116.78, 103.94], F)
+        d = K.conv_desc(x.shape, w.shape, 2, 1, 'SAME_EXPLICIT', 'relu')
+        assert K._lib.load().lmh_conv2d_kernel_id(d, 0) == 7007
+        y = K.conv2d_fwd(d, T(x), T(w), T(scale), T(shift), None, T(in_sub))
+        yt = torch.relu(ot.conv2d_nhwc(torch.tensor(x) - torch.tensor(in_sub), torch.tensor(w), 2, 1, 'SAME_EXPLICIT') *
+                        torch.tensor(scale) + torch.tensor(shift))
+        assert tuple(y.shape) == tuple(yt.shape)
+        np.testing.assert_allclose(y.cpu().numpy(), yt.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(yt.abs().max())))
+
+
 def test_bn_param_grads(K):
     rs = np.random.RandomState(5)
     rsc, Kc = 9 * 64, 96
