@@ -54,15 +54,19 @@ extern "C" void lmh_conv2d_force_config(int bm, int bn, int splits) {
 
 // Block tile: minimise (tile rounds over the 256 CUs) x (tile area), i.e. the matrix-pipe time of the
 // busiest CU; ties go to the larger tile (less L2 traffic).  Fitted to scripts/sweep_conv.py on MI355X.
-static void pick_tile(int64_t M, int64_t Ncols, int* bm, int* bn) {
+static void pick_tile(int64_t M, int64_t Ncols, int* bm, int* bn, int slots = 256) {
   if (g_force_bm && g_force_bn) { *bm = g_force_bm; *bn = g_force_bn; return; }
   static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
   int64_t best = -1;
   for (int i = 0; i < 3; ++i) {
     const int64_t tiles = ((M + cand[i][0] - 1) / cand[i][0]) * ((Ncols + cand[i][1] - 1) / cand[i][1]);
-    const int64_t cost = ((tiles + 255) / 256) * cand[i][0] * cand[i][1];
+    const int64_t cost = ((tiles + slots - 1) / slots) * cand[i][0] * cand[i][1];
     if (best < 0 || cost < best) { best = cost; *bm = cand[i][0]; *bn = cand[i][1]; }
   }
+}
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
 }
 
 static bool stem_fast(const lmh_conv_desc* d) {
@@ -125,7 +129,8 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   const int64_t M = (int64_t)d->N * d->H * d->W;
   const bool fast = bwd_data_fast(d);
   int bm, bn;
-  pick_tile(M, d->C, &bm, &bn);
+  static const int bd_slots = env_int("LMH_BD_SLOTS", 256);
+  pick_tile(M, d->C, &bm, &bn, bd_slots);
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
 #define LAUNCH_BD(BM_, BN_)                                                                                 \
@@ -161,10 +166,11 @@ static void bwd_weight_plan(const lmh_conv_desc* d, int* bm, int* bn, int* split
   const int KT = (int)((P + BK - 1) / BK);
   int max_split = KT / 16 > 0 ? KT / 16 : 1;
   if (max_split > 64) max_split = 64;
+  static const int bw_slots = env_int("LMH_BW_SLOTS", 512);
   int want = 1;
   double best_eff = -1.0;
   for (int s = 1; s <= max_split; ++s) {
-    const double rounds = (double)(tiles * s) / 512.0;
+    const double rounds = (double)(tiles * s) / (double)bw_slots;
     const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
     if (eff >= 0.9) { want = s; best_eff = eff; break; }
     if (eff > best_eff + 1e-9) { best_eff = eff; want = s; }
@@ -183,7 +189,7 @@ extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
     return bm * 1000 + bn + (fwd_fast(d) ? 0 : 1000000);
   }
   if (op == 1) {
-    pick_tile((int64_t)d->N * d->H * d->W, d->C, &bm, &bn);
+    pick_tile((int64_t)d->N * d->H * d->W, d->C, &bm, &bn, env_int("LMH_BD_SLOTS", 256));
     return bm * 1000 + bn + (bwd_data_fast(d) ? 0 : 1000000);
   }
   int splits, kps;

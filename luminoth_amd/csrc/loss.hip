@@ -44,6 +44,7 @@ k_rpn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_p
            const float* __restrict__ labels, const float* __restrict__ bbox_targets, int B, int N,
            float sigma2, float w_cls, float w_reg, float* __restrict__ per_image,
            float* __restrict__ d_cls, float* __restrict__ d_bbox) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ float sh[72];
   const int b = blockIdx.x;
   const float2* cs = reinterpret_cast<const float2*>(cls_score) + (size_t)b * N;
@@ -137,6 +138,7 @@ k_rcnn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_
             const float* __restrict__ labels, const float* __restrict__ targets, int B, int R, int C,
             float sigma2, float w_cls, float w_reg, float* __restrict__ per_image,
             float* __restrict__ d_cls, float* __restrict__ d_off) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ float sh[72];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;

@@ -15,6 +15,7 @@ k_rpn_decode(lmh_rpn_proposal_desc d, int N, int Npad, const float* __restrict__
              const float* __restrict__ bbox_pred, const int32_t* __restrict__ anchor_ref,
              float* __restrict__ cls_prob, float4* __restrict__ boxes, uint64_t* __restrict__ keys,
              int32_t* __restrict__ n_valid) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   const int b = blockIdx.y;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= Npad) return;
@@ -68,6 +69,7 @@ __device__ __forceinline__ void cmp_swap(uint64_t& a, uint64_t& b, bool asc) {
 // Sort (full network up to k = min(n_pad, SORT_CHUNK)) each chunk in LDS.
 __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_local(uint64_t* __restrict__ keys, int n_pad, int chunk) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
   const size_t base = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * chunk;
@@ -90,6 +92,7 @@ k_sort_local(uint64_t* __restrict__ keys, int n_pad, int chunk) {
 // One global compare-exchange pass (stride j >= chunk) of merge step k.
 __global__ void __launch_bounds__(256)
 k_sort_global(uint64_t* __restrict__ keys, int n_pad, int k, int j) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_pad / 2) return;
   uint64_t* kb = keys + (size_t)blockIdx.y * n_pad;
@@ -102,6 +105,7 @@ k_sort_global(uint64_t* __restrict__ keys, int n_pad, int k, int j) {
 // Finish merge step k inside each chunk (strides chunk/2 .. 1) in LDS.
 __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_merge_local(uint64_t* __restrict__ keys, int n_pad, int chunk, int k) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
   const size_t base = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * chunk;
@@ -149,6 +153,7 @@ k_gather_topk(const uint64_t* __restrict__ keys, const float4* __restrict__ boxe
               const float* __restrict__ cls_prob, const int32_t* __restrict__ n_valid, int N,
               int Npad, int K, float4* __restrict__ top_boxes, float* __restrict__ top_scores,
               int32_t* __restrict__ top_count) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int cnt = min(n_valid[b], K);
@@ -221,6 +226,7 @@ k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts,
 __global__ void __launch_bounds__(NMS_RED_THREADS)
 k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts, int K, int W,
              int max_out, int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   // all LDS static: a static object in front of a dynamic region would leave the u64 bitmap
   // 4-byte aligned (64-bit LDS atomics then misbehave) — guide §6 G17.
   __shared__ __attribute__((aligned(16))) unsigned long long removed[NMS_MAX_W];
@@ -325,6 +331,7 @@ k_gather_keep(const float4* __restrict__ top_boxes, const float* __restrict__ to
               const int32_t* __restrict__ keep_idx, const int32_t* __restrict__ keep_count, int K,
               int max_out, int clip_after, float im_h, float im_w, float4* __restrict__ proposals,
               float* __restrict__ scores, int32_t* __restrict__ num) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) num[b] = keep_count[b];

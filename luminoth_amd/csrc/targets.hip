@@ -85,6 +85,7 @@ k_rpn_target_rowmax(lmh_rpn_target_desc d, int N, const int32_t* __restrict__ an
                     const float* __restrict__ gt, const int32_t* __restrict__ gt_count,
                     float* __restrict__ max_overlaps, int32_t* __restrict__ argmax,
                     uint32_t* __restrict__ gt_max_bits) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ lmh_box sgt[RT_MAX_G];
   __shared__ float sarea[RT_MAX_G];
   __shared__ uint32_t scolmax[RT_MAX_G];
@@ -134,6 +135,7 @@ k_rpn_target_labels(lmh_rpn_target_desc d, int N, const int32_t* __restrict__ an
                     const float* __restrict__ max_overlaps, const int32_t* __restrict__ argmax,
                     const uint32_t* __restrict__ gt_max_bits, float* __restrict__ labels,
                     float* __restrict__ labels_pre) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ lmh_box sgt[RT_MAX_G];
   __shared__ float sarea[RT_MAX_G];
   __shared__ float scolmax[RT_MAX_G];
@@ -170,11 +172,11 @@ k_rpn_target_labels(lmh_rpn_target_desc d, int N, const int32_t* __restrict__ an
   if (labels_pre) labels_pre[row] = label;
 }
 
-// kernel C: exact random subsampling of fg then bg, one block per image
+// kernel C (fallback for N > RT_LDS_MAX_N): exact random subsampling of fg then bg, one block per image
 // (rpn_target.py:203-284), then bbox targets (rpn_target.py:289-304).
 #define RT_SUB_THREADS 1024
 __global__ void __launch_bounds__(RT_SUB_THREADS)
-k_rpn_target_subsample(lmh_rpn_target_desc d, int N, const int32_t* __restrict__ anchor_ref,
+k_rpn_target_subsample_global(lmh_rpn_target_desc d, int N, const int32_t* __restrict__ anchor_ref,
                        const float* __restrict__ gt, const int32_t* __restrict__ gt_count,
                        const uint32_t* __restrict__ seeds, const int32_t* __restrict__ argmax,
                        float* __restrict__ labels, float* __restrict__ bbox_targets) {
@@ -245,6 +247,84 @@ k_rpn_target_subsample(lmh_rpn_target_desc d, int N, const int32_t* __restrict__
   }
 }
 
+// kernel C: exact random subsampling of fg then bg (rpn_target.py:203-284), then bbox targets
+// (rpn_target.py:289-304), one block per image.  The labels are staged ONCE into LDS as int8 (48 KiB for
+// the 49 152 anchors of a 1024^2 image): the ~12 scans of the radix selects then never touch global memory
+// (the global-memory version above spent 0.2 ms on dependent scan latency, on the step's critical path).
+#define RT_LDS_MAX_N 61440
+__global__ void __launch_bounds__(RT_SUB_THREADS)
+k_rpn_target_subsample(lmh_rpn_target_desc d, int N, const int32_t* __restrict__ anchor_ref,
+                       const float* __restrict__ gt, const int32_t* __restrict__ gt_count,
+                       const uint32_t* __restrict__ seeds, const int32_t* __restrict__ argmax,
+                       float* __restrict__ labels, float* __restrict__ bbox_targets) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
+  __shared__ int8_t sl[RT_LDS_MAX_N];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t eq_list[LMH_SELECT_MAX_EQ];
+  __shared__ uint32_t bc[4];
+  __shared__ uint32_t s_cnt[2];
+  const int b = blockIdx.x;
+  float* lab = labels + (size_t)b * N;
+  const uint32_t seed = seeds[b];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  uint32_t cf = 0, cb = 0;
+  for (int i = threadIdx.x; i < N; i += RT_SUB_THREADS) {
+    const float l = lab[i];
+    sl[i] = (int8_t)(int)l;
+    cf += (l == 1.f);
+  }
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) cf += __shfl_down(cf, o);
+  if ((threadIdx.x & 63) == 0 && cf) atomicAdd(&s_cnt[0], cf);
+  __syncthreads();
+  const uint32_t num_fg = (uint32_t)(int)(d.foreground_fraction * (float)d.minibatch_size);
+  uint32_t n_fg = s_cnt[0];
+  if (n_fg > num_fg) {
+    if (num_fg == 0) {
+      for (int i = threadIdx.x; i < N; i += RT_SUB_THREADS) if (sl[i] == 1) sl[i] = -1;
+    } else {
+      lmh_select_state st;
+      block_select_kth(N, num_fg, seed, LMH_STREAM_RPN_FG, [&](int i) { return sl[i] == 1; }, hist, eq_list, bc, &st);
+      for (int i = threadIdx.x; i < N; i += RT_SUB_THREADS)
+        if (sl[i] == 1 && !select_keep(st, eq_list, seed, LMH_STREAM_RPN_FG, (uint32_t)i)) sl[i] = -1;
+    }
+    n_fg = num_fg;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += RT_SUB_THREADS) cb += (sl[i] == 0);
+  for (int o = 32; o > 0; o >>= 1) cb += __shfl_down(cb, o);
+  if ((threadIdx.x & 63) == 0 && cb) atomicAdd(&s_cnt[1], cb);
+  __syncthreads();
+  const int num_bg_i = d.minibatch_size - (int)n_fg;
+  const uint32_t num_bg = num_bg_i > 0 ? (uint32_t)num_bg_i : 0u;
+  if (s_cnt[1] > num_bg) {
+    if (num_bg == 0) {
+      for (int i = threadIdx.x; i < N; i += RT_SUB_THREADS) if (sl[i] == 0) sl[i] = -1;
+    } else {
+      lmh_select_state st;
+      block_select_kth(N, num_bg, seed, LMH_STREAM_RPN_BG, [&](int i) { return sl[i] == 0; }, hist, eq_list, bc, &st);
+      for (int i = threadIdx.x; i < N; i += RT_SUB_THREADS)
+        if (sl[i] == 0 && !select_keep(st, eq_list, seed, LMH_STREAM_RPN_BG, (uint32_t)i)) sl[i] = -1;
+    }
+  }
+  __syncthreads();
+  // final labels + bbox targets: encode(anchor, gt[argmax]) where label == 1 else 0
+  for (int i = threadIdx.x; i < N; i += RT_SUB_THREADS) {
+    const int l = sl[i];
+    lab[i] = (float)l;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    if (l == 1) {
+      int32_t a4[4];
+      lmh_anchor(anchor_ref, i, d.A, d.feat_w, d.anchor_stride, a4);
+      const lmh_box a = {(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+      const float* p = gt + ((size_t)b * d.Gmax + argmax[(size_t)b * N + i]) * 5;
+      const lmh_box g = {p[0], p[1], p[2], p[3]};
+      lmh_encode(a, g, 1.f, 1.f, t);
+    }
+    reinterpret_cast<float4*>(bbox_targets)[(size_t)b * N + i] = make_float4(t[0], t[1], t[2], t[3]);
+  }
+}
+
 extern "C" size_t lmh_rpn_target_workspace_bytes(const lmh_rpn_target_desc* d) {
   if (!d) return 0;
   const size_t N = (size_t)d->feat_h * d->feat_w * d->A;
@@ -273,7 +353,11 @@ extern "C" int lmh_rpn_target(const lmh_rpn_target_desc* d, const int32_t* ancho
                      max_overlaps, argmax, gt_max);
   hipLaunchKernelGGL(k_rpn_target_labels, g, dim3(256), 0, st, *d, N, anchor_ref, gt, gt_count,
                      max_overlaps, argmax, gt_max, labels, labels_pre);
-  hipLaunchKernelGGL(k_rpn_target_subsample, dim3(d->B), dim3(RT_SUB_THREADS), 0, st, *d, N,
+  if (N <= RT_LDS_MAX_N)
+    hipLaunchKernelGGL(k_rpn_target_subsample, dim3(d->B), dim3(RT_SUB_THREADS), 0, st, *d, N,
+                     anchor_ref, gt, gt_count, seeds, argmax, labels, bbox_targets);
+  else
+    hipLaunchKernelGGL(k_rpn_target_subsample_global, dim3(d->B), dim3(RT_SUB_THREADS), 0, st, *d, N,
                      anchor_ref, gt, gt_count, seeds, argmax, labels, bbox_targets);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -293,6 +377,7 @@ k_rcnn_target(lmh_rcnn_target_desc d, const float* __restrict__ proposals,
               float* __restrict__ labels_pre, float* __restrict__ rois,
               float* __restrict__ roi_labels, float* __restrict__ roi_targets,
               int32_t* __restrict__ roi_count) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ lmh_box sgt[RT_MAX_G];
   __shared__ float sarea[RT_MAX_G];
   __shared__ float sglabel[RT_MAX_G];

@@ -318,7 +318,10 @@ class FasterRCNN(object):
     def _aux_stream(self):
         st = getattr(self, '_aux', None)
         if st is None:
-            st = self._aux = torch.cuda.Stream(device=self.device)
+            # high priority: the proposal/RCNN chain is a string of small latency-bound launches; its blocks must
+            # not queue behind the CU-filling convolution grids of the main / side streams
+            prio = int(os.environ.get('LUMINOTH_AMD_AUX_PRIORITY', '-1'))
+            st = self._aux = torch.cuda.Stream(device=self.device, priority=prio)
         return st
 
     # --------------------------------------------------------------- variables --
