@@ -272,32 +272,49 @@ k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict
 #undef FWD_STORE
 #undef FWD_SETUP_RS
 
-  // ---- epilogue through LDS: float4 rows
-  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
-  __syncthreads();
+  // ---- epilogue through LDS: float4 rows.  The residual rows of the first chunk are requested BEFORE the
+  // accumulator transpose so their (L2 / HBM) latency runs under it; each later chunk issues all of its loads
+  // together (the old row-by-row loop exposed that latency four times per tile).
   constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  constexpr int NR = BM / RSTEP, NRC = NR < 8 ? NR : 8, NCH = NR / NRC;
   const int c4 = tid % CT, r0 = tid / CT;
   const int col = n0 + 4 * c4;
-  if (col < K) {
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (scale) sc = *reinterpret_cast<const float4*>(scale + col);
-    if (shift) sh = *reinterpret_cast<const float4*>(shift + col);
-    const int act = d.act;
-#pragma unroll 4
-    for (int r = r0; r < BM; r += RSTEP) {
-      const int row = m0 + r;
-      if (row >= M) break;
-      float4 v = *reinterpret_cast<const float4*>(&smem[r * LDC + 4 * c4]);
-      if (scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
-      v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
-      if (residual) {
-        const float4 rr = *reinterpret_cast<const float4*>(residual + (size_t)row * K + col);
-        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+  const bool col_ok = col < K;
+  f32x4 ex[NRC];
+#define FWD_EPI_ISSUE(ch_)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < NRC; ++i) {                                              \
+    const int row = m0 + r0 + ((ch_) * NRC + i) * RSTEP;                                         \
+    ex[i] = (residual && col_ok && row < M) ? *reinterpret_cast<const f32x4*>(residual + (size_t)row * K + col) \
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};                         \
+  }
+  FWD_EPI_ISSUE(0)
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  if (col_ok) {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + col);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + col);
+    const float act_lo = d.act ? 0.f : -INFINITY, act_hi = (d.act == 2) ? 6.f : INFINITY;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (ch > 0) { FWD_EPI_ISSUE(ch) }
+#pragma unroll
+      for (int i = 0; i < NRC; ++i) {
+        const int r = r0 + (ch * NRC + i) * RSTEP;
+        const int row = m0 + r;
+        if (row < M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
+          if (scale) v *= sc;
+          v += sh;
+          v += ex[i];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
+          *reinterpret_cast<f32x4*>(y + (size_t)row * K + col) = v;
+        }
       }
-      v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
-      *reinterpret_cast<float4*>(y + (size_t)row * K + col) = v;
     }
   }
+#undef FWD_EPI_ISSUE
 }
 
 // ============================================================================
@@ -429,25 +446,44 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
 #undef BD_STORE
 #undef BD_SETUP_RS
 
-  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
-  __syncthreads();
+  // epilogue: same chunked prefetch of the addend / mask rows as the forward kernel
   constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  constexpr int NR = BM / RSTEP, NRC = NR < 8 ? NR : 8, NCH = NR / NRC;
   const int c4 = tid % CT, r0 = tid / CT;
   const int col = n0 + 4 * c4;
+  const bool col_ok = col < C;
   const float xm_hi = (xmask_act == 2) ? 6.f : INFINITY;
-  if (col < C) {
-#pragma unroll 4
-    for (int r = r0; r < BM; r += RSTEP) {
-      const int row = m0 + r;
-      if (row >= M) break;
-      f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
-      if (addend) v += *reinterpret_cast<const f32x4*>(addend + (size_t)row * C + col);
-      // x is the (post-activation) output of the layer below: emitting dx * act'(x) hands that layer its
-      // pre-activation gradient directly — no separate lmh_act_bwd pass over dx
-      if (xmask) v = act_mask(v, *reinterpret_cast<const f32x4*>(xmask + (size_t)row * C + col), xm_hi);
-      *reinterpret_cast<f32x4*>(dx + (size_t)row * C + col) = v;
+  f32x4 ex[NRC], xm[NRC];
+#define BD_EPI_ISSUE(ch_)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < NRC; ++i) {                                              \
+    const int row = m0 + r0 + ((ch_) * NRC + i) * RSTEP;                                         \
+    const bool ok = col_ok && row < M;                                                           \
+    ex[i] = (addend && ok) ? *reinterpret_cast<const f32x4*>(addend + (size_t)row * C + col) : f32x4{0.f, 0.f, 0.f, 0.f}; \
+    if (xmask) xm[i] = ok ? *reinterpret_cast<const f32x4*>(xmask + (size_t)row * C + col) : f32x4{1.f, 1.f, 1.f, 1.f}; \
+  }
+  BD_EPI_ISSUE(0)
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  if (col_ok) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (ch > 0) { BD_EPI_ISSUE(ch) }
+#pragma unroll
+      for (int i = 0; i < NRC; ++i) {
+        const int r = r0 + (ch * NRC + i) * RSTEP;
+        const int row = m0 + r;
+        if (row < M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
+          v += ex[i];
+          // x is the (post-activation) output of the layer below: emitting dx * act'(x) hands that layer its
+          // pre-activation gradient directly — no separate lmh_act_bwd pass over dx
+          if (xmask) v = act_mask(v, xm[i], xm_hi);
+          *reinterpret_cast<f32x4*>(dx + (size_t)row * C + col) = v;
+        }
+      }
     }
   }
+#undef BD_EPI_ISSUE
 }
 
 // ============================================================================

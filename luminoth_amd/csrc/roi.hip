@@ -11,6 +11,8 @@
 #include "lmh_common.h"
 #include <stdlib.h>
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct roi_geom {
   float y1n, x1n, hs, ws;  // normalised top-left * (dim-1), per-sample scale
 };
@@ -54,55 +56,75 @@ __device__ __forceinline__ float bilerp(float tl, float tr, float bl, float br, 
   return top + (bot - top) * yl;
 }
 
-// grid: (ph*pw, B*R); block: min(C/4, 256) threads, each a float4 of channels.
+// grid: B*R*ph blocks, one per (ROI, cell row); block: min(C/4, 256) threads, each a float4 of channels,
+// looping over the pw cells of the row.  Block ids are mapped so that the ph rows of one ROI land on the same
+// XCD (ids 8 apart): neighbouring cells share their bilinear corner rows, which then hit in that XCD's L2 / the
+// CU's L1 (the first version launched one block per (ROI, cell) in launch order: 701 MB fetched for a 33.5 MB
+// feature map — PMC — and 0.48 ms when running beside the convolution streams).  All 16 corner loads of a cell
+// are unconditional (clamped coordinates, value selected afterwards) so they are in flight together.
 __global__ void __launch_bounds__(256)
 k_roi_pool_fwd(const float* __restrict__ feat, const float4* __restrict__ rois,
-               const int32_t* __restrict__ roi_count, int R, int FH, int FW, int C, float im_h,
+               const int32_t* __restrict__ roi_count, int R, int BR, int FH, int FW, int C, float im_h,
                float im_w, int ph, int pw, float* __restrict__ out, uint8_t* __restrict__ argmax) {
-  const int rr = blockIdx.y;
+  int rr, py;
+  {
+    const int id = blockIdx.x, n8 = (BR >> 3) << 3;
+    if (id < n8 * ph) {
+      const int g8 = id >> 3;
+      rr = (id & 7) + 8 * (g8 / ph);
+      py = g8 % ph;
+    } else {
+      const int t = id - n8 * ph;
+      rr = n8 + t / ph;
+      py = t % ph;
+    }
+  }
   const int b = rr / R, r = rr % R;
-  const int cell = blockIdx.x;
-  const int py = cell / pw, px = cell % pw;
-  const size_t obase = ((size_t)rr * ph * pw + cell) * C;
   const bool live = r < roi_count[b];
   const int C4 = C >> 2;
+  const size_t obase0 = ((size_t)rr * ph + py) * pw * C;
   if (!live) {
-    for (int c4 = threadIdx.x; c4 < C4; c4 += blockDim.x) {
-      reinterpret_cast<float4*>(out + obase)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (argmax) reinterpret_cast<uint32_t*>(argmax + obase)[c4] = 0u;
-    }
+    for (int px = 0; px < pw; ++px)
+      for (int c4 = threadIdx.x; c4 < C4; c4 += blockDim.x) {
+        reinterpret_cast<float4*>(out + obase0 + (size_t)px * C)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (argmax) reinterpret_cast<uint32_t*>(argmax + obase0 + (size_t)px * C)[c4] = 0u;
+      }
     return;
   }
   const int ch = 2 * ph, cw = 2 * pw;  // crop size is passed (w*2, h*2): square in practice
   const roi_geom g = roi_geometry(rois[rr], im_h, im_w, FH, FW, ch, cw);
-  roi_sample s[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) s[q] = roi_sample_at(g, 2 * py + (q >> 1), 2 * px + (q & 1), FH, FW, ch, cw);
   const float* fb = feat + (size_t)b * FH * FW * C;
   for (int c4 = threadIdx.x; c4 < C4; c4 += blockDim.x) {
-    float best[4];
-    uint32_t am[4] = {0, 0, 0, 0};
+    const float4* fc = reinterpret_cast<const float4*>(fb) + c4;
+#pragma unroll 2
+    for (int px = 0; px < pw; ++px) {
+      const size_t obase = obase0 + (size_t)px * C;
+      f32x4 tl[4], tr[4], bl[4], br[4];
+      roi_sample s[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (s[q].valid) {
-        const float4 tl = reinterpret_cast<const float4*>(fb + ((size_t)s[q].top * FW + s[q].left) * C)[c4];
-        const float4 tr = reinterpret_cast<const float4*>(fb + ((size_t)s[q].top * FW + s[q].right) * C)[c4];
-        const float4 bl = reinterpret_cast<const float4*>(fb + ((size_t)s[q].bot * FW + s[q].left) * C)[c4];
-        const float4 br = reinterpret_cast<const float4*>(fb + ((size_t)s[q].bot * FW + s[q].right) * C)[c4];
-        v[0] = bilerp(tl.x, tr.x, bl.x, br.x, s[q].xlerp, s[q].ylerp);
-        v[1] = bilerp(tl.y, tr.y, bl.y, br.y, s[q].xlerp, s[q].ylerp);
-        v[2] = bilerp(tl.z, tr.z, bl.z, br.z, s[q].xlerp, s[q].ylerp);
-        v[3] = bilerp(tl.w, tr.w, bl.w, br.w, s[q].xlerp, s[q].ylerp);
+      for (int q = 0; q < 4; ++q) {
+        s[q] = roi_sample_at(g, 2 * py + (q >> 1), 2 * px + (q & 1), FH, FW, ch, cw);
+        const int t = min(max(s[q].top, 0), FH - 1), bo = min(max(s[q].bot, 0), FH - 1);
+        const int l = min(max(s[q].left, 0), FW - 1), ri = min(max(s[q].right, 0), FW - 1);
+        tl[q] = *reinterpret_cast<const f32x4*>(fc + ((size_t)t * FW + l) * C4);
+        tr[q] = *reinterpret_cast<const f32x4*>(fc + ((size_t)t * FW + ri) * C4);
+        bl[q] = *reinterpret_cast<const f32x4*>(fc + ((size_t)bo * FW + l) * C4);
+        br[q] = *reinterpret_cast<const f32x4*>(fc + ((size_t)bo * FW + ri) * C4);
       }
+      float best[4];
+      uint32_t am[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (q == 0 || v[e] > best[e]) { best[e] = v[e]; am[e] = q; }  // first max wins
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = s[q].valid ? bilerp(tl[q][e], tr[q][e], bl[q][e], br[q][e], s[q].xlerp, s[q].ylerp) : 0.f;
+          if (q == 0 || v > best[e]) { best[e] = v; am[e] = q; }  // first max wins
+        }
       }
+      reinterpret_cast<float4*>(out + obase)[c4] = make_float4(best[0], best[1], best[2], best[3]);
+      if (argmax)
+        reinterpret_cast<uint32_t*>(argmax + obase)[c4] = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
     }
-    reinterpret_cast<float4*>(out + obase)[c4] = make_float4(best[0], best[1], best[2], best[3]);
-    if (argmax)
-      reinterpret_cast<uint32_t*>(argmax + obase)[c4] = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
   }
 }
 
@@ -148,9 +170,9 @@ extern "C" int lmh_roi_pool_fwd(const float* feat, const float* rois, const int3
   LMH_CHECK_ARG(feat && rois && roi_count && out);
   LMH_CHECK_ARG(B > 0 && R > 0 && FH > 0 && FW > 0 && C > 0 && (C % 4) == 0 && ph > 0 && pw > 0);
   const int threads = (C / 4) < 256 ? ((C / 4 + 63) / 64 * 64) : 256;
-  hipLaunchKernelGGL(k_roi_pool_fwd, dim3(ph * pw, B * R), dim3(threads), 0, (hipStream_t)stream, feat,
-                     reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw,
-                     out, argmax);
+  hipLaunchKernelGGL(k_roi_pool_fwd, dim3(B * R * ph), dim3(threads), 0, (hipStream_t)stream, feat,
+                     reinterpret_cast<const float4*>(rois), roi_count, R, B * R, FH, FW, C, im_h, im_w,
+                     ph, pw, out, argmax);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

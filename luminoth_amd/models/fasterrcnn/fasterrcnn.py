@@ -301,14 +301,16 @@ class FasterRCNN(object):
             main.wait_stream(aux)
             for t in (f_rcnn.grad, rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']):
                 t.record_stream(main)
+            # loss scalars (tiny launches) go BEFORE the trunk backward so that nothing but the optimizer is left
+            # on the main stream once the weight-gradient stream drains
+            no_reg_loss = (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss'] +
+                           rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).detach()
+            regularization_loss = self.regularization_loss()
+            total_loss = no_reg_loss + regularization_loss
             feat.backward(f_rpn.grad + f_rcnn.grad)
         SideStream.join()
         rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})
         rpn_pred['num_proposals'] = prop['num_proposals']
-        no_reg_loss = (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss'] +
-                       rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).detach()
-        regularization_loss = self.regularization_loss()
-        total_loss = no_reg_loss + regularization_loss
         self._last_losses = dict(rpn_losses, total_loss=total_loss, no_reg_loss=no_reg_loss,
                                  regularization_loss=regularization_loss, **rcnn_losses)
         pred = {'rpn_prediction': rpn_pred, 'classification_prediction': cp, 'rpn_loss_dict': rpn_losses,
