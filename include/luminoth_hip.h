@@ -112,6 +112,12 @@ int lmh_maxpool_bwd(const float* x, const float* y, const float* dy, int N, int 
                     int ksize, int stride, int pad_top, int pad_left, int OH, int OW, float* dx,
                     lmh_stream_t stream);
 
+/* tf.image.resize_images(BILINEAR) as called by luminoth/utils/image.py:92-95 (resize_image) and :126-129
+ * (resize_image_fixed) — the first op of the `lumi predict` path (utils/predicting.py:43-47).  TF 1.x legacy
+ * sampling (align_corners=False, no half-pixel centres).  src is (H,W,C) uint8 or float32, dst (OH,OW,C) f32. */
+int lmh_resize_bilinear(const void* src, int src_is_u8, int H, int W, int C, float* dst, int OH,
+                        int OW, lmh_stream_t stream);
+
 /* ------------------------------------------------------------ proposals --
  * RPNProposal._build (models/fasterrcnn/rpn_proposal.py:41-197) for a batch:
  * softmax(2) (rpn.py:163) -> anchors generated on the fly with the int32

@@ -303,3 +303,49 @@ extern "C" int lmh_maxpool_bwd(const float* x, const float* y, const float* dy, 
   return LMH_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// tf.image.resize_images(method=BILINEAR) as luminoth calls it (utils/image.py:92-95,126-129): TF 1.x legacy
+// sampling — align_corners=False, no half-pixel centres: in = i * (in_size / out_size), lower = (int)in,
+// upper = min(lower + 1, in_size - 1), lerp = in - lower; value = top + (bottom - top) * y_lerp with
+// top/bottom lerped along x first.  Products and sums are rounded separately (no FMA contraction) so the
+// result is bit-identical to the numpy restatement in oracle/image.py.  One thread per output pixel; HBM-bound.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_resize_bilinear(const T* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int OH, int OW,
+                  float hscale, float wscale) {
+  const int64_t total = (int64_t)OH * OW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int oy = (int)(i / OW), ox = (int)(i - (int64_t)oy * OW);
+    const float in_y = __fmul_rn((float)oy, hscale), in_x = __fmul_rn((float)ox, wscale);
+    const int y0 = (int)in_y, x0 = (int)in_x;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float yl = __fsub_rn(in_y, (float)y0), xl = __fsub_rn(in_x, (float)x0);
+    const T* r0 = src + (size_t)y0 * W * C;
+    const T* r1 = src + (size_t)y1 * W * C;
+    float* o = dst + (size_t)i * C;
+    for (int c = 0; c < C; ++c) {
+      const float tl = (float)r0[(size_t)x0 * C + c], tr = (float)r0[(size_t)x1 * C + c];
+      const float bl = (float)r1[(size_t)x0 * C + c], br = (float)r1[(size_t)x1 * C + c];
+      const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), xl));
+      const float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), xl));
+      o[c] = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), yl));
+    }
+  }
+}
+
+extern "C" int lmh_resize_bilinear(const void* src, int src_is_u8, int H, int W, int C, float* dst, int OH,
+                                   int OW, lmh_stream_t stream) {
+  LMH_CHECK_ARG(src && dst && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0);
+  const float hscale = (float)H / (float)OH, wscale = (float)W / (float)OW;
+  const int64_t total = (int64_t)OH * OW;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (src_is_u8)
+    hipLaunchKernelGGL(k_resize_bilinear<uint8_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)src, H, W, C, dst, OH, OW, hscale, wscale);
+  else
+    hipLaunchKernelGGL(k_resize_bilinear<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)src, H, W, C, dst, OH, OW, hscale, wscale);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}

@@ -240,6 +240,19 @@ def maxpool_fwd(x, ksize, stride, padding='SAME'):
     return y, (pt, pl, OH, OW)
 
 
+def resize_bilinear(image, out_h, out_w):
+    """tf.image.resize_images(BILINEAR) (TF 1.x legacy sampling) of one (H,W,C) uint8/float32 image."""
+    lib = _lib.load()
+    assert image.dim() == 3 and image.is_cuda and image.dtype in (torch.uint8, torch.float32), \
+        (image.shape, image.dtype, image.device)
+    image = image.contiguous()
+    H, W, C = image.shape
+    out = torch.empty((int(out_h), int(out_w), C), dtype=torch.float32, device=image.device)
+    check(lib.lmh_resize_bilinear(_p(image), int(image.dtype == torch.uint8), H, W, C, _p(out), int(out_h),
+                                  int(out_w), _stream()), 'lmh_resize_bilinear')
+    return out
+
+
 def maxpool_bwd(x, y, dy, ksize, stride, geom):
     lib = _lib.load()
     N, H, W, C = x.shape

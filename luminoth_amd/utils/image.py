@@ -1,0 +1,71 @@
+"""Image resize of the `lumi predict` / dataset-preprocess path (reference: luminoth/utils/image.py:6-147).
+
+Host side computes the scale factor and output size with the reference's float32 arithmetic and int32
+truncation; the pixels are resampled on the device by `lmh_resize_bilinear` (TF 1.x legacy bilinear).  The
+augmentation functions of the reference module (flip, patch, distortion, expand: image.py:150-620) are CPU-side
+training augmentation and out of scope.
+"""
+import numpy as np
+import torch
+
+from luminoth_amd import kernels as K
+
+_F = np.float32
+
+
+def _device_image(image, device=None):
+    if not torch.is_tensor(image):
+        image = torch.from_numpy(np.ascontiguousarray(np.asarray(image)))
+    if image.dtype not in (torch.uint8, torch.float32):
+        image = image.to(torch.float32)
+    if not image.is_cuda:
+        if device is None:
+            if not torch.cuda.is_available():
+                from luminoth_amd import _lib
+                raise _lib.LuminothHipError('image resize needs a ROCm device (no CPU fallback on the product path)')
+            device = torch.device('cuda', torch.cuda.current_device())
+        image = image.to(device)
+    return image
+
+
+def adjust_bboxes(bboxes, old_height, old_width, new_height, new_width):
+    """image.py:6-35.  bboxes (G,5) [x_min, y_min, x_max, y_max, label] -> int32, truncated toward zero."""
+    b = np.asarray(bboxes).astype(_F)
+    out = np.empty(b.shape, np.int32)
+    for col, (old, new) in enumerate(((old_width, new_width), (old_height, new_height)) * 2):
+        out[:, col] = (b[:, col] / _F(old) * _F(new)).astype(np.int32)
+    out[:, 4] = b[:, 4].astype(np.int32)
+    return out
+
+
+def resize_plan(height, width, min_size=None, max_size=None):
+    """The float32 arithmetic of image.py:59-89: returns (scale_factor, new_height, new_width) as float32 — the
+    output size is the int32 truncation of the new sizes, the boxes are scaled by the untruncated ones."""
+    height, width = _F(height), _F(width)
+    up = max(_F(min_size) / min(height, width), _F(1.0)) if min_size is not None else _F(1.0)
+    down = min(_F(max_size) / max(height, width), _F(1.0)) if max_size is not None else _F(1.0)
+    scale = _F(up) * _F(down)
+    return scale, height * scale, width * scale
+
+
+def resize_image(image, bboxes=None, min_size=None, max_size=None, device=None):
+    """image.py:38-114: upscale so the short side reaches `min_size`, downscale so the long side fits
+    `max_size` (the product of both factors — an image may still end outside either bound)."""
+    image = _device_image(image, device)
+    height, width = image.shape[0], image.shape[1]
+    scale, new_h, new_w = resize_plan(height, width, min_size, max_size)
+    out = {'image': K.resize_bilinear(image, int(new_h), int(new_w)), 'scale_factor': float(scale)}
+    if bboxes is not None:
+        out['bboxes'] = adjust_bboxes(bboxes, height, width, new_h, new_w)
+    return out
+
+
+def resize_image_fixed(image, new_height, new_width, bboxes=None, device=None):
+    """image.py:117-147: scale_factor is (height factor, width factor)."""
+    image = _device_image(image, device)
+    height, width = _F(image.shape[0]), _F(image.shape[1])
+    out = {'image': K.resize_bilinear(image, int(new_height), int(new_width)),
+           'scale_factor': (float(_F(new_height) / height), float(_F(new_width) / width))}
+    if bboxes is not None:
+        out['bboxes'] = adjust_bboxes(bboxes, height, width, new_height, new_width)
+    return out
