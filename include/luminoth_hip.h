@@ -114,9 +114,11 @@ int lmh_maxpool_bwd(const float* x, const float* y, const float* dy, int N, int 
 
 /* tf.image.resize_images(BILINEAR) as called by luminoth/utils/image.py:92-95 (resize_image) and :126-129
  * (resize_image_fixed) — the first op of the `lumi predict` path (utils/predicting.py:43-47).  TF 1.x legacy
- * sampling (align_corners=False, no half-pixel centres).  src is (H,W,C) uint8 or float32, dst (OH,OW,C) f32. */
+ * sampling (align_corners=False, no half-pixel centres).  src is (H,W,C) uint8 or float32, dst (OH,OW,C) f32.
+ * flip_lr / flip_ud: resample tf.image.flip_left_right / flip_up_down of src (the flip augmentation,
+ * utils/image.py:318-370, runs before the resize: object_detection_dataset.py:77-78) without materialising it. */
 int lmh_resize_bilinear(const void* src, int src_is_u8, int H, int W, int C, float* dst, int OH,
-                        int OW, lmh_stream_t stream);
+                        int OW, int flip_lr, int flip_ud, lmh_stream_t stream);
 
 /* ------------------------------------------------------------ proposals --
  * RPNProposal._build (models/fasterrcnn/rpn_proposal.py:41-197) for a batch:

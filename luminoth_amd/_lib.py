@@ -86,7 +86,7 @@ SIGNATURES = {
     'lmh_bn_param_grads': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i, c_f, c_f, c_sz, c_f]),
     'lmh_maxpool_fwd': (c_i, [c_f] + [c_i] * 10 + [c_f, c_f]),
     'lmh_maxpool_bwd': (c_i, [c_f, c_f, c_f] + [c_i] * 10 + [c_f, c_f]),
-    'lmh_resize_bilinear': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_f]),
+    'lmh_resize_bilinear': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
     'lmh_rpn_proposal_workspace_bytes': (c_sz, [P(RpnProposalDesc)]),
     'lmh_rpn_proposal': (c_i, [P(RpnProposalDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_sort_u64': (c_i, [c_f, c_i, c_i, c_f]),

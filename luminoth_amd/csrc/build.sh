@@ -1,5 +1,6 @@
 #!/bin/bash
-# Builds libluminoth_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+# Builds libluminoth_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU) and libluminoth_io.so (host C:
+# TFRecord framing + CRC32C for the dataset reader).
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
@@ -7,7 +8,12 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-
 OBJS=""
 pids=""
 for f in api proposals detect targets roi loss optim elementwise ssd conv; do
-  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ lmh_common.h -nt "$f.o" ] || [ conv_common.h -nt "$f.o" ] || [ conv_generic.h -nt "$f.o" ] || [ ../../include/luminoth_hip.h -nt "$f.o" ]; then
+  stale=0
+  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ]; then stale=1; fi
+  for h in *.h ../../include/luminoth_hip.h; do
+    if [ "$h" -nt "$f.o" ]; then stale=1; fi
+  done
+  if [ $stale = 1 ]; then
     $HIPCC $FLAGS -c "$f.hip" -o "$f.o" &
     pids="$pids $!"
   fi
@@ -16,3 +22,7 @@ done
 for p in $pids; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o libluminoth_hip.so
 echo "built $(pwd)/libluminoth_hip.so"
+if [ ! -f libluminoth_io.so ] || [ hostio.c -nt libluminoth_io.so ] || [ ../../include/luminoth_io.h -nt libluminoth_io.so ]; then
+  ${CC:-gcc} -O2 -std=c11 -fPIC -shared -Wall -o libluminoth_io.so hostio.c
+fi
+echo "built $(pwd)/libluminoth_io.so"

@@ -313,14 +313,18 @@ extern "C" int lmh_maxpool_bwd(const float* x, const float* y, const float* dy, 
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_resize_bilinear(const T* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int OH, int OW,
-                  float hscale, float wscale) {
+                  float hscale, float wscale, int flip_lr, int flip_ud) {
   const int64_t total = (int64_t)OH * OW;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int oy = (int)(i / OW), ox = (int)(i - (int64_t)oy * OW);
     const float in_y = __fmul_rn((float)oy, hscale), in_x = __fmul_rn((float)ox, wscale);
-    const int y0 = (int)in_y, x0 = (int)in_x;
-    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    int y0 = (int)in_y, x0 = (int)in_x;
+    int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const float yl = __fsub_rn(in_y, (float)y0), xl = __fsub_rn(in_x, (float)x0);
+    // flip augmentation (utils/image.py:318-370) happens BEFORE the resize in the reference: sample the
+    // mirrored source instead of materialising the flipped image
+    if (flip_lr) { x0 = W - 1 - x0; x1 = W - 1 - x1; }
+    if (flip_ud) { y0 = H - 1 - y0; y1 = H - 1 - y1; }
     const T* r0 = src + (size_t)y0 * W * C;
     const T* r1 = src + (size_t)y1 * W * C;
     float* o = dst + (size_t)i * C;
@@ -335,17 +339,17 @@ k_resize_bilinear(const T* __restrict__ src, int H, int W, int C, float* __restr
 }
 
 extern "C" int lmh_resize_bilinear(const void* src, int src_is_u8, int H, int W, int C, float* dst, int OH,
-                                   int OW, lmh_stream_t stream) {
+                                   int OW, int flip_lr, int flip_ud, lmh_stream_t stream) {
   LMH_CHECK_ARG(src && dst && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0);
   const float hscale = (float)H / (float)OH, wscale = (float)W / (float)OW;
   const int64_t total = (int64_t)OH * OW;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (src_is_u8)
     hipLaunchKernelGGL(k_resize_bilinear<uint8_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t*)src, H, W, C, dst, OH, OW, hscale, wscale);
+                       (const uint8_t*)src, H, W, C, dst, OH, OW, hscale, wscale, flip_lr, flip_ud);
   else
     hipLaunchKernelGGL(k_resize_bilinear<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)src, H, W, C, dst, OH, OW, hscale, wscale);
+                       (const float*)src, H, W, C, dst, OH, OW, hscale, wscale, flip_lr, flip_ud);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

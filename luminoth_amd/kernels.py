@@ -240,8 +240,9 @@ def maxpool_fwd(x, ksize, stride, padding='SAME'):
     return y, (pt, pl, OH, OW)
 
 
-def resize_bilinear(image, out_h, out_w):
-    """tf.image.resize_images(BILINEAR) (TF 1.x legacy sampling) of one (H,W,C) uint8/float32 image."""
+def resize_bilinear(image, out_h, out_w, flip_lr=False, flip_ud=False):
+    """tf.image.resize_images(BILINEAR) (TF 1.x legacy sampling) of one (H,W,C) uint8/float32 image, optionally
+    of its left-right / up-down flip."""
     lib = _lib.load()
     assert image.dim() == 3 and image.is_cuda and image.dtype in (torch.uint8, torch.float32), \
         (image.shape, image.dtype, image.device)
@@ -249,7 +250,8 @@ def resize_bilinear(image, out_h, out_w):
     H, W, C = image.shape
     out = torch.empty((int(out_h), int(out_w), C), dtype=torch.float32, device=image.device)
     check(lib.lmh_resize_bilinear(_p(image), int(image.dtype == torch.uint8), H, W, C, _p(out), int(out_h),
-                                  int(out_w), _stream()), 'lmh_resize_bilinear')
+                                  int(out_w), int(bool(flip_lr)), int(bool(flip_ud)), _stream()),
+          'lmh_resize_bilinear')
     return out
 
 

@@ -48,24 +48,59 @@ def resize_plan(height, width, min_size=None, max_size=None):
     return scale, height * scale, width * scale
 
 
-def resize_image(image, bboxes=None, min_size=None, max_size=None, device=None):
+def resize_image(image, bboxes=None, min_size=None, max_size=None, device=None, flip_lr=False, flip_ud=False):
     """image.py:38-114: upscale so the short side reaches `min_size`, downscale so the long side fits
     `max_size` (the product of both factors — an image may still end outside either bound)."""
     image = _device_image(image, device)
     height, width = image.shape[0], image.shape[1]
     scale, new_h, new_w = resize_plan(height, width, min_size, max_size)
-    out = {'image': K.resize_bilinear(image, int(new_h), int(new_w)), 'scale_factor': float(scale)}
+    out = {'image': K.resize_bilinear(image, int(new_h), int(new_w), flip_lr, flip_ud), 'scale_factor': float(scale)}
     if bboxes is not None:
         out['bboxes'] = adjust_bboxes(bboxes, height, width, new_h, new_w)
     return out
 
 
-def resize_image_fixed(image, new_height, new_width, bboxes=None, device=None):
+def resize_image_fixed(image, new_height, new_width, bboxes=None, device=None, flip_lr=False, flip_ud=False):
     """image.py:117-147: scale_factor is (height factor, width factor)."""
     image = _device_image(image, device)
     height, width = _F(image.shape[0]), _F(image.shape[1])
-    out = {'image': K.resize_bilinear(image, int(new_height), int(new_width)),
+    out = {'image': K.resize_bilinear(image, int(new_height), int(new_width), flip_lr, flip_ud),
            'scale_factor': (float(_F(new_height) / height), float(_F(new_width) / width))}
     if bboxes is not None:
         out['bboxes'] = adjust_bboxes(bboxes, height, width, new_height, new_width)
+    return out
+
+
+def flip_bboxes(bboxes, height, width, left_right=True, up_down=False):
+    """The box half of image.py:318-370 (`flip_image`): int32 boxes, x' = width - x_max - 1 (same for y)."""
+    b = np.asarray(bboxes).astype(np.int32).copy()
+    if left_right:
+        new_x_min = np.int32(width) - b[:, 2] - 1
+        b[:, 2] = new_x_min + (b[:, 2] - b[:, 0])
+        b[:, 0] = new_x_min
+    if up_down:
+        new_y_min = np.int32(height) - b[:, 3] - 1
+        b[:, 3] = new_y_min + (b[:, 3] - b[:, 1])
+        b[:, 1] = new_y_min
+    return b
+
+
+def flip_image(image, bboxes=None, left_right=True, up_down=False):
+    """image.py:318-370 on a numpy array or a torch tensor (H,W,C) — materialised; the dataset iterator folds
+    the flip into the resize kernel instead."""
+    height, width = image.shape[0], image.shape[1]
+    if bboxes is not None:
+        bboxes = flip_bboxes(bboxes, height, width, left_right, up_down)
+    if torch.is_tensor(image):
+        dims = ([1] if left_right else []) + ([0] if up_down else [])
+        image = torch.flip(image, dims) if dims else image
+    else:
+        image = np.asarray(image)
+        if left_right:
+            image = image[:, ::-1]
+        if up_down:
+            image = image[::-1]
+    out = {'image': image}
+    if bboxes is not None:
+        out['bboxes'] = bboxes
     return out

@@ -83,3 +83,27 @@ def format_predictions(objects, labels, probs, scale_factor, class_labels=None):
     objs = [[int(round(c)) for c in o] for o in objects.tolist()]
     preds = [{'bbox': o, 'label': l, 'prob': round(float(p), 4)} for o, l, p in zip(objs, labels, probs)]
     return sorted(preds, key=lambda x: x['prob'], reverse=True)
+
+
+def flip_image(image, bboxes=None, left_right=True, up_down=False):
+    """luminoth/utils/image.py:318-370; pinned by image_test.py:278-353 (tests/test_tfrecord.py)."""
+    image = np.asarray(image)
+    height, width = image.shape[0], image.shape[1]
+    if bboxes is not None:
+        bboxes = np.asarray(bboxes).astype(np.int32)
+    if left_right:
+        image = image[:, ::-1]
+        if bboxes is not None:
+            x_min, y_min, x_max, y_max, label = bboxes.T
+            nx = width - x_max - 1
+            bboxes = np.stack([nx, y_min, nx + (x_max - x_min), y_max, label], 1)
+    if up_down:
+        image = image[::-1]
+        if bboxes is not None:
+            x_min, y_min, x_max, y_max, label = bboxes.T
+            ny = height - y_max - 1
+            bboxes = np.stack([x_min, ny, x_max, ny + (y_max - y_min), label], 1)
+    out = {'image': np.ascontiguousarray(image)}
+    if bboxes is not None:
+        out['bboxes'] = bboxes.astype(np.int32)
+    return out

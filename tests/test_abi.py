@@ -39,3 +39,20 @@ def test_product_path_refuses_cpu_tensors():
     from luminoth_amd import _lib, kernels
     with pytest.raises(_lib.LuminothHipError):
         kernels.softmax(torch.zeros(4, 3))
+
+
+def test_host_io_library_exports_every_declared_symbol():
+    """include/luminoth_io.h <-> libluminoth_io.so (host C: TFRecord framing + CRC-32C)."""
+    from luminoth_amd import _lib
+    from luminoth_amd.datasets import tfrecord
+    src = open(os.path.join(ROOT, 'include', 'luminoth_io.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    syms = sorted(set(re.findall(r'\b(lmh_io_[a-z0-9_]+)\s*\(', src)))
+    assert len(syms) == 6, syms
+    io_path = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libluminoth_io.so')
+    if not os.path.exists(io_path):
+        _lib.build()
+    lib = ctypes.CDLL(io_path)
+    for s in syms:
+        assert hasattr(lib, s), 'libluminoth_io.so lacks %s' % s
+    assert tfrecord.crc32c(b'123456789') == 0xE3069283
