@@ -74,6 +74,24 @@ def bbox_overlap(b1, b2):
     return iou.astype(F)
 
 
+def bbox_overlap_np(b1, b2):
+    """luminoth/utils/bbox_overlap.py:51-94 — the numpy twin `lumi eval` uses (eval.py:577).  No dtype is forced:
+    float32 detections against int32 ground truth promote to float64 where they meet, while each set's own area
+    stays in its input dtype, exactly as numpy evaluates the reference expression."""
+    b1, b2 = np.asarray(b1), np.asarray(b2)
+    ix1 = np.maximum(b1[:, 0:1], b2[:, 0:1].T)
+    iy1 = np.maximum(b1[:, 1:2], b2[:, 1:2].T)
+    ix2 = np.minimum(b1[:, 2:3], b2[:, 2:3].T)
+    iy2 = np.minimum(b1[:, 3:4], b2[:, 3:4].T)
+    inter = np.maximum(ix2 - ix1 + 1, 0.) * np.maximum(iy2 - iy1 + 1, 0.)
+    area1 = (b1[:, 2:3] - b1[:, 0:1] + 1) * (b1[:, 3:4] - b1[:, 1:2] + 1)
+    area2 = (b2[:, 2:3] - b2[:, 0:1] + 1) * (b2[:, 3:4] - b2[:, 1:2] + 1)
+    union = (area1 + area2.T) - inter
+    iou = np.zeros((b1.shape[0], b2.shape[0]))
+    np.divide(inter, union, out=iou, where=inter > 0.)
+    return iou
+
+
 def get_width_upright(b):
     """luminoth/utils/bbox_transform_tf.py:4-15."""
     b = np.asarray(b).astype(F)
