@@ -20,6 +20,12 @@ FUSE_MASK = os.environ.get('LUMINOTH_AMD_FUSE_MASK', '0') == '1'
 BN_EPS = 1e-5  # slim resnet_arg_scope batch_norm_epsilon (truncated_base_network.py:69-73)
 
 
+# Called by Trunk.backward as hook(nodes, j) once node j's backward (data + weight gradients) is enqueued, and as
+# hook(nodes, len(nodes)) before the first node: lets the data-parallel layer start all-reducing finished gradient
+# ranges under the rest of the backward pass.
+BACKWARD_HOOK = None
+
+
 class SideStream(object):
     """Second HIP stream for the weight-gradient chain of every layer (bwd_weight -> split-K reduce ->
     BN parameter gradients).  It is independent of the data-gradient chain once g = dy*act'(y) exists,
@@ -367,10 +373,15 @@ class Trunk(object):
     def backward(self, saved, dy, save_from, need_dx_first=False):
         nodes = self.nodes[save_from:]
         dy_is_g = False
+        hook = BACKWARD_HOOK        # data-parallel gradient buckets (utils/training.py); None on one GPU
+        if hook is not None:
+            hook(nodes, len(nodes))
         for j in range(len(nodes) - 1, -1, -1):
             need_dx = (j > 0) or need_dx_first
             # node j-1's output activation is folded into node j's data gradient (fused epilogue mask)
             below = nodes[j - 1].out_act if (j > 0 and FUSE_MASK) else None
             dy = nodes[j].backward(saved[j], dy, need_dx, dy_is_g=dy_is_g, mask_input=below)
             dy_is_g = below is not None
+            if hook is not None:
+                hook(nodes, j)
         return dy

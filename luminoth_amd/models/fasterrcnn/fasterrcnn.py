@@ -307,7 +307,15 @@ class FasterRCNN(object):
                            rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).detach()
             regularization_loss = self.regularization_loss()
             total_loss = no_reg_loss + regularization_loss
+            # data parallel: head gradients (RPN on main/side, RCNN joined from aux) are complete here, so the
+            # gradient buckets may start all-reducing under the trunk backward (utils/training.py)
+            from luminoth_amd.utils import training as _tr
+            buckets = _tr.ACTIVE_BUCKETS
+            if buckets is not None and buckets.store is self.store:
+                buckets.arm(self.base_network.trunk)
             feat.backward(f_rpn.grad + f_rcnn.grad)
+            if buckets is not None:
+                buckets.disarm()
         SideStream.join()
         rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})
         rpn_pred['num_proposals'] = prop['num_proposals']

@@ -43,6 +43,152 @@ def get_learning_rate(train_config, global_step=0):
     return base * float(lr_config['decay_rate']) ** p
 
 
+class _Done(object):
+    def wait(self):
+        return True
+
+
+class GradientBuckets(object):
+    """Overlap of the data-parallel gradient exchange with the trunk backward.
+
+    The flat gradient buffer is laid out in registration order (trunk conv weights block by block, the BatchNorm
+    gamma/beta block, then RPN and RCNN) while the backward pass finishes it from the back: RPN / RCNN first,
+    then the trunk nodes last to first.  Instead of ONE all-reduce after the whole backward, finished contiguous
+    ranges are all-reduced (RCCL, async) on a communication stream while the earlier nodes are still running:
+
+      * `[end of trunk parameters, end)` — the heads — when the trunk backward starts,
+      * runs of trunk nodes of >= `bucket_bytes` of conv weights as soon as their last node is enqueued,
+      * whatever is left (first nodes, BatchNorm block) in `finish()`, right before the update.
+
+    The model arms it around the one backward call whose preconditions hold (`FasterRCNN.train_step`: every head
+    gradient is complete and joined before the trunk backward); everything else falls through to `finish()`,
+    which then is the single all-reduce of the whole buffer.  Every element is reduced exactly once per step
+    (tested on one GPU with a stand-in reduce that doubles the range: tests/test_gpu_model.py)."""
+
+    def __init__(self, store, reduce_fn=None, bucket_bytes=None):
+        self.store = store
+        self.reduce_fn = reduce_fn or self._all_reduce
+        if bucket_bytes is None:
+            bucket_bytes = int(os.environ.get('LUMINOTH_AMD_BUCKET_MB', '12')) << 20
+        self.bucket_bytes = int(bucket_bytes)
+        self._armed = None
+        self._plans = {}
+        self._works = []
+        self._done = []          # [lo, hi) ranges already handed to reduce_fn this step
+        self._comm = None
+
+    @staticmethod
+    def _all_reduce(t):
+        return dist.all_reduce(t, async_op=True)
+
+    # ---- planning (host, once per trunk) -------------------------------------------------
+    def _plan(self, nodes):
+        key = tuple(id(n) for n in nodes)
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        off = self.store.offsets
+        numel = int(self.store.grad.numel())
+        ranges, trunk_hi = [], 0
+        for n in nodes:
+            lo, hi = None, None
+            for l in n.layers:
+                for name in l.var_names():
+                    t, o, cnt = off.get(name, (False, 0, 0))
+                    if not t:
+                        continue
+                    trunk_hi = max(trunk_hi, o + cnt)
+                    if name == l.w_name:
+                        lo = o if lo is None else min(lo, o)
+                        hi = o + cnt if hi is None else max(hi, o + cnt)
+            ranges.append((lo, hi))
+        plan = {}
+        ok = True
+        prev_lo = None
+        for lo, hi in reversed([r for r in ranges if r[0] is not None]):
+            if prev_lo is not None and hi > prev_lo:
+                ok = False               # not laid out node after node: no early buckets, finish() does it all
+            prev_lo = lo
+        if ok:
+            heads_lo = (trunk_hi + 3) // 4 * 4
+            if heads_lo < numel:
+                plan[len(nodes)] = (heads_lo, numel)
+            cur_hi = None
+            for j in range(len(nodes) - 1, -1, -1):
+                lo, hi = ranges[j]
+                if lo is None:
+                    continue
+                if cur_hi is None:
+                    cur_hi = hi
+                if (cur_hi - lo) * 4 >= self.bucket_bytes:
+                    plan[j] = (lo, cur_hi)
+                    cur_hi = None
+        self._plans[key] = plan
+        return plan
+
+    # ---- per step ----------------------------------------------------------------------------
+    def arm(self, trunk):
+        """Early buckets are allowed for the next backward of `trunk` (or of a suffix of its nodes)."""
+        self._armed = trunk.nodes[-1]
+
+    def disarm(self):
+        self._armed = None
+
+    def on_node(self, nodes, j):
+        if self._armed is None or nodes[-1] is not self._armed:
+            return
+        rng = self._plan(nodes).get(j)
+        if rng is not None:
+            self._launch(*rng)
+
+    def _launch(self, lo, hi):
+        from luminoth_amd.models.base.layers import SideStream
+        grad = self.store.grad
+        cur = torch.cuda.current_stream(grad.device)
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=grad.device)
+        comm = self._comm
+        comm.wait_stream(cur)                         # data-gradient stream up to this node
+        for st in SideStream._streams.values():       # every weight-gradient chain enqueued so far
+            comm.wait_stream(st)
+        with torch.cuda.stream(comm):
+            self._works.append(self.reduce_fn(grad[lo:hi]) or _Done())
+        self._done.append((lo, hi))
+
+    def finish(self):
+        """Called on the update stream after the backward (side streams joined): waits for the early buckets and
+        reduces every range they did not cover."""
+        grad = self.store.grad
+        numel = int(grad.numel())
+        todo, pos = [], 0
+        for lo, hi in sorted(self._done):
+            if lo > pos:
+                todo.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < numel:
+            todo.append((pos, numel))
+        for w in self._works:
+            w.wait()
+        if self._comm is not None and self._works:
+            torch.cuda.current_stream(grad.device).wait_stream(self._comm)
+        for lo, hi in todo:
+            w = self.reduce_fn(grad[lo:hi]) or _Done()
+            w.wait()
+        self._works, self._done = [], []
+        self._armed = None
+
+
+ACTIVE_BUCKETS = None          # the GradientBuckets of the optimizer in use (None: single GPU)
+
+
+def install_buckets(buckets):
+    """Routes Trunk.backward's node hook to `buckets` (None uninstalls)."""
+    global ACTIVE_BUCKETS
+    from luminoth_amd.models.base import layers as L
+    ACTIVE_BUCKETS = buckets
+    L.BACKWARD_HOOK = buckets.on_node if buckets is not None else None
+
+
 class MomentumOptimizer(object):
     """tf.train.MomentumOptimizer (non-Nesterov): v = m*v + g ; w -= lr*v, with
     g = grad/world + wd*w (the L2 regulariser of total_loss)."""
@@ -51,11 +197,22 @@ class MomentumOptimizer(object):
         self.model, self.store, self.cfg = model, model.store, train_config
         self.momentum = float(momentum)
         self.global_step = 0
+        self.buckets = None
+        if dist.is_available() and dist.is_initialized() and \
+                (dist.get_world_size() > 1 or os.environ.get('LUMINOTH_AMD_FORCE_BUCKETS') == '1'):
+            if os.environ.get('LUMINOTH_AMD_BUCKETED_ALLREDUCE', '1') != '0' and self.store.grad.is_cuda:
+                self.buckets = GradientBuckets(self.store)
+                install_buckets(self.buckets)
 
     def reduce_gradients(self):
-        """Sum the flat gradient buffer over the data-parallel replicas (one collective);
-        returns the factor that turns the sum into the mean (applied inside the update kernel)."""
+        """Sum the flat gradient buffer over the data-parallel replicas; returns the factor that turns the sum
+        into the mean (applied inside the update kernel).  With buckets installed most of the buffer was already
+        all-reduced under the trunk backward and only the remainder is exchanged here; otherwise this is ONE
+        collective over the whole flat buffer."""
         st = self.store
+        if self.buckets is not None:
+            self.buckets.finish()
+            return 1.0 / dist.get_world_size()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(st.grad)                 # ONE bucket: the flat gradient buffer
             return 1.0 / dist.get_world_size()

@@ -3,6 +3,8 @@ module API) vs the CPU oracle on identical seeded inputs and identical weights.
 Continuous quantities within the north_star tolerance (1e-4 fp32 for box
 coords and losses); discrete ones (labels, keep sets) bit-exact on identical
 inputs.  Run with `-m gpu`."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -230,3 +232,81 @@ def test_fused_two_stream_step_equals_plain_step(setup):
     assert torch.equal(ca['proposals'], cb['proposals'])
     scale = float(g_plain.abs().max())
     np.testing.assert_allclose(g_fused.cpu().numpy(), g_plain.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_gradient_buckets_reduce_every_element_exactly_once(setup):
+    """Data-parallel overlap (utils/training.py GradientBuckets) on one GPU: a stand-in reduce that doubles its
+    range, issued with the production stream protocol, must leave grad == 2 x the plain step's gradient — every
+    element handed over exactly once and never before the kernels that write it have finished."""
+    from luminoth_amd.utils import training as T
+    cfg, model, images, gts = setup
+    model._step = 0
+    model.train_step(images, gts)
+    torch.cuda.synchronize()
+    ref = model.store.grad.clone()
+    calls = []
+
+    def doubling(t):
+        calls.append(int(t.numel()))
+        t.mul_(2.0)
+
+    buckets = T.GradientBuckets(model.store, reduce_fn=doubling, bucket_bytes=4 << 20)
+    T.install_buckets(buckets)
+    try:
+        for rep in range(3):                       # repeated: plans are cached, per-step state is reset
+            model._step = 0
+            del calls[:]
+            model.train_step(images, gts)
+            early = len(calls)
+            buckets.finish()
+            torch.cuda.synchronize()
+            assert early >= 3 and len(calls) > early, (early, len(calls))     # heads + trunk runs, then the rest
+            assert sum(calls) == model.store.grad.numel()
+            got = model.store.grad
+            scale = float(ref.abs().max())
+            np.testing.assert_allclose(got.cpu().numpy(), 2.0 * ref.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+        # a path that never arms the buckets (plain call sequence): finish() is the single whole-buffer reduce
+        model._step = 0
+        del calls[:]
+        pred = model(images, gts, is_training=True)
+        model.backward(model.loss(pred))
+        buckets.finish()
+        torch.cuda.synchronize()
+        assert calls == [model.store.grad.numel()]
+        np.testing.assert_allclose(model.store.grad.cpu().numpy(), 2.0 * ref.cpu().numpy(), rtol=1e-4,
+                                   atol=2e-5 * float(ref.abs().max()))
+    finally:
+        T.install_buckets(None)
+
+
+def test_rccl_single_rank_bucketed_step(setup, tmp_path):
+    """The real RCCL path on one rank (world_size 1, forced): process group init, async all_reduce of the buckets
+    from the autograd thread on the communication stream, finish() + fused update — identical weights to the
+    un-bucketed optimizer step."""
+    import torch.distributed as dist
+    from luminoth_amd.utils import training as T
+    cfg, model, images, gts = setup
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = T.get_optimizer(cfg.train, model)
+    assert opt.buckets is None
+    model._step = 0
+    T.train_step(model, opt, images, gts)
+    torch.cuda.synchronize()
+    want = model.store.flat.clone()
+    model.load_state_dict(sd0)
+    model.store.mom.zero_()
+    os.environ['LUMINOTH_AMD_FORCE_BUCKETS'] = '1'
+    dist.init_process_group('nccl', init_method='file://%s' % (tmp_path / 'rdzv'), world_size=1, rank=0)
+    try:
+        opt2 = T.get_optimizer(cfg.train, model)
+        assert opt2.buckets is not None and T.ACTIVE_BUCKETS is opt2.buckets
+        model._step = 0
+        T.train_step(model, opt2, images, gts)
+        torch.cuda.synchronize()
+        scale = float(want.abs().max())
+        np.testing.assert_allclose(model.store.flat.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-7 * scale)
+    finally:
+        T.install_buckets(None)
+        os.environ.pop('LUMINOTH_AMD_FORCE_BUCKETS', None)
+        dist.destroy_process_group()
+        model.load_state_dict(sd0)
