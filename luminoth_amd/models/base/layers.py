@@ -32,11 +32,20 @@ class SideStream(object):
     so running it beside bwd_data fills the CUs each kernel leaves idle in its prologue / tail.
     `join()` makes the caller's stream wait for everything enqueued here (before all-reduce / update)."""
     enabled = os.environ.get('LUMINOTH_AMD_SIDE_STREAM', '1') != '0'
-    _streams = {}      # one side stream per issuing stream (the fused train step issues from two)
+    # Side streams per issuing stream, used round-robin layer by layer.  ONE by default: two were meant to run a
+    # layer's short tail (split-K reduce, BN dot, BN finish) under the next layer's bwd_weight, but three
+    # MFMA-heavy kernels in flight (bwd_data + two bwd_weight) thrash each other: 10.45 -> 13.8 ms/step on
+    # MI355X (15.1 ms with GPU_MAX_HW_QUEUES=8, so it is contention, not hardware-queue aliasing).
+    fanout = max(1, int(os.environ.get('LUMINOTH_AMD_SIDE_STREAMS', '1')))
+    _streams = {}      # (device, issuing stream, slot) -> stream (the fused train step issues from two streams)
+    _next = {}
 
     @classmethod
     def get(cls, device):
-        key = (device, K._stream_id(device))
+        issuer = (device, K._stream_id(device))
+        slot = cls._next.get(issuer, 0)
+        cls._next[issuer] = (slot + 1) % cls.fanout
+        key = issuer + (slot,)
         st = cls._streams.get(key)
         if st is None:
             st = torch.cuda.Stream(device=device)
