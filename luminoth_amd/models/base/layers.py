@@ -37,6 +37,13 @@ class SideStream(object):
     # MFMA-heavy kernels in flight (bwd_data + two bwd_weight) thrash each other: 10.45 -> 13.8 ms/step on
     # MI355X (15.1 ms with GPU_MAX_HW_QUEUES=8, so it is contention, not hardware-queue aliasing).
     fanout = max(1, int(os.environ.get('LUMINOTH_AMD_SIDE_STREAMS', '1')))
+    # The side stream lags the data-gradient stream, so when the main stream finishes the trunk backward it
+    # idles while the side stream drains its backlog.  The weight gradients of the LAST `inline_tail` trunk nodes
+    # of the backward are therefore issued on the main stream itself (behind that layer's data gradient).
+    inline_tail = int(os.environ.get('LUMINOTH_AMD_INLINE_TAIL', '0'))        # whole nodes
+    inline_layers = int(os.environ.get('LUMINOTH_AMD_INLINE_LAYERS', '4'))    # or single conv layers
+    force_inline = False
+    layers_left = 0
     _streams = {}      # (device, issuing stream, slot) -> stream (the fused train step issues from two streams)
     _next = {}
 
@@ -152,9 +159,17 @@ class ConvLayer(object):
             g, yact = dy, y                               # fused: kernels mask on load
         else:
             g = K.act_bwd(dy, y, self.act, want_g=True, colsum=None if colsum_in_wgrad else colsum)
+        inline = SideStream.force_inline or (self.trainable and 0 < SideStream.layers_left <= SideStream.inline_layers)
+        if self.trainable:
+            SideStream.layers_left -= 1
+        dx = None
+        if inline and need_dx:        # tail of the backward: data gradient first, weight gradients behind it
+            dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
+                                   addend=addend, yact=yact, xmask=x if mask_input else None,
+                                   xmask_act=mask_input)
         if self.trainable:
             cs = colsum if colsum_in_wgrad else None
-            if SideStream.enabled:
+            if SideStream.enabled and not inline:
                 main = torch.cuda.current_stream(x.device)
                 side = SideStream.get(x.device)
                 side.wait_stream(main)                  # dy / g are ready once `main` gets here
@@ -165,8 +180,7 @@ class ConvLayer(object):
                         t.record_stream(side)
             else:
                 self._weight_grads(d, x, g, yact, cs)
-        dx = None
-        if need_dx:
+        if need_dx and not inline:
             dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
                                    addend=addend, yact=yact, xmask=x if mask_input else None,
                                    xmask_act=mask_input)
@@ -385,12 +399,16 @@ class Trunk(object):
         hook = BACKWARD_HOOK        # data-parallel gradient buckets (utils/training.py); None on one GPU
         if hook is not None:
             hook(nodes, len(nodes))
+        SideStream.layers_left = sum(1 for n in nodes for l in n.layers if l.trainable)
         for j in range(len(nodes) - 1, -1, -1):
             need_dx = (j > 0) or need_dx_first
+            SideStream.force_inline = j < SideStream.inline_tail
             # node j-1's output activation is folded into node j's data gradient (fused epilogue mask)
             below = nodes[j - 1].out_act if (j > 0 and FUSE_MASK) else None
             dy = nodes[j].backward(saved[j], dy, need_dx, dy_is_g=dy_is_g, mask_input=below)
             dy_is_g = below is not None
             if hook is not None:
                 hook(nodes, j)
+        SideStream.force_inline = False
+        SideStream.layers_left = 0
         return dy

@@ -290,7 +290,10 @@ class FasterRCNN(object):
                 rpn.targets(rpn_tgt, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape)
             rpn_pred.update(rpn_tgt)
             rpn_losses = rpn.loss(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
+            rpn_inline = os.environ.get('LUMINOTH_AMD_RPN_INLINE', '0') == '1'
+            SideStream.force_inline = rpn_inline
             (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss']).backward()
+            SideStream.force_inline = False
             # ---- aux stream: RCNN forward -> RCNN loss -> RCNN backward
             with torch.cuda.stream(aux):
                 cp = self._rcnn(f_rcnn, prop['proposals'], prop['num_proposals'], im_shape, self.base_network,
