@@ -42,8 +42,7 @@ __device__ void block_sum4(float v[4], float* sh /* 4 * LOSS_THREADS/64 */) {
 __global__ void __launch_bounds__(LOSS_THREADS)
 k_rpn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_pred,
            const float* __restrict__ labels, const float* __restrict__ bbox_targets, int B, int N,
-           float sigma2, float w_cls, float w_reg, float* __restrict__ per_image,
-           float* __restrict__ d_cls, float* __restrict__ d_bbox) {
+           float sigma2, float* __restrict__ per_image) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ float sh[72];
   const int b = blockIdx.x;
@@ -52,21 +51,32 @@ k_rpn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_p
   const float4* bt = reinterpret_cast<const float4*>(bbox_targets) + (size_t)b * N;
   const float* lab = labels + (size_t)b * N;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};  // ce_sum, n_cls, reg_sum, n_pos
-  for (int n = threadIdx.x; n < N; n += blockDim.x) {
-    const float l = lab[n];
-    if (l != -1.f) {
-      const float2 s = cs[n];
-      const float m = fmaxf(s.x, s.y);
-      const float lse = logf(expf(s.x - m) + expf(s.y - m));
-      const float z = ((l == 1.f) ? s.y : s.x) - m;
-      acc[0] += lse - z;
-      acc[1] += 1.f;
+  // four label loads in flight per thread (all but ~256 of the 49 152 labels are -1: the loop is load latency)
+  for (int n0 = threadIdx.x; n0 < N; n0 += 4 * blockDim.x) {
+    float l4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + u * blockDim.x;
+      l4[u] = n < N ? lab[n] : -1.f;
     }
-    if (l == 1.f) {
-      const float4 p = bp[n], t = bt[n];
-      acc[2] += ((sl1_val(p.x - t.x, sigma2) + sl1_val(p.y - t.y, sigma2)) + sl1_val(p.z - t.z, sigma2)) +
-                sl1_val(p.w - t.w, sigma2);
-      acc[3] += 1.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + u * blockDim.x;
+      const float l = l4[u];
+      if (l != -1.f) {
+        const float2 s = cs[n];
+        const float m = fmaxf(s.x, s.y);
+        const float lse = logf(expf(s.x - m) + expf(s.y - m));
+        const float z = ((l == 1.f) ? s.y : s.x) - m;
+        acc[0] += lse - z;
+        acc[1] += 1.f;
+      }
+      if (l == 1.f) {
+        const float4 p = bp[n], t = bt[n];
+        acc[2] += ((sl1_val(p.x - t.x, sigma2) + sl1_val(p.y - t.y, sigma2)) + sl1_val(p.z - t.z, sigma2)) +
+                  sl1_val(p.w - t.w, sigma2);
+        acc[3] += 1.f;
+      }
     }
   }
   block_sum4(acc, sh);
@@ -76,34 +86,45 @@ k_rpn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_p
     per_image[b * 4 + 2] = acc[1];
     per_image[b * 4 + 3] = acc[3];
   }
-  if (!d_cls && !d_bbox) return;
-  const float gc = w_cls / (acc[1] * (float)B);
-  const float gr = w_reg / (acc[3] * (float)B);
-  float2* dc = reinterpret_cast<float2*>(d_cls) + (size_t)b * N;
-  float4* db = reinterpret_cast<float4*>(d_bbox) + (size_t)b * N;
-  for (int n = threadIdx.x; n < N; n += blockDim.x) {
-    const float l = lab[n];
-    float2 g = make_float2(0.f, 0.f);
-    float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (l != -1.f) {
-      const float2 s = cs[n];
-      const float m = fmaxf(s.x, s.y);
-      const float e0 = expf(s.x - m), e1 = expf(s.y - m);
-      const float den = e0 + e1;
-      const float p0 = e0 / den, p1 = e1 / den;
-      g.x = (p0 - ((l == 1.f) ? 0.f : 1.f)) * gc;
-      g.y = (p1 - ((l == 1.f) ? 1.f : 0.f)) * gc;
-    }
-    if (l == 1.f) {
-      const float4 p = bp[n], t = bt[n];
-      gb.x = sl1_grad(p.x - t.x, sigma2) * gr;
-      gb.y = sl1_grad(p.y - t.y, sigma2) * gr;
-      gb.z = sl1_grad(p.z - t.z, sigma2) * gr;
-      gb.w = sl1_grad(p.w - t.w, sigma2) * gr;
-    }
-    if (d_cls) dc[n] = g;
-    if (d_bbox) db[n] = gb;
+}
+
+// Gradient pass of the RPN loss, one thread per anchor over the whole grid (the sums above are a one-block-per-image
+// reduction; writing the 2+4 floats of all 49 152 anchors from that same block kept the step's critical path
+// waiting ~50 us on a single CU).  Same arithmetic as before: gc / gr from the per-image counts.
+__global__ void __launch_bounds__(256)
+k_rpn_loss_grad(const float* __restrict__ cls_score, const float* __restrict__ bbox_pred,
+                const float* __restrict__ labels, const float* __restrict__ bbox_targets, int B, int N,
+                float sigma2, float w_cls, float w_reg, const float* __restrict__ per_image,
+                float* __restrict__ d_cls, float* __restrict__ d_bbox) {
+  __builtin_amdgcn_s_setprio(3);
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float gc = w_cls / (per_image[b * 4 + 2] * (float)B);
+  const float gr = w_reg / (per_image[b * 4 + 3] * (float)B);
+  const size_t row = (size_t)b * N + n;
+  const float l = labels[row];
+  float2 g = make_float2(0.f, 0.f);
+  float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (l != -1.f) {
+    const float2 s = reinterpret_cast<const float2*>(cls_score)[row];
+    const float m = fmaxf(s.x, s.y);
+    const float e0 = expf(s.x - m), e1 = expf(s.y - m);
+    const float den = e0 + e1;
+    const float p0 = e0 / den, p1 = e1 / den;
+    g.x = (p0 - ((l == 1.f) ? 0.f : 1.f)) * gc;
+    g.y = (p1 - ((l == 1.f) ? 1.f : 0.f)) * gc;
   }
+  if (l == 1.f) {
+    const float4 p = reinterpret_cast<const float4*>(bbox_pred)[row];
+    const float4 t = reinterpret_cast<const float4*>(bbox_targets)[row];
+    gb.x = sl1_grad(p.x - t.x, sigma2) * gr;
+    gb.y = sl1_grad(p.y - t.y, sigma2) * gr;
+    gb.z = sl1_grad(p.z - t.z, sigma2) * gr;
+    gb.w = sl1_grad(p.w - t.w, sigma2) * gr;
+  }
+  if (d_cls) reinterpret_cast<float2*>(d_cls)[row] = g;
+  if (d_bbox) reinterpret_cast<float4*>(d_bbox)[row] = gb;
 }
 
 // losses[q] = mean_b per_image[b*4 + q], q in {0,1}
@@ -124,7 +145,10 @@ extern "C" int lmh_rpn_loss(const float* cls_score, const float* bbox_pred, cons
   LMH_CHECK_ARG(B > 0 && N > 0);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_rpn_loss, dim3(B), dim3(LOSS_THREADS), 0, st, cls_score, bbox_pred, labels,
-                     bbox_targets, B, N, sigma * sigma, w_cls, w_reg, per_image, d_cls_score, d_bbox_pred);
+                     bbox_targets, B, N, sigma * sigma, per_image);
+  if (d_cls_score || d_bbox_pred)
+    hipLaunchKernelGGL(k_rpn_loss_grad, dim3((N + 255) / 256, B), dim3(256), 0, st, cls_score, bbox_pred, labels,
+                       bbox_targets, B, N, sigma * sigma, w_cls, w_reg, per_image, d_cls_score, d_bbox_pred);
   hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, w_cls, w_reg, losses);
   LMH_CHECK_LAUNCH();
   return LMH_OK;

@@ -232,6 +232,7 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
   __shared__ __attribute__((aligned(16))) unsigned long long removed[NMS_MAX_W];
   __shared__ __attribute__((aligned(16))) unsigned long long s_kept;
   __shared__ int s_total;
+  __shared__ int s_rows[64];
   const int b = blockIdx.x;
   const int cnt = counts[b];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -242,10 +243,18 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
   if (tid == 0) s_total = 0;
   __syncthreads();
   const int nchunks = (cnt + 63) / 64;
+  // The loop is a chain of dependent global-load latencies (the mask lives in HBM / MALL: 18 MB per image), so
+  // (1) the diagonal word of chunk c+1 is fetched while chunk c is being resolved and (2) the words of the kept
+  // rows are fetched four at a time per thread over a flat (row, word) index instead of row after row.
+  uint64_t diag_next = 0ull;
+  if (wave == 0 && nchunks > 0) diag_next = (lane < cnt) ? mb[(size_t)lane * W] : 0ull;
   for (int c = 0; c < nchunks; ++c) {
     if (wave == 0) {
-      const int r = c * 64 + lane;
-      const uint64_t diag = (r < cnt) ? mb[(size_t)r * W + c] : 0ull;
+      const uint64_t diag = diag_next;
+      {
+        const int rn = (c + 1) * 64 + lane;
+        diag_next = (c + 1 < nchunks && rn < cnt) ? mb[(size_t)rn * W + c + 1] : 0ull;
+      }
       const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
       const int nin = min(64, cnt - c * 64);
       uint64_t alive = ~removed[c];
@@ -262,10 +271,11 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
         alive &= ~dj;
         alive &= ~(1ull << j);
       }
-      // write kept indices in order
+      // write kept indices in order (global list + this chunk's row list for the OR phase)
       if ((kept >> lane) & 1ull) {
-        const int pos = s_total + __popcll(kept & ((1ull << lane) - 1ull));
-        kidx[pos] = c * 64 + lane;
+        const int local = __popcll(kept & ((1ull << lane) - 1ull));
+        kidx[s_total + local] = c * 64 + lane;
+        s_rows[local] = lane;
       }
       if (lane == 0) { s_kept = kept; s_total = total; }
     }
@@ -273,18 +283,27 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
     const uint64_t kept = s_kept;
     const bool done = (s_total >= max_out);
     if (done) break;
-    // OR rows of kept candidates into removed[c+1 .. W)
+    // OR the kept rows into removed[c+1 .. nchunks): flat index over (row, word), four loads in flight per thread
     const int nk = __popcll(kept);
-    for (int q = wave; q < nk; q += NMS_RED_THREADS / 64) {
-      // q-th set bit of kept
-      uint64_t kk = kept;
-      for (int s = 0; s < q; ++s) kk &= kk - 1;
-      const int j = __builtin_ctzll(kk);
-      const uint64_t* row = mb + (size_t)(c * 64 + j) * W;
-      for (int w = c + 1 + lane; w < nchunks; w += 64) {  // words >= nchunks are never written
-        const uint64_t v = row[w];
-        if (v) atomicOr(&removed[w], (unsigned long long)v);
+    const int nw = nchunks - c - 1;                 // words >= nchunks are never read
+    const int items = nk * nw;
+    for (int i0 = tid; i0 < items; i0 += 4 * NMS_RED_THREADS) {
+      uint64_t v[4];
+      int wi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NMS_RED_THREADS;
+        v[u] = 0ull;
+        wi[u] = 0;
+        if (i < items) {
+          const int q = i / nw;
+          wi[u] = c + 1 + (i - q * nw);
+          v[u] = mb[(size_t)(c * 64 + s_rows[q]) * W + wi[u]];
+        }
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (v[u]) atomicOr(&removed[wi[u]], (unsigned long long)v[u]);
     }
     __syncthreads();
   }

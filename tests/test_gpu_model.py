@@ -290,6 +290,7 @@ def test_rccl_single_rank_bucketed_step(setup, tmp_path):
     opt = T.get_optimizer(cfg.train, model)
     assert opt.buckets is None
     model._step = 0
+    model.store.mom.zero_()
     T.train_step(model, opt, images, gts)
     torch.cuda.synchronize()
     want = model.store.flat.clone()
