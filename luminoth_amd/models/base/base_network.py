@@ -72,8 +72,20 @@ class BaseNetwork(object):
         return networks._RGB_MEANS if (self.vgg_type or self.resnet_type) else None
 
     def get_checkpoint_file(self):
-        raise IOError('pretrained checkpoints need network access (download.tensorflow.org); '
-                      'load weights with model.load_state_dict instead')
+        """base_network.py:193-194 / utils/checkpoint_downloader.py:92-104 without the download: the explicit
+        `weights` path of the config, else `<LUMINOTH_HOME or ~/.luminoth>/<architecture>.ckpt` (V1 file or V2
+        prefix) if it is already there; None when nothing is available (no network in this deployment)."""
+        import os
+        explicit = self._config.get('weights')
+        if explicit:
+            if os.path.exists(explicit) or os.path.exists(explicit + '.index'):
+                return explicit
+            raise IOError('model.base_network.weights: "{}" does not exist'.format(explicit))
+        home = os.environ.get('LUMINOTH_HOME') or os.path.join(os.path.expanduser('~'), '.luminoth')
+        path = os.path.join(home, '{}.ckpt'.format(self._architecture))
+        if os.path.exists(path) or os.path.exists(path + '.index'):
+            return path
+        return None
 
     # -- variable bookkeeping -----------------------------------------------------
     def _ordered_var_names(self):

@@ -111,7 +111,14 @@ def run(config, get_model_fn=None, get_dataset_fn=None, train_step_fn=None, max_
         global_step = 0
     else:
         log.info('%sRestored checkpoint at step %d from %s', log_prefix, global_step, ckpt_dir)
-    if global_step == 0 and not config.model.get('base_network', {}).get('weights'):
+    pretrained = None
+    if global_step == 0 and hasattr(model, 'get_checkpoint_file') and hasattr(model, 'get_base_network_checkpoint_vars'):
+        pretrained = model.get_checkpoint_file()                  # train.py:114-127
+        if pretrained:
+            from luminoth_amd.utils.tf_checkpoint import restore_base_network
+            names = restore_base_network(model, pretrained)
+            log.info('%sLoaded %d base-network variables from %s', log_prefix, len(names), pretrained)
+    if global_step == 0 and not pretrained:
         log.warning('%sno pretrained base-network weights (model.base_network.weights) and no checkpoint to resume: '
                     'training starts from random initialisation (BatchNorm statistics are identity)', log_prefix)
     optimizer.global_step = global_step        # slots (momentum) start from zero, like train.py:93-112

@@ -1,0 +1,327 @@
+"""CPU tests of the TensorFlow-checkpoint reader (second half): Snappy against pyarrow's codec, the
+LevelDB-style table container (round trip, checksums, compressed blocks), the V1 / V2 protobuf messages against the
+`protobuf` runtime built from the published schemas, and restoring a slim-named checkpoint into the base network."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from luminoth_amd.utils import tf_checkpoint as C
+
+F = np.float32
+
+
+def _snappy(b):
+    import pyarrow as pa
+    return pa.Codec('snappy').compress(b, asbytes=True)
+
+
+@pytest.mark.parametrize('data', [
+    b'', b'a', b'hello world, hello world, hello snappy! ' * 40, bytes(range(256)) * 300, b'\x00' * 100000,
+    np.random.RandomState(0).bytes(70000), b'ab' * 5 + b'xyz' * 3000 + np.random.RandomState(1).bytes(300) * 7])
+def test_snappy_decoder_against_pyarrow(data):
+    assert C.snappy_uncompress(_snappy(data)) == data
+
+
+def test_snappy_rejects_corruption():
+    z = bytearray(_snappy(b'hello world, hello world, hello snappy! ' * 40))
+    with pytest.raises(C.CheckpointError):
+        C.snappy_uncompress(bytes(z[:-3]))
+    z[0] ^= 0x10                                         # declared length no longer matches
+    with pytest.raises(C.CheckpointError):
+        C.snappy_uncompress(bytes(z))
+
+
+def _entries(n, seed=0):
+    rs = np.random.RandomState(seed)
+    keys = sorted(set(b'scope/%s/var_%05d' % (rs.choice([b'conv', b'bn', b'fc']), rs.randint(0, 10 ** 5)) for _ in range(n)))
+    return [(k, rs.bytes(rs.randint(0, 300))) for k in keys]
+
+
+@pytest.mark.parametrize('compress', [None, _snappy])
+def test_table_round_trip(compress):
+    ents = [(b'', b'header')] + _entries(600)
+    img = C.write_table(ents, block_size=2048, compress=compress)
+    assert struct.unpack('<Q', img[-8:])[0] == 0xdb4775248b80fb57 and len(img) > 48
+    got = C.read_table(img)
+    assert [(bytes(k), bytes(v)) for k, v in got] == ents
+    one = C.write_table([(b'k', b'v')], compress=compress)
+    assert [(bytes(k), bytes(v)) for k, v in C.read_table(one)] == [(b'k', b'v')]
+    assert C.read_table(C.write_table([])) == []
+    with pytest.raises(ValueError):
+        C.write_table([(b'b', b''), (b'a', b'')])
+
+
+def test_table_detects_corruption():
+    img = bytearray(C.write_table(_entries(200), block_size=1024))
+    bad = bytearray(img)
+    bad[100] ^= 0x01
+    with pytest.raises(C.CheckpointError, match='checksum'):
+        C.read_table(bytes(bad))
+    assert len(C.read_table(bytes(bad), verify=False)) == len(C.read_table(bytes(img)))
+    bad = bytearray(img)
+    bad[-1] ^= 0xFF
+    with pytest.raises(C.CheckpointError, match='magic'):
+        C.read_table(bytes(bad))
+    with pytest.raises(C.CheckpointError):
+        C.read_table(b'short')
+
+
+def _schemas():
+    """saved_tensor_slice.proto, tensor.proto, tensor_shape.proto, tensor_slice.proto, tensor_bundle.proto (public
+    TensorFlow schemas; only the fields checkpoints use) for the protobuf runtime."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    T = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name='lmh_ckpt.proto', package='tensorflow', syntax='proto3')
+
+    def msg(name, parent=None):
+        m = (parent.nested_type if parent is not None else fd.message_type).add()
+        m.name = name
+        return m
+
+    def field(m, name, num, typ, rep=False, type_name=None, packed=None, oneof=None):
+        f = m.field.add(name=name, number=num, type=typ, label=T.LABEL_REPEATED if rep else T.LABEL_OPTIONAL)
+        if type_name:
+            f.type_name = type_name
+        if packed is not None:
+            f.options.packed = packed
+        if oneof is not None:
+            f.oneof_index = oneof
+
+    shape = msg('TensorShapeProto')
+    dim = msg('Dim', shape)
+    field(dim, 'size', 1, T.TYPE_INT64)
+    field(dim, 'name', 2, T.TYPE_STRING)
+    field(shape, 'dim', 2, T.TYPE_MESSAGE, True, '.tensorflow.TensorShapeProto.Dim')
+    sl = msg('TensorSliceProto')
+    ext = msg('Extent', sl)
+    ext.oneof_decl.add(name='has_length')
+    field(ext, 'start', 1, T.TYPE_INT64)
+    field(ext, 'length', 2, T.TYPE_INT64, oneof=0)
+    field(sl, 'extent', 1, T.TYPE_MESSAGE, True, '.tensorflow.TensorSliceProto.Extent')
+    tp = msg('TensorProto')
+    field(tp, 'dtype', 1, T.TYPE_INT32)
+    field(tp, 'tensor_shape', 2, T.TYPE_MESSAGE, type_name='.tensorflow.TensorShapeProto')
+    field(tp, 'version_number', 3, T.TYPE_INT32)
+    field(tp, 'tensor_content', 4, T.TYPE_BYTES)
+    field(tp, 'float_val', 5, T.TYPE_FLOAT, True, packed=True)
+    field(tp, 'double_val', 6, T.TYPE_DOUBLE, True, packed=True)
+    field(tp, 'int_val', 7, T.TYPE_INT32, True, packed=True)
+    field(tp, 'int64_val', 10, T.TYPE_INT64, True, packed=True)
+    sm = msg('SavedSliceMeta')
+    field(sm, 'name', 1, T.TYPE_STRING)
+    field(sm, 'shape', 2, T.TYPE_MESSAGE, type_name='.tensorflow.TensorShapeProto')
+    field(sm, 'type', 3, T.TYPE_INT32)
+    field(sm, 'slice', 4, T.TYPE_MESSAGE, True, '.tensorflow.TensorSliceProto')
+    stm = msg('SavedTensorSliceMeta')
+    field(stm, 'tensor', 1, T.TYPE_MESSAGE, True, '.tensorflow.SavedSliceMeta')
+    ss = msg('SavedSlice')
+    field(ss, 'name', 1, T.TYPE_STRING)
+    field(ss, 'slice', 2, T.TYPE_MESSAGE, type_name='.tensorflow.TensorSliceProto')
+    field(ss, 'data', 3, T.TYPE_MESSAGE, type_name='.tensorflow.TensorProto')
+    sts = msg('SavedTensorSlices')
+    field(sts, 'meta', 1, T.TYPE_MESSAGE, type_name='.tensorflow.SavedTensorSliceMeta')
+    field(sts, 'data', 2, T.TYPE_MESSAGE, type_name='.tensorflow.SavedSlice')
+    bh = msg('BundleHeaderProto')
+    field(bh, 'num_shards', 1, T.TYPE_INT32)
+    field(bh, 'endianness', 2, T.TYPE_INT32)
+    be = msg('BundleEntryProto')
+    field(be, 'dtype', 1, T.TYPE_INT32)
+    field(be, 'shape', 2, T.TYPE_MESSAGE, type_name='.tensorflow.TensorShapeProto')
+    field(be, 'shard_id', 3, T.TYPE_INT32)
+    field(be, 'offset', 4, T.TYPE_INT64)
+    field(be, 'size', 5, T.TYPE_INT64)
+    field(be, 'crc32c', 6, T.TYPE_FIXED32)
+    field(be, 'slices', 7, T.TYPE_MESSAGE, True, '.tensorflow.TensorSliceProto')
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName('tensorflow.' + n))   # noqa: E731
+    return get('SavedTensorSlices'), get('BundleHeaderProto'), get('BundleEntryProto')
+
+
+def test_v1_reader_on_protobuf_runtime_messages(tmp_path):
+    """A V1 file assembled with the protobuf runtime: float_val data, a tensor split into two slices, an int64
+    scalar (global_step) and tensor_content data."""
+    STS = _schemas()[0]
+    rs = np.random.RandomState(0)
+    w = rs.randn(3, 3, 4, 8).astype(F)
+    big = rs.randn(10, 6).astype(F)
+    bias = rs.randn(8).astype(F)
+
+    def meta_entry(m, name, shape, dtype, slices):
+        t = m.meta.tensor.add()
+        t.name, t.type = name, dtype
+        for d in shape:
+            t.shape.dim.add().size = d
+        for s in slices:
+            e = t.slice.add()
+            for start, length in s:
+                x = e.extent.add()
+                if start is not None:
+                    x.start, x.length = start, length
+
+    meta = STS()
+    meta_entry(meta, 'net/conv1/weights', w.shape, 1, [[(None, None)] * 4])
+    meta_entry(meta, 'net/fc/weights', big.shape, 1, [[(0, 4), (None, None)], [(4, 6), (None, None)]])
+    meta_entry(meta, 'net/conv1/biases', bias.shape, 1, [[(None, None)]])
+    meta_entry(meta, 'global_step', (), 9, [[]])
+    ents = [(b'', meta.SerializeToString())]
+
+    def data_entry(key, name, arr, extents, content=False, dtype=1):
+        m = STS()
+        m.data.name = name
+        for start, length in extents:
+            x = m.data.slice.extent.add()
+            if start is not None:
+                x.start, x.length = start, length
+        m.data.data.dtype = dtype
+        for d in arr.shape:
+            m.data.data.tensor_shape.dim.add().size = d
+        if content:
+            m.data.data.tensor_content = arr.tobytes()
+        elif dtype == 9:
+            m.data.data.int64_val.extend(arr.reshape(-1).tolist())
+        else:
+            m.data.data.float_val.extend(arr.reshape(-1).tolist())
+        ents.append((key, m.SerializeToString()))
+
+    data_entry(b'\x00a', 'net/conv1/weights', w, [(None, None)] * 4)
+    data_entry(b'\x00b', 'net/fc/weights', big[:4], [(0, 4), (None, None)])
+    data_entry(b'\x00c', 'net/fc/weights', big[4:], [(4, 6), (None, None)])
+    data_entry(b'\x00d', 'net/conv1/biases', bias, [(None, None)], content=True)
+    data_entry(b'\x00e', 'global_step', np.array(12345, np.int64), [], dtype=9)
+    path = str(tmp_path / 'model.ckpt')
+    with open(path, 'wb') as f:
+        f.write(C.write_table(sorted(ents), block_size=512, compress=_snappy))
+    got = C.load_checkpoint(path)
+    assert set(got) == {'net/conv1/weights', 'net/fc/weights', 'net/conv1/biases', 'global_step'}
+    np.testing.assert_array_equal(got['net/conv1/weights'], w)
+    np.testing.assert_array_equal(got['net/fc/weights'], big)
+    np.testing.assert_array_equal(got['net/conv1/biases'], bias)
+    assert got['global_step'].dtype == np.int64 and int(got['global_step']) == 12345
+
+
+def test_v1_writer_is_readable_by_protobuf_runtime_and_round_trips(tmp_path):
+    STS = _schemas()[0]
+    rs = np.random.RandomState(1)
+    tensors = {'vgg_16/conv1/conv1_1/weights': rs.randn(3, 3, 3, 64).astype(F),
+               'vgg_16/conv1/conv1_1/biases': rs.randn(64).astype(F), 'global_step': np.array(7, np.int64)}
+    path = str(tmp_path / 'vgg_16.ckpt')
+    C.save_v1(path, tensors)
+    got = C.load_v1(path)
+    assert set(got) == set(tensors)
+    for k in tensors:
+        np.testing.assert_array_equal(got[k], tensors[k])
+        assert got[k].dtype == tensors[k].dtype
+    names = []
+    for key, value in C.read_table(open(path, 'rb').read()):
+        m = STS()
+        m.ParseFromString(bytes(value))
+        if bytes(key) == b'':
+            assert sorted(t.name for t in m.meta.tensor) == sorted(tensors)
+            shapes = {t.name: tuple(d.size for d in t.shape.dim) for t in m.meta.tensor}
+            assert shapes['vgg_16/conv1/conv1_1/weights'] == (3, 3, 3, 64) and shapes['global_step'] == ()
+        else:
+            names.append(m.data.name)
+            if m.data.name.endswith('weights'):
+                np.testing.assert_array_equal(np.array(m.data.data.float_val, F).reshape(3, 3, 3, 64),
+                                              tensors[m.data.name])
+    assert sorted(names) == sorted(tensors)
+
+
+def test_v2_bundle(tmp_path):
+    _, BH, BE = _schemas()
+    rs = np.random.RandomState(2)
+    tensors = {'fasterrcnn/rpn/conv/w': rs.randn(3, 3, 16, 8).astype(F), 'fasterrcnn/rpn/conv/b': rs.randn(8).astype(F),
+               'global_step': np.array(99, np.int64), 'beta1_power': np.array(0.5, np.float64)}
+    prefix = str(tmp_path / 'model.ckpt-99')
+    C.save_v2(prefix, tensors)
+    assert os.path.exists(prefix + '.index') and os.path.exists(prefix + '.data-00000-of-00001')
+    got = C.load_checkpoint(prefix)
+    for k in tensors:
+        np.testing.assert_array_equal(got[k], tensors[k])
+        assert got[k].dtype == tensors[k].dtype
+    np.testing.assert_array_equal(C.load_checkpoint(prefix + '.index')['global_step'], 99)
+    data = open(prefix + '.data-00000-of-00001', 'rb').read()
+    for key, value in C.read_table(open(prefix + '.index', 'rb').read()):
+        if bytes(key) == b'':
+            h = BH()
+            h.ParseFromString(bytes(value))
+            assert h.num_shards == 1 and h.endianness == 0
+            continue
+        e = BE()
+        e.ParseFromString(bytes(value))
+        t = tensors[bytes(key).decode()]
+        assert tuple(d.size for d in e.shape.dim) == t.shape and e.size == t.nbytes and e.shard_id == 0
+        assert data[e.offset:e.offset + e.size] == t.tobytes()
+    # an index written by the protobuf runtime (the reader must not depend on this writer's field order)
+    ents = [(b'', BH(num_shards=1).SerializeToString())]
+    off = 0
+    from luminoth_amd.datasets.tfrecord import masked_crc32c
+    for name in sorted(tensors):
+        t = tensors[name]
+        e = BE(dtype=C.DTYPE_ENUM[t.dtype], shard_id=0, offset=off, size=t.nbytes, crc32c=masked_crc32c(t.tobytes()))
+        for d in t.shape:
+            e.shape.dim.add().size = d
+        ents.append((name.encode(), e.SerializeToString()))
+        off += t.nbytes
+    with open(prefix + '.index', 'wb') as f:
+        f.write(C.write_table(ents, compress=_snappy))
+    got = C.load_v2(prefix)
+    for k in tensors:
+        np.testing.assert_array_equal(got[k], tensors[k])
+    # corrupted payload
+    blob = bytearray(data)
+    blob[10] ^= 0xFF
+    open(prefix + '.data-00000-of-00001', 'wb').write(bytes(blob))
+    with pytest.raises(C.CheckpointError, match='checksum'):
+        C.load_v2(prefix)
+    with pytest.raises(C.CheckpointError):
+        C.load_checkpoint(str(tmp_path / 'nope'))
+
+
+def test_restore_slim_named_checkpoint_into_base_network(tmp_path, monkeypatch):
+    """train.py:114-127 path: a checkpoint with slim's names (`resnet_v1_50/...`, no module scope) fills exactly the
+    base-network variables, frozen BatchNorm statistics included; everything else keeps its initial value."""
+    from luminoth_amd.models import get_model
+    from luminoth_amd.utils.config import get_config
+    cfg = get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': 3},
+                                'base_network': {'architecture': 'resnet_v1_50'}}, 'train': {'seed': 0}})
+    model = get_model('fasterrcnn')(cfg, device='cpu')
+    monkeypatch.setenv('LUMINOTH_HOME', str(tmp_path / 'home'))
+    assert model.get_checkpoint_file() is None
+    var_map = model.get_base_network_checkpoint_vars()
+    assert 'resnet_v1_50/conv1/weights' in var_map and 'resnet_v1_50/conv1/BatchNorm/moving_variance' in var_map
+    rs = np.random.RandomState(3)
+    ckpt = {n: rs.randn(*t.shape).astype(F) for n, t in var_map.items()}
+    ckpt['global_step'] = np.array(0, np.int64)
+    ckpt['resnet_v1_50/logits/weights'] = rs.randn(1, 1, 2048, 1000).astype(F)     # present in slim files, unused
+    os.makedirs(str(tmp_path / 'home'))
+    path = str(tmp_path / 'home' / 'resnet_v1_50.ckpt')
+    C.save_v1(path, ckpt)
+    assert model.get_checkpoint_file() == path
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    names = C.restore_base_network(model, path)
+    assert sorted(names) == sorted(var_map)
+    after = model.state_dict()
+    prefix = 'truncated_base_network/'
+    for k, v in after.items():
+        if k.startswith(prefix) and k[len(prefix):] in var_map:
+            np.testing.assert_array_equal(v.numpy(), ckpt[k[len(prefix):]])
+        else:
+            assert (v == before[k]).all(), k
+    # explicit path through the config, shape mismatch and missing variables
+    cfg2 = get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': 3},
+                                 'base_network': {'architecture': 'resnet_v1_50', 'weights': path}}, 'train': {'seed': 0}})
+    assert get_model('fasterrcnn')(cfg2, device='cpu').get_checkpoint_file() == path
+    bad = dict(ckpt)
+    bad['resnet_v1_50/conv1/weights'] = np.zeros((7, 7, 3, 32), F)
+    C.save_v1(str(tmp_path / 'bad.ckpt'), bad)
+    with pytest.raises(C.CheckpointError, match='shape'):
+        C.restore_base_network(model, str(tmp_path / 'bad.ckpt'))
+    short = {k: v for k, v in ckpt.items() if 'block3' not in k}
+    C.save_v2(str(tmp_path / 'short.ckpt'), short)
+    with pytest.raises(C.CheckpointError, match='lacks'):
+        C.restore_base_network(model, str(tmp_path / 'short.ckpt'))
+    assert len(C.restore_base_network(model, str(tmp_path / 'short.ckpt'), strict=False)) == len(short) - 2
