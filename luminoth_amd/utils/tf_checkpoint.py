@@ -442,8 +442,9 @@ def restore_base_network(model, path, strict=True):
             raise CheckpointError('%s: checkpoint shape %s, variable shape %s' % (name, arr.shape, tuple(target.shape)))
         target.copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(target.device))
         restored.append(name)
-    if hasattr(model, '_frozen_reg'):
-        model._frozen_reg = None                        # cached L2 value of the frozen variables
+    # derived state: BatchNorm scale/shift tables of the frozen statistics, cached L2 value of the frozen variables
+    if restored and hasattr(model, 'load_state_dict') and hasattr(model, 'state_dict'):
+        model.load_state_dict(model.state_dict())
     if strict and missing:
         raise CheckpointError('checkpoint %s lacks %d base-network variables, e.g. %s' % (path, len(missing), missing[:3]))
     return restored

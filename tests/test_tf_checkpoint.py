@@ -304,6 +304,9 @@ def test_restore_slim_named_checkpoint_into_base_network(tmp_path, monkeypatch):
     before = {k: v.clone() for k, v in model.state_dict().items()}
     names = C.restore_base_network(model, path)
     assert sorted(names) == sorted(var_map)
+    # the BatchNorm tables derived from the (frozen) statistics follow the restored values
+    bn = model.base_network.bn_table._views['truncated_base_network/resnet_v1_50/conv1']
+    np.testing.assert_allclose(bn['mean'].numpy(), ckpt['resnet_v1_50/conv1/BatchNorm/moving_mean'])
     after = model.state_dict()
     prefix = 'truncated_base_network/'
     for k, v in after.items():
