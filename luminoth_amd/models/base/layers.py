@@ -24,6 +24,9 @@ BN_EPS = 1e-5  # slim resnet_arg_scope batch_norm_epsilon (truncated_base_networ
 # hook(nodes, len(nodes)) before the first node: lets the data-parallel layer start all-reducing finished gradient
 # ranges under the rest of the backward pass.
 BACKWARD_HOOK = None
+# (j, callable): called once node j's backward is enqueued (the fused train step marks the point after which the
+# next step's frozen prefix may start)
+PROGRESS_HOOK = None
 
 
 class SideStream(object):
@@ -409,6 +412,8 @@ class Trunk(object):
             dy_is_g = below is not None
             if hook is not None:
                 hook(nodes, j)
+            if PROGRESS_HOOK is not None and PROGRESS_HOOK[0] == j:
+                PROGRESS_HOOK[1]()
         SideStream.force_inline = False
         SideStream.layers_left = 0
         return dy

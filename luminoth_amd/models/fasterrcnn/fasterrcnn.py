@@ -32,6 +32,10 @@ from luminoth_amd.utils import rng
 from luminoth_amd.utils.anchors import generate_anchors_reference, truncate_reference, all_anchors_numpy
 
 
+PREFIX_OVERLAP = os.environ.get('LUMINOTH_AMD_PREFIX_OVERLAP', '0') == '1'
+PREFIX_AFTER_NODE = int(os.environ.get('LUMINOTH_AMD_PREFIX_AFTER_NODE', '-1'))
+
+
 class FasterRCNN(object):
     def __init__(self, config, name='fasterrcnn', device=None):
         self._config = config
@@ -266,7 +270,21 @@ class FasterRCNN(object):
                     self._tgt_event.record(aux)
             for t in (gt, gt_count, seeds):
                 t.record_stream(aux)
-            feat = self.base_network(image, is_training=True)
+            # The frozen prefix of the trunk (conv1 + block1) needs nothing the optimizer writes: it runs on the
+            # aux stream, ordered only after the previous step's trunk backward, i.e. underneath that step's
+            # weight-gradient backlog, gradient exchange and update instead of behind them.
+            pre = None
+            if PREFIX_OVERLAP:
+                ev = getattr(self, '_bwd_done', None)
+                if ev is not None:
+                    aux.wait_event(ev)
+                with torch.cuda.stream(aux):
+                    pre = self.base_network.frozen_prefix(image)
+                if pre is not None:
+                    image.record_stream(aux)
+                    main.wait_stream(aux)
+                    pre.record_stream(main)
+            feat = self.base_network(image, is_training=True, prefix_out=pre)
             assert (feat.shape[1], feat.shape[2]) == (fh, fw)
             f_rpn = feat.detach().requires_grad_(True)
             f_rcnn = feat.detach().requires_grad_(True)
@@ -316,9 +334,18 @@ class FasterRCNN(object):
             buckets = _tr.ACTIVE_BUCKETS
             if buckets is not None and buckets.store is self.store:
                 buckets.arm(self.base_network.trunk)
+            if PREFIX_OVERLAP:
+                from luminoth_amd.models.base import layers as _L
+                self._bwd_done = torch.cuda.Event()
+                mark = lambda: self._bwd_done.record(torch.cuda.current_stream(self.device))   # noqa: E731
+                _L.PROGRESS_HOOK = (PREFIX_AFTER_NODE, mark) if PREFIX_AFTER_NODE >= 0 else None
             feat.backward(f_rpn.grad + f_rcnn.grad)
             if buckets is not None:
                 buckets.disarm()
+            if PREFIX_OVERLAP:
+                _L.PROGRESS_HOOK = None
+                if PREFIX_AFTER_NODE < 0:
+                    self._bwd_done.record(main)
         SideStream.join()
         rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})
         rpn_pred['num_proposals'] = prop['num_proposals']
