@@ -1,10 +1,24 @@
 """Task-level API (reference: luminoth/tasks.py:12-159).
 
-`Detector(config=cfg).predict(images, prob=None, classes=None)` with the reference's semantics: the model's own
-probability filter is switched off and the threshold / class filter is applied here.  The checkpoint registry
-behind `Detector(checkpoint='accurate')` (tools/checkpoint/, needs network) is out of scope, so `config` is
-required."""
+`Detector(config=cfg).predict(images, prob=None, classes=None)` keeps the reference's contract: the model's own
+probability cut is disabled and the threshold / class filter is applied on the host after the forward pass.  The
+remote checkpoint registry behind `Detector(checkpoint='accurate')` (luminoth/tools/checkpoint, needs network) is not
+hosted, so a `config` is required; `config.train.job_dir` selects the weights to restore.
+"""
+import numpy as np
+
 from luminoth_amd.utils.predicting import PredictorNetwork
+
+_PROB_KEYS = {'fasterrcnn': ('model', 'rcnn', 'proposals'), 'ssd': ('model', 'proposals')}
+
+
+def _disable_model_threshold(config):
+    """tasks.py:58-65: the detector filters, not the model."""
+    node = config
+    for key in _PROB_KEYS.get(config.model.type, ()):
+        node = node[key]
+    if node is not config:
+        node['min_prob_threshold'] = 0.0
 
 
 class Detector(object):
@@ -15,37 +29,27 @@ class Detector(object):
             raise ValueError('Only one of `checkpoint` or `config` must be specified in order to instantiate '
                              'a Detector.')
         if config is None:
-            raise NotImplementedError('the remote checkpoint registry (luminoth/tools/checkpoint) is not hosted: '
-                                      'pass `config` (its train.job_dir selects the checkpoint to restore)')
-        if config.model.type == 'fasterrcnn':                       # tasks.py:62-65
-            config.model.rcnn.proposals.min_prob_threshold = 0.0
-        elif config.model.type == 'ssd':
-            config.model.proposals.min_prob_threshold = 0.0
+            raise NotImplementedError('the checkpoint registry (`checkpoint=%r`) is not hosted: pass `config`'
+                                      % (checkpoint or self.DEFAULT_CHECKPOINT))
+        _disable_model_threshold(config)
         self._network = PredictorNetwork(config)
         self.prob = prob
-        self._model_classes = (self._network.class_labels if self._network.class_labels
-                               else list(range(config.model.network.num_classes)))
-        if classes:
-            self.classes = set(classes)
-            if not set(self._model_classes).issuperset(self.classes):
-                raise ValueError('`classes` must be contained in the detector\'s classes. '
-                                 'Available classes are: {}.'.format(self._model_classes))
-        else:
-            self.classes = set(self._model_classes)
+        names = self._network.class_labels
+        self._model_classes = list(names) if names else list(range(config.model.network.num_classes))
+        wanted = set(classes) if classes else set(self._model_classes)
+        unknown = wanted - set(self._model_classes)
+        if unknown:
+            raise ValueError('`classes` must be contained in the detector\'s classes. Available classes are: '
+                             '{}.'.format(self._model_classes))
+        self.classes = wanted
 
     def predict(self, images, prob=None, classes=None):
-        single_image = False
-        if not isinstance(images, list):
-            if len(images.shape) == 3:
-                images = [images]
-                single_image = True
-        if prob is None:
-            prob = self.prob
-        classes = self.classes if classes is None else set(classes)
-        predictions = []
-        for image in images:
-            predictions.append([pred for pred in self._network.predict_image(image)
-                                if pred['prob'] >= prob and pred['label'] in classes])
-        if single_image:
-            predictions = predictions[0]
-        return predictions
+        """images: one (H,W,3) array, an (N,H,W,3) array or a list of (H,W,3) arrays -> list of
+        `{'bbox': [x_min, y_min, x_max, y_max], 'label', 'prob'}` per image (a flat list for a single image)."""
+        single = not isinstance(images, list) and np.ndim(images) == 3
+        batch = [images] if single else list(images)
+        threshold = self.prob if prob is None else prob
+        allowed = self.classes if classes is None else set(classes)
+        results = [[obj for obj in self._network.predict_image(image)
+                    if obj['prob'] >= threshold and obj['label'] in allowed] for image in batch]
+        return results[0] if single else results
