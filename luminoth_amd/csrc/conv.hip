@@ -74,6 +74,16 @@ static bool stem_fast(const lmh_conv_desc* d) {
 }
 static bool fwd_fast(const lmh_conv_desc* d) { return (d->C % BK) == 0 && (d->K & 3) == 0; }
 static bool bwd_data_fast(const lmh_conv_desc* d) { return (d->K % BK) == 0 && (d->C & 3) == 0; }
+// Stride-2 3x3 backward data walks the pixels parity class by parity class (k_conv_bwd_data): the classes carry
+// 1, 2, 2 and 4 taps, so with one 128-row tile per CU the launch lasts as long as its 4-tap tiles.  64x64 tiles
+// (several per CU, scheduled dynamically) even that out: 56 -> measured below in scripts/bench_conv.py.
+static void bwd_data_parity_tile(const lmh_conv_desc* d, int64_t M, int* bm, int* bn) {
+  static const int on = env_int("LMH_BD_PARITY_SMALL", 1);
+  if (!on || !bwd_data_fast(d) || g_force_bm) return;
+  const bool par = d->stride == 2 && d->dilation == 1 && d->R * d->S > 1 && d->R <= 3 && d->S <= 3 &&
+                   !(d->H & 1) && !(d->W & 1) && ((M >> 2) % 64) == 0;
+  if (par && (M / *bm) * ((d->C + *bn - 1) / *bn) <= 512) { *bm = 64; *bn = 64; }
+}
 static bool bwd_weight_fast(const lmh_conv_desc* d) { return (d->C & 3) == 0 && (d->K & 3) == 0; }
 
 extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
@@ -131,6 +141,7 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   int bm, bn;
   static const int bd_slots = env_int("LMH_BD_SLOTS", 256);
   pick_tile(M, d->C, &bm, &bn, bd_slots);
+  bwd_data_parity_tile(d, M, &bm, &bn);
   hipStream_t st = (hipStream_t)stream;
   const int grid = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
 #define LAUNCH_BD(BM_, BN_)                                                                                 \
@@ -190,6 +201,7 @@ extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
   }
   if (op == 1) {
     pick_tile((int64_t)d->N * d->H * d->W, d->C, &bm, &bn, env_int("LMH_BD_SLOTS", 256));
+    bwd_data_parity_tile(d, (int64_t)d->N * d->H * d->W, &bm, &bn);
     return bm * 1000 + bn + (bwd_data_fast(d) ? 0 : 1000000);
   }
   int splits, kps;

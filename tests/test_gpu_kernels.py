@@ -356,6 +356,10 @@ CONV_CASES = [
     (2, 9, 9, 512, 126, 3, 1, 1, 'SAME', None),         # SSD multibox classes head: 3x3, K % 4 != 0
     (1, 19, 19, 512, 1024, 3, 1, 6, 'SAME', 'relu'),    # SSD conv6: rate 6
     (2, 5, 5, 128, 256, 3, 1, 1, 'VALID', 'relu'),      # SSD conv10_2
+    # stride-2 3x3 with even sizes: bwd_data walks the pixels parity class by parity class and skips dead taps
+    (2, 64, 64, 128, 128, 3, 2, 1, 'SAME_EXPLICIT', 'relu'),   # ResNet block2 unit4 (explicit pad 1/1)
+    (1, 32, 32, 64, 128, 3, 2, 1, 'SAME', 'relu'),             # TF SAME on an even size: pad 0 before, 1 after
+    (2, 32, 64, 96, 64, 3, 2, 1, 'SAME_EXPLICIT', None),       # C % 64 != 0 (partial column tile), no activation
 ]
 
 
