@@ -79,7 +79,9 @@ def pmc_traffic(kernel):
     if not files:
         return None, None
     try:
-        k = json.load(open(files[-1]))['kernels'].get(kernel.replace(' ', ''))
+        table = json.load(open(files[-1]))['kernels']
+        name = kernel.replace(' ', '')
+        k = table.get(name) or table.get(name[:-1] + ',false>')     # template default argument shown by rocprofv3
         return (k['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)) if k else (None, None)
     except Exception:
         return None, None
@@ -170,7 +172,7 @@ def main():
         # streams: their per-launch durations are stretched by the sharing (and their overlap pattern moves under
         # rocprofv3), so they are listed in `all_conv_kernels` but not used for the roofline line; the whole-step
         # MFMA fraction is reported next to it.
-        mfma = {k: v for k, v in prof.items() if 'fwd' in k}
+        mfma = {k: v for k, v in prof.items() if k.startswith('k_conv_fwd')}   # single kernels, not the Winograd pipeline
         name = max(mfma, key=lambda k: mfma[k]['ms'])
         step_flops = sum(v['flops'] for v in prof.values()) / nprof
         r = prof[name]

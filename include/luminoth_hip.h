@@ -105,6 +105,18 @@ int lmh_bn_param_grads(const float* w, float* dw_raw_inout, const float* dbeta,
                        const float* mean, const float* rstd, const float* scale,
                        int64_t rsc, int K, float* dgamma, void* ws, size_t ws_bytes,
                        lmh_stream_t stream);
+/* Winograd F(2x2,3x3) variants of lmh_conv2d_fwd / lmh_conv2d_bwd_data for stride-1, dilation-1, pad-1 3x3
+ * convolutions with C % 32 == 0 and K % 32 == 0 (lmh_conv2d_winograd_ok): same results up to fp32
+ * rounding of the transforms, 2.25x fewer matrix FLOPs.  Same call sites as the direct entry points (the sonnet
+ * Conv2D of rpn.py:69-75, slim conv2d of vgg / resnet 3x3 layers).  ws: lmh_conv2d_winograd_workspace_bytes(d). */
+int lmh_conv2d_winograd_ok(const lmh_conv_desc* d);
+size_t lmh_conv2d_winograd_workspace_bytes(const lmh_conv_desc* d);
+int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
+                            const float* shift, const float* residual, float* y, void* ws,
+                            size_t ws_bytes, lmh_stream_t stream);
+int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w,
+                                 const float* kscale, const float* addend, float* dx, void* ws,
+                                 size_t ws_bytes, lmh_stream_t stream);
 /* tf.nn.max_pool NHWC (slim resnet pool1 3x3/2 SAME; vgg 2x2/2 VALID; SSD 3x3/1 SAME). */
 int lmh_maxpool_fwd(const float* x, int N, int H, int W, int C, int ksize, int stride,
                     int pad_top, int pad_left, int OH, int OW, float* y, lmh_stream_t stream);

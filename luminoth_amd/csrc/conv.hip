@@ -265,3 +265,5 @@ extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, con
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
+
+#include "conv_winograd.h"

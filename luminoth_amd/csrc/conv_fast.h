@@ -172,11 +172,13 @@ __device__ __forceinline__ void acc_to_lds(float* __restrict__ Cs, const f32x16 
 //   y[p, k] = act( sum_{r,s,c} x[pix(p,r,s), c] * w[r,s,c,k] * scale[k] + shift[k] + res[p,k] )
 //   GEMM M = N*OH*OW, N = K, Kg = R*S*C.  A: gather, K-contiguous.  B: HWIO, K-major.
 // ============================================================================
-template <int BM, int BN>
+// GB: `gbatch` independent problems of the same shape stacked behind each other in x / w / y (the 16 transformed-
+// domain GEMMs of a Winograd convolution are launched as ONE grid: 64 tiles each would leave the chip empty).
+template <int BM, int BN, bool GB = false>
 __global__ void __launch_bounds__(256)
 k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
            const float* __restrict__ scale, const float* __restrict__ shift,
-           const float* __restrict__ residual, float* __restrict__ y) {
+           const float* __restrict__ residual, float* __restrict__ y, int gbatch = 1) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BM * LDK, B_SZ = BK * BN;
@@ -189,7 +191,14 @@ k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict
   const int wm = wave >> 1, wn = wave & 1;
   const int M = d.N * d.OH * d.OW, K = d.K, C = d.C;
   const int tiles_n = (K + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n * (GB ? gbatch : 1));
+  if (GB) {
+    const int g = tile / (tiles_m * tiles_n);
+    tile -= g * (tiles_m * tiles_n);
+    x += (size_t)g * M * C;
+    w += (size_t)g * d.R * d.S * C * K;
+    y += (size_t)g * M * K;
+  }
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int CC = C / BK, KT = d.R * d.S * CC;
 

@@ -1,0 +1,256 @@
+// Winograd F(2x2, 3x3) convolution for the wide stride-1 3x3 layers (RPN 1024->512, VGG conv4/conv5): the 9-tap
+// implicit GEMM becomes 16 element-wise GEMMs over 4x4 transformed tiles — 2.25x fewer MFMA FLOPs — between two
+// HBM-bound transform passes.  Y = A^T [ (G g G^T) (.) (B^T d B) ] A  (Lavin & Gray 2015, correlation form = TF
+// conv2d).  Used for forward (x, w[r][s][c][k]) and for backward data, which is the same correlation of dy with
+// w'[r][s][k][c] = w[2-r][2-s][c][k] * kscale[k].
+//
+// Workspace layout (floats): U [16][Cg][Kg] | V [16][T][Cg] | Mo [16][T][Kg], T = N*ceil(H/2)*ceil(W/2) tiles,
+// (Cg, Kg) = (C, K) forward, (K, C) backward data; odd H / W use ceil(H/2) x ceil(W/2) tiles.  Included by conv.hip (needs lmh_zero_page in the same TU).
+#pragma once
+
+// ---- weights: U[t][cg][kg], t = 4*a + b -----------------------------------------------------------------------
+// forward: thread = (c, k4): float4 loads along k.
+__global__ void __launch_bounds__(256)
+k_wino_weight_fwd(const float* __restrict__ w, int C, int K, float* __restrict__ U) {
+  const int K4 = K >> 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * K4) return;
+  const int c = idx / K4, k4 = idx - c * K4;
+  f32x4 g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      g[r][s] = *reinterpret_cast<const f32x4*>(w + ((size_t)(r * 3 + s) * C + c) * K + 4 * k4);
+  // Gg: rows [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2]
+  f32x4 t[4][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    t[0][s] = g[0][s];
+    t[1][s] = (g[0][s] + g[1][s] + g[2][s]) * 0.5f;
+    t[2][s] = (g[0][s] - g[1][s] + g[2][s]) * 0.5f;
+    t[3][s] = g[2][s];
+  }
+  const size_t plane = (size_t)C * K;
+  float* o = U + (size_t)c * K + 4 * k4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 0) * plane) = t[a][0];
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 1) * plane) = (t[a][0] + t[a][1] + t[a][2]) * 0.5f;
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 2) * plane) = (t[a][0] - t[a][1] + t[a][2]) * 0.5f;
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 3) * plane) = t[a][2];
+  }
+}
+
+// backward data: U'[t][k][c] from w[2-r][2-s][c][k] * kscale[k]; thread = (k, c4): four k-strided loads per tap
+// (33 MB once per step), float4 stores along c.
+__global__ void __launch_bounds__(256)
+k_wino_weight_bwd(const float* __restrict__ w, const float* __restrict__ kscale, int C, int K,
+                  float* __restrict__ U) {
+  const int C4 = C >> 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= K * C4) return;
+  const int c4 = idx % C4, k = idx / C4;     // consecutive threads: consecutive c4 (stores coalesce along c)
+  const float ks = kscale ? kscale[k] : 1.f;
+  f32x4 g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const float* p = w + ((size_t)((2 - r) * 3 + (2 - s)) * C + 4 * c4) * K + k;
+      g[r][s] = f32x4{p[0], p[K], p[2 * (size_t)K], p[3 * (size_t)K]} * ks;
+    }
+  f32x4 t[4][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    t[0][s] = g[0][s];
+    t[1][s] = (g[0][s] + g[1][s] + g[2][s]) * 0.5f;
+    t[2][s] = (g[0][s] - g[1][s] + g[2][s]) * 0.5f;
+    t[3][s] = g[2][s];
+  }
+  const size_t plane = (size_t)K * C;
+  float* o = U + (size_t)k * C + 4 * c4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 0) * plane) = t[a][0];
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 1) * plane) = (t[a][0] + t[a][1] + t[a][2]) * 0.5f;
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 2) * plane) = (t[a][0] - t[a][1] + t[a][2]) * 0.5f;
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 3) * plane) = t[a][2];
+  }
+}
+
+// ---- input: V[t][tile][c] = B^T d B of the 4x4 patch at (2i-1, 2j-1), zero outside the image ------------------
+__global__ void __launch_bounds__(256)
+k_wino_input(const float* __restrict__ x, int N, int H, int W, int C, float* __restrict__ V) {
+  const int C4 = C >> 2, th = (H + 1) >> 1, tw = (W + 1) >> 1;   // odd sizes: the last tile row / column is half empty
+  const int T = N * th * tw;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)T * C4) return;
+  const int c4 = (int)(idx % C4), tile = (int)(idx / C4);
+  const int j = tile % tw, t1 = tile / tw, i = t1 % th, n = t1 / th;
+  f32x4 d[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int h = 2 * i - 1 + a;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ww = 2 * j - 1 + b;
+      const bool ok = (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W;
+      d[a][b] = ok ? *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + h) * W + ww) * C + 4 * c4)
+                   : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // B^T d: rows [d0-d2, d1+d2, d2-d1, d1-d3]
+  f32x4 t[4][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    t[0][b] = d[0][b] - d[2][b];
+    t[1][b] = d[1][b] + d[2][b];
+    t[2][b] = d[2][b] - d[1][b];
+    t[3][b] = d[1][b] - d[3][b];
+  }
+  const size_t plane = (size_t)T * C;
+  float* o = V + (size_t)tile * C + 4 * c4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 0) * plane) = t[a][0] - t[a][2];
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 1) * plane) = t[a][1] + t[a][2];
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 2) * plane) = t[a][2] - t[a][1];
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 3) * plane) = t[a][1] - t[a][3];
+  }
+}
+
+// ---- output: y = act( (A^T m A) * scale + shift + extra ), 2x2 pixels per tile ----------------------------------
+__global__ void __launch_bounds__(256)
+k_wino_output(const float* __restrict__ Mo, int N, int H, int W, int K, const float* __restrict__ scale,
+              const float* __restrict__ shift, const float* __restrict__ extra, float act_lo, float act_hi,
+              float* __restrict__ y) {
+  const int K4 = K >> 2, th = (H + 1) >> 1, tw = (W + 1) >> 1;
+  const int T = N * th * tw;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)T * K4) return;
+  const int k4 = (int)(idx % K4), tile = (int)(idx / K4);
+  const int j = tile % tw, t1 = tile / tw, i = t1 % th, n = t1 / th;
+  const size_t plane = (size_t)T * K;
+  const float* src = Mo + (size_t)tile * K + 4 * k4;
+  f32x4 m[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) m[a][b] = *reinterpret_cast<const f32x4*>(src + (size_t)(4 * a + b) * plane);
+  // A^T m: rows [m0+m1+m2, m1-m2-m3]
+  f32x4 t[2][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    t[0][b] = m[0][b] + m[1][b] + m[2][b];
+    t[1][b] = m[1][b] - m[2][b] - m[3][b];
+  }
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (scale) sc = *reinterpret_cast<const f32x4*>(scale + 4 * k4);
+  if (shift) sh = *reinterpret_cast<const f32x4*>(shift + 4 * k4);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    f32x4 o2[2] = {t[a][0] + t[a][1] + t[a][2], t[a][1] - t[a][2] - t[a][3]};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (2 * i + a >= H || 2 * j + b >= W) continue;
+      const size_t off = ((size_t)(n * H + 2 * i + a) * W + 2 * j + b) * K + 4 * k4;
+      f32x4 v = o2[b] * sc + sh;
+      if (extra) v += *reinterpret_cast<const f32x4*>(extra + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
+      *reinterpret_cast<f32x4*>(y + off) = v;
+    }
+  }
+}
+
+// ---- host -----------------------------------------------------------------------------------------------------
+static bool wino_ok(const lmh_conv_desc* d) {
+  return d->R == 3 && d->S == 3 && d->stride == 1 && d->dilation == 1 && d->pad_top == 1 && d->pad_left == 1 &&
+         d->OH == d->H && d->OW == d->W && (d->C % BK) == 0 && (d->K % BK) == 0;
+}
+
+extern "C" int lmh_conv2d_winograd_ok(const lmh_conv_desc* d) { return d && wino_ok(d) ? 1 : 0; }
+
+extern "C" size_t lmh_conv2d_winograd_workspace_bytes(const lmh_conv_desc* d) {
+  if (!d || !wino_ok(d)) return 0;
+  const size_t T = (size_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+  return 16 * sizeof(float) * ((size_t)d->C * d->K + T * d->C + T * d->K);
+}
+
+// Cg = reduction channels, Kg = output channels of this direction.
+static int wino_run(const lmh_conv_desc* d, const float* in, int Cg, int Kg, const float* U, float* V, float* Mo,
+                    const float* scale, const float* shift, const float* extra, float act_lo, float act_hi,
+                    float* out, hipStream_t st) {
+  const int T = d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+  {
+    const int64_t n = (int64_t)T * (Cg / 4);
+    hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, d->N, d->H, d->W, Cg, V);
+  }
+  // 16 GEMMs [T x Cg] x [Cg x Kg] as ONE grid of the forward kernel (a 1x1 convolution over T "pixels")
+  lmh_conv_desc g = *d;
+  g.N = 1; g.H = T; g.W = 1; g.OH = T; g.OW = 1; g.C = Cg; g.K = Kg; g.R = 1; g.S = 1;
+  g.stride = 1; g.dilation = 1; g.pad_top = 0; g.pad_left = 0; g.act = 0;
+  int bm, bn;
+  pick_tile((int64_t)T * 16, Kg, &bm, &bn);
+  const int grid = 16 * ((T + bm - 1) / bm) * ((Kg + bn - 1) / bn);
+#define LAUNCH_WG(BM_, BN_)                                                                           \
+  hipLaunchKernelGGL((k_conv_fwd<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U,  \
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, 16)
+  if (bm == 128 && bn == 128) LAUNCH_WG(128, 128);
+  else if (bm == 128) LAUNCH_WG(128, 64);
+  else LAUNCH_WG(64, 64);
+#undef LAUNCH_WG
+  {
+    const int64_t n = (int64_t)T * (Kg / 4);
+    hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,
+                       d->H, d->W, Kg, scale, shift, extra, act_lo, act_hi, out);
+  }
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+static int wino_carve(const lmh_conv_desc* d, void* ws, size_t ws_bytes, int Cg, int Kg, float** U, float** V,
+                      float** Mo) {
+  if (!ws || ws_bytes < lmh_conv2d_winograd_workspace_bytes(d)) {
+    lmh_set_error("winograd: workspace %zu < %zu", ws_bytes, lmh_conv2d_winograd_workspace_bytes(d));
+    return LMH_ERR_WORKSPACE;
+  }
+  const size_t T = (size_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+  *U = reinterpret_cast<float*>(ws);
+  *V = *U + 16 * (size_t)d->C * d->K;
+  *Mo = *V + 16 * T * Cg;
+  (void)Kg;
+  return LMH_OK;
+}
+
+extern "C" int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
+                                       const float* shift, const float* residual, float* y, void* ws,
+                                       size_t ws_bytes, lmh_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  LMH_CHECK_ARG(x && w && y && wino_ok(d));
+  float *U, *V, *Mo;
+  rc = wino_carve(d, ws, ws_bytes, d->C, d->K, &U, &V, &Mo);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = d->C * (d->K / 4);
+  hipLaunchKernelGGL(k_wino_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, U);
+  const float lo = d->act ? 0.f : -INFINITY, hi = (d->act == 2) ? 6.f : INFINITY;
+  return wino_run(d, x, d->C, d->K, U, V, Mo, scale, shift, residual, lo, hi, y, st);
+}
+
+extern "C" int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w,
+                                            const float* kscale, const float* addend, float* dx, void* ws,
+                                            size_t ws_bytes, lmh_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  LMH_CHECK_ARG(dy && w && dx && wino_ok(d));
+  float *U, *V, *Mo;
+  rc = wino_carve(d, ws, ws_bytes, d->K, d->C, &U, &V, &Mo);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = d->K * (d->C / 4);
+  hipLaunchKernelGGL(k_wino_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, U);
+  return wino_run(d, dy, d->K, d->C, U, V, Mo, nullptr, nullptr, addend, -INFINITY, INFINITY, dx, st);
+}

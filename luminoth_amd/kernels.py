@@ -6,6 +6,7 @@ that merely own the memory.  Nothing in this file computes with torch ops, and
 nothing falls back to the CPU: tensors must live on a ROCm device.
 """
 import ctypes
+import os
 
 import torch
 
@@ -93,13 +94,15 @@ def _conv_flops(d):
 
 
 class _timed(object):
-    def __init__(self, d, op):
+    def __init__(self, d, op, wino=False):
         self.on = _Profile.enabled
         if self.on:
             kid = _lib.load().lmh_conv2d_kernel_id(ctypes.byref(d), op)
             gen = '_gen' if kid >= 1000000 else ''
             kid %= 1000000
             self.name = '%s%s<%d,%d>' % (_OPN[op], gen, kid // 1000, kid % 1000)
+            if wino:   # whole Winograd pipeline (transforms + 16 GEMMs); flops stay the direct-convolution count
+                self.name = _OPN[op].replace('k_conv', 'winograd')
             self.flops = _conv_flops(d)
 
     def __enter__(self):
@@ -146,8 +149,47 @@ def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding='SAME', act=None):
     return ConvDesc(N, H, W, C, K, R, S, OH, OW, stride, dilation, pt, pl, ACT[act])
 
 
+# Winograd F(2x2,3x3) for the wide stride-1 3x3 layers, above a C*K threshold: RPN 1024->512
+# 652 -> 334 us, block3 256->256 89 -> 65 us, 128->128 break-even (scripts/bench_winograd.py); whole step
+# 9.99 -> 9.31 ms with the threshold at 256*256 (9.45 at 512*512, 9.35 at 128*128).
+WINOGRAD = os.environ.get('LUMINOTH_AMD_WINOGRAD', '1') == '1'
+WINOGRAD_MIN_CK = int(os.environ.get('LUMINOTH_AMD_WINOGRAD_MIN_CK', str(256 * 256)))
+
+
+def winograd_ok(d):
+    return bool(_lib.load().lmh_conv2d_winograd_ok(ctypes.byref(d)))
+
+
+def _use_winograd(d):
+    return WINOGRAD and d.R == 3 and d.C * d.K >= WINOGRAD_MIN_CK and winograd_ok(d)
+
+
+def conv2d_fwd_winograd(d, x, w, scale=None, shift=None, residual=None, out=None):
+    lib = _lib.load()
+    y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.lmh_conv2d_winograd_workspace_bytes(ctypes.byref(d)), x.device, 'winograd')
+    with _timed(d, 0, wino=True):
+        check(lib.lmh_conv2d_fwd_winograd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(scale), _p(shift),
+                                          _p(residual), _p(y), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
+              'lmh_conv2d_fwd_winograd')
+    return y
+
+
+def conv2d_bwd_data_winograd(d, dy, w, kscale=None, addend=None, out=None):
+    lib = _lib.load()
+    dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
+    ws = _workspace(lib.lmh_conv2d_winograd_workspace_bytes(ctypes.byref(d)), dy.device, 'winograd')
+    with _timed(d, 1, wino=True):
+        check(lib.lmh_conv2d_bwd_data_winograd(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(kscale), _p(addend),
+                                               _p(dx), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
+              'lmh_conv2d_bwd_data_winograd')
+    return dx
+
+
 def conv2d_fwd(d, x, w, scale=None, shift=None, residual=None, in_sub=None, out=None):
     lib = _lib.load()
+    if in_sub is None and _use_winograd(d):
+        return conv2d_fwd_winograd(d, x, w, scale, shift, residual, out)
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
     with _timed(d, 0):
         check(lib.lmh_conv2d_fwd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(scale), _p(shift), _p(residual),
@@ -176,6 +218,8 @@ def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None, yact=None, xma
     xmask (= the layer input x) + xmask_act: the result is dx * act'(x), i.e. the pre-activation gradient
     of the layer that produced x (fused in the epilogue on the fast path, one extra pass otherwise)."""
     lib = _lib.load()
+    if yact is None and xmask is None and _use_winograd(d):
+        return conv2d_bwd_data_winograd(d, dy, w, kscale, addend, out)
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
     fuse_mask = xmask is not None and conv_bwd_data_fast(d)
     with _timed(d, 1):

@@ -364,7 +364,8 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_fwd_bwd(K, case):
+def test_conv_fwd_bwd(K, case, monkeypatch):
+    monkeypatch.setattr(K, 'WINOGRAD', False)      # the direct kernels are under test here (bit-identity checks)
     N, H, W, C, Kc, R, stride, dil, padding, act = case
     rs = np.random.RandomState(CONV_CASES.index(case) + 100)     # (hash() of a str-bearing tuple is per-process)
     x = rs.randn(N, H, W, C).astype(F)
@@ -422,6 +423,58 @@ def test_conv_fwd_bwd(K, case):
             dw_f = K.conv2d_bwd_weight(d, T(xw), g, colsum=cs)
         assert torch.equal(dw_f, dw)
         np.testing.assert_allclose(cs.cpu().numpy(), gref.reshape(-1, Kc).sum(0), rtol=1e-3, atol=1e-3)
+
+
+WINO_CASES = [
+    # N, H, W, C, K, act
+    (2, 16, 16, 64, 96, 'relu'),        # several GEMM tiles per transformed plane, K not a multiple of 64
+    (1, 64, 64, 1024, 512, 'relu6'),    # the RPN convolution (rpn.py:69-75) at the benchmark size
+    (2, 6, 10, 32, 32, None),           # tiny, H != W, no activation
+    (2, 38, 38, 512, 512, 'relu'),      # VGG conv4 block at SSD-like size
+    (2, 37, 37, 256, 256, 'relu'),      # odd sizes (SSD conv4_3 map): half-empty last tile row / column
+    (1, 5, 7, 32, 64, None),
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv_winograd_equals_direct(K, case):
+    """Winograd F(2x2,3x3) forward / backward-data against the torch fp32 reference AND the direct HIP kernels
+    (same operands, same epilogues): the transforms only reorder fp32 roundings."""
+    N, H, W, C, Kc, act = case
+    rs = np.random.RandomState(WINO_CASES.index(case) + 900)
+    x = rs.randn(N, H, W, C).astype(F)
+    w = (rs.randn(3, 3, C, Kc) * np.sqrt(2.0 / (9 * C))).astype(F)
+    scale = (1 + 0.1 * rs.randn(Kc)).astype(F)
+    shift = (0.1 * rs.randn(Kc)).astype(F)
+    res = rs.randn(N, H, W, Kc).astype(F)
+    d = K.conv_desc(x.shape, w.shape, 1, 1, 'SAME', act)
+    assert K.winograd_ok(d)
+    assert not K.winograd_ok(K.conv_desc(x.shape, w.shape, 2, 1, 'SAME', act))
+    assert not K.winograd_ok(K.conv_desc(x.shape, w.shape, 1, 2, 'SAME', act))
+    y_dir = K.conv2d_fwd(d, T(x), T(w), T(scale), T(shift), T(res))
+    y_win = K.conv2d_fwd_winograd(d, T(x), T(w), T(scale), T(shift), T(res))
+    xt = torch.tensor(x, requires_grad=True)
+    conv = ot.conv2d_nhwc(xt, torch.tensor(w), 1, 1, 'SAME')
+    yt = conv * torch.tensor(scale) + torch.tensor(shift) + torch.tensor(res)
+    yt = torch.relu(yt) if act == 'relu' else (torch.clamp(yt, 0, 6) if act == 'relu6' else yt)
+    tol = 4e-5 * max(1.0, float(yt.abs().max()))
+    np.testing.assert_allclose(y_win.cpu().numpy(), yt.detach().numpy(), rtol=2e-4, atol=tol)
+    np.testing.assert_allclose(y_win.cpu().numpy(), y_dir.cpu().numpy(), rtol=2e-4, atol=tol)
+    plain = K.conv2d_fwd_winograd(d, T(x), T(w))                       # no scale / shift / residual
+    ref_plain = torch.relu(conv) if act == 'relu' else (torch.clamp(conv, 0, 6) if act == 'relu6' else conv)
+    np.testing.assert_allclose(plain.cpu().numpy(), ref_plain.detach().numpy(), rtol=2e-4, atol=tol)
+    g = rs.randn(N, H, W, Kc).astype(F)
+    (conv * torch.tensor(scale)).backward(torch.tensor(g))
+    add = rs.randn(*x.shape).astype(F)
+    dx_dir = K.conv2d_bwd_data(d, T(g), T(w), T(scale), addend=T(add))
+    dx_win = K.conv2d_bwd_data_winograd(d, T(g), T(w), T(scale), addend=T(add))
+    tolx = 4e-5 * max(1.0, float(xt.grad.abs().max()))
+    np.testing.assert_allclose(dx_win.cpu().numpy(), xt.grad.numpy() + add, rtol=2e-4, atol=tolx)
+    np.testing.assert_allclose(dx_win.cpu().numpy(), dx_dir.cpu().numpy(), rtol=2e-4, atol=tolx)
+    dx0 = K.conv2d_bwd_data_winograd(d, T(g), T(w))                    # no kscale, no addend
+    xt.grad = None
+    ot.conv2d_nhwc(xt, torch.tensor(w), 1, 1, 'SAME').backward(torch.tensor(g))
+    np.testing.assert_allclose(dx0.cpu().numpy(), xt.grad.numpy(), rtol=2e-4, atol=tolx)
 
 
 def test_conv_stem_kernel(K):

@@ -54,7 +54,13 @@ def setup():
     return cfg, model, images, gts
 
 
-def test_train_step_matches_oracle(setup):
+@pytest.mark.parametrize('winograd', [False, True], ids=['direct', 'winograd'])
+def test_train_step_matches_oracle(setup, winograd, monkeypatch):
+    """Whole step against the oracle, once with the direct 3x3 kernels and once with the Winograd F(2x2,3x3) path
+    on every layer it covers (the default routes RPN + block3 through it)."""
+    from luminoth_amd import kernels as KK
+    monkeypatch.setattr(KK, 'WINOGRAD', winograd)
+    monkeypatch.setattr(KK, 'WINOGRAD_MIN_CK', 64 * 64)
     cfg, model, images, gts = setup
     model._step = 0
     pred = model(images, gts, is_training=True)
@@ -132,7 +138,10 @@ def test_train_step_matches_oracle(setup):
         # elements, loose bound on all of them.
         tight = err <= 2e-4 * scale + 2e-3 * np.abs(g_ref.numpy())
         assert tight.mean() >= 0.995, (n, float(tight.mean()))
-        assert err.max() <= 1e-2 * scale, (n, float(err.max()), scale)
+        # Winograd reorders the fp32 roundings of the pre-activations (error a few 1e-6 instead of 1e-6 of the
+        # activation scale): proportionally more ReLU-kink flips, each moving one weight-gradient element by a
+        # full dy*x term, hence the wider bound on the single worst element; the 99.5 % criterion is unchanged.
+        assert err.max() <= (5e-2 if winograd else 1e-2) * scale, (n, float(err.max()), scale)
         checked += 1
     assert checked > 100
 
