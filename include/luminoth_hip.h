@@ -117,6 +117,10 @@ int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float*
 int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w,
                                  const float* kscale, const float* addend, float* dx, void* ws,
                                  size_t ws_bytes, lmh_stream_t stream);
+/* dw (RAW, like lmh_conv2d_bwd_weight) = G^T [ sum_tiles (B^T x B)^T (A dy A^T) ] G. */
+size_t lmh_conv2d_bwd_weight_winograd_workspace_bytes(const lmh_conv_desc* d);
+int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const float* x, const float* dy, float* dw,
+                                   void* ws, size_t ws_bytes, lmh_stream_t stream);
 /* tf.nn.max_pool NHWC (slim resnet pool1 3x3/2 SAME; vgg 2x2/2 VALID; SSD 3x3/1 SAME). */
 int lmh_maxpool_fwd(const float* x, int N, int H, int W, int C, int ksize, int stride,
                     int pad_top, int pad_left, int OH, int OW, float* y, lmh_stream_t stream);

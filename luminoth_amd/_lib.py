@@ -80,6 +80,8 @@ SIGNATURES = {
     'lmh_conv2d_winograd_workspace_bytes': (c_sz, [P(ConvDesc)]),
     'lmh_conv2d_fwd_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_data_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_conv2d_bwd_weight_winograd_workspace_bytes': (c_sz, [P(ConvDesc)]),
+    'lmh_conv2d_bwd_weight_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_weight_workspace_bytes': (c_sz, [P(ConvDesc)]),
     'lmh_conv2d_bwd_weight': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_kernel_id': (c_i, [P(ConvDesc), c_i]),

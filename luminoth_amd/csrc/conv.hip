@@ -218,12 +218,22 @@ extern "C" size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d) 
   return slabs + lmh_align_up((size_t)splits * d->K * sizeof(float), 256);
 }
 
+static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float* dy, const float* yact,
+                             float* dw, float* colsum, void* ws, size_t ws_bytes, hipStream_t stream, bool gb);
+
 extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* dy, const float* yact,
                                      float* dw, float* colsum, void* ws, size_t ws_bytes,
                                      lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
+  return bwd_weight_launch(d, x, dy, yact, dw, colsum, ws, ws_bytes, (hipStream_t)stream, false);
+}
+
+// gb: stacked independent GEMMs (see k_conv_bwd_weight<..., GB>); fast path only, no fused operands.
+static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float* dy, const float* yact,
+                             float* dw, float* colsum, void* ws, size_t ws_bytes, hipStream_t stream, bool gb) {
   LMH_CHECK_ARG(x && dy && dw);
+  LMH_CHECK_ARG(!gb || (bwd_weight_fast(d) && !yact && !colsum));
   int bm, bn, splits, kps;
   bwd_weight_plan(d, &bm, &bn, &splits, &kps);
   if (ws_bytes < lmh_conv2d_bwd_weight_workspace_bytes(d) || (splits > 1 && !ws)) {
@@ -241,7 +251,10 @@ extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, con
   const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
 #define LAUNCH_BW(BM_, BN_)                                                                              \
   do {                                                                                                   \
-    if (fast && yact)                                                                                    \
+    if (gb)                                                                                              \
+      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, false, true>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, st, \
+                         *d, x, dy, out, kps, dvw, dvh, yact, cpart, (int)grid.x, (int)grid.y, (int)grid.z); \
+    else if (fast && yact)                                                                               \
       hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, true>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, st, \
                          *d, x, dy, out, kps, dvw, dvh, yact, cpart, (int)grid.x, (int)grid.y, (int)grid.z); \
     else if (fast)                                                                                       \

@@ -550,7 +550,9 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
 //   dw[rs, c, k] = sum_p x[pix(p,r,s), c] * dy[p, k];  reduction split over gridDim.z
 //   GEMM M = C (per tap), N = K, Kg = P = N*OH*OW.  Both operands K-major ([pixel][channel]).
 // ============================================================================
-template <int BM, int BN, bool YACT>   // YACT: B operand is dy * act'(yact) (fused activation backward)
+// GB: the R*S "taps" are independent GEMMs stacked in x / dy (the 16 transformed planes of a Winograd weight
+// gradient, launched with a fake 4x4 filter, dilation 0, no padding): tap rs reads x + rs*P*C and dy + rs*P*K.
+template <int BM, int BN, bool YACT, bool GB = false>   // YACT: B operand is dy * act'(yact) (fused activation backward)
 __global__ void __launch_bounds__(256)
 k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ dy,
                   float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh,
@@ -591,8 +593,8 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
   // division (branch-free: the whole stage stays one basic block for the MFMA/VMEM interleave)
   int pa0 = kt_begin * BK + ak;
   int bp = kt_begin * BK + bk;
-  const float* xb = x + m0 + 4 * ax4;
-  const size_t dy_off0 = (size_t)bp * K + n0 + 4 * bx4;
+  const float* xb = x + m0 + 4 * ax4 + (GB ? (size_t)rs * P * C : 0);
+  const size_t dy_off0 = (size_t)bp * K + n0 + 4 * bx4 + (GB ? (size_t)rs * P * K : 0);
   const float* pdy = dy + dy_off0;
   const float* pyy = YACT ? yact + dy_off0 : lmh_zero_page;
   const size_t dy_row = (size_t)BROW_STEP * K, dy_stage = (size_t)BK * K;

@@ -164,6 +164,74 @@ k_wino_output(const float* __restrict__ Mo, int N, int H, int W, int K, const fl
   }
 }
 
+// ---- weight gradient: dU[t] = V[t]^T dM[t] with dM = A dY A^T per 2x2 gradient tile, dw = G^T dU G --------------
+__global__ void __launch_bounds__(256)
+k_wino_dy(const float* __restrict__ g, int N, int H, int W, int K, float* __restrict__ dM) {
+  const int K4 = K >> 2, th = (H + 1) >> 1, tw = (W + 1) >> 1;
+  const int T = N * th * tw;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)T * K4) return;
+  const int k4 = (int)(idx % K4), tile = (int)(idx / K4);
+  const int j = tile % tw, t1 = tile / tw, i = t1 % th, n = t1 / th;
+  f32x4 y[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const bool ok = 2 * i + a < H && 2 * j + b < W;
+      y[a][b] = ok ? *reinterpret_cast<const f32x4*>(g + ((size_t)(n * H + 2 * i + a) * W + 2 * j + b) * K + 4 * k4)
+                   : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  // A = [[1,0],[1,1],[1,-1],[0,-1]]: rows of A y
+  f32x4 t[4][2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    t[0][b] = y[0][b];
+    t[1][b] = y[0][b] + y[1][b];
+    t[2][b] = y[0][b] - y[1][b];
+    t[3][b] = -y[1][b];
+  }
+  const size_t plane = (size_t)T * K;
+  float* o = dM + (size_t)tile * K + 4 * k4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 0) * plane) = t[a][0];
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 1) * plane) = t[a][0] + t[a][1];
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 2) * plane) = t[a][0] - t[a][1];
+    *reinterpret_cast<f32x4*>(o + (size_t)(4 * a + 3) * plane) = -t[a][1];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_wino_dw(const float* __restrict__ dU, int C, int K, float* __restrict__ dw) {
+  const int K4 = K >> 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * K4) return;
+  const int c = idx / K4, k4 = idx - c * K4;
+  const size_t plane = (size_t)C * K;
+  const float* src = dU + (size_t)c * K + 4 * k4;
+  f32x4 u[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) u[a][b] = *reinterpret_cast<const f32x4*>(src + (size_t)(4 * a + b) * plane);
+  // G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+  f32x4 t[3][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    t[0][b] = u[0][b] + (u[1][b] + u[2][b]) * 0.5f;
+    t[1][b] = (u[1][b] - u[2][b]) * 0.5f;
+    t[2][b] = (u[1][b] + u[2][b]) * 0.5f + u[3][b];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float* o = dw + ((size_t)(r * 3) * C + c) * K + 4 * k4;
+    *reinterpret_cast<f32x4*>(o) = t[r][0] + (t[r][1] + t[r][2]) * 0.5f;
+    *reinterpret_cast<f32x4*>(o + plane) = (t[r][1] - t[r][2]) * 0.5f;
+    *reinterpret_cast<f32x4*>(o + 2 * plane) = (t[r][1] + t[r][2]) * 0.5f + t[r][3];
+  }
+}
+
 // ---- host -----------------------------------------------------------------------------------------------------
 static bool wino_ok(const lmh_conv_desc* d) {
   return d->R == 3 && d->S == 3 && d->stride == 1 && d->dilation == 1 && d->pad_top == 1 && d->pad_left == 1 &&
@@ -253,4 +321,51 @@ extern "C" int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float*
   const int n = d->K * (d->C / 4);
   hipLaunchKernelGGL(k_wino_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, U);
   return wino_run(d, dy, d->K, d->C, U, V, Mo, nullptr, nullptr, addend, -INFINITY, INFINITY, dx, st);
+}
+
+// ---- weight gradient -------------------------------------------------------------------------------------------
+static lmh_conv_desc wino_gemm_desc(const lmh_conv_desc* d, int T) {
+  lmh_conv_desc g = *d;        // 16 stacked [T x C]^T [T x K] products as the taps of a fake 4x4 filter
+  g.N = 1; g.H = T; g.W = 1; g.OH = T; g.OW = 1; g.R = 4; g.S = 4;
+  g.stride = 1; g.dilation = 0; g.pad_top = 0; g.pad_left = 0; g.act = 0;
+  return g;
+}
+
+extern "C" size_t lmh_conv2d_bwd_weight_winograd_workspace_bytes(const lmh_conv_desc* d) {
+  if (!d || !wino_ok(d)) return 0;
+  const int T = d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+  const lmh_conv_desc g = wino_gemm_desc(d, T);
+  const size_t planes = 16 * sizeof(float) * ((size_t)T * d->C + (size_t)T * d->K + (size_t)d->C * d->K);
+  return lmh_align_up(planes, 256) + lmh_conv2d_bwd_weight_workspace_bytes(&g);
+}
+
+extern "C" int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const float* x, const float* dy, float* dw,
+                                              void* ws, size_t ws_bytes, lmh_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  LMH_CHECK_ARG(x && dy && dw && wino_ok(d));
+  if (!ws || ws_bytes < lmh_conv2d_bwd_weight_winograd_workspace_bytes(d)) {
+    lmh_set_error("lmh_conv2d_bwd_weight_winograd: workspace too small");
+    return LMH_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int T = d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+  float* V = reinterpret_cast<float*>(ws);
+  float* dM = V + 16 * (size_t)T * d->C;
+  float* dU = dM + 16 * (size_t)T * d->K;
+  const size_t planes = lmh_align_up(16 * sizeof(float) * ((size_t)T * d->C + (size_t)T * d->K + (size_t)d->C * d->K), 256);
+  void* ws2 = reinterpret_cast<char*>(ws) + planes;
+  {
+    const int64_t n = (int64_t)T * (d->C / 4);
+    hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
+    const int64_t m = (int64_t)T * (d->K / 4);
+    hipLaunchKernelGGL(k_wino_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
+  }
+  const lmh_conv_desc g = wino_gemm_desc(d, T);
+  rc = bwd_weight_launch(&g, V, dM, nullptr, dU, nullptr, ws2, ws_bytes - planes, st, true);
+  if (rc) return rc;
+  const int n = d->C * (d->K / 4);
+  hipLaunchKernelGGL(k_wino_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
 }

@@ -20,5 +20,11 @@ for name, N, H, C, Kc in [('rpn 3x3 1024->512 @64', 2, 64, 1024, 512), ('b3 3x3 
          timeit(lambda: K.conv2d_fwd_winograd(d, x, w, sc, sh, out=y)) * 1e3,
          timeit(lambda: K.conv2d_bwd_data(d, g, w, sc, out=dx)) * 1e3,
          timeit(lambda: K.conv2d_bwd_data_winograd(d, g, w, sc, out=dx)) * 1e3]
+    dw = torch.empty_like(w)
+    K.WINOGRAD = False
+    t.append(timeit(lambda: K.conv2d_bwd_weight(d, x, g, out=dw)) * 1e3)
+    K.WINOGRAD = True
+    t.append(timeit(lambda: K.conv2d_bwd_weight_winograd(d, x, g, out=dw)) * 1e3)
     print('%-30s %7.1f GF | fwd direct %7.1f us (%5.1f TF) winograd %7.1f us (%5.1f TF-eq) | bwd_data direct %7.1f us '
-          'winograd %7.1f us' % (name, gf, t[0], gf / t[0] * 1e3, t[1], gf / t[1] * 1e3, t[2], t[3]))
+          'winograd %7.1f us | bwd_weight direct %7.1f us winograd %7.1f us' %
+          (name, gf, t[0], gf / t[0] * 1e3, t[1], gf / t[1] * 1e3, t[2], t[3], t[4], t[5]))

@@ -471,6 +471,14 @@ def test_conv_winograd_equals_direct(K, case):
     tolx = 4e-5 * max(1.0, float(xt.grad.abs().max()))
     np.testing.assert_allclose(dx_win.cpu().numpy(), xt.grad.numpy() + add, rtol=2e-4, atol=tolx)
     np.testing.assert_allclose(dx_win.cpu().numpy(), dx_dir.cpu().numpy(), rtol=2e-4, atol=tolx)
+    dw_dir = K.conv2d_bwd_weight(d, T(x), T(g)) if not K.WINOGRAD else None
+    dw_win = K.conv2d_bwd_weight_winograd(d, T(x), T(g))               # raw: w.r.t. the un-scaled conv output
+    wt = torch.tensor(w, requires_grad=True)
+    ot.conv2d_nhwc(torch.tensor(x), wt, 1, 1, 'SAME').backward(torch.tensor(g))
+    tolw = 1e-4 * max(1.0, float(wt.grad.abs().max()))
+    np.testing.assert_allclose(dw_win.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=tolw)
+    if dw_dir is not None:
+        np.testing.assert_allclose(dw_win.cpu().numpy(), dw_dir.cpu().numpy(), rtol=1e-3, atol=tolw)
     dx0 = K.conv2d_bwd_data_winograd(d, T(g), T(w))                    # no kscale, no addend
     xt.grad = None
     ot.conv2d_nhwc(xt, torch.tensor(w), 1, 1, 'SAME').backward(torch.tensor(g))

@@ -61,6 +61,7 @@ def test_train_step_matches_oracle(setup, winograd, monkeypatch):
     from luminoth_amd import kernels as KK
     monkeypatch.setattr(KK, 'WINOGRAD', winograd)
     monkeypatch.setattr(KK, 'WINOGRAD_MIN_CK', 64 * 64)
+    monkeypatch.setattr(KK, 'WINOGRAD_WGRAD_MIN_CK', 64 * 64)
     cfg, model, images, gts = setup
     model._step = 0
     pred = model(images, gts, is_training=True)
