@@ -111,10 +111,14 @@ int lmh_bn_param_grads(const float* w, float* dw_raw_inout, const float* dbeta,
  * Conv2D of rpn.py:69-75, slim conv2d of vgg / resnet 3x3 layers).  ws: lmh_conv2d_winograd_workspace_bytes(d). */
 int lmh_conv2d_winograd_ok(const lmh_conv_desc* d);
 size_t lmh_conv2d_winograd_workspace_bytes(const lmh_conv_desc* d);
-int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
-                            const float* shift, const float* residual, float* y, void* ws,
-                            size_t ws_bytes, lmh_stream_t stream);
-int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w,
+/* u: 16*C*K floats of transformed weights from lmh_conv2d_winograd_transform_weights (forward: G w G^T as
+ * [16][C][K]; backward: of w[2-r][2-s][c][k]*kscale[k] as [16][K][C]), or NULL to transform inside the call. */
+int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, const float* w, const float* kscale,
+                                          int backward, float* u, lmh_stream_t stream);
+int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float* w, const float* u,
+                            const float* scale, const float* shift, const float* residual, float* y,
+                            void* ws, size_t ws_bytes, lmh_stream_t stream);
+int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w, const float* u,
                                  const float* kscale, const float* addend, float* dx, void* ws,
                                  size_t ws_bytes, lmh_stream_t stream);
 /* dw (RAW, like lmh_conv2d_bwd_weight) = G^T [ sum_tiles (B^T x B)^T (A dy A^T) ] G. */

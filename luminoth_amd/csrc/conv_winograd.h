@@ -292,35 +292,61 @@ static int wino_carve(const lmh_conv_desc* d, void* ws, size_t ws_bytes, int Cg,
   return LMH_OK;
 }
 
-extern "C" int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
-                                       const float* shift, const float* residual, float* y, void* ws,
-                                       size_t ws_bytes, lmh_stream_t stream) {
+// The transformed weights depend on nothing but the weights (and, backward, the BN scale): the train step computes
+// them for every Winograd layer on the idle weight-gradient stream at the start of the step and passes them in
+// (u != NULL); with u == NULL they are computed here, into the workspace.
+extern "C" int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, const float* w, const float* kscale,
+                                                     int backward, float* u, lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  LMH_CHECK_ARG(x && w && y && wino_ok(d));
+  LMH_CHECK_ARG(w && u && wino_ok(d));
+  hipStream_t st = (hipStream_t)stream;
+  if (backward) {
+    const int n = d->K * (d->C / 4);
+    hipLaunchKernelGGL(k_wino_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, u);
+  } else {
+    const int n = d->C * (d->K / 4);
+    hipLaunchKernelGGL(k_wino_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, u);
+  }
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+extern "C" int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float* w, const float* u,
+                                       const float* scale, const float* shift, const float* residual, float* y,
+                                       void* ws, size_t ws_bytes, lmh_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  LMH_CHECK_ARG(x && (w || u) && y && wino_ok(d));
   float *U, *V, *Mo;
   rc = wino_carve(d, ws, ws_bytes, d->C, d->K, &U, &V, &Mo);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int n = d->C * (d->K / 4);
-  hipLaunchKernelGGL(k_wino_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, U);
+  if (!u) {
+    const int n = d->C * (d->K / 4);
+    hipLaunchKernelGGL(k_wino_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, U);
+    u = U;
+  }
   const float lo = d->act ? 0.f : -INFINITY, hi = (d->act == 2) ? 6.f : INFINITY;
-  return wino_run(d, x, d->C, d->K, U, V, Mo, scale, shift, residual, lo, hi, y, st);
+  return wino_run(d, x, d->C, d->K, u, V, Mo, scale, shift, residual, lo, hi, y, st);
 }
 
-extern "C" int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w,
+extern "C" int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w, const float* u,
                                             const float* kscale, const float* addend, float* dx, void* ws,
                                             size_t ws_bytes, lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  LMH_CHECK_ARG(dy && w && dx && wino_ok(d));
+  LMH_CHECK_ARG(dy && (w || u) && dx && wino_ok(d));
   float *U, *V, *Mo;
   rc = wino_carve(d, ws, ws_bytes, d->K, d->C, &U, &V, &Mo);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int n = d->K * (d->C / 4);
-  hipLaunchKernelGGL(k_wino_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, U);
-  return wino_run(d, dy, d->K, d->C, U, V, Mo, nullptr, nullptr, addend, -INFINITY, INFINITY, dx, st);
+  if (!u) {
+    const int n = d->K * (d->C / 4);
+    hipLaunchKernelGGL(k_wino_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, U);
+    u = U;
+  }
+  return wino_run(d, dy, d->K, d->C, u, V, Mo, nullptr, nullptr, addend, -INFINITY, INFINITY, dx, st);
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------

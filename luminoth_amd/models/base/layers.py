@@ -120,6 +120,28 @@ class ConvLayer(object):
         d = self.desc(x.shape)
         return K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub)
 
+    def prepare_winograd(self):
+        """Transformed weights of this layer for the shapes it has already seen, computed on the CURRENT stream
+        (the idle weight-gradient stream at the start of the fused train step) and published in
+        K.WINOGRAD_READY until the step ends.  No-op for layers the Winograd path does not take."""
+        if self.k != 3 or not K.WINOGRAD:
+            return False
+        for d in self._desc.values():
+            if not K._use_winograd(d):
+                continue
+            bufs = getattr(self, '_wino_u', None)
+            if bufs is None:
+                n = 16 * self.cin * self.cout
+                bufs = self._wino_u = (torch.empty(n, dtype=torch.float32, device=self.w.device),
+                                       torch.empty(n, dtype=torch.float32, device=self.w.device)
+                                       if self.trainable else None)
+            K.winograd_transform_weights(d, self.w, None, False, bufs[0])
+            if bufs[1] is not None:
+                K.winograd_transform_weights(d, self.w, self.scale if self.norm == 'bn' else None, True, bufs[1])
+            K.WINOGRAD_READY[self.w.data_ptr()] = bufs
+            return True
+        return False
+
     def _weight_grads(self, d, x, g, yact, colsum):
         K.conv2d_bwd_weight(d, x, g, out=self.gw, yact=yact, colsum=colsum)
         if self.norm == 'bn':

@@ -33,6 +33,7 @@ from luminoth_amd.utils.anchors import generate_anchors_reference, truncate_refe
 
 
 PREFIX_OVERLAP = os.environ.get('LUMINOTH_AMD_PREFIX_OVERLAP', '0') == '1'
+PREPARE_WINOGRAD = os.environ.get('LUMINOTH_AMD_PREPARE_WINOGRAD', '0') == '1'   # measured neutral (8.95 vs 8.98 ms): the transforms then compete with the HBM-bound stem / block1 kernels
 PREFIX_AFTER_NODE = int(os.environ.get('LUMINOTH_AMD_PREFIX_AFTER_NODE', '-1'))
 
 
@@ -270,6 +271,18 @@ class FasterRCNN(object):
                     self._tgt_event.record(aux)
             for t in (gt, gt_count, seeds):
                 t.record_stream(aux)
+            # Winograd layers: the transformed weights (forward and backward-data variants) depend only on the
+            # weights and the BN scale, so they are produced on the weight-gradient stream — idle during the
+            # forward pass — instead of in front of each layer's GEMMs on the main stream.
+            if PREPARE_WINOGRAD and K.WINOGRAD:
+                self.base_network.bn_table.refresh()
+                side = SideStream.get(self.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    n = sum(bool(l.prepare_winograd()) for l in self._winograd_layers())
+                    if n:
+                        K.WINOGRAD_EVENT = torch.cuda.Event()
+                        K.WINOGRAD_EVENT.record(side)
             # The frozen prefix of the trunk (conv1 + block1) needs nothing the optimizer writes: it runs on the
             # aux stream, ordered only after the previous step's trunk backward, i.e. underneath that step's
             # weight-gradient backlog, gradient exchange and update instead of behind them.
@@ -347,6 +360,8 @@ class FasterRCNN(object):
                 if PREFIX_AFTER_NODE < 0:
                     self._bwd_done.record(main)
         SideStream.join()
+        K.WINOGRAD_READY.clear()      # the optimizer is about to change the weights
+        K.WINOGRAD_EVENT = None
         rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})
         rpn_pred['num_proposals'] = prop['num_proposals']
         self._last_losses = dict(rpn_losses, total_loss=total_loss, no_reg_loss=no_reg_loss,
@@ -354,6 +369,16 @@ class FasterRCNN(object):
         pred = {'rpn_prediction': rpn_pred, 'classification_prediction': cp, 'rpn_loss_dict': rpn_losses,
                 'rcnn_loss_dict': rcnn_losses, '_batch': {'B': B, 'unbatched': False}}
         return total_loss, pred
+
+    def _winograd_layers(self):
+        ls = getattr(self, '_wino_layers', None)
+        if ls is None:
+            ls = [l for l in self.base_network.trunk.all_layers() if getattr(l, 'k', 0) == 3]
+            if self.base_network.tail is not None:
+                ls += [l for l in self.base_network.tail.all_layers() if getattr(l, 'k', 0) == 3]
+            ls.append(self._rpn._rpn)
+            self._wino_layers = ls
+        return ls
 
     def _aux_stream(self):
         st = getattr(self, '_aux', None)

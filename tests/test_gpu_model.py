@@ -228,7 +228,12 @@ def test_fused_two_stream_step_equals_plain_step(setup):
     torch.cuda.synchronize()
     g_plain = model.store.grad.clone()
     model._step = 0
-    total, pred2 = model.train_step(images, gts)
+    from luminoth_amd.models.fasterrcnn import fasterrcnn as FR
+    FR.PREPARE_WINOGRAD = True          # also exercises the transformed weights prepared on the side stream
+    try:
+        total, pred2 = model.train_step(images, gts)
+    finally:
+        FR.PREPARE_WINOGRAD = False
     torch.cuda.synchronize()
     g_fused = model.store.grad.clone()
     np.testing.assert_allclose(float(total), float(losses['total_loss']), rtol=1e-6)
