@@ -106,12 +106,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (the product path has no CPU fallback)')
+    backend = os.environ.get('LUMINOTH_AMD_DIST_BACKEND', 'nccl')   # 'gloo': ranks may share a GPU (control-flow test)
+    if backend != 'nccl':
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, (world, args.gpus)
 
     from luminoth_amd import kernels as K
@@ -135,7 +141,7 @@ def main():
             sd[k].fill_(16.0)
     model.load_state_dict(sd)
     broadcast_parameters(model)
-    sd0 = model.state_dict() if (rank == 0 and not args.no_cpu_baseline) else None
+    sd0 = model.state_dict() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     opt = get_optimizer(cfg.train, model)
     H = W = args.size
     images, gts = synth_batch(args.batch, H, W, 8, args.classes, 100 + rank, device)
@@ -161,9 +167,14 @@ def main():
     assert np.isfinite(loss_val), 'train step diverged (loss %r)' % loss_val
 
     roofline = None
+    nprof = min(args.steps, 3)
+    if not args.no_roofline and rank != 0:
+        # the per-launch profiling steps contain the gradient all-reduce: every rank has to take them
+        for _ in range(nprof):
+            train_step(model, opt, images, gts)
+        torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
         K._Profile.start()
-        nprof = min(args.steps, 3)
         for _ in range(nprof):
             train_step(model, opt, images, gts)
         prof = K._Profile.stop()
@@ -206,7 +217,7 @@ def main():
                        'global_batch': gb, 'parallelism': 'dp%d' % world, 'final_total_loss': loss_val},
             'roofline': roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
             out['cpu_baseline'] = cpu_baseline({'arch': args.arch}, sd0, H, W, 8, args.classes, args.cpu_images)
         print(json.dumps(out))
     if world > 1:
