@@ -102,6 +102,10 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        # main, aux, two weight-gradient side streams, the bucket stream and RCCL's own: more streams than the 4
+        # hardware queues HIP creates by default (read at runtime initialisation, i.e. before the first cuda call)
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
