@@ -106,3 +106,43 @@ def test_param_store_layout_cpu():
     sd['a/weights'] = torch.zeros(3, 5)
     st.load_state_dict(sd)
     assert float(st.flat[:15].abs().sum()) == 0.
+
+
+def test_gradient_bucket_plan_on_resnet50_layout():
+    """utils/training.py GradientBuckets._plan (pure host logic): for the ResNet-50 Faster R-CNN parameter layout the
+    early buckets are contiguous, disjoint, end-aligned with whole trunk nodes, cover the heads, and leave only the
+    first trunk nodes + the BatchNorm block to finish()."""
+    from luminoth_amd.models import get_model
+    from luminoth_amd.utils.config import get_config
+    from luminoth_amd.utils.training import GradientBuckets
+    cfg = get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': 80},
+                                'base_network': {'architecture': 'resnet_v1_50'}}, 'train': {'seed': 0}})
+    model = get_model('fasterrcnn')(cfg, device='cpu')
+    st = model.store
+    numel = int(st.grad.numel())
+    trunk = model.base_network.trunk
+    nodes = trunk.nodes[trunk.first_trainable():]
+    b = GradientBuckets(st, reduce_fn=lambda t: None, bucket_bytes=12 << 20)
+    plan = b._plan(nodes)
+    assert b._plan(nodes) is plan                                         # cached per trunk
+    assert len(nodes) in plan                                              # heads bucket launched before the loop
+    heads_lo, heads_hi = plan[len(nodes)]
+    assert heads_hi == numel and heads_lo % 4 == 0
+    rpn_lo = min(o for n, (t, o, c) in st.offsets.items() if t and '/rpn/' in n)
+    assert heads_lo <= rpn_lo                                              # RPN + RCNN are inside the heads bucket
+    trunk_names = set(nm for n in nodes for l in n.layers for nm in l.var_names())
+    trunk_hi = max(o + c for n, (t, o, c) in st.offsets.items() if t and n in trunk_names)
+    assert heads_lo >= trunk_hi                                            # no trunk parameter inside it
+    ranges = sorted(v for k, v in plan.items())
+    for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+        assert a1 <= b0                                                    # disjoint
+    node_buckets = {k: v for k, v in plan.items() if k < len(nodes)}
+    assert node_buckets and all((hi - lo) * 4 >= 12 << 20 for lo, hi in node_buckets.values())
+    for j, (lo, hi) in node_buckets.items():
+        w0 = min(st.offsets[l.w_name][1] for l in nodes[j].layers)
+        assert lo == w0                                                    # starts at the first weight of node j
+    covered = sum(hi - lo for lo, hi in plan.values())
+    assert 0.85 * numel < covered < numel                                  # >85 % of the buffer goes out early
+    # a trunk whose weights are not laid out node after node gets no early buckets
+    b2 = GradientBuckets(st, reduce_fn=lambda t: None, bucket_bytes=1 << 20)
+    assert b2._plan(list(reversed(nodes))) == {}
