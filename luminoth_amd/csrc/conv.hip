@@ -76,7 +76,8 @@ static bool fwd_fast(const lmh_conv_desc* d) { return (d->C % BK) == 0 && (d->K 
 static bool bwd_data_fast(const lmh_conv_desc* d) { return (d->K % BK) == 0 && (d->C & 3) == 0; }
 // Stride-2 3x3 backward data walks the pixels parity class by parity class (k_conv_bwd_data): the classes carry
 // 1, 2, 2 and 4 taps, so with one 128-row tile per CU the launch lasts as long as its 4-tap tiles.  64x64 tiles
-// (several per CU, scheduled dynamically) even that out: 56 -> measured below in scripts/bench_conv.py.
+// (several per CU, scheduled dynamically) even that out (block2 unit4: 91 us before tap skipping, 56.7 us with
+// 128x128 tiles, 55.3 us with 64x64 — scripts/bench_conv.py "3x3/2").
 static void bwd_data_parity_tile(const lmh_conv_desc* d, int64_t M, int* bm, int* bn) {
   static const int on = env_int("LMH_BD_PARITY_SMALL", 1);
   if (!on || !bwd_data_fast(d) || g_force_bm) return;
