@@ -318,6 +318,7 @@ extern "C" size_t lmh_nms_workspace_bytes(int B, int K) {
 
 int lmh_nms_impl(const float* boxes, const int32_t* counts, int B, int K, float thr, int max_out,
                     int32_t* keep_idx, int32_t* keep_count, void* ws, hipStream_t st) {
+  LMH_CHECK_ARG(K > 0 && K <= 64 * NMS_MAX_W);   // k_nms_reduce keeps the removed-bitmap in static LDS
   const int W = (K + 63) / 64;
   uint64_t* mask = reinterpret_cast<uint64_t*>(ws);
   dim3 g(W, W, B);

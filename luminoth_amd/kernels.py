@@ -164,12 +164,6 @@ def _use_winograd(d):
     return WINOGRAD and d.R == 3 and d.C * d.K >= WINOGRAD_MIN_CK and winograd_ok(d)
 
 
-# Transformed weights prepared ahead of use (ConvLayer.prepare_winograd on the side stream at the start of the
-# fused train step): {weight data_ptr: (U forward or None, U backward or None)}; cleared at the end of the step.
-WINOGRAD_READY = {}
-WINOGRAD_EVENT = None        # recorded on the preparing stream; consumers wait on it before their first use
-
-
 def winograd_transform_weights(d, w, kscale, backward, out):
     check(_lib.load().lmh_conv2d_winograd_transform_weights(ctypes.byref(d), _p(_f32(w)), _p(kscale),
                                                             int(bool(backward)), _p(out), _stream()),
@@ -181,9 +175,7 @@ def conv2d_fwd_winograd(d, x, w, scale=None, shift=None, residual=None, out=None
     lib = _lib.load()
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
     ws = _workspace(lib.lmh_conv2d_winograd_workspace_bytes(ctypes.byref(d)), x.device, 'winograd')
-    u = WINOGRAD_READY.get(w.data_ptr(), (None, None))[0]
-    if u is not None and WINOGRAD_EVENT is not None:
-        torch.cuda.current_stream(x.device).wait_event(WINOGRAD_EVENT)
+    u = None      # transformed weights are produced inside the call (they change every step)
     with _timed(d, 0, wino=True):
         check(lib.lmh_conv2d_fwd_winograd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(u), _p(scale), _p(shift),
                                           _p(residual), _p(y), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
@@ -195,9 +187,7 @@ def conv2d_bwd_data_winograd(d, dy, w, kscale=None, addend=None, out=None):
     lib = _lib.load()
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
     ws = _workspace(lib.lmh_conv2d_winograd_workspace_bytes(ctypes.byref(d)), dy.device, 'winograd')
-    u = WINOGRAD_READY.get(w.data_ptr(), (None, None))[1]
-    if u is not None and WINOGRAD_EVENT is not None:
-        torch.cuda.current_stream(dy.device).wait_event(WINOGRAD_EVENT)
+    u = None
     with _timed(d, 1, wino=True):
         check(lib.lmh_conv2d_bwd_data_winograd(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(u), _p(kscale),
                                                _p(addend), _p(dx), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),

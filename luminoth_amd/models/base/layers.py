@@ -24,9 +24,9 @@ BN_EPS = 1e-5  # slim resnet_arg_scope batch_norm_epsilon (truncated_base_networ
 # hook(nodes, len(nodes)) before the first node: lets the data-parallel layer start all-reducing finished gradient
 # ranges under the rest of the backward pass.
 BACKWARD_HOOK = None
-# (j, callable): called once node j's backward is enqueued (the fused train step marks the point after which the
-# next step's frozen prefix may start)
-PROGRESS_HOOK = None
+# Test instrumentation: when set to a dict, every ConvLayer.forward stores its output under the layer scope, so a
+# parity test can hand the kernels' own ReLU decisions to the oracle (tests/e2e_util.py).  None in production.
+ACT_TAP = None
 
 
 class SideStream(object):
@@ -35,27 +35,19 @@ class SideStream(object):
     so running it beside bwd_data fills the CUs each kernel leaves idle in its prologue / tail.
     `join()` makes the caller's stream wait for everything enqueued here (before all-reduce / update)."""
     enabled = os.environ.get('LUMINOTH_AMD_SIDE_STREAM', '1') != '0'
-    # Side streams per issuing stream, used round-robin layer by layer.  ONE by default: two were meant to run a
-    # layer's short tail (split-K reduce, BN dot, BN finish) under the next layer's bwd_weight, but three
-    # MFMA-heavy kernels in flight (bwd_data + two bwd_weight) thrash each other: 10.45 -> 13.8 ms/step on
-    # MI355X (15.1 ms with GPU_MAX_HW_QUEUES=8, so it is contention, not hardware-queue aliasing).
-    fanout = max(1, int(os.environ.get('LUMINOTH_AMD_SIDE_STREAMS', '1')))
+    # ONE side stream per issuing stream: two MFMA-heavy kernels in flight fill each other's prologues / tails,
+    # three (bwd_data + two bwd_weight) thrash each other (measured 10.45 -> 13.8 ms/step on MI355X).
     # The side stream lags the data-gradient stream, so when the main stream finishes the trunk backward it
-    # idles while the side stream drains its backlog.  The weight gradients of the LAST `inline_tail` trunk nodes
-    # of the backward are therefore issued on the main stream itself (behind that layer's data gradient).
-    inline_tail = int(os.environ.get('LUMINOTH_AMD_INLINE_TAIL', '0'))        # whole nodes
-    inline_layers = int(os.environ.get('LUMINOTH_AMD_INLINE_LAYERS', '4'))    # or single conv layers
-    force_inline = False
+    # would idle while the side stream drains its backlog: the weight gradients of the LAST `inline_layers`
+    # trainable conv layers of a trunk backward are issued on the main stream itself, behind that layer's data
+    # gradient (10.43 -> 10.13 ms/step).
+    inline_layers = 4
     layers_left = 0
-    _streams = {}      # (device, issuing stream, slot) -> stream (the fused train step issues from two streams)
-    _next = {}
+    _streams = {}      # (device, issuing stream) -> stream (the fused train step issues from two streams)
 
     @classmethod
     def get(cls, device):
-        issuer = (device, K._stream_id(device))
-        slot = cls._next.get(issuer, 0)
-        cls._next[issuer] = (slot + 1) % cls.fanout
-        key = issuer + (slot,)
+        key = (device, K._stream_id(device))
         st = cls._streams.get(key)
         if st is None:
             st = torch.cuda.Stream(device=device)
@@ -118,29 +110,10 @@ class ConvLayer(object):
 
     def forward(self, x, residual=None, in_sub=None):
         d = self.desc(x.shape)
-        return K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub)
-
-    def prepare_winograd(self):
-        """Transformed weights of this layer for the shapes it has already seen, computed on the CURRENT stream
-        (the idle weight-gradient stream at the start of the fused train step) and published in
-        K.WINOGRAD_READY until the step ends.  No-op for layers the Winograd path does not take."""
-        if self.k != 3 or not K.WINOGRAD:
-            return False
-        for d in self._desc.values():
-            if not K._use_winograd(d):
-                continue
-            bufs = getattr(self, '_wino_u', None)
-            if bufs is None:
-                n = 16 * self.cin * self.cout
-                bufs = self._wino_u = (torch.empty(n, dtype=torch.float32, device=self.w.device),
-                                       torch.empty(n, dtype=torch.float32, device=self.w.device)
-                                       if self.trainable else None)
-            K.winograd_transform_weights(d, self.w, None, False, bufs[0])
-            if bufs[1] is not None:
-                K.winograd_transform_weights(d, self.w, self.scale if self.norm == 'bn' else None, True, bufs[1])
-            K.WINOGRAD_READY[self.w.data_ptr()] = bufs
-            return True
-        return False
+        y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub)
+        if ACT_TAP is not None:
+            ACT_TAP[self.scope] = y
+        return y
 
     def _weight_grads(self, d, x, g, yact, colsum):
         K.conv2d_bwd_weight(d, x, g, out=self.gw, yact=yact, colsum=colsum)
@@ -184,7 +157,7 @@ class ConvLayer(object):
             g, yact = dy, y                               # fused: kernels mask on load
         else:
             g = K.act_bwd(dy, y, self.act, want_g=True, colsum=None if colsum_in_wgrad else colsum)
-        inline = SideStream.force_inline or (self.trainable and 0 < SideStream.layers_left <= SideStream.inline_layers)
+        inline = self.trainable and 0 < SideStream.layers_left <= SideStream.inline_layers
         if self.trainable:
             SideStream.layers_left -= 1
         dx = None
@@ -427,15 +400,11 @@ class Trunk(object):
         SideStream.layers_left = sum(1 for n in nodes for l in n.layers if l.trainable)
         for j in range(len(nodes) - 1, -1, -1):
             need_dx = (j > 0) or need_dx_first
-            SideStream.force_inline = j < SideStream.inline_tail
             # node j-1's output activation is folded into node j's data gradient (fused epilogue mask)
             below = nodes[j - 1].out_act if (j > 0 and FUSE_MASK) else None
             dy = nodes[j].backward(saved[j], dy, need_dx, dy_is_g=dy_is_g, mask_input=below)
             dy_is_g = below is not None
             if hook is not None:
                 hook(nodes, j)
-            if PROGRESS_HOOK is not None and PROGRESS_HOOK[0] == j:
-                PROGRESS_HOOK[1]()
-        SideStream.force_inline = False
         SideStream.layers_left = 0
         return dy

@@ -133,18 +133,7 @@ class TruncatedBaseNetwork(BaseNetwork):
         self._anchor = torch.zeros(1, device=store.flat.device, requires_grad=True)
 
     # ---- forward ------------------------------------------------------------------
-    def frozen_prefix(self, x):
-        """Forward of the frozen leading nodes (conv1 / block1 under `fine_tune_from: block2`) on the CURRENT
-        stream.  It depends on nothing the optimizer touches, so the fused train step runs it on the auxiliary
-        stream underneath the tail of the previous step.  Returns None when there is no frozen prefix."""
-        start = self.trunk.first_trainable()
-        if start == 0 or start >= len(self.trunk.nodes):
-            return None
-        with torch.no_grad():
-            y, _ = L.Trunk(self.trunk.nodes[:start]).forward(x.contiguous(), save_from=None)
-        return y
-
-    def _run(self, trunk, x, is_training, prefix_out=None):
+    def _run(self, trunk, x, is_training):
         if is_training and self._config.get('train_batch_norm'):
             raise NotImplementedError('train_batch_norm: True (BatchNorm in training mode) is not implemented; '
                                       'the reference default is False (base_config.yml:147)')
@@ -155,11 +144,8 @@ class TruncatedBaseNetwork(BaseNetwork):
             return y
         if not x.requires_grad:
             # frozen prefix: forward only, nothing saved
-            if prefix_out is not None:
-                x = prefix_out
-            else:
-                pre = L.Trunk(trunk.nodes[:start])
-                x, _ = pre.forward(x, save_from=None)
+            pre = L.Trunk(trunk.nodes[:start])
+            x, _ = pre.forward(x, save_from=None)
             sub = L.Trunk(trunk.nodes[start:])
             return _TrunkFn.apply(x, self._anchor, sub, 0, False)
         return _TrunkFn.apply(x, self._anchor, trunk, 0, True)
@@ -168,11 +154,10 @@ class TruncatedBaseNetwork(BaseNetwork):
         """Spatial size of the feature map for an (H, W) input (no launch)."""
         return self.trunk.out_hw(H, W)
 
-    def __call__(self, inputs, is_training=False, prefix_out=None):
-        """inputs (B,H,W,3) fp32 RGB 0..255 -> feature map (B,fh,fw,C).  prefix_out: result of
-        `frozen_prefix(inputs)` computed elsewhere (already ordered before the current stream)."""
+    def __call__(self, inputs, is_training=False):
+        """inputs (B,H,W,3) fp32 RGB 0..255 -> feature map (B,fh,fw,C)."""
         self.bn_table.refresh()
-        return self._run(self.trunk, inputs.contiguous(), is_training, prefix_out)
+        return self._run(self.trunk, inputs.contiguous(), is_training)
 
     def _build_tail(self, inputs, is_training=False):
         if not self._use_tail or self.tail is None:

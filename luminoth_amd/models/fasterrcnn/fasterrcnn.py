@@ -16,8 +16,6 @@ per-image counts (`num_proposals`, `num_objects`) so that the train step never
 synchronises with the host.  For un-batched inference calls the results are
 truncated to the reference's exact shapes.
 """
-import os
-
 import numpy as np
 import torch
 
@@ -31,10 +29,6 @@ from luminoth_amd.params import ParamStore
 from luminoth_amd.utils import rng
 from luminoth_amd.utils.anchors import generate_anchors_reference, truncate_reference, all_anchors_numpy
 
-
-PREFIX_OVERLAP = os.environ.get('LUMINOTH_AMD_PREFIX_OVERLAP', '0') == '1'
-PREPARE_WINOGRAD = os.environ.get('LUMINOTH_AMD_PREPARE_WINOGRAD', '0') == '1'   # measured neutral (8.95 vs 8.98 ms): the transforms then compete with the HBM-bound stem / block1 kernels
-PREFIX_AFTER_NODE = int(os.environ.get('LUMINOTH_AMD_PREFIX_AFTER_NODE', '-1'))
 
 
 class FasterRCNN(object):
@@ -256,48 +250,12 @@ class FasterRCNN(object):
         aux = self._aux_stream()
         self.store.grad.zero_()
         with torch.enable_grad():
-            # RPN anchor targets depend on anchors + gt only: they run on the aux stream under the trunk
-            # forward instead of between the RPN forward and backward.
             fh, fw = self.base_network.feature_hw(H, W)
             rpn = self._rpn
             rpn_tgt = {}
-            early = os.environ.get('LUMINOTH_AMD_EARLY_TARGETS', '0') == '1'   # A/B on MI355X: -0.26 ms/step when off
-            if early:
-                aux.wait_stream(main)
-                with torch.cuda.stream(aux):
-                    rpn.targets(rpn_tgt, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds,
-                                im_shape)
-                    self._tgt_event = torch.cuda.Event()
-                    self._tgt_event.record(aux)
             for t in (gt, gt_count, seeds):
                 t.record_stream(aux)
-            # Winograd layers: the transformed weights (forward and backward-data variants) depend only on the
-            # weights and the BN scale, so they are produced on the weight-gradient stream — idle during the
-            # forward pass — instead of in front of each layer's GEMMs on the main stream.
-            if PREPARE_WINOGRAD and K.WINOGRAD:
-                self.base_network.bn_table.refresh()
-                side = SideStream.get(self.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    n = sum(bool(l.prepare_winograd()) for l in self._winograd_layers())
-                    if n:
-                        K.WINOGRAD_EVENT = torch.cuda.Event()
-                        K.WINOGRAD_EVENT.record(side)
-            # The frozen prefix of the trunk (conv1 + block1) needs nothing the optimizer writes: it runs on the
-            # aux stream, ordered only after the previous step's trunk backward, i.e. underneath that step's
-            # weight-gradient backlog, gradient exchange and update instead of behind them.
-            pre = None
-            if PREFIX_OVERLAP:
-                ev = getattr(self, '_bwd_done', None)
-                if ev is not None:
-                    aux.wait_event(ev)
-                with torch.cuda.stream(aux):
-                    pre = self.base_network.frozen_prefix(image)
-                if pre is not None:
-                    image.record_stream(aux)
-                    main.wait_stream(aux)
-                    pre.record_stream(main)
-            feat = self.base_network(image, is_training=True, prefix_out=pre)
+            feat = self.base_network(image, is_training=True)
             assert (feat.shape[1], feat.shape[2]) == (fh, fw)
             f_rpn = feat.detach().requires_grad_(True)
             f_rcnn = feat.detach().requires_grad_(True)
@@ -312,19 +270,11 @@ class FasterRCNN(object):
                                      self._anchor_ref_i32, (fh, fw), self._anchor_stride, im_shape)
             for t in (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred'], feat):
                 t.record_stream(aux)
-            # ---- main stream: RPN loss -> RPN backward (targets were produced on aux before the proposals)
-            if early:
-                main.wait_event(self._tgt_event)
-                for t in rpn_tgt.values():
-                    t.record_stream(main)
-            else:
-                rpn.targets(rpn_tgt, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape)
+            # ---- main stream: RPN targets -> RPN loss -> RPN backward
+            rpn.targets(rpn_tgt, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape)
             rpn_pred.update(rpn_tgt)
             rpn_losses = rpn.loss(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
-            rpn_inline = os.environ.get('LUMINOTH_AMD_RPN_INLINE', '0') == '1'
-            SideStream.force_inline = rpn_inline
             (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss']).backward()
-            SideStream.force_inline = False
             # ---- aux stream: RCNN forward -> RCNN loss -> RCNN backward
             with torch.cuda.stream(aux):
                 cp = self._rcnn(f_rcnn, prop['proposals'], prop['num_proposals'], im_shape, self.base_network,
@@ -347,21 +297,10 @@ class FasterRCNN(object):
             buckets = _tr.ACTIVE_BUCKETS
             if buckets is not None and buckets.store is self.store:
                 buckets.arm(self.base_network.trunk)
-            if PREFIX_OVERLAP:
-                from luminoth_amd.models.base import layers as _L
-                self._bwd_done = torch.cuda.Event()
-                mark = lambda: self._bwd_done.record(torch.cuda.current_stream(self.device))   # noqa: E731
-                _L.PROGRESS_HOOK = (PREFIX_AFTER_NODE, mark) if PREFIX_AFTER_NODE >= 0 else None
             feat.backward(f_rpn.grad + f_rcnn.grad)
             if buckets is not None:
                 buckets.disarm()
-            if PREFIX_OVERLAP:
-                _L.PROGRESS_HOOK = None
-                if PREFIX_AFTER_NODE < 0:
-                    self._bwd_done.record(main)
         SideStream.join()
-        K.WINOGRAD_READY.clear()      # the optimizer is about to change the weights
-        K.WINOGRAD_EVENT = None
         rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})
         rpn_pred['num_proposals'] = prop['num_proposals']
         self._last_losses = dict(rpn_losses, total_loss=total_loss, no_reg_loss=no_reg_loss,
@@ -370,23 +309,12 @@ class FasterRCNN(object):
                 'rcnn_loss_dict': rcnn_losses, '_batch': {'B': B, 'unbatched': False}}
         return total_loss, pred
 
-    def _winograd_layers(self):
-        ls = getattr(self, '_wino_layers', None)
-        if ls is None:
-            ls = [l for l in self.base_network.trunk.all_layers() if getattr(l, 'k', 0) == 3]
-            if self.base_network.tail is not None:
-                ls += [l for l in self.base_network.tail.all_layers() if getattr(l, 'k', 0) == 3]
-            ls.append(self._rpn._rpn)
-            self._wino_layers = ls
-        return ls
-
     def _aux_stream(self):
         st = getattr(self, '_aux', None)
         if st is None:
             # high priority: the proposal/RCNN chain is a string of small latency-bound launches; its blocks must
             # not queue behind the CU-filling convolution grids of the main / side streams
-            prio = int(os.environ.get('LUMINOTH_AMD_AUX_PRIORITY', '-1'))
-            st = self._aux = torch.cuda.Stream(device=self.device, priority=prio)
+            st = self._aux = torch.cuda.Stream(device=self.device, priority=-1)
         return st
 
     # --------------------------------------------------------------- variables --

@@ -6,9 +6,17 @@ the reference (batch 1: luminoth/models/fasterrcnn/fasterrcnn.py:101-103);
 the batch loss is the mean over images.
 
 Variables come in as a {tf_name: tensor} dict (same names as the reference's
-checkpoints).  PARITY UNPINNED: the slim ResNet arithmetic is third-party
+checkpoints).  PARITY UNPINNED: the slim ResNet / VGG arithmetic is third-party
 (tf.contrib.slim, not in /root/reference); structure per SURVEY.md §8a-A2.
 Citations relative to /root/reference/luminoth/.
+
+Two test-only knobs:
+  * `dtype=torch.float64` runs the dense parts in double precision (conditioning studies: is a loss
+    difference between two fp32 implementations round-off of an ill-conditioned network, or a bug?);
+  * `masks` = {layer scope: that layer's OUTPUT as computed by the HIP kernels}: every ReLU / ReLU6
+    decision is then taken from the kernels' own activations instead of the oracle's pre-activations, so the
+    reference gradient is the derivative of exactly the piecewise-linear branch the kernels were on (an
+    activation within round-off of a kink otherwise moves whole dy*x terms between the two implementations).
 """
 import numpy as np
 import torch
@@ -22,6 +30,9 @@ RESNET_UNITS = {'resnet_v1_50': (3, 4, 6, 3), 'resnet_v1_101': (3, 4, 23, 3), 'r
 MEANS = torch.tensor([123.68, 116.78, 103.94])   # models/base/base_network.py:14-16
 
 
+VGG16_CFG = (('conv1', 2, 64), ('conv2', 2, 128), ('conv3', 3, 256), ('conv4', 3, 512), ('conv5', 3, 512))
+
+
 def _act(x, name):
     if name == 'relu':
         return torch.relu(x)
@@ -33,8 +44,10 @@ def _act(x, name):
 class OracleFasterRCNN(object):
     def __init__(self, variables, arch='resnet_v1_50', num_classes=80, scope='fasterrcnn',
                  base_scope='truncated_base_network', anchors=None, rpn=None, rcnn=None, weight_decay=5e-4,
-                 l2_rpn=5e-4, l2_rcnn=5e-4, fine_tune_from='block2', seed=None):
-        self.v = {k: torch.as_tensor(v).clone().float() for k, v in variables.items()}
+                 l2_rpn=5e-4, l2_rcnn=5e-4, fine_tune_from='block2', seed=None, dtype=torch.float32):
+        self.dtype = dtype
+        self.v = {k: torch.as_tensor(v).clone().to(dtype) for k, v in variables.items()}
+        self.masks = None
         self.arch, self.C, self.scope, self.base = arch, num_classes, scope, '%s/%s' % (base_scope, arch)
         a = anchors or {}
         self.anchor_ref = bx.generate_anchors_reference(a.get('base_size', 256), np.array(a.get('ratios', [.5, 1, 2])),
@@ -48,13 +61,23 @@ class OracleFasterRCNN(object):
         self.fine_tune_from, self.seed = fine_tune_from, seed
         self.step = 0
 
+    def _activate(self, z, act, scope):
+        """Activation of layer `scope`; with `self.masks` the branch is the one the kernels took."""
+        yk = None if self.masks is None else self.masks.get(scope)
+        if yk is None or not act:
+            return _act(z, act)
+        yk = torch.as_tensor(yk).reshape(z.shape)
+        if act == 'relu':
+            return z * (yk > 0).to(z.dtype)
+        return z * ((yk > 0) & (yk < 6)).to(z.dtype) + 6.0 * (yk >= 6).to(z.dtype)
+
     # ---- backbone: slim resnet_v1 up to block3, output_stride 16 ----------------
     def _conv_bn(self, x, scope, stride=1, rate=1, padding='SAME', act='relu'):
         v = self.v
         y = ot.conv2d_nhwc(x, v[scope + '/weights'], stride, rate, padding)
         y = ot.frozen_batch_norm(y, v[scope + '/BatchNorm/gamma'], v[scope + '/BatchNorm/beta'],
                                  v[scope + '/BatchNorm/moving_mean'], v[scope + '/BatchNorm/moving_variance'])
-        return _act(y, act)
+        return self._activate(y, act, scope)
 
     def _bottleneck(self, x, scope, depth, stride, rate):
         p = scope + '/bottleneck_v1'
@@ -66,10 +89,26 @@ class OracleFasterRCNN(object):
         r = self._conv_bn(r, p + '/conv2', stride=stride, rate=rate,
                           padding='SAME' if stride == 1 else 'SAME_EXPLICIT')
         r = self._conv_bn(r, p + '/conv3', act=None)
-        return torch.relu(sc + r)
+        return self._activate(sc + r, 'relu', p + '/conv3')
+
+    def vgg_backbone(self, image):
+        """slim vgg_16 up to conv5/conv5_3 (truncated_base_network.py:8-16): 3x3 SAME conv + bias + ReLU,
+        2x2/2 VALID max-pools after conv1..conv4."""
+        x = image - MEANS.to(self.dtype)
+        for bi, (name, reps, depth) in enumerate(VGG16_CFG):
+            for r in range(reps):
+                sc = '%s/%s/%s_%d' % (self.base, name, name, r + 1)
+                x = ot.conv2d_nhwc(x, self.v[sc + '/weights'], 1, 1, 'SAME', bias=self.v[sc + '/biases'])
+                x = self._activate(x, 'relu', sc)
+            if bi < 4:
+                x = ot.max_pool_nhwc(x, 2, 2, 'VALID')
+        return x
 
     def backbone(self, image, upto=3, output_stride=16):
-        x = image - MEANS
+        image = image.to(self.dtype)
+        if self.arch == 'vgg_16':
+            return self.vgg_backbone(image)
+        x = image - MEANS.to(self.dtype)
         x = self._conv_bn(x, self.base + '/conv1', stride=2, padding='SAME_EXPLICIT')
         x = ot.max_pool_nhwc(x, 3, 2, 'SAME')
         current, rate = 4, 1
@@ -99,14 +138,15 @@ class OracleFasterRCNN(object):
     # ---- heads --------------------------------------------------------------------
     def rpn_head(self, feat):
         v, p = self.v, self.scope + '/rpn'
-        f = _act(ot.conv2d_nhwc(feat, v[p + '/conv/w'], padding='SAME', bias=v[p + '/conv/b']), 'relu6')
+        f = self._activate(ot.conv2d_nhwc(feat, v[p + '/conv/w'], padding='SAME', bias=v[p + '/conv/b']), 'relu6',
+                           p + '/conv')
         cls = ot.conv2d_nhwc(f, v[p + '/cls_conv/w'], padding='VALID', bias=v[p + '/cls_conv/b'])
         box = ot.conv2d_nhwc(f, v[p + '/bbox_conv/w'], padding='VALID', bias=v[p + '/bbox_conv/b'])
         return cls.reshape(-1, 2), box.reshape(-1, 4)
 
     def rcnn_head(self, feat, rois, im_shape):
         v, p = self.v, self.scope + '/rcnn'
-        pooled = ot.roi_pool(feat, rois, torch.zeros(rois.shape[0], dtype=torch.long), im_shape)
+        pooled = ot.roi_pool(feat, rois.to(self.dtype), torch.zeros(rois.shape[0], dtype=torch.long), im_shape)
         net = self.tail(pooled).mean(dim=(1, 2))
         cls = net @ v[p + '/fc_classifier/w'] + v[p + '/fc_classifier/b']
         box = net @ v[p + '/fc_bbox/w'] + v[p + '/fc_bbox/b']
@@ -137,7 +177,7 @@ class OracleFasterRCNN(object):
         out = dict(feat=feat, rpn_cls_score=cls_score, rpn_bbox_pred=bbox_pred)
         labels, targets, _ = of.rpn_target(anchors, gt, (H, W), seed=seed)
         out['rpn_labels'], out['rpn_targets'] = labels, targets
-        l_cls, l_reg = ot.rpn_loss(cls_score, bbox_pred, torch.tensor(labels), torch.tensor(targets), 3.0)
+        l_cls, l_reg = ot.rpn_loss(cls_score, bbox_pred, torch.tensor(labels), torch.tensor(targets).to(self.dtype), 3.0)
         out['rpn_cls_loss'], out['rpn_reg_loss'] = l_cls, l_reg
         if 'rois' in ov:
             rois, roi_labels, roi_targets = ov['rois'], ov['roi_labels'], ov['roi_targets']
@@ -145,8 +185,8 @@ class OracleFasterRCNN(object):
             if 'proposals' in ov:
                 proposals = ov['proposals']
             else:
-                prob = torch.softmax(cls_score.detach(), dim=1).numpy()
-                proposals = of.rpn_proposal(prob, bbox_pred.detach().numpy(), anchors, (H, W),
+                prob = torch.softmax(cls_score.detach(), dim=1).float().numpy()
+                proposals = of.rpn_proposal(prob, bbox_pred.detach().float().numpy(), anchors, (H, W),
                                             **self.rpn_cfg)['proposals']
             out['proposals'] = proposals
             lab, tg = of.rcnn_target(proposals, gt, seed=seed, **self.rcnn_cfg)
@@ -156,16 +196,24 @@ class OracleFasterRCNN(object):
         cls, box, pooled = self.rcnn_head(feat, torch.tensor(np.asarray(rois)), (H, W))
         out['rcnn_cls_score'], out['rcnn_bbox_offsets'], out['pooled'] = cls, box, pooled
         c_cls, c_reg = ot.rcnn_loss(cls, box, torch.tensor(np.asarray(roi_labels)),
-                                    torch.tensor(np.asarray(roi_targets)), self.C, 1.0)
+                                    torch.tensor(np.asarray(roi_targets)).to(self.dtype), self.C, 1.0)
         out['rcnn_cls_loss'], out['rcnn_reg_loss'] = c_cls, c_reg
         return out
 
     # ---- trainable set (base_network.py:211-241, truncated_base_network.py:97-144) ---
     def trainable_names(self):
         names = []
+        if self.arch == 'vgg_16':
+            # creation order conv1_1/{weights,biases}, ...: everything from the first name containing
+            # `fine_tune_from` on (base_network.py:211-241), up to the endpoint conv5_3
+            order = ['%s/%s/%s_%d/%s' % (self.base, n, n, r + 1, kind) for n, reps, _ in VGG16_CFG
+                     for r in range(reps) for kind in ('weights', 'biases')]
+            ft = self.fine_tune_from
+            first = 0 if ft is None else next(i for i, n in enumerate(order) if ft in n)
+            names += order[first:]
         for k in self.v:
             if k.startswith(self.base):
-                if 'moving_' in k:
+                if 'moving_' in k or self.arch == 'vgg_16':
                     continue
                 blk = [b for b in ('block2', 'block3') if '/%s/' % b in k]
                 if blk or (self.arch == 'resnet_v1_101' and '/block4/' in k):

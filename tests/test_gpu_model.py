@@ -9,142 +9,89 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import boxes as obx
-from oracle import frcnn as of
-from oracle import rng as orng
-from oracle.model import OracleFasterRCNN
+import sys
 
+from oracle import frcnn as of
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 F = np.float32
 
 
-def make_config(arch='resnet_v1_50', num_classes=80, **over):
-    from luminoth_amd.utils.config import get_config
-    cfg = {'model': {'type': 'fasterrcnn', 'network': {'num_classes': num_classes},
-                     'base_network': {'architecture': arch}},
-           'train': {'seed': 0}}
-    return get_config(cfg, ['%s=%s' % kv for kv in over.items()])
-
-
-def synth(B, H, W, G, num_classes, seed):
-    g = torch.Generator().manual_seed(seed)
-    images = torch.rand((B, H, W, 3), generator=g) * 255.0
-    rs = np.random.RandomState(seed)
-    gts = []
-    for b in range(B):
-        wh = rs.randint(min(32, H // 4), max(H // 2, 40), size=(G, 2))
-        xy = np.stack([rs.randint(0, W - wh[:, 0]), rs.randint(0, H - wh[:, 1])], 1)
-        gts.append(np.concatenate([xy, xy + wh, rs.randint(0, num_classes, size=(G, 1))], 1).astype(F))
-    return images, gts
+from e2e_util import compare_step_with_oracle, condition_like_pretrained, make_config, synth   # noqa: E402
 
 
 @pytest.fixture(scope='module')
 def setup():
     from luminoth_amd.models import get_model
     cfg = make_config()
-    model = get_model('fasterrcnn')(cfg)
-    # Condition the random-init network like a pretrained one: without real BatchNorm statistics the
-    # activations of raw 0..255 pixels reach O(1e3) and fp32 round-off alone is ~1e-3 absolute on the
-    # RPN logits (identically for the CPU oracle).  Normalising conv1's output keeps everything O(1),
-    # so the 1e-4 comparisons below measure the kernels, not the conditioning of the synthetic weights.
-    sd = model.state_dict()
-    sd['truncated_base_network/resnet_v1_50/conv1/BatchNorm/moving_variance'].fill_(73.6 ** 2 * 2)
-    model.load_state_dict(sd)
+    model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_50')
     images, gts = synth(2, 320, 384, 4, 80, 3)
     return cfg, model, images, gts
+
+
+def _winograd_everywhere(monkeypatch, on):
+    from luminoth_amd import kernels as KK
+    monkeypatch.setattr(KK, 'WINOGRAD', on)
+    monkeypatch.setattr(KK, 'WINOGRAD_MIN_CK', 64 * 64)
+    monkeypatch.setattr(KK, 'WINOGRAD_WGRAD_MIN_CK', 64 * 64)
 
 
 @pytest.mark.parametrize('winograd', [False, True], ids=['direct', 'winograd'])
 def test_train_step_matches_oracle(setup, winograd, monkeypatch):
     """Whole step against the oracle, once with the direct 3x3 kernels and once with the Winograd F(2x2,3x3) path
-    on every layer it covers (the default routes RPN + block3 through it)."""
+    on every layer it covers (the default routes RPN + block3 through it).  Gradients with pinned ReLU branches:
+    every element within 1e-3 of the tensor's scale on BOTH paths (tests/e2e_util.py)."""
+    _winograd_everywhere(monkeypatch, winograd)
+    cfg, model, images, gts = setup
+    compare_step_with_oracle(model, images, gts, 80)
+
+
+def test_train_step_matches_oracle_at_benchmark_shape():
+    """BASELINE configs[1] itself: ResNet-50, 2 x 1024 x 1024, 80 classes, 8 gt boxes / image, default kernel
+    routing (Winograd on RPN + block3) — the shape bench.py times."""
+    from luminoth_amd.models import get_model
+    import bench
+    cfg = make_config()
+    model = get_model('fasterrcnn')(cfg)
+    bench.condition_weights(model, 'resnet_v1_50')
+    images, (gt, cnt) = bench.synth_batch(2, 1024, 1024, 8, 80, 100, 'cpu')
+    gts = [gt[b, :int(cnt[b])].numpy() for b in range(2)]
+    compare_step_with_oracle(model, images, gts, 80)
+
+
+@pytest.mark.parametrize('winograd', [False, True], ids=['direct', 'winograd'])
+def test_resnet101_block4_tail_matches_oracle(winograd, monkeypatch):
+    """A12 (truncated_base_network.py:56-95): ResNet-101, block4 applied to the pooled ROIs with the trunk's block4
+    variables; 23-unit block3.  RCNN minibatch 64 keeps the CPU oracle's tail (12.5k GEMM rows at 256) short."""
+    from luminoth_amd.models import get_model
+    _winograd_everywhere(monkeypatch, winograd)
+    cfg = make_config('resnet_v1_101', 20, **{'model.rcnn.target.minibatch_size': 64})
+    model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_101')
+    assert model.base_network.tail is not None and model.base_network.tail_channels == 2048
+    images, gts = synth(2, 256, 320, 3, 20, 5)
+    compare_step_with_oracle(model, images, gts, 20, arch='resnet_v1_101')
+    # the tail's variables are trained (use_tail, not freeze_tail): their gradients were part of the check
+    g = model.store.grads['truncated_base_network/resnet_v1_101/block4/unit_3/bottleneck_v1/conv2/weights']
+    assert float(g.abs().max()) > 0
+
+
+@pytest.mark.parametrize('winograd', [False, True], ids=['direct', 'winograd'])
+@pytest.mark.parametrize('hw', [(600, 800), (600, 900)], ids=['600x800', '600x900'])
+def test_vgg16_fasterrcnn_matches_oracle(hw, winograd, monkeypatch):
+    """BASELINE configs[0]: Faster R-CNN VGG-16 on Pascal-VOC-shape images (375x500 / 333x500 resized by the
+    600/1024 rule -> 600x800 / 600x900), 20 classes, batch 1 like the reference; conv3..conv5 trainable.
+    Direct and Winograd (default routing sends conv3-conv5 + RPN through Winograd) both within 1e-4."""
+    from luminoth_amd.models import get_model
     from luminoth_amd import kernels as KK
     monkeypatch.setattr(KK, 'WINOGRAD', winograd)
-    monkeypatch.setattr(KK, 'WINOGRAD_MIN_CK', 64 * 64)
-    monkeypatch.setattr(KK, 'WINOGRAD_WGRAD_MIN_CK', 64 * 64)
-    cfg, model, images, gts = setup
-    model._step = 0
-    pred = model(images, gts, is_training=True)
-    losses = model.loss(pred, return_all=True)
-    model.backward(losses['total_loss'])
-    torch.cuda.synchronize()
-    B, H, W = 2, 320, 384
-    oracle = OracleFasterRCNN(model.state_dict(), num_classes=80, seed=0)
-    rp, cp = pred['rpn_prediction'], pred['classification_prediction']
-    names = oracle.trainable_names()
-    for n in names:
-        oracle.v[n].requires_grad_(True)
-    tot = 0.0
-    per = {k: 0.0 for k in ('rpn_cls_loss', 'rpn_reg_loss', 'rcnn_cls_loss', 'rcnn_reg_loss')}
-    for b in range(B):
-        seed = orng.image_seed(0, 0, b)
-        n_roi = int(cp['num_proposals'][b])
-        rois = cp['proposals'][b, :n_roi].cpu().numpy()
-        ov = dict(rois=rois, roi_labels=cp['target']['cls'][b, :n_roi].cpu().numpy(),
-                  roi_targets=cp['target']['bbox_offsets'][b, :n_roi].cpu().numpy())
-        o = oracle.forward_image(images[b], gts[b], seed, overrides=ov)
-        if b == 0:
-            fm = o['feat'].detach().numpy()
-        # --- continuous stages: fp32 conv stack, 1e-4 of the activation scale
-        # (rows of conv_feature_map are compared per image below via the heads)
-        sc = rp['rpn_cls_score'][b].detach().cpu().numpy()
-        np.testing.assert_allclose(sc, o['rpn_cls_score'].detach().numpy(), rtol=1e-3,
-                                   atol=1e-4 * max(1.0, np.abs(sc).max()))
-        bp = rp['rpn_bbox_pred'][b].detach().cpu().numpy()
-        np.testing.assert_allclose(bp, o['rpn_bbox_pred'].detach().numpy(), rtol=1e-3,
-                                   atol=1e-4 * max(1.0, np.abs(bp).max()))
-        # --- anchor labels: bit-exact (functions of anchors + gt only)
-        np.testing.assert_array_equal(rp['rpn_cls_target'][b].cpu().numpy(), o['rpn_labels'])
-        np.testing.assert_allclose(rp['rpn_bbox_target'][b].cpu().numpy(), o['rpn_targets'], rtol=1e-5, atol=1e-6)
-        # --- proposals on identical inputs (the kernel's own probabilities / deltas)
-        anchors = obx.generate_anchors(oracle.anchor_ref, H // 16, W // 16, 16)
-        pr = of.rpn_proposal(rp['rpn_cls_prob'][b].cpu().numpy(), bp, anchors, (H, W))
-        n_p = int(rp['num_proposals'][b])
-        assert n_p == pr['proposals'].shape[0]
-        np.testing.assert_allclose(rp['proposals'][b, :n_p].cpu().numpy(), pr['proposals'], rtol=1e-6, atol=1e-4)
-        # --- proposal targets on identical proposals: labels bit-exact
-        lab, tg = of.rcnn_target(rp['proposals'][b, :n_p].cpu().numpy(), gts[b], seed=seed)
-        keep = lab >= 0
-        assert n_roi == int(keep.sum())
-        np.testing.assert_array_equal(ov['roi_labels'], lab[keep])
-        np.testing.assert_array_equal(rois, rp['proposals'][b, :n_p].cpu().numpy()[keep])
-        np.testing.assert_allclose(ov['roi_targets'], tg[keep], rtol=1e-5, atol=1e-6)
-        # --- RCNN head on identical rois
-        cs = cp['rcnn']['cls_score'][b, :n_roi].detach().cpu().numpy()
-        np.testing.assert_allclose(cs, o['rcnn_cls_score'].detach().numpy(), rtol=1e-3,
-                                   atol=1e-4 * max(1.0, np.abs(cs).max()))
-        for k in per:
-            per[k] = per[k] + o[k] / B
-    # --- losses within 1e-4 (north_star)
-    for k in per:
-        assert abs(float(losses[k].detach()) - float(per[k].detach())) <= 1e-4 * max(1.0, abs(float(per[k]))), (k, float(losses[k]), float(per[k]))
-    reg = float(oracle.regularization_loss())
-    assert abs(float(losses['regularization_loss']) - reg) <= 1e-4 * reg
-    total = sum(per.values())
-    assert abs(float(losses['no_reg_loss']) - float(total)) <= 1e-4 * max(1.0, float(total))
-    # --- gradients (data loss only; the L2 term is folded into the optimizer kernel)
-    total.backward()
-    grads = model.store.grads
-    checked = 0
-    for n in names:
-        g_ref = oracle.v[n].grad
-        if g_ref is None:
-            continue
-        g = grads[n].cpu().numpy().reshape(g_ref.shape)
-        scale = max(1e-6, float(g_ref.abs().max()))
-        err = np.abs(g - g_ref.numpy())
-        # ReLU / max-pool derivatives are discontinuous: an activation within 1 ulp of 0 (or an
-        # arg-max tie) may route its gradient differently in the two fp32 implementations, so a tiny
-        # fraction of elements may move by more than round-off.  Tight bound on 99.5 % of the
-        # elements, loose bound on all of them.
-        tight = err <= 2e-4 * scale + 2e-3 * np.abs(g_ref.numpy())
-        assert tight.mean() >= 0.995, (n, float(tight.mean()))
-        # Winograd reorders the fp32 roundings of the pre-activations (error a few 1e-6 instead of 1e-6 of the
-        # activation scale): proportionally more ReLU-kink flips, each moving one weight-gradient element by a
-        # full dy*x term, hence the wider bound on the single worst element; the 99.5 % criterion is unchanged.
-        assert err.max() <= (5e-2 if winograd else 1e-2) * scale, (n, float(err.max()), scale)
-        checked += 1
-    assert checked > 100
+    cfg = make_config('vgg_16', 20, **{'model.base_network.fine_tune_from': 'conv3'})
+    model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'vgg_16')
+    images, gts = synth(1, hw[0], hw[1], 3, 20, 7)
+    compare_step_with_oracle(model, images, gts, 20, arch='vgg_16', oracle_kwargs={'fine_tune_from': 'conv3'},
+                             min_checked=20)
+    frozen = 'truncated_base_network/vgg_16/conv2/conv2_2/weights'
+    assert frozen not in model.get_trainable_vars()
 
 
 def test_inference_prediction_dict_keys(setup):
@@ -228,12 +175,7 @@ def test_fused_two_stream_step_equals_plain_step(setup):
     torch.cuda.synchronize()
     g_plain = model.store.grad.clone()
     model._step = 0
-    from luminoth_amd.models.fasterrcnn import fasterrcnn as FR
-    FR.PREPARE_WINOGRAD = True          # also exercises the transformed weights prepared on the side stream
-    try:
-        total, pred2 = model.train_step(images, gts)
-    finally:
-        FR.PREPARE_WINOGRAD = False
+    total, pred2 = model.train_step(images, gts)
     torch.cuda.synchronize()
     g_fused = model.store.grad.clone()
     np.testing.assert_allclose(float(total), float(losses['total_loss']), rtol=1e-6)
