@@ -1,29 +1,33 @@
 #!/usr/bin/env python
-"""bench.py — images/sec of the Faster R-CNN ResNet-50 train step (BASELINE.json
-metric) on N MI355X GPUs of one node.
+"""bench.py — images/sec of the Faster R-CNN ResNet-50 train step (BASELINE.json metric) on N MI355X GPUs of one
+node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: re-executes itself under torch.distributed.run
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
 
-A "step" = forward + loss + backward + (gradient all-reduce) + momentum-SGD
-update of BASELINE config[1]: Faster R-CNN ResNet-50 (no FPN), batch 2 per GPU,
-1024x1024 synthetic images (U[0,255), 8 gt boxes/image, 80 classes, 49 152
-anchors/image, RPN minibatch 256, RCNN minibatch 256), fp32, random-init
-weights.  Inputs are resident in HBM before the timed region.  Weak scaling:
-per-GPU batch fixed, one RCCL all-reduce of the flat gradient buffer per step.
+A "step" = forward + loss + backward + (gradient all-reduce) + optimizer update of one batch of synthetic images
+that are resident in HBM before the timed region.  Default workload = BASELINE configs[1] (`--workload frcnn_r50`):
+Faster R-CNN ResNet-50 (no FPN), batch 2 per GPU, 1024x1024, 8 gt boxes/image, 80 classes, 49 152 anchors/image,
+RPN minibatch 256, RCNN minibatch 256, fp32, random-init weights.  The other BASELINE configs are selectable with
+`--workload {frcnn_vgg16, ssd300_b32, frcnn_r101, frcnn_r50_coco}` and print the same contract line.
+Weak scaling: per-GPU batch fixed, gradients all-reduced over RCCL (bucketed, overlapped with the backward).
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline     — dominant MFMA conv kernel: algorithmic FLOPs per launch / mean
-                 launch time (HIP events on the launch stream, instrumented
-                 steps run right after the timed region) vs the 157.3 TFLOP/s
-                 fp32 matrix peak of gfx950;
-  cpu_baseline — the CPU oracle (oracle/model.py, kind "port": the TF reference
-                 cannot run here) timed on this host on a bounded sample.
+  roofline     — the convolution MFMA kernel class with the LARGEST time per step (over forward, backward-data and
+                 backward-weight classes alike): FLOPs the launch executes / mean launch duration vs the dense MFMA
+                 peak of the compute dtype.  Durations are HIP events recorded by the C library on the launch stream
+                 directly around that kernel, in profiling steps run right after the timed region with the
+                 weight-gradient / proposal side streams SERIALISED onto one stream (un-overlapped timing; the timed
+                 region itself uses the production multi-stream schedule).  `whole_step` = algorithmic conv FLOPs of
+                 the step / timed step time.
+  cpu_baseline — the CPU oracle (oracle/, kind "port": the TF reference cannot run here) timed on this host's
+                 cores on a bounded sample: 1 warm-up + median of 5 steps, and a 1-thread step beside it.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -35,15 +39,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+# /opt/skills/guides/MI355X_MICROARCH.md: dense matrix peaks
+PEAK_TFLOPS = {'f32': 157.3, 'f16': 2500.0, 'bf16': 2500.0}
+
+WORKLOADS = {
+    # name: model type, architecture, per-GPU batch, H, W, classes, gt boxes/image, BASELINE.json configs[] index
+    'frcnn_r50': dict(model='fasterrcnn', arch='resnet_v1_50', batch=2, H=1024, W=1024, classes=80, G=8, cfg=1),
+    'frcnn_vgg16': dict(model='fasterrcnn', arch='vgg_16', batch=1, H=600, W=800, classes=20, G=3, cfg=0),
+    'ssd300_b32': dict(model='ssd', arch='truncated_vgg_16', batch=32, H=300, W=300, classes=20, G=4, cfg=2),
+    'frcnn_r101': dict(model='fasterrcnn', arch='resnet_v1_101', batch=2, H=1024, W=1024, classes=80, G=8, cfg=3),
+    'frcnn_r50_coco': dict(model='fasterrcnn', arch='resnet_v1_50', batch=2, H=800, W=1333, classes=80, G=8, cfg=4),
+}
 
 
-def synth_batch(B, H, W, G, num_classes, seed, device):
+def synth_batch(B, H, W, G, num_classes, seed, device, lo=32, hi=512):
     g = torch.Generator().manual_seed(seed)
     images = (torch.rand((B, H, W, 3), generator=g) * 255.0).to(device)
     gt = torch.zeros((B, G, 5), dtype=torch.float32)
+    hi = min(hi, min(H, W) // 2)
     for b in range(B):
-        wh = torch.randint(32, 513, (G, 2), generator=g)
+        wh = torch.randint(lo, hi + 1, (G, 2), generator=g)
         x = (torch.rand((G,), generator=g) * (W - wh[:, 0]).float()).floor()
         y = (torch.rand((G,), generator=g) * (H - wh[:, 1]).float()).floor()
         gt[b, :, 0], gt[b, :, 1] = x, y
@@ -53,38 +68,109 @@ def synth_batch(B, H, W, G, num_classes, seed, device):
     return images, (gt.to(device), cnt.to(device))
 
 
-def cpu_baseline(cfg_kwargs, sd, H, W, G, num_classes, n_images):
-    """The CPU oracle (oracle/model.py: torch-CPU fp32 convs + numpy box/NMS stages — a port, the TF
-    reference cannot run here) timed on this host for ONE full train step over `n_images` images of the
-    benchmark shape.  32 threads: the oracle's scaling peaks there on the 256-thread GPU hosts."""
+def condition_weights(model, arch):
+    """Random-init stand-in for pretrained statistics (no checkpoint can be downloaded): with identity BatchNorm
+    statistics raw 0..255 pixels and 16+ stacked residual adds drive the activations to O(1e3) and momentum-SGD
+    diverges to NaN within 3 steps.  Only FROZEN statistics / the first layer are touched (ResNet conv1: pixel variance
+    x fan-in gain, last BN of every bottleneck: 16 => residual branch x 1/4; VGG: conv1_1 weights / pixel std);
+    architecture, shapes and work per step are unchanged, and the loss stays finite and decreases."""
+    sd = model.state_dict()
+    if arch.startswith('resnet'):
+        sd['truncated_base_network/%s/conv1/BatchNorm/moving_variance' % arch].fill_(73.6 ** 2 * 2)
+        for k in sd:
+            if k.endswith('conv3/BatchNorm/moving_variance'):
+                sd[k].fill_(16.0)
+    elif arch == 'vgg_16':
+        sd['truncated_base_network/vgg_16/conv1/conv1_1/weights'].mul_(1.0 / 73.6)
+    model.load_state_dict(sd)
+    return model
+
+
+def build(wl, device, dtype='f32'):
+    from luminoth_amd.models import get_model
+    from luminoth_amd.utils.config import get_config
+    if wl['model'] == 'ssd':
+        cfg = get_config({'model': {'type': 'ssd', 'network': {'num_classes': wl['classes']}},
+                          'train': {'seed': 0, 'debug': False}})
+    else:
+        bn = {'architecture': wl['arch']}
+        if wl['arch'] == 'vgg_16':
+            bn['fine_tune_from'] = 'conv3'     # the reference default "block2" is ResNet-only (raises for VGG there too)
+        if dtype != 'f32':
+            bn['compute_dtype'] = dtype
+        cfg = get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': wl['classes']},
+                                    'base_network': bn}, 'train': {'seed': 0, 'debug': False}})
+    model = get_model(wl['model'])(cfg, device=device)
+    if wl['model'] != 'ssd':
+        condition_weights(model, wl['arch'])
+    return cfg, model
+
+
+def inputs(wl, seed, device):
+    if wl['model'] == 'ssd':      # O(1) inputs keep the random-init SSD finite (no BN, no mean subtraction)
+        images, gts = synth_batch(wl['batch'], wl['H'], wl['W'], wl['G'], wl['classes'], seed, device, lo=30, hi=200)
+        return images / 127.5 - 1.0, gts
+    return synth_batch(wl['batch'], wl['H'], wl['W'], wl['G'], wl['classes'], seed, device)
+
+
+def cpu_baseline(wl, sd, steps=5):
+    """The CPU oracle (oracle/model.py: torch-CPU fp32 convs + numpy box / NMS stages — a port, the TF reference cannot
+    run here) timed on this host for full train steps over one batch of the benchmark shape: 1 warm-up + median of
+    `steps` steps on min(cores, 32) threads (the oracle's scaling peaks there on the 256-thread GPU hosts), then ONE
+    step of one image on a single thread for a per-core figure."""
+    if wl['model'] == 'ssd':
+        return None
     from oracle.model import OracleFasterRCNN
     cores = min(os.cpu_count() or 1, 32)
+    kw = {'fine_tune_from': 'conv3'} if wl['arch'] == 'vgg_16' else {}
+    images, (gt, _) = synth_batch(wl['batch'], wl['H'], wl['W'], wl['G'], wl['classes'], 1234, 'cpu')
+    ims = [images[i] for i in range(wl['batch'])]
+    gts = [gt[i].numpy() for i in range(wl['batch'])]
     torch.set_num_threads(cores)
-    oracle = OracleFasterRCNN(sd, num_classes=num_classes, seed=0, **cfg_kwargs)
-    images, (gt, _) = synth_batch(n_images, H, W, G, num_classes, 1234, 'cpu')
+    oracle = OracleFasterRCNN(sd, arch=wl['arch'], num_classes=wl['classes'], seed=0, **kw)
+    mom, times = None, []
+    t_all = time.time()
+    for i in range(steps + 1):
+        t0 = time.time()
+        _, _, mom = oracle.train_step(ims, gts, mom_state=mom)
+        if i > 0:
+            times.append(time.time() - t0)
+    med = float(np.median(times))
+    torch.set_num_threads(1)
+    oracle1 = OracleFasterRCNN(sd, arch=wl['arch'], num_classes=wl['classes'], seed=0, **kw)
     t0 = time.time()
-    oracle.train_step([images[i] for i in range(n_images)], [gt[i].numpy() for i in range(n_images)])
-    dt = time.time() - t0
-    return {'value': n_images / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': '%d image(s) %dx%d, one full oracle train step (torch-CPU fp32 + numpy), %.1fs'
-                      % (n_images, H, W, dt)}
+    oracle1.train_step(ims[:1], gts[:1])
+    t1 = time.time() - t0
+    torch.set_num_threads(cores)
+    return {'value': wl['batch'] / med, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'one_thread_value': 1.0 / t1,
+            'sample': '%d-image batch %dx%d, full oracle train step (torch-CPU fp32 + numpy): 1 warm-up + median of %d '
+                      'steps on %d threads (%.2fs/step), plus one 1-image step on 1 thread (%.1fs); %.0fs in all'
+                      % (wl['batch'], wl['H'], wl['W'], steps, cores, med, t1, time.time() - t_all)}
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_traffic.json,
-    produced by scripts/gpu_pmc_bench.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
-    same bench command; counters cannot be read from inside the process).  (None, None) if absent."""
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_traffic.json, produced by
+    scripts/gpu_pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench command; the
+    counters cannot be read from inside the process).  (None, None) if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
     if not files:
         return None, None
     try:
         table = json.load(open(files[-1]))['kernels']
-        name = kernel.replace(' ', '')
-        k = table.get(name) or table.get(name[:-1] + ',false>')     # template default argument shown by rocprofv3
+        k = table.get(kernel.replace(' ', ''))
         return (k['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)) if k else (None, None)
     except Exception:
         return None, None
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -92,18 +178,30 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=2, help='images per GPU')
-    ap.add_argument('--size', type=int, default=1024)
-    ap.add_argument('--arch', default='resnet_v1_50')
-    ap.add_argument('--classes', type=int, default=80)
+    ap.add_argument('--workload', default='frcnn_r50', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the workload\'s)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'],
+                    help='convolution compute dtype (f32 = the parity dtype of north_star)')
+    ap.add_argument('--serial', action='store_true',
+                    help='run EVERY step on one stream (the schedule of the roofline profiling steps): the command '
+                         'the rocprofv3 summaries under profiles/*_serial_* are taken from')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=6)
+    ap.add_argument('--cpu-steps', type=int, default=5)
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # launched plainly with --gpus N: become N ranks (one process per GPU over RCCL)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.execvp(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                                   '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+                                   '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or run `python bench.py '
+                         '--gpus N` and let it spawn them)' % (args.gpus, world))
     if world > 1:
-        # main, aux, two weight-gradient side streams, the bucket stream and RCCL's own: more streams than the 4
+        # main, aux, weight-gradient side stream, the bucket stream and RCCL's own: more streams than the 4
         # hardware queues HIP creates by default (read at runtime initialisation, i.e. before the first cuda call)
         os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     rank = int(os.environ.get('RANK', '0'))
@@ -122,45 +220,36 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, (world, args.gpus)
 
     from luminoth_amd import kernels as K
-    from luminoth_amd.models import get_model
-    from luminoth_amd.utils.config import get_config
-    from luminoth_amd.utils.training import broadcast_parameters, get_optimizer, train_step
+    from luminoth_amd.models.base import layers as L
+    from luminoth_amd.utils import training as T
 
-    cfg = get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': args.classes},
-                                'base_network': {'architecture': args.arch}},
-                      'train': {'seed': 0, 'debug': False}})
-    model = get_model('fasterrcnn')(cfg, device=device)
-    # Random-init stand-in for pretrained BatchNorm statistics (no checkpoint can be downloaded): with
-    # identity BN statistics raw 0..255 pixels and 16 stacked residual adds drive the activations to
-    # O(1e3) and momentum-SGD diverges to NaN within 3 steps.  Only FROZEN moving variances are set
-    # (conv1: pixel variance x fan-in gain; last BN of every bottleneck: 16 => residual branch x 1/4);
-    # architecture, shapes and work per step are unchanged, and the loss stays finite and decreases.
-    sd = model.state_dict()
-    sd['truncated_base_network/%s/conv1/BatchNorm/moving_variance' % args.arch].fill_(73.6 ** 2 * 2)
-    for k in sd:
-        if k.endswith('conv3/BatchNorm/moving_variance'):
-            sd[k].fill_(16.0)
-    model.load_state_dict(sd)
-    broadcast_parameters(model)
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl['batch'] = args.batch
+    cfg, model = build(wl, device, args.dtype)
+    T.broadcast_parameters(model)
     sd0 = model.state_dict() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    opt = get_optimizer(cfg.train, model)
-    H = W = args.size
-    images, gts = synth_batch(args.batch, H, W, 8, args.classes, 100 + rank, device)
+    opt = T.get_optimizer(cfg.train, model)
+    images, gts = inputs(wl, 100 + rank, device)
+
+    def serialise(on):
+        T.FUSED_STEP = not on
+        L.SideStream.enabled = not on
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    serialise(args.serial)
     for _ in range(args.warmup):
-        train_step(model, opt, images, gts)
+        T.train_step(model, opt, images, gts)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        total, _ = train_step(model, opt, images, gts)
+        total, _ = T.train_step(model, opt, images, gts)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -172,57 +261,64 @@ def main():
 
     roofline = None
     nprof = min(args.steps, 3)
-    if not args.no_roofline and rank != 0:
-        # the per-launch profiling steps contain the gradient all-reduce: every rank has to take them
-        for _ in range(nprof):
-            train_step(model, opt, images, gts)
+    if not args.no_roofline:
+        # every rank takes the profiling steps (they contain the gradient all-reduce); rank 0 records
+        serialise(True)
+        T.train_step(model, opt, images, gts)          # settle allocations of the serial schedule
         torch.cuda.synchronize()
-    if rank == 0 and not args.no_roofline:
-        K._Profile.start()
+        if rank == 0:
+            K._Profile.start()
         for _ in range(nprof):
-            train_step(model, opt, images, gts)
-        prof = K._Profile.stop()
-        # Dominant kernel = the convolution class with the most time among those that run ALONE on the GPU (the
-        # forward pass is single-stream).  The backward classes share the GPU with the weight-gradient / aux
-        # streams: their per-launch durations are stretched by the sharing (and their overlap pattern moves under
-        # rocprofv3), so they are listed in `all_conv_kernels` but not used for the roofline line; the whole-step
-        # MFMA fraction is reported next to it.
-        mfma = {k: v for k, v in prof.items() if k.startswith('k_conv_fwd')}   # single kernels, not the Winograd pipeline
-        name = max(mfma, key=lambda k: mfma[k]['ms'])
-        step_flops = sum(v['flops'] for v in prof.values()) / nprof
-        r = prof[name]
-        fl = r['flops'] / r['launches']
-        ms = r['ms'] / r['launches']
-        achieved = fl / (ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(name)
-        roofline = {'bound': 'mfma', 'kernel': name, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-                    'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes)',
-                    'traffic_source': traffic_src,
-                    'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
-                    'whole_step': {'conv_flops': step_flops, 'tflops': step_flops / dt * args.steps / 1e12,
-                                   'frac': step_flops / dt * args.steps / 1e12 / PEAK_FP32_MFMA_TFLOPS},
-                    'all_conv_kernels': {k: {'launches_per_step': v['launches'] / nprof,
-                                             'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
-                                             'ms_per_step': v['ms'] / nprof} for k, v in prof.items()}}
+            T.train_step(model, opt, images, gts)
+        prof = K._Profile.stop() if rank == 0 else None
+        serialise(args.serial)
+        if rank == 0 and prof:
+            peak = PEAK_TFLOPS[args.dtype]
+            name = max(prof, key=lambda k: prof[k]['ms'])          # the dominant kernel class, whichever pass it is in
+            step_flops = sum(v['direct_flops'] for v in prof.values()) / nprof
+            r = prof[name]
+            fl = r['flops'] / r['launches']
+            ms = r['ms'] / r['launches']
+            achieved = fl / (ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(name)
+            roofline = {
+                'bound': 'mfma', 'kernel': name, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': achieved / peak, 'traffic': traffic,
+                'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes)',
+                'traffic_source': traffic_src,
+                'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
+                'ms_per_step': r['ms'] / nprof,
+                'timing': 'HIP events around the kernel on its launch stream, %d serialised profiling steps' % nprof,
+                'whole_step': {'conv_flops': step_flops, 'tflops': step_flops / dt * args.steps / 1e12,
+                               'frac': step_flops / dt * args.steps / 1e12 / peak},
+                'all_conv_kernels': {k: {'launches_per_step': v['launches'] / nprof,
+                                         'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
+                                         'ms_per_step': v['ms'] / nprof}
+                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}}
     if world > 1:
         dist.barrier()
 
     if rank == 0:
-        gb = args.batch * world
+        gb = wl['batch'] * world
+        metric = 'images/sec (1024x1024) Faster R-CNN ResNet-50 train step'
+        if args.workload != 'frcnn_r50':
+            metric = 'images/sec (%dx%d) %s %s train step' % (wl['W'], wl['H'], wl['model'], wl['arch'])
         out = {
-            'metric': 'images/sec (1024x1024) Faster R-CNN ResNet-50 train step',
+            'metric': metric,
             'value': gb * args.steps / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: Faster R-CNN %s FPN-off, %dx%d synthetic, batch %d/GPU, '
-                                   '80 classes, 8 gt/image, 49152 anchors/image, fwd+loss+bwd+momentum-SGD'
-                                   % (args.arch, H, W, args.batch),
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[%d] (%s): %s %s, %dx%d (HxW) synthetic, batch %d/GPU, %d classes, '
+                                   '%d gt/image, fwd+loss+bwd+optimizer update%s'
+                                   % (wl['cfg'], args.workload, wl['model'], wl['arch'], wl['H'], wl['W'], wl['batch'],
+                                      wl['classes'], wl['G'], ' [single-stream schedule]' if args.serial else ''),
                        'global_batch': gb, 'parallelism': 'dp%d' % world, 'final_total_loss': loss_val},
             'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
-            out['cpu_baseline'] = cpu_baseline({'arch': args.arch}, sd0, H, W, 8, args.classes, args.cpu_images)
+            cb = cpu_baseline(wl, sd0, args.cpu_steps)
+            if cb is not None:
+                out['cpu_baseline'] = cb
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

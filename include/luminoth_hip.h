@@ -93,6 +93,16 @@ int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* d
 int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op);
 /* Diagnostics: force the block tile (bm,bn in {64,128}) and the bwd-weight split count; 0 = automatic. */
 void lmh_conv2d_force_config(int bm, int bn, int splits);
+/* Per-launch timing (bench.py roofline leg): arms the NEXT lmh_conv2d_* call of this thread — `ev_start` /
+ * `ev_stop` (hipEvent_t, e.g. from lmh_event_create) are recorded on the launch stream immediately before / after
+ * its MFMA kernel (not the split-K reduce or Winograd transforms around it).  lmh_conv2d_profile_last then returns
+ * that kernel's name as rocprofv3 prints it and the FLOPs the launch executed. */
+int lmh_conv2d_profile_next(void* ev_start, void* ev_stop);
+const char* lmh_conv2d_profile_last(double* flops);
+/* HIP events for hosts without a HIP binding (ctypes): create / destroy / elapsed ms (synchronises on e1). */
+void* lmh_event_create(void);
+void lmh_event_destroy(void* e);
+float lmh_event_elapsed_ms(void* e0, void* e1);
 /* g = dy * (y > 0 [&& y < 6 for relu6]) (g may be NULL); colsum[k] = sum_rows g
  * (may be NULL; written, not accumulated; two-stage deterministic reduction through ws). */
 size_t lmh_act_bwd_workspace_bytes(int64_t rows, int K);

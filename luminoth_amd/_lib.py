@@ -87,6 +87,11 @@ SIGNATURES = {
     'lmh_conv2d_bwd_weight': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_kernel_id': (c_i, [P(ConvDesc), c_i]),
     'lmh_conv2d_force_config': (None, [c_i, c_i, c_i]),
+    'lmh_conv2d_profile_next': (c_i, [c_f, c_f]),
+    'lmh_conv2d_profile_last': (ctypes.c_char_p, [P(ctypes.c_double)]),
+    'lmh_event_create': (ctypes.c_void_p, []),
+    'lmh_event_destroy': (None, [c_f]),
+    'lmh_event_elapsed_ms': (ctypes.c_float, [c_f, c_f]),
     'lmh_act_bwd_workspace_bytes': (c_sz, [c_i64, c_i]),
     'lmh_act_bwd': (c_i, [c_f, c_f, c_i, c_i64, c_i, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_bn_param_grads_workspace_bytes': (c_sz, [c_i64, c_i]),

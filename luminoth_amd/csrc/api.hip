@@ -19,3 +19,19 @@ extern "C" int lmh_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+// ---- HIP events for callers without a HIP binding (bench.py times single kernels with them) --------------------
+extern "C" void* lmh_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return (void*)e;
+}
+extern "C" void lmh_event_destroy(void* e) {
+  if (e) (void)hipEventDestroy((hipEvent_t)e);
+}
+extern "C" float lmh_event_elapsed_ms(void* e0, void* e1) {
+  float ms = -1.f;
+  if (hipEventSynchronize((hipEvent_t)e1) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)e0, (hipEvent_t)e1) != hipSuccess) return -1.f;
+  return ms;
+}

@@ -26,6 +26,7 @@
 //     range of tiles so operand panels stay in its private L2).
 // Shapes that break the alignment rules (C % 32, K % 4 ...) go through the
 // predicated kernels in conv_generic.h.
+#include <stdarg.h>
 #include <stdlib.h>
 #include "conv_common.h"
 #include "conv_generic.h"
@@ -44,6 +45,42 @@ static int check_desc(const lmh_conv_desc* d) {
   LMH_CHECK_ARG(d->act >= 0 && d->act <= 2);
   LMH_CHECK_ARG((int64_t)d->N * d->OH * d->OW < (1ll << 31) && (int64_t)d->N * d->H * d->W < (1ll << 31));
   return LMH_OK;
+}
+
+// ---- per-launch profiling hook (bench.py roofline leg) -------------------------------------------------------
+// lmh_conv2d_profile_next(e0, e1) arms the NEXT convolution entry point called from this thread: the two HIP events
+// are recorded on the launch stream immediately before / after its MFMA kernel (the implicit-GEMM kernel itself —
+// not the split-K reduce or the Winograd transforms around it), and lmh_conv2d_profile_last() then returns that
+// kernel's name as rocprofv3 prints it plus the FLOPs the launch executed.
+static thread_local hipEvent_t g_prof_e0 = nullptr, g_prof_e1 = nullptr;
+static thread_local char g_prof_name[96] = "";
+static thread_local double g_prof_flops = 0.0;
+extern "C" int lmh_conv2d_profile_next(void* ev_start, void* ev_stop) {
+  g_prof_e0 = (hipEvent_t)ev_start;
+  g_prof_e1 = (hipEvent_t)ev_stop;
+  g_prof_name[0] = 0;
+  g_prof_flops = 0.0;
+  return LMH_OK;
+}
+extern "C" const char* lmh_conv2d_profile_last(double* flops) {
+  if (flops) *flops = g_prof_flops;
+  return g_prof_name;
+}
+static inline void prof_begin(hipStream_t st) {
+  if (g_prof_e0) (void)hipEventRecord(g_prof_e0, st);
+}
+static inline void prof_end(hipStream_t st, double flops, const char* fmt, ...) {
+  if (!g_prof_e0) return;
+  (void)hipEventRecord(g_prof_e1, st);
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_prof_name, sizeof(g_prof_name), fmt, ap);
+  va_end(ap);
+  g_prof_flops = flops;
+  g_prof_e0 = g_prof_e1 = nullptr;
+}
+static inline double desc_flops(const lmh_conv_desc* d) {
+  return 2.0 * d->N * d->OH * d->OW * (double)d->K * d->R * d->S * d->C;
 }
 
 // Tuning override (diagnostics only: scripts/bench_conv.py sweeps tile shapes / split counts with it).
@@ -103,8 +140,10 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
     const int tiles_h = (d->OH + STEM_TH - 1) / STEM_TH, tiles_w = (d->OW + STEM_TW - 1) / STEM_TW;
     const int ntiles = d->N * tiles_h * tiles_w;
     const int grid1 = ntiles < 512 ? ntiles : 512;   // 2 resident blocks per CU (61 KB LDS each)
+    prof_begin(st);
     hipLaunchKernelGGL(k_conv_stem7x7s2<0>, dim3(grid1), dim3(256), 0, st, *d, x, w, scale, shift, in_sub, y, tiles_h,
                        tiles_w);
+    prof_end(st, desc_flops(d), "k_conv_stem7x7s2<0>");
     LMH_CHECK_LAUNCH();
     return LMH_OK;
   }
@@ -121,10 +160,13 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
       hipLaunchKernelGGL((k_conv_fwd_gen<BM_, BN_, false>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, \
                          shift, residual, in_sub, y);                                                     \
   } while (0)
+  prof_begin(st);
   if (bm == 128 && bn == 128) LAUNCH_FWD(128, 128);
   else if (bm == 128) LAUNCH_FWD(128, 64);
   else LAUNCH_FWD(64, 64);
 #undef LAUNCH_FWD
+  if (fast) prof_end(st, desc_flops(d), "k_conv_fwd<%d, %d, false>", bm, bn);
+  else prof_end(st, desc_flops(d), "k_conv_fwd_gen<%d, %d, %s>", bm, bn, (d->C % BK) != 0 ? "true" : "false");
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -157,10 +199,13 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
       hipLaunchKernelGGL((k_conv_bwd_data_gen<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale,  \
                          addend, dx);                                                                       \
   } while (0)
+  prof_begin(st);
   if (bm == 128 && bn == 128) LAUNCH_BD(128, 128);
   else if (bm == 128) LAUNCH_BD(128, 64);
   else LAUNCH_BD(64, 64);
 #undef LAUNCH_BD
+  if (fast) prof_end(st, desc_flops(d), "k_conv_bwd_data<%d, %d, %s>", bm, bn, yact ? "true" : "false");
+  else prof_end(st, desc_flops(d), "k_conv_bwd_data_gen<%d, %d>", bm, bn);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -264,11 +309,15 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     else                                                                                                 \
       hipLaunchKernelGGL((k_conv_bwd_weight_gen<BM_, BN_>), grid, dim3(256), 0, st, *d, x, dy, out, kps); \
   } while (0)
+  prof_begin(st);
   if (bm == 128 && bn == 128) LAUNCH_BW(128, 128);
   else if (bm == 128) LAUNCH_BW(128, 64);
   else if (bn == 128) LAUNCH_BW(64, 128);
   else LAUNCH_BW(64, 64);
 #undef LAUNCH_BW
+  if (fast) prof_end(st, desc_flops(d), "k_conv_bwd_weight<%d, %d, %s, %s>", bm, bn, (yact && !gb) ? "true" : "false",
+                     gb ? "true" : "false");
+  else prof_end(st, desc_flops(d), "k_conv_bwd_weight_gen<%d, %d>", bm, bn);
   if (splits > 1 || colsum) {
     const int64_t n = splits > 1 ? (int64_t)d->R * d->S * d->C * d->K : 0;
     const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;

@@ -265,10 +265,12 @@ static int wino_run(const lmh_conv_desc* d, const float* in, int Cg, int Kg, con
 #define LAUNCH_WG(BM_, BN_)                                                                           \
   hipLaunchKernelGGL((k_conv_fwd<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U,  \
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, 16)
+  prof_begin(st);
   if (bm == 128 && bn == 128) LAUNCH_WG(128, 128);
   else if (bm == 128) LAUNCH_WG(128, 64);
   else LAUNCH_WG(64, 64);
 #undef LAUNCH_WG
+  prof_end(st, 16.0 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd<%d, %d, true>", bm, bn);
   {
     const int64_t n = (int64_t)T * (Kg / 4);
     hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,

@@ -63,10 +63,12 @@ def _workspace(nbytes, device, tag):
 
 # ------------------------------------------------------------- profiling ----
 class _Profile(object):
-    """Optional per-launch HIP-event timing of the conv kernels (bench.py roofline leg).
-    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+    """Optional per-launch timing of the convolution MFMA kernels (bench.py roofline leg).  The HIP events are
+    recorded by the C library on the launch stream directly around the implicit-GEMM kernel of each conv call
+    (lmh_conv2d_profile_next); the library also names the kernel as rocprofv3 prints it and reports the FLOPs
+    the launch executed (for a Winograd stacked GEMM: the 16 transformed-domain products, not the direct count)."""
     enabled = False
-    records = []   # (kernel_name, algorithmic_flops, start_event, end_event)
+    records = []   # (kernel, executed flops, direct-convolution flops of the layer, e0, e1)
 
     @classmethod
     def start(cls):
@@ -76,17 +78,18 @@ class _Profile(object):
     def stop(cls):
         cls.enabled = False
         torch.cuda.synchronize()
+        lib = _lib.load()
         out = {}
-        for name, flops, e0, e1 in cls.records:
-            r = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
+        for name, flops, direct, e0, e1 in cls.records:
+            r = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'direct_flops': 0.0, 'ms': 0.0})
             r['launches'] += 1
             r['flops'] += flops
-            r['ms'] += e0.elapsed_time(e1)
+            r['direct_flops'] += direct
+            r['ms'] += lib.lmh_event_elapsed_ms(e0, e1)
+            lib.lmh_event_destroy(e0)
+            lib.lmh_event_destroy(e1)
         cls.records = []
         return out
-
-
-_OPN = {0: 'k_conv_fwd', 1: 'k_conv_bwd_data', 2: 'k_conv_bwd_weight'}
 
 
 def _conv_flops(d):
@@ -94,27 +97,23 @@ def _conv_flops(d):
 
 
 class _timed(object):
-    def __init__(self, d, op, wino=False):
+    def __init__(self, d, op=None, wino=False):
         self.on = _Profile.enabled
-        if self.on:
-            kid = _lib.load().lmh_conv2d_kernel_id(ctypes.byref(d), op)
-            gen = '_gen' if kid >= 1000000 else ''
-            kid %= 1000000
-            self.name = '%s%s<%d,%d>' % (_OPN[op], gen, kid // 1000, kid % 1000)
-            if wino:   # whole Winograd pipeline (transforms + 16 GEMMs); flops stay the direct-convolution count
-                self.name = _OPN[op].replace('k_conv', 'winograd')
-            self.flops = _conv_flops(d)
+        self.d = d
 
     def __enter__(self):
         if self.on:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
+            lib = _lib.load()
+            self.e0, self.e1 = lib.lmh_event_create(), lib.lmh_event_create()
+            lib.lmh_conv2d_profile_next(self.e0, self.e1)
 
     def __exit__(self, *a):
         if self.on:
-            self.e1.record()
-            _Profile.records.append((self.name, self.flops, self.e0, self.e1))
+            fl = ctypes.c_double(0.0)
+            name = _lib.load().lmh_conv2d_profile_last(ctypes.byref(fl))
+            name = name.decode() if name else ''
+            if name:
+                _Profile.records.append((name, fl.value, _conv_flops(self.d), self.e0, self.e1))
 
 
 # ------------------------------------------------------------------ conv ----

@@ -144,6 +144,10 @@ class GradientBuckets(object):
     def _launch(self, lo, hi):
         from luminoth_amd.models.base.layers import SideStream
         grad = self.store.grad
+        if not grad.is_cuda:          # host tensors (gloo tests): program order is the only order
+            self._works.append(self.reduce_fn(grad[lo:hi]) or _Done())
+            self._done.append((lo, hi))
+            return
         cur = torch.cuda.current_stream(grad.device)
         if self._comm is None:
             self._comm = torch.cuda.Stream(device=grad.device)
@@ -169,7 +173,7 @@ class GradientBuckets(object):
             todo.append((pos, numel))
         for w in self._works:
             w.wait()
-        if self._comm is not None and self._works:
+        if self._comm is not None and self._works and grad.is_cuda:
             torch.cuda.current_stream(grad.device).wait_stream(self._comm)
         for lo, hi in todo:
             w = self.reduce_fn(grad[lo:hi]) or _Done()
@@ -200,7 +204,8 @@ class MomentumOptimizer(object):
         self.buckets = None
         if dist.is_available() and dist.is_initialized() and \
                 (dist.get_world_size() > 1 or os.environ.get('LUMINOTH_AMD_FORCE_BUCKETS') == '1'):
-            if os.environ.get('LUMINOTH_AMD_BUCKETED_ALLREDUCE', '1') != '0' and self.store.grad.is_cuda:
+            if os.environ.get('LUMINOTH_AMD_BUCKETED_ALLREDUCE', '1') != '0' and \
+                    (self.store.grad.is_cuda or os.environ.get('LUMINOTH_AMD_FORCE_BUCKETS') == '1'):
                 self.buckets = GradientBuckets(self.store)
                 install_buckets(self.buckets)
 

@@ -75,6 +75,117 @@ def test_flat_gradient_allreduce_world2():
     np.testing.assert_allclose(w0_new, exp, rtol=1e-5, atol=1e-7)
 
 
+class _FakeLayer(object):
+    def __init__(self, scope, with_bn):
+        self.w_name = scope + '/weights'
+        self._names = [self.w_name] + ([scope + '/BatchNorm/beta', scope + '/BatchNorm/gamma'] if with_bn else [])
+
+    def var_names(self):
+        return self._names
+
+
+class _FakeNode(object):
+    def __init__(self, layers):
+        self.layers = layers
+
+
+class _FakeTrunk(object):
+    def __init__(self, nodes):
+        self.nodes = nodes
+
+
+def _bucket_worker(rank, world, port, q):
+    """The path N > 1 actually takes: MomentumOptimizer installs GradientBuckets, the (simulated) trunk backward
+    finishes the flat gradient buffer from the back and calls the node hook, early buckets are all-reduced
+    asynchronously (gloo) while 'earlier nodes' are still being written, finish() reduces the rest."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LUMINOTH_AMD_FORCE_BUCKETS='1', LUMINOTH_AMD_BUCKET_MB='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from luminoth_amd.models.base import layers as L
+    from luminoth_amd.utils import training
+    from luminoth_amd.utils.config import Config
+
+    def sgd_twin(w, g, v, seg_offset, seg_wd, lr, momentum, gscale):
+        v.mul_(momentum).add_(g * gscale)
+        w.sub_(lr * v)
+    training.K.sgd_momentum = sgd_twin
+    # flat layout like the real store: conv weights node after node, then the BatchNorm block, then the heads
+    sizes = [40, 24, 64, 16, 100]
+    nodes = [_FakeNode([_FakeLayer('n%d' % i, True)]) for i in range(len(sizes))]
+    offsets, o = {}, 0
+    for i, sz in enumerate(sizes):
+        offsets['n%d/weights' % i] = (True, o, sz)
+        o += sz
+    for kind in ('gamma', 'beta'):
+        for i in range(len(sizes)):
+            offsets['n%d/BatchNorm/%s' % (i, kind)] = (True, o, 4)
+            o += 4
+    heads_lo = o
+    n = o + 60                                            # RPN / RCNN variables
+    m = _Model()
+    m.store = _Store(n, rank)
+    m.store.offsets = offsets
+    m.store.grad = torch.zeros(n)
+    g_local = torch.randn(n, generator=torch.Generator().manual_seed(100 + rank))
+    cfg = Config({'learning_rate': {'decay_method': None, 'learning_rate': 0.01},
+                  'optimizer': {'type': 'momentum', 'momentum': 0.9}, 'clip_by_norm': False})
+    opt = training.get_optimizer(cfg, m)
+    assert opt.buckets is not None and training.ACTIVE_BUCKETS is opt.buckets and L.BACKWARD_HOOK is not None
+    calls = []
+    real = opt.buckets.reduce_fn
+
+    def counting(t):
+        calls.append(int(t.numel()))
+        return real(t)
+    opt.buckets.reduce_fn = counting
+    trunk = _FakeTrunk(nodes)
+    w0 = m.store.flat.clone()
+    for step in range(2):
+        del calls[:]
+        m.store.grad.zero_()
+        m.store.grad[heads_lo:] = g_local[heads_lo:]      # head gradients complete before the trunk backward
+        opt.buckets.arm(trunk)
+        L.BACKWARD_HOOK(nodes, len(nodes))
+        for j in range(len(nodes) - 1, -1, -1):           # Trunk.backward: node j's gradients, then the hook
+            _, lo, cnt = offsets['n%d/weights' % j]
+            m.store.grad[lo:lo + cnt] = g_local[lo:lo + cnt]
+            for kind in ('gamma', 'beta'):
+                _, lo, cnt = offsets['n%d/BatchNorm/%s' % (j, kind)]
+                m.store.grad[lo:lo + cnt] = g_local[lo:lo + cnt]
+            L.BACKWARD_HOOK(nodes, j)
+        early = len(calls)
+        opt.buckets.disarm()
+        opt.step()                                        # finish() + update
+        if step == 0:
+            first = (early, list(calls), m.store.grad.clone())
+    training.install_buckets(None)
+    q.put((rank, g_local.numpy(), first[0], first[1], first[2].numpy(), m.store.flat.numpy().copy(), w0.numpy(), n))
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, g0, early0, calls0, s0, w0_new, w0, n), (_, g1, early1, calls1, s1, w1_new, _, _) = res
+    assert early0 == early1 >= 3 and len(calls0) > early0          # heads + trunk runs early, the BN block in finish()
+    assert calls0 == calls1 and sum(calls0) == n                    # every element exactly once, same order on all ranks
+    np.testing.assert_allclose(s0, g0 + g1, rtol=1e-6)
+    np.testing.assert_array_equal(s0, s1)
+    np.testing.assert_array_equal(w0_new, w1_new)                   # replicas stay bit-identical after two steps
+    v1 = (g0 + g1) * 0.5
+    exp = w0 - 0.01 * v1 - 0.01 * (0.9 * v1 + v1)
+    np.testing.assert_allclose(w0_new, exp, rtol=1e-5, atol=1e-6)
+
+
 def test_learning_rate_schedules():
     sys.path.insert(0, ROOT)
     from luminoth_amd.utils.config import Config
