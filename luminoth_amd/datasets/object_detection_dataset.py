@@ -60,6 +60,18 @@ class ObjectDetectionDataset(object):
             self._image_fixed_width = ip.fixed_width
         self._data_augmentation = ds.get('data_augmentation') or []   # object_detection_dataset.py:65-66
         self._rng = np.random.RandomState(self._seed)
+        # data parallel: the record order is permuted identically on every rank and dealt out rank::world; the
+        # augmentation draws are per rank (rank 0 / single GPU keep the stream above)
+        from luminoth_amd.utils.sharding import rank_world, shared_seed
+        self._rank, self._world = kwargs.get('rank'), kwargs.get('world')
+        if self._rank is None or self._world is None:
+            self._rank, self._world = rank_world()
+        self._order_rng = None
+        if self._world > 1:
+            s = shared_seed(self._seed)
+            self._order_rng = np.random.RandomState(s)
+            if self._rank > 0:
+                self._rng = np.random.RandomState(((s or 0) * 1000003 + self._rank) % (2 ** 32))
         self._decode_threads = int(ds.get('decode_threads', 4))
         self._warned = set()
 
@@ -153,7 +165,7 @@ class ObjectDetectionDataset(object):
         f = tfrecord.TFRecordFile(path, verify=False)
         n = len(f)
         f.close()
-        return (n // self._batch_size) * int(self._num_epochs or 1)
+        return ((n // self._world) // self._batch_size) * int(self._num_epochs or 1)
 
     def __iter__(self):
         """Yields {'image': (B,H',W',3) float32 device tensor, 'bboxes': [ (G,5) float32 ], 'filename': [str],
@@ -173,7 +185,12 @@ class ObjectDetectionDataset(object):
         try:
             order = []
             for _ in range(epochs):
-                order.extend(self._rng.permutation(n).tolist() if self._random_shuffle else range(n))
+                if self._world > 1:
+                    from luminoth_amd.utils.sharding import shard_order
+                    full = self._order_rng.permutation(n).tolist() if self._random_shuffle else range(n)
+                    order.extend(shard_order(full, self._rank, self._world))
+                else:
+                    order.extend(self._rng.permutation(n).tolist() if self._random_shuffle else range(n))
             pending = []
             pos = 0
             batch = []

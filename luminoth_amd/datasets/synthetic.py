@@ -19,15 +19,19 @@ class SyntheticObjectDetectionDataset(object):
         self.num_images = int(ds.get('num_images', 64))
         self.num_epochs = int(config.train.get('num_epochs', 1) or 1)
         self.seed = int(config.train.get('seed') or 0)
+        from luminoth_amd.utils.sharding import rank_world
+        self.rank, self.world = rank_world()
 
     def __len__(self):
-        return (self.num_images // self.batch_size) * self.num_epochs
+        return ((self.num_images // self.batch_size) // self.world) * self.num_epochs
 
     def __iter__(self):
         for epoch in range(self.num_epochs):
             g = torch.Generator().manual_seed(self.seed)          # same images every epoch
             rs = np.random.RandomState(self.seed)
-            for i in range(self.num_images // self.batch_size):
+            nb = self.num_images // self.batch_size
+            for i in range(nb):
+                mine = i % self.world == self.rank and i // self.world < nb // self.world   # batches dealt rank::world
                 H, W, G = self.height, self.width, self.boxes_per_image
                 image = torch.rand((self.batch_size, H, W, 3), generator=g) * 255.0
                 boxes = []
@@ -36,5 +40,7 @@ class SyntheticObjectDetectionDataset(object):
                     xy = np.stack([rs.randint(0, W - wh[:, 0]), rs.randint(0, H - wh[:, 1])], 1)
                     lab = rs.randint(0, self.num_classes, size=(G, 1))
                     boxes.append(np.concatenate([xy, xy + wh - 1, lab], 1).astype(np.float32))
+                if not mine:
+                    continue
                 yield {'image': image, 'bboxes': boxes,
                        'filename': ['synthetic_%d_%d' % (epoch, i * self.batch_size + b) for b in range(self.batch_size)]}

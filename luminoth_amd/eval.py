@@ -191,7 +191,7 @@ def evaluate(config_files, override_params=(), dataset_split='val', watch=True, 
     the latest with --no-watch).  Returns the list of result dicts."""
     from luminoth_amd.datasets import get_dataset
     from luminoth_amd.models import get_model
-    from luminoth_amd.train import list_checkpoints
+    from luminoth_amd.train import list_checkpoints, restore_checkpoint
     from luminoth_amd.utils.config import get_config
     try:
         config = get_config(list(config_files), override_params=list(override_params))
@@ -220,8 +220,7 @@ def evaluate(config_files, override_params=(), dataset_split='val', watch=True, 
             log.info('No checkpoints found')
         for step, path in ckpts:
             log.info('Evaluating global_step %d using checkpoint \'%s\'', step, path)
-            data = np.load(path)
-            model.load_state_dict({k: data[k] for k in data.files if k != 'global_step'})
+            restore_checkpoint(model, path)
             dataset = get_dataset(config.dataset.type)(config)
             res = evaluate_once(config, model, dataset, global_step=step, class_labels=class_labels,
                                 split=dataset_split)

@@ -22,7 +22,7 @@ import time
 import numpy as np
 
 log = logging.getLogger('luminoth_amd')
-CKPT_RE = re.compile(r'model\.ckpt-(\d+)\.npz$')
+CKPT_RE = re.compile(r'model\.ckpt-(\d+)\.(?:index|npz)$')
 
 
 # ------------------------------------------------------------ checkpoints ----
@@ -36,27 +36,67 @@ def checkpoint_dir(config):
 
 
 def list_checkpoints(ckpt_dir):
-    out = []
-    for f in glob.glob(os.path.join(ckpt_dir, 'model.ckpt-*.npz')):
+    """[(global_step, path)] sorted by step.  `path` is the TensorFlow V2 bundle PREFIX `model.ckpt-N` (files
+    `.index` + `.data-00000-of-00001`, what `tf.train.Saver` writes and the reference's tooling reads); `.npz`
+    files written by round-1 builds of this repo are still listed (path ends in .npz)."""
+    found = {}
+    for f in glob.glob(os.path.join(ckpt_dir, 'model.ckpt-*')):
         m = CKPT_RE.search(f)
         if m:
-            out.append((int(m.group(1)), f))
-    return sorted(out)
+            step = int(m.group(1))
+            path = f[:-len('.index')] if f.endswith('.index') else f
+            if step not in found or not path.endswith('.npz'):
+                found[step] = path
+    return sorted(found.items())
+
+
+def _remove_checkpoint(path):
+    for f in ([path] if path.endswith('.npz') else glob.glob(path + '.index') + glob.glob(path + '.data-*')):
+        os.remove(f)
 
 
 def save_checkpoint(model, global_step, ckpt_dir, max_to_keep=1):
-    """Model variables + global_step (no optimizer slots), `max_to_keep` newest files kept."""
+    """Model variables + `global_step` (no optimizer slots, like train.py:93-112) as a TensorFlow V2 tensor
+    bundle under the variables' TF names, so checkpoints travel both ways between this path and the reference's
+    tooling (`tf.train.Saver`, `lumi predict --checkpoint`); the `checkpoint` pointer file names the prefix.
+    The `max_to_keep` newest checkpoints are kept."""
+    from luminoth_amd.utils import tf_checkpoint
     os.makedirs(ckpt_dir, exist_ok=True)
-    path = os.path.join(ckpt_dir, 'model.ckpt-%d.npz' % global_step)
-    sd = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, 'detach') else v) for k, v in model.state_dict().items()}
-    tmp = path + '.tmp.npz'
-    np.savez(tmp, global_step=np.int64(global_step), **sd)
-    os.replace(tmp, path)
-    with open(os.path.join(ckpt_dir, 'checkpoint'), 'w') as f:       # the TF-style pointer file
-        f.write('model_checkpoint_path: "%s"\n' % os.path.basename(path))
+    prefix = os.path.join(ckpt_dir, 'model.ckpt-%d' % global_step)
+    sd = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, 'detach') else v)
+          for k, v in model.state_dict().items()}
+    sd['global_step'] = np.asarray(global_step, dtype=np.int64)
+    tmp = prefix + '.tmp'
+    tf_checkpoint.save_v2(tmp, sd)
+    os.replace(tf_checkpoint._shard_name(tmp, 0, 1), tf_checkpoint._shard_name(prefix, 0, 1))
+    os.replace(tmp + '.index', prefix + '.index')       # the index goes last: a visible index has its data
+    with open(os.path.join(ckpt_dir, 'checkpoint'), 'w') as f:       # the TF pointer file
+        f.write('model_checkpoint_path: "%s"\n' % os.path.basename(prefix))
     for _, old in list_checkpoints(ckpt_dir)[:-max(1, int(max_to_keep))]:
-        os.remove(old)
-    return path
+        _remove_checkpoint(old)
+    return prefix
+
+
+def load_checkpoint_variables(path):
+    """{name: ndarray} (incl. `global_step` when present) of a checkpoint written by this repo or by TensorFlow
+    (V2 bundle prefix / V1 file), or of a legacy `.npz`."""
+    if path.endswith('.npz'):
+        data = np.load(path)
+        return {k: data[k] for k in data.files}
+    from luminoth_amd.utils import tf_checkpoint
+    return tf_checkpoint.load_checkpoint(path)
+
+
+def restore_checkpoint(model, path):
+    """Loads the model variables of `path`; returns its global step (parsed from the file name when the
+    checkpoint holds no `global_step` tensor)."""
+    values = load_checkpoint_variables(path)
+    step = values.pop('global_step', None)
+    model.load_state_dict(values)        # extra tensors (optimizer slots of a TF-written file) are ignored, missing ones raise
+    if step is None:
+        m = re.search(r'-(\d+)(?:\.npz)?$', path)
+        step = int(m.group(1)) if m else 0
+    return int(step)
 
 
 def restore_latest(model, ckpt_dir):
@@ -66,10 +106,7 @@ def restore_latest(model, ckpt_dir):
     ckpts = list_checkpoints(ckpt_dir)
     if not ckpts:
         return None
-    step, path = ckpts[-1]
-    data = np.load(path)
-    model.load_state_dict({k: data[k] for k in data.files if k != 'global_step'})
-    return int(data['global_step'])
+    return restore_checkpoint(model, ckpts[-1][1])
 
 
 # ------------------------------------------------------------------- run ----

@@ -146,3 +146,28 @@ def test_gradient_bucket_plan_on_resnet50_layout():
     # a trunk whose weights are not laid out node after node gets no early buckets
     b2 = GradientBuckets(st, reduce_fn=lambda t: None, bucket_bytes=1 << 20)
     assert b2._plan(list(reversed(nodes))) == {}
+
+
+def test_data_parallel_sharding_is_disjoint_and_equal_length(monkeypatch):
+    """every rank must see different records and run the same number of steps."""
+    from luminoth_amd.utils import sharding
+    order = list(np.random.RandomState(0).permutation(103))
+    parts = [sharding.shard_order(order, r, 4) for r in range(4)]
+    assert [len(p) for p in parts] == [25] * 4
+    flat = [i for p in parts for i in p]
+    assert len(set(flat)) == 100 and set(flat) <= set(order)
+    assert sharding.shard_order(order, 0, 1) == order
+    # synthetic dataset: batches dealt rank::world, same count on every rank
+    from luminoth_amd.datasets.synthetic import SyntheticObjectDetectionDataset
+    from luminoth_amd.utils.config import get_config
+    cfg = get_config({'model': {'type': 'fasterrcnn'}, 'dataset': {'type': 'synthetic', 'num_images': 7, 'height': 32,
+                                                                  'width': 32, 'boxes_per_image': 1},
+                      'train': {'batch_size': 1, 'num_epochs': 1, 'seed': 3}})
+    seen = []
+    for r in range(2):
+        monkeypatch.setattr(sharding, 'rank_world', lambda r=r: (r, 2))
+        ds = SyntheticObjectDetectionDataset(cfg)
+        names = [b['filename'][0] for b in ds]
+        assert len(names) == len(ds) == 3
+        seen.append(names)
+    assert not set(seen[0]) & set(seen[1])

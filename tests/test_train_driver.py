@@ -61,16 +61,33 @@ def test_train_runs_without_job_dir(monkeypatch):
 def test_train_saves_checkpoint_and_resumes(tmp_path, monkeypatch):
     cfg = make_config(str(tmp_path))
     assert patched_run(cfg, monkeypatch) == 3
-    ckpt = tmp_path / 'test_runname' / 'model.ckpt-3.npz'
-    assert ckpt.exists() and (tmp_path / 'test_runname' / 'checkpoint').read_text().strip().endswith('model.ckpt-3.npz"')
-    data = np.load(str(ckpt))
+    # checkpoints are TensorFlow V2 tensor bundles (what tf.train.Saver writes: train.py:93-112, 153)
+    run_dir = tmp_path / 'test_runname'
+    assert (run_dir / 'model.ckpt-3.index').exists() and (run_dir / 'model.ckpt-3.data-00000-of-00001').exists()
+    assert (run_dir / 'checkpoint').read_text().strip() == 'model_checkpoint_path: "model.ckpt-3"'
+    from luminoth_amd.utils import tf_checkpoint
+    data = tf_checkpoint.load_v2(str(run_dir / 'model.ckpt-3'))
     np.testing.assert_allclose(data['mockfasterrcnn/w'], [3.5, 4.0])  # 3 steps of +0.5 (train_test.py:155-157 analogue)
-    assert int(data['global_step']) == 3
+    assert int(data['global_step']) == 3 and data['global_step'].dtype == np.int64
     # resume: continues from step 3 with the saved weights; old checkpoints beyond max_to_keep are dropped
     assert patched_run(cfg, monkeypatch) == 6
-    files = sorted(os.listdir(str(tmp_path / 'test_runname')))
-    assert 'model.ckpt-6.npz' in files and 'model.ckpt-3.npz' not in files
-    np.testing.assert_allclose(np.load(str(tmp_path / 'test_runname' / 'model.ckpt-6.npz'))['mockfasterrcnn/w'], [5.0, 5.5])
+    files = sorted(os.listdir(str(run_dir)))
+    assert 'model.ckpt-6.index' in files and not [f for f in files if f.startswith('model.ckpt-3')]
+    np.testing.assert_allclose(tf_checkpoint.load_v2(str(run_dir / 'model.ckpt-6'))['mockfasterrcnn/w'], [5.0, 5.5])
+
+
+def test_restore_reads_legacy_npz_and_foreign_tf_checkpoints(tmp_path):
+    """A round-1 `.npz` checkpoint and a TF-written bundle with optimizer slots / no global_step both restore."""
+    from luminoth_amd.utils import tf_checkpoint
+    m = MockModel(None)
+    np.savez(str(tmp_path / 'model.ckpt-5.npz'), global_step=np.int64(5), **{'mockfasterrcnn/w': np.array([7.0, 8.0], np.float32)})
+    assert T.restore_latest(m, str(tmp_path)) == 5
+    np.testing.assert_allclose(m.w.numpy(), [7.0, 8.0])
+    tf_checkpoint.save_v2(str(tmp_path / 'model.ckpt-12'), {'mockfasterrcnn/w': np.array([1.0, 2.0], np.float32),
+                                                           'mockfasterrcnn/w/Momentum': np.zeros(2, np.float32)})
+    assert [s for s, _ in T.list_checkpoints(str(tmp_path))] == [5, 12]
+    assert T.restore_latest(m, str(tmp_path)) == 12          # step parsed from the file name
+    np.testing.assert_allclose(m.w.numpy(), [1.0, 2.0])
 
 
 def test_checkpoint_rotation_and_dataset_registry(tmp_path):
