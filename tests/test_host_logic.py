@@ -160,8 +160,8 @@ def test_data_parallel_sharding_is_disjoint_and_equal_length(monkeypatch):
     # synthetic dataset: batches dealt rank::world, same count on every rank
     from luminoth_amd.datasets.synthetic import SyntheticObjectDetectionDataset
     from luminoth_amd.utils.config import get_config
-    cfg = get_config({'model': {'type': 'fasterrcnn'}, 'dataset': {'type': 'synthetic', 'num_images': 7, 'height': 32,
-                                                                  'width': 32, 'boxes_per_image': 1},
+    cfg = get_config({'model': {'type': 'fasterrcnn'}, 'dataset': {'type': 'synthetic', 'num_images': 7, 'height': 96,
+                                                                  'width': 96, 'boxes_per_image': 1},
                       'train': {'batch_size': 1, 'num_epochs': 1, 'seed': 3}})
     seen = []
     for r in range(2):
