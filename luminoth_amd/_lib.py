@@ -87,6 +87,8 @@ SIGNATURES = {
     'lmh_conv2d_bwd_weight': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_kernel_id': (c_i, [P(ConvDesc), c_i]),
     'lmh_conv2d_force_config': (None, [c_i, c_i, c_i]),
+    'lmh_conv2d_force_wgrad_variant': (None, [c_i]),
+    'lmh_conv2d_bwd_weight_fuses_colsum': (c_i, [P(ConvDesc)]),
     'lmh_conv2d_profile_next': (c_i, [c_f, c_f]),
     'lmh_conv2d_profile_last': (ctypes.c_char_p, [P(ctypes.c_double)]),
     'lmh_event_create': (ctypes.c_void_p, []),

@@ -34,6 +34,7 @@
 __device__ __attribute__((aligned(64))) float lmh_zero_page[16];  // zero-initialised: padding source
 
 #include "conv_fast.h"
+#include "conv_wgrad1x1.h"
 
 // ============================================================================
 // host dispatch
@@ -237,6 +238,41 @@ static void bwd_weight_plan(const lmh_conv_desc* d, int* bm, int* bn, int* split
   *splits = (KT + *kt_per_split - 1) / *kt_per_split;
 }
 
+// ---- 1x1 / stride-1 weight gradient through the direct-to-LDS GEMM kernel (conv_wgrad1x1.h) -------------------
+// variant: 0 automatic, -1 never (the register-staged k_conv_bwd_weight), 2..4 = forced LDS ring depth
+static int g_wg_variant = 0;
+extern "C" void lmh_conv2d_force_wgrad_variant(int v) { g_wg_variant = v; }
+static bool wgrad_1x1_ok(const lmh_conv_desc* d) {
+  static const int on = env_int("LMH_WGRAD_GLDS", 1);
+  return on && g_wg_variant >= 0 && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_top == 0 &&
+         d->pad_left == 0 && d->OH == d->H && d->OW == d->W && (d->C & 3) == 0 && (d->K & 3) == 0 &&
+         d->C >= 32 && d->K >= 32;
+}
+// 64x64 tiles: the partial-slab traffic of a split-K weight gradient is 2 * 4 B * (blocks) * BM * BN whatever the
+// layer, so small tiles win on these skinny outputs once the per-stage instruction overhead is gone (glds).
+// Splits: fill `slots` resident blocks (2 per CU) with >= 8 stages per block.
+static void wgrad_1x1_plan(const lmh_conv_desc* d, int* bm, int* bn, int* nbuf, int* splits, int* kt_per_split) {
+  *bm = 64; *bn = 64;
+  if (g_force_bm && g_force_bn) { *bm = g_force_bm; *bn = g_force_bn; }
+  *nbuf = (g_wg_variant >= 2 && g_wg_variant <= 4) ? g_wg_variant : 4;
+  if (*bm == 128 && *bn == 128 && *nbuf > 4) *nbuf = 4;
+  const int64_t tiles = (int64_t)((d->C + *bm - 1) / *bm) * ((d->K + *bn - 1) / *bn);
+  const int64_t P = (int64_t)d->N * d->OH * d->OW;
+  const int KT = (int)((P + BK - 1) / BK);
+  static const int slots = env_int("LMH_WG_SLOTS", 512);
+  int want = (int)(slots / tiles);
+  if (want < 1) want = 1;
+  const int max_split = KT / 8 > 0 ? KT / 8 : 1;
+  if (want > max_split) want = max_split;
+  if (g_force_splits) want = g_force_splits < KT ? g_force_splits : KT;
+  *kt_per_split = (KT + want - 1) / want;
+  *splits = (KT + *kt_per_split - 1) / *kt_per_split;
+}
+
+extern "C" int lmh_conv2d_bwd_weight_fuses_colsum(const lmh_conv_desc* d) {
+  return d && bwd_weight_fast(d) && !wgrad_1x1_ok(d) ? 1 : 0;
+}
+
 extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
   if (!d) return -1;
   int bm = 0, bn = 0;
@@ -251,6 +287,11 @@ extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
     return bm * 1000 + bn + (bwd_data_fast(d) ? 0 : 1000000);
   }
   int splits, kps;
+  if (wgrad_1x1_ok(d)) {
+    int nbuf;
+    wgrad_1x1_plan(d, &bm, &bn, &nbuf, &splits, &kps);
+    return bm * 1000 + bn;
+  }
   bwd_weight_plan(d, &bm, &bn, &splits, &kps);
   return bm * 1000 + bn + (bwd_weight_fast(d) ? 0 : 1000000);
 }
@@ -258,6 +299,17 @@ extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
 extern "C" size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d) {
   if (!d) return 0;
   int bm, bn, splits, kps;
+  if (wgrad_1x1_ok(d)) {
+    int nbuf;
+    wgrad_1x1_plan(d, &bm, &bn, &nbuf, &splits, &kps);
+    // slabs; the column sums of this path are NOT fused (the caller takes them from lmh_act_bwd), but a caller that
+    // passes `colsum` anyway is served by the register-staged kernel, whose plan may need more room
+    int bm2, bn2, s2, k2;
+    bwd_weight_plan(d, &bm2, &bn2, &s2, &k2);
+    if (s2 > splits) splits = s2;
+    const size_t slabs = splits <= 1 ? 256 : lmh_align_up((size_t)splits * d->C * d->K * sizeof(float), 256);
+    return slabs + lmh_align_up((size_t)splits * d->K * sizeof(float), 256);
+  }
   bwd_weight_plan(d, &bm, &bn, &splits, &kps);
   // split-K slabs, then [splits][K] column-sum partials (fused dbeta / dbias)
   const size_t slabs = splits <= 1 ? 256 : lmh_align_up((size_t)splits * d->R * d->S * d->C * d->K * sizeof(float), 256);
@@ -281,6 +333,39 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
   LMH_CHECK_ARG(x && dy && dw);
   LMH_CHECK_ARG(!gb || (bwd_weight_fast(d) && !yact && !colsum));
   int bm, bn, splits, kps;
+  if (!gb && !yact && !colsum && wgrad_1x1_ok(d)) {       // pure TN GEMM: direct-to-LDS kernel
+    int nbuf;
+    wgrad_1x1_plan(d, &bm, &bn, &nbuf, &splits, &kps);
+    if (ws_bytes < lmh_conv2d_bwd_weight_workspace_bytes(d) || (splits > 1 && !ws)) {
+      lmh_set_error("lmh_conv2d_bwd_weight: workspace too small");
+      return LMH_ERR_WORKSPACE;
+    }
+    const int P = d->N * d->OH * d->OW;
+    const int tc = (d->C + bm - 1) / bm, tk = (d->K + bn - 1) / bn;
+    float* o = splits > 1 ? reinterpret_cast<float*>(ws) : dw;
+    const dim3 grid1(tc * tk * splits);
+#define LAUNCH_WG1(BM_, BN_, NB_)                                                                              \
+    hipLaunchKernelGGL((k_wgrad_1x1<BM_, BN_, NB_>), grid1, dim3(256), 0, stream, x, dy, o, P, d->C, d->K, kps, tc, \
+                       tk, splits)
+#define LAUNCH_WG1_T(BM_, BN_)                                                                                 \
+    do { if (nbuf == 2) LAUNCH_WG1(BM_, BN_, 2); else if (nbuf == 3) LAUNCH_WG1(BM_, BN_, 3); else LAUNCH_WG1(BM_, BN_, 4); } while (0)
+    prof_begin(stream);
+    if (bm == 128 && bn == 128) LAUNCH_WG1_T(128, 128);
+    else if (bm == 128) LAUNCH_WG1_T(128, 64);
+    else if (bn == 128) LAUNCH_WG1_T(64, 128);
+    else LAUNCH_WG1_T(64, 64);
+#undef LAUNCH_WG1_T
+#undef LAUNCH_WG1
+    prof_end(stream, desc_flops(d), "k_wgrad_1x1<%d, %d, %d>", bm, bn, nbuf);
+    if (splits > 1) {
+      const int64_t n = (int64_t)d->C * d->K;
+      const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
+      hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, stream, reinterpret_cast<const float*>(ws), n,
+                         splits, dw, (const float*)nullptr, (float*)nullptr, d->K, nb_slab);
+    }
+    LMH_CHECK_LAUNCH();
+    return LMH_OK;
+  }
   bwd_weight_plan(d, &bm, &bn, &splits, &kps);
   if (ws_bytes < lmh_conv2d_bwd_weight_workspace_bytes(d) || (splits > 1 && !ws)) {
     lmh_set_error("lmh_conv2d_bwd_weight: workspace too small");

@@ -231,8 +231,9 @@ def conv_fused_act_ok(d):
 
 
 def conv_fused_colsum_ok(d):
-    """True when bwd_weight of `d` can emit the per-channel sums of its dy operand (fast path)."""
-    return _lib.load().lmh_conv2d_kernel_id(ctypes.byref(d), 2) < 1000000
+    """True when bwd_weight of `d` can emit the per-channel sums of its dy operand itself (register-staged fast
+    path); the 1x1 direct-to-LDS kernel cannot, its layers take them from the lmh_act_bwd pass that makes g."""
+    return bool(_lib.load().lmh_conv2d_bwd_weight_fuses_colsum(ctypes.byref(d)))
 
 
 def conv_bwd_data_fast(d):

@@ -436,6 +436,52 @@ WINO_CASES = [
 ]
 
 
+WG1_CASES = [
+    # N, H, W, C, K: 1x1 / stride-1 weight gradients = TN GEMMs over P = N*H*W pixels (conv_wgrad1x1.h)
+    (2, 16, 16, 64, 64),        # one tile, P = 512
+    (1, 13, 17, 96, 160),       # ragged P = 221, partial tiles on both axes
+    (2, 32, 32, 256, 128),      # ResNet block2 conv1 geometry, scaled down
+    (1, 1, 500, 1024, 320),     # Sonnet Linear (fc_bbox): P = ROIs
+    (1, 7, 9, 32, 36),          # smaller than one tile everywhere
+]
+
+
+@pytest.mark.parametrize('case', WG1_CASES)
+def test_wgrad_1x1_direct_to_lds_variants(K, case):
+    """Every tile shape x LDS ring depth x split count of the direct-to-LDS 1x1 weight-gradient kernel against a
+    plain fp32 reference, and bit-identical results across ring depths (same summation order)."""
+    N, H, W, C, Kc = case
+    rs = np.random.RandomState(7 + WG1_CASES.index(case))
+    x = rs.randn(N, H, W, C).astype(F)
+    g = rs.randn(N, H, W, Kc).astype(F)
+    d = K.conv_desc(x.shape, (1, 1, C, Kc), 1, 1, 'VALID', None)
+    ref = torch.tensor(x).reshape(-1, C).double().t() @ torch.tensor(g).reshape(-1, Kc).double()
+    scale = float(ref.abs().max())
+    lib = K._lib.load()
+    assert lib.lmh_conv2d_bwd_weight_fuses_colsum(d) == 0
+    try:
+        for bm, bn in ((64, 64), (128, 64), (64, 128), (128, 128)):
+            for splits in (0, 1, 3):
+                outs = []
+                for nbuf in (2, 3, 4):
+                    lib.lmh_conv2d_force_config(bm, bn, splits)
+                    lib.lmh_conv2d_force_wgrad_variant(nbuf)
+                    dw = K.conv2d_bwd_weight(d, T(x), T(g)).cpu()
+                    np.testing.assert_allclose(dw.reshape(C, Kc).numpy(), ref.numpy(), rtol=1e-4, atol=2e-5 * scale,
+                                               err_msg='tile %dx%d splits %d nbuf %d' % (bm, bn, splits, nbuf))
+                    outs.append(dw)
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        # the register-staged kernel (variant -1) agrees too
+        lib.lmh_conv2d_force_config(0, 0, 0)
+        lib.lmh_conv2d_force_wgrad_variant(-1)
+        assert lib.lmh_conv2d_bwd_weight_fuses_colsum(d) == 1
+        dw_old = K.conv2d_bwd_weight(d, T(x), T(g)).cpu()
+        np.testing.assert_allclose(dw_old.reshape(C, Kc).numpy(), ref.numpy(), rtol=1e-4, atol=2e-5 * scale)
+    finally:
+        lib.lmh_conv2d_force_config(0, 0, 0)
+        lib.lmh_conv2d_force_wgrad_variant(0)
+
+
 @pytest.mark.parametrize('case', WINO_CASES)
 def test_conv_winograd_equals_direct(K, case):
     """Winograd F(2x2,3x3) forward / backward-data against the torch fp32 reference AND the direct HIP kernels
