@@ -67,6 +67,10 @@ typedef struct lmh_conv_desc {
   int32_t stride, dilation;
   int32_t pad_top, pad_left;
   int32_t act;
+  /* Arithmetic of the MFMA operands: 0 = fp32 (v_mfma_f32_32x32x2_f32, the parity dtype), 1 = f16, 2 = bf16
+   * (v_mfma_f32_32x32x16_*: operands rounded to half precision on their way into LDS, fp32 accumulation, fp32
+   * tensors in memory — BASELINE configs[4]).  Shapes the half kernels do not cover run in fp32. */
+  int32_t compute;
 } lmh_conv_desc;
 
 int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const float* w,

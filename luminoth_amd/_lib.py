@@ -22,7 +22,7 @@ c_sz = ctypes.c_size_t
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         'N', 'H', 'W', 'C', 'K', 'R', 'S', 'OH', 'OW', 'stride', 'dilation',
-        'pad_top', 'pad_left', 'act')]
+        'pad_top', 'pad_left', 'act', 'compute')]
 
 
 class RpnProposalDesc(ctypes.Structure):

@@ -35,6 +35,7 @@ __device__ __attribute__((aligned(64))) float lmh_zero_page[16];  // zero-initia
 
 #include "conv_fast.h"
 #include "conv_wgrad1x1.h"
+#include "conv_half.h"
 
 // ============================================================================
 // host dispatch
@@ -44,6 +45,7 @@ static int check_desc(const lmh_conv_desc* d) {
   LMH_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0);
   LMH_CHECK_ARG(d->OH > 0 && d->OW > 0 && d->stride > 0 && d->dilation > 0);
   LMH_CHECK_ARG(d->act >= 0 && d->act <= 2);
+  LMH_CHECK_ARG(d->compute >= 0 && d->compute <= 2);
   LMH_CHECK_ARG((int64_t)d->N * d->OH * d->OW < (1ll << 31) && (int64_t)d->N * d->H * d->W < (1ll << 31));
   return LMH_OK;
 }
@@ -124,6 +126,10 @@ static void bwd_data_parity_tile(const lmh_conv_desc* d, int64_t M, int* bm, int
   if (par && (M / *bm) * ((d->C + *bn - 1) / *bn) <= 512) { *bm = 64; *bn = 64; }
 }
 static bool bwd_weight_fast(const lmh_conv_desc* d) { return (d->C & 3) == 0 && (d->K & 3) == 0; }
+// Static loss scaling inside the half-precision backward kernels: the gradient operand is multiplied by 2^10 before
+// it is rounded to f16 (5 exponent bits: activations gradients of 1e-7 would flush) and the fp32 accumulators by
+// 2^-10 afterwards — exact in fp32.  bf16 has fp32's exponent range and needs none.
+static float half_gscale(const lmh_conv_desc* d) { return d->compute == 1 ? 1024.f : 1.f; }
 
 extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
                               const float* shift, const float* residual, const float* in_sub, float* y,
@@ -149,6 +155,21 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
     return LMH_OK;
   }
   const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
+  if (d->compute && fast && in_sub == nullptr) {          // f16 / bf16 operands, fp32 accumulate (conv_half.h)
+#define LAUNCH_FWD_H(DT_, BM_, BN_)                                                                       \
+    hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y)
+#define LAUNCH_FWD_HT(BM_, BN_)                                                                           \
+    do { if (d->compute == 1) LAUNCH_FWD_H(1, BM_, BN_); else LAUNCH_FWD_H(2, BM_, BN_); } while (0)
+    prof_begin(st);
+    if (bm == 128 && bn == 128) LAUNCH_FWD_HT(128, 128);
+    else if (bm == 128) LAUNCH_FWD_HT(128, 64);
+    else LAUNCH_FWD_HT(64, 64);
+#undef LAUNCH_FWD_HT
+#undef LAUNCH_FWD_H
+    prof_end(st, desc_flops(d), "k_conv_fwd_h<%d, %d, %d>", d->compute, bm, bn);
+    LMH_CHECK_LAUNCH();
+    return LMH_OK;
+  }
 #define LAUNCH_FWD(BM_, BN_)                                                                              \
   do {                                                                                                    \
     if (fast)                                                                                             \
@@ -187,6 +208,24 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   pick_tile(M, d->C, &bm, &bn, bd_slots);
   bwd_data_parity_tile(d, M, &bm, &bn);
   hipStream_t st = (hipStream_t)stream;
+  if (d->compute && fast && !yact && !xmask) {
+    pick_tile(M, d->C, &bm, &bn, bd_slots);               // no parity classes in the half kernel: plain tile choice
+    const int gridh = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
+    const float gs = half_gscale(d);
+#define LAUNCH_BD_H(DT_, BM_, BN_)                                                                        \
+    hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx)
+#define LAUNCH_BD_HT(BM_, BN_)                                                                            \
+    do { if (d->compute == 1) LAUNCH_BD_H(1, BM_, BN_); else LAUNCH_BD_H(2, BM_, BN_); } while (0)
+    prof_begin(st);
+    if (bm == 128 && bn == 128) LAUNCH_BD_HT(128, 128);
+    else if (bm == 128) LAUNCH_BD_HT(128, 64);
+    else LAUNCH_BD_HT(64, 64);
+#undef LAUNCH_BD_HT
+#undef LAUNCH_BD_H
+    prof_end(st, desc_flops(d), "k_conv_bwd_data_h<%d, %d, %d>", d->compute, bm, bn);
+    LMH_CHECK_LAUNCH();
+    return LMH_OK;
+  }
   const int grid = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
 #define LAUNCH_BD(BM_, BN_)                                                                                 \
   do {                                                                                                      \
@@ -244,7 +283,7 @@ static int g_wg_variant = 0;
 extern "C" void lmh_conv2d_force_wgrad_variant(int v) { g_wg_variant = v; }
 static bool wgrad_1x1_ok(const lmh_conv_desc* d) {
   static const int on = env_int("LMH_WGRAD_GLDS", 1);
-  return on && g_wg_variant >= 0 && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_top == 0 &&
+  return on && g_wg_variant >= 0 && d->compute == 0 && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_top == 0 &&
          d->pad_left == 0 && d->OH == d->H && d->OW == d->W && (d->C & 3) == 0 && (d->K & 3) == 0 &&
          d->C >= 32 && d->K >= 32;
 }
@@ -270,7 +309,7 @@ static void wgrad_1x1_plan(const lmh_conv_desc* d, int* bm, int* bn, int* nbuf, 
 }
 
 extern "C" int lmh_conv2d_bwd_weight_fuses_colsum(const lmh_conv_desc* d) {
-  return d && bwd_weight_fast(d) && !wgrad_1x1_ok(d) ? 1 : 0;
+  return d && bwd_weight_fast(d) && !wgrad_1x1_ok(d) && d->compute == 0 ? 1 : 0;
 }
 
 extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
@@ -380,6 +419,31 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
   const bool fast = bwd_weight_fast(d);
   dim3 grid(d->R * d->S * ((d->C + bm - 1) / bm), (d->K + bn - 1) / bn, splits);
   const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
+  if (d->compute && fast && !gb && !yact && !colsum) {
+    const float gs = half_gscale(d);
+    const int nblk = (int)(grid.x * grid.y * grid.z);
+#define LAUNCH_BW_H(DT_, BM_, BN_)                                                                         \
+    hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z)
+#define LAUNCH_BW_HT(BM_, BN_)                                                                             \
+    do { if (d->compute == 1) LAUNCH_BW_H(1, BM_, BN_); else LAUNCH_BW_H(2, BM_, BN_); } while (0)
+    prof_begin(st);
+    if (bm == 128 && bn == 128) LAUNCH_BW_HT(128, 128);
+    else if (bm == 128) LAUNCH_BW_HT(128, 64);
+    else if (bn == 128) LAUNCH_BW_HT(64, 128);
+    else LAUNCH_BW_HT(64, 64);
+#undef LAUNCH_BW_HT
+#undef LAUNCH_BW_H
+    prof_end(st, desc_flops(d), "k_conv_bwd_weight_h<%d, %d, %d>", d->compute, bm, bn);
+    if (splits > 1) {
+      const int64_t n = (int64_t)d->R * d->S * d->C * d->K;
+      const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
+      hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
+                         splits, dw, (const float*)nullptr, (float*)nullptr, d->K, nb_slab);
+    }
+    LMH_CHECK_LAUNCH();
+    return LMH_OK;
+  }
 #define LAUNCH_BW(BM_, BN_)                                                                              \
   do {                                                                                                   \
     if (gb)                                                                                              \

@@ -1,0 +1,435 @@
+// Mixed-precision implicit-GEMM convolutions (gfx950): fp32 tensors in HBM, f16 / bf16 operands in LDS,
+// v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulation, fp32 epilogue.  BASELINE configs[4] ("fp16 MFMA path").
+//
+// What changes against conv_fast.h (v_mfma_f32_32x32x2_f32, 1/16 of this MFMA rate):
+//   * operands are rounded to half precision (RNE, v_cvt_pk_*) on their way from the staging registers into LDS, so
+//     nothing outside these three kernels changes: activations, gradients and master weights stay fp32 in HBM;
+//   * BOTH operands sit in LDS K-contiguous as [row][BK + 8] halfs (80-byte rows: 16-byte aligned and conflict-free
+//     for the 4 x 16-lane groups of ds_read_b128), because a 32x32x16 fragment is 8 consecutive k per lane = one
+//     ds_read_b128.  Operands whose reduction axis is the SLOW axis in memory (HWIO weights in the forward pass,
+//     both pixel-major operands of the weight gradient) are transposed in registers: a thread loads a 4(k) x 4(col)
+//     block as four float4 rows and writes four 8-byte k-quads, lanes ordered k-quad fastest so that a 16-lane
+//     group of ds_write_b64 covers all 32 banks;
+//   * backward operands are multiplied by a power-of-two `gscale` before rounding and the accumulators by 1/gscale
+//     in the epilogue (static loss scaling inside the kernel: f16 has 5 exponent bits; exact in fp32);
+//   * with the matrix pipe 16x faster the kernels are bound by the staging path (L2 -> VGPR -> cvt -> LDS), so the
+//     pipeline is the plain one: global loads of tile t+1 before the MFMAs of tile t, converted and written to the
+//     other LDS buffer after them, one barrier per stage.
+#pragma once
+#include "conv_fast.h"
+
+#define LDH (BK + 8)   // halfs per LDS row
+
+template <int DT> struct HT;
+template <> struct HT<1> {
+  typedef _Float16 T;
+  typedef _Float16 V4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 V8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct HT<2> {
+  typedef __bf16 T;
+  typedef __bf16 V4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 V8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <int DT>
+__device__ __forceinline__ typename HT<DT>::V4 cvt4(float a, float b, float c, float d) {
+  typedef typename HT<DT>::T T;
+  typename HT<DT>::V4 r;
+  r[0] = (T)a; r[1] = (T)b; r[2] = (T)c; r[3] = (T)d;
+  return r;
+}
+
+// K-contiguous source row -> LDS row segment (4 halfs at k = 4*kq)
+template <int DT>
+__device__ __forceinline__ void st_kc(typename HT<DT>::T* __restrict__ S, int row, int kq, f32x4 v) {
+  *reinterpret_cast<typename HT<DT>::V4*>(&S[row * LDH + 4 * kq]) = cvt4<DT>(v.x, v.y, v.z, v.w);
+}
+// 4(k) x 4(col) register block of a K-major source -> four LDS rows (cols), k-quad kq4
+template <int DT>
+__device__ __forceinline__ void st_km(typename HT<DT>::T* __restrict__ S, int col0, int kq4, const f32x4 (&r)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    *reinterpret_cast<typename HT<DT>::V4*>(&S[(col0 + e) * LDH + 4 * kq4]) = cvt4<DT>(r[0][e], r[1][e], r[2][e], r[3][e]);
+}
+
+// one BK = 32 stage: 2 k-steps of 16, fragments by ds_read_b128
+template <int DT, int TM, int TN>
+__device__ __forceinline__ void mfma_stage_h(const typename HT<DT>::T* __restrict__ As,
+                                             const typename HT<DT>::T* __restrict__ Bs, f32x16 (&acc)[TM][TN],
+                                             int a_off, int b_off, int lane) {
+  typedef typename HT<DT>::V8 V8;
+  const int l31 = lane & 31, kh = 8 * (lane >> 5);
+  V8 a[2][TM], b[2][TN];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int t = 0; t < TM; ++t) a[s][t] = *reinterpret_cast<const V8*>(&As[(a_off + t * 32 + l31) * LDH + s * 16 + kh]);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) b[s][t] = *reinterpret_cast<const V8*>(&Bs[(b_off + t * 32 + l31) * LDH + s * 16 + kh]);
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[s][tm], b[s][tn], acc[tm][tn]);
+}
+
+#define HALF_SMEM_FLOATS(BM_, BN_) \
+  (((2 * ((BM_) + (BN_)) * LDH + 1) / 2 > (BM_) * ((BN_) + 4)) ? (2 * ((BM_) + (BN_)) * LDH + 1) / 2 : (BM_) * ((BN_) + 4))
+
+// ============================================================================
+// forward:  y[p,k] = act( sum_{r,s,c} x[pix(p,r,s),c] * w[r,s,c,k] * scale[k] + shift[k] + res[p,k] )
+//   needs C % 32 == 0, K % 4 == 0.  A: gather (K-contiguous).  B: HWIO rows (K-major) -> transposed in registers.
+// ============================================================================
+template <int DT, int BM, int BN>
+__global__ void __launch_bounds__(256)
+k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
+             const float* __restrict__ scale, const float* __restrict__ shift,
+             const float* __restrict__ residual, float* __restrict__ y) {
+  typedef typename HT<DT>::T HTT;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32;
+  constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
+  constexpr int LDC = BN + 4;
+  __shared__ __attribute__((aligned(16))) float smem[HALF_SMEM_FLOATS(BM, BN)];
+  HTT* const As = reinterpret_cast<HTT*>(smem);       // [2][BM][LDH]
+  HTT* const Bs = As + 2 * A_SZ;                      // [2][BN][LDH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = d.N * d.OH * d.OW, K = d.K, C = d.C;
+  const int tiles_n = (K + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int CC = C / BK, KT = d.R * d.S * CC;
+  // ---- A gather state (as k_conv_fwd)
+  const int kq = tid & 7, arow = tid >> 3;
+  int a_n[AJ], a_ih0[AJ], a_iw0[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int p = m0 + arow + 32 * j;
+    if (p < M) {
+      const int ow = p % d.OW, t = p / d.OW;
+      a_n[j] = t / d.OH;
+      a_ih0[j] = (t % d.OH) * d.stride - d.pad_top;
+      a_iw0[j] = ow * d.stride - d.pad_left;
+    } else { a_n[j] = -1; a_ih0[j] = 0; a_iw0[j] = 0; }
+  }
+  const float* pa[AJ];
+  int inca[AJ];
+  auto setup_rs = [&](int rs_) {
+    const int r_ = rs_ / d.S, s_ = rs_ - r_ * d.S;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int ih = a_ih0[j] + r_ * d.dilation, iw = a_iw0[j] + s_ * d.dilation;
+      const bool ok = a_n[j] >= 0 && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+      pa[j] = ok ? x + ((size_t)(a_n[j] * d.H + ih) * d.W + iw) * C + 4 * kq : lmh_zero_page;
+      inca[j] = ok ? BK : 0;
+    }
+  };
+  // ---- B: rows (rs*C + c) of w are consecutive GEMM-k rows; 4x4 block per thread: k-quad kq, column quad cq
+  const int cq = tid >> 3;                             // 0..31
+  const bool b_act = cq < BN / 4;
+  const bool b_ok = b_act && (n0 + 4 * cq) < K;
+  const float* pb = b_ok ? w + (size_t)(4 * kq) * K + n0 + 4 * cq : lmh_zero_page;
+  const size_t rowb = b_ok ? (size_t)K : 0, incb = b_ok ? (size_t)BK * K : 0;
+
+  f32x4 ra[AJ], rb[4];
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  int rs = 0, cc = 0;
+  setup_rs(0);
+  auto advance = [&]() {
+    if (++cc == CC) { cc = 0; ++rs; setup_rs(rs); }
+    else {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) pa[j] += inca[j];
+    }
+    pb += incb;
+  };
+  auto load = [&]() {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
+    if (b_act) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(pb + i * rowb);
+    }
+  };
+  auto store = [&](int buf) {
+    HTT* Ad = As + buf * A_SZ;
+    HTT* Bd = Bs + buf * B_SZ;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) st_kc<DT>(Ad, arow + 32 * j, kq, ra[j]);
+    if (b_act) st_km<DT>(Bd, 4 * cq, kq, rb);
+  };
+  load();
+  store(0);
+  if (KT > 1) advance();
+  load();
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    mfma_stage_h<DT, TM, TN>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    store(cur ^ 1);                    // tile kt+1 (harmless duplicate after the last tile)
+    if (kt + 2 < KT) advance();
+    load();                            // tile kt+2 (or a valid re-read)
+    __syncthreads();
+  }
+  // ---- epilogue through LDS (fp32), as k_conv_fwd
+  constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  const int c4 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 4 * c4;
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  if (col < K) {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + col);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + col);
+    const float act_lo = d.act ? 0.f : -INFINITY, act_hi = (d.act == 2) ? 6.f : INFINITY;
+    for (int r = r0; r < BM; r += RSTEP) {
+      const int row = m0 + r;
+      if (row >= M) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
+      v = v * sc + sh;
+      if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * K + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
+      *reinterpret_cast<f32x4*>(y + (size_t)row * K + col) = v;
+    }
+  }
+}
+
+// ============================================================================
+// backward data:  dx[p,c] = sum_{r,s,k} dy[opix(p,r,s),k] * kscale[k] * w[r,s,c,k]  (+ addend)
+//   needs K % 32 == 0, C % 4 == 0.  A: dy gather (K-contiguous).  B: w[rs][c][k] rows (K-contiguous).
+// ============================================================================
+template <int DT, int BM, int BN>
+__global__ void __launch_bounds__(256)
+k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
+                  const float* __restrict__ kscale, const float* __restrict__ addend, float gscale,
+                  float* __restrict__ dx) {
+  typedef typename HT<DT>::T HTT;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32, BJ = BN / 32;
+  constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
+  constexpr int LDC = BN + 4;
+  __shared__ __attribute__((aligned(16))) float smem[HALF_SMEM_FLOATS(BM, BN)];
+  HTT* const As = reinterpret_cast<HTT*>(smem);
+  HTT* const Bs = As + 2 * A_SZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = d.N * d.H * d.W, K = d.K, C = d.C;
+  const int KC = K / BK;
+  const int tiles_n = (C + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int kq = tid & 7, arow = tid >> 3;
+  const int KT = d.R * d.S * KC;
+  int a_n[AJ], a_h[AJ], a_w[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int p = m0 + arow + 32 * j;
+    if (p < M) {
+      const int t = p / d.W;
+      a_w[j] = p - t * d.W + d.pad_left;
+      a_n[j] = t / d.H;
+      a_h[j] = t - a_n[j] * d.H + d.pad_top;
+    } else { a_n[j] = -1; a_h[j] = 0; a_w[j] = 0; }
+  }
+  const float* pa[AJ];
+  int inca[AJ];
+  auto setup_rs = [&](int rs_) {
+    const int r_ = rs_ / d.S, s_ = rs_ - r_ * d.S;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int th = a_h[j] - r_ * d.dilation, tw = a_w[j] - s_ * d.dilation;
+      int oh = th, ow = tw;
+      bool ok = a_n[j] >= 0 && th >= 0 && tw >= 0;
+      if (d.stride > 1) {
+        oh = th / d.stride; ow = tw / d.stride;
+        ok = ok && (oh * d.stride == th) && (ow * d.stride == tw);
+      }
+      ok = ok && oh < d.OH && ow < d.OW;
+      pa[j] = ok ? dy + ((size_t)(a_n[j] * d.OH + oh) * d.OW + ow) * K + 4 * kq : lmh_zero_page;
+      inca[j] = ok ? BK : 0;
+    }
+  };
+  const float* pb[BJ];
+  int incb[BJ];
+  size_t tapb[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int c = n0 + arow + 32 * j;
+    const bool ok = c < C;
+    pb[j] = ok ? w + (size_t)c * K + 4 * kq : lmh_zero_page;
+    incb[j] = ok ? BK : 0;
+    tapb[j] = ok ? (size_t)C * K - K + BK : 0;     // end of this tap's k range -> start of the next tap
+  }
+  const float* pks = kscale ? kscale + 4 * kq : lmh_zero_page;
+  const int incks = kscale ? BK : 0;
+  f32x4 ra[AJ], rb[BJ], ks;
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  int rs = 0, kc = 0;
+  setup_rs(0);
+  auto advance = [&]() {
+    if (++kc == KC) {
+      kc = 0; ++rs;
+      setup_rs(rs);
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) pb[j] += tapb[j];
+      pks -= (KC - 1) * incks;
+    } else {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) pa[j] += inca[j];
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) pb[j] += incb[j];
+      pks += incks;
+    }
+  };
+  auto load = [&]() {
+    ks = *reinterpret_cast<const f32x4*>(pks);
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb[j]);
+  };
+  auto store = [&](int buf) {
+    HTT* Ad = As + buf * A_SZ;
+    HTT* Bd = Bs + buf * B_SZ;
+    const f32x4 m = kscale ? ks * gscale : f32x4{gscale, gscale, gscale, gscale};
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) st_kc<DT>(Ad, arow + 32 * j, kq, ra[j] * m);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) st_kc<DT>(Bd, arow + 32 * j, kq, rb[j]);
+  };
+  load();
+  store(0);
+  if (KT > 1) advance();
+  load();
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    mfma_stage_h<DT, TM, TN>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    store(cur ^ 1);
+    if (kt + 2 < KT) advance();
+    load();
+    __syncthreads();
+  }
+  constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  const int c4 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 4 * c4;
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  if (col < C) {
+    const float inv = 1.f / gscale;
+    for (int r = r0; r < BM; r += RSTEP) {
+      const int row = m0 + r;
+      if (row >= M) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]) * inv;
+      if (addend) v += *reinterpret_cast<const f32x4*>(addend + (size_t)row * C + col);
+      *reinterpret_cast<f32x4*>(dx + (size_t)row * C + col) = v;
+    }
+  }
+}
+
+// ============================================================================
+// backward weight:  dw[rs,c,k] = sum_p x[pix(p,r,s),c] * g[p,k]; reduction split over the pixels (slabs in `out`,
+//   reduced by k_splitk_reduce).  needs C % 4 == 0, K % 4 == 0.  Both operands pixel-major -> register transposes.
+// ============================================================================
+template <int DT, int BM, int BN>
+__global__ void __launch_bounds__(256)
+k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ g,
+                    float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh,
+                    float gscale, int tiles_x, int tiles_y, int splits) {
+  typedef typename HT<DT>::T HTT;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
+  constexpr int LDC = BN + 4;
+  __shared__ __attribute__((aligned(16))) float smem[HALF_SMEM_FLOATS(BM, BN)];
+  HTT* const As = reinterpret_cast<HTT*>(smem);
+  HTT* const Bs = As + 2 * A_SZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int P = d.N * d.OH * d.OW, K = d.K, C = d.C;
+  const int lin = xcd_remap(blockIdx.x, tiles_x * tiles_y * splits);
+  const int bz = lin / (tiles_x * tiles_y), rem = lin - bz * (tiles_x * tiles_y);
+  const int by = rem / tiles_x, bx = rem - by * tiles_x;
+  const int tiles_c = (C + BM - 1) / BM;
+  const int rs = bx / tiles_c, m0 = (bx % tiles_c) * BM;
+  const int n0 = by * BN;
+  const int r = rs / d.S, s = rs - r * d.S;
+  const int KT_all = (P + BK - 1) / BK;
+  const int kt_begin = bz * kt_per_split;
+  const int kt_end = min(KT_all, kt_begin + kt_per_split);
+  const int dh0 = r * d.dilation - d.pad_top, dw0 = s * d.dilation - d.pad_left;
+  // 4(pixel) x 4(channel) block per thread and operand: pixel quad kq (fastest over lanes), channel quad cq
+  const int kq = tid & 7, cq = tid >> 3;
+  const bool a_act = cq < BM / 4, b_act = cq < BN / 4;
+  const bool a_ok = a_act && (m0 + 4 * cq) < C, b_ok = b_act && (n0 + 4 * cq) < K;
+  const float* xb = x + m0 + 4 * cq;
+  const float* gb = g + n0 + 4 * cq;
+  int p0 = kt_begin * BK + 4 * kq;       // first of this thread's 4 pixels in the next tile to load
+  f32x4 ra[4], rb[4];
+  auto load = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned p = (unsigned)(p0 + i);
+      const unsigned t = lmh_div(p, div_ow), ow = p - t * (unsigned)d.OW;
+      const unsigned n = lmh_div(t, div_oh), oh = t - n * (unsigned)d.OH;
+      const int ih = (int)oh * d.stride + dh0, iw = (int)ow * d.stride + dw0;
+      const bool oka = a_ok && n < (unsigned)d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+      const float* pa_ = oka ? xb + ((size_t)((int)n * d.H + ih) * d.W + iw) * C : lmh_zero_page;
+      if (a_act) ra[i] = *reinterpret_cast<const f32x4*>(pa_);
+      const bool okb = b_ok && (int)p < P;
+      const float* pb_ = okb ? gb + (size_t)p * K : lmh_zero_page;
+      if (b_act) rb[i] = *reinterpret_cast<const f32x4*>(pb_);
+    }
+  };
+  auto store = [&](int buf) {
+    HTT* Ad = As + buf * A_SZ;
+    HTT* Bd = Bs + buf * B_SZ;
+    if (a_act) st_km<DT>(Ad, 4 * cq, kq, ra);
+    if (b_act) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] *= gscale;
+      st_km<DT>(Bd, 4 * cq, kq, rb);
+    }
+  };
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  load();
+  store(0);
+  p0 += BK;
+  load();
+  __syncthreads();
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    mfma_stage_h<DT, TM, TN>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    store(cur ^ 1);       // tile kt+1: past the split's end it is never multiplied
+    p0 += BK;
+    load();               // tile kt+2: rows past P read the zero page
+    __syncthreads();
+  }
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  float* o = out + (size_t)bz * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;
+  constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  const int c4 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 4 * c4;
+  if (col < K) {
+    const float inv = 1.f / gscale;
+    for (int rr = r0; rr < BM; rr += RSTEP) {
+      const int row = m0 + rr;
+      if (row >= C) break;
+      *reinterpret_cast<f32x4*>(o + (size_t)row * K + col) = *reinterpret_cast<const f32x4*>(&smem[rr * LDC + 4 * c4]) * inv;
+    }
+  }
+}

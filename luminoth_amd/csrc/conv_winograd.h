@@ -234,8 +234,8 @@ k_wino_dw(const float* __restrict__ dU, int C, int K, float* __restrict__ dw) {
 
 // ---- host -----------------------------------------------------------------------------------------------------
 static bool wino_ok(const lmh_conv_desc* d) {
-  return d->R == 3 && d->S == 3 && d->stride == 1 && d->dilation == 1 && d->pad_top == 1 && d->pad_left == 1 &&
-         d->OH == d->H && d->OW == d->W && (d->C % BK) == 0 && (d->K % BK) == 0;
+  return d->compute == 0 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dilation == 1 && d->pad_top == 1 &&
+         d->pad_left == 1 && d->OH == d->H && d->OW == d->W && (d->C % BK) == 0 && (d->K % BK) == 0;
 }
 
 extern "C" int lmh_conv2d_winograd_ok(const lmh_conv_desc* d) { return d && wino_ok(d) ? 1 : 0; }
@@ -258,7 +258,7 @@ static int wino_run(const lmh_conv_desc* d, const float* in, int Cg, int Kg, con
   // 16 GEMMs [T x Cg] x [Cg x Kg] as ONE grid of the forward kernel (a 1x1 convolution over T "pixels")
   lmh_conv_desc g = *d;
   g.N = 1; g.H = T; g.W = 1; g.OH = T; g.OW = 1; g.C = Cg; g.K = Kg; g.R = 1; g.S = 1;
-  g.stride = 1; g.dilation = 1; g.pad_top = 0; g.pad_left = 0; g.act = 0;
+  g.stride = 1; g.dilation = 1; g.pad_top = 0; g.pad_left = 0; g.act = 0; g.compute = 0;
   int bm, bn;
   pick_tile((int64_t)T * 16, Kg, &bm, &bn);
   const int grid = 16 * ((T + bm - 1) / bm) * ((Kg + bn - 1) / bn);

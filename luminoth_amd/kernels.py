@@ -125,9 +125,14 @@ def same_pads(in_size, k, stride, dilation=1):
     return out, total // 2
 
 
-def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding='SAME', act=None):
+COMPUTE = {None: 0, 'f32': 0, 'fp32': 0, 'float32': 0, 'f16': 1, 'fp16': 1, 'float16': 1, 'bf16': 2, 'bfloat16': 2}
+
+
+def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding='SAME', act=None, compute=None):
     """padding: 'SAME' | 'VALID' | 'SAME_EXPLICIT' (slim conv2d_same: pad
-    (k_eff-1)//2 before, VALID after) | (pad_top, pad_left, OH, OW)."""
+    (k_eff-1)//2 before, VALID after) | (pad_top, pad_left, OH, OW).
+    compute: MFMA operand arithmetic — None / 'f32' (parity dtype), 'f16', 'bf16' (fp32 tensors, half-precision
+    operands, fp32 accumulate: BASELINE configs[4])."""
     N, H, W, C = x_shape
     R, S, C2, K = w_shape
     assert C == C2, (x_shape, w_shape)
@@ -145,7 +150,7 @@ def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding='SAME', act=None):
         OW = (W + kew - 1 - kew) // stride + 1
     else:
         pt, pl, OH, OW = padding
-    return ConvDesc(N, H, W, C, K, R, S, OH, OW, stride, dilation, pt, pl, ACT[act])
+    return ConvDesc(N, H, W, C, K, R, S, OH, OW, stride, dilation, pt, pl, ACT[act], COMPUTE[compute])
 
 
 # Winograd F(2x2,3x3) for the wide stride-1 3x3 layers, above a C*K threshold: RPN 1024->512
@@ -160,7 +165,7 @@ def winograd_ok(d):
 
 
 def _use_winograd(d):
-    return WINOGRAD and d.R == 3 and d.C * d.K >= WINOGRAD_MIN_CK and winograd_ok(d)
+    return WINOGRAD and d.compute == 0 and d.R == 3 and d.C * d.K >= WINOGRAD_MIN_CK and winograd_ok(d)
 
 
 def winograd_transform_weights(d, w, kscale, backward, out):
@@ -261,8 +266,8 @@ def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None, yact=None, xma
 def conv2d_bwd_weight(d, x, dy, out=None, yact=None, colsum=None):
     """yact: fused g = dy*act'(y); colsum (K,): WRITTEN with the per-channel sums of g."""
     lib = _lib.load()
-    if yact is None and WINOGRAD and WINOGRAD_WGRAD and d.R == 3 and d.C * d.K >= WINOGRAD_WGRAD_MIN_CK and \
-            winograd_ok(d):
+    if yact is None and WINOGRAD and WINOGRAD_WGRAD and d.compute == 0 and d.R == 3 and \
+            d.C * d.K >= WINOGRAD_WGRAD_MIN_CK and winograd_ok(d):
         if colsum is not None:                       # dbeta / dbias: one streaming pass over g
             act_bwd(dy, None, None, want_g=False, colsum=colsum)
         return conv2d_bwd_weight_winograd(d, x, dy, out)

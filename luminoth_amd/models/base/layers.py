@@ -73,6 +73,7 @@ class ConvLayer(object):
         self.norm = norm          # 'bn' | 'bias' | None
         self.wd, self.init = wd, init
         self.trainable = True
+        self.compute = None       # MFMA operand arithmetic: None = fp32; 'f16' / 'bf16' = mixed precision (conv_half.h)
         self.w_name = '%s/%s' % (scope, weight_name)
         self.b_name = '%s/%s' % (scope, bias_name)
         self._desc = {}
@@ -100,11 +101,11 @@ class ConvLayer(object):
             self.gb = store.grads.get(self.b_name)
 
     def desc(self, x_shape):
-        key = tuple(x_shape)
+        key = tuple(x_shape) + (self.compute,)
         d = self._desc.get(key)
         if d is None:
             d = K.conv_desc(x_shape, (self.k, self.k, self.cin, self.cout), self.stride, self.rate,
-                            self.padding, self.act)
+                            self.padding, self.act, self.compute)
             self._desc[key] = d
         return d
 

@@ -8,6 +8,7 @@ import torch
 
 from luminoth_amd.models.base import layers as L
 from luminoth_amd.models.base import networks
+from luminoth_amd.kernels import COMPUTE as K_COMPUTE
 from luminoth_amd.models.base.base_network import BaseNetwork, he_normal, ones, zeros
 
 DEFAULT_ENDPOINTS = {
@@ -77,6 +78,14 @@ class TruncatedBaseNetwork(BaseNetwork):
             self.tail_channels = self.feat_channels
         self.bn_table = L.BNTable()
         self._in_sub = None
+        # extension key: model.base_network.compute_dtype in {None, 'f32', 'f16', 'bf16'} — half-precision MFMA
+        # operands with fp32 accumulation for every backbone / tail convolution (BASELINE configs[4])
+        self.compute_dtype = config.get('compute_dtype')
+        if self.compute_dtype not in (None, 'f32', 'fp32', 'float32'):
+            if self.compute_dtype not in K_COMPUTE:
+                raise ValueError('Invalid compute_dtype: "{}"'.format(self.compute_dtype))
+            for layer in self._creation_order_layers() + (self.tail.all_layers() if self.tail else []):
+                layer.compute = self.compute_dtype
 
     # ---- variables --------------------------------------------------------------
     def _creation_order_layers(self):

@@ -62,6 +62,8 @@ class FasterRCNN(object):
         self.base_network = TruncatedBaseNetwork(config.model.base_network)
         self._rpn = RPN(self._num_anchors, config.model.rpn, self.base_network.feat_channels,
                         debug=self._debug, seed=self._seed, scope=name)
+        if self.base_network.compute_dtype not in (None, 'f32', 'fp32', 'float32'):
+            self._rpn._rpn.compute = self.base_network.compute_dtype     # the 3x3 RPN conv; the 1x1 heads stay fp32
         self._rcnn = None
         if self._with_rcnn:
             self._rcnn = RCNN(self._num_classes, config.model.rcnn, self.base_network.tail_channels,

@@ -1,0 +1,134 @@
+"""Mixed-precision convolution path (BASELINE configs[4]: "fp16 MFMA path"): v_mfma_f32_32x32x16_{f16,bf16} with
+fp32 tensors in memory and fp32 accumulation (csrc/conv_half.h).
+
+Tolerances are stated HERE, separately from the fp32 contract (north_star's 1e-4 is an fp32 figure):
+  * inputs that are exactly representable in the operand format (small integers) must reproduce the fp32 kernels
+    BIT FOR BIT — this pins every index, transpose and k-slot of the half kernels;
+  * on random data the only error is the rounding of the operands (2^-11 relative for f16, 2^-8 for bf16):
+    3e-3 (f16) / 2.5e-2 (bf16) of the output scale per convolution;
+  * end to end (ResNet-50 train step vs the fp32 CPU oracle): every loss within 2e-2 relative (f16) and the
+    gradient of every large tensor at cosine similarity >= 0.995 with the oracle's."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+HALF_CASES = [
+    # N, H, W, C, K, R, stride, dil, padding
+    (2, 16, 16, 64, 128, 1, 1, 1, 'SAME'),
+    (1, 20, 24, 128, 64, 3, 1, 1, 'SAME'),
+    (1, 17, 19, 64, 96, 3, 2, 1, 'SAME_EXPLICIT'),      # odd sizes, stride 2, partial column tile
+    (1, 12, 12, 32, 256, 3, 1, 2, 'SAME'),              # dilated
+    (1, 8, 8, 256, 36, 1, 1, 1, 'VALID'),               # K < one tile
+    (2, 32, 32, 256, 256, 3, 1, 1, 'SAME'),             # 128x128 tiles, several stages per tap
+]
+
+
+def T(a):
+    return torch.tensor(np.ascontiguousarray(a)).to('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def K():
+    from luminoth_amd import kernels
+    return kernels
+
+
+def _run_all(K, case, compute, x, w, scale, shift, res, gy, act='relu'):
+    N, H, W, C, Kc, R, stride, dil, padding = case
+    d = K.conv_desc(x.shape, w.shape, stride, dil, padding, act, compute)
+    y = K.conv2d_fwd(d, T(x), T(w), T(scale), T(shift), T(res))
+    dx = K.conv2d_bwd_data(d, T(gy), T(w), T(scale), addend=T(x))
+    dw = K.conv2d_bwd_weight(d, T(x), T(gy))
+    return y.cpu().numpy(), dx.cpu().numpy(), dw.cpu().numpy(), d
+
+
+@pytest.mark.parametrize('compute', ['f16', 'bf16'])
+@pytest.mark.parametrize('case', HALF_CASES)
+def test_half_kernels_are_exact_on_representable_inputs(K, case, compute, monkeypatch):
+    monkeypatch.setattr(K, 'WINOGRAD', False)
+    N, H, W, C, Kc, R, stride, dil, padding = case
+    rs = np.random.RandomState(11 + HALF_CASES.index(case))
+    x = rs.randint(-3, 4, size=(N, H, W, C)).astype(F)
+    w = rs.randint(-1, 2, size=(R, R, C, Kc)).astype(F)
+    scale = rs.randint(1, 3, size=(Kc,)).astype(F)
+    shift = rs.randint(-2, 3, size=(Kc,)).astype(F)
+    d0 = K.conv_desc(x.shape, w.shape, stride, dil, padding, 'relu')
+    res = rs.randint(-4, 5, size=(N, d0.OH, d0.OW, Kc)).astype(F)
+    gy = rs.randint(-3, 4, size=(N, d0.OH, d0.OW, Kc)).astype(F)
+    ref = _run_all(K, case, None, x, w, scale, shift, res, gy)
+    got = _run_all(K, case, compute, x, w, scale, shift, res, gy)
+    assert got[3].compute == (1 if compute == 'f16' else 2)
+    for name, a, b in zip(('fwd', 'bwd_data', 'bwd_weight'), got[:3], ref[:3]):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    assert np.abs(ref[0]).max() > 4 and np.abs(ref[2]).max() > 4
+
+
+@pytest.mark.parametrize('compute,tol', [('f16', 3e-3), ('bf16', 2.5e-2)])
+@pytest.mark.parametrize('case', HALF_CASES)
+def test_half_kernels_random_data_within_operand_rounding(K, case, compute, tol, monkeypatch):
+    monkeypatch.setattr(K, 'WINOGRAD', False)
+    N, H, W, C, Kc, R, stride, dil, padding = case
+    rs = np.random.RandomState(23 + HALF_CASES.index(case))
+    x = rs.randn(N, H, W, C).astype(F)
+    w = (rs.randn(R, R, C, Kc) * np.sqrt(2.0 / (R * R * C))).astype(F)
+    scale = (1 + 0.1 * rs.randn(Kc)).astype(F)
+    shift = (0.1 * rs.randn(Kc)).astype(F)
+    d0 = K.conv_desc(x.shape, w.shape, stride, dil, padding, None)
+    res = rs.randn(N, d0.OH, d0.OW, Kc).astype(F)
+    gy = (rs.randn(N, d0.OH, d0.OW, Kc) * 1e-4).astype(F)        # gradient-sized values: exercises the in-kernel scaling
+    ref = _run_all(K, case, None, x, w, scale, shift, res, gy, act=None)
+    got = _run_all(K, case, compute, x, w, scale, shift, res, gy, act=None)
+    for name, a, b, extra in zip(('fwd', 'bwd_data', 'bwd_weight'), got[:3], ref[:3], (res, x, 0.0)):
+        conv_part = np.abs(b - extra).max()                      # scale of the convolution itself (residual / addend are exact)
+        assert np.abs(a - b).max() <= tol * conv_part, (name, float(np.abs(a - b).max()), float(conv_part))
+
+
+@pytest.mark.parametrize('compute,loss_tol', [('f16', 2e-2), ('bf16', 8e-2)])
+def test_half_precision_train_step_vs_fp32_oracle(compute, loss_tol):
+    from e2e_util import condition_like_pretrained, make_config, run_step_with_tap, synth
+    from luminoth_amd.models import get_model
+    from oracle import rng as orng
+    from oracle.model import OracleFasterRCNN
+    cfg = make_config('resnet_v1_50', 20, **{'model.base_network.compute_dtype': compute})
+    model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_50')
+    assert model.base_network.trunk.all_layers()[5].compute == compute and model._rpn._rpn.compute == compute
+    images, gts = synth(2, 320, 384, 4, 20, 3)
+    pred, losses, _ = run_step_with_tap(model, images, gts)
+    oracle = OracleFasterRCNN(model.state_dict(), num_classes=20, seed=0)
+    names = oracle.trainable_names()
+    for n in names:
+        oracle.v[n].requires_grad_(True)
+    cp = pred['classification_prediction']
+    per = {k: 0.0 for k in ('rpn_cls_loss', 'rpn_reg_loss', 'rcnn_cls_loss', 'rcnn_reg_loss')}
+    for b in range(2):
+        n_roi = int(cp['num_proposals'][b])
+        ov = dict(rois=cp['proposals'][b, :n_roi].cpu().numpy(), roi_labels=cp['target']['cls'][b, :n_roi].cpu().numpy(),
+                  roi_targets=cp['target']['bbox_offsets'][b, :n_roi].cpu().numpy())
+        o = oracle.forward_image(images[b], gts[b], orng.image_seed(0, 0, b), overrides=ov)
+        # anchor labels do not depend on the network: still bit-exact
+        np.testing.assert_array_equal(pred['rpn_prediction']['rpn_cls_target'][b].cpu().numpy(), o['rpn_labels'])
+        for k in per:
+            per[k] = per[k] + o[k] / 2
+    report = {}
+    for k in per:
+        got, ref = float(losses[k]), float(per[k])
+        report[k] = (got, ref)
+        assert abs(got - ref) <= loss_tol * max(1.0, abs(ref)), (k, got, ref)
+    sum(per.values()).backward()
+    worst = 1.0
+    for n in names:
+        g_ref = oracle.v[n].grad
+        if g_ref is None or g_ref.numel() < 4096:
+            continue
+        g = model.store.grads[n].cpu().reshape(g_ref.shape)
+        cos = float((g * g_ref).sum() / (g.norm() * g_ref.norm() + 1e-30))
+        worst = min(worst, cos)
+        assert cos >= (0.995 if compute == 'f16' else 0.97), (n, cos)
+    print('half-precision e2e %s: losses %s, worst gradient cosine %.5f' % (compute, report, worst))
