@@ -185,6 +185,8 @@ def main():
     ap.add_argument('--serial', action='store_true',
                     help='run EVERY step on one stream (the schedule of the roofline profiling steps): the command '
                          'the rocprofv3 summaries under profiles/*_serial_* are taken from')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='enqueue every timed step from Python instead of replaying the captured HIP graph of the step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=5)
@@ -244,12 +246,26 @@ def main():
         torch.cuda.synchronize()
 
     serialise(args.serial)
+    step_fn = lambda: T.train_step(model, opt, images, gts)        # noqa: E731
+    schedule = 'eager (one Python enqueue per kernel)'
     for _ in range(args.warmup):
-        T.train_step(model, opt, images, gts)
+        step_fn()
+    if not args.no_graph and not args.serial and T.GraphedTrainStep.supported(model, opt, cfg.train):
+        # same kernels and arithmetic, replayed from ONE captured HIP graph (all three streams): the GPU front end no
+        # longer waits for the interpreter where the proposal / RCNN branch forks
+        try:
+            graphed = T.GraphedTrainStep(model, opt, images, gts)
+            step_fn = lambda: graphed()                           # noqa: E731
+            schedule = 'hip-graph replay of the captured step'
+            for _ in range(2):
+                step_fn()
+        except Exception as e:                                    # capture is an optimisation, never a requirement
+            sys.stderr.write('bench.py: HIP-graph capture failed (%r); timing the eager step\n' % (e,))
+            model._seed_override = None
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        total, _ = T.train_step(model, opt, images, gts)
+        total, _ = step_fn()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -312,7 +328,8 @@ def main():
                                    '%d gt/image, fwd+loss+bwd+optimizer update%s'
                                    % (wl['cfg'], args.workload, wl['model'], wl['arch'], wl['H'], wl['W'], wl['batch'],
                                       wl['classes'], wl['G'], ' [single-stream schedule]' if args.serial else ''),
-                       'global_batch': gb, 'parallelism': 'dp%d' % world, 'final_total_loss': loss_val},
+                       'global_batch': gb, 'parallelism': 'dp%d' % world, 'final_total_loss': loss_val,
+                       'schedule': schedule},
             'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only

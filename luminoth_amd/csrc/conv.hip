@@ -57,14 +57,17 @@ static int check_desc(const lmh_conv_desc* d) {
 // kernel's name as rocprofv3 prints it plus the FLOPs the launch executed.
 static thread_local hipEvent_t g_prof_e0 = nullptr, g_prof_e1 = nullptr;
 static thread_local char g_prof_name[96] = "";
-static thread_local double g_prof_flops = 0.0;
+static thread_local double g_prof_flops = 0.0, g_prof_bytes = 0.0;
 extern "C" int lmh_conv2d_profile_next(void* ev_start, void* ev_stop) {
   g_prof_e0 = (hipEvent_t)ev_start;
   g_prof_e1 = (hipEvent_t)ev_stop;
   g_prof_name[0] = 0;
   g_prof_flops = 0.0;
+  g_prof_bytes = 0.0;
   return LMH_OK;
 }
+// compulsory HBM bytes of the profiled launch: every operand tensor read once, the result written once (fp32)
+extern "C" double lmh_conv2d_profile_last_bytes(void) { return g_prof_bytes; }
 extern "C" const char* lmh_conv2d_profile_last(double* flops) {
   if (flops) *flops = g_prof_flops;
   return g_prof_name;
@@ -84,6 +87,9 @@ static inline void prof_end(hipStream_t st, double flops, const char* fmt, ...) 
 }
 static inline double desc_flops(const lmh_conv_desc* d) {
   return 2.0 * d->N * d->OH * d->OW * (double)d->K * d->R * d->S * d->C;
+}
+static inline double desc_bytes(const lmh_conv_desc* d) {
+  return 4.0 * ((double)d->N * d->H * d->W * d->C + (double)d->R * d->S * d->C * d->K + (double)d->N * d->OH * d->OW * d->K);
 }
 
 // Tuning override (diagnostics only: scripts/bench_conv.py sweeps tile shapes / split counts with it).
@@ -130,6 +136,15 @@ static bool bwd_weight_fast(const lmh_conv_desc* d) { return (d->C & 3) == 0 && 
 // it is rounded to f16 (5 exponent bits: activations gradients of 1e-7 would flush) and the fp32 accumulators by
 // 2^-10 afterwards — exact in fp32.  bf16 has fp32's exponent range and needs none.
 static float half_gscale(const lmh_conv_desc* d) { return d->compute == 1 ? 1024.f : 1.f; }
+// Tile of the half-precision kernels: they are bound by the staging path (bytes per MFMA), not by matrix-pipe rounds, so
+// the largest tile the problem fills wins (128x128 moves half the bytes per FLOP of 64x64) as long as the grid still
+// covers the chip once.
+static void half_tile(int64_t M, int64_t Ncols, int* bm, int* bn) {
+  if (g_force_bm && g_force_bn) { *bm = g_force_bm; *bn = g_force_bn; return; }
+  *bm = 128;
+  *bn = Ncols > 64 ? 128 : 64;
+  if (((M + 127) / 128) * ((Ncols + *bn - 1) / *bn) < 128) { *bm = 64; *bn = 64; }
+}
 
 extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
                               const float* shift, const float* residual, const float* in_sub, float* y,
@@ -156,6 +171,8 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
   }
   const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
   if (d->compute && fast && in_sub == nullptr) {          // f16 / bf16 operands, fp32 accumulate (conv_half.h)
+    half_tile(M, d->K, &bm, &bn);
+    const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
 #define LAUNCH_FWD_H(DT_, BM_, BN_)                                                                       \
     hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y)
 #define LAUNCH_FWD_HT(BM_, BN_)                                                                           \
@@ -209,7 +226,7 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   bwd_data_parity_tile(d, M, &bm, &bn);
   hipStream_t st = (hipStream_t)stream;
   if (d->compute && fast && !yact && !xmask) {
-    pick_tile(M, d->C, &bm, &bn, bd_slots);               // no parity classes in the half kernel: plain tile choice
+    half_tile(M, d->C, &bm, &bn);                         // (no parity classes in the half kernel)
     const int gridh = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
     const float gs = half_gscale(d);
 #define LAUNCH_BD_H(DT_, BM_, BN_)                                                                        \
@@ -257,12 +274,15 @@ static void bwd_weight_plan(const lmh_conv_desc* d, int* bm, int* bn, int* split
   const int64_t t128 = (int64_t)d->R * d->S * ((d->C + 127) / 128) * ((d->K + 127) / 128);
   if (t128 >= 128 && d->C >= 128 && d->K >= 128) { *bm = 128; *bn = 128; }
   else { *bm = 64; *bn = 64; }
+  // half-precision operands: the kernel is bound by its staging path, 128x128 tiles halve the bytes per FLOP
+  if (d->compute && d->C >= 128 && d->K >= 128) { *bm = 128; *bn = 128; }
   if (g_force_bm && g_force_bn) { *bm = g_force_bm; *bn = g_force_bn; }
   const int64_t tiles = (int64_t)d->R * d->S * ((d->C + *bm - 1) / *bm) * ((d->K + *bn - 1) / *bn);
   const int64_t P = (int64_t)d->N * d->OH * d->OW;
   const int KT = (int)((P + BK - 1) / BK);
   int max_split = KT / 16 > 0 ? KT / 16 : 1;
-  if (max_split > 64) max_split = 64;
+  if (d->compute) max_split = KT / 8 > 0 ? KT / 8 : 1;
+  if (max_split > (d->compute ? 128 : 64)) max_split = d->compute ? 128 : 64;
   static const int bw_slots = env_int("LMH_BW_SLOTS", 512);
   int want = 1;
   double best_eff = -1.0;

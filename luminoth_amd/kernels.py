@@ -47,6 +47,14 @@ def _f32(t):
     return t
 
 
+def keep_alive(t, stream):
+    """tensor.record_stream(stream) — the caching allocator must not recycle `t` while `stream` still reads it.
+    Skipped while the step is being captured into a HIP graph: the graph's private pool keeps every block it
+    handed out alive (and at a fixed address) for as long as the graph exists."""
+    if t is not None and not torch.cuda.is_current_stream_capturing():
+        t.record_stream(stream)
+
+
 _ws_cache = {}
 
 

@@ -175,8 +175,7 @@ class ConvLayer(object):
                 with torch.cuda.stream(side):
                     self._weight_grads(d, x, g, yact, cs)
                 for t in (x, g, yact):                  # keep the buffers alive for the side stream
-                    if t is not None:
-                        t.record_stream(side)
+                    K.keep_alive(t, side)
             else:
                 self._weight_grads(d, x, g, yact, cs)
         if need_dx and not inline:

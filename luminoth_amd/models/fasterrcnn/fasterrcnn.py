@@ -90,6 +90,8 @@ class FasterRCNN(object):
         """Per-image RNG seeds of the current step as a device tensor (B,) int32.  Seeds for the next
         _SEED_BLOCK steps are generated and uploaded in one go: a per-step host->device copy from
         pageable memory would re-synchronise the host with the GPU every step."""
+        if getattr(self, '_seed_override', None) is not None:      # HIP-graph replay: a static buffer refreshed per step
+            return self._seed_override
         c = getattr(self, '_seed_cache', None)
         if c is None or c[0] != B or not (c[1] <= self._step < c[1] + self._SEED_BLOCK):
             base = self._step
@@ -259,7 +261,7 @@ class FasterRCNN(object):
             rpn = self._rpn
             rpn_tgt = {}
             for t in (gt, gt_count, seeds):
-                t.record_stream(aux)
+                K.keep_alive(t, aux)
             feat = self.base_network(image, is_training=True)
             assert (feat.shape[1], feat.shape[2]) == (fh, fw)
             f_rpn = feat.detach().requires_grad_(True)
@@ -274,7 +276,7 @@ class FasterRCNN(object):
                 prop = rpn._proposal(rpn_pred['rpn_cls_score'].detach(), rpn_pred['rpn_bbox_pred'].detach(),
                                      self._anchor_ref_i32, (fh, fw), self._anchor_stride, im_shape)
             for t in (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred'], feat):
-                t.record_stream(aux)
+                K.keep_alive(t, aux)
             # ---- main stream: RPN targets -> RPN loss -> RPN backward
             rpn.targets(rpn_tgt, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape)
             rpn_pred.update(rpn_tgt)
@@ -289,7 +291,7 @@ class FasterRCNN(object):
             # ---- join, trunk backward
             main.wait_stream(aux)
             for t in (f_rcnn.grad, rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']):
-                t.record_stream(main)
+                K.keep_alive(t, main)
             # loss scalars (tiny launches) go BEFORE the trunk backward so that nothing but the optimizer is left
             # on the main stream once the weight-gradient stream drains
             no_reg_loss = (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss'] +

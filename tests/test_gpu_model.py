@@ -268,3 +268,43 @@ def test_rccl_single_rank_bucketed_step(setup, tmp_path):
         os.environ.pop('LUMINOTH_AMD_FORCE_BUCKETS', None)
         dist.destroy_process_group()
         model.load_state_dict(sd0)
+
+
+def test_hip_graph_replay_equals_eager_steps(setup):
+    """GraphedTrainStep (the whole three-stream step captured once, replayed): two replays from a given state give
+    the weights of two eager steps from the same state (per-step seeds refreshed through the static buffer)."""
+    from luminoth_amd.utils import training as T
+    cfg, model, images, gts = setup
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = T.get_optimizer(cfg.train, model)
+    assert T.GraphedTrainStep.supported(model, opt, cfg.train)
+
+    def reset():
+        model.load_state_dict(sd0)
+        model.store.mom.zero_()
+        model._step = 0
+        opt.global_step = 0
+
+    reset()
+    losses_e = []
+    for _ in range(2):
+        total, _ = T.train_step(model, opt, images, gts)
+        losses_e.append(float(total))
+    torch.cuda.synchronize()
+    want = model.store.flat.clone()
+    try:
+        graphed = T.GraphedTrainStep(model, opt, images.to(model.device), gts, warmup=1)
+        reset()
+        losses_g = []
+        for _ in range(2):
+            total, _ = graphed()
+            losses_g.append(float(total))
+        torch.cuda.synchronize()
+        assert model._step == 2 and opt.global_step == 2
+        np.testing.assert_allclose(losses_g, losses_e, rtol=1e-6)
+        scale = float(want.abs().max())
+        np.testing.assert_allclose(model.store.flat.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-7 * scale)
+    finally:
+        model._seed_override = None
+        model.load_state_dict(sd0)
+        model.store.mom.zero_()
