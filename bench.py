@@ -41,6 +41,7 @@ if ROOT not in sys.path:
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense matrix peaks
 PEAK_TFLOPS = {'f32': 157.3, 'f16': 2500.0, 'bf16': 2500.0}
+PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
     # name: model type, architecture, per-GPU batch, H, W, classes, gt boxes/image, BASELINE.json configs[] index
@@ -185,8 +186,10 @@ def main():
     ap.add_argument('--serial', action='store_true',
                     help='run EVERY step on one stream (the schedule of the roofline profiling steps): the command '
                          'the rocprofv3 summaries under profiles/*_serial_* are taken from')
-    ap.add_argument('--no-graph', action='store_true',
-                    help='enqueue every timed step from Python instead of replaying the captured HIP graph of the step')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the captured HIP graph of the step instead of enqueuing every kernel from Python '
+                         '(measured SLOWER on ROCm 7.2: 14.2 vs 8.9 ms/step — the graph executor serialises the three '
+                         'captured streams; kept for re-measurement on newer runtimes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=5)
@@ -250,7 +253,7 @@ def main():
     schedule = 'eager (one Python enqueue per kernel)'
     for _ in range(args.warmup):
         step_fn()
-    if not args.no_graph and not args.serial and T.GraphedTrainStep.supported(model, opt, cfg.train):
+    if args.graph and not args.serial and T.GraphedTrainStep.supported(model, opt, cfg.train):
         # same kernels and arithmetic, replayed from ONE captured HIP graph (all three streams): the GPU front end no
         # longer waits for the interpreter where the proposal / RCNN branch forks
         try:
@@ -294,12 +297,21 @@ def main():
             step_flops = sum(v['direct_flops'] for v in prof.values()) / nprof
             r = prof[name]
             fl = r['flops'] / r['launches']
+            by = r['bytes'] / r['launches']
             ms = r['ms'] / r['launches']
             achieved = fl / (ms * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic(name)
-            roofline = {
-                'bound': 'mfma', 'kernel': name, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': achieved / peak, 'traffic': traffic,
+            # which roofline bounds this kernel: the larger of its two ideal times (fp32 convolutions are always
+            # matrix-bound; with f16 / bf16 operands the fp32 tensors in HBM become the limit)
+            t_mfma, t_hbm = fl / (peak * 1e12), by / (PEAK_HBM_GBS * 1e9)
+            if t_hbm > t_mfma:
+                bound = {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                         'frac': by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 'mfma_tflops': achieved}
+            else:
+                bound = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak}
+            roofline = dict(bound, **{
+                'kernel': name, 'traffic': traffic, 'algorithmic_bytes_per_launch': by,
                 'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes)',
                 'traffic_source': traffic_src,
                 'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
@@ -309,8 +321,9 @@ def main():
                                'frac': step_flops / dt * args.steps / 1e12 / peak},
                 'all_conv_kernels': {k: {'launches_per_step': v['launches'] / nprof,
                                          'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
+                                         'gbs': v['bytes'] / (v['ms'] * 1e-3) / 1e9,
                                          'ms_per_step': v['ms'] / nprof}
-                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}}
+                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}})
     if world > 1:
         dist.barrier()
 

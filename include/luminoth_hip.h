@@ -109,6 +109,8 @@ int lmh_conv2d_bwd_weight_fuses_colsum(const lmh_conv_desc* d);
  * that kernel's name as rocprofv3 prints it and the FLOPs the launch executed. */
 int lmh_conv2d_profile_next(void* ev_start, void* ev_stop);
 const char* lmh_conv2d_profile_last(double* flops);
+/* Compulsory HBM bytes of that launch: every operand tensor read once + the result written once (fp32). */
+double lmh_conv2d_profile_last_bytes(void);
 /* HIP events for hosts without a HIP binding (ctypes): create / destroy / elapsed ms (synchronises on e1). */
 void* lmh_event_create(void);
 void lmh_event_destroy(void* e);
@@ -353,6 +355,21 @@ int lmh_ssd_loss(const float* cls_pred, const float* loc_pred, const float* labe
 int lmh_sgd_momentum(float* w, const float* g, float* v, int64_t n, const int64_t* seg_offset,
                      const float* seg_wd, int nseg, float lr, float momentum, float gscale,
                      lmh_stream_t stream);
+/* The non-default rest of utils/training.py.  lmh_grad_clip_factors: factors[s] = clip / max(||g'_s||, clip) per
+ * segment (clip_gradients_by_norm: tf.clip_by_norm(g', 10), training.py:84-120; g' includes the L2 term like TF's
+ * gradient of total_loss).  lmh_optimizer_step: kind 0 momentum (p1 = momentum; 0 = GradientDescentOptimizer),
+ * 1 Adam (p1, p2 = beta1, beta2; lr = bias-corrected lr_t), 2 RMSProp (p1 = decay, p2 = momentum); OPTIMIZERS table
+ * training.py:6-11.  slot2 may be NULL for kind 0; seg_factor may be NULL (no clipping). */
+size_t lmh_grad_clip_workspace_bytes(int nseg);
+int lmh_grad_clip_factors(const float* w, const float* g, int64_t n, const int64_t* seg_offset, const float* seg_wd,
+                          int nseg, float gscale, float clip_norm, float* factors, void* ws, size_t ws_bytes,
+                          lmh_stream_t stream);
+int lmh_optimizer_step(int kind, float* w, const float* g, float* slot1, float* slot2, int64_t n,
+                       const int64_t* seg_offset, const float* seg_wd, const float* seg_factor, int nseg, float lr,
+                       float p1, float p2, float eps, float gscale, lmh_stream_t stream);
+/* tf.nn.dropout of the RCNN head (models/fasterrcnn/rcnn.py:196,218): y = x * keep / keep_prob, keep a pure function
+ * of (seed, element index) — call it again on dy with the same seed for the backward pass. */
+int lmh_dropout(const float* x, int64_t n, float keep_prob, uint32_t seed, float* y, lmh_stream_t stream);
 /* regularization_loss = sum_s wd[s] * sum(w_s^2)/2 (tf l2_regularizer), out (1) zeroed by caller. */
 int lmh_l2_reg_loss(const float* w, int64_t n, const int64_t* seg_offset, const float* seg_wd,
                     int nseg, float* out, lmh_stream_t stream);

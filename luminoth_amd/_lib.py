@@ -91,6 +91,7 @@ SIGNATURES = {
     'lmh_conv2d_bwd_weight_fuses_colsum': (c_i, [P(ConvDesc)]),
     'lmh_conv2d_profile_next': (c_i, [c_f, c_f]),
     'lmh_conv2d_profile_last': (ctypes.c_char_p, [P(ctypes.c_double)]),
+    'lmh_conv2d_profile_last_bytes': (ctypes.c_double, []),
     'lmh_event_create': (ctypes.c_void_p, []),
     'lmh_event_destroy': (None, [c_f]),
     'lmh_event_elapsed_ms': (ctypes.c_float, [c_f, c_f]),
@@ -126,6 +127,10 @@ SIGNATURES = {
     'lmh_ssd_target': (c_i, [P(SsdTargetDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_ssd_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
     'lmh_sgd_momentum': (c_i, [c_f, c_f, c_f, c_i64, c_f, c_f, c_i, c_fl, c_fl, c_fl, c_f]),
+    'lmh_grad_clip_workspace_bytes': (c_sz, [c_i]),
+    'lmh_grad_clip_factors': (c_i, [c_f, c_f, c_i64, c_f, c_f, c_i, c_fl, c_fl, c_f, c_f, c_sz, c_f]),
+    'lmh_optimizer_step': (c_i, [c_i, c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_i, c_fl, c_fl, c_fl, c_fl, c_fl, c_f]),
+    'lmh_dropout': (c_i, [c_f, c_i64, c_fl, ctypes.c_uint32, c_f, c_f]),
     'lmh_l2_reg_loss': (c_i, [c_f, c_i64, c_f, c_f, c_i, c_f, c_f]),
 }
 

@@ -66,6 +66,20 @@ class SpatialMeanFn(torch.autograd.Function):
         return K.spatial_mean_bwd(dy.contiguous(), ctx.shape)
 
 
+class DropoutFn(torch.autograd.Function):
+    """tf.nn.dropout(net, keep_prob) of the RCNN head (rcnn.py:196,218); the mask is regenerated from the seed."""
+
+    @staticmethod
+    def forward(ctx, x, keep_prob, seed):
+        ctx.meta = (keep_prob, seed)
+        return K.dropout(x.contiguous(), keep_prob, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        keep_prob, seed = ctx.meta
+        return K.dropout(dy.contiguous(), keep_prob, seed), None, None
+
+
 class RpnLossFn(torch.autograd.Function):
     """RPN.loss (rpn.py:219-309): returns (2,) = [w_cls*cls, w_reg*reg]."""
 

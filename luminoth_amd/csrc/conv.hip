@@ -72,6 +72,7 @@ extern "C" const char* lmh_conv2d_profile_last(double* flops) {
   if (flops) *flops = g_prof_flops;
   return g_prof_name;
 }
+static thread_local double g_prof_pending_bytes = 0.0;      // set by the entry point before its launch
 static inline void prof_begin(hipStream_t st) {
   if (g_prof_e0) (void)hipEventRecord(g_prof_e0, st);
 }
@@ -83,6 +84,7 @@ static inline void prof_end(hipStream_t st, double flops, const char* fmt, ...) 
   vsnprintf(g_prof_name, sizeof(g_prof_name), fmt, ap);
   va_end(ap);
   g_prof_flops = flops;
+  g_prof_bytes = g_prof_pending_bytes;
   g_prof_e0 = g_prof_e1 = nullptr;
 }
 static inline double desc_flops(const lmh_conv_desc* d) {
@@ -152,6 +154,7 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(x && w && y);
+  g_prof_pending_bytes = desc_bytes(d);
   const int64_t M = (int64_t)d->N * d->OH * d->OW;
   const bool fast = fwd_fast(d);
   LMH_CHECK_ARG((d->C % BK) != 0 || in_sub == nullptr);
@@ -216,6 +219,7 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(dy && w && dx);
+  g_prof_pending_bytes = desc_bytes(d);
   LMH_CHECK_ARG(yact == nullptr || (bwd_data_fast(d) && d->act != 0));   // fused act'(y) only on the fast path
   LMH_CHECK_ARG(xmask == nullptr || (bwd_data_fast(d) && (xmask_act == 1 || xmask_act == 2)));
   const int64_t M = (int64_t)d->N * d->H * d->W;
@@ -391,6 +395,8 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
                              float* dw, float* colsum, void* ws, size_t ws_bytes, hipStream_t stream, bool gb) {
   LMH_CHECK_ARG(x && dy && dw);
   LMH_CHECK_ARG(!gb || (bwd_weight_fast(d) && !yact && !colsum));
+  g_prof_pending_bytes = gb ? 4.0 * d->R * d->S * ((double)d->H * d->C + (double)d->H * d->K + (double)d->C * d->K)
+                            : desc_bytes(d);
   int bm, bn, splits, kps;
   if (!gb && !yact && !colsum && wgrad_1x1_ok(d)) {       // pure TN GEMM: direct-to-LDS kernel
     int nbuf;

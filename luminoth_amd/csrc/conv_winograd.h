@@ -265,6 +265,7 @@ static int wino_run(const lmh_conv_desc* d, const float* in, int Cg, int Kg, con
 #define LAUNCH_WG(BM_, BN_)                                                                           \
   hipLaunchKernelGGL((k_conv_fwd<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U,  \
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, 16)
+  g_prof_pending_bytes = 16.0 * 4.0 * ((double)T * Cg + (double)Cg * Kg + (double)T * Kg);
   prof_begin(st);
   if (bm == 128 && bn == 128) LAUNCH_WG(128, 128);
   else if (bm == 128) LAUNCH_WG(128, 64);

@@ -353,3 +353,26 @@ extern "C" int lmh_resize_bilinear(const void* src, int src_is_u8, int H, int W,
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
+
+// ---- dropout (tf.nn.dropout in the RCNN head: models/fasterrcnn/rcnn.py:196,218) ------------------------------
+// y = x * keep(i) / keep_prob with keep(i) = hash(seed, LMH_STREAM_DROPOUT, i) < keep_prob * 2^32.  The mask is a pure
+// function of (seed, element index): the backward pass regenerates it (dx = dy * keep / keep_prob) instead of storing
+// it.  TF's own Philox stream is not reproducible; the oracle twin is oracle/rng.py::dropout_mask.
+__global__ void __launch_bounds__(256)
+k_dropout(const float* __restrict__ x, int64_t n, uint32_t seed, uint32_t thr, float inv_keep, float* __restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const uint32_t h = lmh_hash_u32(seed, LMH_STREAM_DROPOUT, (uint32_t)i);
+    y[i] = (h < thr) ? x[i] * inv_keep : 0.f;
+  }
+}
+
+extern "C" int lmh_dropout(const float* x, int64_t n, float keep_prob, uint32_t seed, float* y, lmh_stream_t stream) {
+  LMH_CHECK_ARG(x && y && n > 0 && n < (1ll << 32) && keep_prob > 0.f && keep_prob <= 1.f);
+  const double t = (double)keep_prob * 4294967296.0;
+  const uint32_t thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_dropout, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, seed, thr, 1.f / keep_prob, y);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}

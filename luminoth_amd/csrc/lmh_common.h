@@ -57,7 +57,7 @@ __host__ __device__ inline uint32_t lmh_hash_u32(uint32_t seed, uint32_t stream,
   return lmh_fmix32(h);
 }
 enum { LMH_STREAM_RPN_FG = 0, LMH_STREAM_RPN_BG = 1, LMH_STREAM_RCNN_FG = 2, LMH_STREAM_RCNN_BG = 3,
-       LMH_STREAM_SSD = 4 };
+       LMH_STREAM_SSD = 4, LMH_STREAM_DROPOUT = 5 };
 
 #ifdef __HIPCC__
 // ---- box arithmetic, op-for-op the reference's fp32 graph (compiled with

@@ -118,3 +118,122 @@ extern "C" int lmh_l2_reg_loss(const float* w, int64_t n, const int64_t* seg_off
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
+
+// ============================================================================
+// The rest of the optimizer surface of luminoth/utils/training.py (all non-default in base_config.yml):
+//   * per-tensor clip_by_norm(g', 10) of `clip_gradients_by_norm` (training.py:84-120): g' = g*gscale + wd*w is
+//     what TF differentiates (total_loss includes the L2 terms), so the norm is taken over g';
+//   * tf.train.AdamOptimizer / RMSPropOptimizer / GradientDescentOptimizer of the OPTIMIZERS table (training.py:6-11).
+// Two kernels: per-segment sum of squares -> clip factors, then one fused update over the flat buffer.
+// ============================================================================
+// Segment sums are accumulated with fp64 atomics: the order of the additions is not fixed, but with 53-bit partial
+// sums the fp32 factor that comes out is the same in practice.
+__global__ void __launch_bounds__(256)
+k_seg_sqnorm(const float* __restrict__ w, const float* __restrict__ g, int64_t n,
+             const int64_t* __restrict__ seg_offset, const float* __restrict__ seg_wd, int nseg, float gscale,
+             double* __restrict__ ss) {
+  __shared__ int64_t s_off[OPT_MAX_SEG + 1];
+  __shared__ float s_wd[OPT_MAX_SEG];
+  for (int i = threadIdx.x; i <= nseg; i += 256) s_off[i] = seg_offset[i];
+  for (int i = threadIdx.x; i < nseg; i += 256) s_wd[i] = seg_wd[i];
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int seg = seg_find(s_off, nseg, i);
+  double acc = 0.0;
+  for (; i < n; i += stride) {
+    int s2 = seg;
+    while (s_off[s2 + 1] <= i) ++s2;
+    if (s2 != seg) { atomicAdd(&ss[seg], acc); acc = 0.0; seg = s2; }
+    const float gp = g[i] * gscale + s_wd[seg] * w[i];
+    acc += (double)gp * (double)gp;
+  }
+  atomicAdd(&ss[seg], acc);
+}
+
+__global__ void k_clip_factor(const double* __restrict__ ss, int nseg, float clip, float* __restrict__ factor) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nseg) {
+    const float nrm = sqrtf((float)ss[s]);          // tf.clip_by_norm: g * clip / max(||g||, clip)
+    factor[s] = clip / fmaxf(nrm, clip);
+  }
+}
+
+extern "C" size_t lmh_grad_clip_workspace_bytes(int nseg) { return lmh_align_up((size_t)nseg * sizeof(double), 256); }
+
+extern "C" int lmh_grad_clip_factors(const float* w, const float* g, int64_t n, const int64_t* seg_offset,
+                                     const float* seg_wd, int nseg, float gscale, float clip_norm, float* factors,
+                                     void* ws, size_t ws_bytes, lmh_stream_t stream) {
+  LMH_CHECK_ARG(w && g && seg_offset && seg_wd && factors && ws && n > 0 && nseg > 0 && nseg <= OPT_MAX_SEG);
+  LMH_CHECK_ARG(clip_norm > 0.f && ws_bytes >= lmh_grad_clip_workspace_bytes(nseg));
+  hipStream_t st = (hipStream_t)stream;
+  double* ss = reinterpret_cast<double*>(ws);
+  LMH_CHECK_HIP(hipMemsetAsync(ss, 0, sizeof(double) * nseg, st));
+  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(k_seg_sqnorm, dim3(blocks), dim3(256), 0, st, w, g, n, seg_offset, seg_wd, nseg, gscale, ss);
+  hipLaunchKernelGGL(k_clip_factor, dim3((nseg + 255) / 256), dim3(256), 0, st, (const double*)ss, nseg, clip_norm,
+                     factors);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+// kind 0: momentum / gradient descent  v = p1*v + g' ; w -= lr*v
+// kind 1: Adam      m = p1*m + (1-p1)*g' ; v = p2*v + (1-p2)*g'^2 ; w -= lr * m / (sqrt(v) + eps)
+//                   (lr = lr_t = lr0 * sqrt(1-p2^t) / (1-p1^t), computed by the host like TF's _prepare)
+// kind 2: RMSProp   ms = p1*ms + (1-p1)*g'^2 ; mom = p2*mom + lr*g'/sqrt(ms + eps) ; w -= mom
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_optimizer(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ s1, float* __restrict__ s2,
+            int64_t n, const int64_t* __restrict__ seg_offset, const float* __restrict__ seg_wd,
+            const float* __restrict__ seg_factor, int nseg, float lr, float p1, float p2, float eps, float gscale) {
+  __shared__ int64_t s_off[OPT_MAX_SEG + 1];
+  __shared__ float s_wd[OPT_MAX_SEG], s_f[OPT_MAX_SEG];
+  for (int i = threadIdx.x; i <= nseg; i += 256) s_off[i] = seg_offset[i];
+  for (int i = threadIdx.x; i < nseg; i += 256) { s_wd[i] = seg_wd[i]; s_f[i] = seg_factor ? seg_factor[i] : 1.f; }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int seg = seg_find(s_off, nseg, i);
+  for (; i < n; i += stride) {
+    while (s_off[seg + 1] <= i) ++seg;
+    const float wi = w[i];
+    const float gp = (g[i] * gscale + s_wd[seg] * wi) * s_f[seg];
+    if (KIND == 0) {
+      const float v = p1 * s1[i] + gp;
+      s1[i] = v;
+      w[i] = wi - lr * v;
+    } else if (KIND == 1) {
+      const float m = p1 * s1[i] + (1.f - p1) * gp;
+      const float v = p2 * s2[i] + (1.f - p2) * (gp * gp);
+      s1[i] = m;
+      s2[i] = v;
+      w[i] = wi - lr * m / (sqrtf(v) + eps);
+    } else {
+      const float ms = p1 * s1[i] + (1.f - p1) * (gp * gp);
+      const float mom = p2 * s2[i] + lr * gp / sqrtf(ms + eps);
+      s1[i] = ms;
+      s2[i] = mom;
+      w[i] = wi - mom;
+    }
+  }
+}
+
+extern "C" int lmh_optimizer_step(int kind, float* w, const float* g, float* slot1, float* slot2, int64_t n,
+                                  const int64_t* seg_offset, const float* seg_wd, const float* seg_factor, int nseg,
+                                  float lr, float p1, float p2, float eps, float gscale, lmh_stream_t stream) {
+  LMH_CHECK_ARG(w && g && slot1 && seg_offset && seg_wd && n > 0 && nseg > 0 && nseg <= OPT_MAX_SEG);
+  LMH_CHECK_ARG(kind >= 0 && kind <= 2 && (kind == 0 || slot2 != nullptr));
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_OPT(K_)                                                                                          \
+  hipLaunchKernelGGL((k_optimizer<K_>), dim3(blocks), dim3(256), 0, st, w, g, slot1, slot2, n, seg_offset, seg_wd, \
+                     seg_factor, nseg, lr, p1, p2, eps, gscale)
+  if (kind == 0) LAUNCH_OPT(0);
+  else if (kind == 1) LAUNCH_OPT(1);
+  else LAUNCH_OPT(2);
+#undef LAUNCH_OPT
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}

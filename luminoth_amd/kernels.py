@@ -76,7 +76,7 @@ class _Profile(object):
     (lmh_conv2d_profile_next); the library also names the kernel as rocprofv3 prints it and reports the FLOPs
     the launch executed (for a Winograd stacked GEMM: the 16 transformed-domain products, not the direct count)."""
     enabled = False
-    records = []   # (kernel, executed flops, direct-convolution flops of the layer, e0, e1)
+    records = []   # (kernel, executed flops, compulsory HBM bytes, direct-convolution flops of the layer, e0, e1)
 
     @classmethod
     def start(cls):
@@ -88,10 +88,11 @@ class _Profile(object):
         torch.cuda.synchronize()
         lib = _lib.load()
         out = {}
-        for name, flops, direct, e0, e1 in cls.records:
-            r = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'direct_flops': 0.0, 'ms': 0.0})
+        for name, flops, nbytes, direct, e0, e1 in cls.records:
+            r = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'bytes': 0.0, 'direct_flops': 0.0, 'ms': 0.0})
             r['launches'] += 1
             r['flops'] += flops
+            r['bytes'] += nbytes
             r['direct_flops'] += direct
             r['ms'] += lib.lmh_event_elapsed_ms(e0, e1)
             lib.lmh_event_destroy(e0)
@@ -118,10 +119,12 @@ class _timed(object):
     def __exit__(self, *a):
         if self.on:
             fl = ctypes.c_double(0.0)
-            name = _lib.load().lmh_conv2d_profile_last(ctypes.byref(fl))
+            lib = _lib.load()
+            name = lib.lmh_conv2d_profile_last(ctypes.byref(fl))
             name = name.decode() if name else ''
             if name:
-                _Profile.records.append((name, fl.value, _conv_flops(self.d), self.e0, self.e1))
+                _Profile.records.append((name, fl.value, lib.lmh_conv2d_profile_last_bytes(), _conv_flops(self.d),
+                                         self.e0, self.e1))
 
 
 # ------------------------------------------------------------------ conv ----
@@ -556,6 +559,33 @@ def sgd_momentum(w, g, v, seg_offset, seg_wd, lr, momentum, gscale=1.0):
     lib = _lib.load()
     check(lib.lmh_sgd_momentum(_p(w), _p(g), _p(v), w.numel(), _p(seg_offset), _p(seg_wd), seg_wd.numel(),
                                float(lr), float(momentum), float(gscale), _stream()), 'lmh_sgd_momentum')
+
+
+def grad_clip_factors(w, g, seg_offset, seg_wd, gscale, clip_norm, out):
+    """out[s] = clip / max(||g*gscale + wd*w||_2 over segment s, clip)  (tf.clip_by_norm per variable)."""
+    lib = _lib.load()
+    nseg = seg_wd.numel()
+    ws = _workspace(lib.lmh_grad_clip_workspace_bytes(nseg), w.device, 'clip')
+    check(lib.lmh_grad_clip_factors(_p(w), _p(g), w.numel(), _p(seg_offset), _p(seg_wd), nseg, float(gscale),
+                                    float(clip_norm), _p(out), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
+          'lmh_grad_clip_factors')
+    return out
+
+
+def optimizer_step(kind, w, g, slot1, slot2, seg_offset, seg_wd, seg_factor, lr, p1, p2, eps, gscale=1.0):
+    """kind 0 momentum, 1 Adam, 2 RMSProp (lmh_optimizer_step); seg_factor: per-segment clip factors or None."""
+    lib = _lib.load()
+    check(lib.lmh_optimizer_step(int(kind), _p(w), _p(g), _p(slot1), _p(slot2), w.numel(), _p(seg_offset),
+                                 _p(seg_wd), _p(seg_factor), seg_wd.numel(), float(lr), float(p1), float(p2),
+                                 float(eps), float(gscale), _stream()), 'lmh_optimizer_step')
+
+
+def dropout(x, keep_prob, seed):
+    """tf.nn.dropout: x * keep / keep_prob, keep = f(seed, element index) — the same call on dy is the backward."""
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    check(lib.lmh_dropout(_p(x), x.numel(), float(keep_prob), int(seed) & 0xFFFFFFFF, _p(y), _stream()), 'lmh_dropout')
+    return y
 
 
 def l2_reg_loss(w, seg_offset, seg_wd):

@@ -74,6 +74,7 @@ class ConvLayer(object):
         self.wd, self.init = wd, init
         self.trainable = True
         self.compute = None       # MFMA operand arithmetic: None = fp32; 'f16' / 'bf16' = mixed precision (conv_half.h)
+        self.compute_wgrad = 'same'   # arithmetic of the weight-gradient GEMM alone ('same' = self.compute)
         self.w_name = '%s/%s' % (scope, weight_name)
         self.b_name = '%s/%s' % (scope, bias_name)
         self._desc = {}
@@ -100,12 +101,13 @@ class ConvLayer(object):
             self.shift = store[self.b_name]
             self.gb = store.grads.get(self.b_name)
 
-    def desc(self, x_shape):
-        key = tuple(x_shape) + (self.compute,)
+    def desc(self, x_shape, wgrad=False):
+        compute = self.compute if (not wgrad or self.compute_wgrad == 'same') else self.compute_wgrad
+        key = tuple(x_shape) + (compute,)
         d = self._desc.get(key)
         if d is None:
             d = K.conv_desc(x_shape, (self.k, self.k, self.cin, self.cout), self.stride, self.rate,
-                            self.padding, self.act, self.compute)
+                            self.padding, self.act, compute)
             self._desc[key] = d
         return d
 
@@ -117,6 +119,8 @@ class ConvLayer(object):
         return y
 
     def _weight_grads(self, d, x, g, yact, colsum):
+        if self.compute_wgrad != 'same':
+            d = self.desc(x.shape, wgrad=True)
         K.conv2d_bwd_weight(d, x, g, out=self.gw, yact=yact, colsum=colsum)
         if self.norm == 'bn':
             K.bn_param_grads(self.w, self.gw, self.bn['gbeta'], self.bn['mean'], self.bn['rstd'],

@@ -26,8 +26,7 @@ class RCNN(object):
         self._variances = config.target_normalization_variances
         self._l1_sigma = config.l1_sigma
         self._debug, self._config, self._seed = debug, config, seed
-        if self._dropout_keep_prob not in (None, 1, 1.0):
-            raise NotImplementedError('dropout_keep_prob != 1.0 has no HIP kernel yet (reference default 1.0)')
+        self._dropout_calls = 0
         wd = float(config.l2_regularization_scale or 0.0)
         p = '%s/%s' % (scope, name)
         roi = config.roi
@@ -65,6 +64,17 @@ class RCNN(object):
             l.gw = store.grads[l.w_name].view(1, 1, l.cin, l.cout)
         self._anchor = torch.zeros(1, device=store.flat.device, requires_grad=True)
 
+    def _dropout(self, net, is_training):
+        """tf.nn.dropout(net, keep_prob=dropout_keep_prob) while training (rcnn.py:196,218); identity at the reference
+        default 1.0 and at inference."""
+        kp = self._dropout_keep_prob
+        if not is_training or kp in (None, 1, 1.0):
+            return net
+        from luminoth_amd.utils import rng
+        self._dropout_calls += 1
+        seed = rng.hash_u32(0 if self._seed is None else int(self._seed), 0xD509, self._dropout_calls & 0xFFFFFFFF)
+        return A.DropoutFn.apply(net, float(kp), seed)
+
     def _linear(self, layer, x2d):
         y = A.conv(layer, x2d.reshape(1, 1, x2d.shape[0], x2d.shape[1]), self._anchor)
         return y.reshape(x2d.shape[0], layer.cout)
@@ -88,8 +98,9 @@ class RCNN(object):
             net = A.SpatialMeanFn.apply(features)                        # (B*R, C)
         else:
             net = features.reshape(features.shape[0], -1)
+        net = self._dropout(net, is_training)                          # rcnn.py:196
         for layer in self._layers:
-            net = self._linear(layer, net)
+            net = self._dropout(self._linear(layer, net), is_training)   # rcnn.py:214-218
         cls_score = self._linear(self._classifier_layer, net)          # (B*R, C+1)
         bbox_offsets = self._linear(self._bbox_layer, net)             # (B*R, 4C)
         cls_prob = K.softmax(cls_score.detach())

@@ -195,13 +195,20 @@ def install_buckets(buckets):
 
 class MomentumOptimizer(object):
     """tf.train.MomentumOptimizer (non-Nesterov): v = m*v + g ; w -= lr*v, with
-    g = grad/world + wd*w (the L2 regulariser of total_loss)."""
+    g = grad/world + wd*w (the L2 regulariser of total_loss).  One fused kernel over the flat buffer; with
+    `train.clip_by_norm` the per-variable clip factors of `clip_gradients_by_norm` (training.py:84-120) are computed
+    by one reduction launch in front of it."""
+    KIND = 0
 
-    def __init__(self, model, train_config, momentum=0.9):
+    def __init__(self, model, train_config, momentum=0.9, **hyper):
         self.model, self.store, self.cfg = model, model.store, train_config
         self.momentum = float(momentum)
+        self.hyper = hyper
+        self.clip_norm = 10.0 if train_config.get('clip_by_norm') else None      # training.py:108: clip_by_norm(g, 10.)
         self.global_step = 0
         self.buckets = None
+        self._slot2 = None
+        self._factors = None
         if dist.is_available() and dist.is_initialized() and \
                 (dist.get_world_size() > 1 or os.environ.get('LUMINOTH_AMD_FORCE_BUCKETS') == '1'):
             if os.environ.get('LUMINOTH_AMD_BUCKETED_ALLREDUCE', '1') != '0' and \
@@ -223,29 +230,84 @@ class MomentumOptimizer(object):
             return 1.0 / dist.get_world_size()
         return 1.0
 
-    def step(self):
+    def _clip_factors(self, gscale):
+        if self.clip_norm is None:
+            return None
         st = self.store
+        if self._factors is None:
+            self._factors = torch.empty_like(st.seg_wd)
+        K.grad_clip_factors(st.flat, st.grad, st.seg_offset, st.seg_wd, gscale, self.clip_norm, self._factors)
+        return self._factors
+
+    def _update(self, lr, gscale, factors):
+        st = self.store
+        if factors is None:
+            K.sgd_momentum(st.flat, st.grad, st.mom, st.seg_offset, st.seg_wd, lr, self.momentum, gscale)
+        else:
+            K.optimizer_step(0, st.flat, st.grad, st.mom, None, st.seg_offset, st.seg_wd, factors, lr,
+                             self.momentum, 0.0, 0.0, gscale)
+
+    def step(self):
         gscale = self.reduce_gradients()
         lr = get_learning_rate(self.cfg, self.global_step)
-        K.sgd_momentum(st.flat, st.grad, st.mom, st.seg_offset, st.seg_wd, lr, self.momentum, gscale)
+        self._update(lr, gscale, self._clip_factors(gscale))
         self.global_step += 1
 
 
+class AdamOptimizer(MomentumOptimizer):
+    """tf.train.AdamOptimizer(learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8): slots m, v start at zero, the
+    bias-corrected rate lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) is formed on the host (TF: _prepare/_finish)."""
+    KIND = 1
+
+    def __init__(self, model, train_config, beta1=0.9, beta2=0.999, epsilon=1e-8, **hyper):
+        super(AdamOptimizer, self).__init__(model, train_config, momentum=0.0, **hyper)
+        self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
+        self._slot2 = torch.zeros_like(self.store.mom)
+        self._t = 0
+
+    def _update(self, lr, gscale, factors):
+        st = self.store
+        self._t += 1
+        lr_t = lr * (1.0 - self.beta2 ** self._t) ** 0.5 / (1.0 - self.beta1 ** self._t)
+        K.optimizer_step(1, st.flat, st.grad, st.mom, self._slot2, st.seg_offset, st.seg_wd, factors, lr_t,
+                         self.beta1, self.beta2, self.epsilon, gscale)
+
+
+class RMSPropOptimizer(MomentumOptimizer):
+    """tf.train.RMSPropOptimizer(learning_rate, decay=0.9, momentum=0.0, epsilon=1e-10): the mean-square slot starts
+    at ONE (TF's initialiser), the momentum slot at zero."""
+    KIND = 2
+
+    def __init__(self, model, train_config, decay=0.9, momentum=0.0, epsilon=1e-10, **hyper):
+        super(RMSPropOptimizer, self).__init__(model, train_config, momentum=momentum, **hyper)
+        self.decay, self.epsilon = float(decay), float(epsilon)
+        self.store.mom.fill_(1.0)                    # slot 1 = ms
+        self._slot2 = torch.zeros_like(self.store.mom)
+
+    def _update(self, lr, gscale, factors):
+        st = self.store
+        K.optimizer_step(2, st.flat, st.grad, st.mom, self._slot2, st.seg_offset, st.seg_wd, factors, lr,
+                         self.decay, self.momentum, self.epsilon, gscale)
+
+
 def get_optimizer(train_config, model):
-    """training.py:64-81."""
+    """training.py:64-81: OPTIMIZERS[type](learning_rate, **remaining optimizer config)."""
     opt = dict(train_config.optimizer)
     opt.pop('_replace', None)
     kind = opt.pop('type')
     if kind not in OPTIMIZERS:
         raise ValueError('Invalid optimizer type "{}"'.format(kind))
-    if train_config.get('clip_by_norm'):
-        raise NotImplementedError('train.clip_by_norm (per-tensor clip_by_norm, training.py:84-120) '
-                                  'is not implemented in the fused optimizer yet (reference default: False)')
+    opt.pop('use_locking', None)
+    opt.pop('name', None)
     if kind == 'momentum':
-        return MomentumOptimizer(model, train_config, momentum=opt.get('momentum', 0.9))
+        if opt.pop('use_nesterov', False):
+            raise NotImplementedError('use_nesterov=True has no fused HIP kernel (reference default: False)')
+        return MomentumOptimizer(model, train_config, momentum=opt.pop('momentum', 0.9))
     if kind == 'gradient_descent':
         return MomentumOptimizer(model, train_config, momentum=0.0)
-    raise NotImplementedError('optimizer "{}" has no fused HIP kernel yet (reference default: momentum)'.format(kind))
+    if kind == 'adam':
+        return AdamOptimizer(model, train_config, **opt)
+    return RMSPropOptimizer(model, train_config, **opt)
 
 
 def broadcast_parameters(model, src=0):

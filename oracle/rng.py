@@ -15,6 +15,7 @@ STREAM_RPN_BG = 1
 STREAM_RCNN_FG = 2
 STREAM_RCNN_BG = 3
 STREAM_SSD = 4
+STREAM_DROPOUT = 5
 
 _M32 = np.uint64(0xFFFFFFFF)
 
@@ -59,3 +60,10 @@ def keep_k_smallest(candidates, k, seed, stream):
     keep = np.zeros(candidates.shape[0], dtype=bool)
     keep[order[:max(k, 0)]] = True
     return keep
+
+
+def dropout_mask(n, keep_prob, seed):
+    """Twin of csrc/elementwise.hip::k_dropout: element i is kept iff hash(seed, STREAM_DROPOUT, i) < keep_prob*2^32."""
+    t = float(keep_prob) * 4294967296.0
+    thr = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+    return hash_u32(seed, STREAM_DROPOUT, np.arange(n)) < np.uint32(thr)

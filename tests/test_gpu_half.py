@@ -7,9 +7,9 @@ Tolerances are stated HERE, separately from the fp32 contract (north_star's 1e-4
   * on random data the only error is the rounding of the operands (2^-11 relative for f16, 2^-8 for bf16):
     3e-3 (f16) / 2.5e-2 (bf16) of the output scale per convolution;
   * end to end (ResNet-50 train step vs the fp32 CPU oracle): every loss within 2e-2 relative (f16) and the
-    gradient of every large tensor at cosine similarity >= 0.98 (f16) / 0.90 (bf16) with the oracle's (ReLU units whose
-    pre-activation is within the operand rounding of zero take the other branch: the gradients are those of a
-    slightly different piecewise-linear function, not a rounded copy of the oracle's)."""
+    gradient of every large tensor at cosine similarity >= 0.999 (f16) / 0.995 (bf16) with the oracle's.  (The weight
+    gradient of the RPN 3x3 convolution is kept in fp32 by the model: a sparse signed sum of positive features whose
+    cancellation amplified the operand rounding to cosine 0.99 / 0.78 when it ran in f16 / bf16.)"""
 import os
 import sys
 
@@ -92,7 +92,7 @@ def test_half_kernels_random_data_within_operand_rounding(K, case, compute, tol,
         assert np.abs(a - b).max() <= tol * conv_part, (name, float(np.abs(a - b).max()), float(conv_part))
 
 
-@pytest.mark.parametrize('compute,loss_tol,cos_tol', [('f16', 2e-2, 0.98), ('bf16', 8e-2, 0.90)])
+@pytest.mark.parametrize('compute,loss_tol,cos_tol', [('f16', 2e-2, 0.999), ('bf16', 8e-2, 0.995)])
 def test_half_precision_train_step_vs_fp32_oracle(compute, loss_tol, cos_tol):
     from e2e_util import condition_like_pretrained, make_config, run_step_with_tap, synth
     from luminoth_amd.models import get_model

@@ -594,3 +594,109 @@ def test_sgd_momentum_and_l2(K):
     vv = F(0.9) * v + gg
     np.testing.assert_allclose(vt.cpu().numpy(), vv, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(wt.cpu().numpy(), w - F(3e-4) * vv, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------- optimizer surface ----
+def _np_clip_factors(w, g, off, wd, gscale, clip):
+    f = np.ones(len(wd), F)
+    for s in range(len(wd)):
+        gp = g[off[s]:off[s + 1]] * F(gscale) + F(wd[s]) * w[off[s]:off[s + 1]]
+        nrm = np.sqrt(np.sum(gp.astype(np.float64) ** 2))
+        f[s] = clip / max(nrm, clip)
+    return f
+
+
+def test_optimizer_variants_match_tf_formulas(K):
+    """lmh_grad_clip_factors + lmh_optimizer_step against numpy restatements of tf.clip_by_norm (training.py:84-120),
+    tf.train.MomentumOptimizer / AdamOptimizer / RMSPropOptimizer (OPTIMIZERS table, training.py:6-11)."""
+    rs = np.random.RandomState(5)
+    off = np.array([0, 1000, 1004, 5003], np.int64)
+    n = int(off[-1])
+    wd = np.array([5e-4, 0.0, 1e-3], F)
+    w0 = rs.randn(n).astype(F)
+    grads = [(rs.randn(n) * sc).astype(F) for sc in (0.5, 0.01)]     # step 1 is clipped, step 2 is not
+    seg_of = np.repeat(np.arange(3), np.diff(off))
+    dev_off, dev_wd = T(off), T(wd)
+    gscale, clip, lr = 0.5, 10.0, 0.01
+    # --- clip factors
+    fac = torch.empty(3, device=dev())
+    K.grad_clip_factors(T(w0), T(grads[0]), dev_off, dev_wd, gscale, clip, fac)
+    want = _np_clip_factors(w0, grads[0], off, wd, gscale, clip)
+    assert want.min() < 0.9 and want.max() == 1.0       # segment 1 (4 elements) is below the clip norm
+    np.testing.assert_allclose(fac.cpu().numpy(), want, rtol=1e-6)
+    for kind, p1, p2, eps in ((0, 0.9, 0.0, 0.0), (1, 0.9, 0.999, 1e-8), (2, 0.9, 0.1, 1e-10)):
+        w = w0.copy()
+        s1 = np.ones(n, F) if kind == 2 else np.zeros(n, F)
+        s2 = np.zeros(n, F)
+        dw, ds1, ds2 = T(w), T(s1), T(s2)
+        for t, g in enumerate(grads, 1):
+            f = _np_clip_factors(w, g, off, wd, gscale, clip)
+            gp = (g * F(gscale) + wd[seg_of] * w) * f[seg_of]
+            lr_t = lr
+            if kind == 0:
+                s1 = F(p1) * s1 + gp
+                w = w - F(lr) * s1
+            elif kind == 1:
+                lr_t = lr * np.sqrt(1 - p2 ** t) / (1 - p1 ** t)
+                s1 = F(p1) * s1 + F(1 - p1) * gp
+                s2 = F(p2) * s2 + F(1 - p2) * gp * gp
+                w = w - F(lr_t) * s1 / (np.sqrt(s2) + F(eps))
+            else:
+                s1 = F(p1) * s1 + F(1 - p1) * gp * gp
+                s2 = F(p2) * s2 + F(lr) * gp / np.sqrt(s1 + F(eps))
+                w = w - s2
+            K.grad_clip_factors(dw, T(g), dev_off, dev_wd, gscale, clip, fac)
+            K.optimizer_step(kind, dw, T(g), ds1, ds2 if kind else None, dev_off, dev_wd, fac, lr_t, p1, p2, eps, gscale)
+        np.testing.assert_allclose(dw.cpu().numpy(), w, rtol=2e-5, atol=1e-6, err_msg='kind %d' % kind)
+        np.testing.assert_allclose(ds1.cpu().numpy(), s1, rtol=2e-5, atol=1e-7, err_msg='kind %d slot1' % kind)
+    # the fused default kernel (lmh_sgd_momentum) == kind 0 without clipping
+    a, va = T(w0), torch.zeros(n, device=dev())
+    b, vb = T(w0), torch.zeros(n, device=dev())
+    K.sgd_momentum(a, T(grads[0]), va, dev_off, dev_wd, lr, 0.9, gscale)
+    K.optimizer_step(0, b, T(grads[0]), vb, None, dev_off, dev_wd, None, lr, 0.9, 0.0, 0.0, gscale)
+    assert torch.equal(a, b) and torch.equal(va, vb)
+
+
+def test_get_optimizer_builds_every_reference_optimizer(K):
+    from luminoth_amd.utils import training as TR
+    from luminoth_amd.utils.config import Config
+
+    class Store(object):
+        pass
+
+    class Model(object):
+        pass
+    n = 1024
+    for kind, cls in (('momentum', TR.MomentumOptimizer), ('gradient_descent', TR.MomentumOptimizer),
+                      ('adam', TR.AdamOptimizer), ('rmsprop', TR.RMSPropOptimizer)):
+        m = Model()
+        m.store = Store()
+        m.store.flat = torch.ones(n, device=dev())
+        m.store.grad = torch.full((n,), 0.5, device=dev())
+        m.store.mom = torch.zeros(n, device=dev())
+        m.store.seg_offset = T(np.array([0, n], np.int64))
+        m.store.seg_wd = T(np.array([0.0], F))
+        cfg = Config({'learning_rate': {'decay_method': None, 'learning_rate': 0.1}, 'optimizer': {'type': kind},
+                      'clip_by_norm': True})
+        opt = TR.get_optimizer(cfg, m)
+        assert type(opt) is cls and opt.clip_norm == 10.0
+        opt.step()
+        w = m.store.flat.cpu().numpy()
+        clipped = 0.5 * 10.0 / np.sqrt(n * 0.25)                       # ||g|| = 16 > 10
+        expect = {'momentum': 1 - 0.1 * clipped, 'gradient_descent': 1 - 0.1 * clipped,
+                  'adam': 1 - 0.1 * np.sqrt(1 - 0.999) / (1 - 0.9) * (0.1 * clipped) / (np.sqrt(0.001 * clipped ** 2) + 1e-8),
+                  'rmsprop': 1 - 0.1 * clipped / np.sqrt(0.9 + 0.1 * clipped ** 2 + 1e-10)}[kind]
+        np.testing.assert_allclose(w, expect, rtol=1e-5, err_msg=kind)
+
+
+def test_dropout_matches_oracle_mask(K):
+    from oracle import rng as orng
+    rs = np.random.RandomState(9)
+    x = rs.randn(513, 37).astype(F)
+    for keep, seed in ((0.5, 1234), (0.9, 7), (1.0, 3)):
+        y = K.dropout(T(x), keep, seed).cpu().numpy()
+        mask = orng.dropout_mask(x.size, keep, seed).reshape(x.shape)
+        np.testing.assert_array_equal(y, np.where(mask, x * F(1.0 / keep), F(0)))
+        assert abs(mask.mean() - keep) < 0.02
+        dy = rs.randn(*x.shape).astype(F)
+        np.testing.assert_array_equal(K.dropout(T(dy), keep, seed).cpu().numpy(), np.where(mask, dy * F(1.0 / keep), F(0)))
