@@ -218,96 +218,114 @@ k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts,
   if (r < K) mask[((size_t)b * K + r) * W + cb] = word;
 }
 
-//    Phase 2: greedy reduce, one 256-thread block per image.  Wave 0 resolves
-//    the 64 candidates of a chunk serially in registers (diagonal word per
-//    lane), then all waves OR the kept rows into the LDS `removed` bitmap.
-#define NMS_RED_THREADS 256
+//    Phase 2: greedy reduce, one 1024-thread block per image, in SUPER-CHUNKS of 16 mask words (1024 candidates).
+//    The greedy scan is a dependent chain over the candidates; what round 1 paid for was not that chain but a global
+//    round trip per 64-candidate chunk: after every chunk the kept rows were OR-ed into ALL remaining words of the
+//    removed-bitmap (188 words at 12 000 candidates) although the scan stops after max_out (2000) keeps — 377 us, the
+//    longest kernel of the proposal chain the main stream waits for.  Here
+//      (1) thread t owns row r0 + t of the current super-chunk and holds that row's 16 diagonal-block words in
+//          REGISTERS (one 128-byte read per row, issued before anything depends on it);
+//      (2) the removed-words of the super-chunk start as the OR of those 16 words over every row kept so far
+//          (<= max_out rows x 128 contiguous bytes: one fully parallel gather per super-chunk, not per chunk);
+//      (3) the 16 chunks are then resolved back to back without touching global memory: wave c resolves chunk c (its
+//          lanes hold exactly the diagonal word of their rows), kept lanes OR their later words into the LDS bitmap
+//          with ds_or_b64, one block barrier per chunk.
+//    Global round trips: 2 per 1024 candidates instead of 1 per 64.
+#define NMS_RED_THREADS 1024
+#define NMS_SC_WORDS 16
+#define NMS_LDS_KEEP 2048
 #define NMS_MAX_W 512  // K <= 32768 candidates
 __global__ void __launch_bounds__(NMS_RED_THREADS)
 k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts, int K, int W,
              int max_out, int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
-  // all LDS static: a static object in front of a dynamic region would leave the u64 bitmap
-  // 4-byte aligned (64-bit LDS atomics then misbehave) — guide §6 G17.
-  __shared__ __attribute__((aligned(16))) unsigned long long removed[NMS_MAX_W];
-  __shared__ __attribute__((aligned(16))) unsigned long long s_kept;
+  __shared__ __attribute__((aligned(16))) unsigned long long rem[NMS_SC_WORDS];
   __shared__ int s_total;
-  __shared__ int s_rows[64];
+  __shared__ int32_t s_kidx[NMS_LDS_KEEP];     // LDS mirror of the kept indices (one global latency less in (2))
+  const bool lds_keep = max_out <= NMS_LDS_KEEP;
   const int b = blockIdx.x;
-  const int cnt = counts[b];
+  const int cnt = min(counts[b], K);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t* mb = mask + (size_t)b * K * W;
   int32_t* kidx = keep_idx + (size_t)b * max_out;
-  for (int w = tid; w < W; w += blockDim.x) removed[w] = 0ull;
-  for (int i = tid; i < max_out; i += blockDim.x) kidx[i] = -1;
+  for (int i = tid; i < max_out; i += NMS_RED_THREADS) kidx[i] = -1;
   if (tid == 0) s_total = 0;
   __syncthreads();
-  const int nchunks = (cnt + 63) / 64;
-  // The loop is a chain of dependent global-load latencies (the mask lives in HBM / MALL: 18 MB per image), so
-  // (1) the diagonal word of chunk c+1 is fetched while chunk c is being resolved and (2) the words of the kept
-  // rows are fetched four at a time per thread over a flat (row, word) index instead of row after row.
-  uint64_t diag_next = 0ull;
-  if (wave == 0 && nchunks > 0) diag_next = (lane < cnt) ? mb[(size_t)lane * W] : 0ull;
-  for (int c = 0; c < nchunks; ++c) {
-    if (wave == 0) {
-      const uint64_t diag = diag_next;
-      {
-        const int rn = (c + 1) * 64 + lane;
-        diag_next = (c + 1 < nchunks && rn < cnt) ? mb[(size_t)rn * W + c + 1] : 0ull;
-      }
-      const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
-      const int nin = min(64, cnt - c * 64);
-      uint64_t alive = ~removed[c];
-      if (nin < 64) alive &= ((1ull << nin) - 1ull);
-      uint64_t kept = 0;
-      int total = s_total;
-      while (alive && total < max_out) {
-        const int j = __builtin_ctzll(alive);
-        kept |= (1ull << j);
-        ++total;
-        // readlane returns a signed int: go through uint32_t or bit 31 sign-extends into the high word
-        const uint64_t dj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
-                            (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dlo, j);
-        alive &= ~dj;
-        alive &= ~(1ull << j);
-      }
-      // write kept indices in order (global list + this chunk's row list for the OR phase)
-      if ((kept >> lane) & 1ull) {
-        const int local = __popcll(kept & ((1ull << lane) - 1ull));
-        kidx[s_total + local] = c * 64 + lane;
-        s_rows[local] = lane;
-      }
-      if (lane == 0) { s_kept = kept; s_total = total; }
+  const int nchunks = (cnt + 63) / 64;                       // mask words >= nchunks were never written
+  const int nsc = (nchunks + NMS_SC_WORDS - 1) / NMS_SC_WORDS;
+  for (int sc = 0; sc < nsc; ++sc) {
+    const int r0 = sc * 64 * NMS_SC_WORDS, w0 = sc * NMS_SC_WORDS;
+    const int nw = min(NMS_SC_WORDS, nchunks - w0);          // words of this super-chunk
+    // (1) this thread's row: words w0 .. w0+nw-1; the mask holds only the upper triangle (word >= row / 64)
+    const int row = r0 + tid;
+    uint64_t d[NMS_SC_WORDS];
+#pragma unroll
+    for (int j = 0; j < NMS_SC_WORDS; ++j) {
+      const bool ok = row < cnt && j < nw && (w0 + j) >= (row >> 6);
+      d[j] = ok ? mb[(size_t)row * W + w0 + j] : 0ull;
     }
+    // (2) removed-words of this super-chunk from every row kept so far (rows < r0: all their words here are valid)
+    if (tid < NMS_SC_WORDS) rem[tid] = 0ull;
     __syncthreads();
-    const uint64_t kept = s_kept;
-    const bool done = (s_total >= max_out);
-    if (done) break;
-    // OR the kept rows into removed[c+1 .. nchunks): flat index over (row, word), four loads in flight per thread
-    const int nk = __popcll(kept);
-    const int nw = nchunks - c - 1;                 // words >= nchunks are never read
-    const int items = nk * nw;
-    for (int i0 = tid; i0 < items; i0 += 4 * NMS_RED_THREADS) {
+    const int nkept = s_total;
+    for (int i0 = tid; i0 < nkept * NMS_SC_WORDS; i0 += 4 * NMS_RED_THREADS) {
       uint64_t v[4];
-      int wi[4];
+      int wj[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * NMS_RED_THREADS;
+        wj[u] = i & (NMS_SC_WORDS - 1);
         v[u] = 0ull;
-        wi[u] = 0;
-        if (i < items) {
-          const int q = i / nw;
-          wi[u] = c + 1 + (i - q * nw);
-          v[u] = mb[(size_t)(c * 64 + s_rows[q]) * W + wi[u]];
+        if (i < nkept * NMS_SC_WORDS && wj[u] < nw) {
+          const int kr = lds_keep ? s_kidx[i / NMS_SC_WORDS] : kidx[i / NMS_SC_WORDS];
+          v[u] = mb[(size_t)kr * W + w0 + wj[u]];
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (v[u]) atomicOr(&removed[wi[u]], (unsigned long long)v[u]);
+        if (v[u]) atomicOr(&rem[wj[u]], (unsigned long long)v[u]);
     }
     __syncthreads();
+    // (3) the chunks of this super-chunk, wave c resolves chunk c
+    bool done = false;
+    for (int c = 0; c < nw; ++c) {
+      if (wave == c) {
+        const uint64_t diag = d[c];
+        const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+        const int nin = min(64, cnt - (w0 + c) * 64);
+        uint64_t alive = ~rem[c];
+        if (nin < 64) alive &= ((1ull << nin) - 1ull);
+        uint64_t kept = 0;
+        const int base = s_total;
+        int total = base;
+        while (alive && total < max_out) {
+          const int j = __builtin_ctzll(alive);
+          kept |= (1ull << j);
+          ++total;
+          // readlane returns a signed int: go through uint32_t or bit 31 sign-extends into the high word
+          const uint64_t dj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                              (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dlo, j);
+          alive &= ~dj;
+          alive &= ~(1ull << j);
+        }
+        if ((kept >> lane) & 1ull) {
+          const int slot = base + __popcll(kept & ((1ull << lane) - 1ull));
+          kidx[slot] = (w0 + c) * 64 + lane;              // kept indices, in order
+          if (lds_keep) s_kidx[slot] = (w0 + c) * 64 + lane;
+#pragma unroll
+          for (int j = 0; j < NMS_SC_WORDS; ++j)          // suppress later candidates of this super-chunk
+            if (j > c && d[j]) atomicOr(&rem[j], (unsigned long long)d[j]);
+        }
+        if (lane == 0) s_total = total;
+      }
+      __syncthreads();
+      if (s_total >= max_out) { done = true; break; }
+    }
+    if (done) break;
+    // the kept indices written above are read back (kidx) by the next super-chunk's gather: same block, global memory
+    __threadfence_block();
+    __syncthreads();
   }
-  __syncthreads();
   if (tid == 0) keep_count[b] = s_total;
 }
 

@@ -72,6 +72,28 @@ def test_nms_matches_oracle_bit_exact(K):
             assert (keep[b, kc[b]:] == -1).all()
 
 
+def test_nms_full_size_super_chunks(K):
+    """12 000 candidates (12 super-chunks of 1024 in k_nms_reduce), clustered boxes so that suppression reaches far
+    down the list; max_out both inside (2000) and beyond (5000) the LDS mirror of the kept list; ragged counts."""
+    rs = np.random.RandomState(4)
+    B, Kn = 2, 12000
+    boxes = np.zeros((B, Kn, 4), F)
+    counts = np.array([12000, 9001], np.int32)
+    for b in range(B):
+        base = rand_boxes(rs, 400 + 2000 * b, 1000, 30, 300)
+        jit = base[rs.randint(0, base.shape[0], size=Kn)] + rs.randint(-10, 11, size=(Kn, 4))
+        boxes[b] = jit.astype(F)
+    for thr, max_out in ((0.7, 2000), (0.5, 5000), (0.9, 300)):
+        keep, kc = K.nms(T(boxes), T(counts), thr, max_out)
+        keep, kc = keep.cpu().numpy(), kc.cpu().numpy()
+        for b in range(B):
+            scores = np.arange(counts[b], 0, -1).astype(F)
+            ref = tfops.non_max_suppression(boxes[b, :counts[b]][:, [1, 0, 3, 2]], scores, max_out, thr)
+            assert kc[b] == ref.shape[0], (thr, max_out, b, kc[b], ref.shape[0])
+            np.testing.assert_array_equal(keep[b, :kc[b]], ref)
+            assert (keep[b, kc[b]:] == -1).all()
+
+
 # ---------------------------------------------------------- RPN proposal ----
 def _proposal_case(K, feat, A, stride, im, pre, post, thr, zero_wh, seed, **kw):
     rs = np.random.RandomState(seed)

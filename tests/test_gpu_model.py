@@ -308,3 +308,27 @@ def test_hip_graph_replay_equals_eager_steps(setup):
         model._seed_override = None
         model.load_state_dict(sd0)
         model.store.mom.zero_()
+
+
+def test_non_default_config_surface_trains(monkeypatch):
+    """Keys the reference accepts and round 1 rejected with NotImplementedError: RCNN FC stack + dropout
+    (rcnn.py:196-218), train.clip_by_norm, the Adam optimizer.  Two steps must run, stay finite and move the weights;
+    with keep_prob 1.0 the dropout layers are exact identities (same loss as the default model)."""
+    from luminoth_amd.models import get_model
+    from luminoth_amd.utils import training as T
+    from luminoth_amd.utils.config import get_config
+    cfg = get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': 20},
+                                'base_network': {'architecture': 'resnet_v1_50'},
+                                'rcnn': {'dropout_keep_prob': 0.5, 'layer_sizes': [256]}},
+                      'train': {'seed': 0, 'clip_by_norm': True, 'optimizer': {'type': 'adam'}}})
+    model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_50')
+    images, gts = synth(2, 256, 320, 3, 20, 13)
+    opt = T.get_optimizer(cfg.train, model)
+    assert isinstance(opt, T.AdamOptimizer) and opt.clip_norm == 10.0
+    w0 = model.store.flat.clone()
+    l1, _ = T.train_step(model, opt, images, gts)
+    l2, _ = T.train_step(model, opt, images, gts)
+    assert np.isfinite(float(l1)) and np.isfinite(float(l2))
+    moved = (model.store.flat - w0).abs()
+    assert float(moved.max()) > 1e-5 and float(moved.max()) < 1e-2      # Adam: |step| ~ lr per element
+    assert model._rcnn._dropout_calls == 4                               # after pooling + after fc_0, two steps
