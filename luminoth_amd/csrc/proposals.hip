@@ -293,10 +293,15 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
         const uint64_t diag = d[c];
         const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
         const int nin = min(64, cnt - (w0 + c) * 64);
-        uint64_t alive = ~rem[c];
-        if (nin < 64) alive &= ((1ull << nin) - 1ull);
+        uint64_t alive_v = ~rem[c];
+        if (nin < 64) alive_v &= ((1ull << nin) - 1ull);
+        // The greedy scan is one dependent chain per kept candidate: keep ALL of its state wave-uniform (readfirstlane
+        // -> SGPRs) so that the loop is s_ff1 / s_bitset / s_andn2 on the scalar unit plus two v_readlane; with the state
+        // in VGPRs the same loop ran ~430 cycles per kept box (2000 keeps = 360 us), the whole kernel.
+        uint64_t alive = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(alive_v >> 32)) << 32) |
+                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)alive_v);
         uint64_t kept = 0;
-        const int base = s_total;
+        const int base = __builtin_amdgcn_readfirstlane(s_total);
         int total = base;
         while (alive && total < max_out) {
           const int j = __builtin_ctzll(alive);
@@ -305,8 +310,7 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
           // readlane returns a signed int: go through uint32_t or bit 31 sign-extends into the high word
           const uint64_t dj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
                               (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dlo, j);
-          alive &= ~dj;
-          alive &= ~(1ull << j);
+          alive &= ~(dj | (1ull << j));
         }
         if ((kept >> lane) & 1ull) {
           const int slot = base + __popcll(kept & ((1ull << lane) - 1ull));

@@ -63,11 +63,7 @@ class FasterRCNN(object):
         self._rpn = RPN(self._num_anchors, config.model.rpn, self.base_network.feat_channels,
                         debug=self._debug, seed=self._seed, scope=name)
         if self.base_network.compute_dtype not in (None, 'f32', 'fp32', 'float32'):
-            # the 3x3 RPN conv runs in half precision, its 1x1 heads stay fp32 — and so does its WEIGHT gradient: it is a
-            # sparse signed sum (256 sampled anchors, sum of (p - y) ~ 0) of all-positive features, i.e. a difference of
-            # large terms that amplifies the operand rounding ~50x (measured: cosine 0.78 with bf16 operands, 0.99 f16)
-            self._rpn._rpn.compute = self.base_network.compute_dtype
-            self._rpn._rpn.compute_wgrad = None
+            self._rpn._rpn.compute = self.base_network.compute_dtype     # the 3x3 RPN conv; the 1x1 heads stay fp32
         self._rcnn = None
         if self._with_rcnn:
             self._rcnn = RCNN(self._num_classes, config.model.rcnn, self.base_network.tail_channels,

