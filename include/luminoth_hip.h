@@ -355,6 +355,31 @@ int lmh_ssd_loss(const float* cls_pred, const float* loc_pred, const float* labe
 int lmh_sgd_momentum(float* w, const float* g, float* v, int64_t n, const int64_t* seg_offset,
                      const float* seg_wd, int nseg, float lr, float momentum, float gscale,
                      lmh_stream_t stream);
+/* Deferred weight-gradient tails.  While lmh_tail_defer(1) is in effect on the calling thread, lmh_conv2d_bwd_weight and
+ * lmh_act_bwd launch their main kernel only: the split-K slabs stay in the caller's `ws`, the per-channel partial sums
+ * of g stay in theirs, and lmh_tail_last_plan reports where (slabs NULL / splits 0: `dw` already holds the raw
+ * gradient).  The caller keeps those workspaces untouched, queues one lmh_wgrad_tail per layer and finishes the whole
+ * backlog with lmh_wgrad_tail_batch (two launches per <= 20 layers): split-K reduction in fixed order, frozen-BatchNorm
+ * scaling dW = dW_raw * scale[k] and dgamma[k] = rstd[k] * (sum_i w[i,k] dW_raw[i,k] - mean[k] dbeta[k]) (slim
+ * batch_norm in inference mode, base_network.py:84-89), dbeta / dbias = column sums of the partial rows. */
+typedef struct lmh_wgrad_tail {
+  const float* slabs;   /* [splits][n] or NULL */
+  float* dw;            /* (n) out; in when splits == 0 */
+  const float* w;       /* BN only */
+  const float* scale;   /* BN only: gamma * rstd */
+  const float* mean;    /* BN only */
+  const float* rstd;    /* BN only */
+  float* dgamma;        /* BN only (NULL: plain / bias layer) */
+  const float* colpart; /* [colrows][K] or NULL */
+  float* colsum;        /* dbeta / dbias (out when colpart != NULL, else read for dgamma) */
+  int64_t n;            /* R*S*C*K */
+  int32_t splits, K, colrows, reserved;
+} lmh_wgrad_tail;
+void lmh_tail_defer(int on);
+void lmh_tail_last_plan(const float** slabs, int* splits, const float** colpart, int* colrows);
+size_t lmh_wgrad_tail_batch_workspace_bytes(const lmh_wgrad_tail* tails, int count);
+int lmh_wgrad_tail_batch(const lmh_wgrad_tail* tails, int count, void* ws, size_t ws_bytes, lmh_stream_t stream);
+
 /* The non-default rest of utils/training.py.  lmh_grad_clip_factors: factors[s] = clip / max(||g'_s||, clip) per
  * segment (clip_gradients_by_norm: tf.clip_by_norm(g', 10), training.py:84-120; g' includes the L2 term like TF's
  * gradient of total_loss).  lmh_optimizer_step: kind 0 momentum (p1 = momentum; 0 = GradientDescentOptimizer),

@@ -68,6 +68,13 @@ class SsdTargetDesc(ctypes.Structure):
                 ('variance_wh', ctypes.c_float)]
 
 
+class WgradTail(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ('slabs', 'dw', 'w', 'scale', 'mean', 'rstd', 'dgamma', 'colpart',
+                                                 'colsum')] + \
+               [('n', ctypes.c_int64), ('splits', ctypes.c_int32), ('K', ctypes.c_int32), ('colrows', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
 P = ctypes.POINTER
 SIGNATURES = {
     # name: (restype, argtypes)   -- lists EVERY symbol include/luminoth_hip.h declares
@@ -127,6 +134,10 @@ SIGNATURES = {
     'lmh_ssd_target': (c_i, [P(SsdTargetDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_ssd_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
     'lmh_sgd_momentum': (c_i, [c_f, c_f, c_f, c_i64, c_f, c_f, c_i, c_fl, c_fl, c_fl, c_f]),
+    'lmh_tail_defer': (None, [c_i]),
+    'lmh_tail_last_plan': (None, [P(ctypes.c_void_p), P(c_i), P(ctypes.c_void_p), P(c_i)]),
+    'lmh_wgrad_tail_batch_workspace_bytes': (c_sz, [P(WgradTail), c_i]),
+    'lmh_wgrad_tail_batch': (c_i, [P(WgradTail), c_i, c_f, c_sz, c_f]),
     'lmh_grad_clip_workspace_bytes': (c_sz, [c_i]),
     'lmh_grad_clip_factors': (c_i, [c_f, c_f, c_i64, c_f, c_f, c_i, c_fl, c_fl, c_f, c_f, c_sz, c_f]),
     'lmh_optimizer_step': (c_i, [c_i, c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_i, c_fl, c_fl, c_fl, c_fl, c_fl, c_f]),

@@ -35,3 +35,17 @@ extern "C" float lmh_event_elapsed_ms(void* e0, void* e1) {
   if (hipEventElapsedTime(&ms, (hipEvent_t)e0, (hipEvent_t)e1) != hipSuccess) return -1.f;
   return ms;
 }
+
+// ---- deferred weight-gradient tails: per-thread switch + the plan of the last deferred call ----------------------
+thread_local int g_lmh_defer_tail = 0;
+thread_local lmh_tail_plan g_lmh_last_plan = {nullptr, 0, nullptr, 0};
+extern "C" void lmh_tail_defer(int on) {
+  g_lmh_defer_tail = on;
+  g_lmh_last_plan = lmh_tail_plan{nullptr, 0, nullptr, 0};
+}
+extern "C" void lmh_tail_last_plan(const float** slabs, int* splits, const float** colpart, int* colrows) {
+  if (slabs) *slabs = g_lmh_last_plan.slabs;
+  if (splits) *splits = g_lmh_last_plan.splits;
+  if (colpart) *colpart = g_lmh_last_plan.colpart;
+  if (colrows) *colrows = g_lmh_last_plan.colrows;
+}

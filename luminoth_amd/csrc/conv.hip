@@ -422,7 +422,10 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
 #undef LAUNCH_WG1_T
 #undef LAUNCH_WG1
     prof_end(stream, desc_flops(d), "k_wgrad_1x1<%d, %d, %d>", bm, bn, nbuf);
-    if (splits > 1) {
+    if (g_lmh_defer_tail) {
+      g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;
+      g_lmh_last_plan.splits = splits > 1 ? splits : 0;
+    } else if (splits > 1) {
       const int64_t n = (int64_t)d->C * d->K;
       const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
       hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, stream, reinterpret_cast<const float*>(ws), n,
@@ -461,7 +464,10 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
 #undef LAUNCH_BW_HT
 #undef LAUNCH_BW_H
     prof_end(st, desc_flops(d), "k_conv_bwd_weight_h<%d, %d, %d>", d->compute, bm, bn);
-    if (splits > 1) {
+    if (g_lmh_defer_tail) {
+      g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;
+      g_lmh_last_plan.splits = splits > 1 ? splits : 0;
+    } else if (splits > 1) {
       const int64_t n = (int64_t)d->R * d->S * d->C * d->K;
       const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
       hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
@@ -493,7 +499,12 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
   if (fast) prof_end(st, desc_flops(d), "k_conv_bwd_weight<%d, %d, %s, %s>", bm, bn, (yact && !gb) ? "true" : "false",
                      gb ? "true" : "false");
   else prof_end(st, desc_flops(d), "k_conv_bwd_weight_gen<%d, %d>", bm, bn);
-  if (splits > 1 || colsum) {
+  if (g_lmh_defer_tail && !gb) {
+    g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;
+    g_lmh_last_plan.splits = splits > 1 ? splits : 0;
+    g_lmh_last_plan.colpart = cpart;                 // [splits][K] partial sums of g (fused dbeta / dbias), or NULL
+    g_lmh_last_plan.colrows = cpart ? splits : 0;
+  } else if (splits > 1 || colsum) {
     const int64_t n = splits > 1 ? (int64_t)d->R * d->S * d->C * d->K : 0;
     const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;
     const int nb_col = colsum ? (d->K + 31) / 32 : 0;

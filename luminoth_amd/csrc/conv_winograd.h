@@ -391,7 +391,7 @@ extern "C" int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const floa
     hipLaunchKernelGGL(k_wino_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
   }
   const lmh_conv_desc g = wino_gemm_desc(d, T);
-  rc = bwd_weight_launch(&g, V, dM, nullptr, dU, nullptr, ws2, ws_bytes - planes, st, true);
+  rc = bwd_weight_launch(&g, V, dM, nullptr, dU, nullptr, ws2, ws_bytes - planes, st, true);   // gb: never deferred
   if (rc) return rc;
   const int n = d->C * (d->K / 4);
   hipLaunchKernelGGL(k_wino_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);

@@ -133,8 +133,12 @@ extern "C" int lmh_act_bwd(const float* dy, const float* y, int act, int64_t row
     hipLaunchKernelGGL((k_act_bwd<false>), dim3(nb), dim3(256), 0, st, dy, y, act, rows, K, g, partial, rpb);
   else
     hipLaunchKernelGGL((k_act_bwd<true>), dim3(nb), dim3(256), 0, st, dy, y, act, rows, K, g, partial, rpb);
-  if (colsum)
+  if (colsum && g_lmh_defer_tail) {
+    g_lmh_last_plan.colpart = partial;
+    g_lmh_last_plan.colrows = nb;
+  } else if (colsum) {
     hipLaunchKernelGGL(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, partial, nb, K, colsum);
+  }
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

@@ -15,6 +15,18 @@ int lmh_sort_u64_impl(uint64_t* keys, int B, int n_pad, hipStream_t st);
 int lmh_nms_impl(const float* boxes, const int32_t* counts, int B, int K, float thr, int max_out,
                  int32_t* keep_idx, int32_t* keep_count, void* ws, hipStream_t st);
 
+// Deferred weight-gradient tails (tail.hip): while lmh_tail_defer(1) is in effect on the calling thread,
+// lmh_conv2d_bwd_weight / lmh_act_bwd launch their main kernel only, leave the split-K slabs / column-sum partial rows
+// where they are and record them here; lmh_wgrad_tail_batch later finishes many layers in two launches.
+struct lmh_tail_plan {
+  const float* slabs;    // [splits][n] partial gradients, or NULL when dw already holds the raw gradient
+  int splits;
+  const float* colpart;  // [colrows][K] partial column sums, or NULL
+  int colrows;
+};
+extern thread_local int g_lmh_defer_tail;
+extern thread_local lmh_tail_plan g_lmh_last_plan;
+
 #define LMH_CHECK_ARG(cond)                                                 \
   do {                                                                      \
     if (!(cond)) {                                                          \

@@ -69,6 +69,69 @@ def _workspace(nbytes, device, tag):
     return ws
 
 
+# ------------------------------------------------------- deferred tails ----
+class TailQueue(object):
+    """Backlog of weight-gradient tails (csrc/tail.hip): while `TAILS.active`, ConvLayer backward passes launch only the
+    MFMA weight-gradient kernel (and the g = dy*act'(y) pass) and queue what is left — split-K reduction, BatchNorm
+    scaling + dgamma, dbeta / dbias — as one descriptor per layer; `flush()` finishes the whole backlog with two
+    launches on the current stream.  The caller flushes after joining every stream that produced gradients and before
+    anything reads them (optimizer, gradient all-reduce).  Entries keep their tensors alive until the flush."""
+
+    def __init__(self):
+        self.active = False
+        self.entries = {}      # layer key -> dict of fields
+        self.order = []
+
+    def begin(self):
+        """Start queueing (drops anything a failed step may have left behind)."""
+        self.entries, self.order = {}, []
+        self.active = True
+
+    def entry(self, key):
+        e = self.entries.get(key)
+        if e is None:
+            e = self.entries[key] = {}
+            self.order.append(key)
+        return e
+
+    def flush(self):
+        if not self.order:
+            return
+        lib = _lib.load()
+        n = len(self.order)
+        arr = (_lib.WgradTail * n)()
+        dev = None
+        for i, key in enumerate(self.order):
+            e = self.entries[key]
+            t = arr[i]
+            dw = e['dw']
+            dev = dw.device
+            t.dw = dw.data_ptr()
+            t.n = dw.numel()
+            t.K = dw.shape[-1]
+            t.slabs, t.splits = e.get('slabs', 0) or 0, e.get('splits', 0)
+            bn = e.get('bn')
+            if bn is not None:
+                t.w, t.scale, t.mean, t.rstd, t.dgamma = (bn[k].data_ptr() for k in ('w', 'scale', 'mean', 'rstd', 'dgamma'))
+            t.colpart, t.colrows = e.get('colpart', 0) or 0, e.get('colrows', 0)
+            cs = e.get('colsum')
+            t.colsum = cs.data_ptr() if cs is not None else 0
+        ws = _workspace(lib.lmh_wgrad_tail_batch_workspace_bytes(arr, n), dev, 'tails')
+        check(lib.lmh_wgrad_tail_batch(arr, n, _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_wgrad_tail_batch')
+        self.entries, self.order = {}, []
+
+
+TAILS = TailQueue()
+
+
+def _last_plan():
+    lib = _lib.load()
+    slabs, colpart = ctypes.c_void_p(), ctypes.c_void_p()
+    splits, colrows = ctypes.c_int(), ctypes.c_int()
+    lib.lmh_tail_last_plan(ctypes.byref(slabs), ctypes.byref(splits), ctypes.byref(colpart), ctypes.byref(colrows))
+    return slabs.value or 0, splits.value, colpart.value or 0, colrows.value
+
+
 # ------------------------------------------------------------- profiling ----
 class _Profile(object):
     """Optional per-launch timing of the convolution MFMA kernels (bench.py roofline leg).  The HIP events are
@@ -274,35 +337,64 @@ def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None, yact=None, xma
     return dx
 
 
-def conv2d_bwd_weight(d, x, dy, out=None, yact=None, colsum=None):
-    """yact: fused g = dy*act'(y); colsum (K,): WRITTEN with the per-channel sums of g."""
+def conv2d_bwd_weight(d, x, dy, out=None, yact=None, colsum=None, defer=None):
+    """yact: fused g = dy*act'(y); colsum (K,): WRITTEN with the per-channel sums of g.
+    defer: layer key — with TAILS.active the split-K reduction (and the last stage of `colsum`) is queued instead of
+    launched; the slabs then live in a workspace of their own (per layer) until TAILS.flush()."""
     lib = _lib.load()
+    defer = defer if (defer is not None and TAILS.active and d.K % 4 == 0 and d.K <= 4096) else None
     if yact is None and WINOGRAD and WINOGRAD_WGRAD and d.compute == 0 and d.R == 3 and \
             d.C * d.K >= WINOGRAD_WGRAD_MIN_CK and winograd_ok(d):
         if colsum is not None:                       # dbeta / dbias: one streaming pass over g
-            act_bwd(dy, None, None, want_g=False, colsum=colsum)
-        return conv2d_bwd_weight_winograd(d, x, dy, out)
+            act_bwd(dy, None, None, want_g=False, colsum=colsum, defer=defer)
+        dw = conv2d_bwd_weight_winograd(d, x, dy, out)
+        if defer is not None:
+            TAILS.entry(defer).update(dw=dw, slabs=0, splits=0)
+        return dw
     dw = out if out is not None else torch.empty((d.R, d.S, d.C, d.K), dtype=torch.float32, device=x.device)
     nbytes = lib.lmh_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
-    ws = _workspace(nbytes, x.device, 'bwd_weight')
-    with _timed(d, 2):
-        check(lib.lmh_conv2d_bwd_weight(ctypes.byref(d), _p(_f32(x)), _p(_f32(dy)), _p(yact), _p(dw), _p(colsum),
-                                        _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_conv2d_bwd_weight')
+    ws = _workspace(nbytes, x.device, 'bwd_weight' if defer is None else ('wgslab', defer))
+    if defer is not None:
+        lib.lmh_tail_defer(1)
+    try:
+        with _timed(d, 2):
+            check(lib.lmh_conv2d_bwd_weight(ctypes.byref(d), _p(_f32(x)), _p(_f32(dy)), _p(yact), _p(dw), _p(colsum),
+                                            _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_conv2d_bwd_weight')
+        if defer is not None:
+            slabs, splits, colpart, colrows = _last_plan()
+            e = TAILS.entry(defer)
+            e.update(dw=dw, slabs=slabs, splits=splits, _ws=ws)
+            if colsum is not None and colrows:
+                e.update(colpart=colpart, colrows=colrows, colsum=colsum)
+    finally:
+        if defer is not None:
+            lib.lmh_tail_defer(0)
     return dw
 
 
-def act_bwd(dy, y, act, want_g=True, colsum=None):
-    """g = dy * act'(y); colsum (K,) is WRITTEN with the per-channel sums of g."""
+def act_bwd(dy, y, act, want_g=True, colsum=None, defer=None):
+    """g = dy * act'(y); colsum (K,) is WRITTEN with the per-channel sums of g (with `defer` + TAILS.active: its
+    last stage is queued; the partial rows wait in a per-layer workspace)."""
     lib = _lib.load()
     K = dy.shape[-1]
     rows = dy.numel() // K
     g = torch.empty_like(dy) if want_g else None
     ws, nbytes = None, 0
+    defer = defer if (defer is not None and colsum is not None and TAILS.active and K % 4 == 0 and K <= 4096) else None
     if colsum is not None:
         nbytes = lib.lmh_act_bwd_workspace_bytes(rows, K)
-        ws = _workspace(nbytes, dy.device, 'colsum')
-    check(lib.lmh_act_bwd(_p(dy), _p(y), ACT[act], rows, K, _p(g), _p(colsum), _p(ws),
-                          ctypes.c_size_t(0 if ws is None else ws.numel()), _stream()), 'lmh_act_bwd')
+        ws = _workspace(nbytes, dy.device, 'colsum' if defer is None else ('colpart', defer))
+    if defer is not None:
+        lib.lmh_tail_defer(1)
+    try:
+        check(lib.lmh_act_bwd(_p(dy), _p(y), ACT[act], rows, K, _p(g), _p(colsum), _p(ws),
+                              ctypes.c_size_t(0 if ws is None else ws.numel()), _stream()), 'lmh_act_bwd')
+        if defer is not None:
+            _, _, colpart, colrows = _last_plan()
+            TAILS.entry(defer).update(colpart=colpart, colrows=colrows, colsum=colsum, _cws=ws)
+    finally:
+        if defer is not None:
+            lib.lmh_tail_defer(0)
     return g
 
 

@@ -121,10 +121,17 @@ class ConvLayer(object):
     def _weight_grads(self, d, x, g, yact, colsum):
         if self.compute_wgrad != 'same':
             d = self.desc(x.shape, wgrad=True)
-        K.conv2d_bwd_weight(d, x, g, out=self.gw, yact=yact, colsum=colsum)
+        key = self.w_name if (K.TAILS.active and self.cout % 4 == 0 and self.cout <= 4096) else None
+        K.conv2d_bwd_weight(d, x, g, out=self.gw, yact=yact, colsum=colsum, defer=key)
         if self.norm == 'bn':
-            K.bn_param_grads(self.w, self.gw, self.bn['gbeta'], self.bn['mean'], self.bn['rstd'],
-                             self.scale, out=self.bn['ggamma'])
+            if key is not None:        # queued: reduction + BN scaling + dgamma + dbeta happen in TAILS.flush()
+                e = K.TAILS.entry(key)
+                e['bn'] = dict(w=self.w, scale=self.scale, mean=self.bn['mean'], rstd=self.bn['rstd'],
+                               dgamma=self.bn['ggamma'])
+                e.setdefault('colsum', self.bn['gbeta'])
+            else:
+                K.bn_param_grads(self.w, self.gw, self.bn['gbeta'], self.bn['mean'], self.bn['rstd'],
+                                 self.scale, out=self.bn['ggamma'])
 
     def _fused_ok(self, d, key):
         ok = self._fused.get(key)
@@ -154,14 +161,15 @@ class ConvLayer(object):
                 colsum = self.gb
         colsum_in_wgrad = colsum is not None and colsum_fused
         yact = None
+        dkey = self.w_name if K.TAILS.active else None
         if dy_is_g or not self.act:
             g = dy
             if colsum is not None and not colsum_in_wgrad:
-                K.act_bwd(dy, None, None, want_g=False, colsum=colsum)
+                K.act_bwd(dy, None, None, want_g=False, colsum=colsum, defer=dkey)
         elif self.act and act_fused and not want_g:
             g, yact = dy, y                               # fused: kernels mask on load
         else:
-            g = K.act_bwd(dy, y, self.act, want_g=True, colsum=None if colsum_in_wgrad else colsum)
+            g = K.act_bwd(dy, y, self.act, want_g=True, colsum=None if colsum_in_wgrad else colsum, defer=dkey)
         inline = self.trainable and 0 < SideStream.layers_left <= SideStream.inline_layers
         if self.trainable:
             SideStream.layers_left -= 1

@@ -223,8 +223,13 @@ class FasterRCNN(object):
         """Gradients of the data loss flow through the HIP backward kernels into the flat
         gradient buffer; the L2 term's gradient (wd*w) is folded into the optimizer kernel."""
         self.store.grad.zero_()
-        total_loss.backward()
-        SideStream.join()      # weight-gradient chain runs on a second stream (models/base/layers.py)
+        K.TAILS.begin()      # split-K reductions / BN parameter gradients are queued, finished in two launches
+        try:
+            total_loss.backward()
+            SideStream.join()      # weight-gradient chain runs on a second stream (models/base/layers.py)
+            K.TAILS.flush()
+        finally:
+            K.TAILS.active = False
 
     # ------------------------------------------------------------ fused step --
     def train_step(self, image, gt_boxes):
@@ -256,6 +261,7 @@ class FasterRCNN(object):
         main = torch.cuda.current_stream(self.device)
         aux = self._aux_stream()
         self.store.grad.zero_()
+        K.TAILS.begin()
         with torch.enable_grad():
             fh, fw = self.base_network.feature_hw(H, W)
             rpn = self._rpn
@@ -308,6 +314,8 @@ class FasterRCNN(object):
             if buckets is not None:
                 buckets.disarm()
         SideStream.join()
+        K.TAILS.flush()          # every weight-gradient tail of the step (RPN, RCNN, trunk) in two launches
+        K.TAILS.active = False
         rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})
         rpn_pred['num_proposals'] = prop['num_proposals']
         self._last_losses = dict(rpn_losses, total_loss=total_loss, no_reg_loss=no_reg_loss,

@@ -194,8 +194,13 @@ class SSD(object):
 
     def backward(self, total_loss):
         self.store.grad.zero_()
-        total_loss.backward()
-        SideStream.join()
+        K.TAILS.begin()      # weight-gradient tails are queued and finished in two launches (csrc/tail.hip)
+        try:
+            total_loss.backward()
+            SideStream.join()
+            K.TAILS.flush()
+        finally:
+            K.TAILS.active = False
 
     # -------------------------------------------------------------- variables --
     @property

@@ -156,6 +156,7 @@ class GradientBuckets(object):
         for st in SideStream._streams.values():       # every weight-gradient chain enqueued so far
             comm.wait_stream(st)
         with torch.cuda.stream(comm):
+            K.TAILS.flush()       # the queued split-K / BatchNorm tails of everything enqueued so far, on the comm stream
             self._works.append(self.reduce_fn(grad[lo:hi]) or _Done())
         self._done.append((lo, hi))
 

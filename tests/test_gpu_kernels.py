@@ -722,3 +722,52 @@ def test_dropout_matches_oracle_mask(K):
         assert abs(mask.mean() - keep) < 0.02
         dy = rs.randn(*x.shape).astype(F)
         np.testing.assert_array_equal(K.dropout(T(dy), keep, seed).cpu().numpy(), np.where(mask, dy * F(1.0 / keep), F(0)))
+
+
+# ------------------------------------------------------- deferred tails ----
+@pytest.mark.parametrize('shape', [(2, 24, 24, 64, 128, 1), (1, 20, 20, 64, 64, 3), (1, 9, 11, 256, 36, 1)])
+def test_deferred_weight_gradient_tails_equal_immediate_path(K, shape, monkeypatch):
+    """csrc/tail.hip: queueing the split-K reduction, BatchNorm scaling + dgamma and dbeta of several layers and
+    finishing them with lmh_wgrad_tail_batch gives the results of the per-layer launches (same slab order: the weight
+    gradient is bit-identical; dgamma / dbeta sum their partial rows in a different tree: 1e-5)."""
+    monkeypatch.setattr(K, 'WINOGRAD', False)
+    N, H, W, C, Kc, R = shape
+    rs = np.random.RandomState(3)
+    x = T(rs.randn(N, H, W, C).astype(F))
+    y = T(rs.randn(N, H, W, Kc).astype(F))
+    dy = T(rs.randn(N, H, W, Kc).astype(F))
+    w = T((rs.randn(R, R, C, Kc) * 0.1).astype(F))
+    scale = T((1 + 0.1 * rs.randn(Kc)).astype(F))
+    mean, rstd = T(rs.randn(Kc).astype(F)), T((1 + 0.1 * rs.rand(Kc)).astype(F))
+    d = K.conv_desc(x.shape, w.shape, 1, 1, 'SAME', 'relu')
+
+    def run(deferred):
+        dw = torch.zeros_like(w)
+        dbeta, dgamma = torch.zeros(Kc, device=dev()), torch.zeros(Kc, device=dev())
+        dw2 = torch.zeros_like(w)                           # a second, bias-only layer in the same batch
+        dbias2 = torch.zeros(Kc, device=dev())
+        if deferred:
+            K.TAILS.begin()
+        try:
+            g = K.act_bwd(dy, y, 'relu', want_g=True, colsum=dbeta, defer='layer_a' if deferred else None)
+            K.conv2d_bwd_weight(d, x, g, out=dw, defer='layer_a' if deferred else None)
+            g2 = K.act_bwd(dy, None, None, want_g=False, colsum=dbias2, defer='layer_b' if deferred else None)
+            assert g2 is None
+            K.conv2d_bwd_weight(d, x, dy, out=dw2, defer='layer_b' if deferred else None)
+            if deferred:
+                K.TAILS.entry('layer_a')['bn'] = dict(w=w, scale=scale, mean=mean, rstd=rstd, dgamma=dgamma)
+                assert len(K.TAILS.order) == 2
+                K.TAILS.flush()
+                assert not K.TAILS.order
+            else:
+                K.bn_param_grads(w, dw, dbeta, mean, rstd, scale, out=dgamma)
+        finally:
+            K.TAILS.active = False
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (dw, dbeta, dgamma, dw2, dbias2)]
+
+    a, b = run(False), run(True)
+    np.testing.assert_array_equal(a[3], b[3])              # plain layer: pure split-K reduction, same order
+    for i, name in enumerate(('dw (BN-scaled)', 'dbeta', 'dgamma', 'dw2', 'dbias2')):
+        sc = max(1.0, float(np.abs(a[i]).max()))
+        np.testing.assert_allclose(b[i], a[i], rtol=1e-5, atol=1e-5 * sc, err_msg=name)
