@@ -100,8 +100,8 @@ void lmh_conv2d_force_config(int bm, int bn, int splits);
 /* Diagnostics: 1x1 weight-gradient kernel variant: 0 automatic, -1 register-staged kernel only, 2..4 LDS ring depth
  * of the direct-to-LDS GEMM kernel (conv_wgrad1x1.h). */
 void lmh_conv2d_force_wgrad_variant(int v);
-/* 1 when lmh_conv2d_bwd_weight(d) can emit `colsum` itself; 0 when the caller should take the per-channel sums of g
- * from lmh_act_bwd (the 1x1 direct-to-LDS path does not stage g through registers). */
+/* 1 when lmh_conv2d_bwd_weight(d) can emit `colsum` itself (fp32 fast paths); 0 when the caller should take the
+ * per-channel sums of g from lmh_act_bwd (generic and half-precision kernels). */
 int lmh_conv2d_bwd_weight_fuses_colsum(const lmh_conv_desc* d);
 /* Per-launch timing (bench.py roofline leg): arms the NEXT lmh_conv2d_* call of this thread — `ev_start` /
  * `ev_stop` (hipEvent_t, e.g. from lmh_event_create) are recorded on the launch stream immediately before / after

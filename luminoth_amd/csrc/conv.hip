@@ -138,6 +138,8 @@ static bool bwd_weight_fast(const lmh_conv_desc* d) { return (d->C & 3) == 0 && 
 // it is rounded to f16 (5 exponent bits: activations gradients of 1e-7 would flush) and the fp32 accumulators by
 // 2^-10 afterwards — exact in fp32.  bf16 has fp32's exponent range and needs none.
 static float half_gscale(const lmh_conv_desc* d) { return d->compute == 1 ? 1024.f : 1.f; }
+// prefetch depth of the half-precision kernels (register sets of staged tiles): 2 by default, LMH_HALF_PF=1 for A/B
+static const int half_pf = env_int("LMH_HALF_PF", 2) == 1 ? 1 : 2;
 // Tile of the half-precision kernels: they are bound by the staging path (bytes per MFMA), not by matrix-pipe rounds, so
 // the largest tile the problem fills wins (128x128 moves half the bytes per FLOP of 64x64) as long as the grid still
 // covers the chip once.
@@ -177,7 +179,8 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
     half_tile(M, d->K, &bm, &bn);
     const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
 #define LAUNCH_FWD_H(DT_, BM_, BN_)                                                                       \
-    hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y)
+    do { if (half_pf == 2) hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 2>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
+         else hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); } while (0)
 #define LAUNCH_FWD_HT(BM_, BN_)                                                                           \
     do { if (d->compute == 1) LAUNCH_FWD_H(1, BM_, BN_); else LAUNCH_FWD_H(2, BM_, BN_); } while (0)
     prof_begin(st);
@@ -234,7 +237,8 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
     const int gridh = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
     const float gs = half_gscale(d);
 #define LAUNCH_BD_H(DT_, BM_, BN_)                                                                        \
-    hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx)
+    do { if (half_pf == 2) hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 2>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); } while (0)
 #define LAUNCH_BD_HT(BM_, BN_)                                                                            \
     do { if (d->compute == 1) LAUNCH_BD_H(1, BM_, BN_); else LAUNCH_BD_H(2, BM_, BN_); } while (0)
     prof_begin(st);
@@ -333,7 +337,7 @@ static void wgrad_1x1_plan(const lmh_conv_desc* d, int* bm, int* bn, int* nbuf, 
 }
 
 extern "C" int lmh_conv2d_bwd_weight_fuses_colsum(const lmh_conv_desc* d) {
-  return d && bwd_weight_fast(d) && !wgrad_1x1_ok(d) && d->compute == 0 ? 1 : 0;
+  return d && bwd_weight_fast(d) && d->compute == 0 ? 1 : 0;
 }
 
 extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
@@ -371,7 +375,7 @@ extern "C" size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d) 
     bwd_weight_plan(d, &bm2, &bn2, &s2, &k2);
     if (s2 > splits) splits = s2;
     const size_t slabs = splits <= 1 ? 256 : lmh_align_up((size_t)splits * d->C * d->K * sizeof(float), 256);
-    return slabs + lmh_align_up((size_t)splits * d->K * sizeof(float), 256);
+    return slabs + lmh_align_up((size_t)splits * BK * d->K * sizeof(float), 256);   // <= splits * 32 partial column rows
   }
   bwd_weight_plan(d, &bm, &bn, &splits, &kps);
   // split-K slabs, then [splits][K] column-sum partials (fused dbeta / dbias)
@@ -398,7 +402,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
   g_prof_pending_bytes = gb ? 4.0 * d->R * d->S * ((double)d->H * d->C + (double)d->H * d->K + (double)d->C * d->K)
                             : desc_bytes(d);
   int bm, bn, splits, kps;
-  if (!gb && !yact && !colsum && wgrad_1x1_ok(d)) {       // pure TN GEMM: direct-to-LDS kernel
+  if (!gb && !yact && wgrad_1x1_ok(d)) {       // pure TN GEMM: direct-to-LDS kernel
     int nbuf;
     wgrad_1x1_plan(d, &bm, &bn, &nbuf, &splits, &kps);
     if (ws_bytes < lmh_conv2d_bwd_weight_workspace_bytes(d) || (splits > 1 && !ws)) {
@@ -408,10 +412,14 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     const int P = d->N * d->OH * d->OW;
     const int tc = (d->C + bm - 1) / bm, tk = (d->K + bn - 1) / bn;
     float* o = splits > 1 ? reinterpret_cast<float*>(ws) : dw;
+    // [splits * min(tc, 32)][K] partial column sums of g behind the slabs (fused dbeta / dbias)
+    const int crows = splits * (tc < BK ? tc : BK);
+    const size_t slab_b = splits > 1 ? lmh_align_up((size_t)splits * d->C * d->K * sizeof(float), 256) : 256;
+    float* cpart1 = colsum ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + slab_b) : nullptr;
     const dim3 grid1(tc * tk * splits);
 #define LAUNCH_WG1(BM_, BN_, NB_)                                                                              \
     hipLaunchKernelGGL((k_wgrad_1x1<BM_, BN_, NB_>), grid1, dim3(256), 0, stream, x, dy, o, P, d->C, d->K, kps, tc, \
-                       tk, splits)
+                       tk, splits, cpart1)
 #define LAUNCH_WG1_T(BM_, BN_)                                                                                 \
     do { if (nbuf == 2) LAUNCH_WG1(BM_, BN_, 2); else if (nbuf == 3) LAUNCH_WG1(BM_, BN_, 3); else LAUNCH_WG1(BM_, BN_, 4); } while (0)
     prof_begin(stream);
@@ -425,11 +433,15 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     if (g_lmh_defer_tail) {
       g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;
       g_lmh_last_plan.splits = splits > 1 ? splits : 0;
-    } else if (splits > 1) {
-      const int64_t n = (int64_t)d->C * d->K;
-      const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
-      hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, stream, reinterpret_cast<const float*>(ws), n,
-                         splits, dw, (const float*)nullptr, (float*)nullptr, d->K, nb_slab);
+      g_lmh_last_plan.colpart = cpart1;
+      g_lmh_last_plan.colrows = cpart1 ? crows : 0;
+    } else if (splits > 1 || colsum) {
+      const int64_t n = splits > 1 ? (int64_t)d->C * d->K : 0;
+      const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;
+      const int nb_col = colsum ? (d->K + 31) / 32 : 0;
+      hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, stream,
+                         reinterpret_cast<const float*>(ws), n, splits, dw, (const float*)cpart1, colsum, d->K, nb_slab,
+                         crows);
     }
     LMH_CHECK_LAUNCH();
     return LMH_OK;
@@ -452,8 +464,10 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     const float gs = half_gscale(d);
     const int nblk = (int)(grid.x * grid.y * grid.z);
 #define LAUNCH_BW_H(DT_, BM_, BN_)                                                                         \
-    hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
-                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z)
+    do { if (half_pf == 2) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+         else hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 1>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z); } while (0)
 #define LAUNCH_BW_HT(BM_, BN_)                                                                             \
     do { if (d->compute == 1) LAUNCH_BW_H(1, BM_, BN_); else LAUNCH_BW_H(2, BM_, BN_); } while (0)
     prof_begin(st);
@@ -471,7 +485,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
       const int64_t n = (int64_t)d->R * d->S * d->C * d->K;
       const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
       hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
-                         splits, dw, (const float*)nullptr, (float*)nullptr, d->K, nb_slab);
+                         splits, dw, (const float*)nullptr, (float*)nullptr, d->K, nb_slab, 0);
     }
     LMH_CHECK_LAUNCH();
     return LMH_OK;
@@ -509,7 +523,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;
     const int nb_col = colsum ? (d->K + 31) / 32 : 0;
     hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, st, reinterpret_cast<const float*>(ws),
-                       n, splits, dw, cpart, colsum, d->K, nb_slab);
+                       n, splits, dw, cpart, colsum, d->K, nb_slab, splits);
   }
   LMH_CHECK_LAUNCH();
   return LMH_OK;

@@ -401,14 +401,14 @@ k_conv_bwd_weight_gen(lmh_conv_desc d, const float* __restrict__ x, const float*
 // columns x 8 split-groups per block with a fixed summation tree
 __global__ void __launch_bounds__(256)
 k_splitk_reduce(const float* __restrict__ part, int64_t n, int splits, float* __restrict__ out,
-                const float* __restrict__ cpart, float* __restrict__ colsum, int K, int nb_slab) {
+                const float* __restrict__ cpart, float* __restrict__ colsum, int K, int nb_slab, int crows) {
   if ((int)blockIdx.x >= nb_slab) {
     __shared__ float red[8][33];
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int c = ((int)blockIdx.x - nb_slab) * 32 + cl;
     float s = 0.f;
     if (c < K)
-      for (int b = g; b < splits; b += 8) s += cpart[(size_t)b * K + c];
+      for (int b = g; b < crows; b += 8) s += cpart[(size_t)b * K + c];
     red[g][cl] = s;
     __syncthreads();
     if (g == 0 && c < K) {

@@ -16,6 +16,7 @@
 //     pipeline is the plain one: global loads of tile t+1 before the MFMAs of tile t, converted and written to the
 //     other LDS buffer after them, one barrier per stage.
 #pragma once
+#include <type_traits>
 #include "conv_fast.h"
 
 #define LDH (BK + 8)   // halfs per LDS row
@@ -82,6 +83,39 @@ __device__ __forceinline__ void mfma_stage_h(const typename HT<DT>::T* __restric
       for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[s][tm], b[s][tn], acc[tm][tn]);
 }
 
+// Software pipeline shared by the three kernels.  The caller defines
+//   load(S)        global -> staging register set S (std::integral_constant<int, 0|1>) at the current pointers
+//   store(buf, S)  register set S -> LDS buffer `buf` (convert / transpose)
+//   step()         advance the pointers to the next tile (no-op past the last tile: loads then re-read a valid tile)
+//   mma(buf)       MFMAs of one stage out of LDS buffer `buf`
+// PF = 1: one register set, tile t+1 is loaded while tile t is multiplied (one MFMA phase = 256 matrix cycles of cover);
+// PF = 2: two register sets, tile t+2 / t+3 are in flight while tile t is multiplied: every load has a whole further
+//         stage (two barriers) to land — the half-precision MFMA phase is 16x shorter than the fp32 one the single-set
+//         schedule of conv_fast.h was built for.
+#define HALF_PIPELINE(PF_, KT_)                                                                     \
+  do {                                                                                              \
+    typedef std::integral_constant<int, 0> S0;                                                      \
+    typedef std::integral_constant<int, 1> S1;                                                      \
+    if constexpr ((PF_) == 1) {                                                                     \
+      load(S0()); store(0, S0()); step(); load(S0());                                               \
+      __syncthreads();                                                                              \
+      for (int kt_ = 0; kt_ < (KT_); ++kt_) {                                                       \
+        mma(kt_ & 1); store((kt_ & 1) ^ 1, S0()); step(); load(S0());                               \
+        __syncthreads();                                                                            \
+      }                                                                                             \
+    } else {                                                                                        \
+      load(S0()); store(0, S0()); step(); load(S0()); step(); load(S1());                           \
+      __syncthreads();                                                                              \
+      for (int kt_ = 0; kt_ < (KT_); kt_ += 2) {                                                    \
+        mma(0); store(1, S0()); step(); load(S0());                                                 \
+        __syncthreads();                                                                            \
+        if (kt_ + 1 >= (KT_)) break;                                                                \
+        mma(1); store(0, S1()); step(); load(S1());                                                 \
+        __syncthreads();                                                                            \
+      }                                                                                             \
+    }                                                                                               \
+  } while (0)
+
 #define HALF_SMEM_FLOATS(BM_, BN_) \
   (((2 * ((BM_) + (BN_)) * LDH + 1) / 2 > (BM_) * ((BN_) + 4)) ? (2 * ((BM_) + (BN_)) * LDH + 1) / 2 : (BM_) * ((BN_) + 4))
 
@@ -89,7 +123,7 @@ __device__ __forceinline__ void mfma_stage_h(const typename HT<DT>::T* __restric
 // forward:  y[p,k] = act( sum_{r,s,c} x[pix(p,r,s),c] * w[r,s,c,k] * scale[k] + shift[k] + res[p,k] )
 //   needs C % 32 == 0, K % 4 == 0.  A: gather (K-contiguous).  B: HWIO rows (K-major) -> transposed in registers.
 // ============================================================================
-template <int DT, int BM, int BN>
+template <int DT, int BM, int BN, int PF>
 __global__ void __launch_bounds__(256)
 k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
              const float* __restrict__ scale, const float* __restrict__ shift,
@@ -141,12 +175,14 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
   const float* pb = b_ok ? w + (size_t)(4 * kq) * K + n0 + 4 * cq : lmh_zero_page;
   const size_t rowb = b_ok ? (size_t)K : 0, incb = b_ok ? (size_t)BK * K : 0;
 
-  f32x4 ra[AJ], rb[4];
+  f32x4 ra[PF][AJ], rb[PF][4];
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  int rs = 0, cc = 0;
+  int rs = 0, cc = 0, ptile = 0;
   setup_rs(0);
-  auto advance = [&]() {
+  auto step = [&]() {
+    if (ptile + 1 >= KT) return;
+    ++ptile;
     if (++cc == CC) { cc = 0; ++rs; setup_rs(rs); }
     else {
 #pragma unroll
@@ -154,34 +190,27 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
     }
     pb += incb;
   };
-  auto load = [&]() {
+  auto load = [&](auto S) {
+    constexpr int s_ = decltype(S)::value;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
+    for (int j = 0; j < AJ; ++j) ra[s_][j] = *reinterpret_cast<const f32x4*>(pa[j]);
     if (b_act) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(pb + i * rowb);
+      for (int i = 0; i < 4; ++i) rb[s_][i] = *reinterpret_cast<const f32x4*>(pb + i * rowb);
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, auto S) {
+    constexpr int s_ = decltype(S)::value;
     HTT* Ad = As + buf * A_SZ;
     HTT* Bd = Bs + buf * B_SZ;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) st_kc<DT>(Ad, arow + 32 * j, kq, ra[j]);
-    if (b_act) st_km<DT>(Bd, 4 * cq, kq, rb);
+    for (int j = 0; j < AJ; ++j) st_kc<DT>(Ad, arow + 32 * j, kq, ra[s_][j]);
+    if (b_act) st_km<DT>(Bd, 4 * cq, kq, rb[s_]);
   };
-  load();
-  store(0);
-  if (KT > 1) advance();
-  load();
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    mfma_stage_h<DT, TM, TN>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
-    store(cur ^ 1);                    // tile kt+1 (harmless duplicate after the last tile)
-    if (kt + 2 < KT) advance();
-    load();                            // tile kt+2 (or a valid re-read)
-    __syncthreads();
-  }
+  auto mma = [&](int buf) {
+    mfma_stage_h<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+  };
+  HALF_PIPELINE(PF, KT);
   // ---- epilogue through LDS (fp32), as k_conv_fwd
   constexpr int CT = BN / 4, RSTEP = 256 / CT;
   const int c4 = tid % CT, r0 = tid / CT;
@@ -210,7 +239,7 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
 // backward data:  dx[p,c] = sum_{r,s,k} dy[opix(p,r,s),k] * kscale[k] * w[r,s,c,k]  (+ addend)
 //   needs K % 32 == 0, C % 4 == 0.  A: dy gather (K-contiguous).  B: w[rs][c][k] rows (K-contiguous).
 // ============================================================================
-template <int DT, int BM, int BN>
+template <int DT, int BM, int BN, int PF>
 __global__ void __launch_bounds__(256)
 k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
                   const float* __restrict__ kscale, const float* __restrict__ addend, float gscale,
@@ -274,12 +303,14 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
   }
   const float* pks = kscale ? kscale + 4 * kq : lmh_zero_page;
   const int incks = kscale ? BK : 0;
-  f32x4 ra[AJ], rb[BJ], ks;
+  f32x4 ra[PF][AJ], rb[PF][BJ], ks[PF];
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  int rs = 0, kc = 0;
+  int rs = 0, kc = 0, ptile = 0;
   setup_rs(0);
-  auto advance = [&]() {
+  auto step = [&]() {
+    if (ptile + 1 >= KT) return;
+    ++ptile;
     if (++kc == KC) {
       kc = 0; ++rs;
       setup_rs(rs);
@@ -294,35 +325,28 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
       pks += incks;
     }
   };
-  auto load = [&]() {
-    ks = *reinterpret_cast<const f32x4*>(pks);
+  auto load = [&](auto S) {
+    constexpr int s_ = decltype(S)::value;
+    ks[s_] = *reinterpret_cast<const f32x4*>(pks);
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j]);
+    for (int j = 0; j < AJ; ++j) ra[s_][j] = *reinterpret_cast<const f32x4*>(pa[j]);
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const f32x4*>(pb[j]);
+    for (int j = 0; j < BJ; ++j) rb[s_][j] = *reinterpret_cast<const f32x4*>(pb[j]);
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, auto S) {
+    constexpr int s_ = decltype(S)::value;
     HTT* Ad = As + buf * A_SZ;
     HTT* Bd = Bs + buf * B_SZ;
-    const f32x4 m = kscale ? ks * gscale : f32x4{gscale, gscale, gscale, gscale};
+    const f32x4 m = kscale ? ks[s_] * gscale : f32x4{gscale, gscale, gscale, gscale};
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) st_kc<DT>(Ad, arow + 32 * j, kq, ra[j] * m);
+    for (int j = 0; j < AJ; ++j) st_kc<DT>(Ad, arow + 32 * j, kq, ra[s_][j] * m);
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) st_kc<DT>(Bd, arow + 32 * j, kq, rb[j]);
+    for (int j = 0; j < BJ; ++j) st_kc<DT>(Bd, arow + 32 * j, kq, rb[s_][j]);
   };
-  load();
-  store(0);
-  if (KT > 1) advance();
-  load();
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    mfma_stage_h<DT, TM, TN>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
-    store(cur ^ 1);
-    if (kt + 2 < KT) advance();
-    load();
-    __syncthreads();
-  }
+  auto mma = [&](int buf) {
+    mfma_stage_h<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+  };
+  HALF_PIPELINE(PF, KT);
   constexpr int CT = BN / 4, RSTEP = 256 / CT;
   const int c4 = tid % CT, r0 = tid / CT;
   const int col = n0 + 4 * c4;
@@ -344,7 +368,7 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
 // backward weight:  dw[rs,c,k] = sum_p x[pix(p,r,s),c] * g[p,k]; reduction split over the pixels (slabs in `out`,
 //   reduced by k_splitk_reduce).  needs C % 4 == 0, K % 4 == 0.  Both operands pixel-major -> register transposes.
 // ============================================================================
-template <int DT, int BM, int BN>
+template <int DT, int BM, int BN, int PF>
 __global__ void __launch_bounds__(256)
 k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ g,
                     float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh,
@@ -376,9 +400,11 @@ k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* _
   const bool a_ok = a_act && (m0 + 4 * cq) < C, b_ok = b_act && (n0 + 4 * cq) < K;
   const float* xb = x + m0 + 4 * cq;
   const float* gb = g + n0 + 4 * cq;
-  int p0 = kt_begin * BK + 4 * kq;       // first of this thread's 4 pixels in the next tile to load
-  f32x4 ra[4], rb[4];
-  auto load = [&]() {
+  int p0 = kt_begin * BK + 4 * kq;       // first of this thread's 4 pixels in the tile the pointers stand on
+  f32x4 ra[PF][4], rb[PF][4];
+  auto step = [&]() { p0 += BK; };       // past the split's end: pixels of the next split or (>= P) the zero page
+  auto load = [&](auto S) {
+    constexpr int s_ = decltype(S)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned p = (unsigned)(p0 + i);
@@ -387,37 +413,30 @@ k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* _
       const int ih = (int)oh * d.stride + dh0, iw = (int)ow * d.stride + dw0;
       const bool oka = a_ok && n < (unsigned)d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
       const float* pa_ = oka ? xb + ((size_t)((int)n * d.H + ih) * d.W + iw) * C : lmh_zero_page;
-      if (a_act) ra[i] = *reinterpret_cast<const f32x4*>(pa_);
+      if (a_act) ra[s_][i] = *reinterpret_cast<const f32x4*>(pa_);
       const bool okb = b_ok && (int)p < P;
       const float* pb_ = okb ? gb + (size_t)p * K : lmh_zero_page;
-      if (b_act) rb[i] = *reinterpret_cast<const f32x4*>(pb_);
+      if (b_act) rb[s_][i] = *reinterpret_cast<const f32x4*>(pb_);
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, auto S) {
+    constexpr int s_ = decltype(S)::value;
     HTT* Ad = As + buf * A_SZ;
     HTT* Bd = Bs + buf * B_SZ;
-    if (a_act) st_km<DT>(Ad, 4 * cq, kq, ra);
+    if (a_act) st_km<DT>(Ad, 4 * cq, kq, ra[s_]);
     if (b_act) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] *= gscale;
-      st_km<DT>(Bd, 4 * cq, kq, rb);
+      for (int i = 0; i < 4; ++i) rb[s_][i] *= gscale;
+      st_km<DT>(Bd, 4 * cq, kq, rb[s_]);
     }
   };
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  load();
-  store(0);
-  p0 += BK;
-  load();
-  __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    mfma_stage_h<DT, TM, TN>(As + cur * A_SZ, Bs + cur * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
-    store(cur ^ 1);       // tile kt+1: past the split's end it is never multiplied
-    p0 += BK;
-    load();               // tile kt+2: rows past P read the zero page
-    __syncthreads();
-  }
+  auto mma = [&](int buf) {
+    mfma_stage_h<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+  };
+  const int n_st = kt_end - kt_begin;
+  HALF_PIPELINE(PF, n_st);
   acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
   __syncthreads();
   float* o = out + (size_t)bz * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;

@@ -25,7 +25,7 @@
 template <int BM, int BN, int NBUF>
 __global__ void __launch_bounds__(256)
 k_wgrad_1x1(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ out, int P, int C, int K,
-            int kt_per_split, int tiles_c, int tiles_k, int splits) {
+            int kt_per_split, int tiles_c, int tiles_k, int splits, float* __restrict__ colpart) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_SZ = BK * BM, B_SZ = BK * BN, STAGE = A_SZ + B_SZ;
   constexpr int A_LPR = BM / 4, B_LPR = BN / 4;            // lanes per tile row (16 B each)
@@ -72,6 +72,14 @@ k_wgrad_1x1(const float* __restrict__ x, const float* __restrict__ g, float* __r
     pa += (size_t)BK * C; pb += (size_t)BK * K; prow += BK;                                               \
   } while (0)
 
+  // Per-channel sums of g (dbeta / dbias) ride along for free: the g tile is in LDS anyway.  Every c-tile block of a
+  // (split, k-tile) sees the same g tile, so the 32 pixel rows of a stage are dealt out over the c-tiles: block `ci`
+  // adds rows ci, ci + CS, ... of its BN columns (thread = column) and writes ONE partial row; the rows are summed by
+  // the reduce / tail kernel in a fixed order.  CS = min(tiles_c, 32) partial rows per split.
+  const int CS = min(tiles_c, BK);
+  const int ci = rem % tiles_c;
+  const bool do_col = colpart != nullptr && ci < CS && tid < BN;
+  float csum = 0.f;
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
 #pragma unroll
@@ -98,11 +106,16 @@ k_wgrad_1x1(const float* __restrict__ x, const float* __restrict__ g, float* __r
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (t + D < n_st) WG_ISSUE(cur == 0 ? NBUF - 1 : cur - 1);     // slot of tile t + D == slot of tile t - 1
     const float* As = smem + cur * STAGE;
+    if (do_col) {
+      const float* Bt = As + A_SZ + tid;
+      for (int k = ci; k < BK; k += CS) csum += Bt[k * BN];
+    }
     mfma_stage_pipelined<TM, TN, false, false, BM, BN>(As, As + A_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
     cur = (cur + 1 == NBUF) ? 0 : cur + 1;
   }
 #undef WG_ISSUE
 
+  if (do_col && (n0 + tid) < K) colpart[(size_t)(bz * CS + ci) * K + n0 + tid] = csum;
   // epilogue: registers -> global; lanes 0..31 of one accumulator register hold 32 consecutive k of one c row
   float* o = out + (size_t)bz * ((size_t)C * K);
   const int l31 = lane & 31, rbase = 4 * (lane >> 5);

@@ -5,6 +5,7 @@
 // oracle/tfops.py).  All kernels are HBM/latency-bound integer + fp32 scalar
 // work: coalesced SoA-free float4 box loads, LDS bitonic sort, 64x64 IoU
 // bit-mask tiles (one u64 word per lane) and a wave-serial greedy reduce.
+#include <stdlib.h>
 #include "lmh_common.h"
 
 // ----------------------------------------------------------------------------
@@ -237,7 +238,7 @@ k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts,
 #define NMS_MAX_W 512  // K <= 32768 candidates
 __global__ void __launch_bounds__(NMS_RED_THREADS)
 k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts, int K, int W,
-             int max_out, int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
+             int max_out, int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count, int dbg) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ __attribute__((aligned(16))) unsigned long long rem[NMS_SC_WORDS];
   __shared__ int s_total;
@@ -261,13 +262,13 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
     uint64_t d[NMS_SC_WORDS];
 #pragma unroll
     for (int j = 0; j < NMS_SC_WORDS; ++j) {
-      const bool ok = row < cnt && j < nw && (w0 + j) >= (row >> 6);
+      const bool ok = row < cnt && j < nw && (w0 + j) >= (row >> 6) && !(dbg & 1);
       d[j] = ok ? mb[(size_t)row * W + w0 + j] : 0ull;
     }
     // (2) removed-words of this super-chunk from every row kept so far (rows < r0: all their words here are valid)
     if (tid < NMS_SC_WORDS) rem[tid] = 0ull;
     __syncthreads();
-    const int nkept = s_total;
+    const int nkept = (dbg & 2) ? 0 : s_total;
     for (int i0 = tid; i0 < nkept * NMS_SC_WORDS; i0 += 4 * NMS_RED_THREADS) {
       uint64_t v[4];
       int wj[4];
@@ -289,6 +290,7 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
     // (3) the chunks of this super-chunk, wave c resolves chunk c
     bool done = false;
     for (int c = 0; c < nw; ++c) {
+      if (dbg & 4) { if (tid == 0 && c == 0) s_total = min(s_total + 16, max_out); __syncthreads(); if (s_total >= max_out) { done = true; break; } continue; }
       if (wave == c) {
         const uint64_t diag = d[c];
         const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
@@ -346,8 +348,9 @@ int lmh_nms_impl(const float* boxes, const int32_t* counts, int B, int K, float 
   dim3 g(W, W, B);
   hipLaunchKernelGGL(k_nms_mask, g, dim3(64), 0, st, reinterpret_cast<const float4*>(boxes), counts,
                      K, W, thr, mask);
+  static const int dbg = getenv("LMH_NMS_DBG") ? atoi(getenv("LMH_NMS_DBG")) : 0;   // timing ablations only (wrong results)
   hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts,
-                     K, W, max_out, keep_idx, keep_count);
+                     K, W, max_out, keep_idx, keep_count, dbg);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

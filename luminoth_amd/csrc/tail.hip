@@ -82,9 +82,16 @@ k_tail_reduce(tail_args a, float* __restrict__ partial) {
 
 // fixed-tree column sum of `nb` partial rows (same tree as elementwise.hip::colsum_partial)
 __device__ __forceinline__ float tail_colsum(const float* __restrict__ p, int nb, int K, int c, int g) {
-  float s = 0.f;
-  for (int b = g; b < nb; b += 8) s += p[(size_t)b * K + c];
-  return s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four independent chains: the loads of a round are in flight together
+  int b = g;
+  for (; b + 24 < nb; b += 32) {
+    s0 += p[(size_t)b * K + c];
+    s1 += p[(size_t)(b + 8) * K + c];
+    s2 += p[(size_t)(b + 16) * K + c];
+    s3 += p[(size_t)(b + 24) * K + c];
+  }
+  for (; b < nb; b += 8) s0 += p[(size_t)b * K + c];
+  return (s0 + s1) + (s2 + s3);
 }
 
 __global__ void __launch_bounds__(256)

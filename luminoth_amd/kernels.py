@@ -310,8 +310,8 @@ def conv_fused_act_ok(d):
 
 
 def conv_fused_colsum_ok(d):
-    """True when bwd_weight of `d` can emit the per-channel sums of its dy operand itself (register-staged fast
-    path); the 1x1 direct-to-LDS kernel cannot, its layers take them from the lmh_act_bwd pass that makes g."""
+    """True when bwd_weight of `d` can emit the per-channel sums of its dy operand itself (fp32 fast paths); other
+    layers take them from the lmh_act_bwd pass that makes g."""
     return bool(_lib.load().lmh_conv2d_bwd_weight_fuses_colsum(ctypes.byref(d)))
 
 

@@ -64,6 +64,20 @@ def resnet_v1_tail_nodes(arch, scope, wd, init):
 VGG16_CFG = [('conv1', 2, 64), ('conv2', 2, 128), ('conv3', 3, 256), ('conv4', 3, 512), ('conv5', 3, 512)]
 
 
+def vgg16_unused_fc_layers(scope, arch, wd, init, num_classes=1000):
+    """slim vgg_16 builds its classifier even when only conv5_3 is consumed (base_network.py:70-75 calls
+    vgg.vgg_16(inputs, is_training, spatial_squeeze) with the default num_classes=1000): fc6 7x7 VALID 4096, fc7 1x1 4096,
+    fc8 1x1 1000.  They are never evaluated for the endpoint, but their weights exist (slim checkpoints carry them)
+    and, created under vgg_arg_scope's weights_regularizer, they are part of regularization_loss (SURVEY.md appendix
+    B.12).  Returned as layers to REGISTER only."""
+    p = '%s/%s' % (scope, arch)
+    out = []
+    for name, k, cin, cout in (('fc6', 7, 512, 4096), ('fc7', 1, 4096, 4096), ('fc8', 1, 4096, num_classes)):
+        out.append(ConvLayer('%s/%s' % (p, name), cin, cout, k, padding='VALID', act='relu' if name != 'fc8' else None,
+                             norm='bias', wd=wd, init=init))
+    return out
+
+
 def vgg16_nodes(scope, arch, wd, init, bias_init, in_sub=None, pool5=False):
     p = '%s/%s' % (scope, arch)
     nodes, endpoints, cin = [], {}, 3

@@ -70,9 +70,11 @@ class TruncatedBaseNetwork(BaseNetwork):
                 raise ValueError('"{}" is an invalid value of endpoint for this architecture.'.format(
                     '%s/%s/%s' % (name, arch, self._endpoint)))
             cut = endpoints[self._endpoint] + 1
-            self._all_nodes = nodes[:cut]        # fc layers are not instantiated (unused, un-regularised here)
+            self._all_nodes = nodes[:cut]
             self.trunk = L.Trunk(nodes[:cut])
             self._unused_nodes = []
+            # full slim vgg_16 (not the SSD 'truncated_vgg_16'): the classifier's variables exist and are regularised
+            self._unused_layers = networks.vgg16_unused_fc_layers(name, arch, wd, he_normal) if self.vgg_type else []
             self.tail = None
             self.feat_channels = self.trunk.nodes[-1].layer.cout
             self.tail_channels = self.feat_channels
@@ -89,7 +91,7 @@ class TruncatedBaseNetwork(BaseNetwork):
 
     # ---- variables --------------------------------------------------------------
     def _creation_order_layers(self):
-        return [l for n in self._all_nodes for l in n.layers]
+        return [l for n in self._all_nodes for l in n.layers] + list(getattr(self, '_unused_layers', []))
 
     def get_trainable_var_names(self):
         """truncated_base_network.py:97-144: fine-tune range cut at the last

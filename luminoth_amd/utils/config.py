@@ -148,7 +148,7 @@ def get_base_config(model_type):
 def get_config(config_files, override_params=None):
     """config_files: path(s) to YAML or dict(s) with the reference's schema."""
     custom = load_config_files(config_files) if config_files else Config()
-    model_type = (custom.get('model') or {}).get('type', 'fasterrcnn')
+    model_type = custom['model']['type']      # KeyError without model.type, like the reference (config.py:16)
     config = get_base_config(model_type)
     config = merge_into(custom, config, overwrite=True)
     if override_params:

@@ -171,3 +171,13 @@ def test_data_parallel_sharding_is_disjoint_and_equal_length(monkeypatch):
         assert len(names) == len(ds) == 3
         seen.append(names)
     assert not set(seen[0]) & set(seen[1])
+
+
+def test_get_config_requires_model_type():
+    """luminoth/utils/config.py:16: `custom_config['model']['type']` — a config without it is a KeyError, not a
+    silently assumed Faster R-CNN (the CLIs turn it into 'model.type should be set on the custom config.')."""
+    import pytest
+    from luminoth_amd.utils.config import get_config
+    with pytest.raises(KeyError):
+        get_config({'train': {'seed': 0}})
+    assert get_config({'model': {'type': 'ssd'}}).model.type == 'ssd'
