@@ -138,8 +138,10 @@ static bool bwd_weight_fast(const lmh_conv_desc* d) { return (d->C & 3) == 0 && 
 // it is rounded to f16 (5 exponent bits: activations gradients of 1e-7 would flush) and the fp32 accumulators by
 // 2^-10 afterwards — exact in fp32.  bf16 has fp32's exponent range and needs none.
 static float half_gscale(const lmh_conv_desc* d) { return d->compute == 1 ? 1024.f : 1.f; }
-// prefetch depth of the half-precision kernels (register sets of staged tiles): 2 by default, LMH_HALF_PF=1 for A/B
-static const int half_pf = env_int("LMH_HALF_PF", 2) == 1 ? 1 : 2;
+// prefetch depth of the half-precision kernels (register sets of staged tiles).  Measured on MI355X (COCO-shape R50
+// step, f16): one set 6.82 ms/step, two sets 8.02 — the second set pushes the 128x128 kernels past 256 VGPRs (one wave
+// per SIMD instead of two), which costs more than the deeper prefetch buys.  LMH_HALF_PF=2 keeps the variant reachable.
+static const int half_pf = env_int("LMH_HALF_PF", 1) == 2 ? 2 : 1;
 // Tile of the half-precision kernels: they are bound by the staging path (bytes per MFMA), not by matrix-pipe rounds, so
 // the largest tile the problem fills wins (128x128 moves half the bytes per FLOP of 64x64) as long as the grid still
 // covers the chip once.
@@ -237,8 +239,7 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
     const int gridh = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
     const float gs = half_gscale(d);
 #define LAUNCH_BD_H(DT_, BM_, BN_)                                                                        \
-    do { if (half_pf == 2) hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 2>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); \
-         else hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); } while (0)
+    hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx)
 #define LAUNCH_BD_HT(BM_, BN_)                                                                            \
     do { if (d->compute == 1) LAUNCH_BD_H(1, BM_, BN_); else LAUNCH_BD_H(2, BM_, BN_); } while (0)
     prof_begin(st);

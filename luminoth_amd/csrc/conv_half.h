@@ -124,7 +124,7 @@ __device__ __forceinline__ void mfma_stage_h(const typename HT<DT>::T* __restric
 //   needs C % 32 == 0, K % 4 == 0.  A: gather (K-contiguous).  B: HWIO rows (K-major) -> transposed in registers.
 // ============================================================================
 template <int DT, int BM, int BN, int PF>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
              const float* __restrict__ scale, const float* __restrict__ shift,
              const float* __restrict__ residual, float* __restrict__ y) {
@@ -240,7 +240,7 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
 //   needs K % 32 == 0, C % 4 == 0.  A: dy gather (K-contiguous).  B: w[rs][c][k] rows (K-contiguous).
 // ============================================================================
 template <int DT, int BM, int BN, int PF>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
                   const float* __restrict__ kscale, const float* __restrict__ addend, float gscale,
                   float* __restrict__ dx) {
@@ -369,7 +369,7 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
 //   reduced by k_splitk_reduce).  needs C % 4 == 0, K % 4 == 0.  Both operands pixel-major -> register transposes.
 // ============================================================================
 template <int DT, int BM, int BN, int PF>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ g,
                     float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh,
                     float gscale, int tiles_x, int tiles_y, int splits) {

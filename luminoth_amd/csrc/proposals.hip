@@ -203,10 +203,11 @@ k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts,
     const float x1 = fminf(v.x, v.z), y1 = fminf(v.y, v.w), x2 = fmaxf(v.x, v.z), y2 = fmaxf(v.y, v.w);
     const float area_r = (y2 - y1) * (x2 - x1);
     if (area_r > 0.f) {
-      const int jstart = (cb == rb) ? lane + 1 : 0;
-      for (int j = jstart; j < 64; ++j) {
+      // diagonal tiles carry both triangles (IoU is symmetric; self excluded): lane i of k_nms_reduce then reads
+      // "who suppresses me" (bits j < i) and "whom I suppress" (bits j > i) from the same word
+      for (int j = 0; j < 64; ++j) {
         const float area_c = carea[j];
-        if (!(area_c > 0.f)) continue;
+        if (!(area_c > 0.f) || (cb == rb && j == lane)) continue;
         const float4 c = cbox[j];
         const float iy1 = fmaxf(y1, c.y), ix1 = fmaxf(x1, c.x);
         const float iy2 = fminf(y2, c.w), ix2 = fminf(x2, c.z);
@@ -290,30 +291,31 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
     // (3) the chunks of this super-chunk, wave c resolves chunk c
     bool done = false;
     for (int c = 0; c < nw; ++c) {
-      if (dbg & 4) { if (tid == 0 && c == 0) s_total = min(s_total + 16, max_out); __syncthreads(); if (s_total >= max_out) { done = true; break; } continue; }
       if (wave == c) {
         const uint64_t diag = d[c];
-        const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
         const int nin = min(64, cnt - (w0 + c) * 64);
         uint64_t alive_v = ~rem[c];
         if (nin < 64) alive_v &= ((1ull << nin) - 1ull);
-        // The greedy scan is one dependent chain per kept candidate: keep ALL of its state wave-uniform (readfirstlane
-        // -> SGPRs) so that the loop is s_ff1 / s_bitset / s_andn2 on the scalar unit plus two v_readlane; with the state
-        // in VGPRs the same loop ran ~430 cycles per kept box (2000 keeps = 360 us), the whole kernel.
-        uint64_t alive = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(alive_v >> 32)) << 32) |
-                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)alive_v);
-        uint64_t kept = 0;
-        const int base = __builtin_amdgcn_readfirstlane(s_total);
-        int total = base;
-        while (alive && total < max_out) {
-          const int j = __builtin_ctzll(alive);
-          kept |= (1ull << j);
-          ++total;
-          // readlane returns a signed int: go through uint32_t or bit 31 sign-extends into the high word
-          const uint64_t dj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
-                              (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dlo, j);
-          alive &= ~(dj | (1ull << j));
+        // Greedy NMS inside the chunk as a parallel fixed point instead of a 64-step serial scan (a dependent chain
+        // of ~200 cycles per kept box on one wave: 2000 keeps = the whole 360 us of round 1's kernel).  Candidate i is
+        // kept  <=>  it is alive and no KEPT candidate j < i suppresses it.  With the symmetric diagonal word (bit j of
+        // lane i = IoU(i, j) > thr) that is local to lane i once the kept set K is known:
+        //     K_0 = alive;   K_{t+1} = { i alive : (diag_i & below_i & K_t) == 0 }
+        // Bits only depend on lower bits, so K_t is exact on the first t levels of the suppression chains and the
+        // iteration reaches the greedy answer in (longest chain + 1) ballots — typically 2-4, never more than 64.
+        const uint64_t below = (1ull << lane) - 1ull;
+        const bool me_alive = (alive_v >> lane) & 1ull;
+        uint64_t kept = __ballot(me_alive);
+        for (int it = 0; it < 64; ++it) {
+          const uint64_t next = __ballot(me_alive && (diag & below & kept) == 0ull);
+          if (next == kept) break;
+          kept = next;
         }
+        const int base = __builtin_amdgcn_readfirstlane(s_total);
+        const int room = max_out - base;
+        if (__popcll(kept) > room)                      // the scan stops at max_out: keep the first `room` of them
+          kept = __ballot(((kept >> lane) & 1ull) && __popcll(kept & below) < room);
+        const int total = base + __popcll(kept);
         if ((kept >> lane) & 1ull) {
           const int slot = base + __popcll(kept & ((1ull << lane) - 1ull));
           kidx[slot] = (w0 + c) * 64 + lane;              // kept indices, in order

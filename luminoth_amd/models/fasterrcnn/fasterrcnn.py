@@ -281,6 +281,7 @@ class FasterRCNN(object):
             with torch.cuda.stream(aux):
                 prop = rpn._proposal(rpn_pred['rpn_cls_score'].detach(), rpn_pred['rpn_bbox_pred'].detach(),
                                      self._anchor_ref_i32, (fh, fw), self._anchor_stride, im_shape)
+                rcnn_tgt = self._rcnn.targets(prop['proposals'], prop['num_proposals'], gt, gt_count, seeds)
             for t in (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred'], feat):
                 K.keep_alive(t, aux)
             # ---- main stream: RPN targets -> RPN loss -> RPN backward
@@ -291,7 +292,7 @@ class FasterRCNN(object):
             # ---- aux stream: RCNN forward -> RCNN loss -> RCNN backward
             with torch.cuda.stream(aux):
                 cp = self._rcnn(f_rcnn, prop['proposals'], prop['num_proposals'], im_shape, self.base_network,
-                                gt_boxes=gt, gt_count=gt_count, seeds=seeds, is_training=True)
+                                gt_boxes=gt, gt_count=gt_count, seeds=seeds, is_training=True, targets=rcnn_tgt)
                 rcnn_losses = self._rcnn.loss(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
                 (rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).backward()
             # ---- join, trunk backward

@@ -79,12 +79,17 @@ class RCNN(object):
         y = A.conv(layer, x2d.reshape(1, 1, x2d.shape[0], x2d.shape[1]), self._anchor)
         return y.reshape(x2d.shape[0], layer.cout)
 
+    def targets(self, proposals, prop_count, gt_boxes, gt_count, seeds):
+        """RCNNTarget alone (rcnn.py:139-154): the fused train step enqueues it right behind the proposal chain,
+        before the host turns to the RPN branch, so the auxiliary stream does not wait for the interpreter."""
+        return self._rcnn_target(proposals, prop_count, gt_boxes, gt_count, seeds)
+
     def __call__(self, conv_feature_map, proposals, prop_count, im_shape, base_network, gt_boxes=None,
-                 gt_count=None, seeds=None, is_training=False):
+                 gt_count=None, seeds=None, is_training=False, targets=None):
         B = conv_feature_map.shape[0]
         pred = {'_debug': {}}
         if gt_boxes is not None:
-            tgt = self._rcnn_target(proposals, prop_count, gt_boxes, gt_count, seeds)
+            tgt = targets if targets is not None else self._rcnn_target(proposals, prop_count, gt_boxes, gt_count, seeds)
             if is_training:
                 # rcnn.py:156-167 keeps only proposals with label >= 0 (<= minibatch_size per image)
                 proposals, prop_count = tgt['rois'], tgt['roi_count']

@@ -1,44 +1,69 @@
-"""profiles/<round>_bench_summary.md + <round>_bench_kernel_stats.csv from a rocprofv3 --kernel-trace --stats run of
-bench.py (scripts/gpu_prof.sh).  usage: python scripts/make_profile_summary.py gpurun_out/prof_<tag> r01 [steps]"""
+"""profiles/<tag>_summary.md + <tag>_kernel_stats.csv from a rocprofv3 --kernel-trace --stats run of bench.py.
+
+usage: python scripts/make_profile_summary.py gpurun_out/prof_<x> <tag> "<bench command>" [timed_steps]
+
+Per-step figures are computed from the kernel TRACE, over the timed steps only: a step ends with its optimizer
+launch (k_sgd_momentum / k_optimizer), and only the dispatches between the optimizer launches of the last
+`timed_steps` steps are counted — model construction, weight upload (the `__amd_rocclr_copyBuffer` storm of round 1's
+table) and warm-up steps are excluded, so "calls/step" and "us/step" are what one steady-state step does.
+The raw rocprofv3 stats CSV is copied next to the summary unchanged."""
 import csv
 import io
 import os
 import shutil
 import subprocess
 import sys
+from collections import defaultdict
 
-src, rnd = sys.argv[1], sys.argv[2]
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+src, tag, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+timed = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 stats = [f for f in os.listdir(src) if f.endswith('kernel_stats.csv')][0]
 trace = [f for f in os.listdir(src) if f.endswith('kernel_trace.csv')][0]
-dst_csv = os.path.join(root, 'profiles', '%s_bench_kernel_stats.csv' % rnd)
+dst_csv = os.path.join(root, 'profiles', '%s_kernel_stats.csv' % tag)
 shutil.copy(os.path.join(src, stats), dst_csv)
-rows = list(csv.DictReader(open(dst_csv)))
-total = sum(float(r['TotalDurationNs']) for r in rows)
+
+
+def short(name):
+    name = name.replace('void ', '')
+    i = name.find('(')
+    return name[:i] if i > 0 else name
+
+
+rows = []
+with open(os.path.join(src, trace)) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])))
+rows.sort()
+ends = [i for i, r in enumerate(rows) if 'k_sgd_momentum' in r[2] or 'k_optimizer' in r[2]]
+if len(ends) < timed + 1:
+    raise SystemExit('trace holds %d optimizer launches, need %d' % (len(ends), timed + 1))
+lo, hi = ends[-timed - 1] + 1, ends[-1] + 1
+win = rows[lo:hi]
+wall = (win[-1][1] - rows[ends[-timed - 1]][1]) / timed
+agg = defaultdict(lambda: [0, 0])
+for s, e, n in win:
+    agg[n][0] += e - s
+    agg[n][1] += 1
+total = sum(v[0] for v in agg.values())
 out = io.StringIO()
-out.write('# Round %s — rocprofv3 --kernel-trace --stats of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline '
-          '--no-roofline`\n\n' % rnd[1:].lstrip('0'))
-out.write('MI355X, Faster R-CNN ResNet-50, batch 2 x 1024x1024, fp32; %d train steps in the trace (2 warm-up + 5 timed).\n'
-          'Source: `%s` (copied next to this file as `%s`).\n\n' % (steps, os.path.join(src, stats), os.path.basename(dst_csv)))
-out.write('Sum of kernel durations per step: %.2f ms over three concurrent HIP streams (wall-clock per step is the '
-          '`ms_per_step` of the bench line; durations of kernels that share the GPU with another stream include the '
-          'slow-down from sharing).\n\n' % (total / steps / 1e6))
+out.write('# %s — rocprofv3 --kernel-trace --stats of `%s`\n\n' % (tag, cmd))
+out.write('MI355X.  Per-step figures over the LAST %d steps of the trace (dispatches between optimizer launches; model '
+          'load and warm-up excluded).  Raw rocprofv3 stats of the whole process: `%s`.\n\n'
+          % (timed, os.path.relpath(dst_csv, root)))
+out.write('Step (optimizer launch to optimizer launch, under the profiler): **%.3f ms**, %.0f kernel launches/step, sum '
+          'of kernel durations %.2f ms/step (streams overlap; durations of kernels that share the GPU include the '
+          'slow-down from sharing).\n\n' % (wall / 1e6, len(win) / float(timed), total / timed / 1e6))
 out.write('| kernel | calls/step | us/step | avg us | % |\n|---|---|---|---|---|\n')
-for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:32]:
-    name = r['Name'].replace('void ', '').split('(')[0]
-    if len(name) > 70:
-        name = name[:67] + '...'
-    calls = float(r['Calls']) / steps
-    t = float(r['TotalDurationNs'])
-    out.write('| `%s` | %.1f | %.1f | %.1f | %.2f |\n' % (name, calls, t / steps / 1e3, t / float(r['Calls']) / 1e3,
-                                                      100.0 * t / total))
+for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:36]:
+    nm = n if len(n) <= 70 else n[:67] + '...'
+    out.write('| `%s` | %.1f | %.1f | %.1f | %.2f |\n' % (nm, c / float(timed), t / timed / 1e3, t / c / 1e3, 100.0 * t / total))
 tl = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'timeline.py'), os.path.join(src, trace)],
                     capture_output=True, text=True).stdout
 out.write('\n## Last step by HIP queue (scripts/timeline.py)\n\n```\n%s```\n' % tl)
-out.write('\nqueue 1 = main stream (forward, RPN loss + data gradients, trunk data gradients, update); the queue with the '
-          'proposal / RCNN chain is the auxiliary stream; the queue carrying `k_conv_bwd_weight` is the weight-gradient '
-          'side stream.  Gaps listed under the profiler are partly host-side (rocprofv3 slows the launch path: the '
-          'un-profiled step is ~0.4 ms shorter).\n')
-open(os.path.join(root, 'profiles', '%s_bench_summary.md' % rnd), 'w').write(out.getvalue())
-print(out.getvalue()[:1500])
+out.write('\nThe queue with the convolution forward kernels is the main stream (forward, RPN loss + data gradients, trunk '
+          'data gradients, update); the queue with the proposal / RCNN chain is the auxiliary stream; the queue carrying the '
+          'weight-gradient kernels is the side stream.  rocprofv3 slows the launch path: the un-profiled step is shorter '
+          '(bench line next to this file).\n')
+open(os.path.join(root, 'profiles', '%s_summary.md' % tag), 'w').write(out.getvalue())
+print(out.getvalue()[:2500])
