@@ -186,10 +186,11 @@ def main():
     ap.add_argument('--serial', action='store_true',
                     help='run EVERY step on one stream (the schedule of the roofline profiling steps): the command '
                          'the rocprofv3 summaries under profiles/*_serial_* are taken from')
-    ap.add_argument('--graph', action='store_true',
-                    help='replay the captured HIP graph of the step instead of enqueuing every kernel from Python '
-                         '(measured SLOWER on ROCm 7.2: 14.2 vs 8.9 ms/step — the graph executor serialises the three '
-                         'captured streams; kept for re-measurement on newer runtimes)')
+    ap.add_argument('--phases', type=int, default=0, metavar='N',
+                    help='after the timed steps, run N more with HIP-event marks and report the mean un-profiled timeline '
+                         'of the three streams ("phases" in the JSON line; Faster R-CNN workloads)')
+    ap.add_argument('--no-lookahead', action='store_true',
+                    help='do not tell the step which batch comes next (no cross-step prefetch of the frozen trunk prefix)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=5)
@@ -238,6 +239,10 @@ def main():
     sd0 = model.state_dict() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     opt = T.get_optimizer(cfg.train, model)
     images, gts = inputs(wl, 100 + rank, device)
+    # a second synthetic batch: steps alternate between the two like a data loader handing over batch after batch, and
+    # each step is told which batch comes next (the look-ahead luminoth_amd.train.run gives the model)
+    batches = [(images, gts), inputs(wl, 1000 + rank, device)]
+    counter = [0]
 
     def serialise(on):
         T.FUSED_STEP = not on
@@ -249,22 +254,17 @@ def main():
         torch.cuda.synchronize()
 
     serialise(args.serial)
-    step_fn = lambda: T.train_step(model, opt, images, gts)        # noqa: E731
-    schedule = 'eager (one Python enqueue per kernel)'
+    def step_fn():
+        i = counter[0]
+        counter[0] += 1
+        cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+        return T.train_step(model, opt, cur[0], cur[1], next_image=None if args.no_lookahead else nxt[0])
+
+    schedule = 'eager, three streams' + ('' if args.no_lookahead or args.serial else
+                                        '; the frozen trunk prefix (conv1 + block1) of the NEXT batch is computed while the '
+                                        'main stream waits for the RCNN branch (one prefix per step, every step)')
     for _ in range(args.warmup):
         step_fn()
-    if args.graph and not args.serial and T.GraphedTrainStep.supported(model, opt, cfg.train):
-        # same kernels and arithmetic, replayed from ONE captured HIP graph (all three streams): the GPU front end no
-        # longer waits for the interpreter where the proposal / RCNN branch forks
-        try:
-            graphed = T.GraphedTrainStep(model, opt, images, gts)
-            step_fn = lambda: graphed()                           # noqa: E731
-            schedule = 'hip-graph replay of the captured step'
-            for _ in range(2):
-                step_fn()
-        except Exception as e:                                    # capture is an optimisation, never a requirement
-            sys.stderr.write('bench.py: HIP-graph capture failed (%r); timing the eager step\n' % (e,))
-            model._seed_override = None
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -277,6 +277,13 @@ def main():
         dt = float(t[0])
     loss_val = float(total.detach())
     assert np.isfinite(loss_val), 'train step diverged (loss %r)' % loss_val
+
+    phases = None
+    if args.phases > 0 and hasattr(model, 'record_phases') and not args.serial:
+        model.record_phases(args.phases)
+        for _ in range(args.phases):
+            step_fn()
+        phases = {k: round(v, 3) for k, v in sorted(model.phase_times().items(), key=lambda kv: kv[1])}
 
     roofline = None
     nprof = min(args.steps, 3)
@@ -345,6 +352,8 @@ def main():
                        'schedule': schedule},
             'roofline': roofline,
         }
+        if phases:
+            out['phases_ms'] = phases
         if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
             cb = cpu_baseline(wl, sd0, args.cpu_steps)
             if cb is not None:

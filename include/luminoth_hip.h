@@ -287,6 +287,19 @@ int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const float* rois
                      const int32_t* roi_count, int B, int R, int FH, int FW, int C, float im_h,
                      float im_w, int ph, int pw, float* dfeat, void* ws, size_t ws_bytes,
                      lmh_stream_t stream);
+/* ROI pooling fused with tf.reduce_mean(pooled, [1, 2]) (rcnn.py:185-188, `use_mean` with no pooled tail between:
+ * ResNet-50 / VGG configurations): mean (B*R, C) is what lmh_roi_pool_fwd + lmh_spatial_mean_fwd return, bit for
+ * bit, without the (B*R, ph, pw, C) intermediate; the backward takes dmean (B*R, C).  The feature map of one image
+ * has to fit the kernels' LDS slabs (FH*FW <= 5120 at C % 8 == 0): ask lmh_roi_pool_mean_supported first, the
+ * unfused pair is the general path (LMH_ERR_UNSUPPORTED otherwise).  Workspace of the backward:
+ * lmh_roi_pool_bwd_workspace_bytes. */
+int lmh_roi_pool_mean_supported(int FH, int FW, int C);
+int lmh_roi_pool_mean_fwd(const float* feat, const float* rois, const int32_t* roi_count, int B, int R, int FH,
+                          int FW, int C, float im_h, float im_w, int ph, int pw, float* mean, uint8_t* argmax,
+                          lmh_stream_t stream);
+int lmh_roi_pool_mean_bwd(const float* dmean, const uint8_t* argmax, const float* rois, const int32_t* roi_count,
+                          int B, int R, int FH, int FW, int C, float im_h, float im_w, int ph, int pw, float* dfeat,
+                          void* ws, size_t ws_bytes, lmh_stream_t stream);
 /* tf.reduce_mean(features, [1,2]) (rcnn.py:185-188): x (M,S,C) -> y (M,C). */
 int lmh_spatial_mean_fwd(const float* x, int64_t M, int S, int C, float* y, lmh_stream_t stream);
 int lmh_spatial_mean_bwd(const float* dy, int64_t M, int S, int C, float* dx, lmh_stream_t stream);

@@ -122,6 +122,9 @@ SIGNATURES = {
     'lmh_roi_pool_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_f]),
     'lmh_roi_pool_bwd_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'lmh_roi_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_sz, c_f]),
+    'lmh_roi_pool_mean_supported': (c_i, [c_i, c_i, c_i]),
+    'lmh_roi_pool_mean_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_f]),
+    'lmh_roi_pool_mean_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_sz, c_f]),
     'lmh_spatial_mean_fwd': (c_i, [c_f, c_i64, c_i, c_i, c_f, c_f]),
     'lmh_spatial_mean_bwd': (c_i, [c_f, c_i64, c_i, c_i, c_f, c_f]),
     'lmh_rpn_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),

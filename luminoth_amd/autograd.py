@@ -53,6 +53,25 @@ class RoiPoolFn(torch.autograd.Function):
         return dfeat, None, None, None, None, None
 
 
+class RoiPoolMeanFn(torch.autograd.Function):
+    """ROIPoolingLayer followed directly by tf.reduce_mean(pooled, [1, 2]) (roi_pool.py:68-95 + rcnn.py:185-188)."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, roi_count, im_shape, ph, pw):
+        feat = feat.contiguous()
+        mean, argmax = K.roi_pool_mean_fwd(feat, rois, roi_count, im_shape, ph, pw)
+        ctx.save_for_backward(argmax, rois, roi_count)
+        ctx.meta = (tuple(feat.shape), im_shape, ph, pw)
+        return mean
+
+    @staticmethod
+    def backward(ctx, dmean):
+        argmax, rois, roi_count = ctx.saved_tensors
+        shape, im_shape, ph, pw = ctx.meta
+        dfeat = K.roi_pool_mean_bwd(dmean.contiguous(), argmax, rois, roi_count, shape, im_shape, ph, pw)
+        return dfeat, None, None, None, None, None
+
+
 class SpatialMeanFn(torch.autograd.Function):
     """tf.reduce_mean(features, [1, 2]) (rcnn.py:185-188)."""
 

@@ -226,13 +226,22 @@ __device__ __forceinline__ void roi_fx_add(unsigned long long* cell, float v) {
   atomicAdd(cell, (unsigned long long)(long long)__float2ll_rn(v * ROI_FX_SCALE));
 }
 
-template <int CS>
+// Channel slabs that share a 128-byte line of the NHWC feature map are given to blocks of the SAME XCD (ids 8 apart
+// round-robin over the XCDs), so the 32-byte pieces they read / write meet in that XCD's L2.
+__device__ __forceinline__ int roi_slab_of_block(int id, int nslabs) {
+  const int per = nslabs >> 3;
+  return (nslabs & 7) ? id : (id & 7) * per + (id >> 3);
+}
+
+// MEAN: the pooled ROIs were reduced by tf.reduce_mean over the cells (rcnn.py:185-188 use_mean) — the incoming
+// gradient is dy[roi][c] / cells for every cell, read from the (roi, c) tensor instead of a 49x larger broadcast.
+template <int CS, bool MEAN>
 __global__ void __launch_bounds__(1024)
 k_roi_pool_bwd_slab(const float* __restrict__ dout, const uint8_t* __restrict__ argmax,
                     const roi_sample_rec* __restrict__ table, const int32_t* __restrict__ roi_count, int R,
                     int FH, int FW, int C, int cells, float* __restrict__ dfeat) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long slab[];   // [npix][CS] fixed point
-  const int b = blockIdx.y, c0 = blockIdx.x * CS;
+  const int b = blockIdx.y, c0 = roi_slab_of_block(blockIdx.x, gridDim.x) * CS;
   const int npix = FH * FW;
   for (int i = threadIdx.x; i < npix * CS; i += 1024) slab[i] = 0ull;
   __syncthreads();
@@ -242,7 +251,7 @@ k_roi_pool_bwd_slab(const float* __restrict__ dout, const uint8_t* __restrict__ 
   for (int pair = threadIdx.x / CS; pair < pairs; pair += 1024 / CS) {
     const size_t gp = (size_t)b * R * cells + pair;
     const size_t o = gp * C + c0 + cc;
-    const float go = dout[o];
+    const float go = MEAN ? dout[((size_t)b * R + pair / cells) * C + c0 + cc] / (float)cells : dout[o];
     const int q = argmax[o] & 3;
     const roi_sample_rec s = table[gp * 4 + q];
     if (s.top < 0 || go == 0.f) continue;
@@ -271,6 +280,31 @@ extern "C" size_t lmh_roi_pool_bwd_workspace_bytes(int B, int R, int ph, int pw)
   return lmh_align_up((size_t)B * R * ph * pw * 4 * sizeof(roi_sample_rec), 256);
 }
 
+template <int CS, bool MEAN>
+static int roi_bwd_slab_launch(const float* dout, const uint8_t* argmax, const roi_sample_rec* table,
+                               const int32_t* roi_count, int B, int R, int FH, int FW, int C, int cells, float* dfeat,
+                               hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<CS, MEAN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_roi_pool_bwd_slab<CS, MEAN>), dim3(C / CS, B), dim3(1024),
+                     (size_t)FH * FW * CS * sizeof(unsigned long long), st, dout, argmax, table, roi_count, R, FH, FW, C,
+                     cells, dfeat);
+  return LMH_OK;
+}
+
+static int roi_slab_width(int FH, int FW, int C) {      // channels per LDS slab of the backward; 0: does not fit
+  const size_t npix = (size_t)FH * FW, lds_cap = 160 * 1024;
+  static const int force_cs = getenv("LMH_ROI_CS") ? atoi(getenv("LMH_ROI_CS")) : 0;   // diagnostics
+  if (FH >= 32768 || FW >= 32768) return 0;
+  if (force_cs != 4 && (C % 8) == 0 && npix * 8 * sizeof(unsigned long long) <= lds_cap) return 8;
+  if ((C % 4) == 0 && npix * 4 * sizeof(unsigned long long) <= lds_cap) return 4;
+  return 0;
+}
+
 // dfeat is OVERWRITTEN (it does not need to be zeroed by the caller).
 extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const float* rois,
                                 const int32_t* roi_count, int B, int R, int FH, int FW, int C,
@@ -280,11 +314,8 @@ extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const 
   LMH_CHECK_ARG(B > 0 && R > 0 && FH > 0 && FW > 0 && C > 0 && ph > 0 && pw > 0);
   hipStream_t st = (hipStream_t)stream;
   const size_t npix = (size_t)FH * FW;
-  const size_t lds_cap = 160 * 1024;
-  static const int force_cs = getenv("LMH_ROI_CS") ? atoi(getenv("LMH_ROI_CS")) : 0;   // diagnostics
-  const bool slab8 = force_cs != 4 && (C % 8) == 0 && npix * 8 * sizeof(unsigned long long) <= lds_cap;
-  const bool slab4 = (C % 4) == 0 && npix * 4 * sizeof(unsigned long long) <= lds_cap;
-  if ((slab8 || slab4) && FH < 32768 && FW < 32768) {
+  const int cs = roi_slab_width(FH, FW, C);
+  if (cs) {
     if (!ws || ws_bytes < lmh_roi_pool_bwd_workspace_bytes(B, R, ph, pw)) {
       lmh_set_error("lmh_roi_pool_bwd: workspace too small");
       return LMH_ERR_WORKSPACE;
@@ -293,31 +324,152 @@ extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const 
     const int cells = ph * pw;
     hipLaunchKernelGGL(k_roi_sample_table, dim3((B * R * cells + 255) / 256), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(rois), roi_count, B, R, FH, FW, im_h, im_w, ph, pw, table);
-    if (slab8) {
-      static bool attr8 = false;
-      if (!attr8) {
-        LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<8>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-        attr8 = true;
-      }
-      hipLaunchKernelGGL((k_roi_pool_bwd_slab<8>), dim3(C / 8, B), dim3(1024), npix * 8 * sizeof(unsigned long long), st, dout,
-                         argmax, table, roi_count, R, FH, FW, C, cells, dfeat);
-    } else {
-      static bool attr4 = false;
-      if (!attr4) {
-        LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<4>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-        attr4 = true;
-      }
-      hipLaunchKernelGGL((k_roi_pool_bwd_slab<4>), dim3(C / 4, B), dim3(1024), npix * 4 * sizeof(unsigned long long), st, dout,
-                         argmax, table, roi_count, R, FH, FW, C, cells, dfeat);
-    }
+    const int rc = cs == 8 ? roi_bwd_slab_launch<8, false>(dout, argmax, table, roi_count, B, R, FH, FW, C, cells, dfeat, st)
+                           : roi_bwd_slab_launch<4, false>(dout, argmax, table, roi_count, B, R, FH, FW, C, cells, dfeat, st);
+    if (rc != LMH_OK) return rc;
   } else {   // very large feature maps: global scatter-add
     LMH_CHECK_HIP(hipMemsetAsync(dfeat, 0, (size_t)B * npix * C * sizeof(float), st));
     const int threads = C < 256 ? ((C + 63) / 64 * 64) : 256;
     hipLaunchKernelGGL(k_roi_pool_bwd, dim3(ph * pw, B * R), dim3(threads), 0, st, dout, argmax,
                        reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, dfeat);
   }
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+// ---- ROI pooling fused with the spatial mean (rcnn.py:185-188, use_mean without a pooled tail) ----------------
+// When the RCNN head averages the pooled cells straight away (ResNet-50 / VGG configurations), the (B*R, ph, pw, C)
+// pooled tensor (51 MB at R=256, C=1024) only exists to be reduced 49:1 — and its gradient is a 49-fold broadcast.
+// k_roi_pool_mean_fwd never writes it: a 1024-thread block stages CS channels of one image's whole feature map in
+// LDS ([pixel][CS] floats, 128 KiB at 64x64x8) with one coalesced pass, then a thread is one (ROI, channel): it walks
+// the ph*pw cells in order, evaluates the four bilinear samples of each from LDS (same arithmetic as k_roi_pool_fwd,
+// bit for bit), keeps the 2-bit arg-max for the backward and accumulates the cell maxima sequentially — the order
+// k_spatial_mean_fwd uses.  HBM traffic: the feature map once (33.5 MB) + arg-max bytes (12.8 MB) + the means (2 MB),
+// instead of ~485 MB of corner gathers that depend on L2 hit rates — which is what made the gather kernel 3x slower
+// whenever the convolution streams were thrashing the L2 next to it.
+template <int CS>
+__global__ void __launch_bounds__(1024)
+k_roi_pool_mean_fwd(const float* __restrict__ feat, const float4* __restrict__ rois,
+                    const int32_t* __restrict__ roi_count, int R, int FH, int FW, int C, float im_h, float im_w,
+                    int ph, int pw, float* __restrict__ mean, uint8_t* __restrict__ argmax) {
+  extern __shared__ __attribute__((aligned(16))) float fslab[];      // [npix][CS]
+  const int b = blockIdx.y, c0 = roi_slab_of_block(blockIdx.x, gridDim.x) * CS;
+  const int npix = FH * FW;
+  const float* fb = feat + (size_t)b * npix * C + c0;
+  for (int i = threadIdx.x; i < npix * CS / 4; i += 1024) {
+    const int pix = i / (CS / 4), part = i - pix * (CS / 4);
+    *reinterpret_cast<float4*>(fslab + (size_t)pix * CS + 4 * part) =
+        *reinterpret_cast<const float4*>(fb + (size_t)pix * C + 4 * part);
+  }
+  __syncthreads();
+  const int nroi = min(roi_count[b], R);
+  const int cells = ph * pw, ch = 2 * ph, cw = 2 * pw;
+  const int cc = threadIdx.x % CS;
+  for (int r = threadIdx.x / CS; r < R; r += 1024 / CS) {
+    const int rr = b * R + r;
+    uint8_t* am = argmax + (size_t)rr * cells * C + c0 + cc;
+    if (r >= nroi) {                                   // dead ROI: zeros, like k_roi_pool_fwd
+      mean[(size_t)rr * C + c0 + cc] = 0.f;
+      for (int s = 0; s < cells; ++s) am[(size_t)s * C] = 0;
+      continue;
+    }
+    const roi_geom g = roi_geometry(rois[rr], im_h, im_w, FH, FW, ch, cw);
+    float acc = 0.f;
+    for (int py = 0; py < ph; ++py) {
+#pragma unroll 2
+      for (int px = 0; px < pw; ++px) {
+        float best = 0.f;
+        int bq = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const roi_sample s = roi_sample_at(g, 2 * py + (q >> 1), 2 * px + (q & 1), FH, FW, ch, cw);
+          const int t = min(max(s.top, 0), FH - 1), bo = min(max(s.bot, 0), FH - 1);
+          const int l = min(max(s.left, 0), FW - 1), ri = min(max(s.right, 0), FW - 1);
+          const float tl = fslab[(t * FW + l) * CS + cc], tr = fslab[(t * FW + ri) * CS + cc];
+          const float bl = fslab[(bo * FW + l) * CS + cc], br = fslab[(bo * FW + ri) * CS + cc];
+          const float v = s.valid ? bilerp(tl, tr, bl, br, s.xlerp, s.ylerp) : 0.f;
+          if (q == 0 || v > best) { best = v; bq = q; }        // first max wins
+        }
+        acc += best;
+        am[(size_t)(py * pw + px) * C] = (uint8_t)bq;
+      }
+    }
+    mean[(size_t)rr * C + c0 + cc] = acc / (float)cells;
+  }
+}
+
+static int roi_mean_fwd_width(int FH, int FW, int C) {
+  const size_t npix = (size_t)FH * FW, lds_cap = 160 * 1024;
+  if ((C % 8) == 0 && npix * 8 * sizeof(float) <= lds_cap) return 8;
+  if ((C % 4) == 0 && npix * 4 * sizeof(float) <= lds_cap) return 4;
+  return 0;
+}
+
+// 1 when the fused pool+mean kernels can take this feature map (it has to fit the LDS slabs of both directions)
+extern "C" int lmh_roi_pool_mean_supported(int FH, int FW, int C) {
+  return roi_mean_fwd_width(FH, FW, C) != 0 && roi_slab_width(FH, FW, C) != 0;
+}
+
+// mean (B*R, C) = reduce_mean over the ph*pw cells of ROIPoolingLayer's output; argmax (B*R, ph, pw, C) for the backward
+extern "C" int lmh_roi_pool_mean_fwd(const float* feat, const float* rois, const int32_t* roi_count, int B, int R,
+                                     int FH, int FW, int C, float im_h, float im_w, int ph, int pw, float* mean,
+                                     uint8_t* argmax, lmh_stream_t stream) {
+  LMH_CHECK_ARG(feat && rois && roi_count && mean && argmax);
+  LMH_CHECK_ARG(B > 0 && R > 0 && FH > 0 && FW > 0 && C > 0 && ph > 0 && pw > 0);
+  const int cs = roi_mean_fwd_width(FH, FW, C);
+  if (!cs) {
+    lmh_set_error("lmh_roi_pool_mean_fwd: feature map does not fit the LDS slab (use lmh_roi_pool_fwd + lmh_spatial_mean_fwd)");
+    return LMH_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)FH * FW * cs * sizeof(float);
+  if (cs == 8) {
+    static bool attr = false;
+    if (!attr) {
+      LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_mean_fwd<8>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL((k_roi_pool_mean_fwd<8>), dim3(C / 8, B), dim3(1024), lds, st, feat,
+                       reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, mean, argmax);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_mean_fwd<4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL((k_roi_pool_mean_fwd<4>), dim3(C / 4, B), dim3(1024), lds, st, feat,
+                       reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, mean, argmax);
+  }
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+// dmean (B*R, C): gradient of the means; dfeat is OVERWRITTEN.
+extern "C" int lmh_roi_pool_mean_bwd(const float* dmean, const uint8_t* argmax, const float* rois,
+                                     const int32_t* roi_count, int B, int R, int FH, int FW, int C, float im_h,
+                                     float im_w, int ph, int pw, float* dfeat, void* ws, size_t ws_bytes,
+                                     lmh_stream_t stream) {
+  LMH_CHECK_ARG(dmean && argmax && rois && roi_count && dfeat);
+  LMH_CHECK_ARG(B > 0 && R > 0 && FH > 0 && FW > 0 && C > 0 && ph > 0 && pw > 0);
+  const int cs = roi_slab_width(FH, FW, C);
+  if (!cs) {
+    lmh_set_error("lmh_roi_pool_mean_bwd: feature map does not fit the LDS slab");
+    return LMH_ERR_UNSUPPORTED;
+  }
+  if (!ws || ws_bytes < lmh_roi_pool_bwd_workspace_bytes(B, R, ph, pw)) {
+    lmh_set_error("lmh_roi_pool_mean_bwd: workspace too small");
+    return LMH_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  roi_sample_rec* table = reinterpret_cast<roi_sample_rec*>(ws);
+  const int cells = ph * pw;
+  hipLaunchKernelGGL(k_roi_sample_table, dim3((B * R * cells + 255) / 256), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(rois), roi_count, B, R, FH, FW, im_h, im_w, ph, pw, table);
+  const int rc = cs == 8 ? roi_bwd_slab_launch<8, true>(dmean, argmax, table, roi_count, B, R, FH, FW, C, cells, dfeat, st)
+                         : roi_bwd_slab_launch<4, true>(dmean, argmax, table, roi_count, B, R, FH, FW, C, cells, dfeat, st);
+  if (rc != LMH_OK) return rc;
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

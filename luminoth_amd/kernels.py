@@ -592,6 +592,35 @@ def roi_pool_bwd(dout, argmax, rois, roi_count, feat_shape, im_shape, ph=7, pw=7
     return dfeat
 
 
+def roi_pool_mean_supported(feat_shape):
+    _, FH, FW, C = feat_shape
+    return bool(_lib.load().lmh_roi_pool_mean_supported(FH, FW, C))
+
+
+def roi_pool_mean_fwd(feat, rois, roi_count, im_shape, ph=7, pw=7):
+    """reduce_mean over the cells of roi_pool_fwd's output, without that output (see roi.hip)."""
+    lib = _lib.load()
+    B, FH, FW, C = feat.shape
+    R = rois.shape[1]
+    mean = torch.empty((B * R, C), dtype=torch.float32, device=feat.device)
+    argmax = torch.empty((B * R, ph, pw, C), dtype=torch.uint8, device=feat.device)
+    check(lib.lmh_roi_pool_mean_fwd(_p(feat), _p(rois), _p(roi_count), B, R, FH, FW, C, float(im_shape[0]),
+                                    float(im_shape[1]), ph, pw, _p(mean), _p(argmax), _stream()), 'lmh_roi_pool_mean_fwd')
+    return mean, argmax
+
+
+def roi_pool_mean_bwd(dmean, argmax, rois, roi_count, feat_shape, im_shape, ph=7, pw=7):
+    lib = _lib.load()
+    B, FH, FW, C = feat_shape
+    R = rois.shape[1]
+    dfeat = torch.empty(feat_shape, dtype=torch.float32, device=dmean.device)   # overwritten
+    ws = _workspace(lib.lmh_roi_pool_bwd_workspace_bytes(B, R, ph, pw), dmean.device, 'roi_bwd')
+    check(lib.lmh_roi_pool_mean_bwd(_p(dmean), _p(argmax), _p(rois), _p(roi_count), B, R, FH, FW, C,
+                                    float(im_shape[0]), float(im_shape[1]), ph, pw, _p(dfeat), _p(ws),
+                                    ctypes.c_size_t(ws.numel()), _stream()), 'lmh_roi_pool_mean_bwd')
+    return dfeat
+
+
 def spatial_mean_fwd(x):
     lib = _lib.load()
     M, S, C = x.shape[0], x.shape[1] * x.shape[2], x.shape[3]

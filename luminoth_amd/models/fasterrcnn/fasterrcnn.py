@@ -16,6 +16,8 @@ per-image counts (`num_proposals`, `num_objects`) so that the train step never
 synchronises with the host.  For un-batched inference calls the results are
 truncated to the reference's exact shapes.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -29,6 +31,10 @@ from luminoth_amd.params import ParamStore
 from luminoth_amd.utils import rng
 from luminoth_amd.utils.anchors import generate_anchors_reference, truncate_reference, all_anchors_numpy
 
+
+
+# software pipelining across steps (train_step(next_image=...)); LUMINOTH_AMD_PREFETCH_PREFIX=0 turns it off
+PREFETCH_PREFIX = os.environ.get('LUMINOTH_AMD_PREFETCH_PREFIX', '1') != '0'
 
 
 class FasterRCNN(object):
@@ -90,8 +96,6 @@ class FasterRCNN(object):
         """Per-image RNG seeds of the current step as a device tensor (B,) int32.  Seeds for the next
         _SEED_BLOCK steps are generated and uploaded in one go: a per-step host->device copy from
         pageable memory would re-synchronise the host with the GPU every step."""
-        if getattr(self, '_seed_override', None) is not None:      # HIP-graph replay: a static buffer refreshed per step
-            return self._seed_override
         c = getattr(self, '_seed_cache', None)
         if c is None or c[0] != B or not (c[1] <= self._step < c[1] + self._SEED_BLOCK):
             base = self._step
@@ -232,7 +236,15 @@ class FasterRCNN(object):
             K.TAILS.active = False
 
     # ------------------------------------------------------------ fused step --
-    def train_step(self, image, gt_boxes):
+    accepts_next_image = True
+
+    def _device_image(self, image):
+        image = torch.as_tensor(image)
+        if image.dim() == 3:
+            image = image.unsqueeze(0)
+        return image.to(self.device, torch.float32).contiguous()
+
+    def train_step(self, image, gt_boxes, next_image=None):
         """forward + loss + backward of ONE train step (train.py:66-91), same arithmetic as
         `__call__(is_training=True)` -> `loss()` -> `backward()`, scheduled on two HIP streams:
 
@@ -249,10 +261,11 @@ class FasterRCNN(object):
             total = self.loss(pred)
             self.backward(total)
             return total, pred
-        image = torch.as_tensor(image)
-        if image.dim() == 3:
-            image = image.unsqueeze(0)
-        image = image.to(self.device, torch.float32).contiguous()
+        pf, self._prefetch = getattr(self, '_prefetch', None), None
+        if pf is not None and pf[0] is image and pf[1] == image._version:
+            image = pf[2]            # uploaded (and its frozen trunk prefix computed) during the previous step
+        else:
+            image = self._device_image(image)
         B, H, W, _ = image.shape
         gt, gt_count = self._pack_gt(gt_boxes, B)
         seeds = self._image_seeds(B)
@@ -260,6 +273,7 @@ class FasterRCNN(object):
         im_shape = (H, W)
         main = torch.cuda.current_stream(self.device)
         aux = self._aux_stream()
+        self._phase_begin()
         self.store.grad.zero_()
         K.TAILS.begin()
         with torch.enable_grad():
@@ -270,9 +284,11 @@ class FasterRCNN(object):
                 K.keep_alive(t, aux)
             feat = self.base_network(image, is_training=True)
             assert (feat.shape[1], feat.shape[2]) == (fh, fw)
+            self._mark('trunk_fwd_done')
             f_rpn = feat.detach().requires_grad_(True)
             f_rcnn = feat.detach().requires_grad_(True)
             rpn_pred = rpn.heads(f_rpn)
+            self._mark('rpn_heads_done')
             # Host enqueue order matters while the host is not far ahead of the GPU: the proposal chain is
             # ONE C call (cheap to enqueue, long to run), so it goes first; then the RPN branch of the main
             # stream; the RCNN part of the aux stream last (it cannot start before the NMS finishes anyway).
@@ -281,7 +297,9 @@ class FasterRCNN(object):
             with torch.cuda.stream(aux):
                 prop = rpn._proposal(rpn_pred['rpn_cls_score'].detach(), rpn_pred['rpn_bbox_pred'].detach(),
                                      self._anchor_ref_i32, (fh, fw), self._anchor_stride, im_shape)
+                self._mark('aux:proposals_done')
                 rcnn_tgt = self._rcnn.targets(prop['proposals'], prop['num_proposals'], gt, gt_count, seeds)
+                self._mark('aux:rcnn_targets_done')
             for t in (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred'], feat):
                 K.keep_alive(t, aux)
             # ---- main stream: RPN targets -> RPN loss -> RPN backward
@@ -289,14 +307,26 @@ class FasterRCNN(object):
             rpn_pred.update(rpn_tgt)
             rpn_losses = rpn.loss(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
             (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss']).backward()
+            self._mark('rpn_bwd_done')
             # ---- aux stream: RCNN forward -> RCNN loss -> RCNN backward
             with torch.cuda.stream(aux):
+                self._mark('aux:rcnn_enqueue')      # later than aux:rcnn_targets_done = the host was not ahead here
                 cp = self._rcnn(f_rcnn, prop['proposals'], prop['num_proposals'], im_shape, self.base_network,
                                 gt_boxes=gt, gt_count=gt_count, seeds=seeds, is_training=True, targets=rcnn_tgt)
                 rcnn_losses = self._rcnn.loss(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
+                self._mark('aux:rcnn_loss_done')
                 (rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).backward()
+                self._mark('aux:rcnn_bwd_done')
+            # ---- the main stream has nothing left but to wait for the RCNN branch (0.3-0.4 ms at config 2): the slot
+            # for the frozen trunk prefix of the NEXT step's images (conv1 + block1: nothing this step's update writes)
+            if next_image is not None and PREFETCH_PREFIX and torch.is_tensor(next_image):
+                nxt = self._device_image(next_image)
+                if self.base_network.prefetch_prefix(nxt):
+                    self._prefetch = (next_image, next_image._version, nxt)
+                self._mark('next_prefix_done')
             # ---- join, trunk backward
             main.wait_stream(aux)
+            self._mark('joined')
             for t in (f_rcnn.grad, rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']):
                 K.keep_alive(t, main)
             # loss scalars (tiny launches) go BEFORE the trunk backward so that nothing but the optimizer is left
@@ -314,9 +344,12 @@ class FasterRCNN(object):
             feat.backward(f_rpn.grad + f_rcnn.grad)
             if buckets is not None:
                 buckets.disarm()
+            self._mark('trunk_bwd_data_done')
         SideStream.join()
+        self._mark('wgrad_stream_joined')
         K.TAILS.flush()          # every weight-gradient tail of the step (RPN, RCNN, trunk) in two launches
         K.TAILS.active = False
+        self._mark('tails_done')
         rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})
         rpn_pred['num_proposals'] = prop['num_proposals']
         self._last_losses = dict(rpn_losses, total_loss=total_loss, no_reg_loss=no_reg_loss,
@@ -324,6 +357,47 @@ class FasterRCNN(object):
         pred = {'rpn_prediction': rpn_pred, 'classification_prediction': cp, 'rpn_loss_dict': rpn_losses,
                 'rcnn_loss_dict': rcnn_losses, '_batch': {'B': B, 'unbatched': False}}
         return total_loss, pred
+
+    # -------------------------------------------------------------- diagnostics --
+    def record_phases(self, steps):
+        """Arm HIP-event marks for the next `steps` train steps (bench.py --phases): the un-profiled timeline of the
+        three-stream schedule.  rocprofv3 slows the launch path enough to make the step host-bound where it forks, so
+        the gaps in a kernel trace are not the gaps of the real step; a handful of event records are."""
+        self._phase_left = steps
+        self._phase_log = []
+
+    def _mark(self, name, stream=None):
+        cur = getattr(self, '_phase_cur', None)
+        if cur is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
+        cur.append((name, ev))
+
+    def _phase_begin(self):
+        left = getattr(self, '_phase_left', 0)
+        self._phase_cur = None
+        if left > 0:
+            self._phase_left = left - 1
+            self._phase_cur = []
+            self._phase_log.append(self._phase_cur)
+            self._mark('step_start')
+
+    def phase_times(self):
+        """-> {mark: mean ms after step_start} over the recorded steps (synchronises), plus 'next_step_start'."""
+        torch.cuda.synchronize(self.device)
+        log = getattr(self, '_phase_log', [])
+        out, n = {}, 0
+        for i, marks in enumerate(log):
+            t0 = marks[0][1]
+            for name, ev in marks[1:]:
+                out[name] = out.get(name, 0.0) + t0.elapsed_time(ev)
+            if i + 1 < len(log):
+                out['next_step_start'] = out.get('next_step_start', 0.0) + t0.elapsed_time(log[i + 1][0][1])
+                n += 1
+        res = {k: v / (n if k == 'next_step_start' else len(log)) for k, v in out.items()}
+        self._phase_log, self._phase_cur = [], None
+        return res
 
     def _aux_stream(self):
         st = getattr(self, '_aux', None)

@@ -97,12 +97,17 @@ class RCNN(object):
             else:
                 pred['target'] = {'cls': tgt['labels'], 'bbox_offsets': tgt['bbox_targets']}
         R = proposals.shape[1]
-        pooled = self._roi_pool(proposals, prop_count, conv_feature_map, im_shape)['roi_pool']   # (B*R,ph,pw,C)
-        features = base_network._build_tail(pooled, is_training=is_training)
-        if self._use_mean:
-            net = A.SpatialMeanFn.apply(features)                        # (B*R, C)
-        else:
-            net = features.reshape(features.shape[0], -1)
+        net = None
+        if self._use_mean and not base_network.has_tail and not self._debug:
+            # no tail between the pooling and the mean: one kernel, the (B*R,ph,pw,C) tensor is never written
+            net = self._roi_pool.pooled_mean(proposals, prop_count, conv_feature_map, im_shape)
+        if net is None:
+            pooled = self._roi_pool(proposals, prop_count, conv_feature_map, im_shape)['roi_pool']   # (B*R,ph,pw,C)
+            features = base_network._build_tail(pooled, is_training=is_training)
+            if self._use_mean:
+                net = A.SpatialMeanFn.apply(features)                        # (B*R, C)
+            else:
+                net = features.reshape(features.shape[0], -1)
         net = self._dropout(net, is_training)                          # rcnn.py:196
         for layer in self._layers:
             net = self._dropout(self._linear(layer, net), is_training)   # rcnn.py:214-218

@@ -2,6 +2,7 @@
 'crop' mode = crop_and_resize to 2x the pooled size + 2x2 max pool, fused in one
 kernel; 'roi_pooling' raises NotImplementedError exactly like the reference."""
 from luminoth_amd import autograd as A
+from luminoth_amd import kernels as K
 
 CROP = 'crop'
 ROI_POOLING = 'roi_pooling'
@@ -24,3 +25,12 @@ class ROIPoolingLayer(object):
         elif self._pooling_mode == ROI_POOLING:
             raise NotImplementedError()
         raise NotImplementedError('Pooling mode {} does not exist.'.format(self._pooling_mode))
+
+    def pooled_mean(self, roi_proposals, roi_count, conv_feature_map, im_shape):
+        """tf.reduce_mean(self(...)['roi_pool'], [1, 2]) in one kernel, or None when the feature map does not fit it
+        (the caller then pools and averages separately)."""
+        if self._pooling_mode != CROP or not K.roi_pool_mean_supported(conv_feature_map.shape):
+            return None
+        return A.RoiPoolMeanFn.apply(conv_feature_map, roi_proposals, roi_count,
+                                     (float(im_shape[0]), float(im_shape[1])),
+                                     self._pooled_height, self._pooled_width)

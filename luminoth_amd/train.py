@@ -166,9 +166,18 @@ def run(config, get_model_fn=None, get_dataset_fn=None, train_step_fn=None, max_
     last_save = time.time()
     log.info('%sStarting training for %s', log_prefix, type(model).__name__)
     step = global_step
-    for batch in dataset:
+    # one batch of look-ahead: the step is handed the NEXT image as well, so the model may run that image's frozen
+    # trunk prefix in the slot where its main stream waits for the proposal / RCNN branch (FasterRCNN.train_step)
+    lookahead = train_step_fn is training.train_step
+    it = iter(dataset)
+    nxt = next(it, None)
+    while nxt is not None:
+        batch, nxt = nxt, next(it, None)
         before = time.time()
-        total_loss, _ = train_step_fn(model, optimizer, batch['image'], batch['bboxes'])
+        if lookahead and nxt is not None:
+            total_loss, _ = train_step_fn(model, optimizer, batch['image'], batch['bboxes'], next_image=nxt['image'])
+        else:
+            total_loss, _ = train_step_fn(model, optimizer, batch['image'], batch['bboxes'])
         train_loss = float(total_loss)          # the per-step fetch of train.py:237-239 (host sync)
         step += 1
         log.info('%sstep: %d, file: %s, train_loss: %s, in %.2fs', log_prefix, step, batch.get('filename'),

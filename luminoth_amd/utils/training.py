@@ -318,68 +318,15 @@ def broadcast_parameters(model, src=0):
         dist.broadcast(model.store.frozen, src)
 
 
-class GraphedTrainStep(object):
-    """HIP-graph replay of the fixed-shape train step (forward + loss + backward + update on all its streams).
-
-    The step enqueues ~400 kernels from Python; where the proposal / RCNN branch forks onto its own stream the host
-    cannot feed both streams at once and the GPU waits for the interpreter.  Capturing the step once and replaying
-    the graph hands the whole dependency graph to the GPU front end in one go: same kernels, same arithmetic, same
-    stream topology (the forked streams are captured through their wait_stream edges).  Per-step state that lives in
-    device memory (images, gt boxes, the per-image subsample seeds) is copied into static buffers before every
-    replay; scalars baked into kernel arguments (learning rate) must be constant — `supported()` checks.
-    Captured on a dedicated stream after `warmup` eager steps on that same stream (so every workspace, side stream
-    and allocator block the step needs exists before the capture starts)."""
-
-    @staticmethod
-    def supported(model, optimizer, train_config):
-        lr = dict(train_config.learning_rate)
-        return hasattr(model, 'train_step') and hasattr(model, '_image_seeds') and \
-            not (lr.get('decay_method') and lr.get('decay_method') != 'none') and \
-            getattr(optimizer, 'buckets', None) is None and model.store.grad.is_cuda
-
-    def __init__(self, model, optimizer, image, gt_boxes, warmup=2):
-        self.model, self.opt = model, optimizer
-        dev = model.device
-        B = image.shape[0]
-        self.image = image.to(dev, torch.float32).contiguous().clone()
-        gt, cnt = model._pack_gt(gt_boxes, B)
-        self.gt, self.cnt = gt.clone(), cnt.clone()
-        self.stream = torch.cuda.Stream(device=dev)
-        self.stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(self.stream):
-            for _ in range(warmup):
-                train_step(model, optimizer, self.image, (self.gt, self.cnt))
-        self.stream.synchronize()
-        self.seeds = model._image_seeds(B).clone()
-        model._seed_override = self.seeds
-        self.graph = torch.cuda.CUDAGraph()
-        try:
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.total, self.pred = train_step(model, optimizer, self.image, (self.gt, self.cnt))
-        finally:
-            model._seed_override = None
-        torch.cuda.synchronize(dev)
-
-    def __call__(self, image=None, gt_boxes=None):
-        m = self.model
-        if image is not None and image is not self.image:
-            self.image.copy_(image)
-        if gt_boxes is not None:
-            gt, cnt = m._pack_gt(gt_boxes, self.image.shape[0])
-            if gt is not self.gt:
-                self.gt.copy_(gt)
-                self.cnt.copy_(cnt)
-        self.seeds.copy_(m._image_seeds(self.image.shape[0]))
-        self.graph.replay()
-        m._step += 1
-        self.opt.global_step += 1
-        return self.total, self.pred
-
-
-def train_step(model, optimizer, image, gt_boxes):
-    """One step of train.py:66-91: forward, loss, backward, (all-reduce), update."""
+def train_step(model, optimizer, image, gt_boxes, next_image=None):
+    """One step of train.py:66-91: forward, loss, backward, (all-reduce), update.  `next_image` (optional): the image
+    batch of the FOLLOWING step, if the caller already has it — models with a frozen trunk prefix compute that prefix
+    ahead of time in an otherwise idle slot of this step (same arithmetic; see FasterRCNN.train_step)."""
     if FUSED_STEP and hasattr(model, 'train_step'):
-        total, pred = model.train_step(image, gt_boxes)     # same arithmetic, two-stream schedule
+        if next_image is not None and getattr(model, 'accepts_next_image', False):
+            total, pred = model.train_step(image, gt_boxes, next_image=next_image)
+        else:
+            total, pred = model.train_step(image, gt_boxes)     # same arithmetic, two-stream schedule
     else:
         pred = model(image, gt_boxes, is_training=True)
         total = model.loss(pred)

@@ -26,3 +26,13 @@ for dbg in (0,):
 pass
 t = timeit(lambda: K.roi_pool_fwd(feat, roist, cnt, (1024, 1024)), 10)
 print('roi_pool_fwd: %.1f us' % (t * 1e3))
+t = timeit(lambda: K.spatial_mean_fwd(out), 10)
+print('spatial_mean_fwd: %.1f us' % (t * 1e3))
+dy = torch.randn(B * R, C, device=dev)
+t = timeit(lambda: K.spatial_mean_bwd(dy, tuple(out.shape)), 10)
+print('spatial_mean_bwd: %.1f us' % (t * 1e3))
+mean, am2 = K.roi_pool_mean_fwd(feat, roist, cnt, (1024, 1024))
+t = timeit(lambda: K.roi_pool_mean_fwd(feat, roist, cnt, (1024, 1024)), 10)
+print('roi_pool_mean_fwd (fused): %.1f us' % (t * 1e3))
+t = timeit(lambda: K.roi_pool_mean_bwd(dy, am2, roist, cnt, (B, FH, FW, C), (1024, 1024)), 10)
+print('roi_pool_mean_bwd (fused): %.1f us' % (t * 1e3))

@@ -294,6 +294,34 @@ def test_roi_pool_fwd_bwd(K):
     np.testing.assert_array_equal(o[3], [[3, 4], [3, 4]])
 
 
+@pytest.mark.parametrize('shape', [(2, 20, 24, 64, 24), (2, 64, 64, 128, 256), (1, 50, 84, 32, 64), (1, 64, 75, 16, 32)])
+def test_roi_pool_mean_fused_equals_pool_then_mean(K, shape):
+    """k_roi_pool_mean_fwd / the MEAN backward == roi_pool + spatial_mean, bit for bit (forward: same arithmetic in the
+    same order; backward: the fixed-point slab sum does not depend on order).  Last shape: C % 8 == 0 but the map only
+    fits the 4-channel slab of the backward."""
+    B, FH, FW, C, R = shape
+    rs = np.random.RandomState(7)
+    feat = rs.randn(B, FH, FW, C).astype(F)
+    im = (FH * 16, FW * 16)
+    rois = np.zeros((B, R, 4), F)
+    for b in range(B):
+        rois[b] = rand_boxes(rs, R, min(im), 8, min(im) // 2)
+    rois[0, 0] = [-30, -20, 100, 90]
+    rois[0, 1] = [im[1] - 20, im[0] - 30, im[1] + 80, im[0] + 60]
+    cnt = np.array([R, max(1, R // 3)][:B], np.int32)
+    assert K.roi_pool_mean_supported((B, FH, FW, C))
+    out, am = K.roi_pool_fwd(T(feat), T(rois), T(cnt), im)
+    ref_mean = K.spatial_mean_fwd(out)
+    mean, am2 = K.roi_pool_mean_fwd(T(feat), T(rois), T(cnt), im)
+    assert torch.equal(mean, ref_mean)
+    assert torch.equal(am, am2)
+    dy = T(rs.randn(B * R, C).astype(F))
+    ref_d = K.roi_pool_bwd(K.spatial_mean_bwd(dy, tuple(out.shape)), am, T(rois), T(cnt), (B, FH, FW, C), im)
+    d = K.roi_pool_mean_bwd(dy, am2, T(rois), T(cnt), (B, FH, FW, C), im)
+    assert torch.equal(d, ref_d)
+    assert not K.roi_pool_mean_supported((1, 200, 200, 64))          # 40000 pixels: the unfused pair is the path
+
+
 def test_spatial_mean(K):
     x = torch.randn(37, 7, 7, 128, device=dev())
     np.testing.assert_allclose(K.spatial_mean_fwd(x).cpu().numpy(), x.cpu().mean(dim=(1, 2)).numpy(),
@@ -485,7 +513,7 @@ def test_wgrad_1x1_direct_to_lds_variants(K, case):
     ref = torch.tensor(x).reshape(-1, C).double().t() @ torch.tensor(g).reshape(-1, Kc).double()
     scale = float(ref.abs().max())
     lib = K._lib.load()
-    assert lib.lmh_conv2d_bwd_weight_fuses_colsum(d) == 0
+    assert lib.lmh_conv2d_bwd_weight_fuses_colsum(d) == 1       # per-channel sums ride along in both fp32 fast paths
     try:
         for bm, bn in ((64, 64), (128, 64), (64, 128), (128, 128)):
             for splits in (0, 1, 3):
@@ -501,7 +529,6 @@ def test_wgrad_1x1_direct_to_lds_variants(K, case):
         # the register-staged kernel (variant -1) agrees too
         lib.lmh_conv2d_force_config(0, 0, 0)
         lib.lmh_conv2d_force_wgrad_variant(-1)
-        assert lib.lmh_conv2d_bwd_weight_fuses_colsum(d) == 1
         dw_old = K.conv2d_bwd_weight(d, T(x), T(g)).cpu()
         np.testing.assert_allclose(dw_old.reshape(C, Kc).numpy(), ref.numpy(), rtol=1e-4, atol=2e-5 * scale)
     finally:

@@ -270,14 +270,17 @@ def test_rccl_single_rank_bucketed_step(setup, tmp_path):
         model.load_state_dict(sd0)
 
 
-def test_hip_graph_replay_equals_eager_steps(setup):
-    """GraphedTrainStep (the whole three-stream step captured once, replayed): two replays from a given state give
-    the weights of two eager steps from the same state (per-step seeds refreshed through the static buffer)."""
+def test_next_image_prefetch_equals_plain_steps(setup):
+    """train_step(next_image=...) computes the frozen trunk prefix of the following batch ahead of time: three steps over
+    alternating batches end in bit-identical weights and losses with and without the look-ahead, the cached prefix is
+    dropped when the next call gets another tensor, and an in-place change of the announced batch invalidates it."""
     from luminoth_amd.utils import training as T
     cfg, model, images, gts = setup
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     opt = T.get_optimizer(cfg.train, model)
-    assert T.GraphedTrainStep.supported(model, opt, cfg.train)
+    a = images.to(model.device)
+    b = torch.flip(a, dims=[2]).contiguous()
+    seq = [a, b, a]
 
     def reset():
         model.load_state_dict(sd0)
@@ -285,29 +288,35 @@ def test_hip_graph_replay_equals_eager_steps(setup):
         model._step = 0
         opt.global_step = 0
 
-    reset()
-    losses_e = []
-    for _ in range(2):
-        total, _ = T.train_step(model, opt, images, gts)
-        losses_e.append(float(total))
-    torch.cuda.synchronize()
-    want = model.store.flat.clone()
     try:
-        graphed = T.GraphedTrainStep(model, opt, images.to(model.device), gts, warmup=1)
         reset()
-        losses_g = []
-        for _ in range(2):
-            total, _ = graphed()
-            losses_g.append(float(total))
-        torch.cuda.synchronize()
-        assert model._step == 2 and opt.global_step == 2
-        np.testing.assert_allclose(losses_g, losses_e, rtol=1e-6)
-        scale = float(want.abs().max())
-        np.testing.assert_allclose(model.store.flat.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-7 * scale)
+        plain = [float(T.train_step(model, opt, x, gts)[0]) for x in seq]
+        want = model.store.flat.clone()
+        reset()
+        ahead = []
+        for i, x in enumerate(seq):
+            nxt = seq[i + 1] if i + 1 < len(seq) else a
+            ahead.append(float(T.train_step(model, opt, x, gts, next_image=nxt)[0]))
+            assert model.base_network._prefetched is not None and model.base_network._prefetched[0] is nxt
+        assert ahead == plain
+        assert torch.equal(model.store.flat, want)
+        # announced `a`, but `b` arrives: the stale prefix must not be used
+        reset()
+        T.train_step(model, opt, a, gts, next_image=a)
+        l_b = float(T.train_step(model, opt, b, gts)[0])
+        assert model.base_network._prefetched is None
+        assert l_b == plain[1]
+        # announced tensor modified in place afterwards
+        reset()
+        c = a.clone()
+        T.train_step(model, opt, a, gts, next_image=c)
+        c.copy_(b)
+        assert float(T.train_step(model, opt, c, gts)[0]) == plain[1]
     finally:
-        model._seed_override = None
         model.load_state_dict(sd0)
         model.store.mom.zero_()
+        model._prefetch = None
+        model.base_network._prefetched = None
 
 
 def test_non_default_config_surface_trains(monkeypatch):
