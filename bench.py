@@ -40,7 +40,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense matrix peaks
-PEAK_TFLOPS = {'f32': 157.3, 'f16': 2500.0, 'bf16': 2500.0}
+# bf16x3: fp32 arithmetic as six bf16 MFMA products per fp32 product (conv_half.h): 2500 / 6 fp32-equivalent TFLOP/s
+PEAK_TFLOPS = {'f32': 157.3, 'f16': 2500.0, 'bf16': 2500.0, 'bf16x3': 2500.0 / 6}
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -181,7 +182,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='frcnn_r50', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the workload\'s)')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'],
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16', 'bf16x3'],
                     help='convolution compute dtype (f32 = the parity dtype of north_star)')
     ap.add_argument('--serial', action='store_true',
                     help='run EVERY step on one stream (the schedule of the roofline profiling steps): the command '

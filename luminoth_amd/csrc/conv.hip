@@ -45,7 +45,7 @@ static int check_desc(const lmh_conv_desc* d) {
   LMH_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0);
   LMH_CHECK_ARG(d->OH > 0 && d->OW > 0 && d->stride > 0 && d->dilation > 0);
   LMH_CHECK_ARG(d->act >= 0 && d->act <= 2);
-  LMH_CHECK_ARG(d->compute >= 0 && d->compute <= 2);
+  LMH_CHECK_ARG(d->compute >= 0 && d->compute <= 3);
   LMH_CHECK_ARG((int64_t)d->N * d->OH * d->OW < (1ll << 31) && (int64_t)d->N * d->H * d->W < (1ll << 31));
   return LMH_OK;
 }
@@ -142,6 +142,15 @@ static float half_gscale(const lmh_conv_desc* d) { return d->compute == 1 ? 1024
 // step, f16): one set 6.82 ms/step, two sets 8.02 — the second set pushes the 128x128 kernels past 256 VGPRs (one wave
 // per SIMD instead of two), which costs more than the deeper prefetch buys.  LMH_HALF_PF=2 keeps the variant reachable.
 static const int half_pf = env_int("LMH_HALF_PF", 1) == 2 ? 2 : 1;
+// bf16x3 pipeline per pass: 0 = one LDS buffer, two 256-thread blocks per CU; 1 / 2 = double-buffered LDS, one block per
+// CU, one / two register sets of prefetched tiles; 3 = warp-specialised 512-thread block (waves 4-7 split and stage tile
+// t+1 while waves 0-3 multiply tile t).  Measured per layer on MI355X (scripts/bench_conv.py, ResNet-50 shapes, sums over
+// the 19 layers): forward 1.42 / 1.48 / 1.57 / 1.32 ms for 0 / 1 / 2 / 3 (native fp32 MFMA 1.59), backward data 1.28 /
+// 1.36 / 1.42 / 1.45 (1.59), weight gradient 1.69 / 1.98 / 2.00 / 1.78 (1.95).  LMH_X3_PF forces one for all passes.
+static const int x3_pf_all = env_int("LMH_X3_PF", -1);
+static const int x3_pf_fwd = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_FWD", 3);
+static const int x3_pf_bd = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_BD", 0);
+static const int x3_pf_bw = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_BW", 0);
 // Tile of the half-precision kernels: they are bound by the staging path (bytes per MFMA), not by matrix-pipe rounds, so
 // the largest tile the problem fills wins (128x128 moves half the bytes per FLOP of 64x64) as long as the grid still
 // covers the chip once.
@@ -184,7 +193,11 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
     do { if (half_pf == 2) hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 2>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
          else hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); } while (0)
 #define LAUNCH_FWD_HT(BM_, BN_)                                                                           \
-    do { if (d->compute == 1) LAUNCH_FWD_H(1, BM_, BN_); else LAUNCH_FWD_H(2, BM_, BN_); } while (0)
+    do { if (d->compute == 1) LAUNCH_FWD_H(1, BM_, BN_); else if (d->compute == 2) LAUNCH_FWD_H(2, BM_, BN_);                \
+         else if (x3_pf_fwd == 3) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 3>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y); \
+         else if (x3_pf_fwd == 0) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 0>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
+         else if (x3_pf_fwd == 1) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
+         else hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 2>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); } while (0)
     prof_begin(st);
     if (bm == 128 && bn == 128) LAUNCH_FWD_HT(128, 128);
     else if (bm == 128) LAUNCH_FWD_HT(128, 64);
@@ -241,7 +254,11 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
 #define LAUNCH_BD_H(DT_, BM_, BN_)                                                                        \
     hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx)
 #define LAUNCH_BD_HT(BM_, BN_)                                                                            \
-    do { if (d->compute == 1) LAUNCH_BD_H(1, BM_, BN_); else LAUNCH_BD_H(2, BM_, BN_); } while (0)
+    do { if (d->compute == 1) LAUNCH_BD_H(1, BM_, BN_); else if (d->compute == 2) LAUNCH_BD_H(2, BM_, BN_);                  \
+         else if (x3_pf_bd == 3) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 3>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else if (x3_pf_bd == 0) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 0>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else if (x3_pf_bd == 1) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 2>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); } while (0)
     prof_begin(st);
     if (bm == 128 && bn == 128) LAUNCH_BD_HT(128, 128);
     else if (bm == 128) LAUNCH_BD_HT(128, 64);
@@ -470,7 +487,15 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
          else hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 1>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z); } while (0)
 #define LAUNCH_BW_HT(BM_, BN_)                                                                             \
-    do { if (d->compute == 1) LAUNCH_BW_H(1, BM_, BN_); else LAUNCH_BW_H(2, BM_, BN_); } while (0)
+    do { if (d->compute == 1) LAUNCH_BW_H(1, BM_, BN_); else if (d->compute == 2) LAUNCH_BW_H(2, BM_, BN_);                  \
+         else if (x3_pf_bw == 3) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 3>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw, \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+         else if (x3_pf_bw == 0) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 0>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+         else if (x3_pf_bw == 1) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 1>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+         else hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z); } while (0)
     prof_begin(st);
     if (bm == 128 && bn == 128) LAUNCH_BW_HT(128, 128);
     else if (bm == 128) LAUNCH_BW_HT(128, 64);

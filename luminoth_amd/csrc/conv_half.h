@@ -15,6 +15,16 @@
 //   * with the matrix pipe 16x faster the kernels are bound by the staging path (L2 -> VGPR -> cvt -> LDS), so the
 //     pipeline is the plain one: global loads of tile t+1 before the MFMAs of tile t, converted and written to the
 //     other LDS buffer after them, one barrier per stage.
+//
+// PF = 3 ("warp-specialised", 512 threads): see HALF_PIPELINE.
+// DT = 3, "bf16x3": fp32 ARITHMETIC on the bf16 matrix pipe.  Every fp32 operand is split EXACTLY into three bf16 pieces by
+// truncation (a = a0 + a1 + a2, 8 significant bits each: 24 = the fp32 significand), the pieces sit in three LDS planes,
+// and a product is six MFMAs into the same fp32 accumulator: a0b2, a2b0, a1b1, a0b1, a1b0, a0b0 (the three dropped
+// cross terms are <= 2^-23 of the product — below the rounding of the fp32 accumulation itself; every kept product of
+// two 8-bit pieces is exact).  v_mfma_f32_32x32x16_bf16 is 16x the rate of v_mfma_f32_32x32x2_f32, so six of them are
+// 2.67x the fp32-MFMA roofline at fp32 accuracy (the "6-pass bf16" scheme XLA uses for fp32 matmuls on TPUs).  The
+// split costs ~5.5 VALU ops per staged element; one LDS buffer (61 KB at 128x128) so two blocks share a CU and one
+// block's split / staging runs under the other's MFMAs.
 #pragma once
 #include <type_traits>
 #include "conv_fast.h"
@@ -39,6 +49,32 @@ template <> struct HT<2> {
   }
 };
 
+template <> struct HT<3> : HT<2> {};      // bf16 pieces of the exact 3-way split
+template <int DT> struct half_cfg { static constexpr int NS = (DT == 3) ? 3 : 1; };
+
+// exact split of an fp32 value into three bf16 pieces by truncation; returned as fp32 bit patterns whose HIGH halves are
+// the pieces (the low half of the last one is zero by construction)
+__device__ __forceinline__ void split3(float a, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
+  h0 = __float_as_uint(a) & 0xFFFF0000u;
+  const float r1 = a - __uint_as_float(h0);
+  h1 = __float_as_uint(r1) & 0xFFFF0000u;
+  h2 = __float_as_uint(r1 - __uint_as_float(h1));
+}
+// (hi16(e1) << 16) | hi16(e0)
+__device__ __forceinline__ uint32_t pack_hi(uint32_t e0, uint32_t e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
+
+// four fp32 values -> three planes of four bf16 at S (plane stride `pl` elements)
+__device__ __forceinline__ void st_split4(__bf16* __restrict__ S, int pl, float a, float b, float c, float d) {
+  uint32_t x0[4], x1[4], x2[4];
+  split3(a, x0[0], x1[0], x2[0]);
+  split3(b, x0[1], x1[1], x2[1]);
+  split3(c, x0[2], x1[2], x2[2]);
+  split3(d, x0[3], x1[3], x2[3]);
+  *reinterpret_cast<uint2*>(S) = make_uint2(pack_hi(x0[0], x0[1]), pack_hi(x0[2], x0[3]));
+  *reinterpret_cast<uint2*>(S + pl) = make_uint2(pack_hi(x1[0], x1[1]), pack_hi(x1[2], x1[3]));
+  *reinterpret_cast<uint2*>(S + 2 * pl) = make_uint2(pack_hi(x2[0], x2[1]), pack_hi(x2[2], x2[3]));
+}
+
 template <int DT>
 __device__ __forceinline__ typename HT<DT>::V4 cvt4(float a, float b, float c, float d) {
   typedef typename HT<DT>::T T;
@@ -49,24 +85,51 @@ __device__ __forceinline__ typename HT<DT>::V4 cvt4(float a, float b, float c, f
 
 // K-contiguous source row -> LDS row segment (4 halfs at k = 4*kq)
 template <int DT>
-__device__ __forceinline__ void st_kc(typename HT<DT>::T* __restrict__ S, int row, int kq, f32x4 v) {
-  *reinterpret_cast<typename HT<DT>::V4*>(&S[row * LDH + 4 * kq]) = cvt4<DT>(v.x, v.y, v.z, v.w);
+__device__ __forceinline__ void st_kc(typename HT<DT>::T* __restrict__ S, int pl, int row, int kq, f32x4 v) {
+  if constexpr (DT == 3) st_split4(&S[row * LDH + 4 * kq], pl, v.x, v.y, v.z, v.w);
+  else *reinterpret_cast<typename HT<DT>::V4*>(&S[row * LDH + 4 * kq]) = cvt4<DT>(v.x, v.y, v.z, v.w);
 }
 // 4(k) x 4(col) register block of a K-major source -> four LDS rows (cols), k-quad kq4
 template <int DT>
-__device__ __forceinline__ void st_km(typename HT<DT>::T* __restrict__ S, int col0, int kq4, const f32x4 (&r)[4]) {
+__device__ __forceinline__ void st_km(typename HT<DT>::T* __restrict__ S, int pl, int col0, int kq4, const f32x4 (&r)[4]) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    *reinterpret_cast<typename HT<DT>::V4*>(&S[(col0 + e) * LDH + 4 * kq4]) = cvt4<DT>(r[0][e], r[1][e], r[2][e], r[3][e]);
+  for (int e = 0; e < 4; ++e) {
+    if constexpr (DT == 3) st_split4(&S[(col0 + e) * LDH + 4 * kq4], pl, r[0][e], r[1][e], r[2][e], r[3][e]);
+    else *reinterpret_cast<typename HT<DT>::V4*>(&S[(col0 + e) * LDH + 4 * kq4]) = cvt4<DT>(r[0][e], r[1][e], r[2][e], r[3][e]);
+  }
 }
 
 // one BK = 32 stage: 2 k-steps of 16, fragments by ds_read_b128
 template <int DT, int TM, int TN>
 __device__ __forceinline__ void mfma_stage_h(const typename HT<DT>::T* __restrict__ As,
                                              const typename HT<DT>::T* __restrict__ Bs, f32x16 (&acc)[TM][TN],
-                                             int a_off, int b_off, int lane) {
+                                             int a_off, int b_off, int lane, int a_pl = 0, int b_pl = 0) {
   typedef typename HT<DT>::V8 V8;
   const int l31 = lane & 31, kh = 8 * (lane >> 5);
+  if constexpr (DT == 3) {
+    // six products per fragment pair, smallest terms first; consecutive MFMAs go to different accumulators
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      V8 a[3][TM], b[3][TN];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+          a[p][t] = *reinterpret_cast<const V8*>(&As[p * a_pl + (a_off + t * 32 + l31) * LDH + s * 16 + kh]);
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          b[p][t] = *reinterpret_cast<const V8*>(&Bs[p * b_pl + (b_off + t * 32 + l31) * LDH + s * 16 + kh]);
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[PA[q]][tm], b[PB[q]][tn], acc[tm][tn]);
+    }
+    return;
+  }
   V8 a[2][TM], b[2][TN];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -96,7 +159,24 @@ __device__ __forceinline__ void mfma_stage_h(const typename HT<DT>::T* __restric
   do {                                                                                              \
     typedef std::integral_constant<int, 0> S0;                                                      \
     typedef std::integral_constant<int, 1> S1;                                                      \
-    if constexpr ((PF_) == 1) {                                                                     \
+    if constexpr ((PF_) == 3) { /* warp-specialised: waves 4-7 stage tile t+1 (split + LDS writes) while waves 0-3 multiply tile t */ \
+      const bool producer_ = threadIdx.x >= 256;                                                    \
+      if (producer_) { load(S0()); store(0, S0()); step(); load(S0()); }                            \
+      __syncthreads();                                                                              \
+      for (int kt_ = 0; kt_ < (KT_); ++kt_) {                                                       \
+        if (producer_) { store((kt_ & 1) ^ 1, S0()); step(); load(S0()); }                          \
+        else mma(kt_ & 1);                                                                          \
+        __syncthreads();                                                                            \
+      }                                                                                             \
+    } else if constexpr ((PF_) == 0) { /* ONE LDS buffer, two barriers per stage; loads of tile t+1 fly under the MFMAs of t */ \
+      load(S0());                                                                                   \
+      for (int kt_ = 0; kt_ < (KT_); ++kt_) {                                                       \
+        store(0, S0()); step(); load(S0());                                                         \
+        __syncthreads();                                                                            \
+        mma(0);                                                                                     \
+        __syncthreads();                                                                            \
+      }                                                                                             \
+    } else if constexpr ((PF_) == 1) {                                                              \
       load(S0()); store(0, S0()); step(); load(S0());                                               \
       __syncthreads();                                                                              \
       for (int kt_ = 0; kt_ < (KT_); ++kt_) {                                                       \
@@ -116,15 +196,20 @@ __device__ __forceinline__ void mfma_stage_h(const typename HT<DT>::T* __restric
     }                                                                                               \
   } while (0)
 
-#define HALF_SMEM_FLOATS(BM_, BN_) \
-  (((2 * ((BM_) + (BN_)) * LDH + 1) / 2 > (BM_) * ((BN_) + 4)) ? (2 * ((BM_) + (BN_)) * LDH + 1) / 2 : (BM_) * ((BN_) + 4))
+// LDS floats: NB buffers x NS planes x (BM + BN) rows of LDH halfs, or the fp32 epilogue tile, whichever is larger
+template <int DT, int BM, int BN, int PF>
+struct half_smem {
+  static constexpr int NS = half_cfg<DT>::NS, NB = PF == 0 ? 1 : 2;     // (PF 3: double buffer)
+  static constexpr int stage = (NB * NS * (BM + BN) * LDH + 1) / 2, epi = BM * (BN + 4);
+  static constexpr int floats = stage > epi ? stage : epi;
+};
 
 // ============================================================================
 // forward:  y[p,k] = act( sum_{r,s,c} x[pix(p,r,s),c] * w[r,s,c,k] * scale[k] + shift[k] + res[p,k] )
 //   needs C % 32 == 0, K % 4 == 0.  A: gather (K-contiguous).  B: HWIO rows (K-major) -> transposed in registers.
 // ============================================================================
 template <int DT, int BM, int BN, int PF>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(PF == 3 ? 512 : 256, (DT == 3 && PF != 0) ? 1 : 2)
 k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
              const float* __restrict__ scale, const float* __restrict__ shift,
              const float* __restrict__ residual, float* __restrict__ y) {
@@ -133,10 +218,12 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
   constexpr int AJ = BM / 32;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
   constexpr int LDC = BN + 4;
-  __shared__ __attribute__((aligned(16))) float smem[HALF_SMEM_FLOATS(BM, BN)];
-  HTT* const As = reinterpret_cast<HTT*>(smem);       // [2][BM][LDH]
-  HTT* const Bs = As + 2 * A_SZ;                      // [2][BN][LDH]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NS = half_cfg<DT>::NS, NB = PF == 0 ? 1 : 2, NR = (PF == 0 || PF == 3) ? 1 : PF, NT = PF == 3 ? 512 : 256;
+  constexpr int A_BUF = NS * A_SZ, B_BUF = NS * B_SZ;
+  __shared__ __attribute__((aligned(16))) float smem[half_smem<DT, BM, BN, PF>::floats];
+  HTT* const As = reinterpret_cast<HTT*>(smem);       // [NB][NS][BM][LDH]
+  HTT* const Bs = As + NB * A_BUF;                    // [NB][NS][BN][LDH]
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // (PF == 3: producers 256..511 share the staging map)
   const int wm = wave >> 1, wn = wave & 1;
   const int M = d.N * d.OH * d.OW, K = d.K, C = d.C;
   const int tiles_n = (K + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
@@ -175,7 +262,7 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
   const float* pb = b_ok ? w + (size_t)(4 * kq) * K + n0 + 4 * cq : lmh_zero_page;
   const size_t rowb = b_ok ? (size_t)K : 0, incb = b_ok ? (size_t)BK * K : 0;
 
-  f32x4 ra[PF][AJ], rb[PF][4];
+  f32x4 ra[NR][AJ], rb[NR][4];
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   int rs = 0, cc = 0, ptile = 0;
@@ -201,21 +288,21 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
   };
   auto store = [&](int buf, auto S) {
     constexpr int s_ = decltype(S)::value;
-    HTT* Ad = As + buf * A_SZ;
-    HTT* Bd = Bs + buf * B_SZ;
+    HTT* Ad = As + buf * A_BUF;
+    HTT* Bd = Bs + buf * B_BUF;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) st_kc<DT>(Ad, arow + 32 * j, kq, ra[s_][j]);
-    if (b_act) st_km<DT>(Bd, 4 * cq, kq, rb[s_]);
+    for (int j = 0; j < AJ; ++j) st_kc<DT>(Ad, A_SZ, arow + 32 * j, kq, ra[s_][j]);
+    if (b_act) st_km<DT>(Bd, B_SZ, 4 * cq, kq, rb[s_]);
   };
   auto mma = [&](int buf) {
-    mfma_stage_h<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    mfma_stage_h<DT, TM, TN>(As + buf * A_BUF, Bs + buf * B_BUF, acc, wm * (BM / 2), wn * (BN / 2), lane, A_SZ, B_SZ);
   };
   HALF_PIPELINE(PF, KT);
   // ---- epilogue through LDS (fp32), as k_conv_fwd
-  constexpr int CT = BN / 4, RSTEP = 256 / CT;
-  const int c4 = tid % CT, r0 = tid / CT;
+  constexpr int CT = BN / 4, RSTEP = NT / CT;
+  const int c4 = (int)threadIdx.x % CT, r0 = (int)threadIdx.x / CT;
   const int col = n0 + 4 * c4;
-  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  if (threadIdx.x < 256) acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
   __syncthreads();
   if (col < K) {
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -240,7 +327,7 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
 //   needs K % 32 == 0, C % 4 == 0.  A: dy gather (K-contiguous).  B: w[rs][c][k] rows (K-contiguous).
 // ============================================================================
 template <int DT, int BM, int BN, int PF>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(PF == 3 ? 512 : 256, (DT == 3 && PF != 0) ? 1 : 2)
 k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
                   const float* __restrict__ kscale, const float* __restrict__ addend, float gscale,
                   float* __restrict__ dx) {
@@ -249,10 +336,12 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
   constexpr int LDC = BN + 4;
-  __shared__ __attribute__((aligned(16))) float smem[HALF_SMEM_FLOATS(BM, BN)];
+  constexpr int NS = half_cfg<DT>::NS, NB = PF == 0 ? 1 : 2, NR = (PF == 0 || PF == 3) ? 1 : PF, NT = PF == 3 ? 512 : 256;
+  constexpr int A_BUF = NS * A_SZ, B_BUF = NS * B_SZ;
+  __shared__ __attribute__((aligned(16))) float smem[half_smem<DT, BM, BN, PF>::floats];
   HTT* const As = reinterpret_cast<HTT*>(smem);
-  HTT* const Bs = As + 2 * A_SZ;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  HTT* const Bs = As + NB * A_BUF;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // (PF == 3: producers 256..511 share the staging map)
   const int wm = wave >> 1, wn = wave & 1;
   const int M = d.N * d.H * d.W, K = d.K, C = d.C;
   const int KC = K / BK;
@@ -303,7 +392,7 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
   }
   const float* pks = kscale ? kscale + 4 * kq : lmh_zero_page;
   const int incks = kscale ? BK : 0;
-  f32x4 ra[PF][AJ], rb[PF][BJ], ks[PF];
+  f32x4 ra[NR][AJ], rb[NR][BJ], ks[NR];
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   int rs = 0, kc = 0, ptile = 0;
@@ -335,22 +424,22 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
   };
   auto store = [&](int buf, auto S) {
     constexpr int s_ = decltype(S)::value;
-    HTT* Ad = As + buf * A_SZ;
-    HTT* Bd = Bs + buf * B_SZ;
+    HTT* Ad = As + buf * A_BUF;
+    HTT* Bd = Bs + buf * B_BUF;
     const f32x4 m = kscale ? ks[s_] * gscale : f32x4{gscale, gscale, gscale, gscale};
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) st_kc<DT>(Ad, arow + 32 * j, kq, ra[s_][j] * m);
+    for (int j = 0; j < AJ; ++j) st_kc<DT>(Ad, A_SZ, arow + 32 * j, kq, ra[s_][j] * m);
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) st_kc<DT>(Bd, arow + 32 * j, kq, rb[s_][j]);
+    for (int j = 0; j < BJ; ++j) st_kc<DT>(Bd, B_SZ, arow + 32 * j, kq, rb[s_][j]);
   };
   auto mma = [&](int buf) {
-    mfma_stage_h<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    mfma_stage_h<DT, TM, TN>(As + buf * A_BUF, Bs + buf * B_BUF, acc, wm * (BM / 2), wn * (BN / 2), lane, A_SZ, B_SZ);
   };
   HALF_PIPELINE(PF, KT);
-  constexpr int CT = BN / 4, RSTEP = 256 / CT;
-  const int c4 = tid % CT, r0 = tid / CT;
+  constexpr int CT = BN / 4, RSTEP = NT / CT;
+  const int c4 = (int)threadIdx.x % CT, r0 = (int)threadIdx.x / CT;
   const int col = n0 + 4 * c4;
-  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  if (threadIdx.x < 256) acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
   __syncthreads();
   if (col < C) {
     const float inv = 1.f / gscale;
@@ -369,7 +458,7 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
 //   reduced by k_splitk_reduce).  needs C % 4 == 0, K % 4 == 0.  Both operands pixel-major -> register transposes.
 // ============================================================================
 template <int DT, int BM, int BN, int PF>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(PF == 3 ? 512 : 256, (DT == 3 && PF != 0) ? 1 : 2)
 k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ g,
                     float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh,
                     float gscale, int tiles_x, int tiles_y, int splits) {
@@ -377,10 +466,12 @@ k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* _
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
   constexpr int LDC = BN + 4;
-  __shared__ __attribute__((aligned(16))) float smem[HALF_SMEM_FLOATS(BM, BN)];
+  constexpr int NS = half_cfg<DT>::NS, NB = PF == 0 ? 1 : 2, NR = (PF == 0 || PF == 3) ? 1 : PF, NT = PF == 3 ? 512 : 256;
+  constexpr int A_BUF = NS * A_SZ, B_BUF = NS * B_SZ;
+  __shared__ __attribute__((aligned(16))) float smem[half_smem<DT, BM, BN, PF>::floats];
   HTT* const As = reinterpret_cast<HTT*>(smem);
-  HTT* const Bs = As + 2 * A_SZ;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  HTT* const Bs = As + NB * A_BUF;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // (PF == 3: producers 256..511 share the staging map)
   const int wm = wave >> 1, wn = wave & 1;
   const int P = d.N * d.OH * d.OW, K = d.K, C = d.C;
   const int lin = xcd_remap(blockIdx.x, tiles_x * tiles_y * splits);
@@ -401,7 +492,7 @@ k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* _
   const float* xb = x + m0 + 4 * cq;
   const float* gb = g + n0 + 4 * cq;
   int p0 = kt_begin * BK + 4 * kq;       // first of this thread's 4 pixels in the tile the pointers stand on
-  f32x4 ra[PF][4], rb[PF][4];
+  f32x4 ra[NR][4], rb[NR][4];
   auto step = [&]() { p0 += BK; };       // past the split's end: pixels of the next split or (>= P) the zero page
   auto load = [&](auto S) {
     constexpr int s_ = decltype(S)::value;
@@ -421,27 +512,27 @@ k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* _
   };
   auto store = [&](int buf, auto S) {
     constexpr int s_ = decltype(S)::value;
-    HTT* Ad = As + buf * A_SZ;
-    HTT* Bd = Bs + buf * B_SZ;
-    if (a_act) st_km<DT>(Ad, 4 * cq, kq, ra[s_]);
+    HTT* Ad = As + buf * A_BUF;
+    HTT* Bd = Bs + buf * B_BUF;
+    if (a_act) st_km<DT>(Ad, A_SZ, 4 * cq, kq, ra[s_]);
     if (b_act) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) rb[s_][i] *= gscale;
-      st_km<DT>(Bd, 4 * cq, kq, rb[s_]);
+      st_km<DT>(Bd, B_SZ, 4 * cq, kq, rb[s_]);
     }
   };
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   auto mma = [&](int buf) {
-    mfma_stage_h<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    mfma_stage_h<DT, TM, TN>(As + buf * A_BUF, Bs + buf * B_BUF, acc, wm * (BM / 2), wn * (BN / 2), lane, A_SZ, B_SZ);
   };
   const int n_st = kt_end - kt_begin;
   HALF_PIPELINE(PF, n_st);
-  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  if (threadIdx.x < 256) acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
   __syncthreads();
   float* o = out + (size_t)bz * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;
-  constexpr int CT = BN / 4, RSTEP = 256 / CT;
-  const int c4 = tid % CT, r0 = tid / CT;
+  constexpr int CT = BN / 4, RSTEP = NT / CT;
+  const int c4 = (int)threadIdx.x % CT, r0 = (int)threadIdx.x / CT;
   const int col = n0 + 4 * c4;
   if (col < K) {
     const float inv = 1.f / gscale;

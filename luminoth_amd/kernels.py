@@ -199,7 +199,8 @@ def same_pads(in_size, k, stride, dilation=1):
     return out, total // 2
 
 
-COMPUTE = {None: 0, 'f32': 0, 'fp32': 0, 'float32': 0, 'f16': 1, 'fp16': 1, 'float16': 1, 'bf16': 2, 'bfloat16': 2}
+COMPUTE = {None: 0, 'f32': 0, 'fp32': 0, 'float32': 0, 'f16': 1, 'fp16': 1, 'float16': 1, 'bf16': 2, 'bfloat16': 2,
+           'bf16x3': 3, 'f32x3': 3}    # bf16x3: fp32 arithmetic as an exact 3-way bf16 split, six MFMA products (conv_half.h)
 
 
 def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding='SAME', act=None, compute=None):
@@ -236,6 +237,9 @@ WINOGRAD_MIN_CK = int(os.environ.get('LUMINOTH_AMD_WINOGRAD_MIN_CK', str(256 * 2
 
 def winograd_ok(d):
     return bool(_lib.load().lmh_conv2d_winograd_ok(ctypes.byref(d)))
+
+
+X3_KEEPS_WINOGRAD = os.environ.get('LUMINOTH_AMD_X3_WINOGRAD', '1') == '1'
 
 
 def _use_winograd(d):

@@ -108,6 +108,13 @@ class ConvLayer(object):
         if d is None:
             d = K.conv_desc(x_shape, (self.k, self.k, self.cin, self.cout), self.stride, self.rate,
                             self.padding, self.act, compute)
+            if d.compute == 3 and K.X3_KEEPS_WINOGRAD:
+                # bf16x3 is fp32 arithmetic: layers the Winograd F(2x2,3x3) path takes may keep it (native fp32 GEMMs on
+                # 2.25x fewer FLOPs) — which of the two is faster per layer is a measurement
+                d0 = K.conv_desc(x_shape, (self.k, self.k, self.cin, self.cout), self.stride, self.rate,
+                                 self.padding, self.act, None)
+                if K._use_winograd(d0):
+                    d = d0
             self._desc[key] = d
         return d
 

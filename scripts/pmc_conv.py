@@ -13,7 +13,7 @@ for name, H, C, Kc, R, stride, pad in LAYERS:
         continue
     x = torch.randn(B, H, H, C, device=dev)
     w = torch.randn(R, R, C, Kc, device=dev) * 0.05
-    d = K.conv_desc(x.shape, w.shape, stride, 1, pad, 'relu')
+    d = K.conv_desc(x.shape, w.shape, stride, 1, pad, 'relu', os.environ.get('BENCH_COMPUTE') or None)
     scale = torch.ones(Kc, device=dev); shift = torch.zeros(Kc, device=dev)
     y = K.conv2d_fwd(d, x, w, scale, shift)
     gy = torch.randn_like(y); dx = torch.empty_like(x); dw = torch.empty_like(w)

@@ -1,0 +1,143 @@
+"""bf16x3: fp32 convolution arithmetic on the bf16 matrix pipe (csrc/conv_half.h, DT = 3).
+
+Every fp32 operand is split exactly into three bf16 pieces; a product is six v_mfma_f32_32x32x16_bf16 into one fp32
+accumulator.  What is pinned here:
+  * integer inputs whose products and sums stay below 2^24 reproduce the native fp32-MFMA kernels BIT FOR BIT — with
+    values that need one, two and three pieces (the third case reaches the a0*b2 / a2*b0 terms);
+  * on random data the error against a float64 reference is that of fp32 arithmetic: not worse than 2x the native
+    fp32 kernels' own error (both are ~1e-7 of the output scale; plain bf16 operands are at 1e-2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import torch_ops as ot  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+CASES = [
+    # N, H, W, C, K, R, stride, dil, padding
+    (2, 16, 16, 64, 128, 1, 1, 1, 'SAME'),
+    (1, 20, 24, 128, 64, 3, 1, 1, 'SAME'),
+    (1, 17, 19, 64, 96, 3, 2, 1, 'SAME_EXPLICIT'),
+    (1, 12, 12, 32, 256, 3, 1, 2, 'SAME'),
+    (1, 8, 8, 256, 36, 1, 1, 1, 'VALID'),
+    (2, 32, 32, 256, 256, 3, 1, 1, 'SAME'),
+    (2, 32, 32, 1024, 256, 1, 1, 1, 'SAME'),            # block3 bottleneck reduce: 32 stages
+]
+
+
+def T(a):
+    return torch.tensor(np.ascontiguousarray(a)).to('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def K():
+    from luminoth_amd import kernels
+    return kernels
+
+
+def _run_all(K, case, compute, x, w, scale, shift, res, gy, act=None, addend=True):
+    N, H, W, C, Kc, R, stride, dil, padding = case
+    d = K.conv_desc(x.shape, w.shape, stride, dil, padding, act, compute)
+    y = K.conv2d_fwd(d, T(x), T(w), T(scale), T(shift), T(res))
+    dx = K.conv2d_bwd_data(d, T(gy), T(w), T(scale), addend=T(x) if addend else None)
+    dw = K.conv2d_bwd_weight(d, T(x), T(gy))
+    return y.cpu().numpy(), dx.cpu().numpy(), dw.cpu().numpy(), d
+
+
+@pytest.mark.parametrize('mode', ['small', 'two', 'big_x', 'big_w', 'big_gy'])
+@pytest.mark.parametrize('case', CASES)
+def test_bf16x3_is_bit_exact_on_integers(K, case, mode, monkeypatch):
+    """small: every value is one bf16 piece.  two: x and gy carry 10 / 9 significant bits (two pieces on both sides of the
+    weight-gradient product).  big_*: that tensor carries 17 bits (three pieces; its partners are sparse +-1 so that
+    every sum stays an exact fp32 integer) — reaches the a2*b0 / a0*b2 terms on both operand sides of all three kernels."""
+    monkeypatch.setattr(K, 'WINOGRAD', False)
+    N, H, W, C, Kc, R, stride, dil, padding = case
+    rs = np.random.RandomState(5 + 10 * CASES.index(case) + len(mode))
+    d0 = K.conv_desc((N, H, W, C), (R, R, C, Kc), stride, dil, padding, None)
+    oshape = (N, d0.OH, d0.OW, Kc)
+
+    def ints(shape, hi, density=1.0):
+        v = rs.randint(-hi + 1, hi, size=shape)
+        return (v * (rs.rand(*shape) < density)).astype(F)
+
+    def sparse_pm1(shape):
+        return ints(shape, 2, 0.02)
+
+    scale = np.ones(Kc, F)
+    if mode == 'small':
+        x, w, gy = ints((N, H, W, C), 4), ints((R, R, C, Kc), 4), ints(oshape, 4)
+        scale = rs.randint(1, 3, size=(Kc,)).astype(F)
+    elif mode == 'two':
+        x, w, gy = ints((N, H, W, C), 1024, 0.3), ints((R, R, C, Kc), 4), ints(oshape, 512, 0.02)
+    else:
+        big = 1 << 17
+        x = ints((N, H, W, C), big) if mode == 'big_x' else sparse_pm1((N, H, W, C))
+        w = ints((R, R, C, Kc), big) if mode == 'big_w' else sparse_pm1((R, R, C, Kc))
+        gy = ints(oshape, big) if mode == 'big_gy' else sparse_pm1(oshape)
+    shift = rs.randint(-2, 3, size=(Kc,)).astype(F)
+    res = rs.randint(-4, 5, size=oshape).astype(F)
+    ref = _run_all(K, case, None, x, w, scale, shift, res, gy)
+    got = _run_all(K, case, 'bf16x3', x, w, scale, shift, res, gy)
+    assert got[3].compute == 3
+    for name, a, b in zip(('fwd', 'bwd_data', 'bwd_weight'), got[:3], ref[:3]):
+        assert np.abs(b).max() < 2 ** 24, name         # the premise: every fp32 sum is exact
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    assert np.abs(ref[0]).max() > 3 and np.abs(ref[1]).max() > 3
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_bf16x3_has_fp32_accuracy_on_random_data(K, case, monkeypatch):
+    monkeypatch.setattr(K, 'WINOGRAD', False)
+    N, H, W, C, Kc, R, stride, dil, padding = case
+    rs = np.random.RandomState(40 + CASES.index(case))
+    x = rs.randn(N, H, W, C).astype(F)
+    w = (rs.randn(R, R, C, Kc) * np.sqrt(2.0 / (R * R * C))).astype(F)
+    scale = (1 + 0.1 * rs.randn(Kc)).astype(F)
+    shift = (0.1 * rs.randn(Kc)).astype(F)
+    d0 = K.conv_desc(x.shape, w.shape, stride, dil, padding, None)
+    res = rs.randn(N, d0.OH, d0.OW, Kc).astype(F)
+    gy = (rs.randn(N, d0.OH, d0.OW, Kc) * 1e-4).astype(F)
+    # float64 reference of the three passes
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    conv = ot.conv2d_nhwc(xt, wt, stride, dil, padding)
+    y64 = (conv * torch.tensor(scale, dtype=torch.float64) + torch.tensor(shift, dtype=torch.float64) +
+           torch.tensor(res, dtype=torch.float64)).detach().numpy()
+    (conv * torch.tensor(scale, dtype=torch.float64)).backward(torch.tensor(gy, dtype=torch.float64))
+    dx64 = xt.grad.numpy()          # (no addend here: it is O(1e4) times the 1e-4-sized gradient and would set the error)
+    dw64 = wt.grad.numpy() / scale.astype(np.float64)[None, None, None, :]       # kernels return the raw (un-scaled) gradient
+    native = _run_all(K, case, None, x, w, scale, shift, res, gy, addend=False)
+    x3 = _run_all(K, case, 'bf16x3', x, w, scale, shift, res, gy, addend=False)
+    bf = _run_all(K, case, 'bf16', x, w, scale, shift, res, gy, addend=False)
+    for i, (name, truth, extra) in enumerate((('fwd', y64, res), ('bwd_data', dx64, 0.0), ('bwd_weight', dw64, 0.0))):
+        scale_ = np.abs(truth - extra).max()
+        e_native = np.abs(native[i] - truth).max() / scale_
+        e_x3 = np.abs(x3[i] - truth).max() / scale_
+        e_bf = np.abs(bf[i] - truth).max() / scale_
+        print('%-10s native fp32 %.2e   bf16x3 %.2e   bf16 %.2e' % (name, e_native, e_x3, e_bf))
+        assert e_x3 <= 2.0 * e_native + 2e-7, (name, e_x3, e_native)
+        assert e_x3 < 1e-5, (name, e_x3)
+        if not np.array_equal(bf[i], native[i]):          # (shapes off the fast path run the generic fp32 kernel in every mode)
+            assert e_bf > 100 * e_x3, (name, e_x3, e_bf)
+
+
+@pytest.mark.parametrize('keep_winograd', [True, False], ids=['winograd-layers-native', 'all-bf16x3'])
+def test_bf16x3_train_step_matches_oracle_at_the_fp32_tolerances(keep_winograd, monkeypatch):
+    """The whole ResNet-50 step with every trunk / RPN convolution in bf16x3 against the fp32 CPU oracle under the SAME
+    bounds as the native fp32 path (tests/e2e_util.py: losses 1e-4, integer stages bit-exact, every gradient element
+    within 1e-3 of its tensor's scale with pinned ReLU branches)."""
+    from e2e_util import compare_step_with_oracle, condition_like_pretrained, make_config, synth
+    from luminoth_amd import kernels as KK
+    from luminoth_amd.models import get_model
+    monkeypatch.setattr(KK, 'X3_KEEPS_WINOGRAD', keep_winograd)
+    cfg = make_config('resnet_v1_50', 80, **{'model.base_network.compute_dtype': 'bf16x3'})
+    model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_50')
+    assert model.base_network.trunk.all_layers()[5].compute == 'bf16x3' and model._rpn._rpn.compute == 'bf16x3'
+    images, gts = synth(2, 320, 384, 4, 80, 3)
+    compare_step_with_oracle(model, images, gts, 80)
