@@ -26,6 +26,9 @@ def main():
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), int(r['Queue_Id']), r['Kernel_Name']))
     rows.sort()
     ends = [i for i, r in enumerate(rows) if 'k_sgd_momentum' in r[3]]
+    if '--skip' in sys.argv:          # ignore that many steps at the end of the trace
+        skip = int(sys.argv[sys.argv.index('--skip') + 1])
+        ends = ends[:-skip] if skip else ends
     if len(ends) < 2:
         raise SystemExit('need two optimizer launches in the trace')
     lo, hi = ends[-2] + 1, ends[-1] + 1
