@@ -232,6 +232,8 @@ def main():
     from luminoth_amd.models.base import layers as L
     from luminoth_amd.utils import training as T
 
+    T.issue_from_high_priority_stream(device)      # what luminoth_amd.train.run does: critical path first at the dispatcher
+
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl['batch'] = args.batch

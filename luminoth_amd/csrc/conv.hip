@@ -141,7 +141,7 @@ static float half_gscale(const lmh_conv_desc* d) { return d->compute == 1 ? 1024
 // prefetch depth of the half-precision kernels (register sets of staged tiles).  Measured on MI355X (COCO-shape R50
 // step, f16): one set 6.82 ms/step, two sets 8.02 — the second set pushes the 128x128 kernels past 256 VGPRs (one wave
 // per SIMD instead of two), which costs more than the deeper prefetch buys.  LMH_HALF_PF=2 keeps the variant reachable.
-static const int half_pf = env_int("LMH_HALF_PF", 1) == 2 ? 2 : 1;
+static const int half_pf = env_int("LMH_HALF_PF", 1);     // 1, 2: register sets; 3, 4: warp-specialised 512-thread blocks (one / two sets)
 // bf16x3 pipeline per pass: 0 = one LDS buffer, two 256-thread blocks per CU; 1 / 2 = double-buffered LDS, one block per
 // CU, one / two register sets of prefetched tiles; 3 = warp-specialised 512-thread block (waves 4-7 split and stage tile
 // t+1 while waves 0-3 multiply tile t).  Measured per layer on MI355X (scripts/bench_conv.py, ResNet-50 shapes, sums over
@@ -190,10 +190,13 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
     half_tile(M, d->K, &bm, &bn);
     const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
 #define LAUNCH_FWD_H(DT_, BM_, BN_)                                                                       \
-    do { if (half_pf == 2) hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 2>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
+    do { if (half_pf == 4) hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 4>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y); \
+         else if (half_pf == 3) hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 3>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y); \
+         else if (half_pf == 2) hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 2>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
          else hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); } while (0)
 #define LAUNCH_FWD_HT(BM_, BN_)                                                                           \
     do { if (d->compute == 1) LAUNCH_FWD_H(1, BM_, BN_); else if (d->compute == 2) LAUNCH_FWD_H(2, BM_, BN_);                \
+         else if (x3_pf_fwd == 4) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 4>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y); \
          else if (x3_pf_fwd == 3) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 3>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y); \
          else if (x3_pf_fwd == 0) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 0>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
          else if (x3_pf_fwd == 1) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
@@ -252,9 +255,12 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
     const int gridh = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
     const float gs = half_gscale(d);
 #define LAUNCH_BD_H(DT_, BM_, BN_)                                                                        \
-    hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx)
+    do { if (half_pf == 4) hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 4>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else if (half_pf == 3) hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 3>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); } while (0)
 #define LAUNCH_BD_HT(BM_, BN_)                                                                            \
     do { if (d->compute == 1) LAUNCH_BD_H(1, BM_, BN_); else if (d->compute == 2) LAUNCH_BD_H(2, BM_, BN_);                  \
+         else if (x3_pf_bd == 4) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 4>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
          else if (x3_pf_bd == 3) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 3>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
          else if (x3_pf_bd == 0) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 0>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); \
          else if (x3_pf_bd == 1) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); \
@@ -482,12 +488,18 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     const float gs = half_gscale(d);
     const int nblk = (int)(grid.x * grid.y * grid.z);
 #define LAUNCH_BW_H(DT_, BM_, BN_)                                                                         \
-    do { if (half_pf == 2) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
+    do { if (half_pf == 4) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 4>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw,   \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+         else if (half_pf == 3) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 3>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw,   \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+         else if (half_pf == 2) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
          else hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 1>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z); } while (0)
 #define LAUNCH_BW_HT(BM_, BN_)                                                                             \
     do { if (d->compute == 1) LAUNCH_BW_H(1, BM_, BN_); else if (d->compute == 2) LAUNCH_BW_H(2, BM_, BN_);                  \
+         else if (x3_pf_bw == 4) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 4>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw, \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
          else if (x3_pf_bw == 3) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 3>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw, \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
          else if (x3_pf_bw == 0) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 0>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \

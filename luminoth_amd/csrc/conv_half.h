@@ -159,7 +159,20 @@ __device__ __forceinline__ void mfma_stage_h(const typename HT<DT>::T* __restric
   do {                                                                                              \
     typedef std::integral_constant<int, 0> S0;                                                      \
     typedef std::integral_constant<int, 1> S1;                                                      \
-    if constexpr ((PF_) == 3) { /* warp-specialised: waves 4-7 stage tile t+1 (split + LDS writes) while waves 0-3 multiply tile t */ \
+    if constexpr ((PF_) == 4) { /* warp-specialised, TWO register sets: tiles t+2 / t+3 in flight while t+1 is staged */ \
+      const bool producer_ = threadIdx.x >= 256;                                                    \
+      if (producer_) { load(S0()); store(0, S0()); step(); load(S0()); step(); load(S1()); }        \
+      __syncthreads();                                                                              \
+      for (int kt_ = 0; kt_ < (KT_); kt_ += 2) {                                                    \
+        if (producer_) { store(1, S0()); step(); load(S0()); }                                      \
+        else mma(0);                                                                                \
+        __syncthreads();                                                                            \
+        if (kt_ + 1 >= (KT_)) break;                                                                \
+        if (producer_) { store(0, S1()); step(); load(S1()); }                                      \
+        else mma(1);                                                                                \
+        __syncthreads();                                                                            \
+      }                                                                                             \
+    } else if constexpr ((PF_) == 3) { /* warp-specialised: waves 4-7 stage tile t+1 (split + LDS writes) while waves 0-3 multiply tile t */ \
       const bool producer_ = threadIdx.x >= 256;                                                    \
       if (producer_) { load(S0()); store(0, S0()); step(); load(S0()); }                            \
       __syncthreads();                                                                              \
@@ -209,7 +222,7 @@ struct half_smem {
 //   needs C % 32 == 0, K % 4 == 0.  A: gather (K-contiguous).  B: HWIO rows (K-major) -> transposed in registers.
 // ============================================================================
 template <int DT, int BM, int BN, int PF>
-__global__ void __launch_bounds__(PF == 3 ? 512 : 256, (DT == 3 && PF != 0) ? 1 : 2)
+__global__ void __launch_bounds__(PF >= 3 ? 512 : 256, (PF >= 3 || (DT == 3 && PF != 0)) ? 1 : 2)
 k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
              const float* __restrict__ scale, const float* __restrict__ shift,
              const float* __restrict__ residual, float* __restrict__ y) {
@@ -218,7 +231,7 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
   constexpr int AJ = BM / 32;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
   constexpr int LDC = BN + 4;
-  constexpr int NS = half_cfg<DT>::NS, NB = PF == 0 ? 1 : 2, NR = (PF == 0 || PF == 3) ? 1 : PF, NT = PF == 3 ? 512 : 256;
+  constexpr int NS = half_cfg<DT>::NS, NB = PF == 0 ? 1 : 2, NR = (PF == 0 || PF == 3) ? 1 : 2 - (PF == 1), NT = PF >= 3 ? 512 : 256;
   constexpr int A_BUF = NS * A_SZ, B_BUF = NS * B_SZ;
   __shared__ __attribute__((aligned(16))) float smem[half_smem<DT, BM, BN, PF>::floats];
   HTT* const As = reinterpret_cast<HTT*>(smem);       // [NB][NS][BM][LDH]
@@ -327,7 +340,7 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
 //   needs K % 32 == 0, C % 4 == 0.  A: dy gather (K-contiguous).  B: w[rs][c][k] rows (K-contiguous).
 // ============================================================================
 template <int DT, int BM, int BN, int PF>
-__global__ void __launch_bounds__(PF == 3 ? 512 : 256, (DT == 3 && PF != 0) ? 1 : 2)
+__global__ void __launch_bounds__(PF >= 3 ? 512 : 256, (PF >= 3 || (DT == 3 && PF != 0)) ? 1 : 2)
 k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
                   const float* __restrict__ kscale, const float* __restrict__ addend, float gscale,
                   float* __restrict__ dx) {
@@ -336,7 +349,7 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
   constexpr int LDC = BN + 4;
-  constexpr int NS = half_cfg<DT>::NS, NB = PF == 0 ? 1 : 2, NR = (PF == 0 || PF == 3) ? 1 : PF, NT = PF == 3 ? 512 : 256;
+  constexpr int NS = half_cfg<DT>::NS, NB = PF == 0 ? 1 : 2, NR = (PF == 0 || PF == 3) ? 1 : 2 - (PF == 1), NT = PF >= 3 ? 512 : 256;
   constexpr int A_BUF = NS * A_SZ, B_BUF = NS * B_SZ;
   __shared__ __attribute__((aligned(16))) float smem[half_smem<DT, BM, BN, PF>::floats];
   HTT* const As = reinterpret_cast<HTT*>(smem);
@@ -458,7 +471,7 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
 //   reduced by k_splitk_reduce).  needs C % 4 == 0, K % 4 == 0.  Both operands pixel-major -> register transposes.
 // ============================================================================
 template <int DT, int BM, int BN, int PF>
-__global__ void __launch_bounds__(PF == 3 ? 512 : 256, (DT == 3 && PF != 0) ? 1 : 2)
+__global__ void __launch_bounds__(PF >= 3 ? 512 : 256, (PF >= 3 || (DT == 3 && PF != 0)) ? 1 : 2)
 k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ g,
                     float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh,
                     float gscale, int tiles_x, int tiles_y, int splits) {
@@ -466,7 +479,7 @@ k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* _
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
   constexpr int LDC = BN + 4;
-  constexpr int NS = half_cfg<DT>::NS, NB = PF == 0 ? 1 : 2, NR = (PF == 0 || PF == 3) ? 1 : PF, NT = PF == 3 ? 512 : 256;
+  constexpr int NS = half_cfg<DT>::NS, NB = PF == 0 ? 1 : 2, NR = (PF == 0 || PF == 3) ? 1 : 2 - (PF == 1), NT = PF >= 3 ? 512 : 256;
   constexpr int A_BUF = NS * A_SZ, B_BUF = NS * B_SZ;
   __shared__ __attribute__((aligned(16))) float smem[half_smem<DT, BM, BN, PF>::floats];
   HTT* const As = reinterpret_cast<HTT*>(smem);

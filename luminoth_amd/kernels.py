@@ -77,15 +77,36 @@ class TailQueue(object):
     launches on the current stream.  The caller flushes after joining every stream that produced gradients and before
     anything reads them (optimizer, gradient all-reduce).  Entries keep their tensors alive until the flush."""
 
+    EARLY_MIN = int(os.environ.get('LUMINOTH_AMD_EARLY_TAILS', '8'))     # 0: only the final flush
+
     def __init__(self):
         self.active = False
         self.entries = {}      # layer key -> dict of fields
         self.order = []
+        self.early = None      # (idle stream, callable -> streams that produce gradients) while a step allows it
+        self.early_used = False
 
-    def begin(self):
-        """Start queueing (drops anything a failed step may have left behind)."""
+    def begin(self, early=None):
+        """Start queueing (drops anything a failed step may have left behind).  `early`: see maybe_flush_early."""
         self.entries, self.order = {}, []
         self.active = True
+        self.early = early if self.EARLY_MIN > 0 else None
+        self.early_used = False
+
+    def maybe_flush_early(self):
+        """The tails are HBM-bound and tiny next to the MFMA kernels still to come, so a backlog of >= EARLY_MIN layers
+        is finished right away on an otherwise IDLE stream (the proposal / RCNN stream after its branch is done), ordered
+        behind every stream that produced those gradients — instead of serially at the very end of the step, where the
+        main stream has nothing to hide them under.  The caller joins that stream before anything reads the gradients."""
+        if self.early is None or len(self.order) < self.EARLY_MIN:
+            return
+        stream, producers = self.early
+        stream.wait_stream(torch.cuda.current_stream(stream.device))
+        for st in producers():
+            stream.wait_stream(st)
+        with torch.cuda.stream(stream):
+            self.flush()
+        self.early_used = True
 
     def entry(self, key):
         e = self.entries.get(key)

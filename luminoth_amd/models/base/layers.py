@@ -425,5 +425,7 @@ class Trunk(object):
             dy_is_g = below is not None
             if hook is not None:
                 hook(nodes, j)
+            elif j > 2:
+                K.TAILS.maybe_flush_early()
         SideStream.layers_left = 0
         return dy

@@ -275,7 +275,10 @@ class FasterRCNN(object):
         aux = self._aux_stream()
         self._phase_begin()
         self.store.grad.zero_()
-        K.TAILS.begin()
+        from luminoth_amd.utils import training as _tr
+        # the aux stream is idle once the RCNN branch is done: weight-gradient tails of the trunk backward are finished
+        # there in batches while the MFMA kernels run (not with gradient buckets: those flush on their own stream)
+        K.TAILS.begin(early=None if _tr.ACTIVE_BUCKETS is not None else (aux, lambda: list(SideStream._streams.values())))
         with torch.enable_grad():
             fh, fw = self.base_network.feature_hw(H, W)
             rpn = self._rpn
@@ -347,8 +350,11 @@ class FasterRCNN(object):
             self._mark('trunk_bwd_data_done')
         SideStream.join()
         self._mark('wgrad_stream_joined')
-        K.TAILS.flush()          # every weight-gradient tail of the step (RPN, RCNN, trunk) in two launches
+        K.TAILS.flush()          # what is left of the weight-gradient tails (RPN, RCNN, trunk) in two launches
         K.TAILS.active = False
+        if K.TAILS.early_used:
+            main.wait_stream(aux)
+        K.TAILS.early = None
         self._mark('tails_done')
         rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})
         rpn_pred['num_proposals'] = prop['num_proposals']

@@ -132,6 +132,24 @@ def run(config, get_model_fn=None, get_dataset_fn=None, train_step_fn=None, max_
         if not dist.is_initialized():
             dist.init_process_group('nccl')
 
+    prev_stream = hp_stream = None
+    try:
+        import torch
+        if torch.cuda.is_available():
+            prev_stream = torch.cuda.current_stream()
+            hp_stream = training.issue_from_high_priority_stream(prev_stream.device)
+    except ImportError:
+        pass
+    try:
+        return _run(config, get_model_fn, get_dataset_fn, train_step_fn, max_steps, rank, world, is_chief, log_prefix)
+    finally:
+        if hp_stream is not None:
+            prev_stream.wait_stream(hp_stream)
+            torch.cuda.set_stream(prev_stream)
+
+
+def _run(config, get_model_fn, get_dataset_fn, train_step_fn, max_steps, rank, world, is_chief, log_prefix):
+    from luminoth_amd.utils import training
     model = get_model_fn(config.model.type)(config)
     try:
         config['dataset']['type']
