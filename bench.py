@@ -261,11 +261,14 @@ def main():
         i = counter[0]
         counter[0] += 1
         cur, nxt = batches[i % 2], batches[(i + 1) % 2]
-        return T.train_step(model, opt, cur[0], cur[1], next_image=None if args.no_lookahead else nxt[0])
+        if args.no_lookahead:
+            return T.train_step(model, opt, cur[0], cur[1])
+        return T.train_step(model, opt, cur[0], cur[1], next_image=nxt[0], next_gt=nxt[1])
 
     schedule = 'eager, three streams' + ('' if args.no_lookahead or args.serial else
-                                        '; the frozen trunk prefix (conv1 + block1) of the NEXT batch is computed while the '
-                                        'main stream waits for the RCNN branch (one prefix per step, every step)')
+                                        '; the frozen trunk prefix (conv1 + block1) and the anchor targets of the NEXT batch are computed in '
+                                        'idle slots of the step (main stream waiting for the RCNN branch / idle proposal stream): one '
+                                        'prefix and one target pass per step, every step')
     for _ in range(args.warmup):
         step_fn()
     sync()

@@ -575,8 +575,20 @@ k_conv_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __r
   // per launch for ~42 MB of operands, every XCD streaming all of x).
   const int lin = xcd_remap(blockIdx.x, tiles_x * tiles_y * splits);
   const int bz = lin / (tiles_x * tiles_y), rem = lin - bz * (tiles_x * tiles_y);
-  const int by = rem / tiles_x, bx = rem - by * tiles_x;
   const int tiles_c = (C + BM - 1) / BM;
+  int by, bx;
+  if (GB) {
+    // stacked planes are independent GEMMs: a plane's tiles stay together, so ONE XCD streams that plane's x and dy
+    // (PMC on the RPN Winograd weight gradient with the k-tile slowest: 604 MB fetched for 201 MB of operands —
+    // every k-tile row, on its own XCD, re-read all 16 x planes)
+    const int per_plane = tiles_c * tiles_y;
+    const int plane = rem / per_plane, r2 = rem - plane * per_plane;
+    by = r2 / tiles_c;
+    bx = plane * tiles_c + (r2 - by * tiles_c);
+  } else {
+    by = rem / tiles_x;
+    bx = rem - by * tiles_x;
+  }
   const int rs = bx / tiles_c, m0 = (bx % tiles_c) * BM;
   const int n0 = by * BN;
   const int r = rs / d.S, s = rs - r * d.S;

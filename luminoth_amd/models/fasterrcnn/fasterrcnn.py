@@ -244,7 +244,7 @@ class FasterRCNN(object):
             image = image.unsqueeze(0)
         return image.to(self.device, torch.float32).contiguous()
 
-    def train_step(self, image, gt_boxes, next_image=None):
+    def train_step(self, image, gt_boxes, next_image=None, next_gt=None):
         """forward + loss + backward of ONE train step (train.py:66-91), same arithmetic as
         `__call__(is_training=True)` -> `loss()` -> `backward()`, scheduled on two HIP streams:
 
@@ -269,6 +269,9 @@ class FasterRCNN(object):
         B, H, W, _ = image.shape
         gt, gt_count = self._pack_gt(gt_boxes, B)
         seeds = self._image_seeds(B)
+        pt, self._tgt_prefetch = getattr(self, '_tgt_prefetch', None), None
+        if pt is not None and not (pt['src'] is gt_boxes and pt['key'] == (self._step, B, H, W)):
+            pt = None            # another batch arrived than the one announced: compute the targets now
         self._step += 1
         im_shape = (H, W)
         main = torch.cuda.current_stream(self.device)
@@ -306,7 +309,13 @@ class FasterRCNN(object):
             for t in (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred'], feat):
                 K.keep_alive(t, aux)
             # ---- main stream: RPN targets -> RPN loss -> RPN backward
-            rpn.targets(rpn_tgt, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape)
+            if pt is not None:       # anchor targets of this batch were computed on the aux stream during the previous step
+                main.wait_event(pt['event'])
+                rpn_tgt = pt['tgt']
+                for t in rpn_tgt.values():
+                    K.keep_alive(t, main)
+            else:
+                rpn.targets(rpn_tgt, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape)
             rpn_pred.update(rpn_tgt)
             rpn_losses = rpn.loss(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
             (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss']).backward()
@@ -320,6 +329,23 @@ class FasterRCNN(object):
                 self._mark('aux:rcnn_loss_done')
                 (rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).backward()
                 self._mark('aux:rcnn_bwd_done')
+                rcnn_done = torch.cuda.Event()
+                rcnn_done.record(aux)          # the join below waits for THIS, not for what the aux stream is given next
+                # the aux stream is idle from here to the end of the step: the anchor targets of the NEXT batch (they
+                # depend on its gt boxes and this model's seeds only, not on any weight) leave the next step's critical path
+                if next_gt is not None and next_image is not None and PREFETCH_PREFIX and torch.is_tensor(next_image):
+                    nshape = tuple(next_image.shape) if next_image.dim() == 4 else (1,) + tuple(next_image.shape)
+                    Bn, Hn, Wn = nshape[0], nshape[1], nshape[2]
+                    ngt, ncnt = self._pack_gt(next_gt, Bn)
+                    nseeds = self._image_seeds(Bn)             # self._step already counts this step: the next step's seeds
+                    ntgt = {}
+                    rpn.targets(ntgt, self._anchor_ref_i32, self.base_network.feature_hw(Hn, Wn), self._anchor_stride,
+                                ngt, ncnt, nseeds, (Hn, Wn))
+                    ev = torch.cuda.Event()
+                    ev.record(aux)
+                    self._tgt_prefetch = dict(src=next_gt, key=(self._step, Bn, Hn, Wn), tgt=ntgt, event=ev,
+                                              keep=(ngt, ncnt, nseeds))
+                    self._mark('aux:next_targets_done')
             # ---- the main stream has nothing left but to wait for the RCNN branch (0.3-0.4 ms at config 2): the slot
             # for the frozen trunk prefix of the NEXT step's images (conv1 + block1: nothing this step's update writes)
             if next_image is not None and PREFETCH_PREFIX and torch.is_tensor(next_image):
@@ -328,7 +354,7 @@ class FasterRCNN(object):
                     self._prefetch = (next_image, next_image._version, nxt)
                 self._mark('next_prefix_done')
             # ---- join, trunk backward
-            main.wait_stream(aux)
+            main.wait_event(rcnn_done)
             self._mark('joined')
             for t in (f_rcnn.grad, rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']):
                 K.keep_alive(t, main)

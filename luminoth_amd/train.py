@@ -193,7 +193,8 @@ def _run(config, get_model_fn, get_dataset_fn, train_step_fn, max_steps, rank, w
         batch, nxt = nxt, next(it, None)
         before = time.time()
         if lookahead and nxt is not None:
-            total_loss, _ = train_step_fn(model, optimizer, batch['image'], batch['bboxes'], next_image=nxt['image'])
+            total_loss, _ = train_step_fn(model, optimizer, batch['image'], batch['bboxes'], next_image=nxt['image'],
+                                          next_gt=nxt['bboxes'])
         else:
             total_loss, _ = train_step_fn(model, optimizer, batch['image'], batch['bboxes'])
         train_loss = float(total_loss)          # the per-step fetch of train.py:237-239 (host sync)

@@ -332,13 +332,13 @@ def broadcast_parameters(model, src=0):
         dist.broadcast(model.store.frozen, src)
 
 
-def train_step(model, optimizer, image, gt_boxes, next_image=None):
-    """One step of train.py:66-91: forward, loss, backward, (all-reduce), update.  `next_image` (optional): the image
-    batch of the FOLLOWING step, if the caller already has it — models with a frozen trunk prefix compute that prefix
-    ahead of time in an otherwise idle slot of this step (same arithmetic; see FasterRCNN.train_step)."""
+def train_step(model, optimizer, image, gt_boxes, next_image=None, next_gt=None):
+    """One step of train.py:66-91: forward, loss, backward, (all-reduce), update.  `next_image` / `next_gt` (optional): the
+    batch of the FOLLOWING step, if the caller already has it — the model computes that batch's frozen trunk prefix and
+    anchor targets ahead of time in otherwise idle slots of this step (same arithmetic; see FasterRCNN.train_step)."""
     if FUSED_STEP and hasattr(model, 'train_step'):
         if next_image is not None and getattr(model, 'accepts_next_image', False):
-            total, pred = model.train_step(image, gt_boxes, next_image=next_image)
+            total, pred = model.train_step(image, gt_boxes, next_image=next_image, next_gt=next_gt)
         else:
             total, pred = model.train_step(image, gt_boxes)     # same arithmetic, two-stream schedule
     else:

@@ -296,15 +296,16 @@ def test_next_image_prefetch_equals_plain_steps(setup):
         ahead = []
         for i, x in enumerate(seq):
             nxt = seq[i + 1] if i + 1 < len(seq) else a
-            ahead.append(float(T.train_step(model, opt, x, gts, next_image=nxt)[0]))
+            ahead.append(float(T.train_step(model, opt, x, gts, next_image=nxt, next_gt=gts)[0]))
             assert model.base_network._prefetched is not None and model.base_network._prefetched[0] is nxt
+            assert model._tgt_prefetch is not None and model._tgt_prefetch['src'] is gts      # next step's anchor targets
         assert ahead == plain
         assert torch.equal(model.store.flat, want)
-        # announced `a`, but `b` arrives: the stale prefix must not be used
+        # announced `a` with one gt list, but `b` arrives with another list object (same values): nothing stale is used
         reset()
-        T.train_step(model, opt, a, gts, next_image=a)
-        l_b = float(T.train_step(model, opt, b, gts)[0])
-        assert model.base_network._prefetched is None
+        T.train_step(model, opt, a, gts, next_image=a, next_gt=gts)
+        l_b = float(T.train_step(model, opt, b, [g.copy() for g in gts])[0])
+        assert model.base_network._prefetched is None and model._tgt_prefetch is None
         assert l_b == plain[1]
         # announced tensor modified in place afterwards
         reset()
@@ -316,6 +317,7 @@ def test_next_image_prefetch_equals_plain_steps(setup):
         model.load_state_dict(sd0)
         model.store.mom.zero_()
         model._prefetch = None
+        model._tgt_prefetch = None
         model.base_network._prefetched = None
 
 
