@@ -400,7 +400,9 @@ k_roi_pool_mean_fwd(const float* __restrict__ feat, const float4* __restrict__ r
 
 static int roi_mean_fwd_width(int FH, int FW, int C) {
   const size_t npix = (size_t)FH * FW, lds_cap = 160 * 1024;
-  if ((C % 8) == 0 && npix * 8 * sizeof(float) <= lds_cap) return 8;
+  static const int force = getenv("LMH_ROI_MEAN_CS") ? atoi(getenv("LMH_ROI_MEAN_CS")) : -1;   // 0: report "unsupported"
+  if (force == 0) return 0;
+  if (force != 4 && (C % 8) == 0 && npix * 8 * sizeof(float) <= lds_cap) return 8;
   if ((C % 4) == 0 && npix * 4 * sizeof(float) <= lds_cap) return 4;
   return 0;
 }
