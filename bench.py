@@ -153,7 +153,7 @@ def cpu_baseline(wl, sd, steps=5):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_traffic.json, produced by
-    scripts/gpu_pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench command; the
+    scripts/gpu_evidence_profiles.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --serial`; the
     counters cannot be read from inside the process).  (None, None) if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
