@@ -317,20 +317,31 @@ class FasterRCNN(object):
             else:
                 rpn.targets(rpn_tgt, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape)
             rpn_pred.update(rpn_tgt)
-            rpn_losses = rpn.loss(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
-            (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss']).backward()
+            rpn_losses, rpn_g = rpn.loss_and_grads(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
+            rpn_loss_done = torch.cuda.Event()
+            rpn_loss_done.record(main)
+            torch.autograd.backward([rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred']],
+                                    [g.view_as(t) for g, t in zip(rpn_g, (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred']))])
             self._mark('rpn_bwd_done')
             # ---- aux stream: RCNN forward -> RCNN loss -> RCNN backward
             with torch.cuda.stream(aux):
                 self._mark('aux:rcnn_enqueue')      # later than aux:rcnn_targets_done = the host was not ahead here
                 cp = self._rcnn(f_rcnn, prop['proposals'], prop['num_proposals'], im_shape, self.base_network,
                                 gt_boxes=gt, gt_count=gt_count, seeds=seeds, is_training=True, targets=rcnn_tgt)
-                rcnn_losses = self._rcnn.loss(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
+                rcnn_losses, rcnn_g = self._rcnn.loss_and_grads(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
                 self._mark('aux:rcnn_loss_done')
-                (rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).backward()
+                torch.autograd.backward([cp['rcnn']['cls_score'], cp['rcnn']['bbox_offsets']],
+                                        [g.view_as(t) for g, t in zip(rcnn_g, (cp['rcnn']['cls_score'], cp['rcnn']['bbox_offsets']))])
                 self._mark('aux:rcnn_bwd_done')
                 rcnn_done = torch.cuda.Event()
                 rcnn_done.record(aux)          # the join below waits for THIS, not for what the aux stream is given next
+                # the loss scalars (sums, L2 regulariser: a handful of tiny launches) are only reported: they are built here,
+                # on the stream that has nothing else to do, not in front of the trunk backward
+                aux.wait_event(rpn_loss_done)
+                no_reg_loss = (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss'] +
+                               rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss'])
+                regularization_loss = self.regularization_loss()
+                total_loss = no_reg_loss + regularization_loss
                 # the aux stream is idle from here to the end of the step: the anchor targets of the NEXT batch (they
                 # depend on its gt boxes and this model's seeds only, not on any weight) leave the next step's critical path
                 if next_gt is not None and next_image is not None and PREFETCH_PREFIX and torch.is_tensor(next_image):
@@ -356,14 +367,9 @@ class FasterRCNN(object):
             # ---- join, trunk backward
             main.wait_event(rcnn_done)
             self._mark('joined')
-            for t in (f_rcnn.grad, rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']):
-                K.keep_alive(t, main)
-            # loss scalars (tiny launches) go BEFORE the trunk backward so that nothing but the optimizer is left
-            # on the main stream once the weight-gradient stream drains
-            no_reg_loss = (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss'] +
-                           rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss']).detach()
-            regularization_loss = self.regularization_loss()
-            total_loss = no_reg_loss + regularization_loss
+            K.keep_alive(f_rcnn.grad, main)
+            for t in (rpn_losses['rpn_cls_loss'], rpn_losses['rpn_reg_loss']):
+                K.keep_alive(t, aux)
             # data parallel: head gradients (RPN on main/side, RCNN joined from aux) are complete here, so the
             # gradient buckets may start all-reducing under the trunk backward (utils/training.py)
             from luminoth_amd.utils import training as _tr
@@ -378,8 +384,9 @@ class FasterRCNN(object):
         self._mark('wgrad_stream_joined')
         K.TAILS.flush()          # what is left of the weight-gradient tails (RPN, RCNN, trunk) in two launches
         K.TAILS.active = False
-        if K.TAILS.early_used:
-            main.wait_stream(aux)
+        main.wait_stream(aux)        # early tail batches and the loss scalars; long finished by now
+        for t in (total_loss, no_reg_loss, regularization_loss, rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']):
+            K.keep_alive(t, main)
         K.TAILS.early = None
         self._mark('tails_done')
         rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})

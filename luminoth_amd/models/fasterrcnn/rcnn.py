@@ -129,6 +129,16 @@ class RCNN(object):
             pred['num_objects'] = det['num_objects']
         return pred
 
+    def loss_and_grads(self, prediction_dict, w_cls=1.0, w_reg=1.0):
+        """loss() plus d(cls + reg)/d(cls_score, bbox_offsets) from the same kernel launch, outside autograd (see
+        RPN.loss_and_grads)."""
+        cs, bo = prediction_dict['rcnn']['cls_score'], prediction_dict['rcnn']['bbox_offsets']
+        losses, _, d_cls, d_off = K.rcnn_loss(cs.detach().contiguous(), bo.detach().contiguous(),
+                                              prediction_dict['target']['cls'], prediction_dict['target']['bbox_offsets'],
+                                              self._num_classes, float(self._l1_sigma), float(w_cls), float(w_reg),
+                                              want_grad=True)
+        return {'rcnn_cls_loss': losses[0], 'rcnn_reg_loss': losses[1]}, (d_cls, d_off)
+
     def loss(self, prediction_dict, w_cls=1.0, w_reg=1.0):
         """rcnn.py:255-411; batch mean over images; weights per fasterrcnn.py:194-201."""
         losses = A.RcnnLossFn.apply(prediction_dict['rcnn']['cls_score'], prediction_dict['rcnn']['bbox_offsets'],

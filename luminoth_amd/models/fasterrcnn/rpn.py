@@ -5,6 +5,7 @@ the RPN loss.  Variable names follow Sonnet: `<scope>/rpn/{conv,cls_conv,bbox_co
 import torch
 
 from luminoth_amd import autograd as A
+from luminoth_amd import kernels as K
 from luminoth_amd.models.base.layers import ConvLayer
 from luminoth_amd.models.fasterrcnn.rpn_proposal import RPNProposal
 from luminoth_amd.models.fasterrcnn.rpn_target import RPNTarget
@@ -80,6 +81,17 @@ class RPN(object):
         if gt_boxes is not None:
             self.targets(pred, anchor_ref_i32, (fh, fw), stride, gt_boxes, gt_count, seeds, im_shape)
         return pred
+
+    def loss_and_grads(self, prediction_dict, w_cls=1.0, w_reg=1.0):
+        """`loss()` without the autograd detour: the loss kernel writes d(cls + reg)/d(scores, offsets) in the same
+        launch, so the fused train step hands those straight to `torch.autograd.backward` of the head outputs instead of
+        building sum / select / ones / multiply nodes around two scalars (nine tiny launches on the critical path).
+        Returns (loss dict, (d_cls_score, d_bbox_pred)); same values as loss() + backward of the sum."""
+        cs, bp = prediction_dict['rpn_cls_score'], prediction_dict['rpn_bbox_pred']
+        losses, _, d_cls, d_bbox = K.rpn_loss(cs.detach().contiguous(), bp.detach().contiguous(),
+                                              prediction_dict['rpn_cls_target'], prediction_dict['rpn_bbox_target'],
+                                              float(self._l1_sigma), float(w_cls), float(w_reg), want_grad=True)
+        return {'rpn_cls_loss': losses[0], 'rpn_reg_loss': losses[1]}, (d_cls, d_bbox)
 
     def loss(self, prediction_dict, w_cls=1.0, w_reg=1.0):
         """rpn.py:219-309.  Returns {'rpn_cls_loss','rpn_reg_loss'} already multiplied by
