@@ -14,10 +14,10 @@ for i in (1, 2, 3):
     rows = list(csv.DictReader(open('gpurun_out/pmcx_%d/p_counter_collection.csv' % i)))
     agg = collections.defaultdict(list)
     for r in rows:
-        if 'k_conv' in r['Kernel_Name'] and 'gen' not in r['Kernel_Name']:
+        if ('k_conv' in r['Kernel_Name'] or 'k_wgrad' in r['Kernel_Name']) and 'gen' not in r['Kernel_Name']:
             agg[(r['Kernel_Name'].split('(')[0][-40:], r['Counter_Name'])].append(float(r['Counter_Value']))
     for k, v in sorted(agg.items()):
         print('%-42s %-28s n=%d mean=%.4g' % (k[0], k[1], len(v), sum(v[1:]) / max(len(v) - 1, 1)))
     kt = list(csv.DictReader(open('gpurun_out/pmcx_%d/p_kernel_trace.csv' % i)))
-    print('durations us:', [round((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, 1) for r in kt if 'k_conv' in r['Kernel_Name'] and 'gen' not in r['Kernel_Name']][:8])
+    print('durations us:', [round((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, 1) for r in kt if ('k_conv' in r['Kernel_Name'] or 'k_wgrad' in r['Kernel_Name']) and 'gen' not in r['Kernel_Name']][:8])
 PY
