@@ -41,7 +41,7 @@ class SideStream(object):
     # would idle while the side stream drains its backlog: the weight gradients of the LAST `inline_layers`
     # trainable conv layers of a trunk backward are issued on the main stream itself, behind that layer's data
     # gradient (10.43 -> 10.13 ms/step).
-    inline_layers = 4
+    inline_layers = int(os.environ.get('LUMINOTH_AMD_INLINE_LAYERS', '4'))
     layers_left = 0
     _streams = {}      # (device, issuing stream) -> stream (the fused train step issues from two streams)
 
