@@ -15,7 +15,10 @@ template <bool VEC>
 __global__ void __launch_bounds__(256)
 k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act, int64_t rows, int K,
           float* __restrict__ g, float* __restrict__ partial, int rows_per_block) {
-  __shared__ float scol[ACT_MAX_K];
+  // column partials only when asked for: DYNAMIC shared memory, so the plain g = dy * act'(y) pass (most launches: the
+  // weight-gradient kernels produce the channel sums themselves) holds no LDS and fits beside the MFMA blocks of the
+  // weight-gradient stream, whose LDS rings would otherwise cap this kernel at two blocks per CU
+  extern __shared__ float scol[];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(rows, r0 + rows_per_block);
   const float hi = (act == 2) ? 6.f : INFINITY;
@@ -129,10 +132,11 @@ extern "C" int lmh_act_bwd(const float* dy, const float* y, int act, int64_t row
     partial = reinterpret_cast<float*>(ws);
   }
   hipStream_t st = (hipStream_t)stream;
+  const size_t lds = partial ? (size_t)ACT_MAX_K * sizeof(float) : 0;
   if ((K & 3) != 0)
-    hipLaunchKernelGGL((k_act_bwd<false>), dim3(nb), dim3(256), 0, st, dy, y, act, rows, K, g, partial, rpb);
+    hipLaunchKernelGGL((k_act_bwd<false>), dim3(nb), dim3(256), lds, st, dy, y, act, rows, K, g, partial, rpb);
   else
-    hipLaunchKernelGGL((k_act_bwd<true>), dim3(nb), dim3(256), 0, st, dy, y, act, rows, K, g, partial, rpb);
+    hipLaunchKernelGGL((k_act_bwd<true>), dim3(nb), dim3(256), lds, st, dy, y, act, rows, K, g, partial, rpb);
   if (colsum && g_lmh_defer_tail) {
     g_lmh_last_plan.colpart = partial;
     g_lmh_last_plan.colrows = nb;
