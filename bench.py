@@ -192,6 +192,7 @@ def main():
                          'of the three streams ("phases" in the JSON line; Faster R-CNN workloads)')
     ap.add_argument('--no-lookahead', action='store_true',
                     help='do not tell the step which batch comes next (no cross-step prefetch of the frozen trunk prefix)')
+    ap.add_argument('--no-alt', action='store_true', help='skip the bf16x3 re-run reported as `alt_arithmetic`')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=5)
@@ -360,6 +361,38 @@ def main():
         }
         if phases:
             out['phases_ms'] = phases
+        if args.dtype == 'f32' and world == 1 and not args.no_alt and wl['model'] != 'ssd' and not args.serial:
+            # the same step with the convolutions in bf16x3 (fp32 arithmetic on the bf16 matrix pipe),
+            # measured in this process right after the headline run: reported BESIDE `value`, never as it
+            cfg2, model2 = build(wl, device, 'bf16x3')
+            opt2 = T.get_optimizer(cfg2.train, model2)
+            n2 = [0]
+
+            def step2():
+                i = n2[0]
+                n2[0] += 1
+                cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+                if args.no_lookahead:
+                    return T.train_step(model2, opt2, cur[0], cur[1])
+                return T.train_step(model2, opt2, cur[0], cur[1], next_image=nxt[0], next_gt=nxt[1])
+
+            for _ in range(args.warmup):
+                step2()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                total2, _ = step2()
+            sync()
+            dt2 = time.perf_counter() - t0
+            out['alt_arithmetic'] = {
+                'dtype': 'bf16x3', 'value': gb * args.steps / dt2, 'unit': 'images/sec',
+                'ms_per_step': 1e3 * dt2 / args.steps, 'steps': args.steps, 'warmup': args.warmup,
+                'final_total_loss': float(total2.detach()),
+                'note': 'same workload, schedule, tensors and tolerances; every fp32 convolution operand split exactly into '
+                        'three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate (bit-exact with the '
+                        'native kernels on integer data, same error against float64: tests/test_gpu_x3.py).  Not the headline: '
+                        '`value` above is the native fp32-MFMA path.'}
+            del model2, opt2
         if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
             cb = cpu_baseline(wl, sd0, args.cpu_steps)
             if cb is not None:

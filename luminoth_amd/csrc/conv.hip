@@ -143,12 +143,17 @@ static float half_gscale(const lmh_conv_desc* d) { return d->compute == 1 ? 1024
 // per SIMD instead of two), which costs more than the deeper prefetch buys.  LMH_HALF_PF=2 keeps the variant reachable.
 static const int half_pf = env_int("LMH_HALF_PF", 1);     // 1, 2: register sets; 3, 4: warp-specialised 512-thread blocks (one / two sets)
 // bf16x3 pipeline per pass: 0 = one LDS buffer, two 256-thread blocks per CU; 1 / 2 = double-buffered LDS, one block per
-// CU, one / two register sets of prefetched tiles; 3 = warp-specialised 512-thread block (waves 4-7 split and stage tile
-// t+1 while waves 0-3 multiply tile t).  Measured per layer on MI355X (scripts/bench_conv.py, ResNet-50 shapes, sums over
-// the 19 layers): forward 1.42 / 1.48 / 1.57 / 1.32 ms for 0 / 1 / 2 / 3 (native fp32 MFMA 1.59), backward data 1.28 /
-// 1.36 / 1.42 / 1.45 (1.59), weight gradient 1.69 / 1.98 / 2.00 / 1.78 (1.95).  LMH_X3_PF forces one for all passes.
+// CU, one / two register sets of prefetched tiles; 3 / 4 = warp-specialised 512-thread block (waves 4-7 split and stage
+// tile t+1 while waves 0-3 multiply tile t).  Measured per layer on MI355X (scripts/bench_conv.py, ResNet-50 shapes, sums
+// over the 19 layers): forward 1.42 / 1.48 / 1.57 / 1.32 ms for 0 / 1 / 2 / 3 (native fp32 MFMA 1.59), backward data 1.28 /
+// 1.36 / 1.42 / 1.45 (1.59), weight gradient 1.69 / 1.98 / 2.00 / 1.78 (1.95) — but INSIDE the train step, where the
+// other streams fill a CU's second block slot, the two-blocks-per-CU pipeline wins everywhere: whole step 7.19 ms with
+// 0 for every pass against 7.29 (forward 3), 7.46 (stacked Winograd GEMMs 3), 7.60 (forward + stacked 1).
+// LMH_X3_PF forces one value for all passes.
+static const int x3_tile_pick = env_int("LMH_X3_TILE_SLOTS", 256);   // tile of the bf16x3 fwd / bwd_data kernels by pick_tile(slots); 0: half_tile
 static const int x3_pf_all = env_int("LMH_X3_PF", -1);
-static const int x3_pf_fwd = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_FWD", 3);
+static const int x3_pf_fwd = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_FWD", 0);
+static const int x3_pf_gb = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_GB", 0);     // stacked Winograd GEMMs (forward kernel)
 static const int x3_pf_bd = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_BD", 0);
 static const int x3_pf_bw = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_BW", 0);
 // Tile of the half-precision kernels: they are bound by the staging path (bytes per MFMA), not by matrix-pipe rounds, so
@@ -187,7 +192,7 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
   }
   const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
   if (d->compute && fast && in_sub == nullptr) {          // f16 / bf16 operands, fp32 accumulate (conv_half.h)
-    half_tile(M, d->K, &bm, &bn);
+    if (d->compute == 3 && x3_tile_pick) pick_tile(M, d->K, &bm, &bn, x3_tile_pick); else half_tile(M, d->K, &bm, &bn);
     const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
 #define LAUNCH_FWD_H(DT_, BM_, BN_)                                                                       \
     do { if (half_pf == 4) hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 4>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y); \
@@ -251,7 +256,7 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   bwd_data_parity_tile(d, M, &bm, &bn);
   hipStream_t st = (hipStream_t)stream;
   if (d->compute && fast && !yact && !xmask) {
-    half_tile(M, d->C, &bm, &bn);                         // (no parity classes in the half kernel)
+    if (d->compute == 3 && x3_tile_pick) pick_tile(M, d->C, &bm, &bn, x3_tile_pick); else half_tile(M, d->C, &bm, &bn);   // (no parity classes here)
     const int gridh = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
     const float gs = half_gscale(d);
 #define LAUNCH_BD_H(DT_, BM_, BN_)                                                                        \
@@ -484,6 +489,27 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
   const bool fast = bwd_weight_fast(d);
   dim3 grid(d->R * d->S * ((d->C + bm - 1) / bm), (d->K + bn - 1) / bn, splits);
   const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
+  if (d->compute == 3 && fast && gb && !yact && !colsum) {      // Winograd weight gradient, 16 stacked GEMMs in bf16x3
+    const int nblk = (int)(grid.x * grid.y * grid.z);
+#define LAUNCH_BW_G(BM_, BN_)                                                                              \
+    hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 0, true>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
+                       dvh, 1.f, (int)grid.x, (int)grid.y, (int)grid.z)
+    prof_begin(st);
+    if (bm == 128 && bn == 128) LAUNCH_BW_G(128, 128);
+    else if (bm == 128) LAUNCH_BW_G(128, 64);
+    else if (bn == 128) LAUNCH_BW_G(64, 128);
+    else LAUNCH_BW_G(64, 64);
+#undef LAUNCH_BW_G
+    prof_end(st, desc_flops(d), "k_conv_bwd_weight_h<3, %d, %d, GB>", bm, bn);
+    if (splits > 1) {
+      const int64_t n = (int64_t)d->R * d->S * d->C * d->K;
+      const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
+      hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
+                         splits, dw, (const float*)nullptr, (float*)nullptr, d->K, nb_slab, 0);
+    }
+    LMH_CHECK_LAUNCH();
+    return LMH_OK;
+  }
   if (d->compute && fast && !gb && !yact && !colsum) {
     const float gs = half_gscale(d);
     const int nblk = (int)(grid.x * grid.y * grid.z);

@@ -221,11 +221,13 @@ struct half_smem {
 // forward:  y[p,k] = act( sum_{r,s,c} x[pix(p,r,s),c] * w[r,s,c,k] * scale[k] + shift[k] + res[p,k] )
 //   needs C % 32 == 0, K % 4 == 0.  A: gather (K-contiguous).  B: HWIO rows (K-major) -> transposed in registers.
 // ============================================================================
-template <int DT, int BM, int BN, int PF>
+// GB: `gbatch` independent problems of the same shape stacked in x / w / y (the 16 transformed-domain GEMMs of a Winograd
+// convolution: conv_winograd.h), one grid, plane index slowest.
+template <int DT, int BM, int BN, int PF, bool GB = false>
 __global__ void __launch_bounds__(PF >= 3 ? 512 : 256, (PF >= 3 || (DT == 3 && PF != 0)) ? 1 : 2)
 k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
              const float* __restrict__ scale, const float* __restrict__ shift,
-             const float* __restrict__ residual, float* __restrict__ y) {
+             const float* __restrict__ residual, float* __restrict__ y, int gbatch = 1) {
   typedef typename HT<DT>::T HTT;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32;
@@ -240,7 +242,14 @@ k_conv_fwd_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restri
   const int wm = wave >> 1, wn = wave & 1;
   const int M = d.N * d.OH * d.OW, K = d.K, C = d.C;
   const int tiles_n = (K + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n * (GB ? gbatch : 1));
+  if (GB) {
+    const int gi = tile / (tiles_m * tiles_n);
+    tile -= gi * (tiles_m * tiles_n);
+    x += (size_t)gi * M * C;
+    w += (size_t)gi * d.R * d.S * C * K;
+    y += (size_t)gi * M * K;
+  }
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int CC = C / BK, KT = d.R * d.S * CC;
   // ---- A gather state (as k_conv_fwd)
@@ -470,7 +479,8 @@ k_conv_bwd_data_h(lmh_conv_desc d, const float* __restrict__ dy, const float* __
 // backward weight:  dw[rs,c,k] = sum_p x[pix(p,r,s),c] * g[p,k]; reduction split over the pixels (slabs in `out`,
 //   reduced by k_splitk_reduce).  needs C % 4 == 0, K % 4 == 0.  Both operands pixel-major -> register transposes.
 // ============================================================================
-template <int DT, int BM, int BN, int PF>
+// GB: the R*S "taps" are independent GEMMs stacked in x / g (Winograd weight gradient: tap rs reads x + rs*P*C, g + rs*P*K)
+template <int DT, int BM, int BN, int PF, bool GB = false>
 __global__ void __launch_bounds__(PF >= 3 ? 512 : 256, (PF >= 3 || (DT == 3 && PF != 0)) ? 1 : 2)
 k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ g,
                     float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh,
@@ -489,8 +499,17 @@ k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* _
   const int P = d.N * d.OH * d.OW, K = d.K, C = d.C;
   const int lin = xcd_remap(blockIdx.x, tiles_x * tiles_y * splits);
   const int bz = lin / (tiles_x * tiles_y), rem = lin - bz * (tiles_x * tiles_y);
-  const int by = rem / tiles_x, bx = rem - by * tiles_x;
   const int tiles_c = (C + BM - 1) / BM;
+  int by, bx;
+  if (GB) {                                     // plane-major: one XCD streams a plane's operands once (conv_fast.h)
+    const int per_plane = tiles_c * tiles_y;
+    const int plane = rem / per_plane, r2 = rem - plane * per_plane;
+    by = r2 / tiles_c;
+    bx = plane * tiles_c + (r2 - by * tiles_c);
+  } else {
+    by = rem / tiles_x;
+    bx = rem - by * tiles_x;
+  }
   const int rs = bx / tiles_c, m0 = (bx % tiles_c) * BM;
   const int n0 = by * BN;
   const int r = rs / d.S, s = rs - r * d.S;
@@ -502,8 +521,8 @@ k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* _
   const int kq = tid & 7, cq = tid >> 3;
   const bool a_act = cq < BM / 4, b_act = cq < BN / 4;
   const bool a_ok = a_act && (m0 + 4 * cq) < C, b_ok = b_act && (n0 + 4 * cq) < K;
-  const float* xb = x + m0 + 4 * cq;
-  const float* gb = g + n0 + 4 * cq;
+  const float* xb = x + m0 + 4 * cq + (GB ? (size_t)rs * P * C : 0);
+  const float* gb = g + n0 + 4 * cq + (GB ? (size_t)rs * P * K : 0);
   int p0 = kt_begin * BK + 4 * kq;       // first of this thread's 4 pixels in the tile the pointers stand on
   f32x4 ra[NR][4], rb[NR][4];
   auto step = [&]() { p0 += BK; };       // past the split's end: pixels of the next split or (>= P) the zero page

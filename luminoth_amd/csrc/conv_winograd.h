@@ -234,7 +234,7 @@ k_wino_dw(const float* __restrict__ dU, int C, int K, float* __restrict__ dw) {
 
 // ---- host -----------------------------------------------------------------------------------------------------
 static bool wino_ok(const lmh_conv_desc* d) {
-  return d->compute == 0 && d->R == 3 && d->S == 3 && d->stride == 1 && d->dilation == 1 && d->pad_top == 1 &&
+  return (d->compute == 0 || d->compute == 3) && d->R == 3 && d->S == 3 && d->stride == 1 && d->dilation == 1 && d->pad_top == 1 &&
          d->pad_left == 1 && d->OH == d->H && d->OW == d->W && (d->C % BK) == 0 && (d->K % BK) == 0;
 }
 
@@ -262,16 +262,27 @@ static int wino_run(const lmh_conv_desc* d, const float* in, int Cg, int Kg, con
   int bm, bn;
   pick_tile((int64_t)T * 16, Kg, &bm, &bn);
   const int grid = 16 * ((T + bm - 1) / bm) * ((Kg + bn - 1) / bn);
+  const bool x3 = d->compute == 3;        // bf16x3: the 16 GEMMs on the bf16 matrix pipe (conv_half.h), transforms unchanged
 #define LAUNCH_WG(BM_, BN_)                                                                           \
-  hipLaunchKernelGGL((k_conv_fwd<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U,  \
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, 16)
+  do {                                                                                                \
+    if (x3 && x3_pf_gb == 3)                                                                          \
+      hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 3, true>), dim3(grid), dim3(512), 0, st, g, (const float*)V, U, \
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, 16);  \
+    else if (x3)                                                                                      \
+      hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 0, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U, \
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, 16);  \
+    else                                                                                              \
+      hipLaunchKernelGGL((k_conv_fwd<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U,  \
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, 16);  \
+  } while (0)
   g_prof_pending_bytes = 16.0 * 4.0 * ((double)T * Cg + (double)Cg * Kg + (double)T * Kg);
   prof_begin(st);
   if (bm == 128 && bn == 128) LAUNCH_WG(128, 128);
   else if (bm == 128) LAUNCH_WG(128, 64);
   else LAUNCH_WG(64, 64);
 #undef LAUNCH_WG
-  prof_end(st, 16.0 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd<%d, %d, true>", bm, bn);
+  if (x3) prof_end(st, 16.0 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd_h<3, %d, %d, GB>", bm, bn);
+  else prof_end(st, 16.0 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd<%d, %d, true>", bm, bn);
   {
     const int64_t n = (int64_t)T * (Kg / 4);
     hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,

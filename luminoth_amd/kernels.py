@@ -260,11 +260,14 @@ def winograd_ok(d):
     return bool(_lib.load().lmh_conv2d_winograd_ok(ctypes.byref(d)))
 
 
-X3_KEEPS_WINOGRAD = os.environ.get('LUMINOTH_AMD_X3_WINOGRAD', '1') == '1'
+# bf16x3 layers that qualify for Winograd F(2x2,3x3): '1' = run them as native fp32 Winograd (fp32 GEMMs), '3' = Winograd
+# with the 16 transformed-domain GEMMs in bf16x3, '0' = direct bf16x3 convolution
+X3_WINOGRAD_MODE = os.environ.get('LUMINOTH_AMD_X3_WINOGRAD', '3')     # measured 7.83 / 8.16 / 8.23 ms per step for '3' / '1' / '0'
 
 
 def _use_winograd(d):
-    return WINOGRAD and d.compute == 0 and d.R == 3 and d.C * d.K >= WINOGRAD_MIN_CK and winograd_ok(d)
+    return WINOGRAD and (d.compute == 0 or (d.compute == 3 and X3_WINOGRAD_MODE == '3')) and d.R == 3 and \
+        d.C * d.K >= WINOGRAD_MIN_CK and winograd_ok(d)
 
 
 def winograd_transform_weights(d, w, kscale, backward, out):
@@ -368,7 +371,7 @@ def conv2d_bwd_weight(d, x, dy, out=None, yact=None, colsum=None, defer=None):
     launched; the slabs then live in a workspace of their own (per layer) until TAILS.flush()."""
     lib = _lib.load()
     defer = defer if (defer is not None and TAILS.active and d.K % 4 == 0 and d.K <= 4096) else None
-    if yact is None and WINOGRAD and WINOGRAD_WGRAD and d.compute == 0 and d.R == 3 and \
+    if yact is None and WINOGRAD and WINOGRAD_WGRAD and (d.compute == 0 or (d.compute == 3 and X3_WINOGRAD_MODE == '3')) and d.R == 3 and \
             d.C * d.K >= WINOGRAD_WGRAD_MIN_CK and winograd_ok(d):
         if colsum is not None:                       # dbeta / dbias: one streaming pass over g
             act_bwd(dy, None, None, want_g=False, colsum=colsum, defer=defer)

@@ -108,9 +108,9 @@ class ConvLayer(object):
         if d is None:
             d = K.conv_desc(x_shape, (self.k, self.k, self.cin, self.cout), self.stride, self.rate,
                             self.padding, self.act, compute)
-            if d.compute == 3 and K.X3_KEEPS_WINOGRAD:
-                # bf16x3 is fp32 arithmetic: layers the Winograd F(2x2,3x3) path takes may keep it (native fp32 GEMMs on
-                # 2.25x fewer FLOPs) — which of the two is faster per layer is a measurement
+            if d.compute == 3 and K.X3_WINOGRAD_MODE == '1':
+                # bf16x3 is fp32 arithmetic: layers the Winograd F(2x2,3x3) path takes may run it natively (fp32 GEMMs on
+                # 2.25x fewer FLOPs) instead of with bf16x3 GEMMs (mode '3', the default) — DESIGN.md §3.4
                 d0 = K.conv_desc(x_shape, (self.k, self.k, self.cin, self.cout), self.stride, self.rate,
                                  self.padding, self.act, None)
                 if K._use_winograd(d0):

@@ -438,12 +438,17 @@ class FasterRCNN(object):
         self._phase_log, self._phase_cur = [], None
         return res
 
+    _AUX_STREAMS = {}      # device -> stream, shared by every model of the process
+
     def _aux_stream(self):
-        st = getattr(self, '_aux', None)
+        # ONE proposal / RCNN stream per device, not per model: HIP maps streams onto a handful of hardware queues, and
+        # a second model's extra streams alias the first one's (measured: the same step at 12.1 instead of 7.1 ms when a
+        # second model with its own aux stream ran in the process).  High priority: the chain is a string of small
+        # latency-bound launches; its blocks must not queue behind the CU-filling convolution grids of the other streams.
+        key = str(self.device)
+        st = FasterRCNN._AUX_STREAMS.get(key)
         if st is None:
-            # high priority: the proposal/RCNN chain is a string of small latency-bound launches; its blocks must
-            # not queue behind the CU-filling convolution grids of the main / side streams
-            st = self._aux = torch.cuda.Stream(device=self.device, priority=-1)
+            st = FasterRCNN._AUX_STREAMS[key] = torch.cuda.Stream(device=self.device, priority=-1)
         return st
 
     # --------------------------------------------------------------- variables --

@@ -17,7 +17,8 @@ for f in sorted(glob.glob('gpurun_out/ev/*.json')):
     try:
         d = json.load(open(f))
         r = d.get('roofline') or {}
-        print('%-48s %8.1f img/s %8.3f ms  %s %s frac %s  cpu %s' % (f.split('/')[-1], d['value'], d['ms_per_step'], r.get('kernel'), r.get('bound'), round(r['frac'], 3) if r else None, (d.get('cpu_baseline') or {}).get('value')))
+        a = d.get('alt_arithmetic') or {}
+        print('%-48s %8.1f img/s %8.3f ms  %s %s frac %s  cpu %s  alt %s %s' % (f.split('/')[-1], d['value'], d['ms_per_step'], r.get('kernel'), r.get('bound'), round(r['frac'], 3) if r else None, (d.get('cpu_baseline') or {}).get('value'), a.get('dtype'), round(a['value'], 1) if a else None))
     except Exception as e:
         print(f, 'FAILED', e)
 PY

@@ -127,17 +127,47 @@ def test_bf16x3_has_fp32_accuracy_on_random_data(K, case, monkeypatch):
             assert e_bf > 100 * e_x3, (name, e_x3, e_bf)
 
 
-@pytest.mark.parametrize('keep_winograd', [True, False], ids=['winograd-layers-native', 'all-bf16x3'])
-def test_bf16x3_train_step_matches_oracle_at_the_fp32_tolerances(keep_winograd, monkeypatch):
+@pytest.mark.parametrize('wino_mode', ['3', '1', '0'], ids=['winograd-gemms-bf16x3', 'winograd-layers-native', 'all-direct-bf16x3'])
+def test_bf16x3_train_step_matches_oracle_at_the_fp32_tolerances(wino_mode, monkeypatch):
     """The whole ResNet-50 step with every trunk / RPN convolution in bf16x3 against the fp32 CPU oracle under the SAME
     bounds as the native fp32 path (tests/e2e_util.py: losses 1e-4, integer stages bit-exact, every gradient element
     within 1e-3 of its tensor's scale with pinned ReLU branches)."""
     from e2e_util import compare_step_with_oracle, condition_like_pretrained, make_config, synth
     from luminoth_amd import kernels as KK
     from luminoth_amd.models import get_model
-    monkeypatch.setattr(KK, 'X3_KEEPS_WINOGRAD', keep_winograd)
+    monkeypatch.setattr(KK, 'X3_WINOGRAD_MODE', wino_mode)
     cfg = make_config('resnet_v1_50', 80, **{'model.base_network.compute_dtype': 'bf16x3'})
     model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_50')
     assert model.base_network.trunk.all_layers()[5].compute == 'bf16x3' and model._rpn._rpn.compute == 'bf16x3'
     images, gts = synth(2, 320, 384, 4, 80, 3)
     compare_step_with_oracle(model, images, gts, 80)
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 32, 256, 256), (1, 64, 64, 1024, 512), (1, 19, 23, 128, 128)])
+def test_bf16x3_inside_winograd_matches_native_winograd(K, shape, monkeypatch):
+    """LUMINOTH_AMD_X3_WINOGRAD=3: the Winograd F(2x2,3x3) transforms stay fp32, the 16 transformed-domain GEMMs (forward,
+    backward-data and weight-gradient) run as bf16x3 stacked launches.  Same results as the native fp32 Winograd path up
+    to the fp32 rounding of the GEMM (both exact-product schemes): 3e-6 of the output scale; the profile hooks confirm
+    that the stacked bf16x3 kernels are what ran."""
+    N, H, W, C, Kc = shape
+    monkeypatch.setattr(K, 'WINOGRAD', True)
+    monkeypatch.setattr(K, 'WINOGRAD_MIN_CK', 64 * 64)
+    monkeypatch.setattr(K, 'WINOGRAD_WGRAD_MIN_CK', 64 * 64)
+    monkeypatch.setattr(K, 'X3_WINOGRAD_MODE', '3')
+    rs = np.random.RandomState(77)
+    case = (N, H, W, C, Kc, 3, 1, 1, 'SAME')
+    x = rs.randn(N, H, W, C).astype(F)
+    w = (rs.randn(3, 3, C, Kc) * np.sqrt(2.0 / (9 * C))).astype(F)
+    scale = (1 + 0.1 * rs.randn(Kc)).astype(F)
+    shift = (0.1 * rs.randn(Kc)).astype(F)
+    res = rs.randn(N, H, W, Kc).astype(F)
+    gy = rs.randn(N, H, W, Kc).astype(F)
+    native = _run_all(K, case, None, x, w, scale, shift, res, gy, addend=False)
+    K._Profile.start()
+    x3 = _run_all(K, case, 'bf16x3', x, w, scale, shift, res, gy, addend=False)
+    names = set(K._Profile.stop())
+    assert any(n.startswith('k_conv_fwd_h<3') and 'GB' in n for n in names), names
+    assert any(n.startswith('k_conv_bwd_weight_h<3') and 'GB' in n for n in names), names
+    for name, a, b in zip(('fwd', 'bwd_data', 'bwd_weight'), x3[:3], native[:3]):
+        tol = 3e-6 * np.abs(b).max()
+        assert np.abs(a - b).max() <= tol, (name, float(np.abs(a - b).max()), float(tol))
