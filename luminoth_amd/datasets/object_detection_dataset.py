@@ -10,10 +10,11 @@ RandomShuffleQueue, base_dataset.py:48-76):
               --async H2D-->                                    uint8 on the device
               --lmh_resize_bilinear (flip folded in)-->         float32 (H',W',3) ready for the model
 
-so the host never touches float pixels and the flipped image is never materialised.  Hosted augmentation: `flip`
-(the Faster R-CNN default, base_config.yml:94-98); `patch`, `resize`, `distortion`, `expand`
-(utils/image.py:373-620) are not hosted and are skipped with a warning.  Shuffling is a seeded permutation per
-epoch (the reference's is a 100-record window of a queue: not reproducible, not reproduced).
+so the host never touches float pixels and the flipped image is never materialised.  Augmentation: `flip` (the Faster
+R-CNN default, base_config.yml:94-98) is folded into the resize; `patch`, `resize`, `distortion`, `expand` (the SSD
+defaults, utils/image.py:373-620) run on the decoded host image (luminoth_amd/utils/augment.py) for the records that draw
+them, in the configured order, before the upload.  Shuffling is a seeded permutation per epoch (the reference's is a
+100-record window of a queue: not reproducible, not reproduced).
 """
 import io
 import logging
@@ -24,11 +25,11 @@ import numpy as np
 import torch
 
 from luminoth_amd.datasets import tfrecord
-from luminoth_amd.utils.image import flip_bboxes, flip_image, resize_image, resize_image_fixed
+from luminoth_amd.utils import augment
+from luminoth_amd.utils.image import flip_bboxes, resize_image, resize_image_fixed
 
 log = logging.getLogger('luminoth_amd')
 
-HOSTED_AUGMENTATION = ('flip',)
 KNOWN_AUGMENTATION = ('flip', 'patch', 'resize', 'distortion', 'expand')   # object_detection_dataset.py:9-15
 
 
@@ -92,12 +93,6 @@ class ObjectDetectionDataset(object):
             opts = dict(aug_config[aug_type] or {})
             prob = float(opts.pop('prob', default_prob))
             applied = bool(self._rng.uniform() < prob)
-            if aug_type not in HOSTED_AUGMENTATION:
-                if aug_type not in self._warned:
-                    log.warning('data augmentation strategy "%s" is not hosted (CPU-side TF image ops, '
-                                'utils/image.py:373-620). Ignoring', aug_type)
-                    self._warned.add(aug_type)
-                continue
             plan.append((aug_type, applied, opts))
         return plan
 
@@ -117,11 +112,11 @@ class ObjectDetectionDataset(object):
         """object_detection_dataset.py:141-200: (image, bboxes, [{strategy: applied}, ...]) with the image
         materialised (numpy in -> numpy out, tensor in -> tensor out)."""
         plan = self._augment_decide(default_prob)
-        for aug_type, applied, opts in plan:
-            if aug_type == 'flip' and applied:
-                out = flip_image(image, bboxes, left_right=bool(opts.get('left_right', True)),
-                                 up_down=bool(opts.get('up_down', False)))
-                image, bboxes = out['image'], out.get('bboxes')
+        if torch.is_tensor(image):
+            host, bboxes = self._augment_host(image.cpu().numpy(), bboxes, plan)
+            image = torch.from_numpy(host).to(image.device)
+        else:
+            image, bboxes = self._augment_host(np.asarray(image), bboxes, plan)
         if bboxes is not None:
             bboxes = np.asarray(bboxes).astype(np.int32)
         return image, bboxes, [{t: a} for t, a, _ in plan]
@@ -136,11 +131,35 @@ class ObjectDetectionDataset(object):
                                    max_size=self._image_max_size, flip_lr=flip_lr, flip_ud=flip_ud)
         return resized['image'], resized.get('bboxes'), resized['scale_factor']
 
+    def _augment_host(self, image, bboxes, plan):
+        """The applied strategies of `plan`, in order, on a HOST image (numpy (H,W,3) uint8 or float32)."""
+        for aug_type, applied, opts in plan:
+            if not applied:
+                continue
+            if aug_type == 'flip':
+                l, u = bool(opts.get('left_right', True)), bool(opts.get('up_down', False))
+                if bboxes is not None:
+                    bboxes = flip_bboxes(bboxes, image.shape[0], image.shape[1], l, u)
+                image = image[::-1] if u else image
+                image = image[:, ::-1] if l else image
+                continue
+            out = augment.AUGMENTATIONS[aug_type](image, bboxes, rng=self._rng, **opts)
+            image, bboxes = out['image'], out.get('bboxes', bboxes)
+        return np.ascontiguousarray(image), bboxes
+
     def preprocess(self, image, bboxes=None):
         """object_detection_dataset.py:71-83: augment, then resize.  Returns (image (H',W',3) float32 on the
         device, bboxes int32 or None, {'scale_factor', 'applied_augmentations'})."""
         plan = self._augment_decide()
-        lr, ud, bboxes = self._fold_flips(plan, bboxes, image.shape[0], image.shape[1])
+        if any(applied and t != 'flip' for t, applied, _ in plan):
+            host = image.cpu().numpy() if torch.is_tensor(image) else np.asarray(image)
+            host, bboxes = self._augment_host(host, bboxes, plan)
+            lr = ud = False
+            image = torch.from_numpy(host)
+        else:
+            lr, ud, bboxes = self._fold_flips(plan, bboxes, image.shape[0], image.shape[1])
+        if torch.is_tensor(image) and not image.is_cuda and torch.cuda.is_available():
+            image = image.pin_memory().to(torch.device('cuda', torch.cuda.current_device()), non_blocking=True)
         image, bboxes, scale_factor = self._resize_image(image, bboxes, lr, ud)
         return image, bboxes, {'scale_factor': scale_factor,
                                'applied_augmentations': [{t: a} for t, a, _ in plan]}
@@ -199,8 +218,7 @@ class ObjectDetectionDataset(object):
                     pending.append(pool.submit(self.read_record, records[order[pos]]))
                     pos += 1
                 rec = pending.pop(0).result()
-                host = torch.from_numpy(rec['image'])
-                image, bboxes, meta = self.preprocess(host.pin_memory().to(device, non_blocking=True), rec['bboxes'])
+                image, bboxes, meta = self.preprocess(torch.from_numpy(rec['image']), rec['bboxes'])
                 batch.append((image, bboxes.astype(np.float32), rec['filename'], meta['scale_factor']))
                 if len(batch) == self._batch_size:
                     shapes = set(tuple(b[0].shape) for b in batch)

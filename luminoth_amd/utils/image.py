@@ -2,8 +2,8 @@
 
 Host side computes the scale factor and output size with the reference's float32 arithmetic and int32
 truncation; the pixels are resampled on the device by `lmh_resize_bilinear` (TF 1.x legacy bilinear).  The
-augmentation functions of the reference module (flip, patch, distortion, expand: image.py:150-620) are CPU-side
-training augmentation and out of scope.
+training-time augmentations of the reference module (patch, resize, distortion, expand: image.py:150-620) are host code
+in luminoth_amd/utils/augment.py; flip is folded into the device resize.
 """
 import numpy as np
 import torch

@@ -226,11 +226,13 @@ def test_flip_reference_cases_host_and_oracle():
         np.testing.assert_array_equal(flip_image(image, boxes, **kw)['image'], oi.flip_image(image, boxes, **kw)['image'])
 
 
-def test_unhosted_and_invalid_strategies_are_skipped():
+def test_invalid_strategies_are_skipped():
+    """object_detection_dataset.py:163-175: an unknown strategy is ignored with a warning; the known ones run in order
+    (a distortion with no sub-option configured changes nothing but the dtype)."""
     ds = _dataset([{'distortion': {'prob': 1.0}}, {'bogus': {}}, {'flip': {'prob': 1.0, 'left_right': False, 'up_down': True}}])
     image = np.arange(5 * 4 * 3).reshape(5, 4, 3)
     out, _, aug = ds._augment(image, None)
-    assert aug == [{'flip': True}]
+    assert aug == [{'distortion': True}, {'flip': True}]
     np.testing.assert_array_equal(out, image[::-1])
     with pytest.raises(ValueError):
         _dataset([{'flip': {}, 'patch': {}}])._augment(image, None)
