@@ -69,7 +69,10 @@ typedef struct lmh_conv_desc {
   int32_t act;
   /* Arithmetic of the MFMA operands: 0 = fp32 (v_mfma_f32_32x32x2_f32, the parity dtype), 1 = f16, 2 = bf16
    * (v_mfma_f32_32x32x16_*: operands rounded to half precision on their way into LDS, fp32 accumulation, fp32
-   * tensors in memory — BASELINE configs[4]).  Shapes the half kernels do not cover run in fp32. */
+   * tensors in memory — BASELINE configs[4]); 3 = bf16x3: fp32 ARITHMETIC on the bf16 pipe — every fp32 operand split
+   * exactly into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per fp32 product (bit-exact with mode 0 on integer
+   * data, same error against float64; also accepted by the *_winograd entry points, whose 16 stacked GEMMs then run
+   * in bf16x3).  Shapes the half kernels do not cover run in fp32. */
   int32_t compute;
 } lmh_conv_desc;
 
