@@ -366,7 +366,7 @@ static void wgrad_1x1_plan(const lmh_conv_desc* d, int* bm, int* bn, int* nbuf, 
 }
 
 extern "C" int lmh_conv2d_bwd_weight_fuses_colsum(const lmh_conv_desc* d) {
-  return d && bwd_weight_fast(d) && d->compute == 0 ? 1 : 0;
+  return d && bwd_weight_fast(d) && (d->compute == 0 || d->compute == 3) ? 1 : 0;
 }
 
 extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
@@ -510,30 +510,31 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     LMH_CHECK_LAUNCH();
     return LMH_OK;
   }
-  if (d->compute && fast && !gb && !yact && !colsum) {
+  if (d->compute && fast && !gb && !yact && (!colsum || d->compute == 3)) {
     const float gs = half_gscale(d);
+    float* cpart_h = (colsum && d->compute == 3) ? cpart : nullptr;      // fused channel sums: bf16x3 only (exact)
     const int nblk = (int)(grid.x * grid.y * grid.z);
 #define LAUNCH_BW_H(DT_, BM_, BN_)                                                                         \
     do { if (half_pf == 4) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 4>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw,   \
-                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
          else if (half_pf == 3) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 3>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw,   \
-                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
          else if (half_pf == 2) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
-                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
          else hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 1>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
-                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z); } while (0)
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h); } while (0)
 #define LAUNCH_BW_HT(BM_, BN_)                                                                             \
     do { if (d->compute == 1) LAUNCH_BW_H(1, BM_, BN_); else if (d->compute == 2) LAUNCH_BW_H(2, BM_, BN_);                  \
          else if (x3_pf_bw == 4) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 4>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw, \
-                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
          else if (x3_pf_bw == 3) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 3>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw, \
-                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
          else if (x3_pf_bw == 0) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 0>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
-                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
          else if (x3_pf_bw == 1) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 1>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
-                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z);                                    \
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
          else hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
-                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z); } while (0)
+                       dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h); } while (0)
     prof_begin(st);
     if (bm == 128 && bn == 128) LAUNCH_BW_HT(128, 128);
     else if (bm == 128) LAUNCH_BW_HT(128, 64);
@@ -545,11 +546,14 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     if (g_lmh_defer_tail) {
       g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;
       g_lmh_last_plan.splits = splits > 1 ? splits : 0;
-    } else if (splits > 1) {
-      const int64_t n = (int64_t)d->R * d->S * d->C * d->K;
-      const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
-      hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
-                         splits, dw, (const float*)nullptr, (float*)nullptr, d->K, nb_slab, 0);
+      g_lmh_last_plan.colpart = cpart_h;
+      g_lmh_last_plan.colrows = cpart_h ? splits : 0;
+    } else if (splits > 1 || cpart_h) {
+      const int64_t n = splits > 1 ? (int64_t)d->R * d->S * d->C * d->K : 0;
+      const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;
+      const int nb_col = cpart_h ? (d->K + 31) / 32 : 0;
+      hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
+                         splits, dw, (const float*)cpart_h, cpart_h ? colsum : (float*)nullptr, d->K, nb_slab, splits);
     }
     LMH_CHECK_LAUNCH();
     return LMH_OK;

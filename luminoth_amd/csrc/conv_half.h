@@ -484,7 +484,7 @@ template <int DT, int BM, int BN, int PF, bool GB = false>
 __global__ void __launch_bounds__(PF >= 3 ? 512 : 256, (PF >= 3 || (DT == 3 && PF != 0)) ? 1 : 2)
 k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ g,
                     float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh,
-                    float gscale, int tiles_x, int tiles_y, int splits) {
+                    float gscale, int tiles_x, int tiles_y, int splits, float* __restrict__ colpart = nullptr) {
   typedef typename HT<DT>::T HTT;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
@@ -555,11 +555,28 @@ k_conv_bwd_weight_h(lmh_conv_desc d, const float* __restrict__ x, const float* _
   };
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
+  // bf16x3 only: the per-channel sums of g (dbeta / dbias) from the B tile while it sits in LDS — the three pieces of an
+  // element add up to it exactly — by the blocks of ONE tile column (tap 0, first channel tile); [splits][K] partial rows
+  // in `colpart`, folded by the reduce / tail launch.  Fixed order: deterministic.
+  const bool do_col = DT == 3 && !GB && colpart != nullptr && bx == 0 && threadIdx.x < BN;
+  float csum = 0.f;
   auto mma = [&](int buf) {
+    if (do_col) {
+      const HTT* row = Bs + buf * B_BUF + (int)threadIdx.x * LDH;
+#pragma unroll
+      for (int pz = 0; pz < NS; ++pz)
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+          const typename HT<DT>::V8 v = *reinterpret_cast<const typename HT<DT>::V8*>(row + pz * B_SZ + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum += (float)v[e];
+        }
+    }
     mfma_stage_h<DT, TM, TN>(As + buf * A_BUF, Bs + buf * B_BUF, acc, wm * (BM / 2), wn * (BN / 2), lane, A_SZ, B_SZ);
   };
   const int n_st = kt_end - kt_begin;
   HALF_PIPELINE(PF, n_st);
+  if (do_col && n0 + (int)threadIdx.x < K) colpart[(size_t)bz * K + n0 + threadIdx.x] = csum / gscale;
   if (threadIdx.x < 256) acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
   __syncthreads();
   float* o = out + (size_t)bz * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;

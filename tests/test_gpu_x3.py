@@ -171,3 +171,23 @@ def test_bf16x3_inside_winograd_matches_native_winograd(K, shape, monkeypatch):
     for name, a, b in zip(('fwd', 'bwd_data', 'bwd_weight'), x3[:3], native[:3]):
         tol = 3e-6 * np.abs(b).max()
         assert np.abs(a - b).max() <= tol, (name, float(np.abs(a - b).max()), float(tol))
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_bf16x3_weight_gradient_emits_the_channel_sums(K, case, monkeypatch):
+    """The bf16x3 weight-gradient kernel adds up its g tile while it sits in LDS (three exact pieces per element): `colsum`
+    = sum over pixels of g per output channel, with and without a split-K plan, and the weight gradient itself unchanged."""
+    monkeypatch.setattr(K, 'WINOGRAD', False)
+    N, H, W, C, Kc, R, stride, dil, padding = case
+    rs = np.random.RandomState(90 + CASES.index(case))
+    x = rs.randn(N, H, W, C).astype(F)
+    d = K.conv_desc(x.shape, (R, R, C, Kc), stride, dil, padding, None, 'bf16x3')
+    gy = rs.randn(N, d.OH, d.OW, Kc).astype(F)
+    if not K.conv_fused_colsum_ok(d):
+        pytest.skip('shape off the fast path')
+    dw_plain = K.conv2d_bwd_weight(d, T(x), T(gy)).cpu().numpy()
+    cs = torch.full((Kc,), 7.0, device='cuda:0')
+    dw = K.conv2d_bwd_weight(d, T(x), T(gy), colsum=cs).cpu().numpy()
+    np.testing.assert_array_equal(dw, dw_plain)
+    want = gy.reshape(-1, Kc).astype(np.float64).sum(0)
+    np.testing.assert_allclose(cs.cpu().numpy(), want, rtol=1e-5, atol=1e-5 * np.abs(gy).sum(axis=(0, 1, 2)).max())
