@@ -36,7 +36,9 @@ class SyntheticObjectDetectionDataset(object):
                 image = torch.rand((self.batch_size, H, W, 3), generator=g) * 255.0
                 boxes = []
                 for _ in range(self.batch_size):
-                    wh = rs.randint(min(32, W // 4), max(min(512, W // 2), 33), size=(G, 2))
+                    side = min(H, W)                      # box sides between a quarter (<= 32) and half (<= 512) of the short side
+                    lo = max(1, min(32, side // 4))
+                    wh = rs.randint(lo, max(min(512, side // 2), lo + 1), size=(G, 2))
                     xy = np.stack([rs.randint(0, W - wh[:, 0]), rs.randint(0, H - wh[:, 1])], 1)
                     lab = rs.randint(0, self.num_classes, size=(G, 1))
                     boxes.append(np.concatenate([xy, xy + wh - 1, lab], 1).astype(np.float32))

@@ -128,9 +128,10 @@ def run(config, get_model_fn=None, get_dataset_fn=None, train_step_fn=None, max_
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
         if not dist.is_initialized():
-            dist.init_process_group('nccl')
+            dist.init_process_group(os.environ.get('LUMINOTH_AMD_DIST_BACKEND', 'nccl'))   # 'gloo': CPU control-flow tests
 
     prev_stream = hp_stream = None
     try:

@@ -203,3 +203,67 @@ def test_learning_rate_schedules():
         get_learning_rate(Config({'learning_rate': {'decay_method': 'bogus', 'learning_rate': 1.0}}), 0)
     with pytest.raises(ValueError):
         get_optimizer(Config({'optimizer': {'type': 'bogus'}, 'learning_rate': {}}), None)
+
+
+# ------------------------------------------------------------------------------------------------------------
+def _driver_worker(rank, world, port, tmpdir, q):
+    """luminoth_amd.train.run as one of `world` ranks (gloo, CPU): mock model / step, synthetic dataset."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LUMINOTH_AMD_DIST_BACKEND='gloo')
+    from luminoth_amd import train as T
+    from luminoth_amd.utils import training
+    from luminoth_amd.utils.config import get_config
+    seen = []
+
+    class Model(object):
+        def __init__(self, config):
+            self.w = torch.zeros(2)
+
+        def state_dict(self):
+            return {'mock/w': self.w.clone()}
+
+        def load_state_dict(self, sd, strict=True):
+            self.w = torch.as_tensor(np.asarray(sd['mock/w'])).clone()
+
+    class Opt(object):
+        global_step = 0
+
+    def step(model, optimizer, image, gt_boxes):
+        seen.append(float(image.sum()))
+        t = torch.tensor([float(image.mean())])
+        dist.all_reduce(t)                       # every rank must reach every step: a skipped step would hang here
+        model.w = model.w + t / world
+        optimizer.global_step += 1
+        return t[0], {}
+
+    training.get_optimizer = lambda cfg, model: Opt()
+    training.broadcast_parameters = lambda model: None
+    cfg = get_config({'model': {'type': 'fasterrcnn'}},
+                     ['train.num_epochs=1', 'dataset.type=synthetic', 'dataset.num_images=7', 'dataset.height=32',
+                      'dataset.width=48', 'train.save_checkpoint_secs=0', 'train.job_dir=%s' % tmpdir,
+                      'train.run_name=dp', 'train.seed=5'])
+    steps = T.run(cfg, get_model_fn=lambda t: Model, train_step_fn=step)
+    files = sorted(os.listdir(os.path.join(tmpdir, 'dp'))) if os.path.isdir(os.path.join(tmpdir, 'dp')) else []
+    q.put((rank, steps, seen, files))
+    dist.destroy_process_group()
+
+
+def test_train_driver_world2_gloo(tmp_path):
+    """`lumi train` re-host under data parallelism (train.py:282-326 replaced by one process per GPU): the 7 synthetic
+    batches are dealt rank::world and trimmed to a common length (3 steps each — no rank runs a step the other skips),
+    the shards are disjoint, and only rank 0 writes the checkpoint."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_driver_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, s0, seen0, files0), (r1, s1, seen1, files1) = res
+    assert (s0, s1) == (3, 3) and len(seen0) == len(seen1) == 3
+    assert not set(seen0) & set(seen1)                       # disjoint shards
+    assert any(f.startswith('model.ckpt-3') for f in files0) and 'checkpoint' in files0
