@@ -234,6 +234,8 @@ int lmh_rpn_target(const lmh_rpn_target_desc* d, const int32_t* anchor_ref, cons
  *   compacted rows with label >= 0, proposal order preserved:
  *   rois (B,R,4), roi_labels (B,R), roi_targets (B,R,4), roi_count (B)
  *   with R = minibatch_size (rows beyond roi_count: boxes 0, label -1).
+ * Neither P nor Gmax is bounded (the reference bounds neither): the per-proposal state sits in LDS up to 4096
+ * proposals and in `ws` beyond, gt boxes stream through LDS 128 at a time (Gmax <= 32767: int16 indices).
  */
 typedef struct lmh_rcnn_target_desc {
   int32_t B, P, Gmax, minibatch_size;
@@ -242,11 +244,12 @@ typedef struct lmh_rcnn_target_desc {
   float variance_xy, variance_wh;
 } lmh_rcnn_target_desc;
 
+size_t lmh_rcnn_target_workspace_bytes(const lmh_rcnn_target_desc* d);
 int lmh_rcnn_target(const lmh_rcnn_target_desc* d, const float* proposals,
                     const int32_t* prop_count, const float* gt, const int32_t* gt_count,
                     const uint32_t* seeds, float* labels, float* bbox_targets, float* labels_pre,
                     float* rois, float* roi_labels, float* roi_targets, int32_t* roi_count,
-                    lmh_stream_t stream);
+                    void* ws, size_t ws_bytes, lmh_stream_t stream);
 
 /* RCNNProposal._build (models/fasterrcnn/rcnn_proposal.py:46-164): per class
  * decode(variances) -> clip -> (prob >= min_prob & area > 0) -> NMS(thr, <=
@@ -273,6 +276,20 @@ int lmh_rcnn_proposal(const lmh_rcnn_proposal_desc* d, const float* proposals,
                       const int32_t* prop_count, const float* bbox_pred, const float* cls_prob,
                       float* objects, int32_t* labels, float* probs, int32_t* num_objects,
                       void* ws, size_t ws_bytes, lmh_stream_t stream);
+
+/* SSDProposal._build (models/ssd/proposal.py:41-171) with ALL five keys of its return dict (:165-171): the
+ * class-agnostic form of lmh_rcnn_proposal (d->class_agnostic_boxes must be 1; proposals = anchors (B,R,4),
+ * bbox_pred = loc_pred (B,R,4)) plus the two debug outputs:
+ *   raw_proposals (B,R,4), raw_count (B): the UNCLIPPED decode of the anchors that pass the probability filter of
+ *     the LAST class — the loop variable the reference returns after its class loop (:83,167); order preserved;
+ *   det_anchors (B,T,4): `tf.gather(proposal_anchors, top_k.indices)` (:143,162) — the top-k indices address the
+ *     concatenation of the per-class NMS-selected boxes but are applied to the concatenation of every class's
+ *     FILTERED anchors (a longer list): misaligned in the reference, restated as is. */
+size_t lmh_ssd_proposal_workspace_bytes(const lmh_rcnn_proposal_desc* d);
+int lmh_ssd_proposal(const lmh_rcnn_proposal_desc* d, const float* anchors, const int32_t* anchor_count,
+                     const float* loc_pred, const float* cls_prob, float* objects, int32_t* labels,
+                     float* probs, int32_t* num_objects, float* raw_proposals, int32_t* raw_count,
+                     float* det_anchors, void* ws, size_t ws_bytes, lmh_stream_t stream);
 
 /* ------------------------------------------------------------------ ROI --
  * ROIPoolingLayer._roi_crop (models/fasterrcnn/roi_pool.py:37-95):

@@ -116,9 +116,12 @@ SIGNATURES = {
     'lmh_nms': (c_i, [c_f, c_f, c_i, c_i, c_fl, c_i, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_rpn_target_workspace_bytes': (c_sz, [P(RpnTargetDesc)]),
     'lmh_rpn_target': (c_i, [P(RpnTargetDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
-    'lmh_rcnn_target': (c_i, [P(RcnnTargetDesc)] + [c_f] * 13),
+    'lmh_rcnn_target_workspace_bytes': (c_sz, [P(RcnnTargetDesc)]),
+    'lmh_rcnn_target': (c_i, [P(RcnnTargetDesc)] + [c_f] * 13 + [c_sz, c_f]),
     'lmh_rcnn_proposal_workspace_bytes': (c_sz, [P(RcnnProposalDesc)]),
     'lmh_rcnn_proposal': (c_i, [P(RcnnProposalDesc)] + [c_f] * 9 + [c_sz, c_f]),
+    'lmh_ssd_proposal_workspace_bytes': (c_sz, [P(RcnnProposalDesc)]),
+    'lmh_ssd_proposal': (c_i, [P(RcnnProposalDesc)] + [c_f] * 12 + [c_sz, c_f]),
     'lmh_roi_pool_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_f]),
     'lmh_roi_pool_bwd_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
     'lmh_roi_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_sz, c_f]),

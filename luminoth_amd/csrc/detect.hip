@@ -139,10 +139,10 @@ extern "C" size_t lmh_rcnn_proposal_workspace_bytes(const lmh_rcnn_proposal_desc
   return det_layout(d, nullptr).total;
 }
 
-extern "C" int lmh_rcnn_proposal(const lmh_rcnn_proposal_desc* d, const float* proposals,
-                                 const int32_t* prop_count, const float* bbox_pred, const float* cls_prob,
-                                 float* objects, int32_t* labels, float* probs, int32_t* num_objects,
-                                 void* ws, size_t ws_bytes, lmh_stream_t stream) {
+static int det_run(const lmh_rcnn_proposal_desc* d, const float* proposals,
+                   const int32_t* prop_count, const float* bbox_pred, const float* cls_prob,
+                   float* objects, int32_t* labels, float* probs, int32_t* num_objects,
+                   void* ws, size_t ws_bytes, lmh_stream_t stream) {
   LMH_CHECK_ARG(d && proposals && prop_count && bbox_pred && cls_prob && objects && labels && probs &&
                 num_objects && ws);
   LMH_CHECK_ARG(d->B > 0 && d->R > 0 && d->C > 0 && d->class_max_detections > 0 && d->total_max_detections > 0);
@@ -173,6 +173,130 @@ extern "C" int lmh_rcnn_proposal(const lmh_rcnn_proposal_desc* d, const float* p
   hipLaunchKernelGGL(k_final_gather, dim3((d->total_max_detections + 255) / 256, d->B), dim3(256), 0, st, *d,
                      Tpad, w.fkeys, w.n_total, w.keep_idx, w.sorted_src, w.sorted_boxes, cls_prob,
                      reinterpret_cast<float4*>(objects), labels, probs, num_objects);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+extern "C" int lmh_rcnn_proposal(const lmh_rcnn_proposal_desc* d, const float* proposals,
+                                 const int32_t* prop_count, const float* bbox_pred, const float* cls_prob,
+                                 float* objects, int32_t* labels, float* probs, int32_t* num_objects,
+                                 void* ws, size_t ws_bytes, lmh_stream_t stream) {
+  return det_run(d, proposals, prop_count, bbox_pred, cls_prob, objects, labels, probs, num_objects, ws, ws_bytes,
+                 stream);
+}
+
+// ---- SSDProposal's two debug outputs (models/ssd/proposal.py:143,160-171) --------------------------------------
+// 'raw_proposals': the unclipped decode of the LAST class's probability-filtered anchors (the loop variable leaks out
+// of the class loop, proposal.py:83,167), order preserved.  One 1024-thread block per image, ballot compaction.
+__global__ void __launch_bounds__(1024)
+k_ssd_raw_proposals(lmh_rcnn_proposal_desc d, const float4* __restrict__ anchors, const int32_t* __restrict__ prop_count,
+                    const float4* __restrict__ loc_pred, const float* __restrict__ cls_prob,
+                    float4* __restrict__ raw, int32_t* __restrict__ raw_count) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = min(prop_count[b], d.R);
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < d.R; r0 += 1024) {
+    const int r = r0 + tid;
+    const size_t row = (size_t)b * d.R + r;
+    bool ok = false;
+    if (r < n) ok = cls_prob[row * (d.C + 1) + d.C] >= d.min_prob_threshold;   // class C-1 -> column C
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    if (ok) {
+      const float4 a = anchors[row], dl = loc_pred[row];
+      const lmh_box o = lmh_decode(lmh_box{a.x, a.y, a.z, a.w}, dl.x, dl.y, dl.z, dl.w, d.variance_xy, d.variance_wh);
+      raw[(size_t)b * d.R + off + __popcll(bal & ((1ull << lane) - 1ull))] = make_float4(o.x1, o.y1, o.x2, o.y2);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += s_wave[w];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  for (int r = s_base + tid; r < d.R; r += 1024) raw[(size_t)b * d.R + r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid == 0) raw_count[b] = s_base;
+}
+
+// 'anchors': the reference gathers with the top-k indices — positions in the concatenation of the per-class NMS-KEPT
+// lists — from the concatenation of the per-class FILTERED anchor lists (prob >= thr and area > 0, anchor order),
+// which is a longer list (proposal.py:143 appends `proposal_anchors` un-gathered).  Restated as is: detection i with
+// concat position j receives element j of that longer list.  One wave per detection: j is located by walking the
+// classes' n_valid counts, then the q-th valid row of that class by ballot-counting 64 rows at a time.
+__global__ void __launch_bounds__(64)
+k_ssd_det_anchors(lmh_rcnn_proposal_desc d, int Tpad, const uint64_t* __restrict__ fkeys,
+                  const int32_t* __restrict__ n_total, const int32_t* __restrict__ keep_count,
+                  const int32_t* __restrict__ n_valid, const float4* __restrict__ anchors,
+                  const int32_t* __restrict__ prop_count, const float4* __restrict__ loc_pred,
+                  const float* __restrict__ cls_prob, float4* __restrict__ det_anchors) {
+  const int b = blockIdx.y, i = blockIdx.x, lane = threadIdx.x;
+  const int T = d.total_max_detections;
+  const int cnt = min(n_total[b], T);
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < cnt) {
+    const int t = (int)(fkeys[(size_t)b * Tpad + i] & 0xFFFFFFFFull);
+    const int cmax = d.class_max_detections;
+    const int c = t / cmax, slot = t % cmax;
+    int j = slot;
+    for (int cc = 0; cc < c; ++cc) j += keep_count[b * d.C + cc];
+    int cls = 0;
+    while (cls < d.C - 1 && j >= n_valid[b * d.C + cls]) { j -= n_valid[b * d.C + cls]; ++cls; }
+    const int n = min(prop_count[b], d.R);
+    for (int r0 = 0; r0 < n; r0 += 64) {       // uniform across the wave
+      const int r = r0 + lane;
+      bool ok = false;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < n) {
+        const size_t row = (size_t)b * d.R + r;
+        a = anchors[row];
+        const float4 dl = loc_pred[row];
+        lmh_box o = lmh_decode(lmh_box{a.x, a.y, a.z, a.w}, dl.x, dl.y, dl.z, dl.w, d.variance_xy, d.variance_wh);
+        o = lmh_clip(o, d.im_h, d.im_w);
+        ok = (cls_prob[row * (d.C + 1) + cls + 1] >= d.min_prob_threshold) &&
+             (fmaxf(o.x2 - o.x1, 0.f) * fmaxf(o.y2 - o.y1, 0.f) > 0.f);
+      }
+      const unsigned long long bal = __ballot(ok);
+      const int here = __popcll(bal);
+      if (j < here) {
+        const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+        if (ok && rank == j) det_anchors[(size_t)b * T + i] = a;
+        return;
+      }
+      j -= here;
+    }
+    return;   // unreachable: j < total valid rows
+  }
+  if (lane == 0) det_anchors[(size_t)b * T + i] = out;
+}
+
+extern "C" size_t lmh_ssd_proposal_workspace_bytes(const lmh_rcnn_proposal_desc* d) {
+  return lmh_rcnn_proposal_workspace_bytes(d);
+}
+
+extern "C" int lmh_ssd_proposal(const lmh_rcnn_proposal_desc* d, const float* anchors, const int32_t* anchor_count,
+                                const float* loc_pred, const float* cls_prob, float* objects, int32_t* labels,
+                                float* probs, int32_t* num_objects, float* raw_proposals, int32_t* raw_count,
+                                float* det_anchors, void* ws, size_t ws_bytes, lmh_stream_t stream) {
+  LMH_CHECK_ARG(d && d->class_agnostic_boxes == 1 && raw_proposals && raw_count && det_anchors);
+  int rc = det_run(d, anchors, anchor_count, loc_pred, cls_prob, objects, labels, probs, num_objects, ws, ws_bytes,
+                   stream);
+  if (rc) return rc;
+  det_ws w = det_layout(d, ws);
+  hipStream_t st = (hipStream_t)stream;
+  const int Tpad = lmh_next_pow2(d->C * d->class_max_detections);
+  hipLaunchKernelGGL(k_ssd_raw_proposals, dim3(d->B), dim3(1024), 0, st, *d, reinterpret_cast<const float4*>(anchors),
+                     anchor_count, reinterpret_cast<const float4*>(loc_pred), cls_prob,
+                     reinterpret_cast<float4*>(raw_proposals), raw_count);
+  hipLaunchKernelGGL(k_ssd_det_anchors, dim3(d->total_max_detections, d->B), dim3(64), 0, st, *d, Tpad, w.fkeys,
+                     w.n_total, w.keep_count, w.n_valid, reinterpret_cast<const float4*>(anchors), anchor_count,
+                     reinterpret_cast<const float4*>(loc_pred), cls_prob, reinterpret_cast<float4*>(det_anchors));
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

@@ -236,13 +236,14 @@ k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts,
 #define NMS_RED_THREADS 1024
 #define NMS_SC_WORDS 16
 #define NMS_LDS_KEEP 2048
-#define NMS_MAX_W 512  // K <= 32768 candidates
+#define NMS_MAX_K (64 * 65535)  // grid.y of k_nms_mask; the mask itself is K*K/8 bytes of the caller's workspace
 __global__ void __launch_bounds__(NMS_RED_THREADS)
 k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts, int K, int W,
-             int max_out, int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count, int dbg) {
+             int max_out, int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ __attribute__((aligned(16))) unsigned long long rem[NMS_SC_WORDS];
-  __shared__ int s_total;
+  __shared__ int s_tot[NMS_SC_WORDS];          // running total AFTER chunk c of the current super-chunk (one slot per chunk:
+                                               // no slot is rewritten before every wave has read it and passed a barrier)
   __shared__ int32_t s_kidx[NMS_LDS_KEEP];     // LDS mirror of the kept indices (one global latency less in (2))
   const bool lds_keep = max_out <= NMS_LDS_KEEP;
   const int b = blockIdx.x;
@@ -251,8 +252,7 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
   const uint64_t* mb = mask + (size_t)b * K * W;
   int32_t* kidx = keep_idx + (size_t)b * max_out;
   for (int i = tid; i < max_out; i += NMS_RED_THREADS) kidx[i] = -1;
-  if (tid == 0) s_total = 0;
-  __syncthreads();
+  int total = 0;                               // block-uniform copy of the running total
   const int nchunks = (cnt + 63) / 64;                       // mask words >= nchunks were never written
   const int nsc = (nchunks + NMS_SC_WORDS - 1) / NMS_SC_WORDS;
   for (int sc = 0; sc < nsc; ++sc) {
@@ -263,13 +263,13 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
     uint64_t d[NMS_SC_WORDS];
 #pragma unroll
     for (int j = 0; j < NMS_SC_WORDS; ++j) {
-      const bool ok = row < cnt && j < nw && (w0 + j) >= (row >> 6) && !(dbg & 1);
+      const bool ok = row < cnt && j < nw && (w0 + j) >= (row >> 6);
       d[j] = ok ? mb[(size_t)row * W + w0 + j] : 0ull;
     }
     // (2) removed-words of this super-chunk from every row kept so far (rows < r0: all their words here are valid)
     if (tid < NMS_SC_WORDS) rem[tid] = 0ull;
     __syncthreads();
-    const int nkept = (dbg & 2) ? 0 : s_total;
+    const int nkept = total;
     for (int i0 = tid; i0 < nkept * NMS_SC_WORDS; i0 += 4 * NMS_RED_THREADS) {
       uint64_t v[4];
       int wj[4];
@@ -311,11 +311,11 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
           if (next == kept) break;
           kept = next;
         }
-        const int base = __builtin_amdgcn_readfirstlane(s_total);
+        const int base = total;
         const int room = max_out - base;
         if (__popcll(kept) > room)                      // the scan stops at max_out: keep the first `room` of them
           kept = __ballot(((kept >> lane) & 1ull) && __popcll(kept & below) < room);
-        const int total = base + __popcll(kept);
+        const int new_total = base + __popcll(kept);
         if ((kept >> lane) & 1ull) {
           const int slot = base + __popcll(kept & ((1ull << lane) - 1ull));
           kidx[slot] = (w0 + c) * 64 + lane;              // kept indices, in order
@@ -324,17 +324,18 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
           for (int j = 0; j < NMS_SC_WORDS; ++j)          // suppress later candidates of this super-chunk
             if (j > c && d[j]) atomicOr(&rem[j], (unsigned long long)d[j]);
         }
-        if (lane == 0) s_total = total;
+        if (lane == 0) s_tot[c] = new_total;
       }
       __syncthreads();
-      if (s_total >= max_out) { done = true; break; }
+      total = s_tot[c];
+      if (total >= max_out) { done = true; break; }
     }
     if (done) break;
     // the kept indices written above are read back (kidx) by the next super-chunk's gather: same block, global memory
     __threadfence_block();
     __syncthreads();
   }
-  if (tid == 0) keep_count[b] = s_total;
+  if (tid == 0) keep_count[b] = total;
 }
 
 extern "C" size_t lmh_nms_workspace_bytes(int B, int K) {
@@ -344,15 +345,14 @@ extern "C" size_t lmh_nms_workspace_bytes(int B, int K) {
 
 int lmh_nms_impl(const float* boxes, const int32_t* counts, int B, int K, float thr, int max_out,
                     int32_t* keep_idx, int32_t* keep_count, void* ws, hipStream_t st) {
-  LMH_CHECK_ARG(K > 0 && K <= 64 * NMS_MAX_W);   // k_nms_reduce keeps the removed-bitmap in static LDS
+  LMH_CHECK_ARG(K > 0 && K <= NMS_MAX_K);
   const int W = (K + 63) / 64;
   uint64_t* mask = reinterpret_cast<uint64_t*>(ws);
   dim3 g(W, W, B);
   hipLaunchKernelGGL(k_nms_mask, g, dim3(64), 0, st, reinterpret_cast<const float4*>(boxes), counts,
                      K, W, thr, mask);
-  static const int dbg = getenv("LMH_NMS_DBG") ? atoi(getenv("LMH_NMS_DBG")) : 0;   // timing ablations only (wrong results)
   hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts,
-                     K, W, max_out, keep_idx, keep_count, dbg);
+                     K, W, max_out, keep_idx, keep_count);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -361,7 +361,7 @@ extern "C" int lmh_nms(const float* boxes, const int32_t* counts, int B, int K, 
                        int max_out, int32_t* keep_idx, int32_t* keep_count, void* ws,
                        size_t ws_bytes, lmh_stream_t stream) {
   LMH_CHECK_ARG(boxes && counts && keep_idx && keep_count && ws);
-  LMH_CHECK_ARG(B > 0 && K > 0 && max_out > 0 && K <= 64 * NMS_MAX_W);
+  LMH_CHECK_ARG(B > 0 && K > 0 && max_out > 0 && K <= NMS_MAX_K);
   if (ws_bytes < lmh_nms_workspace_bytes(B, K)) {
     lmh_set_error("lmh_nms: workspace %zu < %zu", ws_bytes, lmh_nms_workspace_bytes(B, K));
     return LMH_ERR_WORKSPACE;
@@ -453,7 +453,7 @@ extern "C" int lmh_rpn_proposal(const lmh_rpn_proposal_desc* d, const float* cls
   LMH_CHECK_ARG(d && cls_score && bbox_pred && anchor_ref && cls_prob && proposals && scores &&
                 num_proposals && ws);
   LMH_CHECK_ARG(d->B > 0 && d->feat_h > 0 && d->feat_w > 0 && d->A > 0);
-  LMH_CHECK_ARG(d->pre_nms_top_n > 0 && d->post_nms_top_n > 0 && d->pre_nms_top_n <= 64 * NMS_MAX_W);
+  LMH_CHECK_ARG(d->pre_nms_top_n > 0 && d->post_nms_top_n > 0 && d->pre_nms_top_n <= NMS_MAX_K);
   const int N = d->feat_h * d->feat_w * d->A;
   const int Npad = lmh_next_pow2(N);
   rpn_prop_ws w = rpn_prop_layout(d, ws);

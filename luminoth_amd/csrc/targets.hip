@@ -91,41 +91,47 @@ k_rpn_target_rowmax(lmh_rpn_target_desc d, int N, const int32_t* __restrict__ an
   __shared__ uint32_t scolmax[RT_MAX_G];
   const int b = blockIdx.y;
   const int G = min(gt_count[b], d.Gmax);
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    const float* p = gt + ((size_t)b * d.Gmax + g) * 5;
-    lmh_box bx = {p[0], p[1], p[2], p[3]};
-    sgt[g] = bx;
-    sarea[g] = lmh_area_plus1(bx);
-    scolmax[g] = 0u;
-  }
-  __syncthreads();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t a4[4] = {0, 0, 0, 0};
+  bool inside = false;
   if (n < N) {
-    int32_t a4[4];
     lmh_anchor(anchor_ref, n, d.A, d.feat_w, d.anchor_stride, a4);
     const int bd = d.allowed_border;
-    const bool inside = a4[0] >= -bd && a4[1] >= -bd && a4[2] < d.im_w + bd && a4[3] < d.im_h + bd;
-    float best = 0.f;
-    int besti = -1;  // -1 == outside the image
+    inside = a4[0] >= -bd && a4[1] >= -bd && a4[2] < d.im_w + bd && a4[3] < d.im_h + bd;
+  }
+  const lmh_box a = {(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+  const float aa = lmh_area_plus1(a);
+  float best = inside ? -1.f : 0.f;
+  int besti = inside ? 0 : -1;  // -1 == outside the image
+  // the reference has no bound on the number of gt boxes (rpn_target.py:137): they pass through LDS RT_MAX_G at a time
+  for (int g0 = 0; g0 < G; g0 += RT_MAX_G) {
+    const int gn = min(RT_MAX_G, G - g0);
+    if (g0) __syncthreads();
+    for (int g = threadIdx.x; g < gn; g += blockDim.x) {
+      const float* p = gt + ((size_t)b * d.Gmax + g0 + g) * 5;
+      lmh_box bx = {p[0], p[1], p[2], p[3]};
+      sgt[g] = bx;
+      sarea[g] = lmh_area_plus1(bx);
+      scolmax[g] = 0u;
+    }
+    __syncthreads();
     if (inside) {
-      const lmh_box a = {(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
-      const float aa = lmh_area_plus1(a);
-      besti = 0;
-      best = -1.f;
-      for (int g = 0; g < G; ++g) {
+      for (int g = 0; g < gn; ++g) {
         const float iou = lmh_iou_plus1(a, aa, sgt[g], sarea[g]);
-        if (iou > best) { best = iou; besti = g; }  // first occurrence of the max (tf.argmax)
+        if (iou > best) { best = iou; besti = g0 + g; }  // first occurrence of the max (tf.argmax)
         const uint32_t bits = __float_as_uint(iou);  // iou >= 0: uint order == float order
         if (bits > scolmax[g]) atomicMax(&scolmax[g], bits);
       }
-      if (G == 0) best = 0.f;
     }
+    __syncthreads();
+    for (int g = threadIdx.x; g < gn; g += blockDim.x)
+      if (scolmax[g]) atomicMax(&gt_max_bits[(size_t)b * d.Gmax + g0 + g], scolmax[g]);
+  }
+  if (n < N) {
+    if (G == 0) best = 0.f;
     max_overlaps[(size_t)b * N + n] = inside ? best : 0.f;
     argmax[(size_t)b * N + n] = besti;
   }
-  __syncthreads();
-  for (int g = threadIdx.x; g < G; g += blockDim.x)
-    if (scolmax[g]) atomicMax(&gt_max_bits[(size_t)b * d.Gmax + g], scolmax[g]);
 }
 
 // kernel B: labels before subsampling (rpn_target.py:142-202)
@@ -141,29 +147,35 @@ k_rpn_target_labels(lmh_rpn_target_desc d, int N, const int32_t* __restrict__ an
   __shared__ float scolmax[RT_MAX_G];
   const int b = blockIdx.y;
   const int G = min(gt_count[b], d.Gmax);
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    const float* p = gt + ((size_t)b * d.Gmax + g) * 5;
-    lmh_box bx = {p[0], p[1], p[2], p[3]};
-    sgt[g] = bx;
-    sarea[g] = lmh_area_plus1(bx);
-    scolmax[g] = __uint_as_float(gt_max_bits[(size_t)b * d.Gmax + g]);
-  }
-  __syncthreads();
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
   const size_t row = (size_t)b * N + n;
+  const bool live = n < N && argmax[row] >= 0;      // inside the image
+  int32_t a4[4] = {0, 0, 0, 0};
+  if (live) lmh_anchor(anchor_ref, n, d.A, d.feat_w, d.anchor_stride, a4);
+  const lmh_box a = {(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
+  const float aa = lmh_area_plus1(a);
+  bool is_gt_argmax = false;
+  for (int g0 = 0; g0 < G; g0 += RT_MAX_G) {        // gt boxes pass through LDS RT_MAX_G at a time (no bound on G)
+    const int gn = min(RT_MAX_G, G - g0);
+    if (g0) __syncthreads();
+    for (int g = threadIdx.x; g < gn; g += blockDim.x) {
+      const float* p = gt + ((size_t)b * d.Gmax + g0 + g) * 5;
+      lmh_box bx = {p[0], p[1], p[2], p[3]};
+      sgt[g] = bx;
+      sarea[g] = lmh_area_plus1(bx);
+      scolmax[g] = __uint_as_float(gt_max_bits[(size_t)b * d.Gmax + g0 + g]);
+    }
+    __syncthreads();
+    if (live)
+      for (int g = 0; g < gn; ++g)
+        is_gt_argmax |= (lmh_iou_plus1(a, aa, sgt[g], sarea[g]) == scolmax[g]);
+  }
+  if (n >= N) return;
   float label = -1.f;
-  if (argmax[row] >= 0) {
+  if (live) {
     const float mo = max_overlaps[row];
     const bool neg = mo < d.background_threshold_high;
     if (!d.clobber_positives && neg) label = 0.f;
-    int32_t a4[4];
-    lmh_anchor(anchor_ref, n, d.A, d.feat_w, d.anchor_stride, a4);
-    const lmh_box a = {(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]};
-    const float aa = lmh_area_plus1(a);
-    bool is_gt_argmax = false;
-    for (int g = 0; g < G; ++g)
-      is_gt_argmax |= (lmh_iou_plus1(a, aa, sgt[g], sarea[g]) == scolmax[g]);
     if (is_gt_argmax) label = 1.f;
     if (mo >= d.foreground_threshold) label = 1.f;
     if (d.clobber_positives && neg) label = 0.f;
@@ -337,7 +349,7 @@ extern "C" int lmh_rpn_target(const lmh_rpn_target_desc* d, const int32_t* ancho
                               size_t ws_bytes, lmh_stream_t stream) {
   LMH_CHECK_ARG(d && anchor_ref && gt && gt_count && seeds && labels && bbox_targets && max_overlaps && ws);
   LMH_CHECK_ARG(d->B > 0 && d->A > 0 && d->feat_h > 0 && d->feat_w > 0);
-  LMH_CHECK_ARG(d->Gmax > 0 && d->Gmax <= RT_MAX_G);
+  LMH_CHECK_ARG(d->Gmax > 0);
   if (ws_bytes < lmh_rpn_target_workspace_bytes(d)) {
     lmh_set_error("lmh_rpn_target: workspace too small");
     return LMH_ERR_WORKSPACE;
@@ -364,11 +376,25 @@ extern "C" int lmh_rpn_target(const lmh_rpn_target_desc* d, const int32_t* ancho
 }
 
 // ---------------------------------------------------------------------------
-// RCNN target: one 1024-thread block per image does everything in LDS.
+// RCNN target: one 1024-thread block per image.  Per-proposal state (label, best gt, "is the best proposal of gt g",
+// fg condition) lives in LDS for P <= CT_LDS_MAX_P — every default configuration — and in the caller's workspace
+// beyond; gt boxes pass through LDS RT_MAX_G at a time.  The reference bounds neither (rcnn_target.py:48-66).
 // ---------------------------------------------------------------------------
 #define CT_THREADS 1024
-#define CT_MAX_P 4096
+#define CT_LDS_MAX_P 4096
+#define CT_MAX_G 32767   // best-gt indices are int16
 
+struct ct_state {
+  float* lab; int16_t* bestgt; int16_t* bestg_of_p; uint8_t* fg;
+};
+
+#define CT_A16(x) ((((size_t)(x)) + 15) / 16 * 16)
+static __host__ __device__ inline size_t ct_ws_per_image(int P) {
+  // [carry IoU: P f32][lab: P f32][bestgt: P i16][bestg_of_p: P i16][fg: P u8]
+  return CT_A16((size_t)P * 4) + CT_A16((size_t)P * 4) + 2 * CT_A16((size_t)P * 2) + CT_A16(P);
+}
+
+template <bool WS_STATE>
 __global__ void __launch_bounds__(CT_THREADS)
 k_rcnn_target(lmh_rcnn_target_desc d, const float* __restrict__ proposals,
               const int32_t* __restrict__ prop_count, const float* __restrict__ gt,
@@ -376,16 +402,15 @@ k_rcnn_target(lmh_rcnn_target_desc d, const float* __restrict__ proposals,
               float* __restrict__ labels, float* __restrict__ bbox_targets,
               float* __restrict__ labels_pre, float* __restrict__ rois,
               float* __restrict__ roi_labels, float* __restrict__ roi_targets,
-              int32_t* __restrict__ roi_count) {
+              int32_t* __restrict__ roi_count, unsigned char* __restrict__ ws) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ lmh_box sgt[RT_MAX_G];
   __shared__ float sarea[RT_MAX_G];
-  __shared__ float sglabel[RT_MAX_G];
   __shared__ unsigned long long sbest[RT_MAX_G];  // (iou_bits << 32) | ~p : max == best, first p
-  __shared__ float slab[CT_MAX_P];
-  __shared__ int16_t sbestgt[CT_MAX_P];
-  __shared__ int16_t sbestg_of_p[CT_MAX_P];  // max g whose best proposal is p, or -1
-  __shared__ uint8_t sfgcond[CT_MAX_P];
+  __shared__ float l_lab[WS_STATE ? 1 : CT_LDS_MAX_P];
+  __shared__ int16_t l_bestgt[WS_STATE ? 1 : CT_LDS_MAX_P];
+  __shared__ int16_t l_bestg_of_p[WS_STATE ? 1 : CT_LDS_MAX_P];  // max g whose best proposal is p, or -1
+  __shared__ uint8_t l_fg[WS_STATE ? 1 : CT_LDS_MAX_P];
   __shared__ uint32_t hist[256];
   __shared__ uint32_t eq_list[LMH_SELECT_MAX_EQ];
   __shared__ uint32_t bc[4];
@@ -396,51 +421,75 @@ k_rcnn_target(lmh_rcnn_target_desc d, const float* __restrict__ proposals,
   const int G = min(gt_count[b], d.Gmax);
   const uint32_t seed = seeds[b];
   const float4* props = reinterpret_cast<const float4*>(proposals) + (size_t)b * d.P;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    const float* p = gt + ((size_t)b * d.Gmax + g) * 5;
-    lmh_box bx = {p[0], p[1], p[2], p[3]};
-    sgt[g] = bx;
-    sarea[g] = lmh_area_plus1(bx);
-    sglabel[g] = p[4];
-    sbest[g] = 0ull;
+  const float* gtb = gt + (size_t)b * d.Gmax * 5;
+  unsigned char* wsb = ws + (size_t)b * ct_ws_per_image(d.P);
+  float* carry = reinterpret_cast<float*>(wsb);     // running row max between gt chunks (only touched when G > RT_MAX_G)
+  float* slab;
+  int16_t* sbestgt;
+  int16_t* sbestg_of_p;
+  uint8_t* sfgcond;
+  if (WS_STATE) {
+    unsigned char* q = wsb + CT_A16((size_t)d.P * 4);
+    slab = reinterpret_cast<float*>(q); q += CT_A16((size_t)d.P * 4);
+    sbestgt = reinterpret_cast<int16_t*>(q); q += CT_A16((size_t)d.P * 2);
+    sbestg_of_p = reinterpret_cast<int16_t*>(q); q += CT_A16((size_t)d.P * 2);
+    sfgcond = q;
+  } else {
+    slab = l_lab; sbestgt = l_bestgt; sbestg_of_p = l_bestg_of_p; sfgcond = l_fg;
   }
   if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
   for (int p = threadIdx.x; p < d.P; p += blockDim.x) sbestg_of_p[p] = -1;
-  __syncthreads();
-  // pass 1: per proposal row max/argmax + label by thresholds (rcnn_target.py:66-136)
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    const float4 v = props[p];
-    const lmh_box a = {v.x, v.y, v.z, v.w};
-    const float aa = lmh_area_plus1(a);
-    float best = -1.f;
-    int bi = 0;
-    for (int g = 0; g < G; ++g) {
-      const float iou = lmh_iou_plus1(a, aa, sgt[g], sarea[g]);
-      if (iou > best) { best = iou; bi = g; }
-      const unsigned long long key =
-          ((unsigned long long)__float_as_uint(iou) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)p);
-      if (key > sbest[g]) atomicMax(&sbest[g], key);
+  // pass 1: per proposal row max/argmax + label by thresholds (rcnn_target.py:66-136), gt chunk by gt chunk
+  for (int g0 = 0; g0 < max(G, 1); g0 += RT_MAX_G) {
+    const int gn = max(0, min(RT_MAX_G, G - g0));
+    const bool first = g0 == 0, last = g0 + RT_MAX_G >= G;
+    __syncthreads();
+    for (int g = threadIdx.x; g < gn; g += blockDim.x) {
+      const float* p = gtb + (size_t)(g0 + g) * 5;
+      lmh_box bx = {p[0], p[1], p[2], p[3]};
+      sgt[g] = bx;
+      sarea[g] = lmh_area_plus1(bx);
+      sbest[g] = 0ull;
     }
-    float label = -1.f;
-    if (best >= d.background_threshold_low && best < d.background_threshold_high) label = 0.f;
-    const bool is_fg = best >= d.foreground_threshold;
-    if (is_fg) label = sglabel[bi] + 1.f;
-    slab[p] = label;
-    sbestgt[p] = (int16_t)bi;
-    sfgcond[p] = is_fg ? 1 : 0;
-  }
-  __syncthreads();
-  // best proposal per gt overrides; duplicates: last gt wins (sparse_to_dense, rcnn_target.py:140-153)
-  if (threadIdx.x == 0) {
-    for (int g = 0; g < G && P > 0; ++g) {
-      const uint32_t p = 0xFFFFFFFFu - (uint32_t)(sbest[g] & 0xFFFFFFFFull);
-      sbestg_of_p[p] = (int16_t)g;  // ascending g: last write wins
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+      const float4 v = props[p];
+      const lmh_box a = {v.x, v.y, v.z, v.w};
+      const float aa = lmh_area_plus1(a);
+      float best = first ? -1.f : carry[p];
+      int bi = first ? 0 : (int)sbestgt[p];
+      for (int g = 0; g < gn; ++g) {
+        const float iou = lmh_iou_plus1(a, aa, sgt[g], sarea[g]);
+        if (iou > best) { best = iou; bi = g0 + g; }
+        const unsigned long long key =
+            ((unsigned long long)__float_as_uint(iou) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)p);
+        if (key > sbest[g]) atomicMax(&sbest[g], key);
+      }
+      sbestgt[p] = (int16_t)bi;
+      if (!last) {
+        carry[p] = best;
+      } else {
+        float label = -1.f;
+        if (best >= d.background_threshold_low && best < d.background_threshold_high) label = 0.f;
+        const bool is_fg = best >= d.foreground_threshold;
+        if (is_fg) label = gtb[(size_t)bi * 5 + 4] + 1.f;
+        slab[p] = label;
+        sfgcond[p] = is_fg ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    // best proposal per gt; duplicates: last gt wins (sparse_to_dense, rcnn_target.py:140-153)
+    if (threadIdx.x == 0) {
+      for (int g = 0; g < gn && P > 0; ++g) {
+        const uint32_t p = 0xFFFFFFFFu - (uint32_t)(sbest[g] & 0xFFFFFFFFull);
+        sbestg_of_p[p] = (int16_t)(g0 + g);  // ascending g: last write wins
+      }
     }
   }
   __syncthreads();
   for (int p = threadIdx.x; p < P; p += blockDim.x) {
     const int g = sbestg_of_p[p];
-    if (g >= 0) { slab[p] = sglabel[g] + 1.f; sfgcond[p] = 1; }
+    if (g >= 0) { slab[p] = gtb[(size_t)g * 5 + 4] + 1.f; sfgcond[p] = 1; }
     if (labels_pre) labels_pre[(size_t)b * d.P + p] = slab[p];
   }
   __syncthreads();
@@ -517,7 +566,8 @@ k_rcnn_target(lmh_rcnn_target_desc d, const float* __restrict__ proposals,
       v = props[p];
       if (label > 0.f) {
         const lmh_box a = {v.x, v.y, v.z, v.w};
-        lmh_encode(a, sgt[sbestgt[p]], d.variance_xy, d.variance_wh, t);
+        const float* gp = gtb + (size_t)sbestgt[p] * 5;
+        lmh_encode(a, lmh_box{gp[0], gp[1], gp[2], gp[3]}, d.variance_xy, d.variance_wh, t);
       }
     }
     labels[(size_t)b * d.P + p] = label;
@@ -540,18 +590,32 @@ k_rcnn_target(lmh_rcnn_target_desc d, const float* __restrict__ proposals,
   }
 }
 
+extern "C" size_t lmh_rcnn_target_workspace_bytes(const lmh_rcnn_target_desc* d) {
+  if (!d || d->B <= 0 || d->P <= 0) return 0;
+  return lmh_align_up((size_t)d->B * ct_ws_per_image(d->P), 256);
+}
+
 extern "C" int lmh_rcnn_target(const lmh_rcnn_target_desc* d, const float* proposals,
                                const int32_t* prop_count, const float* gt, const int32_t* gt_count,
                                const uint32_t* seeds, float* labels, float* bbox_targets,
                                float* labels_pre, float* rois, float* roi_labels, float* roi_targets,
-                               int32_t* roi_count, lmh_stream_t stream) {
+                               int32_t* roi_count, void* ws, size_t ws_bytes, lmh_stream_t stream) {
   LMH_CHECK_ARG(d && proposals && prop_count && gt && gt_count && seeds && labels && bbox_targets &&
-                rois && roi_labels && roi_targets && roi_count);
-  LMH_CHECK_ARG(d->B > 0 && d->P > 0 && d->P <= CT_MAX_P && d->Gmax > 0 && d->Gmax <= RT_MAX_G);
+                rois && roi_labels && roi_targets && roi_count && ws);
+  LMH_CHECK_ARG(d->B > 0 && d->P > 0 && d->Gmax > 0 && d->Gmax <= CT_MAX_G);
   LMH_CHECK_ARG(d->minibatch_size > 0);
-  hipLaunchKernelGGL(k_rcnn_target, dim3(d->B), dim3(CT_THREADS), 0, (hipStream_t)stream, *d,
-                     proposals, prop_count, gt, gt_count, seeds, labels, bbox_targets, labels_pre, rois,
-                     roi_labels, roi_targets, roi_count);
+  if (ws_bytes < lmh_rcnn_target_workspace_bytes(d)) {
+    lmh_set_error("lmh_rcnn_target: workspace %zu < %zu", ws_bytes, lmh_rcnn_target_workspace_bytes(d));
+    return LMH_ERR_WORKSPACE;
+  }
+  if (d->P <= CT_LDS_MAX_P)
+    hipLaunchKernelGGL(k_rcnn_target<false>, dim3(d->B), dim3(CT_THREADS), 0, (hipStream_t)stream, *d,
+                       proposals, prop_count, gt, gt_count, seeds, labels, bbox_targets, labels_pre, rois,
+                       roi_labels, roi_targets, roi_count, reinterpret_cast<unsigned char*>(ws));
+  else
+    hipLaunchKernelGGL(k_rcnn_target<true>, dim3(d->B), dim3(CT_THREADS), 0, (hipStream_t)stream, *d,
+                       proposals, prop_count, gt, gt_count, seeds, labels, bbox_targets, labels_pre, rois,
+                       roi_labels, roi_targets, roi_count, reinterpret_cast<unsigned char*>(ws));
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

@@ -565,9 +565,10 @@ def rcnn_target(proposals, prop_count, gt, gt_count, seeds, minibatch_size=256, 
     roi_labels = torch.empty((B, R), dtype=torch.float32, device=dev)
     roi_targets = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
     roi_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = _workspace(lib.lmh_rcnn_target_workspace_bytes(ctypes.byref(d)), dev, 'rcnn_target')
     check(lib.lmh_rcnn_target(ctypes.byref(d), _p(proposals), _p(prop_count), _p(gt), _p(gt_count), _p(seeds),
                               _p(labels), _p(targets), _p(pre), _p(rois), _p(roi_labels), _p(roi_targets),
-                              _p(roi_count), _stream()), 'lmh_rcnn_target')
+                              _p(roi_count), _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_rcnn_target')
     return dict(labels=labels, bbox_targets=targets, labels_pre=pre, rois=rois, roi_labels=roi_labels,
                 roi_targets=roi_targets, roi_count=roi_count)
 
@@ -594,6 +595,35 @@ def rcnn_proposal(proposals, prop_count, bbox_pred, cls_prob, im_shape, num_clas
                                 _p(objects), _p(labels), _p(probs), _p(num), _p(ws),
                                 ctypes.c_size_t(ws.numel()), _stream()), 'lmh_rcnn_proposal')
     return objects, labels, probs, num
+
+
+def ssd_proposal(anchors, anchor_count, loc_pred, cls_prob, im_shape, num_classes, variances=(0.1, 0.2),
+                 class_max_detections=100, class_nms_threshold=0.45, total_max_detections=100,
+                 min_prob_threshold=0.5):
+    """SSDProposal._build (ssd/proposal.py:41-171) with all five keys of its return dict: anchors (B,N,4),
+    loc_pred (B,N,4), cls_prob (B,N,C+1) -> objects (B,T,4), labels, probs, num_objects, raw_proposals (B,N,4) +
+    num_raw_proposals, anchors (B,T,4)."""
+    lib = _lib.load()
+    B, R, _ = anchors.shape
+    v = (1.0, 1.0) if variances is None else variances
+    d = RcnnProposalDesc(B, R, int(num_classes), float(im_shape[0]), float(im_shape[1]), float(v[0]),
+                         float(v[1]), int(class_max_detections), float(class_nms_threshold),
+                         int(total_max_detections), float(min_prob_threshold or 0.0), 1)
+    dev = anchors.device
+    T = int(total_max_detections)
+    objects = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, T), dtype=torch.int32, device=dev)
+    probs = torch.empty((B, T), dtype=torch.float32, device=dev)
+    num = torch.empty((B,), dtype=torch.int32, device=dev)
+    raw = torch.empty((B, R, 4), dtype=torch.float32, device=dev)
+    raw_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    det_anchors = torch.empty((B, T, 4), dtype=torch.float32, device=dev)
+    ws = _workspace(lib.lmh_ssd_proposal_workspace_bytes(ctypes.byref(d)), dev, 'rcnn_proposal')
+    check(lib.lmh_ssd_proposal(ctypes.byref(d), _p(anchors), _p(anchor_count), _p(loc_pred), _p(cls_prob),
+                               _p(objects), _p(labels), _p(probs), _p(num), _p(raw), _p(raw_count),
+                               _p(det_anchors), _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_ssd_proposal')
+    return {'objects': objects, 'labels': labels, 'probs': probs, 'num_objects': num, 'raw_proposals': raw,
+            'num_raw_proposals': raw_count, 'anchors': det_anchors}
 
 
 # ------------------------------------------------------------------- ROI ----

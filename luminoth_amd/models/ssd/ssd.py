@@ -141,13 +141,12 @@ class SSD(object):
             p = self._config.proposals
             props = anchors.unsqueeze(0).expand(B, N, 4).contiguous()
             cnt = torch.full((B,), N, dtype=torch.int32, device=self.device)
-            objects, olabels, probs, num = K.rcnn_proposal(
+            # ssd/proposal.py:165-171: objects, labels, probs, raw_proposals, anchors (+ the counts of the ragged ones)
+            pd['classification_prediction'] = K.ssd_proposal(
                 props, cnt, bbox_offsets.detach().contiguous(), class_probabilities, (H, W), C,
                 variances=self._variances, class_max_detections=p.class_max_detections,
                 class_nms_threshold=p.class_nms_threshold, total_max_detections=p.total_max_detections,
-                min_prob_threshold=p.min_prob_threshold, class_agnostic_boxes=True)
-            pd['classification_prediction'] = {'objects': objects, 'labels': olabels, 'probs': probs,
-                                               'num_objects': num}
+                min_prob_threshold=p.min_prob_threshold)
         if self._debug:
             pd['all_anchors'] = anchors
             pd['cls_prob'] = class_probabilities
@@ -171,8 +170,9 @@ class SSD(object):
         cp = pd.get('classification_prediction')
         if cp is not None:
             d = int(cp['num_objects'][0])
-            for k in ('objects', 'labels', 'probs'):
+            for k in ('objects', 'labels', 'probs', 'anchors'):
                 cp[k] = cp[k][0, :d]
+            cp['raw_proposals'] = cp['raw_proposals'][0, :int(cp['num_raw_proposals'][0])]
 
     # ------------------------------------------------------------------- loss --
     def regularization_loss(self):

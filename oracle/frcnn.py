@@ -95,8 +95,14 @@ def rpn_target(all_anchors, gt_boxes, im_shape, seed=0, allowed_border=0,
     if bg_inds.size > num_bg:
         keep = rng.keep_k_smallest(inds[bg_inds], num_bg, seed, rng.STREAM_RPN_BG)
         labels[bg_inds[~keep]] = -1
-    argmax_overlaps = overlaps.argmax(axis=1)                        # :289
-    bbox_targets = bx.encode(anchors, gt[argmax_overlaps])           # :295-297
+    if gt.shape[0] == 0:
+        # no gt box at all: the reference's graph fails here (tf.argmax over an empty axis, :289); the rebuild defines
+        # the image as background-only (every inside anchor IoU 0 -> label 0, no targets) — kernel and oracle alike
+        argmax_overlaps = np.zeros((anchors.shape[0],), np.int64)
+        bbox_targets = np.zeros((anchors.shape[0], 4), F)
+    else:
+        argmax_overlaps = overlaps.argmax(axis=1)                    # :289
+        bbox_targets = bx.encode(anchors, gt[argmax_overlaps])       # :295-297
     bbox_targets = np.where((labels == 1)[:, None], bbox_targets, F(0)).astype(F)  # :299-304
     # Scatter back to all anchors (:311-333).
     out_t = np.zeros((N, 4), dtype=F)

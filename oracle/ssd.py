@@ -1,10 +1,12 @@
 """Oracle (test infrastructure): numpy restatement of the SSD box stages of the
 reference — anchors, targets with hard-negative mining, proposals, loss.
 
-PARITY UNPINNED: the reference ships no SSD tests, so nothing
-pins these numbers; every function follows the cited reference lines op for op
-(fp32 where the reference computes in fp32, float64 where it uses numpy
-defaults) and is exercised on hand-checkable cases in tests/test_oracle_ssd.py.
+Pinned (round 3) by RUNNING the reference's own code in the build container:
+anchors by tests/golden/make_golden_ref_numpy.py (numpy code), targets /
+proposals / loss by tests/golden/make_golden_ref_tf.py (the TF-graph code of
+target.py / proposal.py / ssd.py executed on an eager numpy `tf` stand-in) —
+bit-exact labels, indices and fp32 values (tests/test_ref_tf_golden.py).  The
+reference itself ships no SSD tests.
 Citations relative to /root/reference/luminoth/.
 """
 import numpy as np
@@ -123,7 +125,8 @@ def ssd_proposal(cls_prob, loc_pred, anchors, im_shape, num_classes, class_nms_t
                  class_max_detections=100, total_max_detections=100, min_prob_threshold=0.5,
                  variances=(0.1, 0.2)):
     """models/ssd/proposal.py:41-171."""
-    sel_boxes, sel_probs, sel_labels = [], [], []
+    sel_boxes, sel_probs, sel_labels, sel_anchors = [], [], [], []
+    raw = np.zeros((0, 4), F)
     for class_id in range(num_classes):
         p = cls_prob[:, class_id + 1]
         f = p >= F(min_prob_threshold)                                         # :74-79
@@ -136,12 +139,18 @@ def ssd_proposal(cls_prob, loc_pred, anchors, im_shape, num_classes, class_nms_t
         sel_boxes.append(boxes[keep])
         sel_probs.append(p[keep])
         sel_labels.append(np.full((len(keep),), class_id, np.int32))
+        sel_anchors.append(an[pf])                                             # :143 NOT gathered by the NMS indices
     boxes = np.concatenate(sel_boxes, 0) if sel_boxes else np.zeros((0, 4), F)
     probs = np.concatenate(sel_probs, 0) if sel_probs else np.zeros((0,), F)
     labels = np.concatenate(sel_labels, 0) if sel_labels else np.zeros((0,), np.int32)
+    cat_anchors = np.concatenate(sel_anchors, 0) if sel_anchors else np.zeros((0, 4), F)
     k = min(total_max_detections, probs.shape[0])                              # :154-159
     vals, idx = tfops.top_k(probs, k)
-    return {'objects': boxes[idx], 'labels': labels[idx], 'probs': vals}
+    # 'anchors' (:162,170): the top-k indices address the concatenation of the NMS-SELECTED boxes, but are applied to
+    # the concatenation of every class's FILTERED anchors (a longer list) — the reference's debug output is
+    # misaligned; restated as is.  'raw_proposals' (:167) is the LAST class's unclipped decode.
+    return {'objects': boxes[idx], 'labels': labels[idx], 'probs': vals, 'anchors': cat_anchors[idx],
+            'raw_proposals': raw}
 
 
 # ------------------------------------------------------------------- loss ----

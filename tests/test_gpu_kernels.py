@@ -253,6 +253,106 @@ def test_rcnn_target_reference_vectors(K):
     assert (lab == 4.).sum() == 1 and (lab == 5.).sum() == 1
 
 
+# ------------------------------------------- edge cases / unbounded sizes ----
+def test_rpn_target_edge_cases_match_oracle(K):
+    """GPU twins of the oracle-only edge cases: B.4 a gt whose best IoU is 0 turns every inside
+    anchor positive (rpn_target.py:155-178); an image without gt boxes; every anchor outside the image."""
+    ref = obx.generate_anchors_reference(64, np.array([.5, 1, 2]), np.array([.25, .5, 1, 2]))
+    ref_i32 = np.trunc(ref).astype(np.int32)
+    fh, fw, stride, im = 12, 16, 16, (192, 256)
+    anchors = obx.generate_anchors(ref, fh, fw, stride)
+    gt = np.zeros((3, 4, 5), F)
+    gt[0, 0] = [300, 220, 340, 260, 1]                 # outside the image: IoU 0 with every inside anchor   (B.4)
+    gt[0, 1] = [20, 30, 90, 120, 2]
+    gt[2, :2] = [[10, 10, 60, 60, 0], [100, 50, 200, 150, 3]]
+    counts = np.array([2, 0, 2], np.int32)              # image 1: no gt at all
+    seeds = np.array([orng.image_seed(2, 1, b) for b in range(3)], np.uint32)
+    labels, targets, mo, pre = K.rpn_target(T(ref_i32), fh, fw, stride, T(gt), T(counts), T(seeds.view(np.int32)), im,
+                                            want_pre=True)
+    labels, targets, mo, pre = [t.cpu().numpy() for t in (labels, targets, mo, pre)]
+    for b in range(3):
+        ol, ot_, om, opre, _ = of.rpn_target(anchors, gt[b, :counts[b]], im, seed=int(seeds[b]),
+                                             return_pre_subsample=True)
+        np.testing.assert_array_equal(pre[b], opre)
+        np.testing.assert_array_equal(labels[b], ol)
+        np.testing.assert_array_equal(mo[b], om)
+        np.testing.assert_allclose(targets[b], ot_, rtol=1e-5, atol=1e-6)
+    inside = pre[0] >= 0
+    assert inside.sum() > 256 and (pre[0][inside] == 1).all()       # B.4: every inside anchor is a positive
+    assert (labels[0] == 1).sum() == 128 and (labels[0] == 0).sum() == 0
+    assert (pre[1][pre[1] >= 0] == 0).all() and (labels[1] == 0).sum() == 256     # no gt: backgrounds only
+    # every anchor outside: a 40x40 image is smaller than every anchor of this set
+    labels, targets, mo, _ = K.rpn_target(T(ref_i32 * 4), 3, 3, 16, T(gt[2:3]), T(counts[2:3]), T(seeds[:1].view(np.int32)),
+                                          (40, 40))
+    assert (labels.cpu().numpy() == -1).all() and (targets.cpu().numpy() == 0).all() and (mo.cpu().numpy() == 0).all()
+
+
+def test_rcnn_target_max_bg_zero_and_no_gt(K):
+    """B.6 (rcnn_target.py:211-250): `#bg >= max_bg` with max_bg == 0 disables EVERY background; fg disabled -> -label."""
+    rs = np.random.RandomState(5)
+    gt = np.zeros((1, 4, 5), F)
+    gt[0, :2] = [[50, 50, 200, 220, 4], [300, 100, 460, 300, 9]]
+    props = np.concatenate([gt[0, rs.randint(0, 2, size=60), :4] + rs.randint(-15, 16, size=(60, 4)),
+                            rand_boxes(rs, 60, 600, 10, 250)]).astype(F)[None]
+    seeds = np.array([77], np.int32)
+    r = K.rcnn_target(T(props), T(np.array([120], np.int32)), T(gt), T(np.array([2], np.int32)), T(seeds),
+                      minibatch_size=16, foreground_fraction=1.0)
+    ol, ot_ = of.rcnn_target(props[0], gt[0, :2], seed=77, minibatch_size=16, foreground_fraction=1.0)
+    lab = r['labels'][0].cpu().numpy()
+    np.testing.assert_array_equal(lab, ol)
+    assert (lab > 0).sum() == 16 and (lab == 0).sum() == 0 and (lab < -1).sum() > 0
+    assert int(r['roi_count'][0]) == 16
+
+
+def test_targets_are_unbounded_in_gt_and_proposals(K):
+    """The reference bounds neither the gt boxes nor the proposals (rcnn_target.py:48-66): 300 gt boxes stream through
+    LDS in three chunks, 6000 proposals keep their state in the workspace (round 2 returned LMH_ERR_INVALID)."""
+    rs = np.random.RandomState(17)
+    G = 300
+    ref = obx.generate_anchors_reference(64, np.array([.5, 1, 2]), np.array([.25, .5, 1, 2]))
+    ref_i32 = np.trunc(ref).astype(np.int32)
+    fh, fw, stride, im = 32, 32, 16, (512, 512)
+    anchors = obx.generate_anchors(ref, fh, fw, stride)
+    gt = np.zeros((1, G, 5), F)
+    gt[0, :, :4] = rand_boxes(rs, G, 512, 12, 160)
+    gt[0, :, 4] = rs.randint(0, 80, size=G)
+    gt[0, 200, :4] = gt[0, 3, :4]                        # duplicates across chunks: argmax keeps the FIRST, best-of-gt the LAST
+    gt[0, 290, :4] = gt[0, 140, :4]
+    cnt = np.array([G], np.int32)
+    seeds = np.array([orng.image_seed(4, 2, 0)], np.uint32)
+    labels, targets, mo, pre = K.rpn_target(T(ref_i32), fh, fw, stride, T(gt), T(cnt), T(seeds.view(np.int32)), im,
+                                            want_pre=True)
+    ol, ot_, om, opre, _ = of.rpn_target(anchors, gt[0], im, seed=int(seeds[0]), return_pre_subsample=True)
+    np.testing.assert_array_equal(pre[0].cpu().numpy(), opre)
+    np.testing.assert_array_equal(labels[0].cpu().numpy(), ol)
+    np.testing.assert_array_equal(mo[0].cpu().numpy(), om)
+    np.testing.assert_allclose(targets[0].cpu().numpy(), ot_, rtol=1e-5, atol=1e-6)
+    for P in (2000, 6000):
+        props = np.concatenate([gt[0, rs.randint(0, G, size=P // 2), :4] + rs.randint(-10, 11, size=(P // 2, 4)),
+                                rand_boxes(rs, P - P // 2, 512, 8, 300)]).astype(F)[rs.permutation(P)][None]
+        r = K.rcnn_target(T(props), T(np.array([P], np.int32)), T(gt), T(cnt), T(seeds.view(np.int32)), want_pre=True)
+        ol, ot_, opre, _, _ = of.rcnn_target(props[0], gt[0], seed=int(seeds[0]), return_pre_subsample=True)
+        np.testing.assert_array_equal(r['labels_pre'][0].cpu().numpy(), opre)
+        np.testing.assert_array_equal(r['labels'][0].cpu().numpy(), ol)
+        np.testing.assert_allclose(r['bbox_targets'][0].cpu().numpy(), ot_, rtol=1e-5, atol=1e-6)
+        keep = ol >= 0
+        assert int(r['roi_count'][0]) == keep.sum() == 256
+        np.testing.assert_array_equal(r['rois'][0].cpu().numpy(), props[0][keep])
+
+
+def test_nms_beyond_32768_candidates(K):
+    """Round 2 refused K > 32768; the only structural limit left is the grid (64 * 65535)."""
+    rs = np.random.RandomState(23)
+    Kn = 40000
+    base = rand_boxes(rs, 3000, 1000, 20, 200)
+    boxes = (base[rs.randint(0, 3000, size=Kn)] + rs.randint(-8, 9, size=(Kn, 4))).astype(F)[None]
+    counts = np.array([Kn], np.int32)
+    keep, kc = K.nms(T(boxes), T(counts), 0.6, 1500)
+    ref = tfops.non_max_suppression(boxes[0][:, [1, 0, 3, 2]], np.arange(Kn, 0, -1).astype(F), 1500, 0.6)
+    assert int(kc[0]) == ref.shape[0]
+    np.testing.assert_array_equal(keep[0, :ref.shape[0]].cpu().numpy(), ref)
+
+
 # -------------------------------------------------------------- ROI pool ----
 def test_roi_pool_fwd_bwd(K):
     rs = np.random.RandomState(31)

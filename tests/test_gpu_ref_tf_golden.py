@@ -1,0 +1,175 @@
+"""The HIP kernels (through the C ABI) against fixtures produced by RUNNING the reference's TensorFlow-graph code
+(tests/golden/make_golden_ref_tf.py; the oracle replays the same file in tests/test_ref_tf_golden.py).  Nothing here
+goes through oracle/: the expected values are the reference's own outputs.  Labels, indices, keep lists, IoUs:
+bit-exact.  fp32 values that pass through expf / logf on the device: 1e-5 relative (tolerance at each assert)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'ref_tf_golden.npz')
+
+
+def names(prefix):
+    z = np.load(GOLD)
+    return sorted({k.split('/')[1] for k in z.files if k.startswith(prefix + '/')})
+
+
+@pytest.fixture(scope='module')
+def G():
+    return np.load(GOLD)
+
+
+@pytest.fixture(scope='module')
+def K():
+    from luminoth_amd import kernels
+    return kernels
+
+
+def T(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to('cuda:0').contiguous()
+
+
+def pack_gt(gt, gmax=None):
+    g = np.zeros((1, gmax or max(1, gt.shape[0]), 5), F)
+    g[0, :gt.shape[0]] = gt
+    return T(g), T(np.array([gt.shape[0]], np.int32))
+
+
+@pytest.mark.parametrize('name', names('rpn_target'))
+def test_rpn_target_kernel_matches_reference_graph(G, K, name):
+    k = 'rpn_target/%s/' % name
+    fh, fw, stride, H, W = [int(v) for v in G[k + 'geom']]
+    border, clobber, fg_thr, bg_thr, fg_frac, mb = G[k + 'cfg']
+    gt, cnt = pack_gt(G[k + 'gt'])
+    labels, targets, max_ov, _ = K.rpn_target(
+        T(G[k + 'ref_i32']), fh, fw, stride, gt, cnt, T(G[k + 'seed'].view(np.int32)), (H, W),
+        allowed_border=int(border), clobber_positives=bool(clobber), foreground_threshold=float(fg_thr),
+        background_threshold_high=float(bg_thr), foreground_fraction=float(fg_frac), minibatch_size=int(mb))
+    np.testing.assert_array_equal(labels[0].cpu().numpy(), G[k + 'labels'])      # incl. the subsample's choice
+    np.testing.assert_array_equal(max_ov[0].cpu().numpy(), G[k + 'max_ov'])      # IoU bit-exact
+    np.testing.assert_allclose(targets[0].cpu().numpy(), G[k + 'targets'], rtol=1e-5, atol=1e-6)   # logf
+
+
+@pytest.mark.parametrize('name', names('rcnn_target'))
+def test_rcnn_target_kernel_matches_reference_graph(G, K, name):
+    k = 'rcnn_target/%s/' % name
+    fg_frac, mb, fg_thr, bg_hi, bg_lo = G[k + 'cfg']
+    props = G[k + 'proposals']
+    gt, cnt = pack_gt(G[k + 'gt'])
+    r = K.rcnn_target(T(props[None]), T(np.array([props.shape[0]], np.int32)), gt, cnt,
+                      T(G[k + 'seed'].view(np.int32)), minibatch_size=int(mb), foreground_fraction=float(fg_frac),
+                      foreground_threshold=float(fg_thr), background_threshold_high=float(bg_hi),
+                      background_threshold_low=float(bg_lo))
+    lab = G[k + 'labels']
+    np.testing.assert_array_equal(r['labels'][0].cpu().numpy(), lab)
+    np.testing.assert_allclose(r['bbox_targets'][0].cpu().numpy(), G[k + 'targets'], rtol=1e-5, atol=1e-6)
+    keep = lab >= 0                                                     # rcnn.py:156-167
+    n = int(keep.sum())
+    assert int(r['roi_count'][0]) == n
+    np.testing.assert_array_equal(r['rois'][0, :n].cpu().numpy(), props[keep])
+    np.testing.assert_array_equal(r['roi_labels'][0, :n].cpu().numpy(), lab[keep])
+
+
+@pytest.mark.parametrize('name', names('rpn_proposal'))
+def test_rpn_proposal_kernel_matches_reference_graph(G, K, name):
+    k = 'rpn_proposal/%s/' % name
+    fh, fw, stride, H, W = [int(v) for v in G[k + 'geom']]
+    pre, post, apply_nms, thr, filt, clip_after, min_prob = G[k + 'cfg']
+    prob, props, scores, cnt = K.rpn_proposal(
+        T(G[k + 'score'][None]), T(G[k + 'pred'][None]), T(G[k + 'ref_i32']), fh, fw, stride, (H, W),
+        pre_nms_top_n=int(pre), post_nms_top_n=int(post), nms_threshold=float(thr),
+        min_prob_threshold=float(min_prob), apply_nms=bool(apply_nms), clip_after_nms=bool(clip_after),
+        filter_outside_anchors=bool(filt))
+    # the kernel computes its own softmax: the fixture's foreground probabilities sit on a 1/N lattice, so a few ulp of
+    # expf difference cannot reorder anything — selection and order must be identical, values agree to 1e-5
+    np.testing.assert_allclose(prob[0].cpu().numpy(), G[k + 'prob'], rtol=1e-5, atol=1e-7)
+    n = G[k + 'proposals'].shape[0]
+    assert int(cnt[0]) == n
+    np.testing.assert_allclose(scores[0, :n].cpu().numpy(), G[k + 'scores'], rtol=1e-5)
+    np.testing.assert_allclose(props[0, :n].cpu().numpy(), G[k + 'proposals'], rtol=1e-5, atol=1e-3)   # expf * width
+
+
+@pytest.mark.parametrize('name', names('rcnn_proposal'))
+def test_rcnn_proposal_kernel_matches_reference_graph(G, K, name):
+    k = 'rcnn_proposal/%s/' % name
+    C, H, W, cmax, cthr, tmax, minp = G[k + 'cfg']
+    props = G[k + 'proposals']
+    objects, labels, probs, num = K.rcnn_proposal(
+        T(props[None]), T(np.array([props.shape[0]], np.int32)), T(G[k + 'pred'][None]), T(G[k + 'prob'][None]),
+        (int(H), int(W)), int(C), class_max_detections=int(cmax), class_nms_threshold=float(cthr),
+        total_max_detections=int(tmax), min_prob_threshold=float(minp))
+    n = G[k + 'objects'].shape[0]
+    assert int(num[0]) == n
+    np.testing.assert_array_equal(labels[0, :n].cpu().numpy(), G[k + 'labels'])
+    np.testing.assert_array_equal(probs[0, :n].cpu().numpy(), G[k + 'probs'])     # probabilities are inputs here
+    np.testing.assert_allclose(objects[0, :n].cpu().numpy(), G[k + 'objects'], rtol=1e-5, atol=1e-3)
+
+
+def test_roi_pool_kernel_matches_reference_graph(G, K):
+    rois = G['roi_pool/rois']
+    out, _ = K.roi_pool_fwd(T(G['roi_pool/feat']), T(rois[None]), T(np.array([rois.shape[0]], np.int32)),
+                            tuple(int(v) for v in G['roi_pool/im_shape']))
+    np.testing.assert_array_equal(out.cpu().numpy(), G['roi_pool/pooled'])
+
+
+def test_loss_kernels_match_reference_graph(G, K):
+    losses, per, _, _ = K.rpn_loss(T(G['rpn_loss/rpn_cls_score'][None]), T(G['rpn_loss/rpn_bbox_pred'][None]),
+                                   T(G['rpn_loss/rpn_cls_target'][None]), T(G['rpn_loss/rpn_bbox_target'][None]),
+                                   sigma=3.0)
+    np.testing.assert_allclose(per[0, :2].cpu().numpy(), [G['rpn_loss/rpn_cls_loss'], G['rpn_loss/rpn_reg_loss']],
+                               rtol=1e-5)                                # means of fp32 sums: order differs
+    losses, per, _, _ = K.rcnn_loss(T(G['rcnn_loss/cls_score'][None]), T(G['rcnn_loss/bbox_offsets'][None]),
+                                    T(G['rcnn_loss/cls_target'][None]), T(G['rcnn_loss/bbox_target'][None]), 20,
+                                    sigma=1.0)
+    np.testing.assert_allclose(per[0, :2].cpu().numpy(), [G['rcnn_loss/rcnn_cls_loss'], G['rcnn_loss/rcnn_reg_loss']],
+                               rtol=1e-5)
+
+
+@pytest.mark.parametrize('name', names('ssd_target'))
+def test_ssd_target_kernel_matches_reference_graph(G, K, name):
+    k = 'ssd_target/%s/' % name
+    ratio, fg_thr, bg_hi = G[k + 'cfg']
+    gt, cnt = pack_gt(G[k + 'gt'])
+    labels, targets, _ = K.ssd_target(T(G['ssd/anchors']), gt, cnt, T(G[k + 'probs'][None]), 5,
+                                      foreground_threshold=float(fg_thr), background_threshold_high=float(bg_hi),
+                                      hard_negative_ratio=float(ratio))
+    np.testing.assert_array_equal(labels[0].cpu().numpy(), G[k + 'labels'])
+    np.testing.assert_allclose(targets[0].cpu().numpy(), G[k + 'targets'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', names('ssd_proposal'))
+def test_ssd_proposal_kernel_matches_reference_graph(G, K, name):
+    k = 'ssd_proposal/%s/' % name
+    C, thr, cmax, tmax, minp = G[k + 'cfg']
+    anchors = G['ssd/anchors']
+    N = anchors.shape[0]
+    r = K.ssd_proposal(T(anchors[None]), T(np.array([N], np.int32)), T(G[k + 'loc'][None]), T(G[k + 'prob'][None]),
+                       (150, 150), int(C), class_max_detections=int(cmax), class_nms_threshold=float(thr),
+                       total_max_detections=int(tmax), min_prob_threshold=float(minp))
+    n = G[k + 'objects'].shape[0]
+    assert int(r['num_objects'][0]) == n
+    np.testing.assert_array_equal(r['labels'][0, :n].cpu().numpy(), G[k + 'labels'])
+    np.testing.assert_array_equal(r['probs'][0, :n].cpu().numpy(), G[k + 'probs'])
+    np.testing.assert_allclose(r['objects'][0, :n].cpu().numpy(), G[k + 'objects'], rtol=1e-5, atol=1e-3)
+    np.testing.assert_array_equal(r['anchors'][0, :n].cpu().numpy(), G[k + 'anchors_out'])      # proposal.py:162 quirk
+    m = G[k + 'raw_proposals'].shape[0]
+    assert int(r['num_raw_proposals'][0]) == m
+    np.testing.assert_allclose(r['raw_proposals'][0, :m].cpu().numpy(), G[k + 'raw_proposals'], rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize('name', ['mixed', 'no_positives'])
+def test_ssd_loss_kernel_matches_reference_graph(G, K, name):
+    k = 'ssd_loss/%s/' % name
+    losses, per, _, _ = K.ssd_loss(T(G[k + 'cls_pred'][None]), T(G[k + 'loc_pred'][None]), T(G[k + 'cls_target'][None]),
+                                   T(G[k + 'bbox_target'][None]), 20, sigma=3.0, w_loc=float(G[k + 'loc_weight']))
+    losses = losses.cpu().numpy()
+    np.testing.assert_allclose(losses[0] + G[k + 'reg'], G[k + 'total_loss'], rtol=1e-5)
+    np.testing.assert_allclose(losses[1], G[k + 'cls_loss'], rtol=1e-5)
+    np.testing.assert_allclose(losses[2], G[k + 'bbox_loss'], rtol=1e-5, atol=1e-6)
