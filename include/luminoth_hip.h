@@ -9,10 +9,17 @@
  * /root/reference/luminoth/).
  *
  * Conventions
- *  - extern "C", plain device pointers + sizes; no allocation inside; no
- *    global state; every launch goes to the caller's `stream` (hipStream_t
- *    passed as void*); returns 0 or a negative lmh_status, message via
- *    lmh_last_error() (thread local).
+ *  - extern "C", plain device pointers + sizes; no allocation inside; every
+ *    launch goes to the caller's `stream` (hipStream_t passed as void*);
+ *    returns 0 or a negative lmh_status, message via lmh_last_error()
+ *    (thread local).
+ *  - State: the data path keeps none — every result is a function of the
+ *    arguments of the call.  What IS process- or thread-global is confined to
+ *    four documented entry points, none of which changes a result: tuning
+ *    options (lmh_set_option: which kernel variant / tile runs; the library
+ *    reads no environment variable), lmh_conv2d_force_config (sweeps),
+ *    lmh_tail_defer (per thread: where a weight-gradient tail is finished) and
+ *    lmh_conv2d_profile_next (event timing of the next convolution launch).
  *  - boxes are (x1,y1,x2,y2) fp32, inclusive-pixel convention; gt boxes are
  *    (G,5) with the 0-based class in column 4; image shape is (H, W).
  *  - Batched: leading B dimension, ragged per-image counts in int32 device
@@ -30,6 +37,12 @@ extern "C" {
 #endif
 
 typedef void* lmh_stream_t; /* hipStream_t */
+
+/* Tuning options (process global; defaults are the measured best on MI355X).  Names: bd_parity_small, half_pf,
+ * x3_tile_slots, x3_pf, x3_pf_fwd, x3_pf_gb, x3_pf_bd, x3_pf_bw, bd_slots, bw_slots, wgrad_glds, wg_slots, roi_cs,
+ * roi_mean_cs (csrc/api.hip documents each).  Unknown name: LMH_ERR_INVALID. */
+int lmh_set_option(const char* name, int value);
+int lmh_get_option(const char* name, int* value);
 
 enum lmh_status {
   LMH_OK = 0,

@@ -81,6 +81,8 @@ SIGNATURES = {
     'lmh_version': (c_i, []),
     'lmh_last_error': (ctypes.c_char_p, []),
     'lmh_device_count': (c_i, []),
+    'lmh_set_option': (c_i, [ctypes.c_char_p, c_i]),
+    'lmh_get_option': (c_i, [ctypes.c_char_p, P(c_i)]),
     'lmh_conv2d_fwd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     'lmh_conv2d_bwd_data': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f]),
     'lmh_conv2d_winograd_ok': (c_i, [P(ConvDesc)]),
@@ -182,6 +184,12 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # the C library reads no environment variable; sweeps / ablations set LMH_<OPTION>=<int> and it is forwarded here
+    for key, val in os.environ.items():
+        if key.startswith('LMH_OPT_'):
+            rc = lib.lmh_set_option(key[len('LMH_OPT_'):].lower().encode(), int(val))
+            if rc != 0:
+                raise LuminothHipError('unknown tuning option %s' % key)
     return lib
 
 

@@ -1,5 +1,6 @@
 // Error plumbing + misc entry points of libluminoth_hip.so.
 #include <stdarg.h>
+#include <string.h>
 
 #include "lmh_common.h"
 
@@ -12,7 +13,44 @@ void lmh_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int lmh_version(void) { return 100; }
+// ---- tuning options: the ONLY process-global knobs of the library (none changes a result; they select among kernel
+// variants that the parity tests hold equal).  No environment variable is read anywhere in this library: the host
+// (luminoth_amd/kernels.py) forwards LMH_* variables through lmh_set_option at load time for sweeps / ablations.
+struct lmh_option { const char* name; int value; };
+static lmh_option g_options[] = {
+    {"bd_parity_small", 1},   // stride-2 3x3 backward data: 64x64 tiles when the parity classes are unbalanced
+    {"half_pf", 1},           // f16/bf16 kernels: 1, 2 register sets; 3, 4 warp-specialised 512-thread blocks
+    {"x3_tile_slots", 256},   // bf16x3 fwd / bwd_data tile by pick_tile(slots); 0: half_tile
+    {"x3_pf", -1},            // bf16x3 pipeline for every pass (-1: per-pass values below)
+    {"x3_pf_fwd", 0}, {"x3_pf_gb", 0}, {"x3_pf_bd", 0}, {"x3_pf_bw", 0},
+    {"bd_slots", 256},        // resident-block slots the backward-data tile choice fills
+    {"bw_slots", 512},        // ... the split-K weight gradient
+    {"wgrad_glds", 1},        // 1x1 weight gradient: operands straight into LDS (conv_wgrad1x1.h)
+    {"wg_slots", 512},        // ... its block count target
+    {"roi_cs", 0},            // ROI backward slab width (0: automatic, 4: force the 4-channel slab)
+    {"roi_mean_cs", -1},      // fused ROI pool+mean (-1: automatic, 0: report unsupported, 4: force 4 channels)
+};
+extern "C" int lmh_set_option(const char* name, int value) {
+  if (!name) return LMH_ERR_INVALID;
+  for (auto& o : g_options)
+    if (!strcmp(o.name, name)) { o.value = value; return LMH_OK; }
+  lmh_set_error("lmh_set_option: unknown option '%s'", name);
+  return LMH_ERR_INVALID;
+}
+extern "C" int lmh_get_option(const char* name, int* value) {
+  if (!name || !value) return LMH_ERR_INVALID;
+  for (auto& o : g_options)
+    if (!strcmp(o.name, name)) { *value = o.value; return LMH_OK; }
+  lmh_set_error("lmh_get_option: unknown option '%s'", name);
+  return LMH_ERR_INVALID;
+}
+int lmh_opt(const char* name) {   // internal reader (a dozen strcmp per convolution launch: nanoseconds)
+  for (auto& o : g_options)
+    if (!strcmp(o.name, name)) return o.value;
+  return 0;
+}
+
+extern "C" int lmh_version(void) { return 101; }
 extern "C" const char* lmh_last_error(void) { return g_err; }
 extern "C" int lmh_device_count(void) {
   int n = 0;

@@ -112,10 +112,7 @@ static void pick_tile(int64_t M, int64_t Ncols, int* bm, int* bn, int slots = 25
     if (best < 0 || cost < best) { best = cost; *bm = cand[i][0]; *bn = cand[i][1]; }
   }
 }
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
+int lmh_opt(const char* name);   // api.hip: the lmh_set_option registry (this library reads no environment variable)
 
 static bool stem_fast(const lmh_conv_desc* d) {
   return d->R == 7 && d->S == 7 && d->C == 3 && d->K == 64 && d->stride == 2 && d->dilation == 1;
@@ -127,7 +124,7 @@ static bool bwd_data_fast(const lmh_conv_desc* d) { return (d->K % BK) == 0 && (
 // (several per CU, scheduled dynamically) even that out (block2 unit4: 91 us before tap skipping, 56.7 us with
 // 128x128 tiles, 55.3 us with 64x64 — scripts/bench_conv.py "3x3/2").
 static void bwd_data_parity_tile(const lmh_conv_desc* d, int64_t M, int* bm, int* bn) {
-  static const int on = env_int("LMH_BD_PARITY_SMALL", 1);
+  const int on = lmh_opt("bd_parity_small");
   if (!on || !bwd_data_fast(d) || g_force_bm) return;
   const bool par = d->stride == 2 && d->dilation == 1 && d->R * d->S > 1 && d->R <= 3 && d->S <= 3 &&
                    !(d->H & 1) && !(d->W & 1) && ((M >> 2) % 64) == 0;
@@ -141,7 +138,7 @@ static float half_gscale(const lmh_conv_desc* d) { return d->compute == 1 ? 1024
 // prefetch depth of the half-precision kernels (register sets of staged tiles).  Measured on MI355X (COCO-shape R50
 // step, f16): one set 6.82 ms/step, two sets 8.02 — the second set pushes the 128x128 kernels past 256 VGPRs (one wave
 // per SIMD instead of two), which costs more than the deeper prefetch buys.  LMH_HALF_PF=2 keeps the variant reachable.
-static const int half_pf = env_int("LMH_HALF_PF", 1);     // 1, 2: register sets; 3, 4: warp-specialised 512-thread blocks (one / two sets)
+#define half_pf lmh_opt("half_pf")     // 1, 2: register sets; 3, 4: warp-specialised 512-thread blocks (one / two sets)
 // bf16x3 pipeline per pass: 0 = one LDS buffer, two 256-thread blocks per CU; 1 / 2 = double-buffered LDS, one block per
 // CU, one / two register sets of prefetched tiles; 3 / 4 = warp-specialised 512-thread block (waves 4-7 split and stage
 // tile t+1 while waves 0-3 multiply tile t).  Measured per layer on MI355X (scripts/bench_conv.py, ResNet-50 shapes, sums
@@ -150,12 +147,12 @@ static const int half_pf = env_int("LMH_HALF_PF", 1);     // 1, 2: register sets
 // other streams fill a CU's second block slot, the two-blocks-per-CU pipeline wins everywhere: whole step 7.19 ms with
 // 0 for every pass against 7.29 (forward 3), 7.46 (stacked Winograd GEMMs 3), 7.60 (forward + stacked 1).
 // LMH_X3_PF forces one value for all passes.
-static const int x3_tile_pick = env_int("LMH_X3_TILE_SLOTS", 256);   // tile of the bf16x3 fwd / bwd_data kernels by pick_tile(slots); 0: half_tile
-static const int x3_pf_all = env_int("LMH_X3_PF", -1);
-static const int x3_pf_fwd = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_FWD", 0);
-static const int x3_pf_gb = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_GB", 0);     // stacked Winograd GEMMs (forward kernel)
-static const int x3_pf_bd = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_BD", 0);
-static const int x3_pf_bw = x3_pf_all >= 0 ? x3_pf_all : env_int("LMH_X3_PF_BW", 0);
+#define x3_tile_pick lmh_opt("x3_tile_slots")   // tile of the bf16x3 fwd / bwd_data kernels by pick_tile(slots); 0: half_tile
+static int x3_pf(const char* pass) { const int a = lmh_opt("x3_pf"); return a >= 0 ? a : lmh_opt(pass); }
+#define x3_pf_fwd x3_pf("x3_pf_fwd")
+#define x3_pf_gb x3_pf("x3_pf_gb")     // stacked Winograd GEMMs (forward kernel)
+#define x3_pf_bd x3_pf("x3_pf_bd")
+#define x3_pf_bw x3_pf("x3_pf_bw")
 // Tile of the half-precision kernels: they are bound by the staging path (bytes per MFMA), not by matrix-pipe rounds, so
 // the largest tile the problem fills wins (128x128 moves half the bytes per FLOP of 64x64) as long as the grid still
 // covers the chip once.
@@ -251,7 +248,7 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   const int64_t M = (int64_t)d->N * d->H * d->W;
   const bool fast = bwd_data_fast(d);
   int bm, bn;
-  static const int bd_slots = env_int("LMH_BD_SLOTS", 256);
+  const int bd_slots = lmh_opt("bd_slots");
   pick_tile(M, d->C, &bm, &bn, bd_slots);
   bwd_data_parity_tile(d, M, &bm, &bn);
   hipStream_t st = (hipStream_t)stream;
@@ -320,7 +317,7 @@ static void bwd_weight_plan(const lmh_conv_desc* d, int* bm, int* bn, int* split
   int max_split = KT / 16 > 0 ? KT / 16 : 1;
   if (d->compute) max_split = KT / 8 > 0 ? KT / 8 : 1;
   if (max_split > (d->compute ? 128 : 64)) max_split = d->compute ? 128 : 64;
-  static const int bw_slots = env_int("LMH_BW_SLOTS", 512);
+  const int bw_slots = lmh_opt("bw_slots");
   int want = 1;
   double best_eff = -1.0;
   for (int s = 1; s <= max_split; ++s) {
@@ -339,7 +336,7 @@ static void bwd_weight_plan(const lmh_conv_desc* d, int* bm, int* bn, int* split
 static int g_wg_variant = 0;
 extern "C" void lmh_conv2d_force_wgrad_variant(int v) { g_wg_variant = v; }
 static bool wgrad_1x1_ok(const lmh_conv_desc* d) {
-  static const int on = env_int("LMH_WGRAD_GLDS", 1);
+  const int on = lmh_opt("wgrad_glds");
   return on && g_wg_variant >= 0 && d->compute == 0 && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_top == 0 &&
          d->pad_left == 0 && d->OH == d->H && d->OW == d->W && (d->C & 3) == 0 && (d->K & 3) == 0 &&
          d->C >= 32 && d->K >= 32;
@@ -355,7 +352,7 @@ static void wgrad_1x1_plan(const lmh_conv_desc* d, int* bm, int* bn, int* nbuf, 
   const int64_t tiles = (int64_t)((d->C + *bm - 1) / *bm) * ((d->K + *bn - 1) / *bn);
   const int64_t P = (int64_t)d->N * d->OH * d->OW;
   const int KT = (int)((P + BK - 1) / BK);
-  static const int slots = env_int("LMH_WG_SLOTS", 512);
+  const int slots = lmh_opt("wg_slots");
   int want = (int)(slots / tiles);
   if (want < 1) want = 1;
   const int max_split = KT / 8 > 0 ? KT / 8 : 1;
@@ -378,7 +375,7 @@ extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
     return bm * 1000 + bn + (fwd_fast(d) ? 0 : 1000000);
   }
   if (op == 1) {
-    pick_tile((int64_t)d->N * d->H * d->W, d->C, &bm, &bn, env_int("LMH_BD_SLOTS", 256));
+    pick_tile((int64_t)d->N * d->H * d->W, d->C, &bm, &bn, lmh_opt("bd_slots"));
     bwd_data_parity_tile(d, (int64_t)d->N * d->H * d->W, &bm, &bn);
     return bm * 1000 + bn + (bwd_data_fast(d) ? 0 : 1000000);
   }

@@ -9,6 +9,7 @@
 // every corner fetch is a fully coalesced 1 KiB wave request and the backward's
 // scatter-add atomics hit distinct addresses per lane.
 #include "lmh_common.h"
+int lmh_opt(const char* name);   // api.hip: the lmh_set_option registry
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -298,7 +299,7 @@ static int roi_bwd_slab_launch(const float* dout, const uint8_t* argmax, const r
 
 static int roi_slab_width(int FH, int FW, int C) {      // channels per LDS slab of the backward; 0: does not fit
   const size_t npix = (size_t)FH * FW, lds_cap = 160 * 1024;
-  static const int force_cs = getenv("LMH_ROI_CS") ? atoi(getenv("LMH_ROI_CS")) : 0;   // diagnostics
+  const int force_cs = lmh_opt("roi_cs");   // diagnostics (lmh_set_option)
   if (FH >= 32768 || FW >= 32768) return 0;
   if (force_cs != 4 && (C % 8) == 0 && npix * 8 * sizeof(unsigned long long) <= lds_cap) return 8;
   if ((C % 4) == 0 && npix * 4 * sizeof(unsigned long long) <= lds_cap) return 4;
@@ -400,7 +401,7 @@ k_roi_pool_mean_fwd(const float* __restrict__ feat, const float4* __restrict__ r
 
 static int roi_mean_fwd_width(int FH, int FW, int C) {
   const size_t npix = (size_t)FH * FW, lds_cap = 160 * 1024;
-  static const int force = getenv("LMH_ROI_MEAN_CS") ? atoi(getenv("LMH_ROI_MEAN_CS")) : -1;   // 0: report "unsupported"
+  const int force = lmh_opt("roi_mean_cs");   // 0: report "unsupported" (lmh_set_option)
   if (force == 0) return 0;
   if (force != 4 && (C % 8) == 0 && npix * 8 * sizeof(float) <= lds_cap) return 8;
   if ((C % 4) == 0 && npix * 4 * sizeof(float) <= lds_cap) return 4;

@@ -108,6 +108,14 @@ class TailQueue(object):
             self.flush()
         self.early_used = True
 
+    def abort(self):
+        """A step failed part-way: stop queueing and drop the backlog, so that a later backward which does not go
+        through begin() / flush() (plain autograd on `model(...)` outputs) runs its tails immediately again."""
+        self.active = False
+        self.early = None
+        self.early_used = False
+        self.entries, self.order = {}, []
+
     def entry(self, key):
         e = self.entries.get(key)
         if e is None:

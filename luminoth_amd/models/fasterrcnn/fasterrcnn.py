@@ -245,6 +245,17 @@ class FasterRCNN(object):
         return image.to(self.device, torch.float32).contiguous()
 
     def train_step(self, image, gt_boxes, next_image=None, next_gt=None):
+        """`_train_step` with the process-global tail queue guarded: if anything raises mid-step (an argument check of a
+        kernel, an out-of-memory) the queue is left inactive and empty, not silently swallowing the tails of whatever
+        backward runs next."""
+        try:
+            return self._train_step(image, gt_boxes, next_image=next_image, next_gt=next_gt)
+        except BaseException:
+            K.TAILS.abort()
+            self._prefetch = self._tgt_prefetch = None
+            raise
+
+    def _train_step(self, image, gt_boxes, next_image=None, next_gt=None):
         """forward + loss + backward of ONE train step (train.py:66-91), same arithmetic as
         `__call__(is_training=True)` -> `loss()` -> `backward()`, scheduled on two HIP streams:
 

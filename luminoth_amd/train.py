@@ -191,7 +191,10 @@ def _run(config, get_model_fn, get_dataset_fn, train_step_fn, max_steps, rank, w
     it = iter(dataset)
     nxt = next(it, None)
     while nxt is not None:
-        batch, nxt = nxt, next(it, None)
+        # no look-ahead behind the last step of a bounded run: the extra batch would be decoded, uploaded, its prefix
+        # and anchor targets computed — and then dropped, one record consumed for nothing
+        is_last = max_steps is not None and step + 1 - global_step >= max_steps
+        batch, nxt = nxt, (None if is_last else next(it, None))
         before = time.time()
         if lookahead and nxt is not None:
             total_loss, _ = train_step_fn(model, optimizer, batch['image'], batch['bboxes'], next_image=nxt['image'],

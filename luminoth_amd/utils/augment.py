@@ -69,8 +69,14 @@ def patch_image(image, bboxes=None, offset_height=0, offset_width=0, target_heig
     if bboxes is None:
         return {'image': resized}
     b = np.asarray(bboxes)
-    cx = _F(np.mean(b[:, [0, 2]].astype(_F)))                    # no axis in the reference: one value for all boxes
-    cy = b[:, [1, 3]].astype(_F).mean(axis=1)
+    if np.issubdtype(b.dtype, np.integer):
+        # the dataset hands int32 boxes (object_detection_dataset.py queue dtypes) and tf.reduce_mean of an integer
+        # tensor is an integer (sum // count): a half-integer centre on the patch border is truncated first
+        cx = int(b[:, [0, 2]].astype(np.int64).sum()) // (2 * b.shape[0])       # no axis in the reference: ONE value
+        cy = b[:, [1, 3]].astype(np.int64).sum(axis=1) // 2
+    else:
+        cx = _F(np.mean(b[:, [0, 2]].astype(_F)))                # no axis in the reference: one value for all boxes
+        cy = b[:, [1, 3]].astype(_F).mean(axis=1)
     inside = (cx > offset_width) & (cx < target_width + offset_width) & \
              (cy > offset_height) & (cy < target_height + offset_height)
     kept = b[inside]

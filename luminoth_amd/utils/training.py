@@ -201,10 +201,9 @@ class MomentumOptimizer(object):
     by one reduction launch in front of it."""
     KIND = 0
 
-    def __init__(self, model, train_config, momentum=0.9, **hyper):
+    def __init__(self, model, train_config, momentum=0.9):
         self.model, self.store, self.cfg = model, model.store, train_config
         self.momentum = float(momentum)
-        self.hyper = hyper
         self.clip_norm = 10.0 if train_config.get('clip_by_norm') else None      # training.py:108: clip_by_norm(g, 10.)
         self.global_step = 0
         self.buckets = None
@@ -260,15 +259,21 @@ class AdamOptimizer(MomentumOptimizer):
     bias-corrected rate lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) is formed on the host (TF: _prepare/_finish)."""
     KIND = 1
 
-    def __init__(self, model, train_config, beta1=0.9, beta2=0.999, epsilon=1e-8, **hyper):
-        super(AdamOptimizer, self).__init__(model, train_config, momentum=0.0, **hyper)
+    def __init__(self, model, train_config, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        super(AdamOptimizer, self).__init__(model, train_config, momentum=0.0)
         self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
         self._slot2 = torch.zeros_like(self.store.mom)
-        self._t = 0
+
+    @property
+    def _t(self):
+        """TF keeps beta1_power / beta2_power as global (non-slot) variables, which the reference's saver DOES
+        checkpoint (train.py:108-112 saves everything but the slots): after a resume the bias correction continues at
+        the restored step while m and v restart at zero.  The counter is therefore a function of `global_step` (which
+        train.run restores), not a private count of the calls made in this process."""
+        return self.global_step + 1
 
     def _update(self, lr, gscale, factors):
         st = self.store
-        self._t += 1
         lr_t = lr * (1.0 - self.beta2 ** self._t) ** 0.5 / (1.0 - self.beta1 ** self._t)
         K.optimizer_step(1, st.flat, st.grad, st.mom, self._slot2, st.seg_offset, st.seg_wd, factors, lr_t,
                          self.beta1, self.beta2, self.epsilon, gscale)
@@ -279,8 +284,8 @@ class RMSPropOptimizer(MomentumOptimizer):
     at ONE (TF's initialiser), the momentum slot at zero."""
     KIND = 2
 
-    def __init__(self, model, train_config, decay=0.9, momentum=0.0, epsilon=1e-10, **hyper):
-        super(RMSPropOptimizer, self).__init__(model, train_config, momentum=momentum, **hyper)
+    def __init__(self, model, train_config, decay=0.9, momentum=0.0, epsilon=1e-10):
+        super(RMSPropOptimizer, self).__init__(model, train_config, momentum=momentum)
         self.decay, self.epsilon = float(decay), float(epsilon)
         self.store.mom.fill_(1.0)                    # slot 1 = ms
         self._slot2 = torch.zeros_like(self.store.mom)
@@ -300,15 +305,27 @@ def get_optimizer(train_config, model):
         raise ValueError('Invalid optimizer type "{}"'.format(kind))
     opt.pop('use_locking', None)
     opt.pop('name', None)
+
+    def take(allowed):
+        """The reference forwards the remaining keys to the TF optimizer constructor, which raises TypeError on an
+        unknown keyword; a key TF knows but no kernel here implements must not be swallowed either."""
+        kw = {k: opt.pop(k) for k in list(opt) if k in allowed}
+        if opt:
+            raise TypeError('optimizer "%s": unsupported argument(s) %s' % (kind, sorted(opt)))
+        return kw
+
     if kind == 'momentum':
         if opt.pop('use_nesterov', False):
             raise NotImplementedError('use_nesterov=True has no fused HIP kernel (reference default: False)')
-        return MomentumOptimizer(model, train_config, momentum=opt.pop('momentum', 0.9))
+        return MomentumOptimizer(model, train_config, **take(('momentum',)))
     if kind == 'gradient_descent':
+        take(())
         return MomentumOptimizer(model, train_config, momentum=0.0)
     if kind == 'adam':
-        return AdamOptimizer(model, train_config, **opt)
-    return RMSPropOptimizer(model, train_config, **opt)
+        return AdamOptimizer(model, train_config, **take(('beta1', 'beta2', 'epsilon')))
+    if opt.pop('centered', False):
+        raise NotImplementedError('RMSProp centered=True has no fused HIP kernel (TF default: False)')
+    return RMSPropOptimizer(model, train_config, **take(('decay', 'momentum', 'epsilon')))
 
 
 def issue_from_high_priority_stream(device):

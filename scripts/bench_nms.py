@@ -1,7 +1,6 @@
 """Standalone timing of lmh_nms (k_nms_mask + k_nms_reduce) at the train-step size: 2 images x 12 000 candidates,
 2 000 kept, threshold 0.7, on anchor-like boxes (a random 12 000 of the 64x64x9 anchors, jittered — what the RPN of a
-freshly initialised network proposes).  LMH_NMS_DBG=1 drops the row loads of k_nms_reduce, =2 the gather of kept rows
-(results are then wrong: timing ablation only)."""
+freshly initialised network proposes)."""
 import os
 import sys
 
@@ -31,4 +30,4 @@ cnt = torch.full((B,), Kn, dtype=torch.int32, device=dev)
 keep, kc = K.nms(bt, cnt, thr, max_out)
 torch.cuda.synchronize()
 t = timeit(lambda: K.nms(bt, cnt, thr, max_out), 20)
-print('nms dbg=%s: %.1f us, kept %s' % (os.environ.get('LMH_NMS_DBG', '0'), t * 1e3, kc.cpu().tolist()))
+print('nms: %.1f us, kept %s' % (t * 1e3, kc.cpu().tolist()))

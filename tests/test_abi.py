@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), 'libluminoth_hip.so lacks %s' % s
     assert sorted(_lib.SIGNATURES) == header_symbols()
     loaded = _lib.load()
-    assert loaded.lmh_version() == 100
+    assert loaded.lmh_version() == 101
     assert loaded.lmh_last_error() is not None
 
 
@@ -56,3 +56,20 @@ def test_host_io_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), 'libluminoth_io.so lacks %s' % s
     assert tfrecord.crc32c(b'123456789') == 0xE3069283
+
+
+def test_tuning_options_registry_and_no_getenv_in_the_library():
+    """the shipped library read ~10 LMH_* environment variables (one of them produced wrong results).  Now
+    it reads none: options go through lmh_set_option, unknown names are an error, defaults are restored here."""
+    import glob
+    from luminoth_amd import _lib
+    lib = _lib.load()
+    v = ctypes.c_int(0)
+    assert lib.lmh_get_option(b'wg_slots', ctypes.byref(v)) == 0 and v.value == 512
+    assert lib.lmh_set_option(b'wg_slots', 256) == 0
+    assert lib.lmh_get_option(b'wg_slots', ctypes.byref(v)) == 0 and v.value == 256
+    assert lib.lmh_set_option(b'wg_slots', 512) == 0
+    assert lib.lmh_set_option(b'nms_dbg', 1) != 0 and b'unknown option' in lib.lmh_last_error()
+    for f in glob.glob(os.path.join(ROOT, 'luminoth_amd', 'csrc', '*.hip')) + \
+            glob.glob(os.path.join(ROOT, 'luminoth_amd', 'csrc', '*.h')):
+        assert 'getenv' not in open(f).read(), f

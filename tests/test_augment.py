@@ -47,6 +47,24 @@ def test_patch_image_crops_moves_clips_and_rescales_boxes():
     np.testing.assert_array_equal(out['image'][0, 0], image[50, 100])
 
 
+def test_patch_image_integer_centres_truncate_like_tf_reduce_mean():
+    """The dataset's boxes are int32 and tf.reduce_mean of an integer tensor is an integer (image.py:208-228): a box
+    whose centre is 10.5 on a patch that starts at 10 has centre 10 -> NOT inside (`greater` is strict); float boxes
+    keep the half.  Odd coordinate sums on both axes."""
+    image = _image(100, 120)
+    # y: (5 + 16) / 2 = 10.5 -> 10, offset_height 10: 10 > 10 fails.  x (one global mean): (31 + 60) // 2 = 45
+    bboxes = np.array([(31, 5, 60, 16, 2)], np.int32)
+    out = A.patch_image(image, bboxes, offset_height=10, offset_width=20, target_height=60, target_width=80)
+    np.testing.assert_array_equal(out['bboxes'], bboxes)                # dropped -> nothing changes
+    np.testing.assert_array_equal(out['image'], image)
+    out = A.patch_image(image, bboxes.astype(F), offset_height=10, offset_width=20, target_height=60, target_width=80)
+    assert out['bboxes'].shape == (1, 5) and not np.array_equal(out['bboxes'], bboxes)      # 10.5 > 10: kept and moved
+    # x: global integer mean over ALL boxes' x1, x2: (0 + 41 + 41 + 82) // 4 = 41 (41.0 exactly), offset 41: dropped
+    b2 = np.array([(0, 20, 41, 60, 1), (41, 20, 82, 60, 1), (1, 20, 42, 61, 1)], np.int32)   # sum 207 // 6 = 34
+    out = A.patch_image(image, b2, offset_height=0, offset_width=34, target_height=90, target_width=70)
+    np.testing.assert_array_equal(out['bboxes'], b2)                     # 34 > 34 fails (float mean 34.5 would pass)
+
+
 @pytest.mark.parametrize('min_hw', [(600, 600), (900, 900)])       # the second: larger than the image, image_test.py:396-434
 def test_random_patch_invariants(min_hw):
     im_shape = (800, 600, 3) if min_hw[0] == 600 else (600, 800, 3)

@@ -120,3 +120,49 @@ def test_cli_dispatch(monkeypatch, capsys):
     import luminoth_amd.predict as P
     monkeypatch.setattr(P, 'main', lambda argv: 2)
     assert cli.main(['predict']) == 2
+
+
+def test_bounded_run_does_not_pull_a_batch_it_will_not_train_on(monkeypatch):
+    """with max_steps the look-ahead used to consume (decode, upload, prefix) one extra record."""
+    from luminoth_amd.datasets import synthetic
+    pulled = []
+    orig_iter = synthetic.SyntheticObjectDetectionDataset.__iter__
+
+    def counting_iter(self):
+        for b in orig_iter(self):
+            pulled.append(1)
+            yield b
+    monkeypatch.setattr(synthetic.SyntheticObjectDetectionDataset, '__iter__', counting_iter)
+    assert patched_run(make_config(None), monkeypatch, max_steps=2) == 2
+    assert len(pulled) == 2
+
+
+def test_optimizer_arguments_are_not_swallowed():
+    """the reference forwards every remaining optimizer key to the TF constructor (training.py:64-81), which
+    raises on unknown keywords; Adam's bias-correction step follows the restored global_step."""
+    import pytest
+    from luminoth_amd.params import ParamStore
+    from luminoth_amd.utils import training
+
+    class M(object):
+        pass
+    m = M()
+    m.store = ParamStore()
+    m.store.add('w', (4,), lambda s, g: torch.ones(s), trainable=True)
+    m.store.build(torch.device('cpu'), seed=0)
+
+    def cfg(**opt):
+        return get_config({'model': {'type': 'fasterrcnn'}, 'train': {'optimizer': dict(_replace=True, **opt)}}).train
+    assert training.get_optimizer(cfg(type='momentum', momentum=0.7), m).momentum == 0.7
+    with pytest.raises(TypeError):
+        training.get_optimizer(cfg(type='momentum', momentun=0.7), m)              # typo
+    with pytest.raises(TypeError):
+        training.get_optimizer(cfg(type='adam', learning_rate=0.1), m)             # TF: multiple values for learning_rate
+    with pytest.raises(NotImplementedError):
+        training.get_optimizer(cfg(type='rmsprop', centered=True), m)
+    with pytest.raises(NotImplementedError):
+        training.get_optimizer(cfg(type='momentum', use_nesterov=True), m)
+    adam = training.get_optimizer(cfg(type='adam', beta1=0.8), m)
+    assert adam.beta1 == 0.8 and adam._t == 1
+    adam.global_step = 500                                                         # what train.run does on resume
+    assert adam._t == 501
