@@ -89,21 +89,29 @@ typedef struct lmh_conv_desc {
   int32_t compute;
 } lmh_conv_desc;
 
+/* act_bits (may be NULL; needs act != 0 and K % 32 == 0): the ACTIVATION BIT MASK of y — N*OH*OW rows of K/32
+ * words, bit (k % 32) of word (k / 32) set iff act'(y) != 0 (relu: y > 0; relu6: 0 < y < 6).  It is what the
+ * backward pass needs of tf.nn.relu's output (TF keeps the whole tensor for ReluGrad): 1/32 of the bytes, written by
+ * the epilogue that already holds the values. */
 int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const float* w,
                    const float* scale, const float* shift, const float* residual,
-                   const float* in_sub, float* y, lmh_stream_t stream);
+                   const float* in_sub, float* y, uint32_t* act_bits, lmh_stream_t stream);
 /* dx (N,H,W,C) = sum_{r,s,k} dy[..] * kscale[k] * w[r,s,c,k] + addend
  * (kscale, addend may be NULL; addend may alias dx: residual-branch accumulate). */
 int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, const float* w,
                         const float* kscale, const float* addend, const float* yact,
-                        const float* xmask, int xmask_act, float* dx, lmh_stream_t stream);
+                        const uint32_t* xbits, float* dx, lmh_stream_t stream);
+/* The mask on its own (layers whose producer / consumer is not a convolution of this library):
+ * bits <- act'(y) != 0 over (rows, K) with K % 32 == 0;  dx <- dx where bit else 0, in place. */
+int lmh_act_bits(const float* y, int act, int64_t rows, int K, uint32_t* bits, lmh_stream_t stream);
+int lmh_apply_act_bits(float* dx, const uint32_t* bits, int64_t rows, int C, lmh_stream_t stream);
 /* dw (R,S,C,K) = sum_{n,oh,ow} x[..] * g[..]; split-K partials are reduced deterministically through `ws`.
  * Fused activation backward (both bwd entry points): when `yact` (the layer output y, same shape as dy) is
  * given, g = dy * act'(y) with act = d->act is applied while the operand is loaded (replaces a separate
  * lmh_act_bwd pass); otherwise g = dy.  `colsum` (K floats, may be NULL) receives sum_rows g (dbeta/dbias).
- * bwd_data only: `xmask` (the layer INPUT x = post-activation output of the layer below, may be NULL) makes
- * the epilogue emit dx * act'(x) with act = xmask_act (1 relu, 2 relu6): the layer below then receives its
- * pre-activation gradient and needs no lmh_act_bwd pass. */
+ * bwd_data only: `xbits` (the activation bit mask of the layer INPUT x = output of the layer below, C % 32 == 0, may
+ * be NULL) makes the epilogue emit dx * act'(x): the layer below then receives its pre-activation gradient and needs
+ * no lmh_act_bwd pass (ReluGrad of the reference graph, fused into the producer of its operand). */
 size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d);
 int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* dy, const float* yact,
                           float* dw, float* colsum, void* ws, size_t ws_bytes, lmh_stream_t stream);
@@ -153,12 +161,13 @@ size_t lmh_conv2d_winograd_workspace_bytes(const lmh_conv_desc* d);
  * [16][C][K]; backward: of w[2-r][2-s][c][k]*kscale[k] as [16][K][C]), or NULL to transform inside the call. */
 int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, const float* w, const float* kscale,
                                           int backward, float* u, lmh_stream_t stream);
+/* act_bits / xbits: as for lmh_conv2d_fwd / lmh_conv2d_bwd_data (emitted / applied by the output transform). */
 int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float* w, const float* u,
                             const float* scale, const float* shift, const float* residual, float* y,
-                            void* ws, size_t ws_bytes, lmh_stream_t stream);
+                            uint32_t* act_bits, void* ws, size_t ws_bytes, lmh_stream_t stream);
 int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w, const float* u,
-                                 const float* kscale, const float* addend, float* dx, void* ws,
-                                 size_t ws_bytes, lmh_stream_t stream);
+                                 const float* kscale, const float* addend, const uint32_t* xbits, float* dx,
+                                 void* ws, size_t ws_bytes, lmh_stream_t stream);
 /* dw (RAW, like lmh_conv2d_bwd_weight) = G^T [ sum_tiles (B^T x B)^T (A dy A^T) ] G. */
 size_t lmh_conv2d_bwd_weight_winograd_workspace_bytes(const lmh_conv_desc* d);
 int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const float* x, const float* dy, float* dw,

@@ -83,13 +83,15 @@ SIGNATURES = {
     'lmh_device_count': (c_i, []),
     'lmh_set_option': (c_i, [ctypes.c_char_p, c_i]),
     'lmh_get_option': (c_i, [ctypes.c_char_p, P(c_i)]),
-    'lmh_conv2d_fwd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
-    'lmh_conv2d_bwd_data': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f]),
+    'lmh_conv2d_fwd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_conv2d_bwd_data': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_act_bits': (c_i, [c_f, c_i, c_i64, c_i, c_f, c_f]),
+    'lmh_apply_act_bits': (c_i, [c_f, c_f, c_i64, c_i, c_f]),
     'lmh_conv2d_winograd_ok': (c_i, [P(ConvDesc)]),
     'lmh_conv2d_winograd_workspace_bytes': (c_sz, [P(ConvDesc)]),
     'lmh_conv2d_winograd_transform_weights': (c_i, [P(ConvDesc), c_f, c_f, c_i, c_f, c_f]),
-    'lmh_conv2d_fwd_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
-    'lmh_conv2d_bwd_data_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_conv2d_fwd_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_conv2d_bwd_data_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_weight_winograd_workspace_bytes': (c_sz, [P(ConvDesc)]),
     'lmh_conv2d_bwd_weight_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_weight_workspace_bytes': (c_sz, [P(ConvDesc)]),

@@ -163,11 +163,31 @@ static void half_tile(int64_t M, int64_t Ncols, int* bm, int* bn) {
   if (((M + 127) / 128) * ((Ncols + *bn - 1) / *bn) < 128) { *bm = 64; *bn = 64; }
 }
 
+int lmh_act_bits_impl(const float* y, int act, int64_t rows, int K, uint32_t* bits, hipStream_t st);   // elementwise.hip
+int lmh_apply_act_bits_impl(float* dx, const uint32_t* bits, int64_t rows, int C, hipStream_t st);
+
+static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
+                             const float* shift, const float* residual, const float* in_sub, float* y,
+                             uint32_t* act_bits, bool* bits_done, lmh_stream_t stream);
+
 extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
                               const float* shift, const float* residual, const float* in_sub, float* y,
-                              lmh_stream_t stream) {
+                              uint32_t* act_bits, lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
+  LMH_CHECK_ARG(act_bits == nullptr || (d->act != 0 && (d->K & 31) == 0));
+  bool bits_done = false;
+  rc = conv2d_fwd_launch(d, x, w, scale, shift, residual, in_sub, y, act_bits, &bits_done, stream);
+  if (rc) return rc;
+  if (act_bits && !bits_done)     // kernels without the fused epilogue (stem, predicated, half precision): one small pass
+    return lmh_act_bits_impl(y, d->act, (int64_t)d->N * d->OH * d->OW, d->K, act_bits, (hipStream_t)stream);
+  return LMH_OK;
+}
+
+static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
+                             const float* shift, const float* residual, const float* in_sub, float* y,
+                             uint32_t* act_bits, bool* bits_done, lmh_stream_t stream) {
+  int rc = 0;
   LMH_CHECK_ARG(x && w && y);
   g_prof_pending_bytes = desc_bytes(d);
   const int64_t M = (int64_t)d->N * d->OH * d->OW;
@@ -217,7 +237,7 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
   do {                                                                                                    \
     if (fast)                                                                                             \
       hipLaunchKernelGGL((k_conv_fwd<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift,    \
-                         residual, y);                                                                    \
+                         residual, y, 1, act_bits);                                                       \
     else if ((d->C % BK) != 0)                                                                            \
       hipLaunchKernelGGL((k_conv_fwd_gen<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, \
                          shift, residual, in_sub, y);                                                     \
@@ -232,19 +252,36 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
 #undef LAUNCH_FWD
   if (fast) prof_end(st, desc_flops(d), "k_conv_fwd<%d, %d, false>", bm, bn);
   else prof_end(st, desc_flops(d), "k_conv_fwd_gen<%d, %d, %s>", bm, bn, (d->C % BK) != 0 ? "true" : "false");
+  *bits_done = fast;
+  (void)rc;
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
 
+static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const float* w, const float* kscale,
+                                  const float* addend, const float* yact, const uint32_t* xbits, bool* bits_done,
+                                  float* dx, lmh_stream_t stream);
+
 extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, const float* w,
                                    const float* kscale, const float* addend, const float* yact,
-                                   const float* xmask, int xmask_act, float* dx, lmh_stream_t stream) {
+                                   const uint32_t* xbits, float* dx, lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
+  LMH_CHECK_ARG(xbits == nullptr || (d->C & 31) == 0);
+  bool bits_done = false;
+  rc = conv2d_bwd_data_launch(d, dy, w, kscale, addend, yact, xbits, &bits_done, dx, stream);
+  if (rc) return rc;
+  if (xbits && !bits_done)        // predicated / half-precision kernels: the mask as one in-place pass over dx
+    return lmh_apply_act_bits_impl(dx, xbits, (int64_t)d->N * d->H * d->W, d->C, (hipStream_t)stream);
+  return LMH_OK;
+}
+
+static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const float* w, const float* kscale,
+                                  const float* addend, const float* yact, const uint32_t* xbits, bool* bits_done,
+                                  float* dx, lmh_stream_t stream) {
   LMH_CHECK_ARG(dy && w && dx);
   g_prof_pending_bytes = desc_bytes(d);
   LMH_CHECK_ARG(yact == nullptr || (bwd_data_fast(d) && d->act != 0));   // fused act'(y) only on the fast path
-  LMH_CHECK_ARG(xmask == nullptr || (bwd_data_fast(d) && (xmask_act == 1 || xmask_act == 2)));
   const int64_t M = (int64_t)d->N * d->H * d->W;
   const bool fast = bwd_data_fast(d);
   int bm, bn;
@@ -252,7 +289,7 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   pick_tile(M, d->C, &bm, &bn, bd_slots);
   bwd_data_parity_tile(d, M, &bm, &bn);
   hipStream_t st = (hipStream_t)stream;
-  if (d->compute && fast && !yact && !xmask) {
+  if (d->compute && fast && !yact) {
     if (d->compute == 3 && x3_tile_pick) pick_tile(M, d->C, &bm, &bn, x3_tile_pick); else half_tile(M, d->C, &bm, &bn);   // (no parity classes here)
     const int gridh = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
     const float gs = half_gscale(d);
@@ -282,10 +319,10 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
   do {                                                                                                      \
     if (fast && yact)                                                                                       \
       hipLaunchKernelGGL((k_conv_bwd_data<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, \
-                         addend, yact, xmask, xmask_act, dx);                                               \
+                         addend, yact, xbits, dx);                                                          \
     else if (fast)                                                                                          \
       hipLaunchKernelGGL((k_conv_bwd_data<BM_, BN_, false>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, \
-                         addend, yact, xmask, xmask_act, dx);                                               \
+                         addend, yact, xbits, dx);                                                          \
     else                                                                                                    \
       hipLaunchKernelGGL((k_conv_bwd_data_gen<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale,  \
                          addend, dx);                                                                       \
@@ -297,6 +334,7 @@ extern "C" int lmh_conv2d_bwd_data(const lmh_conv_desc* d, const float* dy, cons
 #undef LAUNCH_BD
   if (fast) prof_end(st, desc_flops(d), "k_conv_bwd_data<%d, %d, %s>", bm, bn, yact ? "true" : "false");
   else prof_end(st, desc_flops(d), "k_conv_bwd_data_gen<%d, %d>", bm, bn);
+  *bits_done = fast;
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

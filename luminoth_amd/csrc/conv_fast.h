@@ -178,7 +178,11 @@ template <int BM, int BN, bool GB = false>
 __global__ void __launch_bounds__(256)
 k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w,
            const float* __restrict__ scale, const float* __restrict__ shift,
-           const float* __restrict__ residual, float* __restrict__ y, int gbatch = 1) {
+           const float* __restrict__ residual, float* __restrict__ y, int gbatch = 1,
+           uint32_t* __restrict__ act_bits = nullptr) {
+  // act_bits (optional, K % 32 == 0): one bit per output element, [pixel][K / 32] words, bit = act'(y) != 0 (relu:
+  // y > 0; relu6: 0 < y < 6).  The backward-data kernel of the layer ABOVE applies it in its epilogue, so the
+  // gradient that reaches this layer already is g = dy * act'(y) and no separate lmh_act_bwd pass exists.
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BM * LDK, B_SZ = BK * BN;
@@ -319,6 +323,15 @@ k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
           *reinterpret_cast<f32x4*>(y + (size_t)row * K + col) = v;
+          if (act_bits) {      // 8 adjacent lanes hold the 32 channels of one mask word (same row: all active together)
+            unsigned nib = ((v.x > 0.f && v.x < act_hi) ? 1u : 0u) | ((v.y > 0.f && v.y < act_hi) ? 2u : 0u) |
+                           ((v.z > 0.f && v.z < act_hi) ? 4u : 0u) | ((v.w > 0.f && v.w < act_hi) ? 8u : 0u);
+            nib <<= 4 * (c4 & 7);
+            nib |= __shfl_xor(nib, 1);
+            nib |= __shfl_xor(nib, 2);
+            nib |= __shfl_xor(nib, 4);
+            if ((c4 & 7) == 0) act_bits[(size_t)row * (K >> 5) + (col >> 5)] = nib;
+          }
         }
       }
     }
@@ -335,8 +348,10 @@ template <int BM, int BN, bool YACT>   // YACT: A operand is dy * act'(yact) (fu
 __global__ void __launch_bounds__(256)
 k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
                 const float* __restrict__ kscale, const float* __restrict__ addend,
-                const float* __restrict__ yact, const float* __restrict__ xmask, int xmask_act,
+                const float* __restrict__ yact, const uint32_t* __restrict__ xbits,
                 float* __restrict__ dx) {
+  // xbits (optional, C % 32 == 0): the activation bit mask of the layer INPUT x ([pixel][C / 32] words, written by the
+  // forward kernel that produced x): the epilogue emits dx * act'(x), the pre-activation gradient of the layer below.
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BM * LDK, B_SZ = BN * LDK;
@@ -504,9 +519,9 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
   const int c4 = tid % CT, r0 = tid / CT;
   const int col = n0 + 4 * c4;
   const bool col_ok = col < C;
-  const float xm_hi = (xmask_act == 2) ? 6.f : INFINITY;
-  f32x4 ex[NRC], xm[NRC];
-  auto out_row = [&](int p) {      // GEMM row -> pixel index of dx / addend / xmask
+  f32x4 ex[NRC];
+  uint32_t xw[NRC];
+  auto out_row = [&](int p) {      // GEMM row -> pixel index of dx / addend / mask words
     if (!par) return p;
     int n_, h_, w_;
     pixel(p, n_, h_, w_);
@@ -518,7 +533,7 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
     const bool ok = col_ok && prow_ < M;                                                         \
     const int row = ok ? out_row(prow_) : 0;                                                     \
     ex[i] = (addend && ok) ? *reinterpret_cast<const f32x4*>(addend + (size_t)row * C + col) : f32x4{0.f, 0.f, 0.f, 0.f}; \
-    if (xmask) xm[i] = ok ? *reinterpret_cast<const f32x4*>(xmask + (size_t)row * C + col) : f32x4{1.f, 1.f, 1.f, 1.f}; \
+    if (xbits) xw[i] = ok ? xbits[(size_t)row * (C >> 5) + (col >> 5)] : 0u;                     \
   }
   BD_EPI_ISSUE(0)
   acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
@@ -535,8 +550,15 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
           f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
           v += ex[i];
           // x is the (post-activation) output of the layer below: emitting dx * act'(x) hands that layer its
-          // pre-activation gradient directly — no separate lmh_act_bwd pass over dx
-          if (xmask) v = act_mask(v, xm[i], xm_hi);
+          // pre-activation gradient directly — no separate lmh_act_bwd pass over dx (2 KB of mask words per tile,
+          // requested before the accumulator transpose: their latency runs under it)
+          if (xbits) {
+            const unsigned nib = xw[i] >> (4 * (c4 & 7));
+            v.x = (nib & 1u) ? v.x : 0.f;
+            v.y = (nib & 2u) ? v.y : 0.f;
+            v.z = (nib & 4u) ? v.z : 0.f;
+            v.w = (nib & 8u) ? v.w : 0.f;
+          }
           *reinterpret_cast<f32x4*>(dx + (size_t)row * C + col) = v;
         }
       }

@@ -124,7 +124,9 @@ k_wino_input(const float* __restrict__ x, int N, int H, int W, int C, float* __r
 __global__ void __launch_bounds__(256)
 k_wino_output(const float* __restrict__ Mo, int N, int H, int W, int K, const float* __restrict__ scale,
               const float* __restrict__ shift, const float* __restrict__ extra, float act_lo, float act_hi,
-              float* __restrict__ y) {
+              float* __restrict__ y, uint32_t* __restrict__ bits_out, const uint32_t* __restrict__ bits_in) {
+  // bits_out (forward): activation bit mask of y, [pixel][K/32] words (see k_conv_fwd); bits_in (backward data): the
+  // mask of the layer input — the stored value is dx * act'(x).  8 adjacent lanes = the 32 channels of one word.
   const int K4 = K >> 2, th = (H + 1) >> 1, tw = (W + 1) >> 1;
   const int T = N * th * tw;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -159,7 +161,24 @@ k_wino_output(const float* __restrict__ Mo, int N, int H, int W, int K, const fl
       if (extra) v += *reinterpret_cast<const f32x4*>(extra + off);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
+      const size_t word = (off >> 5);            // off = pixel * K + 4 * k4  ->  pixel * (K / 32) + k4 / 8
+      if (bits_in) {
+        const unsigned nib = bits_in[word] >> (4 * (k4 & 7));
+        v.x = (nib & 1u) ? v.x : 0.f;
+        v.y = (nib & 2u) ? v.y : 0.f;
+        v.z = (nib & 4u) ? v.z : 0.f;
+        v.w = (nib & 8u) ? v.w : 0.f;
+      }
       *reinterpret_cast<f32x4*>(y + off) = v;
+      if (bits_out) {                            // K % 32 == 0: the 8 lanes of a word share tile and pixel
+        unsigned nib = ((v.x > 0.f && v.x < act_hi) ? 1u : 0u) | ((v.y > 0.f && v.y < act_hi) ? 2u : 0u) |
+                       ((v.z > 0.f && v.z < act_hi) ? 4u : 0u) | ((v.w > 0.f && v.w < act_hi) ? 8u : 0u);
+        nib <<= 4 * (k4 & 7);
+        nib |= __shfl_xor(nib, 1);
+        nib |= __shfl_xor(nib, 2);
+        nib |= __shfl_xor(nib, 4);
+        if ((k4 & 7) == 0) bits_out[word] = nib;
+      }
     }
   }
 }
@@ -249,7 +268,7 @@ extern "C" size_t lmh_conv2d_winograd_workspace_bytes(const lmh_conv_desc* d) {
 // Cg = reduction channels, Kg = output channels of this direction.
 static int wino_run(const lmh_conv_desc* d, const float* in, int Cg, int Kg, const float* U, float* V, float* Mo,
                     const float* scale, const float* shift, const float* extra, float act_lo, float act_hi,
-                    float* out, hipStream_t st) {
+                    float* out, uint32_t* bits_out, const uint32_t* bits_in, hipStream_t st) {
   const int T = d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
   {
     const int64_t n = (int64_t)T * (Cg / 4);
@@ -286,7 +305,7 @@ static int wino_run(const lmh_conv_desc* d, const float* in, int Cg, int Kg, con
   {
     const int64_t n = (int64_t)T * (Kg / 4);
     hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,
-                       d->H, d->W, Kg, scale, shift, extra, act_lo, act_hi, out);
+                       d->H, d->W, Kg, scale, shift, extra, act_lo, act_hi, out, bits_out, bits_in);
   }
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -328,7 +347,7 @@ extern "C" int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, con
 
 extern "C" int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float* w, const float* u,
                                        const float* scale, const float* shift, const float* residual, float* y,
-                                       void* ws, size_t ws_bytes, lmh_stream_t stream) {
+                                       uint32_t* act_bits, void* ws, size_t ws_bytes, lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(x && (w || u) && y && wino_ok(d));
@@ -342,12 +361,12 @@ extern "C" int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, c
     u = U;
   }
   const float lo = d->act ? 0.f : -INFINITY, hi = (d->act == 2) ? 6.f : INFINITY;
-  return wino_run(d, x, d->C, d->K, u, V, Mo, scale, shift, residual, lo, hi, y, st);
+  return wino_run(d, x, d->C, d->K, u, V, Mo, scale, shift, residual, lo, hi, y, act_bits, nullptr, st);
 }
 
 extern "C" int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w, const float* u,
-                                            const float* kscale, const float* addend, float* dx, void* ws,
-                                            size_t ws_bytes, lmh_stream_t stream) {
+                                            const float* kscale, const float* addend, const uint32_t* xbits,
+                                            float* dx, void* ws, size_t ws_bytes, lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(dy && (w || u) && dx && wino_ok(d));
@@ -360,7 +379,7 @@ extern "C" int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float*
     hipLaunchKernelGGL(k_wino_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, U);
     u = U;
   }
-  return wino_run(d, dy, d->K, d->C, u, V, Mo, nullptr, nullptr, addend, -INFINITY, INFINITY, dx, st);
+  return wino_run(d, dy, d->K, d->C, u, V, Mo, nullptr, nullptr, addend, -INFINITY, INFINITY, dx, nullptr, xbits, st);
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------

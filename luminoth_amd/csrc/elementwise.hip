@@ -147,6 +147,58 @@ extern "C" int lmh_act_bwd(const float* dy, const float* y, int act, int64_t row
   return LMH_OK;
 }
 
+// ---- activation bit masks (standalone forms; the fast convolution kernels emit / apply them in their epilogues) ----
+// bits[row][K/32]: bit c%32 of word c/32 = act'(y[row][c]) != 0  (relu: y > 0; relu6: 0 < y < 6).  One lane per float4,
+// 8 adjacent lanes assemble a word.
+__global__ void __launch_bounds__(256)
+k_act_bits(const float* __restrict__ y, float hi, int64_t n4, uint32_t* __restrict__ bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // float4 index; grid covers a multiple of 8
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) v = reinterpret_cast<const float4*>(y)[i];
+  unsigned nib = ((v.x > 0.f && v.x < hi) ? 1u : 0u) | ((v.y > 0.f && v.y < hi) ? 2u : 0u) |
+                 ((v.z > 0.f && v.z < hi) ? 4u : 0u) | ((v.w > 0.f && v.w < hi) ? 8u : 0u);
+  nib <<= 4 * (threadIdx.x & 7);
+  nib |= __shfl_xor(nib, 1);
+  nib |= __shfl_xor(nib, 2);
+  nib |= __shfl_xor(nib, 4);
+  if ((threadIdx.x & 7) == 0 && i < n4) bits[i >> 3] = nib;
+}
+
+__global__ void __launch_bounds__(256)
+k_apply_act_bits(float* __restrict__ dx, const uint32_t* __restrict__ bits, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const unsigned nib = bits[i >> 3] >> (4 * (i & 7));
+  float4 v = reinterpret_cast<float4*>(dx)[i];
+  v.x = (nib & 1u) ? v.x : 0.f;
+  v.y = (nib & 2u) ? v.y : 0.f;
+  v.z = (nib & 4u) ? v.z : 0.f;
+  v.w = (nib & 8u) ? v.w : 0.f;
+  reinterpret_cast<float4*>(dx)[i] = v;
+}
+
+int lmh_act_bits_impl(const float* y, int act, int64_t rows, int K, uint32_t* bits, hipStream_t st) {
+  LMH_CHECK_ARG(y && bits && rows > 0 && K > 0 && (K & 31) == 0 && (act == 1 || act == 2));
+  const int64_t n4 = rows * (K >> 2);
+  hipLaunchKernelGGL(k_act_bits, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, y, act == 2 ? 6.f : INFINITY, n4,
+                     bits);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+int lmh_apply_act_bits_impl(float* dx, const uint32_t* bits, int64_t rows, int C, hipStream_t st) {
+  LMH_CHECK_ARG(dx && bits && rows > 0 && C > 0 && (C & 31) == 0);
+  const int64_t n4 = rows * (C >> 2);
+  hipLaunchKernelGGL(k_apply_act_bits, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dx, bits, n4);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+extern "C" int lmh_act_bits(const float* y, int act, int64_t rows, int K, uint32_t* bits, lmh_stream_t stream) {
+  return lmh_act_bits_impl(y, act, rows, K, bits, (hipStream_t)stream);
+}
+extern "C" int lmh_apply_act_bits(float* dx, const uint32_t* bits, int64_t rows, int C, lmh_stream_t stream) {
+  return lmh_apply_act_bits_impl(dx, bits, rows, C, (hipStream_t)stream);
+}
+
 // BN (frozen) parameter gradients from the raw weight gradient, two stages:
 //   partial[b][k] = sum_{i in slab b} w[i,k]*dw_raw[i,k];  dw[i,k] = dw_raw[i,k]*scale[k]
 //   dgamma[k] = rstd[k]*(sum_b partial[b][k] - mean[k]*dbeta[k])

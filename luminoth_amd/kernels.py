@@ -285,27 +285,36 @@ def winograd_transform_weights(d, w, kscale, backward, out):
     return out
 
 
-def conv2d_fwd_winograd(d, x, w, scale=None, shift=None, residual=None, out=None):
+def act_bits_ok(channels, act):
+    """A layer output can carry an activation bit mask (one bit per element, 32 channels per word)."""
+    return bool(act) and channels % 32 == 0
+
+
+def new_act_bits(rows, channels, device):
+    return torch.empty((rows, channels // 32), dtype=torch.int32, device=device)
+
+
+def conv2d_fwd_winograd(d, x, w, scale=None, shift=None, residual=None, out=None, act_bits=None):
     lib = _lib.load()
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
     ws = _workspace(lib.lmh_conv2d_winograd_workspace_bytes(ctypes.byref(d)), x.device, 'winograd')
     u = None      # transformed weights are produced inside the call (they change every step)
     with _timed(d, 0, wino=True):
         check(lib.lmh_conv2d_fwd_winograd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(u), _p(scale), _p(shift),
-                                          _p(residual), _p(y), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
-              'lmh_conv2d_fwd_winograd')
+                                          _p(residual), _p(y), _p(act_bits), _p(ws), ctypes.c_size_t(ws.numel()),
+                                          _stream()), 'lmh_conv2d_fwd_winograd')
     return y
 
 
-def conv2d_bwd_data_winograd(d, dy, w, kscale=None, addend=None, out=None):
+def conv2d_bwd_data_winograd(d, dy, w, kscale=None, addend=None, out=None, xbits=None):
     lib = _lib.load()
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
     ws = _workspace(lib.lmh_conv2d_winograd_workspace_bytes(ctypes.byref(d)), dy.device, 'winograd')
     u = None
     with _timed(d, 1, wino=True):
         check(lib.lmh_conv2d_bwd_data_winograd(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(u), _p(kscale),
-                                               _p(addend), _p(dx), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
-              'lmh_conv2d_bwd_data_winograd')
+                                               _p(addend), _p(xbits), _p(dx), _p(ws), ctypes.c_size_t(ws.numel()),
+                                               _stream()), 'lmh_conv2d_bwd_data_winograd')
     return dx
 
 
@@ -327,15 +336,33 @@ def conv2d_bwd_weight_winograd(d, x, dy, out=None):
     return dw
 
 
-def conv2d_fwd(d, x, w, scale=None, shift=None, residual=None, in_sub=None, out=None):
+def conv2d_fwd(d, x, w, scale=None, shift=None, residual=None, in_sub=None, out=None, act_bits=None):
+    """act_bits (int32 (rows, K/32), optional): WRITTEN with the activation bit mask of y (bit = act'(y) != 0) — what the
+    backward pass needs of the activation; the consumer's backward-data epilogue applies it (conv2d_bwd_data xbits)."""
     lib = _lib.load()
     if in_sub is None and _use_winograd(d):
-        return conv2d_fwd_winograd(d, x, w, scale, shift, residual, out)
+        return conv2d_fwd_winograd(d, x, w, scale, shift, residual, out, act_bits)
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
     with _timed(d, 0):
         check(lib.lmh_conv2d_fwd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(scale), _p(shift), _p(residual),
-                                 _p(in_sub), _p(y), _stream()), 'lmh_conv2d_fwd')
+                                 _p(in_sub), _p(y), _p(act_bits), _stream()), 'lmh_conv2d_fwd')
     return y
+
+
+def act_bits(y, act):
+    """The bit mask of an activation tensor on its own (producers that are not a convolution of this library)."""
+    K = y.shape[-1]
+    rows = y.numel() // K
+    bits = new_act_bits(rows, K, y.device)
+    check(_lib.load().lmh_act_bits(_p(y), ACT[act], rows, K, _p(bits), _stream()), 'lmh_act_bits')
+    return bits
+
+
+def apply_act_bits(dx, bits):
+    """dx <- dx where the bit is set else 0, in place."""
+    C = dx.shape[-1]
+    check(_lib.load().lmh_apply_act_bits(_p(dx), _p(bits), dx.numel() // C, C, _stream()), 'lmh_apply_act_bits')
+    return dx
 
 
 def conv_fused_act_ok(d):
@@ -355,21 +382,18 @@ def conv_bwd_data_fast(d):
     return _lib.load().lmh_conv2d_kernel_id(ctypes.byref(d), 1) < 1000000
 
 
-def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None, yact=None, xmask=None, xmask_act=None):
+def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None, yact=None, xbits=None):
     """yact: layer output y -> the kernel applies g = dy*act'(y) on load (fused activation backward).
-    xmask (= the layer input x) + xmask_act: the result is dx * act'(x), i.e. the pre-activation gradient
-    of the layer that produced x (fused in the epilogue on the fast path, one extra pass otherwise)."""
+    xbits (the activation bit mask of the layer input x, written by the forward kernel that produced x): the result is
+    dx * act'(x), i.e. the pre-activation gradient of the layer below (epilogue of the fast / Winograd kernels; one
+    in-place pass inside the C call for the others)."""
     lib = _lib.load()
-    if yact is None and xmask is None and _use_winograd(d):
-        return conv2d_bwd_data_winograd(d, dy, w, kscale, addend, out)
+    if yact is None and _use_winograd(d):
+        return conv2d_bwd_data_winograd(d, dy, w, kscale, addend, out, xbits)
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
-    fuse_mask = xmask is not None and conv_bwd_data_fast(d)
     with _timed(d, 1):
         check(lib.lmh_conv2d_bwd_data(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(kscale), _p(addend), _p(yact),
-                                      _p(xmask if fuse_mask else None), ACT[xmask_act] if fuse_mask else 0,
-                                      _p(dx), _stream()), 'lmh_conv2d_bwd_data')
-    if xmask is not None and not fuse_mask:
-        dx = act_bwd(dx, xmask, xmask_act)
+                                      _p(xbits), _p(dx), _stream()), 'lmh_conv2d_bwd_data')
     return dx
 
 

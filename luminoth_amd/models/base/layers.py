@@ -13,10 +13,14 @@ import torch
 from luminoth_amd import kernels as K
 
 FUSE_ACT = os.environ.get('LUMINOTH_AMD_FUSE_ACT', '0') == '1'
-# act'(x) in the bwd_data epilogue (removes ~30 lmh_act_bwd launches per step).  OFF by default: the mask tensor
-# is a cold forward activation and reading it in the epilogue of a 1-block-per-CU tile is latency-exposed —
-# measured 10.96 ms/step fused vs 10.77 unfused (the streaming lmh_act_bwd pass hides that latency).
-FUSE_MASK = os.environ.get('LUMINOTH_AMD_FUSE_MASK', '0') == '1'
+# ReLU gradient without a pass of its own (round 3).  Every convolution whose output feeds a trainable layer also writes
+# the ACTIVATION BIT MASK of that output (1 bit per element, emitted by the epilogue that holds the values anyway);
+# the backward-data kernel of the consumer applies it in ITS epilogue, so the gradient that reaches a layer already is
+# g = dy * act'(y): ~36 of the 41 lmh_act_bwd launches of a ResNet-50 step (2.1 GB of traffic, 0.44 ms of kernels plus
+# their launch gaps on the critical stream) disappear.  Round 2 tried the same fusion with the fp32 activation itself as
+# the mask operand: 64 KB of cold HBM reads per tile in the epilogue, latency-exposed, measured slower than the
+# streaming pass.  The bit mask is 2 KB per tile and is requested before the accumulator transpose.
+FUSE_MASK = os.environ.get('LUMINOTH_AMD_FUSE_MASK', '1') == '1'
 BN_EPS = 1e-5  # slim resnet_arg_scope batch_norm_epsilon (truncated_base_network.py:69-73)
 
 
@@ -118,12 +122,17 @@ class ConvLayer(object):
             self._desc[key] = d
         return d
 
-    def forward(self, x, residual=None, in_sub=None):
+    def forward(self, x, residual=None, in_sub=None, want_bits=False):
+        """want_bits: also return the activation bit mask of y (None when the layer has no activation or a channel
+        count that is not a multiple of 32) -> (y, bits)."""
         d = self.desc(x.shape)
-        y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub)
+        bits = None
+        if want_bits and FUSE_MASK and K.act_bits_ok(self.cout, self.act):
+            bits = K.new_act_bits(d.N * d.OH * d.OW, self.cout, x.device)
+        y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub, act_bits=bits)
         if ACT_TAP is not None:
             ACT_TAP[self.scope] = y
-        return y
+        return (y, bits) if want_bits else y
 
     def _weight_grads(self, d, x, g, yact, colsum):
         if self.compute_wgrad != 'same':
@@ -149,15 +158,15 @@ class ConvLayer(object):
             ok = self._fused[key] = (FUSE_ACT and K.conv_fused_act_ok(d), K.conv_fused_colsum_ok(d))
         return ok
 
-    def backward(self, x, y, dy, need_dx=True, addend=None, want_g=False, dy_is_g=False, mask_input=None):
+    def backward(self, x, y, dy, need_dx=True, addend=None, want_g=False, dy_is_g=False, mask_bits=None):
         """dy: gradient w.r.t. the layer output (after residual add + act).
         Returns (dx or None, g) with g = dy * act'(y) = gradient w.r.t. the pre-activation sum (== gradient
         of the residual branch); g is only materialised when `want_g` (the bottleneck's shortcut needs
         it) or when the fast kernels cannot take it fused — otherwise both backward convolutions apply
         act'(y) while they load dy, and the per-channel sums (dbeta / dbias) come out of bwd_weight.
         dy_is_g: the incoming gradient already is g (the producer applied act'(y) in its epilogue).
-        mask_input: activation of the layer that produced x ('relu' / 'relu6'): the returned dx is then
-        dx * act'(x), i.e. THAT layer's g (fused into the bwd_data epilogue)."""
+        mask_bits: activation bit mask of x (written by the forward kernel of the layer that produced x): the
+        returned dx is then dx * act'(x), i.e. THAT layer's g (applied in the bwd_data epilogue)."""
         d = self.desc(x.shape)
         act_fused, colsum_fused = self._fused_ok(d, tuple(x.shape))
         colsum = None
@@ -183,8 +192,7 @@ class ConvLayer(object):
         dx = None
         if inline and need_dx:        # tail of the backward: data gradient first, weight gradients behind it
             dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
-                                   addend=addend, yact=yact, xmask=x if mask_input else None,
-                                   xmask_act=mask_input)
+                                   addend=addend, yact=yact, xbits=mask_bits)
         if self.trainable:
             cs = colsum if colsum_in_wgrad else None
             if SideStream.enabled and not inline:
@@ -199,8 +207,7 @@ class ConvLayer(object):
                 self._weight_grads(d, x, g, yact, cs)
         if need_dx and not inline:
             dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
-                                   addend=addend, yact=yact, xmask=x if mask_input else None,
-                                   xmask_act=mask_input)
+                                   addend=addend, yact=yact, xbits=mask_bits)
         return dx, (g if yact is None else None)
 
 
@@ -288,19 +295,25 @@ class ConvNode(object):
         self.layers = [layer]
 
     def forward(self, x, save):
-        y = self.layer.forward(x, in_sub=self.in_sub)
-        return y, ((x, y) if save else None)
+        if not save:
+            return self.layer.forward(x, in_sub=self.in_sub), None
+        y, bits = self.layer.forward(x, in_sub=self.in_sub, want_bits=True)
+        return y, (x, y, bits)
 
     out_act = property(lambda self: self.layer.act)
+
+    @staticmethod
+    def out_bits(saved):
+        return saved[2]
 
     def out_hw(self, h, w):
         l = self.layer
         d = K.conv_desc((1, h, w, l.cin), (l.k, l.k, l.cin, l.cout), l.stride, l.rate, l.padding, l.act)
         return d.OH, d.OW
 
-    def backward(self, saved, dy, need_dx, dy_is_g=False, mask_input=None):
-        x, y = saved
-        dx, _ = self.layer.backward(x, y, dy, need_dx=need_dx, dy_is_g=dy_is_g, mask_input=mask_input)
+    def backward(self, saved, dy, need_dx, dy_is_g=False, mask_bits=None):
+        x, y, _ = saved
+        dx, _ = self.layer.backward(x, y, dy, need_dx=need_dx, dy_is_g=dy_is_g, mask_bits=mask_bits)
         return dx
 
 
@@ -320,12 +333,16 @@ class MaxPoolNode(object):
         y, geom = K.maxpool_fwd(x, self.k, self.s, self.p)
         return y, ((x, y, geom) if save else None)
 
-    def backward(self, saved, dy, need_dx, dy_is_g=False, mask_input=None):
+    @staticmethod
+    def out_bits(saved):
+        return None
+
+    def backward(self, saved, dy, need_dx, dy_is_g=False, mask_bits=None):
         if not need_dx:
             return None
         x, y, geom = saved
         dx = K.maxpool_bwd(x, y, dy, self.k, self.s, geom)
-        return K.act_bwd(dx, x, mask_input) if mask_input else dx
+        return K.apply_act_bits(dx, mask_bits) if mask_bits is not None else dx
 
 
 class BottleneckNode(object):
@@ -353,31 +370,39 @@ class BottleneckNode(object):
             sc, geom = K.maxpool_fwd(x, 1, self.stride, 'VALID')   # resnet_utils.subsample
         else:
             sc = x
-        a = self.conv1.forward(x)
-        b = self.conv2.forward(a)
-        y = self.conv3.forward(b, residual=sc)
-        return y, ((x, sc, a, b, y, geom) if save else None)
+        if not save:
+            a = self.conv1.forward(x)
+            b = self.conv2.forward(a)
+            return self.conv3.forward(b, residual=sc), None
+        a, ba = self.conv1.forward(x, want_bits=True)
+        b, bb = self.conv2.forward(a, want_bits=True)
+        y, by = self.conv3.forward(b, residual=sc, want_bits=True)
+        return y, (x, sc, a, b, y, geom, ba, bb, by)
+
+    @staticmethod
+    def out_bits(saved):
+        return saved[8]
 
     out_act = 'relu'
 
     def out_hw(self, h, w):
         return -(-h // self.stride), -(-w // self.stride)
 
-    def backward(self, saved, dy, need_dx, dy_is_g=False, mask_input=None):
-        """Every bwd_data epilogue multiplies by relu'(its own input), so the gradient that reaches the
-        layer below already is that layer's g: no lmh_act_bwd passes inside the unit (and none for the
-        unit below when `mask_input` asks this unit to do the same for its input x)."""
-        x, sc, a, b, y, geom = saved
-        m = 'relu' if FUSE_MASK else None
-        d_b, g = self.conv3.backward(b, y, dy, want_g=True, dy_is_g=dy_is_g, mask_input=m)
-        d_a, _ = self.conv2.backward(a, b, d_b, dy_is_g=FUSE_MASK, mask_input=m)
+    def backward(self, saved, dy, need_dx, dy_is_g=False, mask_bits=None):
+        """Every bwd_data epilogue applies the activation bit mask of its own input, so the gradient that reaches the
+        layer below already is that layer's g: no lmh_act_bwd passes inside the unit (and none for the unit below when
+        `mask_bits` — the mask of this unit's input x — is handed in)."""
+        x, sc, a, b, y, geom, ba, bb, _ = saved
+        d_b, g = self.conv3.backward(b, y, dy, want_g=True, dy_is_g=dy_is_g, mask_bits=bb)
+        d_a, _ = self.conv2.backward(a, b, d_b, dy_is_g=bb is not None, mask_bits=ba)
         if self.shortcut is not None:
             d_sc, _ = self.shortcut.backward(x, sc, g, need_dx=need_dx)
         elif self.stride > 1:
             d_sc = K.maxpool_bwd(x, sc, g, 1, self.stride, geom) if need_dx else None
         else:
             d_sc = g
-        dx, _ = self.conv1.backward(x, a, d_a, need_dx=need_dx, addend=d_sc, dy_is_g=FUSE_MASK, mask_input=mask_input)
+        dx, _ = self.conv1.backward(x, a, d_a, need_dx=need_dx, addend=d_sc, dy_is_g=ba is not None,
+                                    mask_bits=mask_bits if need_dx else None)
         return dx
 
 
@@ -419,9 +444,9 @@ class Trunk(object):
         SideStream.layers_left = sum(1 for n in nodes for l in n.layers if l.trainable)
         for j in range(len(nodes) - 1, -1, -1):
             need_dx = (j > 0) or need_dx_first
-            # node j-1's output activation is folded into node j's data gradient (fused epilogue mask)
-            below = nodes[j - 1].out_act if (j > 0 and FUSE_MASK) else None
-            dy = nodes[j].backward(saved[j], dy, need_dx, dy_is_g=dy_is_g, mask_input=below)
+            # node j-1's activation gradient is folded into node j's data gradient (bit mask in the bwd_data epilogue)
+            below = nodes[j - 1].out_bits(saved[j - 1]) if (j > 0 and FUSE_MASK) else None
+            dy = nodes[j].backward(saved[j], dy, need_dx, dy_is_g=dy_is_g, mask_bits=below)
             dy_is_g = below is not None
             if hook is not None:
                 hook(nodes, j)

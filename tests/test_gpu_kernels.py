@@ -561,6 +561,23 @@ def test_conv_fwd_bwd(K, case, monkeypatch):
     dws = dw.cpu().numpy() * scale[None, None, None, :]
     tolw = 5e-5 * max(1.0, float(np.abs(dw_ref).max()))
     np.testing.assert_allclose(dws, dw_ref, rtol=1e-3, atol=tolw)
+    # activation bit mask (round 3): the forward epilogue (or the stand-alone pass for kernels without it) writes one bit
+    # per output element; a consumer's backward-data epilogue applies a mask of ITS input: dx * act'(x) — bit-identical
+    # to masking afterwards
+    if act and Kc % 32 == 0:
+        bits = K.new_act_bits(N * d.OH * d.OW, Kc, dev())
+        y2 = K.conv2d_fwd(d, T(x), T(w), T(scale), T(shift), T(res), None if in_sub is None else T(in_sub),
+                          act_bits=bits)
+        assert torch.equal(y2, y)
+        ref_bits = np.packbits(((yg > 0) & ((yg < 6) if act == 'relu6' else True)).reshape(-1, Kc // 32, 32),
+                               axis=-1, bitorder='little').view(np.uint32).reshape(-1, Kc // 32)
+        np.testing.assert_array_equal(bits.cpu().numpy().view(np.uint32), ref_bits)
+        assert torch.equal(K.act_bits(y, act), bits)
+    if C % 32 == 0:
+        xm = rs.rand(N * H * W, C) > 0.4                                    # any mask of the layer input
+        xbits = T(np.packbits(xm.reshape(-1, C // 32, 32), axis=-1, bitorder='little').view(np.int32).reshape(-1, C // 32))
+        dx_m = K.conv2d_bwd_data(d, g, T(w), T(scale), addend=T(add), xbits=xbits)
+        np.testing.assert_array_equal(dx_m.cpu().numpy(), np.where(xm.reshape(x.shape), dx2.cpu().numpy(), 0))
     # fused activation backward: the kernels apply act'(y) while loading dy -> bit-identical results,
     # and bwd_weight emits the per-channel sums of g (dbeta / dbias)
     if K.conv_fused_colsum_ok(d):
@@ -679,6 +696,15 @@ def test_conv_winograd_equals_direct(K, case):
     np.testing.assert_allclose(dw_win.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=tolw)
     if dw_dir is not None:
         np.testing.assert_allclose(dw_win.cpu().numpy(), dw_dir.cpu().numpy(), rtol=1e-3, atol=tolw)
+    # activation bit masks through the output transform (round 3): emitted for y, applied to dx
+    if act and Kc % 32 == 0:
+        bits = K.new_act_bits(N * H * W, Kc, dev())
+        y_b = K.conv2d_fwd_winograd(d, T(x), T(w), T(scale), T(shift), T(res), act_bits=bits)
+        assert torch.equal(y_b, y_win) and torch.equal(bits, K.act_bits(y_win, act))
+    xm = rs.rand(N * H * W, C) > 0.4
+    xbits = T(np.packbits(xm.reshape(-1, C // 32, 32), axis=-1, bitorder='little').view(np.int32).reshape(-1, C // 32))
+    dx_m = K.conv2d_bwd_data_winograd(d, T(g), T(w), T(scale), addend=T(add), xbits=xbits)
+    np.testing.assert_array_equal(dx_m.cpu().numpy(), np.where(xm.reshape(x.shape), dx_win.cpu().numpy(), 0))
     dx0 = K.conv2d_bwd_data_winograd(d, T(g), T(w))                    # no kscale, no addend
     xt.grad = None
     ot.conv2d_nhwc(xt, torch.tensor(w), 1, 1, 'SAME').backward(torch.tensor(g))

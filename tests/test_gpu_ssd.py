@@ -157,20 +157,21 @@ def ssd_setup():
     return cfg, model, images, gts
 
 
-def test_ssd_train_step_matches_oracle(ssd_setup):
-    cfg, model, images, gts = ssd_setup
+def _ssd_step_vs_oracle(model, images, gts):
+    B = images.shape[0]
     pred = model(images, gts, is_training=True)
     losses = model.loss(pred, return_all=True)
     model.backward(losses['total_loss'])
     torch.cuda.synchronize()
-    assert pred['cls_pred'].shape == (2, 8096, 21) and pred['loc_pred'].shape == (2, 8096, 4)
+    assert pred['cls_pred'].shape == (B, 8096, 21) and pred['loc_pred'].shape == (B, 8096, 4)
     oracle = OracleSSD(model.state_dict(), num_classes=20)
     for n in oracle.v:
         oracle.v[n].requires_grad_(True)
     tot = 0.0
-    for b in range(2):
+    for b in range(B):
         # discrete stage pinned to the kernel's labels/targets (they depend on the kernel's own probs; the kernel
-        # itself is checked bit-exactly against the oracle in test_ssd_target_*): the dense path is what is compared
+        # itself is checked bit-exactly against the oracle in test_ssd_target_* and against the reference's own graph
+        # code in test_gpu_ref_tf_golden.py): the dense path is what is compared
         o = oracle.forward_image(images[b], gts[b], overrides={'labels': pred['target']['cls'][b].cpu().numpy(),
                                                                 'targets': pred['target']['bbox_offsets'][b].cpu().numpy()})
         scale = max(1.0, float(o['cls_pred'].abs().max()))
@@ -181,29 +182,49 @@ def test_ssd_train_step_matches_oracle(ssd_setup):
         # the oracle's own target stage on the oracle's probabilities agrees wherever the probabilities do
         ol, _ = oss.ssd_target(pred['cls_prob'][b].cpu().numpy(), o['anchors'], gts[b])
         np.testing.assert_array_equal(pred['target']['cls'][b].cpu().numpy(), ol)
-        tot = tot + o['loss']
-    ref = tot / 2 + oracle.regularization_loss().float()
-    np.testing.assert_allclose(float(losses['total_loss']), float(ref), rtol=1e-4)
-    ref.backward()
+        (o['loss'] / B).backward()           # per image: 32 VGG graphs are never alive together
+        tot = tot + float(o['loss'])
+    reg = oracle.regularization_loss().float()
+    np.testing.assert_allclose(float(losses['total_loss']), tot / B + float(reg), rtol=1e-4)
     grads = model.store.grads
     worst = 0.0
     for n, gk in grads.items():
         go = oracle.v[n].grad
         if go is None:
             continue
-        go = go.numpy().reshape(gk.shape)
-        if n.endswith('/weights') and '/vgg_16/' in n:
-            go = go - 5e-4 * oracle.v[n].detach().numpy().reshape(gk.shape)   # the L2 term lives in the optimizer kernel
+        go = go.numpy().reshape(gk.shape)             # data-loss gradient: the L2 term lives in the optimizer kernel
         err = np.abs(gk.cpu().numpy() - go).max() / max(1e-6, np.abs(go).max())
         worst = max(worst, err)
         assert err < 2e-3, (n, err)
     assert worst > 0
 
 
+def test_ssd_train_step_matches_oracle(ssd_setup):
+    cfg, model, images, gts = ssd_setup
+    _ssd_step_vs_oracle(model, images, gts)
+
+
+def test_ssd_train_step_matches_oracle_at_config3_batch32(ssd_setup):
+    """BASELINE configs[2] at its own shape: SSD VGG-300, batch 32, 4 gt boxes per image with sides U{30..200}, C = 20
+    (SURVEY.md §8d synthetic inputs); pixels conditioned to O(1) like the small test (a random-init VGG on raw 0..255
+    pixels saturates fp32 round-off, see scripts/check_vgg_conditioning.py)."""
+    cfg, model, _, _ = ssd_setup
+    g = torch.Generator().manual_seed(0)
+    images = torch.rand((32, 300, 300, 3), generator=g) * 2.0 - 1.0
+    rs = np.random.RandomState(0)
+    gts = []
+    for b in range(32):
+        wh = rs.randint(30, 201, size=(4, 2))
+        xy = np.stack([rs.randint(0, 300 - wh[:, 0]), rs.randint(0, 300 - wh[:, 1])], 1)
+        gts.append(np.concatenate([xy, xy + wh - 1, rs.randint(0, 20, size=(4, 1))], 1).astype(F))
+    _ssd_step_vs_oracle(model, images, gts)
+
+
 def test_ssd_inference_prediction_dict(ssd_setup):
     cfg, model, images, gts = ssd_setup
     pd = model(images[0], None, is_training=False)
     cp = pd['classification_prediction']
-    assert set(('objects', 'labels', 'probs')) <= set(cp)
+    assert set(('objects', 'labels', 'probs', 'raw_proposals', 'anchors')) <= set(cp)       # ssd/proposal.py:165-171
+    assert cp['anchors'].shape == cp['objects'].shape and cp['raw_proposals'].shape[1] == 4
     assert cp['objects'].shape[1] == 4 and cp['objects'].shape[0] == cp['probs'].shape[0] <= 100
     assert pd['cls_pred'].shape == (8096, 21) and pd['loc_pred'].shape == (8096, 4)
