@@ -192,7 +192,10 @@ def main():
                          'of the three streams ("phases" in the JSON line; Faster R-CNN workloads)')
     ap.add_argument('--no-lookahead', action='store_true',
                     help='do not tell the step which batch comes next (no cross-step prefetch of the frozen trunk prefix)')
-    ap.add_argument('--no-alt', action='store_true', help='skip the bf16x3 re-run reported as `alt_arithmetic`')
+    ap.add_argument('--alt', action='store_true',
+                    help='also re-run the step with bf16x3 convolutions and report it as `alt_arithmetic` (opt-in since '
+                         'round 3: its gain did not reproduce on the driver\'s box)')
+    ap.add_argument('--no-alt', action='store_true', help='(accepted for compatibility; the alt run is opt-in now)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=5)
@@ -309,6 +312,7 @@ def main():
             peak = PEAK_TFLOPS[args.dtype]
             name = max(prof, key=lambda k: prof[k]['ms'])          # the dominant kernel class, whichever pass it is in
             step_flops = sum(v['direct_flops'] for v in prof.values()) / nprof
+            exec_flops = sum(v['flops'] for v in prof.values()) / nprof
             r = prof[name]
             fl = r['flops'] / r['launches']
             by = r['bytes'] / r['launches']
@@ -331,8 +335,17 @@ def main():
                 'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
                 'ms_per_step': r['ms'] / nprof,
                 'timing': 'HIP events around the kernel on its launch stream, %d serialised profiling steps' % nprof,
+                # conv_flops = the ALGORITHMIC count of SURVEY.md 8(d) (direct convolution); executed_flops = what the
+                # launched kernels actually multiply (Winograd F(2x2,3x3) layers do 2.25x fewer): the second is the honest
+                # measure of how busy the matrix pipe is, the first of how fast the step's defined work gets done
                 'whole_step': {'conv_flops': step_flops, 'tflops': step_flops / dt * args.steps / 1e12,
-                               'frac': step_flops / dt * args.steps / 1e12 / peak},
+                               'frac': step_flops / dt * args.steps / 1e12 / peak,
+                               'executed_flops': exec_flops,
+                               'executed_tflops': exec_flops / dt * args.steps / 1e12,
+                               'executed_frac': exec_flops / dt * args.steps / 1e12 / peak,
+                               'conv_kernel_ms_per_step': sum(v['ms'] for v in prof.values()) / nprof,
+                               'executed_frac_of_conv_kernel_time':
+                                   exec_flops / (sum(v['ms'] for v in prof.values()) / nprof * 1e-3) / 1e12 / peak},
                 'all_conv_kernels': {k: {'launches_per_step': v['launches'] / nprof,
                                          'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
                                          'gbs': v['bytes'] / (v['ms'] * 1e-3) / 1e9,
@@ -358,10 +371,15 @@ def main():
                        'global_batch': gb, 'parallelism': 'dp%d' % world, 'final_total_loss': loss_val,
                        'schedule': schedule},
             'roofline': roofline,
+            # what the collective layer saw (SCALE_rNN.json can show that RCCL ran with N ranks)
+            'dist': {'world_size': dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
+                     'backend': dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None,
+                     'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version())
+                     if hasattr(torch.cuda, 'nccl') else None},
         }
         if phases:
             out['phases_ms'] = phases
-        if args.dtype == 'f32' and world == 1 and not args.no_alt and wl['model'] != 'ssd' and not args.serial:
+        if args.dtype == 'f32' and world == 1 and args.alt and wl['model'] != 'ssd' and not args.serial:
             # the same step with the convolutions in bf16x3 (fp32 arithmetic on the bf16 matrix pipe),
             # measured in this process right after the headline run: reported BESIDE `value`, never as it
             cfg2, model2 = build(wl, device, 'bf16x3')

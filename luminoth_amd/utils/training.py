@@ -167,11 +167,17 @@ class GradientBuckets(object):
         numel = int(grad.numel())
         todo, pos = [], 0
         for lo, hi in sorted(self._done):
+            # every element exactly once per step: an early bucket that overlaps another (or runs past the buffer)
+            # would be summed twice over the replicas — a silent 2x on those gradients
+            if lo < pos or hi > numel or lo >= hi:
+                raise RuntimeError('GradientBuckets: early buckets %r overlap or leave [0, %d)' % (sorted(self._done), numel))
             if lo > pos:
                 todo.append((pos, lo))
-            pos = max(pos, hi)
+            pos = hi
         if pos < numel:
             todo.append((pos, numel))
+        covered = sum(hi - lo for lo, hi in self._done) + sum(hi - lo for lo, hi in todo)
+        assert covered == numel, (covered, numel)
         for w in self._works:
             w.wait()
         if self._comm is not None and self._works and grad.is_cuda:

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 F = np.float32
 
 
-from e2e_util import compare_step_with_oracle, condition_like_pretrained, make_config, synth   # noqa: E402
+from e2e_util import (compare_step_with_oracle, condition_like_pretrained, free_running_agreement, make_config,   # noqa: E402
+                      synth)
 
 
 @pytest.fixture(scope='module')
@@ -58,6 +59,41 @@ def test_train_step_matches_oracle_at_benchmark_shape():
     images, (gt, cnt) = bench.synth_batch(2, 1024, 1024, 8, 80, 100, 'cpu')
     gts = [gt[b, :int(cnt[b])].numpy() for b in range(2)]
     compare_step_with_oracle(model, images, gts, 80)
+
+
+def test_free_running_agreement_at_benchmark_shape():
+    """the step comparison is teacher-forced stage by stage.  Here the oracle runs FREE on its own
+    upstream outputs at the benchmark shape; reported (printed) and bounded: the proposal lists and the sampled ROI sets
+    must coincide almost everywhere (near-ties of scores at the last bit may reorder a few), every loss within 1e-3."""
+    from luminoth_amd.models import get_model
+    import bench
+    cfg = make_config()
+    model = get_model('fasterrcnn')(cfg)
+    bench.condition_weights(model, 'resnet_v1_50')
+    images, (gt, cnt) = bench.synth_batch(2, 1024, 1024, 8, 80, 100, 'cpu')
+    gts = [gt[b, :int(cnt[b])].numpy() for b in range(2)]
+    rep = free_running_agreement(model, images, gts, 80)
+    print('free-running agreement @ 2x1024^2: proposals at the same rank %s, as sets %s, sampled ROI sets %s, losses %s'
+          % (rep['same_rank'], rep['same_set'], rep['roi_set'], rep['losses']))
+    assert min(rep['same_set']) >= 0.98 and min(rep['roi_set']) >= 0.95
+    for k, (got, ref) in rep['losses'].items():
+        assert abs(got - ref) <= 1e-3 * max(1.0, abs(ref)), (k, got, ref)
+
+
+def test_resnet101_tail_at_config4_size():
+    """BASELINE configs[3] per-GPU share at its own size: ResNet-101, 2 x 1024 x 1024, 80 classes, RCNN minibatch 256
+    (12 544 GEMM rows through the block4 tail per image).  Losses, head outputs and integer stages only — the
+    small-shape test below covers every gradient of the same code path; here the oracle's backward alone would run
+    minutes on the host."""
+    from luminoth_amd.models import get_model
+    import bench
+    cfg = make_config('resnet_v1_101', 80)
+    model = get_model('fasterrcnn')(cfg)
+    bench.condition_weights(model, 'resnet_v1_101')
+    assert model._rcnn._rcnn_target._minibatch_size == 256 and model.base_network.tail is not None
+    images, (gt, cnt) = bench.synth_batch(2, 1024, 1024, 8, 80, 100, 'cpu')
+    gts = [gt[b, :int(cnt[b])].numpy() for b in range(2)]
+    compare_step_with_oracle(model, images, gts, 80, arch='resnet_v1_101', check_grads=False)
 
 
 @pytest.mark.parametrize('winograd', [False, True], ids=['direct', 'winograd'])
@@ -343,3 +379,26 @@ def test_non_default_config_surface_trains(monkeypatch):
     moved = (model.store.flat - w0).abs()
     assert float(moved.max()) > 1e-5 and float(moved.max()) < 1e-2      # Adam: |step| ~ lr per element
     assert model._rcnn._dropout_calls == 4                               # after pooling + after fc_0, two steps
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """`bench.py --gpus 2` end to end on THIS box every round — the self-spawn through
+    torch.distributed.run, rank-sharded synthetic inputs and seeds, the bucketed gradient exchange under the trunk
+    backward (on device tensors, through the production stream protocol), the collectives of the profiling steps and
+    the max-over-ranks timing — with the gloo backend so that both ranks may share the one GPU (RCCL needs a GPU per
+    rank; the driver's 8-GPU run is the first RCCL world > 1)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LUMINOTH_AMD_DIST_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
+    assert d['dist']['world_size'] == 2 and d['dist']['backend'] == 'gloo'
+    assert np.isfinite(d['config']['final_total_loss']) and d['value'] > 0
+    assert d['roofline'] is not None and d['roofline']['whole_step']['executed_flops'] > 0
