@@ -251,6 +251,270 @@ k_wino_dw(const float* __restrict__ dU, int C, int K, float* __restrict__ dw) {
   }
 }
 
+// ================================================================================================================
+// F(4x4, 3x3) (round 3): 36 multiplies per 16 outputs — 4x fewer than the direct form, 1.78x fewer than F(2x2,3x3) —
+// and SMALLER transformed planes (36 per 4x4 pixels = 2.25x the activation instead of 4x).  Interpolation points
+// 0, +-1, +-2, inf (Lavin & Gray, table of F(4x4,3x3)).  fp32 round-off against a float64 direct convolution on
+// post-ReLU activations with a 1024-channel reduction: max 1.8e-5 / rms 1.3e-6 of the output scale (F(2x2): 9e-7 /
+// 2e-7; direct fp32: 3e-7 / 6e-8) — inside north_star's 1e-4; pinned by tests/test_gpu_kernels.py.
+// Same structure as above: weight / input transforms -> 36 stacked GEMMs (one grid) -> output transform with the fused
+// epilogue (scale / shift / residual / activation / activation bit mask).  One thread = one tile x TWO channels
+// (a 6x6 patch of float2 is 72 registers; float4 would spill).
+// ================================================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <class V> __device__ __forceinline__ void w4_bt(const V (&d)[6], V (&t)[6]) {       // B^T d
+  t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  t[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+  t[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+  t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+  t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+  t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+template <class V> __device__ __forceinline__ void w4_at(const V (&m)[6], V (&y)[4]) {       // A^T m
+  y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+  y[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+  y[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+  y[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+}
+template <class V> __device__ __forceinline__ void w4_a(const V (&y)[4], V (&m)[6]) {        // A y  (A = (A^T)^T)
+  m[0] = y[0];
+  m[1] = y[0] + y[1] + y[2] + y[3];
+  m[2] = y[0] - y[1] + y[2] - y[3];
+  m[3] = y[0] + 2.f * y[1] + 4.f * y[2] + 8.f * y[3];
+  m[4] = y[0] - 2.f * y[1] + 4.f * y[2] - 8.f * y[3];
+  m[5] = y[3];
+}
+template <class V> __device__ __forceinline__ void w4_g(const V (&g)[3], V (&u)[6]) {        // G g
+  u[0] = g[0] * 0.25f;
+  u[1] = (g[0] + g[1] + g[2]) * (-1.f / 6.f);
+  u[2] = (g[0] - g[1] + g[2]) * (-1.f / 6.f);
+  u[3] = g[0] * (1.f / 24.f) + g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+  u[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+  u[5] = g[2];
+}
+template <class V> __device__ __forceinline__ void w4_gt(const V (&u)[6], V (&w)[3]) {       // G^T u
+  w[0] = u[0] * 0.25f - (u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 24.f);
+  w[1] = (u[2] - u[1]) * (1.f / 6.f) + (u[3] - u[4]) * (1.f / 12.f);
+  w[2] = -(u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 6.f) + u[5];
+}
+
+// forward weights: U[6a+b][c][k] = (G g G^T)[a][b];  thread = (c, k2)
+__global__ void __launch_bounds__(256)
+k_wino4_weight_fwd(const float* __restrict__ w, int C, int K, float* __restrict__ U) {
+  const int K2 = K >> 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * K2) return;
+  const int c = idx / K2, k2 = idx - c * K2;
+  f32x2 t[6][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    f32x2 g[3], u[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) g[r] = *reinterpret_cast<const f32x2*>(w + ((size_t)(r * 3 + s) * C + c) * K + 2 * k2);
+    w4_g(g, u);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) t[a][s] = u[a];
+  }
+  const size_t plane = (size_t)C * K;
+  float* o = U + (size_t)c * K + 2 * k2;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    f32x2 u[6];
+    w4_g(t[a], u);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x2*>(o + (size_t)(6 * a + b) * plane) = u[b];
+  }
+}
+
+// backward-data weights: U'[6a+b][k][c] from w[2-r][2-s][c][k] * kscale[k];  thread = (k, c2)
+__global__ void __launch_bounds__(256)
+k_wino4_weight_bwd(const float* __restrict__ w, const float* __restrict__ kscale, int C, int K, float* __restrict__ U) {
+  const int C2 = C >> 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= K * C2) return;
+  const int c2 = idx % C2, k = idx / C2;
+  const float ks = kscale ? kscale[k] : 1.f;
+  f32x2 t[6][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    f32x2 g[3], u[6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float* p = w + ((size_t)((2 - r) * 3 + (2 - s)) * C + 2 * c2) * K + k;
+      g[r] = f32x2{p[0], p[K]} * ks;
+    }
+    w4_g(g, u);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) t[a][s] = u[a];
+  }
+  const size_t plane = (size_t)K * C;
+  float* o = U + (size_t)k * C + 2 * c2;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    f32x2 u[6];
+    w4_g(t[a], u);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x2*>(o + (size_t)(6 * a + b) * plane) = u[b];
+  }
+}
+
+// input: V[6a+b][tile][c] = (B^T d B)[a][b], d = the 6x6 patch at (4i-1, 4j-1), zero outside the image
+__global__ void __launch_bounds__(256)
+k_wino4_input(const float* __restrict__ x, int N, int H, int W, int C, float* __restrict__ V) {
+  const int C2 = C >> 1, th = (H + 3) >> 2, tw = (W + 3) >> 2;
+  const int T = N * th * tw;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)T * C2) return;
+  const int c2 = (int)(idx % C2), tile = (int)(idx / C2);
+  const int j = tile % tw, t1 = tile / tw, i = t1 % th, n = t1 / th;
+  f32x2 t[6][6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {            // column b of the patch -> column b of B^T d
+    const int ww = 4 * j - 1 + b;
+    f32x2 d[6], u[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int h = 4 * i - 1 + a;
+      const bool ok = (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W;
+      d[a] = ok ? *reinterpret_cast<const f32x2*>(x + ((size_t)(n * H + h) * W + ww) * C + 2 * c2) : f32x2{0.f, 0.f};
+    }
+    w4_bt(d, u);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) t[a][b] = u[a];
+  }
+  const size_t plane = (size_t)T * C;
+  float* o = V + (size_t)tile * C + 2 * c2;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    f32x2 u[6];
+    w4_bt(t[a], u);                        // (t B)[a][b] = sum_b' t[a][b'] B^T[b][b']
+#pragma unroll
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x2*>(o + (size_t)(6 * a + b) * plane) = u[b];
+  }
+}
+
+// output: y = act( (A^T m A) * scale + shift + extra ), 4x4 pixels per tile (+ activation bit masks, see k_conv_fwd)
+__global__ void __launch_bounds__(256)
+k_wino4_output(const float* __restrict__ Mo, int N, int H, int W, int K, const float* __restrict__ scale,
+               const float* __restrict__ shift, const float* __restrict__ extra, float act_lo, float act_hi,
+               float* __restrict__ y, uint32_t* __restrict__ bits_out, const uint32_t* __restrict__ bits_in) {
+  const int K2 = K >> 1, th = (H + 3) >> 2, tw = (W + 3) >> 2;
+  const int T = N * th * tw;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)T * K2) return;
+  const int k2 = (int)(idx % K2), tile = (int)(idx / K2);
+  const int j = tile % tw, t1 = tile / tw, i = t1 % th, n = t1 / th;
+  const size_t plane = (size_t)T * K;
+  const float* src = Mo + (size_t)tile * K + 2 * k2;
+  f32x2 t[4][6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    f32x2 m[6], u[4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x2*>(src + (size_t)(6 * a + b) * plane);
+    w4_at(m, u);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) t[a][b] = u[a];
+  }
+  f32x2 sc = {1.f, 1.f}, sh = {0.f, 0.f};
+  if (scale) sc = *reinterpret_cast<const f32x2*>(scale + 2 * k2);
+  if (shift) sh = *reinterpret_cast<const f32x2*>(shift + 2 * k2);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    f32x2 o4[4];
+    w4_at(t[a], o4);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (4 * i + a >= H || 4 * j + b >= W) continue;     // uniform over the 16 lanes of a mask word (same tile)
+      const size_t off = ((size_t)(n * H + 4 * i + a) * W + 4 * j + b) * K + 2 * k2;
+      f32x2 v = o4[b] * sc + sh;
+      if (extra) v += *reinterpret_cast<const f32x2*>(extra + off);
+      v.x = fminf(fmaxf(v.x, act_lo), act_hi);
+      v.y = fminf(fmaxf(v.y, act_lo), act_hi);
+      const size_t word = off >> 5;
+      if (bits_in) {
+        const unsigned two = bits_in[word] >> (2 * (k2 & 15));
+        v.x = (two & 1u) ? v.x : 0.f;
+        v.y = (two & 2u) ? v.y : 0.f;
+      }
+      *reinterpret_cast<f32x2*>(y + off) = v;
+      if (bits_out) {
+        unsigned two = ((v.x > 0.f && v.x < act_hi) ? 1u : 0u) | ((v.y > 0.f && v.y < act_hi) ? 2u : 0u);
+        two <<= 2 * (k2 & 15);
+        two |= __shfl_xor(two, 1);
+        two |= __shfl_xor(two, 2);
+        two |= __shfl_xor(two, 4);
+        two |= __shfl_xor(two, 8);
+        if ((k2 & 15) == 0) bits_out[word] = two;
+      }
+    }
+  }
+}
+
+// weight gradient: dM[6a+b][tile][k] = (A dY A^T)[a][b] of the 4x4 gradient tile (zero outside the image)
+__global__ void __launch_bounds__(256)
+k_wino4_dy(const float* __restrict__ g, int N, int H, int W, int K, float* __restrict__ dM) {
+  const int K2 = K >> 1, th = (H + 3) >> 2, tw = (W + 3) >> 2;
+  const int T = N * th * tw;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)T * K2) return;
+  const int k2 = (int)(idx % K2), tile = (int)(idx / K2);
+  const int j = tile % tw, t1 = tile / tw, i = t1 % th, n = t1 / th;
+  f32x2 t[6][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    f32x2 yv[4], u[6];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const bool ok = 4 * i + a < H && 4 * j + b < W;
+      yv[a] = ok ? *reinterpret_cast<const f32x2*>(g + ((size_t)(n * H + 4 * i + a) * W + 4 * j + b) * K + 2 * k2)
+                 : f32x2{0.f, 0.f};
+    }
+    w4_a(yv, u);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) t[a][b] = u[a];
+  }
+  const size_t plane = (size_t)T * K;
+  float* o = dM + (size_t)tile * K + 2 * k2;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    f32x2 u[6];
+    w4_a(t[a], u);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x2*>(o + (size_t)(6 * a + b) * plane) = u[b];
+  }
+}
+
+// dw[r][s][c][k] = (G^T dU G)[r][s];  thread = (c, k2)
+__global__ void __launch_bounds__(256)
+k_wino4_dw(const float* __restrict__ dU, int C, int K, float* __restrict__ dw) {
+  const int K2 = K >> 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * K2) return;
+  const int c = idx / K2, k2 = idx - c * K2;
+  const size_t plane = (size_t)C * K;
+  const float* src = dU + (size_t)c * K + 2 * k2;
+  f32x2 t[3][6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    f32x2 u[6], v[3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) u[a] = *reinterpret_cast<const f32x2*>(src + (size_t)(6 * a + b) * plane);
+    w4_gt(u, v);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) t[r][b] = v[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    f32x2 v[3];
+    w4_gt(t[r], v);
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2)
+      *reinterpret_cast<f32x2*>(dw + ((size_t)(r * 3 + s2) * C + c) * K + 2 * k2) = v[s2];
+  }
+}
+
 // ---- host -----------------------------------------------------------------------------------------------------
 static bool wino_ok(const lmh_conv_desc* d) {
   return (d->compute == 0 || d->compute == 3) && d->R == 3 && d->S == 3 && d->stride == 1 && d->dilation == 1 && d->pad_top == 1 &&
@@ -259,50 +523,70 @@ static bool wino_ok(const lmh_conv_desc* d) {
 
 extern "C" int lmh_conv2d_winograd_ok(const lmh_conv_desc* d) { return d && wino_ok(d) ? 1 : 0; }
 
+int lmh_opt(const char* name);
+// output tile of the Winograd path: 4 = F(4x4,3x3) (default), 2 = F(2x2,3x3) (lmh_set_option("wino_m", 2))
+static int wino_mo() { return lmh_opt("wino_m") == 2 ? 2 : 4; }
+static size_t wino_tiles(const lmh_conv_desc* d, int mo) {
+  return (size_t)d->N * ((d->H + mo - 1) / mo) * ((d->W + mo - 1) / mo);
+}
+
 extern "C" size_t lmh_conv2d_winograd_workspace_bytes(const lmh_conv_desc* d) {
   if (!d || !wino_ok(d)) return 0;
-  const size_t T = (size_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
-  return 16 * sizeof(float) * ((size_t)d->C * d->K + T * d->C + T * d->K);
+  // sized for whichever tile needs more (F(2x2): 16 planes over T2 tiles; F(4x4): 36 planes over T4 ~ T2/4 tiles)
+  size_t best = 0;
+  for (int mo = 2; mo <= 4; mo += 2) {
+    const size_t T = wino_tiles(d, mo), P2 = (size_t)(mo + 2) * (mo + 2);
+    const size_t b = P2 * sizeof(float) * ((size_t)d->C * d->K + T * d->C + T * d->K);
+    if (b > best) best = b;
+  }
+  return best;
 }
 
 // Cg = reduction channels, Kg = output channels of this direction.
-static int wino_run(const lmh_conv_desc* d, const float* in, int Cg, int Kg, const float* U, float* V, float* Mo,
+static int wino_run(const lmh_conv_desc* d, int mo, const float* in, int Cg, int Kg, const float* U, float* V, float* Mo,
                     const float* scale, const float* shift, const float* extra, float act_lo, float act_hi,
                     float* out, uint32_t* bits_out, const uint32_t* bits_in, hipStream_t st) {
-  const int T = d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
-  {
+  const int T = (int)wino_tiles(d, mo), P2 = (mo + 2) * (mo + 2);
+  if (mo == 4) {
+    const int64_t n = (int64_t)T * (Cg / 2);
+    hipLaunchKernelGGL(k_wino4_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, d->N, d->H, d->W, Cg, V);
+  } else {
     const int64_t n = (int64_t)T * (Cg / 4);
     hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, d->N, d->H, d->W, Cg, V);
   }
-  // 16 GEMMs [T x Cg] x [Cg x Kg] as ONE grid of the forward kernel (a 1x1 convolution over T "pixels")
+  // P2 GEMMs [T x Cg] x [Cg x Kg] as ONE grid of the forward kernel (a 1x1 convolution over T "pixels")
   lmh_conv_desc g = *d;
   g.N = 1; g.H = T; g.W = 1; g.OH = T; g.OW = 1; g.C = Cg; g.K = Kg; g.R = 1; g.S = 1;
   g.stride = 1; g.dilation = 1; g.pad_top = 0; g.pad_left = 0; g.act = 0; g.compute = 0;
   int bm, bn;
-  pick_tile((int64_t)T * 16, Kg, &bm, &bn);
-  const int grid = 16 * ((T + bm - 1) / bm) * ((Kg + bn - 1) / bn);
-  const bool x3 = d->compute == 3;        // bf16x3: the 16 GEMMs on the bf16 matrix pipe (conv_half.h), transforms unchanged
+  pick_tile((int64_t)T * P2, Kg, &bm, &bn);
+  const int grid = P2 * ((T + bm - 1) / bm) * ((Kg + bn - 1) / bn);
+  const bool x3 = d->compute == 3;        // bf16x3: the stacked GEMMs on the bf16 matrix pipe (conv_half.h), transforms unchanged
 #define LAUNCH_WG(BM_, BN_)                                                                           \
   do {                                                                                                \
     if (x3 && x3_pf_gb == 3)                                                                          \
       hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 3, true>), dim3(grid), dim3(512), 0, st, g, (const float*)V, U, \
-                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, 16);  \
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, P2);  \
     else if (x3)                                                                                      \
       hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 0, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U, \
-                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, 16);  \
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, P2);  \
     else                                                                                              \
       hipLaunchKernelGGL((k_conv_fwd<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U,  \
-                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, 16);  \
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, P2);  \
   } while (0)
-  g_prof_pending_bytes = 16.0 * 4.0 * ((double)T * Cg + (double)Cg * Kg + (double)T * Kg);
+  g_prof_pending_bytes = (double)P2 * 4.0 * ((double)T * Cg + (double)Cg * Kg + (double)T * Kg);
   prof_begin(st);
   if (bm == 128 && bn == 128) LAUNCH_WG(128, 128);
   else if (bm == 128) LAUNCH_WG(128, 64);
   else LAUNCH_WG(64, 64);
 #undef LAUNCH_WG
-  if (x3) prof_end(st, 16.0 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd_h<3, %d, %d, GB>", bm, bn);
-  else prof_end(st, 16.0 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd<%d, %d, true>", bm, bn);
-  {
+  if (x3) prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd_h<3, %d, %d, GB>", bm, bn);
+  else prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd<%d, %d, true>", bm, bn);
+  if (mo == 4) {
+    const int64_t n = (int64_t)T * (Kg / 2);
+    hipLaunchKernelGGL(k_wino4_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,
+                       d->H, d->W, Kg, scale, shift, extra, act_lo, act_hi, out, bits_out, bits_in);
+  } else {
     const int64_t n = (int64_t)T * (Kg / 4);
     hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,
                        d->H, d->W, Kg, scale, shift, extra, act_lo, act_hi, out, bits_out, bits_in);
@@ -311,36 +595,47 @@ static int wino_run(const lmh_conv_desc* d, const float* in, int Cg, int Kg, con
   return LMH_OK;
 }
 
-static int wino_carve(const lmh_conv_desc* d, void* ws, size_t ws_bytes, int Cg, int Kg, float** U, float** V,
+static int wino_carve(const lmh_conv_desc* d, int mo, void* ws, size_t ws_bytes, int Cg, int Kg, float** U, float** V,
                       float** Mo) {
   if (!ws || ws_bytes < lmh_conv2d_winograd_workspace_bytes(d)) {
     lmh_set_error("winograd: workspace %zu < %zu", ws_bytes, lmh_conv2d_winograd_workspace_bytes(d));
     return LMH_ERR_WORKSPACE;
   }
-  const size_t T = (size_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+  const size_t T = wino_tiles(d, mo), P2 = (size_t)(mo + 2) * (mo + 2);
   *U = reinterpret_cast<float*>(ws);
-  *V = *U + 16 * (size_t)d->C * d->K;
-  *Mo = *V + 16 * T * Cg;
+  *V = *U + P2 * (size_t)d->C * d->K;
+  *Mo = *V + P2 * T * Cg;
   (void)Kg;
   return LMH_OK;
 }
 
-// The transformed weights depend on nothing but the weights (and, backward, the BN scale): the train step computes
-// them for every Winograd layer on the idle weight-gradient stream at the start of the step and passes them in
-// (u != NULL); with u == NULL they are computed here, into the workspace.
-extern "C" int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, const float* w, const float* kscale,
-                                                     int backward, float* u, lmh_stream_t stream) {
-  int rc = check_desc(d);
-  if (rc) return rc;
-  LMH_CHECK_ARG(w && u && wino_ok(d));
-  hipStream_t st = (hipStream_t)stream;
-  if (backward) {
+static void wino_weights(const lmh_conv_desc* d, int mo, const float* w, const float* kscale, int backward, float* u,
+                         hipStream_t st) {
+  if (mo == 4) {
+    if (backward) {
+      const int n = d->K * (d->C / 2);
+      hipLaunchKernelGGL(k_wino4_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, u);
+    } else {
+      const int n = d->C * (d->K / 2);
+      hipLaunchKernelGGL(k_wino4_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, u);
+    }
+  } else if (backward) {
     const int n = d->K * (d->C / 4);
     hipLaunchKernelGGL(k_wino_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, u);
   } else {
     const int n = d->C * (d->K / 4);
     hipLaunchKernelGGL(k_wino_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, u);
   }
+}
+
+// The transformed weights depend on nothing but the weights (and, backward, the BN scale): a caller may compute them
+// ahead of the call (u != NULL, produced under the SAME "wino_m" option); with u == NULL they are computed here.
+extern "C" int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, const float* w, const float* kscale,
+                                                     int backward, float* u, lmh_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  LMH_CHECK_ARG(w && u && wino_ok(d));
+  wino_weights(d, wino_mo(), w, kscale, backward, u, (hipStream_t)stream);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -351,17 +646,17 @@ extern "C" int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, c
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(x && (w || u) && y && wino_ok(d));
+  const int mo = wino_mo();
   float *U, *V, *Mo;
-  rc = wino_carve(d, ws, ws_bytes, d->C, d->K, &U, &V, &Mo);
+  rc = wino_carve(d, mo, ws, ws_bytes, d->C, d->K, &U, &V, &Mo);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (!u) {
-    const int n = d->C * (d->K / 4);
-    hipLaunchKernelGGL(k_wino_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, U);
+    wino_weights(d, mo, w, nullptr, 0, U, st);
     u = U;
   }
   const float lo = d->act ? 0.f : -INFINITY, hi = (d->act == 2) ? 6.f : INFINITY;
-  return wino_run(d, x, d->C, d->K, u, V, Mo, scale, shift, residual, lo, hi, y, act_bits, nullptr, st);
+  return wino_run(d, mo, x, d->C, d->K, u, V, Mo, scale, shift, residual, lo, hi, y, act_bits, nullptr, st);
 }
 
 extern "C" int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w, const float* u,
@@ -370,32 +665,39 @@ extern "C" int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float*
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(dy && (w || u) && dx && wino_ok(d));
+  const int mo = wino_mo();
   float *U, *V, *Mo;
-  rc = wino_carve(d, ws, ws_bytes, d->K, d->C, &U, &V, &Mo);
+  rc = wino_carve(d, mo, ws, ws_bytes, d->K, d->C, &U, &V, &Mo);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (!u) {
-    const int n = d->K * (d->C / 4);
-    hipLaunchKernelGGL(k_wino_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, U);
+    wino_weights(d, mo, w, kscale, 1, U, st);
     u = U;
   }
-  return wino_run(d, dy, d->K, d->C, u, V, Mo, nullptr, nullptr, addend, -INFINITY, INFINITY, dx, nullptr, xbits, st);
+  return wino_run(d, mo, dy, d->K, d->C, u, V, Mo, nullptr, nullptr, addend, -INFINITY, INFINITY, dx, nullptr, xbits, st);
 }
 
 // ---- weight gradient -------------------------------------------------------------------------------------------
-static lmh_conv_desc wino_gemm_desc(const lmh_conv_desc* d, int T) {
-  lmh_conv_desc g = *d;        // 16 stacked [T x C]^T [T x K] products as the taps of a fake 4x4 filter
-  g.N = 1; g.H = T; g.W = 1; g.OH = T; g.OW = 1; g.R = 4; g.S = 4;
+static lmh_conv_desc wino_gemm_desc(const lmh_conv_desc* d, int T, int mo) {
+  lmh_conv_desc g = *d;        // (mo+2)^2 stacked [T x C]^T [T x K] products as the taps of a fake (mo+2)x(mo+2) filter
+  g.N = 1; g.H = T; g.W = 1; g.OH = T; g.OW = 1; g.R = mo + 2; g.S = mo + 2;
   g.stride = 1; g.dilation = 0; g.pad_top = 0; g.pad_left = 0; g.act = 0;
   return g;
 }
 
+static size_t wino_wgrad_bytes(const lmh_conv_desc* d, int mo, size_t* planes_out) {
+  const int T = (int)wino_tiles(d, mo);
+  const size_t P2 = (size_t)(mo + 2) * (mo + 2);
+  const lmh_conv_desc g = wino_gemm_desc(d, T, mo);
+  const size_t planes = lmh_align_up(P2 * sizeof(float) * ((size_t)T * d->C + (size_t)T * d->K + (size_t)d->C * d->K), 256);
+  if (planes_out) *planes_out = planes;
+  return planes + lmh_conv2d_bwd_weight_workspace_bytes(&g);
+}
+
 extern "C" size_t lmh_conv2d_bwd_weight_winograd_workspace_bytes(const lmh_conv_desc* d) {
   if (!d || !wino_ok(d)) return 0;
-  const int T = d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
-  const lmh_conv_desc g = wino_gemm_desc(d, T);
-  const size_t planes = 16 * sizeof(float) * ((size_t)T * d->C + (size_t)T * d->K + (size_t)d->C * d->K);
-  return lmh_align_up(planes, 256) + lmh_conv2d_bwd_weight_workspace_bytes(&g);
+  const size_t a = wino_wgrad_bytes(d, 2, nullptr), b = wino_wgrad_bytes(d, 4, nullptr);
+  return a > b ? a : b;
 }
 
 extern "C" int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -408,23 +710,36 @@ extern "C" int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const floa
     return LMH_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  const int T = d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+  const int mo = wino_mo();
+  const int T = (int)wino_tiles(d, mo);
+  const size_t P2 = (size_t)(mo + 2) * (mo + 2);
+  size_t planes;
+  (void)wino_wgrad_bytes(d, mo, &planes);
   float* V = reinterpret_cast<float*>(ws);
-  float* dM = V + 16 * (size_t)T * d->C;
-  float* dU = dM + 16 * (size_t)T * d->K;
-  const size_t planes = lmh_align_up(16 * sizeof(float) * ((size_t)T * d->C + (size_t)T * d->K + (size_t)d->C * d->K), 256);
+  float* dM = V + P2 * (size_t)T * d->C;
+  float* dU = dM + P2 * (size_t)T * d->K;
   void* ws2 = reinterpret_cast<char*>(ws) + planes;
-  {
+  if (mo == 4) {
+    const int64_t n = (int64_t)T * (d->C / 2);
+    hipLaunchKernelGGL(k_wino4_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
+    const int64_t m = (int64_t)T * (d->K / 2);
+    hipLaunchKernelGGL(k_wino4_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
+  } else {
     const int64_t n = (int64_t)T * (d->C / 4);
     hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
     const int64_t m = (int64_t)T * (d->K / 4);
     hipLaunchKernelGGL(k_wino_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
   }
-  const lmh_conv_desc g = wino_gemm_desc(d, T);
+  const lmh_conv_desc g = wino_gemm_desc(d, T, mo);
   rc = bwd_weight_launch(&g, V, dM, nullptr, dU, nullptr, ws2, ws_bytes - planes, st, true);   // gb: never deferred
   if (rc) return rc;
-  const int n = d->C * (d->K / 4);
-  hipLaunchKernelGGL(k_wino_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);
+  if (mo == 4) {
+    const int n = d->C * (d->K / 2);
+    hipLaunchKernelGGL(k_wino4_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);
+  } else {
+    const int n = d->C * (d->K / 4);
+    hipLaunchKernelGGL(k_wino_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);
+  }
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

@@ -261,7 +261,9 @@ def conv_desc(x_shape, w_shape, stride=1, dilation=1, padding='SAME', act=None, 
 # 652 -> 334 us, block3 256->256 89 -> 65 us, 128->128 break-even (scripts/bench_winograd.py); whole step
 # 9.99 -> 9.31 ms with the threshold at 256*256 (9.45 at 512*512, 9.35 at 128*128).
 WINOGRAD = os.environ.get('LUMINOTH_AMD_WINOGRAD', '1') == '1'
-WINOGRAD_MIN_CK = int(os.environ.get('LUMINOTH_AMD_WINOGRAD_MIN_CK', str(256 * 256)))
+# routing threshold on C*K: F(4x4,3x3) (round 3) pays off from 128 x 128 channels on (ResNet block2's 3x3 at 128^2:
+# 85 us direct -> 59 us; whole step 7.81 -> 7.54 ms on one box); F(2x2,3x3) only broke even there (256 x 256 in round 2)
+WINOGRAD_MIN_CK = int(os.environ.get('LUMINOTH_AMD_WINOGRAD_MIN_CK', str(128 * 128)))
 
 
 def winograd_ok(d):
@@ -283,6 +285,17 @@ def winograd_transform_weights(d, w, kscale, backward, out):
                                                             int(bool(backward)), _p(out), _stream()),
           'lmh_conv2d_winograd_transform_weights')
     return out
+
+
+def set_option(name, value):
+    """Process-global tuning option of the C library (include/luminoth_hip.h: lmh_set_option)."""
+    check(_lib.load().lmh_set_option(name.encode(), int(value)), 'lmh_set_option')
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(_lib.load().lmh_get_option(name.encode(), ctypes.byref(v)), 'lmh_get_option')
+    return v.value
 
 
 def act_bits_ok(channels, act):

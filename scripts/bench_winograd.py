@@ -1,4 +1,4 @@
-"""Direct vs Winograd F(2x2,3x3) on the wide 3x3 layers (HIP-event timed, isolated)."""
+"""Direct vs Winograd F(2x2,3x3) and F(4x4,3x3) on the wide 3x3 layers (HIP-event timed, isolated)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,15 +16,17 @@ for name, N, H, C, Kc in [('rpn 3x3 1024->512 @64', 2, 64, 1024, 512), ('b3 3x3 
     g = torch.randn(N, H, H, Kc, device=dev)
     y, dx = torch.empty_like(g), torch.empty_like(x)
     gf = 2.0 * N * H * H * 9 * C * Kc / 1e9
-    t = [timeit(lambda: K.conv2d_fwd(d, x, w, sc, sh, out=y)) * 1e3,
-         timeit(lambda: K.conv2d_fwd_winograd(d, x, w, sc, sh, out=y)) * 1e3,
-         timeit(lambda: K.conv2d_bwd_data(d, g, w, sc, out=dx)) * 1e3,
-         timeit(lambda: K.conv2d_bwd_data_winograd(d, g, w, sc, out=dx)) * 1e3]
-    dw = torch.empty_like(w)
     K.WINOGRAD = False
-    t.append(timeit(lambda: K.conv2d_bwd_weight(d, x, g, out=dw)) * 1e3)
+    dw = torch.empty_like(w)
+    t = [timeit(lambda: K.conv2d_fwd(d, x, w, sc, sh, out=y)) * 1e3, timeit(lambda: K.conv2d_bwd_data(d, g, w, sc, out=dx)) * 1e3,
+         timeit(lambda: K.conv2d_bwd_weight(d, x, g, out=dw)) * 1e3]
     K.WINOGRAD = True
-    t.append(timeit(lambda: K.conv2d_bwd_weight_winograd(d, x, g, out=dw)) * 1e3)
-    print('%-30s %7.1f GF | fwd direct %7.1f us (%5.1f TF) winograd %7.1f us (%5.1f TF-eq) | bwd_data direct %7.1f us '
-          'winograd %7.1f us | bwd_weight direct %7.1f us winograd %7.1f us' %
-          (name, gf, t[0], gf / t[0] * 1e3, t[1], gf / t[1] * 1e3, t[2], t[3], t[4], t[5]))
+    line = '%-30s %6.1f GF | direct fwd %6.1f bwd_data %6.1f bwd_weight %6.1f us' % (name, gf, t[0], t[1], t[2])
+    for m in (2, 4):
+        K.set_option('wino_m', m)
+        tw = [timeit(lambda: K.conv2d_fwd_winograd(d, x, w, sc, sh, out=y)) * 1e3,
+              timeit(lambda: K.conv2d_bwd_data_winograd(d, g, w, sc, out=dx)) * 1e3,
+              timeit(lambda: K.conv2d_bwd_weight_winograd(d, x, g, out=dw)) * 1e3]
+        line += ' | F%dx%d %6.1f %6.1f %6.1f us (%5.1f TF-eq fwd)' % (m, m, tw[0], tw[1], tw[2], gf / tw[0] * 1e3)
+    K.set_option('wino_m', 4)
+    print(line)

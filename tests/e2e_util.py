@@ -162,8 +162,8 @@ def free_running_agreement(model, images, gts, num_classes, arch='resnet_v1_50',
     """What the teacher-forced comparison above cannot say: how far a REAL step drifts from the reference when the
     oracle runs on its OWN upstream outputs (its probabilities -> its proposals -> its sampled ROIs) instead of being
     handed the kernels'.  Decisions on near-ties (scores equal to the last bits) may then fall differently.  Returns per
-    image the fraction of proposals that coincide (same box, bit for bit, at the same rank / anywhere), the fraction of
-    the sampled ROI set shared, and the relative difference of every loss."""
+    image the fraction of proposals that coincide (same box to 1e-3 px at the same rank / anywhere in the list), the
+    fraction of the sampled ROI set shared, and both values of every loss."""
     pred = model(images, gts, is_training=True)
     losses = model.loss(pred, return_all=True)
     torch.cuda.synchronize()
@@ -179,16 +179,17 @@ def free_running_agreement(model, images, gts, num_classes, arch='resnet_v1_50',
             mine = rp['proposals'][b, :n_p].cpu().numpy()
             theirs = o['proposals']
             n = min(n_p, theirs.shape[0])
-            rep['same_rank'].append(float((mine[:n] == theirs[:n]).all(axis=1).mean()))
-            a = set(map(tuple, mine.tolist()))
-            bset = set(map(tuple, theirs.tolist()))
+            # "the same box": within 1e-3 px (the device's expf and numpy's differ in the last bits of a coordinate);
+            # set membership through a 0.01 px grid
+            rep['same_rank'].append(float((np.abs(mine[:n] - theirs[:n]).max(axis=1) < 1e-3).mean()))
+            q = lambda a_: set(map(tuple, np.round(np.asarray(a_, np.float64) * 100).astype(np.int64).tolist()))   # noqa: E731
+            a, bset = q(mine), q(theirs)
             rep['same_set'].append(len(a & bset) / float(max(1, len(a | bset))))
             n_roi = int(cp['num_proposals'][b])
-            ra = set(map(tuple, cp['proposals'][b, :n_roi].cpu().numpy().tolist()))
-            rb = set(map(tuple, np.asarray(o['rois']).tolist()))
+            ra, rb = q(cp['proposals'][b, :n_roi].cpu().numpy()), q(o['rois'])
             rep['roi_set'].append(len(ra & rb) / float(max(1, len(ra | rb))))
             for k in acc:
                 acc[k] += float(o[k]) / B
     for k in acc:
-        rep['losses'][k] = (float(losses[k]), acc[k])
+        rep['losses'][k] = (float(losses[k].detach()), acc[k])
     return rep

@@ -653,11 +653,22 @@ def test_wgrad_1x1_direct_to_lds_variants(K, case):
         lib.lmh_conv2d_force_wgrad_variant(0)
 
 
+@pytest.fixture(params=[2, 4], ids=['F2x2', 'F4x4'])
+def wino_m(request, K):
+    """Both Winograd output tiles: F(4x4,3x3) is the default of round 3, F(2x2,3x3) stays selectable."""
+    K.set_option('wino_m', request.param)
+    yield request.param
+    K.set_option('wino_m', 4)
+
+
 @pytest.mark.parametrize('case', WINO_CASES)
-def test_conv_winograd_equals_direct(K, case):
-    """Winograd F(2x2,3x3) forward / backward-data against the torch fp32 reference AND the direct HIP kernels
-    (same operands, same epilogues): the transforms only reorder fp32 roundings."""
+def test_conv_winograd_equals_direct(K, case, wino_m):
+    """Winograd F(2x2,3x3) / F(4x4,3x3) forward / backward-data / weight gradient against the torch fp32 reference AND
+    the direct HIP kernels (same operands, same epilogues).  F(2x2): the transforms only reorder fp32 roundings (4e-5 of
+    the output scale).  F(4x4): coefficients up to 8 and 1/24 amplify round-off ~20x (measured against float64 on
+    post-ReLU data with a 1024-channel reduction: max 1.8e-5, rms 1.3e-6 of the output scale) — bound 1e-4, north_star's."""
     N, H, W, C, Kc, act = case
+    wtol = 1.0 if wino_m == 2 else 2.5
     rs = np.random.RandomState(WINO_CASES.index(case) + 900)
     x = rs.randn(N, H, W, C).astype(F)
     w = (rs.randn(3, 3, C, Kc) * np.sqrt(2.0 / (9 * C))).astype(F)
@@ -674,7 +685,7 @@ def test_conv_winograd_equals_direct(K, case):
     conv = ot.conv2d_nhwc(xt, torch.tensor(w), 1, 1, 'SAME')
     yt = conv * torch.tensor(scale) + torch.tensor(shift) + torch.tensor(res)
     yt = torch.relu(yt) if act == 'relu' else (torch.clamp(yt, 0, 6) if act == 'relu6' else yt)
-    tol = 4e-5 * max(1.0, float(yt.abs().max()))
+    tol = wtol * 4e-5 * max(1.0, float(yt.abs().max()))
     np.testing.assert_allclose(y_win.cpu().numpy(), yt.detach().numpy(), rtol=2e-4, atol=tol)
     np.testing.assert_allclose(y_win.cpu().numpy(), y_dir.cpu().numpy(), rtol=2e-4, atol=tol)
     plain = K.conv2d_fwd_winograd(d, T(x), T(w))                       # no scale / shift / residual
@@ -685,14 +696,14 @@ def test_conv_winograd_equals_direct(K, case):
     add = rs.randn(*x.shape).astype(F)
     dx_dir = K.conv2d_bwd_data(d, T(g), T(w), T(scale), addend=T(add))
     dx_win = K.conv2d_bwd_data_winograd(d, T(g), T(w), T(scale), addend=T(add))
-    tolx = 4e-5 * max(1.0, float(xt.grad.abs().max()))
+    tolx = wtol * 4e-5 * max(1.0, float(xt.grad.abs().max()))
     np.testing.assert_allclose(dx_win.cpu().numpy(), xt.grad.numpy() + add, rtol=2e-4, atol=tolx)
     np.testing.assert_allclose(dx_win.cpu().numpy(), dx_dir.cpu().numpy(), rtol=2e-4, atol=tolx)
     dw_dir = K.conv2d_bwd_weight(d, T(x), T(g)) if not K.WINOGRAD else None
     dw_win = K.conv2d_bwd_weight_winograd(d, T(x), T(g))               # raw: w.r.t. the un-scaled conv output
     wt = torch.tensor(w, requires_grad=True)
     ot.conv2d_nhwc(torch.tensor(x), wt, 1, 1, 'SAME').backward(torch.tensor(g))
-    tolw = 1e-4 * max(1.0, float(wt.grad.abs().max()))
+    tolw = wtol * 1e-4 * max(1.0, float(wt.grad.abs().max()))
     np.testing.assert_allclose(dw_win.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=tolw)
     if dw_dir is not None:
         np.testing.assert_allclose(dw_win.cpu().numpy(), dw_dir.cpu().numpy(), rtol=1e-3, atol=tolw)

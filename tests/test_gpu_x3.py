@@ -168,8 +168,11 @@ def test_bf16x3_inside_winograd_matches_native_winograd(K, shape, monkeypatch):
     names = set(K._Profile.stop())
     assert any(n.startswith('k_conv_fwd_h<3') and 'GB' in n for n in names), names
     assert any(n.startswith('k_conv_bwd_weight_h<3') and 'GB' in n for n in names), names
+    # F(2x2,3x3): 3e-6 of the output scale; F(4x4,3x3) (round 3 default): the output transform amplifies the GEMMs' own
+    # fp32 rounding (the two GEMM schemes round differently) by its coefficients, up to 8 x 8: 4e-5
+    amp = 3e-6 if K.get_option('wino_m') == 2 else 4e-5
     for name, a, b in zip(('fwd', 'bwd_data', 'bwd_weight'), x3[:3], native[:3]):
-        tol = 3e-6 * np.abs(b).max()
+        tol = amp * np.abs(b).max()
         assert np.abs(a - b).max() <= tol, (name, float(np.abs(a - b).max()), float(tol))
 
 
