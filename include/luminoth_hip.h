@@ -162,16 +162,23 @@ size_t lmh_conv2d_winograd_workspace_bytes(const lmh_conv_desc* d);
 int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, const float* w, const float* kscale,
                                           int backward, float* u, lmh_stream_t stream);
 /* act_bits / xbits: as for lmh_conv2d_fwd / lmh_conv2d_bwd_data (emitted / applied by the output transform). */
+/* v_keep (may be NULL; lmh_conv2d_winograd_v_bytes(d) bytes): receives the transformed input planes B^T x B, which
+ * lmh_conv2d_bwd_weight_winograd(v_cached) needs again for the same x — the training forward keeps them instead of
+ * transforming x twice. */
+size_t lmh_conv2d_winograd_v_bytes(const lmh_conv_desc* d);
 int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float* w, const float* u,
                             const float* scale, const float* shift, const float* residual, float* y,
-                            uint32_t* act_bits, void* ws, size_t ws_bytes, lmh_stream_t stream);
+                            uint32_t* act_bits, float* v_keep, void* ws, size_t ws_bytes, lmh_stream_t stream);
 int lmh_conv2d_bwd_data_winograd(const lmh_conv_desc* d, const float* dy, const float* w, const float* u,
                                  const float* kscale, const float* addend, const uint32_t* xbits, float* dx,
                                  void* ws, size_t ws_bytes, lmh_stream_t stream);
 /* dw (RAW, like lmh_conv2d_bwd_weight) = G^T [ sum_tiles (B^T x B)^T (A dy A^T) ] G. */
 size_t lmh_conv2d_bwd_weight_winograd_workspace_bytes(const lmh_conv_desc* d);
+/* v_cached (may be NULL): see v_keep above (then x may be NULL).  colsum (may be NULL, K floats): WRITTEN with the
+ * per-channel sums of dy (dbeta / dbias), taken from the (1,1) plane of the transformed gradient. */
 int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const float* x, const float* dy, float* dw,
-                                   void* ws, size_t ws_bytes, lmh_stream_t stream);
+                                   const float* v_cached, float* colsum, void* ws, size_t ws_bytes,
+                                   lmh_stream_t stream);
 /* tf.nn.max_pool NHWC (slim resnet pool1 3x3/2 SAME; vgg 2x2/2 VALID; SSD 3x3/1 SAME). */
 int lmh_maxpool_fwd(const float* x, int N, int H, int W, int C, int ksize, int stride,
                     int pad_top, int pad_left, int OH, int OW, float* y, lmh_stream_t stream);

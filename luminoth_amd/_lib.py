@@ -90,10 +90,11 @@ SIGNATURES = {
     'lmh_conv2d_winograd_ok': (c_i, [P(ConvDesc)]),
     'lmh_conv2d_winograd_workspace_bytes': (c_sz, [P(ConvDesc)]),
     'lmh_conv2d_winograd_transform_weights': (c_i, [P(ConvDesc), c_f, c_f, c_i, c_f, c_f]),
-    'lmh_conv2d_fwd_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_conv2d_winograd_v_bytes': (c_sz, [P(ConvDesc)]),
+    'lmh_conv2d_fwd_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_data_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_weight_winograd_workspace_bytes': (c_sz, [P(ConvDesc)]),
-    'lmh_conv2d_bwd_weight_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_conv2d_bwd_weight_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_weight_workspace_bytes': (c_sz, [P(ConvDesc)]),
     'lmh_conv2d_bwd_weight': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_kernel_id': (c_i, [P(ConvDesc), c_i]),

@@ -16,7 +16,7 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, layer):
         x = x.contiguous()
-        y = layer.forward(x)
+        y = layer.forward(x, keep_v=True)
         ctx.layer, ctx.x, ctx.y = layer, x, y
         ctx.need_dx = x.requires_grad
         return y

@@ -595,6 +595,14 @@ static int wino_run(const lmh_conv_desc* d, int mo, const float* in, int Cg, int
   return LMH_OK;
 }
 
+// bytes of the transformed INPUT planes V of the forward pass under the current "wino_m" (a caller that keeps them —
+// lmh_conv2d_fwd_winograd v_keep — hands them back to lmh_conv2d_bwd_weight_winograd, which needs exactly B^T x B again)
+extern "C" size_t lmh_conv2d_winograd_v_bytes(const lmh_conv_desc* d) {
+  if (!d || !wino_ok(d)) return 0;
+  const int mo = wino_mo();
+  return (size_t)(mo + 2) * (mo + 2) * wino_tiles(d, mo) * d->C * sizeof(float);
+}
+
 static int wino_carve(const lmh_conv_desc* d, int mo, void* ws, size_t ws_bytes, int Cg, int Kg, float** U, float** V,
                       float** Mo) {
   if (!ws || ws_bytes < lmh_conv2d_winograd_workspace_bytes(d)) {
@@ -642,7 +650,8 @@ extern "C" int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, con
 
 extern "C" int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, const float* w, const float* u,
                                        const float* scale, const float* shift, const float* residual, float* y,
-                                       uint32_t* act_bits, void* ws, size_t ws_bytes, lmh_stream_t stream) {
+                                       uint32_t* act_bits, float* v_keep, void* ws, size_t ws_bytes,
+                                       lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(x && (w || u) && y && wino_ok(d));
@@ -650,6 +659,7 @@ extern "C" int lmh_conv2d_fwd_winograd(const lmh_conv_desc* d, const float* x, c
   float *U, *V, *Mo;
   rc = wino_carve(d, mo, ws, ws_bytes, d->C, d->K, &U, &V, &Mo);
   if (rc) return rc;
+  if (v_keep) V = v_keep;          // the caller keeps B^T x B for this layer's weight gradient
   hipStream_t st = (hipStream_t)stream;
   if (!u) {
     wino_weights(d, mo, w, nullptr, 0, U, st);
@@ -700,11 +710,18 @@ extern "C" size_t lmh_conv2d_bwd_weight_winograd_workspace_bytes(const lmh_conv_
   return a > b ? a : b;
 }
 
+int lmh_colsum_rows_impl(const float* rows_, int nb, int K, float* out, hipStream_t st);   // elementwise.hip
+
+// v_cached (may be NULL): the V planes lmh_conv2d_fwd_winograd kept for this x (same "wino_m"): the input transform is
+// skipped.  colsum (may be NULL): K floats, WRITTEN with sum over pixels of dy per output channel (dbeta / dbias) — the
+// (1,1) plane of A dY A^T is every tile's pixel sum (row 1 of A is all ones), so T rows of K are added instead of a pass
+// over dy.
 extern "C" int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const float* x, const float* dy, float* dw,
-                                              void* ws, size_t ws_bytes, lmh_stream_t stream) {
+                                              const float* v_cached, float* colsum, void* ws, size_t ws_bytes,
+                                              lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  LMH_CHECK_ARG(x && dy && dw && wino_ok(d));
+  LMH_CHECK_ARG((x || v_cached) && dy && dw && wino_ok(d));
   if (!ws || ws_bytes < lmh_conv2d_bwd_weight_winograd_workspace_bytes(d)) {
     lmh_set_error("lmh_conv2d_bwd_weight_winograd: workspace too small");
     return LMH_ERR_WORKSPACE;
@@ -719,19 +736,26 @@ extern "C" int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const floa
   float* dM = V + P2 * (size_t)T * d->C;
   float* dU = dM + P2 * (size_t)T * d->K;
   void* ws2 = reinterpret_cast<char*>(ws) + planes;
+  const float* Vin = v_cached ? v_cached : V;
   if (mo == 4) {
     const int64_t n = (int64_t)T * (d->C / 2);
-    hipLaunchKernelGGL(k_wino4_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
+    if (!v_cached)
+      hipLaunchKernelGGL(k_wino4_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
     const int64_t m = (int64_t)T * (d->K / 2);
     hipLaunchKernelGGL(k_wino4_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
   } else {
     const int64_t n = (int64_t)T * (d->C / 4);
-    hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
+    if (!v_cached)
+      hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
     const int64_t m = (int64_t)T * (d->K / 4);
     hipLaunchKernelGGL(k_wino_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
   }
+  if (colsum) {      // plane (1,1) = index (mo+2)*1 + 1: the tiles' pixel sums
+    rc = lmh_colsum_rows_impl(dM + (size_t)(mo + 3) * T * d->K, T, d->K, colsum, st);
+    if (rc) return rc;
+  }
   const lmh_conv_desc g = wino_gemm_desc(d, T, mo);
-  rc = bwd_weight_launch(&g, V, dM, nullptr, dU, nullptr, ws2, ws_bytes - planes, st, true);   // gb: never deferred
+  rc = bwd_weight_launch(&g, Vin, dM, nullptr, dU, nullptr, ws2, ws_bytes - planes, st, true);   // gb: never deferred
   if (rc) return rc;
   if (mo == 4) {
     const int n = d->C * (d->K / 2);

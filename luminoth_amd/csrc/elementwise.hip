@@ -101,6 +101,14 @@ k_colsum_finish(const float* __restrict__ partial, int nb, int K, float* __restr
   }
 }
 
+// per-channel sums of `nb` rows of K floats (deterministic, fixed order) — used by the Winograd weight gradient, whose
+// transformed-gradient plane (1,1) holds every tile's pixel sum (conv_winograd.h)
+int lmh_colsum_rows_impl(const float* rows_, int nb, int K, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, rows_, nb, K, out);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
 static int act_bwd_blocks(int64_t rows, int K, int* rpb_out) {
   int rpb = (int)((rows + 1023) / 1024);   // ~4 slabs per CU
   const int k4 = (K & 3) ? K : (K >> 2);

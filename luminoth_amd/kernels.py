@@ -307,15 +307,26 @@ def new_act_bits(rows, channels, device):
     return torch.empty((rows, channels // 32), dtype=torch.int32, device=device)
 
 
-def conv2d_fwd_winograd(d, x, w, scale=None, shift=None, residual=None, out=None, act_bits=None):
+def _desc_key(d):
+    return tuple(getattr(d, f) for f, _ in d._fields_)
+
+
+def conv2d_fwd_winograd(d, x, w, scale=None, shift=None, residual=None, out=None, act_bits=None, keep_v=False):
+    """keep_v: the transformed input planes B^T x B are written to a tensor of their own and left on `x` (attribute
+    `_lmh_wino_v`): this layer's Winograd weight gradient needs exactly them again (conv2d_bwd_weight_winograd)."""
     lib = _lib.load()
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
     ws = _workspace(lib.lmh_conv2d_winograd_workspace_bytes(ctypes.byref(d)), x.device, 'winograd')
     u = None      # transformed weights are produced inside the call (they change every step)
+    v = None
+    if keep_v:
+        v = torch.empty((lib.lmh_conv2d_winograd_v_bytes(ctypes.byref(d)) // 4,), dtype=torch.float32, device=x.device)
     with _timed(d, 0, wino=True):
         check(lib.lmh_conv2d_fwd_winograd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(u), _p(scale), _p(shift),
-                                          _p(residual), _p(y), _p(act_bits), _p(ws), ctypes.c_size_t(ws.numel()),
+                                          _p(residual), _p(y), _p(act_bits), _p(v), _p(ws), ctypes.c_size_t(ws.numel()),
                                           _stream()), 'lmh_conv2d_fwd_winograd')
+    if v is not None:
+        x._lmh_wino_v = (_desc_key(d), get_option('wino_m'), x._version, v)
     return y
 
 
@@ -337,24 +348,36 @@ WINOGRAD_WGRAD = os.environ.get('LUMINOTH_AMD_WINOGRAD_WGRAD', '1') == '1'
 WINOGRAD_WGRAD_MIN_CK = int(os.environ.get('LUMINOTH_AMD_WINOGRAD_WGRAD_MIN_CK', str(128 * 128)))
 
 
-def conv2d_bwd_weight_winograd(d, x, dy, out=None):
-    """RAW weight gradient (w.r.t. the un-scaled convolution output), like conv2d_bwd_weight."""
+def conv2d_bwd_weight_winograd(d, x, dy, out=None, colsum=None):
+    """RAW weight gradient (w.r.t. the un-scaled convolution output), like conv2d_bwd_weight.  colsum (K,): WRITTEN
+    with the per-channel sums of dy (one tiny reduction over the tiles' pixel sums, no pass over dy).  The transformed
+    input planes are taken from `x._lmh_wino_v` when the forward pass left them there for this very x."""
     lib = _lib.load()
     dw = out if out is not None else torch.empty((3, 3, d.C, d.K), dtype=torch.float32, device=x.device)
     ws = _workspace(lib.lmh_conv2d_bwd_weight_winograd_workspace_bytes(ctypes.byref(d)), x.device, 'winograd_w')
+    v = None
+    kept = getattr(x, '_lmh_wino_v', None)
+    if kept is not None:
+        dk = _desc_key(d)
+        # same geometry (the activation / compute fields do not enter the transform), same tile size, x unmodified
+        same = all(a == b for a, b, (f, _) in zip(kept[0], dk, d._fields_) if f not in ('act', 'compute'))
+        if same and kept[1] == get_option('wino_m') and kept[2] == x._version:
+            v = kept[3]
+            keep_alive(v, torch.cuda.current_stream(x.device))
     with _timed(d, 2, wino=True):
-        check(lib.lmh_conv2d_bwd_weight_winograd(ctypes.byref(d), _p(_f32(x)), _p(_f32(dy)), _p(dw), _p(ws),
-                                                 ctypes.c_size_t(ws.numel()), _stream()),
+        check(lib.lmh_conv2d_bwd_weight_winograd(ctypes.byref(d), _p(_f32(x)), _p(_f32(dy)), _p(dw), _p(v), _p(colsum),
+                                                 _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
               'lmh_conv2d_bwd_weight_winograd')
     return dw
 
 
-def conv2d_fwd(d, x, w, scale=None, shift=None, residual=None, in_sub=None, out=None, act_bits=None):
+def conv2d_fwd(d, x, w, scale=None, shift=None, residual=None, in_sub=None, out=None, act_bits=None, keep_v=False):
     """act_bits (int32 (rows, K/32), optional): WRITTEN with the activation bit mask of y (bit = act'(y) != 0) — what the
     backward pass needs of the activation; the consumer's backward-data epilogue applies it (conv2d_bwd_data xbits)."""
     lib = _lib.load()
     if in_sub is None and _use_winograd(d):
-        return conv2d_fwd_winograd(d, x, w, scale, shift, residual, out, act_bits)
+        return conv2d_fwd_winograd(d, x, w, scale, shift, residual, out, act_bits,
+                                   keep_v=keep_v and WINOGRAD_WGRAD and d.C * d.K >= WINOGRAD_WGRAD_MIN_CK)
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
     with _timed(d, 0):
         check(lib.lmh_conv2d_fwd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(scale), _p(shift), _p(residual),
@@ -418,9 +441,7 @@ def conv2d_bwd_weight(d, x, dy, out=None, yact=None, colsum=None, defer=None):
     defer = defer if (defer is not None and TAILS.active and d.K % 4 == 0 and d.K <= 4096) else None
     if yact is None and WINOGRAD and WINOGRAD_WGRAD and (d.compute == 0 or (d.compute == 3 and X3_WINOGRAD_MODE == '3')) and d.R == 3 and \
             d.C * d.K >= WINOGRAD_WGRAD_MIN_CK and winograd_ok(d):
-        if colsum is not None:                       # dbeta / dbias: one streaming pass over g
-            act_bwd(dy, None, None, want_g=False, colsum=colsum, defer=defer)
-        dw = conv2d_bwd_weight_winograd(d, x, dy, out)
+        dw = conv2d_bwd_weight_winograd(d, x, dy, out, colsum=colsum)      # dbeta / dbias from the tiles' pixel sums
         if defer is not None:
             TAILS.entry(defer).update(dw=dw, slabs=0, splits=0)
         return dw

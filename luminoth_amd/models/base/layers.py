@@ -122,14 +122,16 @@ class ConvLayer(object):
             self._desc[key] = d
         return d
 
-    def forward(self, x, residual=None, in_sub=None, want_bits=False):
+    def forward(self, x, residual=None, in_sub=None, want_bits=False, keep_v=False):
         """want_bits: also return the activation bit mask of y (None when the layer has no activation or a channel
         count that is not a multiple of 32) -> (y, bits)."""
         d = self.desc(x.shape)
         bits = None
         if want_bits and FUSE_MASK and K.act_bits_ok(self.cout, self.act):
             bits = K.new_act_bits(d.N * d.OH * d.OW, self.cout, x.device)
-        y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub, act_bits=bits)
+        # a training forward of a trainable Winograd layer keeps B^T x B for its weight gradient (kernels.py)
+        y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub, act_bits=bits,
+                         keep_v=(want_bits or keep_v) and self.trainable)
         if ACT_TAP is not None:
             ACT_TAP[self.scope] = y
         return (y, bits) if want_bits else y

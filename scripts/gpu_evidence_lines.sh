@@ -1,16 +1,16 @@
-# Round 2 evidence, part 1: bench lines of every workload / dtype (copied into profiles/ afterwards)
+# Round 3 evidence, part 1: bench lines of every workload / dtype (copied into profiles/ afterwards)
 R=$GRAFT_REPO_ROOT
 cd $R; mkdir -p gpurun_out/ev
-timeout 500 python bench.py > gpurun_out/ev/r02_bench_line.json 2> gpurun_out/ev/r02_bench_line.err; tail -c 600 gpurun_out/ev/r02_bench_line.json; echo
-timeout 200 python bench.py --serial --no-cpu-baseline > gpurun_out/ev/r02_bench_serial_line.json 2>/dev/null
-timeout 200 python bench.py --no-lookahead --no-cpu-baseline --no-roofline > gpurun_out/ev/r02_bench_nolookahead_line.json 2>/dev/null
-timeout 200 python bench.py --dtype bf16x3 --no-cpu-baseline > gpurun_out/ev/r02_bench_frcnn_r50_bf16x3.json 2>/dev/null
+timeout 500 python bench.py > gpurun_out/ev/r03_bench_line.json 2> gpurun_out/ev/r03_bench_line.err; tail -c 600 gpurun_out/ev/r03_bench_line.json; echo
+timeout 200 python bench.py --serial --no-cpu-baseline > gpurun_out/ev/r03_bench_serial_line.json 2>/dev/null
+timeout 200 python bench.py --no-lookahead --no-cpu-baseline --no-roofline > gpurun_out/ev/r03_bench_nolookahead_line.json 2>/dev/null
+timeout 300 python bench.py --alt --no-cpu-baseline --no-roofline > gpurun_out/ev/r03_bench_with_alt.json 2>/dev/null
 for dt in f32 f16 bf16 bf16x3; do
-  timeout 200 python bench.py --workload frcnn_r50_coco --dtype $dt --no-cpu-baseline > gpurun_out/ev/r02_bench_frcnn_r50_coco_$dt.json 2>/dev/null
+  timeout 200 python bench.py --workload frcnn_r50_coco --dtype $dt --no-cpu-baseline > gpurun_out/ev/r03_bench_frcnn_r50_coco_$dt.json 2>/dev/null
 done
-timeout 300 python bench.py --workload frcnn_vgg16 --cpu-steps 3 > gpurun_out/ev/r02_bench_frcnn_vgg16_f32.json 2>/dev/null
-timeout 300 python bench.py --workload ssd300_b32 --no-cpu-baseline > gpurun_out/ev/r02_bench_ssd300_b32_f32.json 2>/dev/null
-timeout 300 python bench.py --workload frcnn_r101 --no-cpu-baseline > gpurun_out/ev/r02_bench_frcnn_r101_f32.json 2>/dev/null
+timeout 300 python bench.py --workload frcnn_vgg16 --cpu-steps 3 > gpurun_out/ev/r03_bench_frcnn_vgg16_f32.json 2>/dev/null
+timeout 300 python bench.py --workload ssd300_b32 --no-cpu-baseline > gpurun_out/ev/r03_bench_ssd300_b32_f32.json 2>/dev/null
+timeout 300 python bench.py --workload frcnn_r101 --no-cpu-baseline > gpurun_out/ev/r03_bench_frcnn_r101_f32.json 2>/dev/null
 python - <<PY
 import glob, json
 for f in sorted(glob.glob('gpurun_out/ev/*.json')):

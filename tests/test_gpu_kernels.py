@@ -707,6 +707,15 @@ def test_conv_winograd_equals_direct(K, case, wino_m):
     np.testing.assert_allclose(dw_win.cpu().numpy(), wt.grad.numpy(), rtol=1e-3, atol=tolw)
     if dw_dir is not None:
         np.testing.assert_allclose(dw_win.cpu().numpy(), dw_dir.cpu().numpy(), rtol=1e-3, atol=tolw)
+    # round 3: the forward pass may keep B^T x B for the weight gradient (bit-identical result, one transform less), and
+    # the per-channel sums of g come from the (1,1) plane of the transformed gradient (every tile's pixel sum)
+    xk = T(x)
+    K.conv2d_fwd_winograd(d, xk, T(w), T(scale), T(shift), T(res), keep_v=True)
+    assert getattr(xk, '_lmh_wino_v', None) is not None
+    cs = torch.full((Kc,), 7.0, device=dev())
+    dw_kept = K.conv2d_bwd_weight_winograd(d, xk, T(g), colsum=cs)
+    assert torch.equal(dw_kept, dw_win)
+    np.testing.assert_allclose(cs.cpu().numpy(), g.reshape(-1, Kc).sum(0), rtol=1e-4, atol=1e-4 * np.abs(g).sum(axis=(0, 1, 2)).max())
     # activation bit masks through the output transform (round 3): emitted for y, applied to dx
     if act and Kc % 32 == 0:
         bits = K.new_act_bits(N * H * W, Kc, dev())
