@@ -178,8 +178,11 @@ def free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    # defaults: 60 timed steps after 15 warm-up steps (< 1 s of GPU time).  A fresh box needs a moment to reach its steady
+    # state (host cores ramping up matter: the host enqueues ~280 launches in ~5.5 ms of a 7.2 ms step) — measured on one
+    # box, three consecutive processes at 5 + 20 steps: 7.72, 7.53, 7.20 ms/step.
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=15)
     ap.add_argument('--workload', default='frcnn_r50', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the workload\'s)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16', 'bf16x3'],

@@ -17,6 +17,7 @@ synchronises with the host.  For un-batched inference calls the results are
 truncated to the reference's exact shapes.
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -422,7 +423,7 @@ class FasterRCNN(object):
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
-        cur.append((name, ev))
+        cur.append((name, ev, time.perf_counter()))
 
     def _phase_begin(self):
         left = getattr(self, '_phase_left', 0)
@@ -440,8 +441,11 @@ class FasterRCNN(object):
         out, n = {}, 0
         for i, marks in enumerate(log):
             t0 = marks[0][1]
-            for name, ev in marks[1:]:
+            for name, ev, host_t in marks[1:]:
                 out[name] = out.get(name, 0.0) + t0.elapsed_time(ev)
+                # when the HOST enqueued the mark, relative to the step's first enqueue: a mark whose host time is
+                # later than its GPU time was waited for by the GPU (the step is host-bound there)
+                out['host:' + name] = out.get('host:' + name, 0.0) + (host_t - marks[0][2]) * 1e3
             if i + 1 < len(log):
                 out['next_step_start'] = out.get('next_step_start', 0.0) + t0.elapsed_time(log[i + 1][0][1])
                 n += 1
