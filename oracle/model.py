@@ -44,8 +44,11 @@ def _act(x, name):
 class OracleFasterRCNN(object):
     def __init__(self, variables, arch='resnet_v1_50', num_classes=80, scope='fasterrcnn',
                  base_scope='truncated_base_network', anchors=None, rpn=None, rcnn=None, weight_decay=5e-4,
-                 l2_rpn=5e-4, l2_rcnn=5e-4, fine_tune_from='block2', seed=None, dtype=torch.float32):
+                 l2_rpn=5e-4, l2_rcnn=5e-4, fine_tune_from='block2', seed=None, dtype=torch.float32, compute=None):
         self.dtype = dtype
+        # 'f16' / 'bf16': the operands of every backbone / tail convolution with C % 32 == 0 and of the RPN 3x3
+        # convolution are rounded like the mixed-precision kernels round them (oracle/torch_ops.py QuantConvFn)
+        self.compute = compute if compute in ('f16', 'bf16') else None
         self.v = {k: torch.as_tensor(v).clone().to(dtype) for k, v in variables.items()}
         self.masks = None
         self.arch, self.C, self.scope, self.base = arch, num_classes, scope, '%s/%s' % (base_scope, arch)
@@ -74,7 +77,8 @@ class OracleFasterRCNN(object):
     # ---- backbone: slim resnet_v1 up to block3, output_stride 16 ----------------
     def _conv_bn(self, x, scope, stride=1, rate=1, padding='SAME', act='relu'):
         v = self.v
-        y = ot.conv2d_nhwc(x, v[scope + '/weights'], stride, rate, padding)
+        q = self.compute if x.shape[-1] % 32 == 0 else None          # conv1 (3 channels) runs the fp32 stem kernel
+        y = ot.conv2d_nhwc(x, v[scope + '/weights'], stride, rate, padding, quant=q)
         y = ot.frozen_batch_norm(y, v[scope + '/BatchNorm/gamma'], v[scope + '/BatchNorm/beta'],
                                  v[scope + '/BatchNorm/moving_mean'], v[scope + '/BatchNorm/moving_variance'])
         return self._activate(y, act, scope)
@@ -98,7 +102,8 @@ class OracleFasterRCNN(object):
         for bi, (name, reps, depth) in enumerate(VGG16_CFG):
             for r in range(reps):
                 sc = '%s/%s/%s_%d' % (self.base, name, name, r + 1)
-                x = ot.conv2d_nhwc(x, self.v[sc + '/weights'], 1, 1, 'SAME', bias=self.v[sc + '/biases'])
+                x = ot.conv2d_nhwc(x, self.v[sc + '/weights'], 1, 1, 'SAME', bias=self.v[sc + '/biases'],
+                                   quant=self.compute if x.shape[-1] % 32 == 0 else None)
                 x = self._activate(x, 'relu', sc)
             if bi < 4:
                 x = ot.max_pool_nhwc(x, 2, 2, 'VALID')
@@ -138,7 +143,8 @@ class OracleFasterRCNN(object):
     # ---- heads --------------------------------------------------------------------
     def rpn_head(self, feat):
         v, p = self.v, self.scope + '/rpn'
-        f = self._activate(ot.conv2d_nhwc(feat, v[p + '/conv/w'], padding='SAME', bias=v[p + '/conv/b']), 'relu6',
+        f = self._activate(ot.conv2d_nhwc(feat, v[p + '/conv/w'], padding='SAME', bias=v[p + '/conv/b'],
+                                          quant=self.compute), 'relu6',
                            p + '/conv')
         cls = ot.conv2d_nhwc(f, v[p + '/cls_conv/w'], padding='VALID', bias=v[p + '/cls_conv/b'])
         box = ot.conv2d_nhwc(f, v[p + '/bbox_conv/w'], padding='VALID', bias=v[p + '/bbox_conv/b'])

@@ -15,8 +15,41 @@ def tf_same_pad(in_size, k, stride, dilation=1):
     return total // 2, total - total // 2
 
 
-def conv2d_nhwc(x, w_hwio, stride=1, dilation=1, padding='SAME', bias=None):
-    """tf.nn.conv2d / slim conv2d / conv2d_same on NHWC input with HWIO weights."""
+def _q(t, quant):
+    """Round to the half-precision operand format and back (RNE, like v_cvt_pk_* / the compiler's fp32 -> f16 / bf16)."""
+    return t.to(torch.float16 if quant == 'f16' else torch.bfloat16).to(t.dtype)
+
+
+class QuantConvFn(torch.autograd.Function):
+    """Convolution whose MFMA OPERANDS are rounded to f16 / bf16 while tensors, accumulation and everything around it
+    stay fp32 — the arithmetic of luminoth_amd/csrc/conv_half.h (BASELINE configs[4]), restated so that the
+    half-precision path is compared against an oracle that rounds the SAME operands:
+        forward   y  = conv(q(x), q(w))
+        backward  dx = conv^T(q(dy * s), q(w)) / s        dw = corr(q(x), q(dy * s)) / s
+    with the static loss scale s = 2^10 for f16 (the kernels multiply the gradient operand by it before rounding and the
+    accumulators by 1/s afterwards; exact in fp32) and 1 for bf16."""
+
+    @staticmethod
+    def forward(ctx, xt, wt, stride, dilation, quant):
+        xq, wq = _q(xt, quant), _q(wt, quant)
+        ctx.save_for_backward(xq, wq)
+        ctx.meta = (stride, dilation, quant)
+        return F.conv2d(xq, wq, stride=stride, dilation=dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xq, wq = ctx.saved_tensors
+        stride, dilation, quant = ctx.meta
+        s = 1024.0 if quant == 'f16' else 1.0
+        gq = _q(dy * s, quant)
+        dx, dw, _ = torch.ops.aten.convolution_backward(gq, xq, wq, None, [stride, stride], [0, 0], [dilation, dilation],
+                                                        False, [0, 0], 1, [True, True, False])
+        return dx / s, dw / s, None, None, None
+
+
+def conv2d_nhwc(x, w_hwio, stride=1, dilation=1, padding='SAME', bias=None, quant=None):
+    """tf.nn.conv2d / slim conv2d / conv2d_same on NHWC input with HWIO weights.  quant: 'f16' / 'bf16' rounds the two
+    operands like the mixed-precision kernels do (QuantConvFn); None = plain fp32."""
     R, S = w_hwio.shape[0], w_hwio.shape[1]
     xt = x.permute(0, 3, 1, 2)
     if padding == 'SAME':
@@ -30,7 +63,12 @@ def conv2d_nhwc(x, w_hwio, stride=1, dilation=1, padding='SAME', bias=None):
         pt = pb = pl = pr = 0
     if pt or pb or pl or pr:
         xt = F.pad(xt, (pl, pr, pt, pb))
-    y = F.conv2d(xt, w_hwio.permute(3, 2, 0, 1), bias=bias, stride=stride, dilation=dilation)
+    if quant:
+        y = QuantConvFn.apply(xt, w_hwio.permute(3, 2, 0, 1), stride, dilation, quant)
+        if bias is not None:
+            y = y + bias.reshape(1, -1, 1, 1)
+    else:
+        y = F.conv2d(xt, w_hwio.permute(3, 2, 0, 1), bias=bias, stride=stride, dilation=dilation)
     return y.permute(0, 2, 3, 1)
 
 

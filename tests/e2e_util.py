@@ -55,6 +55,11 @@ def condition_like_pretrained(model, arch):
     return model
 
 
+def _stat(stats, name, got, ref):
+    if stats is not None:
+        stats[name] = max(stats.get(name, 0.0), float(np.abs(got - ref).max() / max(1.0, np.abs(got).max())))
+
+
 def run_step_with_tap(model, images, gts):
     """model(...) -> loss -> backward with every conv layer's output recorded (CPU copies)."""
     from luminoth_amd.models.base import layers as L
@@ -72,7 +77,10 @@ def run_step_with_tap(model, images, gts):
 
 
 def compare_step_with_oracle(model, images, gts, num_classes, arch='resnet_v1_50', oracle_kwargs=None,
-                             check_grads=True, min_checked=100):
+                             check_grads=True, min_checked=100, out_tol=1e-4, loss_tol=1e-4, grad_tight=2e-4,
+                             grad_max=1e-3, stats=None):
+    """out_tol / loss_tol / grad_tight / grad_max: the fp32 bounds by default; the mixed-precision tests pass theirs
+    (stated in tests/test_gpu_half.py).  stats (dict, optional): filled with the errors actually observed."""
     B, H, W = images.shape[0], images.shape[1], images.shape[2]
     pred, losses, tap = run_step_with_tap(model, images, gts)
     oracle = OracleFasterRCNN(model.state_dict(), arch=arch, num_classes=num_classes, seed=0,
@@ -95,11 +103,13 @@ def compare_step_with_oracle(model, images, gts, num_classes, arch='resnet_v1_50
         oracle.masks = {k: (v[b:b + 1] if v.shape[0] == B else v[b * R:b * R + n_roi]) for k, v in tap.items()}
         o = oracle.forward_image(images[b], gts[b], seed, overrides=ov)
         sc = rp['rpn_cls_score'][b].detach().cpu().numpy()
-        np.testing.assert_allclose(sc, o['rpn_cls_score'].detach().numpy(), rtol=1e-3,
-                                   atol=1e-4 * max(1.0, np.abs(sc).max()))
+        _stat(stats, 'rpn_cls_score', sc, o['rpn_cls_score'].detach().numpy())
+        np.testing.assert_allclose(sc, o['rpn_cls_score'].detach().numpy(), rtol=10 * out_tol,
+                                   atol=out_tol * max(1.0, np.abs(sc).max()))
         bp = rp['rpn_bbox_pred'][b].detach().cpu().numpy()
-        np.testing.assert_allclose(bp, o['rpn_bbox_pred'].detach().numpy(), rtol=1e-3,
-                                   atol=1e-4 * max(1.0, np.abs(bp).max()))
+        _stat(stats, 'rpn_bbox_pred', bp, o['rpn_bbox_pred'].detach().numpy())
+        np.testing.assert_allclose(bp, o['rpn_bbox_pred'].detach().numpy(), rtol=10 * out_tol,
+                                   atol=out_tol * max(1.0, np.abs(bp).max()))
         # anchor labels: bit-exact (functions of anchors + gt only)
         np.testing.assert_array_equal(rp['rpn_cls_target'][b].cpu().numpy(), o['rpn_labels'])
         np.testing.assert_allclose(rp['rpn_bbox_target'][b].cpu().numpy(), o['rpn_targets'], rtol=1e-5, atol=1e-6)
@@ -120,21 +130,25 @@ def compare_step_with_oracle(model, images, gts, num_classes, arch='resnet_v1_50
         np.testing.assert_allclose(ov['roi_targets'], tg[keep], rtol=1e-5, atol=1e-6)
         # RCNN head (ROI pooling, block4 tail for ResNet-101, FCs) on identical rois
         cs = cp['rcnn']['cls_score'][b, :n_roi].detach().cpu().numpy()
-        np.testing.assert_allclose(cs, o['rcnn_cls_score'].detach().numpy(), rtol=1e-3,
-                                   atol=1e-4 * max(1.0, np.abs(cs).max()))
+        _stat(stats, 'rcnn_cls_score', cs, o['rcnn_cls_score'].detach().numpy())
+        np.testing.assert_allclose(cs, o['rcnn_cls_score'].detach().numpy(), rtol=10 * out_tol,
+                                   atol=out_tol * max(1.0, np.abs(cs).max()))
         bo = cp['rcnn']['bbox_offsets'][b, :n_roi].detach().cpu().numpy()
-        np.testing.assert_allclose(bo, o['rcnn_bbox_offsets'].detach().numpy(), rtol=1e-3,
-                                   atol=1e-4 * max(1.0, np.abs(bo).max()))
+        _stat(stats, 'rcnn_bbox_offsets', bo, o['rcnn_bbox_offsets'].detach().numpy())
+        np.testing.assert_allclose(bo, o['rcnn_bbox_offsets'].detach().numpy(), rtol=10 * out_tol,
+                                   atol=out_tol * max(1.0, np.abs(bo).max()))
         for k in per:
             per[k] = per[k] + o[k] / B
     # losses within 1e-4 (north_star)
     for k in per:
         got, ref = float(losses[k].detach()), float(per[k])
-        assert abs(got - ref) <= 1e-4 * max(1.0, abs(ref)), (k, got, ref)
+        if stats is not None:
+            stats['loss:' + k] = abs(got - ref) / max(1.0, abs(ref))
+        assert abs(got - ref) <= loss_tol * max(1.0, abs(ref)), (k, got, ref)
     reg = float(oracle.regularization_loss())
     assert abs(float(losses['regularization_loss']) - reg) <= 1e-4 * reg
     total = sum(per.values())
-    assert abs(float(losses['no_reg_loss']) - float(total)) <= 1e-4 * max(1.0, float(total))
+    assert abs(float(losses['no_reg_loss']) - float(total)) <= loss_tol * max(1.0, float(total))
     if not check_grads:
         return losses, per
     # gradients (data loss only; the L2 term is folded into the optimizer kernel), ReLU branches pinned
@@ -148,9 +162,12 @@ def compare_step_with_oracle(model, images, gts, num_classes, arch='resnet_v1_50
         g = grads[n].cpu().numpy().reshape(g_ref.shape)
         scale = max(1e-6, float(g_ref.abs().max()))
         err = np.abs(g - g_ref.numpy())
-        tight = err <= 2e-4 * scale + 2e-3 * np.abs(g_ref.numpy())
+        tight = err <= grad_tight * scale + 10 * grad_tight * np.abs(g_ref.numpy())
+        if stats is not None:
+            stats['grad_tight_min'] = min(stats.get('grad_tight_min', 1.0), float(tight.mean()))
+            stats['grad_max'] = max(stats.get('grad_max', 0.0), float(err.max() / scale))
         assert tight.mean() >= 0.995, (n, float(tight.mean()))
-        assert err.max() <= 1e-3 * scale, (n, float(err.max()), scale)
+        assert err.max() <= grad_max * scale, (n, float(err.max()), scale)
         if err.max() / scale > worst[0]:
             worst = (float(err.max() / scale), n)
         checked += 1
