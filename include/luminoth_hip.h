@@ -162,6 +162,17 @@ size_t lmh_conv2d_winograd_workspace_bytes(const lmh_conv_desc* d);
 int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, const float* w, const float* kscale,
                                           int backward, float* u, lmh_stream_t stream);
 /* act_bits / xbits: as for lmh_conv2d_fwd / lmh_conv2d_bwd_data (emitted / applied by the output transform). */
+/* Transformed weights ahead of the convolution calls: every job of a step in ONE launch (`u` of job i:
+ * lmh_winograd_u_bytes(C, K) bytes; forward: G g G^T of w (R,S,C,K); backward: of w[2-r][2-s][c][k] * kscale[k], kscale may
+ * be NULL).  Pass the result as `u` to lmh_conv2d_fwd_winograd / lmh_conv2d_bwd_data_winograd (same "wino_m"). */
+typedef struct lmh_wino_weight_job {
+  const float* w;
+  const float* kscale;
+  float* u;
+  int32_t C, K;
+} lmh_wino_weight_job;
+size_t lmh_winograd_u_bytes(int C, int K);
+int lmh_winograd_transform_weights_batch(const lmh_wino_weight_job* jobs, int n, int backward, lmh_stream_t stream);
 /* v_keep (may be NULL; lmh_conv2d_winograd_v_bytes(d) bytes): receives the transformed input planes B^T x B, which
  * lmh_conv2d_bwd_weight_winograd(v_cached) needs again for the same x — the training forward keeps them instead of
  * transforming x twice. */

@@ -68,6 +68,11 @@ class SsdTargetDesc(ctypes.Structure):
                 ('variance_wh', ctypes.c_float)]
 
 
+class WinoWeightJob(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_void_p), ('kscale', ctypes.c_void_p), ('u', ctypes.c_void_p),
+                ('C', ctypes.c_int32), ('K', ctypes.c_int32)]
+
+
 class WgradTail(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ('slabs', 'dw', 'w', 'scale', 'mean', 'rstd', 'dgamma', 'colpart',
                                                  'colsum')] + \
@@ -91,6 +96,8 @@ SIGNATURES = {
     'lmh_conv2d_winograd_workspace_bytes': (c_sz, [P(ConvDesc)]),
     'lmh_conv2d_winograd_transform_weights': (c_i, [P(ConvDesc), c_f, c_f, c_i, c_f, c_f]),
     'lmh_conv2d_winograd_v_bytes': (c_sz, [P(ConvDesc)]),
+    'lmh_winograd_u_bytes': (c_sz, [c_i, c_i]),
+    'lmh_winograd_transform_weights_batch': (c_i, [P(WinoWeightJob), c_i, c_i, c_f]),
     'lmh_conv2d_fwd_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_data_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_weight_winograd_workspace_bytes': (c_sz, [P(ConvDesc)]),

@@ -300,10 +300,9 @@ template <class V> __device__ __forceinline__ void w4_gt(const V (&u)[6], V (&w)
 }
 
 // forward weights: U[6a+b][c][k] = (G g G^T)[a][b];  thread = (c, k2)
-__global__ void __launch_bounds__(256)
-k_wino4_weight_fwd(const float* __restrict__ w, int C, int K, float* __restrict__ U) {
+__device__ __forceinline__ void wino4_weight_fwd_body(const float* __restrict__ w, int C, int K, float* __restrict__ U,
+                                                      int idx) {
   const int K2 = K >> 1;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= C * K2) return;
   const int c = idx / K2, k2 = idx - c * K2;
   f32x2 t[6][3];
@@ -327,11 +326,15 @@ k_wino4_weight_fwd(const float* __restrict__ w, int C, int K, float* __restrict_
   }
 }
 
-// backward-data weights: U'[6a+b][k][c] from w[2-r][2-s][c][k] * kscale[k];  thread = (k, c2)
 __global__ void __launch_bounds__(256)
-k_wino4_weight_bwd(const float* __restrict__ w, const float* __restrict__ kscale, int C, int K, float* __restrict__ U) {
+k_wino4_weight_fwd(const float* __restrict__ w, int C, int K, float* __restrict__ U) {
+  wino4_weight_fwd_body(w, C, K, U, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// backward-data weights: U'[6a+b][k][c] from w[2-r][2-s][c][k] * kscale[k];  thread = (k, c2)
+__device__ __forceinline__ void wino4_weight_bwd_body(const float* __restrict__ w, const float* __restrict__ kscale, int C,
+                                                      int K, float* __restrict__ U, int idx) {
   const int C2 = C >> 1;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= K * C2) return;
   const int c2 = idx % C2, k = idx / C2;
   const float ks = kscale ? kscale[k] : 1.f;
@@ -357,6 +360,32 @@ k_wino4_weight_bwd(const float* __restrict__ w, const float* __restrict__ kscale
 #pragma unroll
     for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x2*>(o + (size_t)(6 * a + b) * plane) = u[b];
   }
+}
+
+__global__ void __launch_bounds__(256)
+k_wino4_weight_bwd(const float* __restrict__ w, const float* __restrict__ kscale, int C, int K, float* __restrict__ U) {
+  wino4_weight_bwd_body(w, kscale, C, K, U, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Every F(4x4,3x3) layer's weight transform of a step in ONE launch (the transforms depend on nothing but the weights and,
+// backward, the BatchNorm scale): the train step issues the forward set before the trunk and the backward set on the idle
+// weight-gradient stream during the forward pass, instead of 2 x 10 small launches inside the convolution calls.
+#define WINO_BATCH_MAX 32
+struct wino_weight_batch {
+  const float* w[WINO_BATCH_MAX];
+  const float* kscale[WINO_BATCH_MAX];
+  float* u[WINO_BATCH_MAX];
+  int32_t C[WINO_BATCH_MAX], K[WINO_BATCH_MAX];
+  int32_t first_block[WINO_BATCH_MAX + 1];
+  int32_t n, backward;
+};
+__global__ void __launch_bounds__(256)
+k_wino4_weight_batch(wino_weight_batch b) {
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.first_block[j + 1]) ++j;
+  const int idx = ((int)blockIdx.x - b.first_block[j]) * 256 + threadIdx.x;
+  if (b.backward) wino4_weight_bwd_body(b.w[j], b.kscale[j], b.C[j], b.K[j], b.u[j], idx);
+  else wino4_weight_fwd_body(b.w[j], b.C[j], b.K[j], b.u[j], idx);
 }
 
 // input: V[6a+b][tile][c] = (B^T d B)[a][b], d = the 6x6 patch at (4i-1, 4j-1), zero outside the image
@@ -644,6 +673,43 @@ extern "C" int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, con
   if (rc) return rc;
   LMH_CHECK_ARG(w && u && wino_ok(d));
   wino_weights(d, wino_mo(), w, kscale, backward, u, (hipStream_t)stream);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+extern "C" size_t lmh_winograd_u_bytes(int C, int K) {
+  const int mo = wino_mo();
+  return (size_t)(mo + 2) * (mo + 2) * C * K * sizeof(float);
+}
+
+extern "C" int lmh_winograd_transform_weights_batch(const lmh_wino_weight_job* jobs, int n, int backward,
+                                                    lmh_stream_t stream) {
+  LMH_CHECK_ARG(jobs && n > 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (wino_mo() != 4) {                      // F(2x2,3x3): the per-layer kernels
+    for (int i = 0; i < n; ++i) {
+      lmh_conv_desc d = {};
+      d.C = jobs[i].C; d.K = jobs[i].K;
+      wino_weights(&d, 2, jobs[i].w, jobs[i].kscale, backward, jobs[i].u, st);
+    }
+    LMH_CHECK_LAUNCH();
+    return LMH_OK;
+  }
+  for (int i0 = 0; i0 < n; i0 += WINO_BATCH_MAX) {
+    wino_weight_batch b;
+    b.n = (n - i0) < WINO_BATCH_MAX ? (n - i0) : WINO_BATCH_MAX;
+    b.backward = backward;
+    int blocks = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const lmh_wino_weight_job& j = jobs[i0 + i];
+      LMH_CHECK_ARG(j.w && j.u && j.C > 0 && j.K > 0 && (j.C % BK) == 0 && (j.K % BK) == 0);
+      b.w[i] = j.w; b.kscale[i] = j.kscale; b.u[i] = j.u; b.C[i] = j.C; b.K[i] = j.K;
+      b.first_block[i] = blocks;
+      blocks += (j.C * (j.K / 2) + 255) / 256;       // (c, k2) forward / (k, c2) backward: the same count
+    }
+    b.first_block[b.n] = blocks;
+    hipLaunchKernelGGL(k_wino4_weight_batch, dim3(blocks), dim3(256), 0, st, b);
+  }
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

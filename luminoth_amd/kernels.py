@@ -311,13 +311,31 @@ def _desc_key(d):
     return tuple(getattr(d, f) for f, _ in d._fields_)
 
 
-def conv2d_fwd_winograd(d, x, w, scale=None, shift=None, residual=None, out=None, act_bits=None, keep_v=False):
+def winograd_weights_batch(jobs, backward):
+    """jobs: [(w (3,3,C,K), kscale or None, u)] -> every transformed weight tensor `u` in ONE launch (forward: G g G^T;
+    backward: of the flipped, BatchNorm-scaled weights).  `u` tensors: new_winograd_u(C, K)."""
+    if not jobs:
+        return
+    arr = (_lib.WinoWeightJob * len(jobs))()
+    for i, (w, ks, u) in enumerate(jobs):
+        arr[i].w, arr[i].u = w.data_ptr(), u.data_ptr()
+        arr[i].kscale = ks.data_ptr() if ks is not None else None
+        arr[i].C, arr[i].K = w.shape[2], w.shape[3]
+    check(_lib.load().lmh_winograd_transform_weights_batch(arr, len(jobs), int(bool(backward)), _stream()),
+          'lmh_winograd_transform_weights_batch')
+
+
+def new_winograd_u(C, K, device):
+    return torch.empty((_lib.load().lmh_winograd_u_bytes(int(C), int(K)) // 4,), dtype=torch.float32, device=device)
+
+
+def conv2d_fwd_winograd(d, x, w, scale=None, shift=None, residual=None, out=None, act_bits=None, keep_v=False, u=None):
     """keep_v: the transformed input planes B^T x B are written to a tensor of their own and left on `x` (attribute
     `_lmh_wino_v`): this layer's Winograd weight gradient needs exactly them again (conv2d_bwd_weight_winograd)."""
     lib = _lib.load()
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
     ws = _workspace(lib.lmh_conv2d_winograd_workspace_bytes(ctypes.byref(d)), x.device, 'winograd')
-    u = None      # transformed weights are produced inside the call (they change every step)
+    # u: transformed weights prepared ahead (winograd_weights_batch); None: produced inside the call
     v = None
     if keep_v:
         v = torch.empty((lib.lmh_conv2d_winograd_v_bytes(ctypes.byref(d)) // 4,), dtype=torch.float32, device=x.device)
@@ -330,11 +348,10 @@ def conv2d_fwd_winograd(d, x, w, scale=None, shift=None, residual=None, out=None
     return y
 
 
-def conv2d_bwd_data_winograd(d, dy, w, kscale=None, addend=None, out=None, xbits=None):
+def conv2d_bwd_data_winograd(d, dy, w, kscale=None, addend=None, out=None, xbits=None, u=None):
     lib = _lib.load()
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
     ws = _workspace(lib.lmh_conv2d_winograd_workspace_bytes(ctypes.byref(d)), dy.device, 'winograd')
-    u = None
     with _timed(d, 1, wino=True):
         check(lib.lmh_conv2d_bwd_data_winograd(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(u), _p(kscale),
                                                _p(addend), _p(xbits), _p(dx), _p(ws), ctypes.c_size_t(ws.numel()),
@@ -371,13 +388,14 @@ def conv2d_bwd_weight_winograd(d, x, dy, out=None, colsum=None):
     return dw
 
 
-def conv2d_fwd(d, x, w, scale=None, shift=None, residual=None, in_sub=None, out=None, act_bits=None, keep_v=False):
+def conv2d_fwd(d, x, w, scale=None, shift=None, residual=None, in_sub=None, out=None, act_bits=None, keep_v=False,
+               wino_u=None):
     """act_bits (int32 (rows, K/32), optional): WRITTEN with the activation bit mask of y (bit = act'(y) != 0) — what the
     backward pass needs of the activation; the consumer's backward-data epilogue applies it (conv2d_bwd_data xbits)."""
     lib = _lib.load()
     if in_sub is None and _use_winograd(d):
         return conv2d_fwd_winograd(d, x, w, scale, shift, residual, out, act_bits,
-                                   keep_v=keep_v and WINOGRAD_WGRAD and d.C * d.K >= WINOGRAD_WGRAD_MIN_CK)
+                                   keep_v=keep_v and WINOGRAD_WGRAD and d.C * d.K >= WINOGRAD_WGRAD_MIN_CK, u=wino_u)
     y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
     with _timed(d, 0):
         check(lib.lmh_conv2d_fwd(ctypes.byref(d), _p(_f32(x)), _p(_f32(w)), _p(scale), _p(shift), _p(residual),
@@ -418,14 +436,14 @@ def conv_bwd_data_fast(d):
     return _lib.load().lmh_conv2d_kernel_id(ctypes.byref(d), 1) < 1000000
 
 
-def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None, yact=None, xbits=None):
+def conv2d_bwd_data(d, dy, w, kscale=None, addend=None, out=None, yact=None, xbits=None, wino_u=None):
     """yact: layer output y -> the kernel applies g = dy*act'(y) on load (fused activation backward).
     xbits (the activation bit mask of the layer input x, written by the forward kernel that produced x): the result is
     dx * act'(x), i.e. the pre-activation gradient of the layer below (epilogue of the fast / Winograd kernels; one
     in-place pass inside the C call for the others)."""
     lib = _lib.load()
     if yact is None and _use_winograd(d):
-        return conv2d_bwd_data_winograd(d, dy, w, kscale, addend, out, xbits)
+        return conv2d_bwd_data_winograd(d, dy, w, kscale, addend, out, xbits, u=wino_u)
     dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
     with _timed(d, 1):
         check(lib.lmh_conv2d_bwd_data(ctypes.byref(d), _p(_f32(dy)), _p(_f32(w)), _p(kscale), _p(addend), _p(yact),

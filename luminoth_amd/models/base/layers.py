@@ -83,6 +83,9 @@ class ConvLayer(object):
         self.b_name = '%s/%s' % (scope, bias_name)
         self._desc = {}
         self._fused = {}
+        # transformed Winograd weights prepared ahead of the convolution calls (prepare_winograd_weights): [forward, backward]
+        self._wino_u = [None, None]
+        self._wino_ready = [False, False]
 
     # ---- variable names in TF creation order (drives fine_tune_from) --------
     def var_names(self):
@@ -131,7 +134,8 @@ class ConvLayer(object):
             bits = K.new_act_bits(d.N * d.OH * d.OW, self.cout, x.device)
         # a training forward of a trainable Winograd layer keeps B^T x B for its weight gradient (kernels.py)
         y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub, act_bits=bits,
-                         keep_v=(want_bits or keep_v) and self.trainable)
+                         keep_v=(want_bits or keep_v) and self.trainable,
+                         wino_u=self._wino_u[0] if self._wino_ready[0] else None)
         if ACT_TAP is not None:
             ACT_TAP[self.scope] = y
         return (y, bits) if want_bits else y
@@ -194,7 +198,8 @@ class ConvLayer(object):
         dx = None
         if inline and need_dx:        # tail of the backward: data gradient first, weight gradients behind it
             dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
-                                   addend=addend, yact=yact, xbits=mask_bits)
+                                   addend=addend, yact=yact, xbits=mask_bits,
+                                   wino_u=self._wino_u[1] if self._wino_ready[1] else None)
         if self.trainable:
             cs = colsum if colsum_in_wgrad else None
             if SideStream.enabled and not inline:
@@ -209,8 +214,37 @@ class ConvLayer(object):
                 self._weight_grads(d, x, g, yact, cs)
         if need_dx and not inline:
             dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
-                                   addend=addend, yact=yact, xbits=mask_bits)
+                                   addend=addend, yact=yact, xbits=mask_bits,
+                                   wino_u=self._wino_u[1] if self._wino_ready[1] else None)
         return dx, (g if yact is None else None)
+
+
+def winograd_candidates(layers):
+    """The layers whose 3x3 convolution the kernels route through Winograd whatever the spatial size (stride 1, SAME,
+    fp32, channel counts the transforms cover, above the routing threshold)."""
+    return [l for l in layers if l.k == 3 and l.stride == 1 and l.rate == 1 and l.padding == 'SAME' and l.compute is None and
+            l.cin % 32 == 0 and l.cout % 32 == 0 and K.WINOGRAD and l.cin * l.cout >= K.WINOGRAD_MIN_CK]
+
+
+def prepare_winograd_weights(layers, backward):
+    """One launch for the transformed weights of every layer in `layers` (forward or backward set) on the current stream;
+    the layers use them until release_winograd_weights.  The weights (and BatchNorm scales) must not change in between:
+    the fused train step prepares both sets at its start and releases them before the optimizer update."""
+    jobs = []
+    b = int(bool(backward))
+    for l in layers:
+        n = K._lib.load().lmh_winograd_u_bytes(l.cin, l.cout) // 4
+        if l._wino_u[b] is None or l._wino_u[b].numel() != n:
+            l._wino_u[b] = K.new_winograd_u(l.cin, l.cout, l.w.device)
+        jobs.append((l.w, (l.scale if l.norm == 'bn' else None) if backward else None, l._wino_u[b]))
+    K.winograd_weights_batch(jobs, backward)
+    for l in layers:
+        l._wino_ready[b] = True
+
+
+def release_winograd_weights(layers):
+    for l in layers:
+        l._wino_ready = [False, False]
 
 
 class BNTable(object):

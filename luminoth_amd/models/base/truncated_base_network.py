@@ -185,7 +185,10 @@ class TruncatedBaseNetwork(BaseNetwork):
 
     def __call__(self, inputs, is_training=False):
         """inputs (B,H,W,3) fp32 RGB 0..255 -> feature map (B,fh,fw,C)."""
-        self.bn_table.refresh()
+        if getattr(self, '_bn_fresh', False):
+            self._bn_fresh = False            # the caller refreshed the table itself (FasterRCNN._train_step)
+        else:
+            self.bn_table.refresh()
         return self._run(self.trunk, inputs.contiguous(), is_training)
 
     @property

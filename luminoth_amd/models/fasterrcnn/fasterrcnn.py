@@ -24,6 +24,7 @@ import torch
 
 from luminoth_amd import _lib
 from luminoth_amd import kernels as K
+from luminoth_amd.models.base import layers as L
 from luminoth_amd.models.base.layers import SideStream
 from luminoth_amd.models.base.truncated_base_network import TruncatedBaseNetwork
 from luminoth_amd.models.fasterrcnn.rcnn import RCNN
@@ -36,6 +37,7 @@ from luminoth_amd.utils.anchors import generate_anchors_reference, truncate_refe
 
 # software pipelining across steps (train_step(next_image=...)); LUMINOTH_AMD_PREFETCH_PREFIX=0 turns it off
 PREFETCH_PREFIX = os.environ.get('LUMINOTH_AMD_PREFETCH_PREFIX', '1') != '0'
+WINO_BATCH = os.environ.get('LUMINOTH_AMD_WINO_BATCH', '1') != '0'      # transformed Winograd weights of the whole step in two launches
 
 
 class FasterRCNN(object):
@@ -255,6 +257,15 @@ class FasterRCNN(object):
             K.TAILS.abort()
             self._prefetch = self._tgt_prefetch = None
             raise
+        finally:
+            L.release_winograd_weights(self._winograd_layers())
+
+    def _winograd_layers(self):
+        wl = getattr(self, '_wino_layers', None)
+        if wl is None:
+            layers = self.base_network.trunk.all_layers() + [self._rpn._rpn]
+            wl = self._wino_layers = L.winograd_candidates(layers)
+        return wl
 
     def _train_step(self, image, gt_boxes, next_image=None, next_gt=None):
         """forward + loss + backward of ONE train step (train.py:66-91), same arithmetic as
@@ -289,6 +300,21 @@ class FasterRCNN(object):
         main = torch.cuda.current_stream(self.device)
         aux = self._aux_stream()
         self._phase_begin()
+        # Winograd weight transforms of the whole step: the forward set in one launch here, the backward set in one launch
+        # on the (idle) weight-gradient stream while the forward pass runs — instead of one small launch inside each of
+        # the ~20 Winograd convolution calls.  Nothing writes the weights or the BatchNorm scales before the update.
+        self.base_network.bn_table.refresh()
+        self.base_network._bn_fresh = True
+        wl = self._winograd_layers() if WINO_BATCH else []
+        wino_bwd_ready = None
+        if wl:
+            L.prepare_winograd_weights(wl, backward=False)
+            side0 = SideStream.get(self.device)
+            side0.wait_stream(main)
+            with torch.cuda.stream(side0):
+                L.prepare_winograd_weights([l for l in wl if l.trainable], backward=True)
+                wino_bwd_ready = torch.cuda.Event()
+                wino_bwd_ready.record(side0)
         self.store.grad.zero_()
         from luminoth_amd.utils import training as _tr
         # the aux stream is idle once the RCNN branch is done: weight-gradient tails of the trunk backward are finished
@@ -332,6 +358,8 @@ class FasterRCNN(object):
             rpn_losses, rpn_g = rpn.loss_and_grads(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
             rpn_loss_done = torch.cuda.Event()
             rpn_loss_done.record(main)
+            if wino_bwd_ready is not None:
+                main.wait_event(wino_bwd_ready)      # (recorded before the forward pass was even enqueued: long done)
             torch.autograd.backward([rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred']],
                                     [g.view_as(t) for g, t in zip(rpn_g, (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred']))])
             self._mark('rpn_bwd_done')
