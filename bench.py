@@ -336,8 +336,12 @@ def main():
                 'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes)',
                 'traffic_source': traffic_src,
                 'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
+                'ms_per_launch_raw_event_interval': r['ms_raw'] / r['launches'],
+                'event_pair_overhead_ms': K._Profile.overhead_ms,
                 'ms_per_step': r['ms'] / nprof,
-                'timing': 'HIP events around the kernel on its launch stream, %d serialised profiling steps' % nprof,
+                'timing': 'HIP events around the kernel on its launch stream, %d serialised profiling steps; minus the '
+                          'interval of an event pair around an EMPTY kernel (dispatch latency, calibrated in this process): '
+                          'comparable with rocprofv3 kernel durations (profiles/r03_bench_roofline_steps_summary.md)' % nprof,
                 # conv_flops = the ALGORITHMIC count of SURVEY.md 8(d) (direct convolution); executed_flops = what the
                 # launched kernels actually multiply (Winograd F(2x2,3x3) layers do 2.25x fewer): the second is the honest
                 # measure of how busy the matrix pipe is, the first of how fast the step's defined work gets done

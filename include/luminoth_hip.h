@@ -139,6 +139,9 @@ double lmh_conv2d_profile_last_bytes(void);
 void* lmh_event_create(void);
 void lmh_event_destroy(void* e);
 float lmh_event_elapsed_ms(void* e0, void* e1);
+/* Median interval of an event pair around an EMPTY kernel on `stream` (synchronises it): the dispatch latency an event
+ * pair adds to a kernel's own duration.  bench.py subtracts it from its per-launch timings (comparable with rocprofv3). */
+float lmh_event_pair_overhead_ms(int reps, lmh_stream_t stream);
 /* g = dy * (y > 0 [&& y < 6 for relu6]) (g may be NULL); colsum[k] = sum_rows g
  * (may be NULL; written, not accumulated; two-stage deterministic reduction through ws). */
 size_t lmh_act_bwd_workspace_bytes(int64_t rows, int K);

@@ -75,6 +75,37 @@ extern "C" float lmh_event_elapsed_ms(void* e0, void* e1) {
   return ms;
 }
 
+// What an event pair around ONE kernel measures on top of the kernel's own duration: the dispatch latency between the
+// start event's completion and the kernel's first wave, and the end event's own processing.  Measured with an empty
+// kernel (median of `reps` pairs on `stream`, which is synchronised); bench.py subtracts it from its per-launch event
+// timings so that they are comparable with rocprofv3's kernel durations (begin / end timestamps of the dispatch itself).
+__global__ void k_noop() {}
+extern "C" float lmh_event_pair_overhead_ms(int reps, lmh_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (reps < 1) reps = 1;
+  if (reps > 64) reps = 64;
+  hipEvent_t e0[64], e1[64];
+  float ms[64];
+  for (int i = 0; i < reps; ++i) {
+    if (hipEventCreate(&e0[i]) != hipSuccess || hipEventCreate(&e1[i]) != hipSuccess) return -1.f;
+  }
+  for (int i = 0; i < reps; ++i) {
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st);       // something in front, like in a real step
+    (void)hipEventRecord(e0[i], st);
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st);
+    (void)hipEventRecord(e1[i], st);
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) return -1.f;
+  for (int i = 0; i < reps; ++i) {
+    if (hipEventElapsedTime(&ms[i], e0[i], e1[i]) != hipSuccess) ms[i] = 0.f;
+    (void)hipEventDestroy(e0[i]);
+    (void)hipEventDestroy(e1[i]);
+  }
+  for (int i = 1; i < reps; ++i)          // insertion sort: median
+    for (int j = i; j > 0 && ms[j] < ms[j - 1]; --j) { const float t = ms[j]; ms[j] = ms[j - 1]; ms[j - 1] = t; }
+  return ms[reps / 2];
+}
+
 // ---- deferred weight-gradient tails: per-thread switch + the plan of the last deferred call ----------------------
 thread_local int g_lmh_defer_tail = 0;
 thread_local lmh_tail_plan g_lmh_last_plan = {nullptr, 0, nullptr, 0};

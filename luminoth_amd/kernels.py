@@ -174,19 +174,28 @@ class _Profile(object):
     def start(cls):
         cls.enabled, cls.records = True, []
 
+    overhead_ms = 0.0   # of the last stop(): what an event pair adds to a kernel's own duration (lmh_event_pair_overhead_ms)
+
     @classmethod
     def stop(cls):
+        """-> {kernel: {launches, flops, bytes, direct_flops, ms, ms_raw}}: `ms_raw` sums the event intervals as measured,
+        `ms` the same minus the calibrated interval of an event pair around an empty kernel (the dispatch latency
+        between the start event and the kernel's first wave is not kernel time; rocprofv3's durations exclude it too)."""
         cls.enabled = False
         torch.cuda.synchronize()
         lib = _lib.load()
+        cls.overhead_ms = max(0.0, float(lib.lmh_event_pair_overhead_ms(32, _stream())))
         out = {}
         for name, flops, nbytes, direct, e0, e1 in cls.records:
-            r = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'bytes': 0.0, 'direct_flops': 0.0, 'ms': 0.0})
+            r = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'bytes': 0.0, 'direct_flops': 0.0, 'ms': 0.0,
+                                      'ms_raw': 0.0})
             r['launches'] += 1
             r['flops'] += flops
             r['bytes'] += nbytes
             r['direct_flops'] += direct
-            r['ms'] += lib.lmh_event_elapsed_ms(e0, e1)
+            raw = lib.lmh_event_elapsed_ms(e0, e1)
+            r['ms_raw'] += raw
+            r['ms'] += max(raw - cls.overhead_ms, 0.25 * raw)
             lib.lmh_event_destroy(e0)
             lib.lmh_event_destroy(e1)
         cls.records = []

@@ -1,7 +1,7 @@
 # Round 3 evidence, part 1: bench lines of every workload / dtype (copied into profiles/ afterwards)
 R=$GRAFT_REPO_ROOT
 cd $R; mkdir -p gpurun_out/ev
-timeout 500 python bench.py > gpurun_out/ev/r03_bench_line.json 2> gpurun_out/ev/r03_bench_line.err; tail -c 600 gpurun_out/ev/r03_bench_line.json; echo
+timeout 600 python bench.py > gpurun_out/ev/r03_bench_line.json 2> gpurun_out/ev/r03_bench_line.err; tail -c 600 gpurun_out/ev/r03_bench_line.json; echo
 timeout 200 python bench.py --serial --no-cpu-baseline > gpurun_out/ev/r03_bench_serial_line.json 2>/dev/null
 timeout 200 python bench.py --no-lookahead --no-cpu-baseline --no-roofline > gpurun_out/ev/r03_bench_nolookahead_line.json 2>/dev/null
 timeout 300 python bench.py --alt --no-cpu-baseline --no-roofline > gpurun_out/ev/r03_bench_with_alt.json 2>/dev/null
