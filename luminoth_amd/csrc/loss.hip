@@ -160,8 +160,7 @@ extern "C" int lmh_rpn_loss(const float* cls_score, const float* bbox_pred, cons
 __global__ void __launch_bounds__(LOSS_THREADS)
 k_rcnn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_offsets,
             const float* __restrict__ labels, const float* __restrict__ targets, int B, int R, int C,
-            float sigma2, float w_cls, float w_reg, float* __restrict__ per_image,
-            float* __restrict__ d_cls, float* __restrict__ d_off) {
+            float sigma2, float* __restrict__ per_image) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ float sh[72];
   const int b = blockIdx.x;
@@ -199,37 +198,49 @@ k_rcnn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_
     per_image[b * 4 + 2] = acc[1];
     per_image[b * 4 + 3] = acc[3];
   }
-  if (!d_cls && !d_off) return;
-  const float gc = w_cls / (acc[1] * (float)B);
-  const float gr = w_reg / (acc[3] * (float)B);
-  for (int r = wave; r < R; r += nw) {
-    const size_t row = (size_t)b * R + r;
-    const float l = labels[row];
-    if (d_cls) {
-      const float* s = cls_score + row * C1;
-      float* g = d_cls + row * C1;
-      if (l >= 0.f) {
-        float m = -INFINITY;
-        for (int c = lane; c < C1; c += 64) m = fmaxf(m, s[c]);
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float se = 0.f;
-        for (int c = lane; c < C1; c += 64) se += expf(s[c] - m);
-        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
-        for (int c = lane; c < C1; c += 64)
-          g[c] = (expf(s[c] - m) / se - ((c == (int)l) ? 1.f : 0.f)) * gc;
-      } else {
-        for (int c = lane; c < C1; c += 64) g[c] = 0.f;
-      }
+}
+
+// Gradient pass of the RCNN loss, one WAVE per row over the whole grid (round 3): written from the one block per image of
+// the sum kernel, the 81 + 320 floats of each of the 512 rows kept the proposal / RCNN chain — the critical path of the
+// middle of the step — on two CUs for 70 us.  Same arithmetic: gc / gr from the per-image counts.
+__global__ void __launch_bounds__(256)
+k_rcnn_loss_grad(const float* __restrict__ cls_score, const float* __restrict__ bbox_offsets,
+                 const float* __restrict__ labels, const float* __restrict__ targets, int B, int R, int C,
+                 float sigma2, float w_cls, float w_reg, const float* __restrict__ per_image,
+                 float* __restrict__ d_cls, float* __restrict__ d_off) {
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * R) return;
+  const int b = (int)(row / R);
+  const int C1 = C + 1;
+  const float gc = w_cls / (per_image[b * 4 + 2] * (float)B);
+  const float gr = w_reg / (per_image[b * 4 + 3] * (float)B);
+  const float l = labels[row];
+  if (d_cls) {
+    const float* s = cls_score + row * C1;
+    float* g = d_cls + row * C1;
+    if (l >= 0.f) {
+      float m = -INFINITY;
+      for (int c = lane; c < C1; c += 64) m = fmaxf(m, s[c]);
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      float se = 0.f;
+      for (int c = lane; c < C1; c += 64) se += expf(s[c] - m);
+      for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+      for (int c = lane; c < C1; c += 64)
+        g[c] = (expf(s[c] - m) / se - ((c == (int)l) ? 1.f : 0.f)) * gc;
+    } else {
+      for (int c = lane; c < C1; c += 64) g[c] = 0.f;
     }
-    if (d_off) {
-      float* g = d_off + row * 4 * C;
-      const int lo = (l > 0.f) ? 4 * ((int)l - 1) : -1;
-      for (int c = lane; c < 4 * C; c += 64) {
-        float v = 0.f;
-        if (lo >= 0 && c >= lo && c < lo + 4)
-          v = sl1_grad(bbox_offsets[row * 4 * C + c] - targets[row * 4 + (c - lo)], sigma2) * gr;
-        g[c] = v;
-      }
+  }
+  if (d_off) {
+    float* g = d_off + row * 4 * C;
+    const int lo = (l > 0.f) ? 4 * ((int)l - 1) : -1;
+    for (int c = lane; c < 4 * C; c += 64) {
+      float v = 0.f;
+      if (lo >= 0 && c >= lo && c < lo + 4)
+        v = sl1_grad(bbox_offsets[row * 4 * C + c] - targets[row * 4 + (c - lo)], sigma2) * gr;
+      g[c] = v;
     }
   }
 }
@@ -242,7 +253,11 @@ extern "C" int lmh_rcnn_loss(const float* cls_score, const float* bbox_offsets, 
   LMH_CHECK_ARG(B > 0 && R > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_rcnn_loss, dim3(B), dim3(LOSS_THREADS), 0, st, cls_score, bbox_offsets, labels,
-                     targets, B, R, C, sigma * sigma, w_cls, w_reg, per_image, d_cls_score, d_bbox_offsets);
+                     targets, B, R, C, sigma * sigma, per_image);
+  if (d_cls_score || d_bbox_offsets)
+    hipLaunchKernelGGL(k_rcnn_loss_grad, dim3((unsigned)(((int64_t)B * R + 3) / 4)), dim3(256), 0, st, cls_score,
+                       bbox_offsets, labels, targets, B, R, C, sigma * sigma, w_cls, w_reg, per_image, d_cls_score,
+                       d_bbox_offsets);
   hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, w_cls, w_reg, losses);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
