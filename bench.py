@@ -88,7 +88,7 @@ def condition_weights(model, arch):
     return model
 
 
-def build(wl, device, dtype='f32'):
+def build(wl, device, dtype='f32', half_storage=True):
     from luminoth_amd.models import get_model
     from luminoth_amd.utils.config import get_config
     if wl['model'] == 'ssd':
@@ -100,6 +100,11 @@ def build(wl, device, dtype='f32'):
             bn['fine_tune_from'] = 'conv3'     # the reference default "block2" is ResNet-only (raises for VGG there too)
         if dtype != 'f32':
             bn['compute_dtype'] = dtype
+            # f16 / bf16: 16-bit activations, activation gradients and working weights in HBM for the ResNet trunk
+            # (csrc/conv_hs.h); --fp32-storage keeps the round-2 path (fp32 tensors, operands rounded
+            # on their way into LDS)
+            if half_storage and dtype in ('f16', 'bf16') and wl['arch'].startswith('resnet_v1') and wl['arch'] != 'resnet_v1_101':
+                bn['storage_dtype'] = dtype
         cfg = get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': wl['classes']},
                                     'base_network': bn}, 'train': {'seed': 0, 'debug': False}})
     model = get_model(wl['model'])(cfg, device=device)
@@ -187,6 +192,8 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the workload\'s)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16', 'bf16x3'],
                     help='convolution compute dtype (f32 = the parity dtype of north_star)')
+    ap.add_argument('--fp32-storage', action='store_true',
+                    help='with --dtype f16 / bf16: keep fp32 tensors in HBM (round-2 path) instead of the half-storage trunk')
     ap.add_argument('--serial', action='store_true',
                     help='run EVERY step on one stream (the schedule of the roofline profiling steps): the command '
                          'the rocprofv3 summaries under profiles/*_serial_* are taken from')
@@ -244,7 +251,7 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl['batch'] = args.batch
-    cfg, model = build(wl, device, args.dtype)
+    cfg, model = build(wl, device, args.dtype, half_storage=not args.fp32_storage)
     T.broadcast_parameters(model)
     sd0 = model.state_dict() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     opt = T.get_optimizer(cfg.train, model)
@@ -376,6 +383,9 @@ def main():
                                    % (wl['cfg'], args.workload, wl['model'], wl['arch'], wl['H'], wl['W'], wl['batch'],
                                       wl['classes'], wl['G'], ' [single-stream schedule]' if args.serial else ''),
                        'global_batch': gb, 'parallelism': 'dp%d' % world, 'final_total_loss': loss_val,
+                       'storage': (getattr(getattr(model, 'base_network', None), 'storage_dtype', None) or 'f32') +
+                                  (' trunk activations / gradients / working weights in HBM, fp32 master weights'
+                                   if getattr(getattr(model, 'base_network', None), 'storage_dtype', None) else ''),
                        'schedule': schedule},
             'roofline': roofline,
             # what the collective layer saw (SCALE_rNN.json can show that RCCL ran with N ranks)

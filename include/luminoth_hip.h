@@ -200,6 +200,46 @@ int lmh_maxpool_bwd(const float* x, const float* y, const float* dy, int N, int 
                     int ksize, int stride, int pad_top, int pad_left, int OH, int OW, float* dx,
                     lmh_stream_t stream);
 
+/* ---- Half-STORAGE convolution path (BASELINE.json configs[4] "fp16 MFMA path"; SURVEY.md 8(d): "fp16 activations/weights
+ * with fp32 accumulate + fp32 master weights") for the conv stack the reference builds in
+ * luminoth/models/base/base_network.py:82-93 (slim resnet_v1 bottlenecks).  Every `void*` tensor below holds 16-bit
+ * elements: IEEE f16 when d->compute == 1, bfloat16 when d->compute == 2 (other values: LMH_ERR_UNSUPPORTED); needs
+ * C % 64 == 0 and K % 64 == 0 (lmh_conv2d_hs_supported).  Master weights, weight gradients, BatchNorm vectors stay fp32.
+ *   w_fwd [K][R][S][C] = q(w[r][s][c][k])                 w_bwd [R][S][C][K] = q(w[r][s][c][k] * kscale[k])
+ * are the working copies lmh_half_weights_batch writes from the fp32 HWIO master weights (once per optimizer step).
+ *   forward    y  = q( act( conv(x, w_fwd) * scale + shift + residual ) )        (y fp32 and unrounded when y_is_f32)
+ *              act_bits (may be NULL): activation mask of the STORED y, layout of lmh_act_bits
+ *   backward   dx = q( ( conv^T(g, w_bwd) + addend ) * act'(x) )                act'(x) from xbits (may be NULL)
+ *   weights    dw = inv_scale * corr(x, g)   (fp32, RAW like lmh_conv2d_bwd_weight);  colsum[k] = inv_scale * sum_p g[p][k]
+ * g carries the caller's loss scale (a power of two; 1 for bf16): inv_scale removes it.  Workspace of the weight
+ * gradient: lmh_conv2d_bwd_weight_workspace_bytes(d); deferred tails (lmh_tail_defer) work as for lmh_conv2d_bwd_weight. */
+int lmh_conv2d_hs_supported(const lmh_conv_desc* d);
+int lmh_conv2d_fwd_hs(const lmh_conv_desc* d, const void* x, const void* w_fwd, const float* scale, const float* shift,
+                      const void* residual, void* y, int y_is_f32, uint32_t* act_bits, lmh_stream_t stream);
+int lmh_conv2d_bwd_data_hs(const lmh_conv_desc* d, const void* g, const void* w_bwd, const void* addend,
+                           const uint32_t* xbits, void* dx, lmh_stream_t stream);
+int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, const void* g, float inv_scale, float* dw,
+                             float* colsum, void* ws, size_t ws_bytes, lmh_stream_t stream);
+typedef struct lmh_half_weight_job {
+  const float* w;       /* (R*S, C, K) fp32 master weights (HWIO) */
+  const float* kscale;  /* K floats folded into w_bwd (frozen-BatchNorm scale), or NULL */
+  void* w_fwd;          /* [K][R*S*C] halfs, or NULL */
+  void* w_bwd;          /* [R*S*C][K] halfs, or NULL */
+  int32_t RS, C, K;
+} lmh_half_weight_job;
+int lmh_half_weights_batch(const lmh_half_weight_job* jobs, int n, int dtype, lmh_stream_t stream);
+/* y = q(x * mul * mask): fp32 (rows, C) -> half; bits (may be NULL): activation mask [rows][C / 32] — the entry of the
+ * trunk backward (gradient of the fp32 feature map times the loss scale, masked by the top layer's ReLU).  C % 8 == 0. */
+int lmh_cast_to_half(const float* x, int64_t rows, int C, float mul, const uint32_t* bits, void* y, int dtype,
+                     lmh_stream_t stream);
+int lmh_cast_to_f32(const void* x, int64_t n, float mul, float* y, int dtype, lmh_stream_t stream);   /* n % 8 == 0 */
+/* tf.nn.max_pool on NHWC with a half result; x fp32 (x_is_f32: the fp32 stem output) or half.  C % 8 == 0. */
+int lmh_maxpool_fwd_hs(const void* x, int x_is_f32, int N, int H, int W, int C, int ksize, int stride, int pad_top,
+                       int pad_left, int OH, int OW, void* y, int dtype, lmh_stream_t stream);
+/* backward of resnet_utils.subsample (1x1 max pool, stride s) on 16-bit tensors: dx (N,H,W,C) fully written. */
+int lmh_subsample_bwd_hs(const void* dy, int N, int H, int W, int C, int stride, int OH, int OW, void* dx,
+                         lmh_stream_t stream);
+
 /* tf.image.resize_images(BILINEAR) as called by luminoth/utils/image.py:92-95 (resize_image) and :126-129
  * (resize_image_fixed) — the first op of the `lumi predict` path (utils/predicting.py:43-47).  TF 1.x legacy
  * sampling (align_corners=False, no half-pixel centres).  src is (H,W,C) uint8 or float32, dst (OH,OW,C) f32.

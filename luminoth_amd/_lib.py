@@ -73,6 +73,11 @@ class WinoWeightJob(ctypes.Structure):
                 ('C', ctypes.c_int32), ('K', ctypes.c_int32)]
 
 
+class HalfWeightJob(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_void_p), ('kscale', ctypes.c_void_p), ('w_fwd', ctypes.c_void_p), ('w_bwd', ctypes.c_void_p),
+                ('RS', ctypes.c_int32), ('C', ctypes.c_int32), ('K', ctypes.c_int32)]
+
+
 class WgradTail(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ('slabs', 'dw', 'w', 'scale', 'mean', 'rstd', 'dgamma', 'colpart',
                                                  'colsum')] + \
@@ -121,6 +126,15 @@ SIGNATURES = {
     'lmh_bn_param_grads': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i, c_f, c_f, c_sz, c_f]),
     'lmh_maxpool_fwd': (c_i, [c_f] + [c_i] * 10 + [c_f, c_f]),
     'lmh_maxpool_bwd': (c_i, [c_f, c_f, c_f] + [c_i] * 10 + [c_f, c_f]),
+    'lmh_conv2d_hs_supported': (c_i, [P(ConvDesc)]),
+    'lmh_conv2d_fwd_hs': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f]),
+    'lmh_conv2d_bwd_data_hs': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_conv2d_bwd_weight_hs': (c_i, [P(ConvDesc), c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_half_weights_batch': (c_i, [P(HalfWeightJob), c_i, c_i, c_f]),
+    'lmh_cast_to_half': (c_i, [c_f, ctypes.c_int64, c_i, ctypes.c_float, c_f, c_f, c_i, c_f]),
+    'lmh_cast_to_f32': (c_i, [c_f, ctypes.c_int64, ctypes.c_float, c_f, c_i, c_f]),
+    'lmh_maxpool_fwd_hs': (c_i, [c_f, c_i] + [c_i] * 10 + [c_f, c_i, c_f]),
+    'lmh_subsample_bwd_hs': (c_i, [c_f] + [c_i] * 7 + [c_f, c_f]),
     'lmh_resize_bilinear': (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_f]),
     'lmh_rpn_proposal_workspace_bytes': (c_sz, [P(RpnProposalDesc)]),
     'lmh_rpn_proposal': (c_i, [P(RpnProposalDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),

@@ -662,3 +662,112 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
 }
 
 #include "conv_winograd.h"
+
+// ============================================================================
+// half-storage entry points (conv_hs.h): f16 / bf16 tensors in HBM
+// ============================================================================
+#include "conv_hs.h"
+
+static bool hs_ok(const lmh_conv_desc* d) {
+  return (d->compute == 1 || d->compute == 2) && (d->C % HS_BK) == 0 && (d->K % HS_BK) == 0;
+}
+extern "C" int lmh_conv2d_hs_supported(const lmh_conv_desc* d) { return d && check_desc(d) == LMH_OK && hs_ok(d) ? 1 : 0; }
+
+// bytes of a half-storage launch: every operand read once, the result written once, 2 bytes per element
+static inline double hs_bytes(const lmh_conv_desc* d) {
+  return 2.0 * ((double)d->N * d->H * d->W * d->C + (double)d->R * d->S * d->C * d->K + (double)d->N * d->OH * d->OW * d->K);
+}
+
+template <bool BWD>
+static int hs_launch(const lmh_conv_desc* d, const void* A, const void* B, const hs_epilogue& e, hipStream_t st) {
+  const int64_t M = BWD ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->OH * d->OW;
+  const int NC = BWD ? d->C : d->K;
+  int bm, bn;
+  pick_tile(M, NC, &bm, &bn, 512);      // two resident blocks per CU
+  const int grid = (int)(((M + bm - 1) / bm) * ((NC + bn - 1) / bn));
+#define LAUNCH_HS(DT_, BM_, BN_)                                                                             \
+  hipLaunchKernelGGL((k_conv_hs<DT_, BM_, BN_, BWD>), dim3(grid), dim3(256), 0, st, *d,                         \
+                     reinterpret_cast<const HT<DT_>::T*>(A), reinterpret_cast<const HT<DT_>::T*>(B), e)
+#define LAUNCH_HS_T(BM_, BN_) do { if (d->compute == 1) LAUNCH_HS(1, BM_, BN_); else LAUNCH_HS(2, BM_, BN_); } while (0)
+  prof_begin(st);
+  if (bm == 128 && bn == 128) LAUNCH_HS_T(128, 128);
+  else if (bm == 128) LAUNCH_HS_T(128, 64);
+  else LAUNCH_HS_T(64, 64);
+#undef LAUNCH_HS_T
+#undef LAUNCH_HS
+  prof_end(st, desc_flops(d), "k_conv_hs<%d, %d, %d, %s>", d->compute, bm, bm == 128 ? bn : 64, BWD ? "true" : "false");
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+extern "C" int lmh_conv2d_fwd_hs(const lmh_conv_desc* d, const void* x, const void* w_fwd, const float* scale,
+                                 const float* shift, const void* residual, void* y, int y_is_f32, uint32_t* act_bits,
+                                 lmh_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  LMH_CHECK_ARG(x && w_fwd && y);
+  if (!hs_ok(d)) { lmh_set_error("lmh_conv2d_fwd_hs: needs compute f16 / bf16, C %% 64 == 0, K %% 64 == 0"); return LMH_ERR_UNSUPPORTED; }
+  LMH_CHECK_ARG(act_bits == nullptr || d->act != 0);
+  g_prof_pending_bytes = hs_bytes(d);
+  hs_epilogue e = {scale, shift, residual, nullptr, act_bits, y, y_is_f32, 1.f};
+  return hs_launch<false>(d, x, w_fwd, e, (hipStream_t)stream);
+}
+
+extern "C" int lmh_conv2d_bwd_data_hs(const lmh_conv_desc* d, const void* g, const void* w_bwd, const void* addend,
+                                      const uint32_t* xbits, void* dx, lmh_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  LMH_CHECK_ARG(g && w_bwd && dx);
+  if (!hs_ok(d)) { lmh_set_error("lmh_conv2d_bwd_data_hs: needs compute f16 / bf16, C %% 64 == 0, K %% 64 == 0"); return LMH_ERR_UNSUPPORTED; }
+  g_prof_pending_bytes = hs_bytes(d);
+  hs_epilogue e = {nullptr, nullptr, addend, xbits, nullptr, dx, 0, 1.f};
+  return hs_launch<true>(d, g, w_bwd, e, (hipStream_t)stream);
+}
+
+extern "C" int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, const void* g, float inv_scale, float* dw,
+                                        float* colsum, void* ws, size_t ws_bytes, lmh_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  LMH_CHECK_ARG(x && g && dw);
+  if (!hs_ok(d)) { lmh_set_error("lmh_conv2d_bwd_weight_hs: needs compute f16 / bf16, C %% 64 == 0, K %% 64 == 0"); return LMH_ERR_UNSUPPORTED; }
+  int bm, bn, splits, kps;
+  bwd_weight_plan(d, &bm, &bn, &splits, &kps);
+  if (ws_bytes < lmh_conv2d_bwd_weight_workspace_bytes(d) || ((splits > 1 || colsum) && !ws)) {
+    lmh_set_error("lmh_conv2d_bwd_weight_hs: workspace too small");
+    return LMH_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  g_prof_pending_bytes = 2.0 * ((double)d->N * d->H * d->W * d->C + (double)d->N * d->OH * d->OW * d->K) +
+                         4.0 * d->R * d->S * d->C * d->K;
+  const size_t slab_bytes = splits > 1 ? lmh_align_up((size_t)splits * d->R * d->S * d->C * d->K * sizeof(float), 256) : 256;
+  float* out = splits > 1 ? reinterpret_cast<float*>(ws) : dw;
+  float* cpart = colsum ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + slab_bytes) : nullptr;
+  const int tx = d->R * d->S * ((d->C + bm - 1) / bm), ty = (d->K + bn - 1) / bn;
+  const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
+#define LAUNCH_BW_HS(DT_, BM_, BN_)                                                                          \
+  hipLaunchKernelGGL((k_conv_bwd_weight_hs<DT_, BM_, BN_>), dim3(tx * ty * splits), dim3(256), 0, st, *d,         \
+                     reinterpret_cast<const HT<DT_>::T*>(x), reinterpret_cast<const HT<DT_>::T*>(g), out, kps, dvw, dvh, \
+                     inv_scale, tx, ty, splits, cpart)
+#define LAUNCH_BW_HS_T(BM_, BN_) do { if (d->compute == 1) LAUNCH_BW_HS(1, BM_, BN_); else LAUNCH_BW_HS(2, BM_, BN_); } while (0)
+  prof_begin(st);
+  if (bm == 128 && bn == 128) LAUNCH_BW_HS_T(128, 128);
+  else LAUNCH_BW_HS_T(64, 64);
+#undef LAUNCH_BW_HS_T
+#undef LAUNCH_BW_HS
+  prof_end(st, desc_flops(d), "k_conv_bwd_weight_hs<%d, %d, %d>", d->compute, bm == 128 && bn == 128 ? 128 : 64,
+           bm == 128 && bn == 128 ? 128 : 64);
+  if (g_lmh_defer_tail) {
+    g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;
+    g_lmh_last_plan.splits = splits > 1 ? splits : 0;
+    g_lmh_last_plan.colpart = cpart;
+    g_lmh_last_plan.colrows = cpart ? splits : 0;
+  } else if (splits > 1 || cpart) {
+    const int64_t n = splits > 1 ? (int64_t)d->R * d->S * d->C * d->K : 0;
+    const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;
+    const int nb_col = cpart ? (d->K + 31) / 32 : 0;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
+                       splits, dw, (const float*)cpart, colsum, d->K, nb_slab, splits);
+  }
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}

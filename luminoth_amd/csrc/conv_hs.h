@@ -1,0 +1,357 @@
+// Half-STORAGE convolutions (gfx950): activations, activation gradients and the working copy of the weights are f16 / bf16
+// tensors in HBM; v_mfma_f32_32x32x16_{f16,bf16} accumulate in fp32; master weights and weight gradients stay fp32.
+// BASELINE configs[4] ("fp16 MFMA path", SURVEY.md §8(d): "fp16 activations/weights with fp32 accumulate + fp32 master
+// weights").  conv_half.h keeps fp32 tensors and rounds operands on their way into LDS — every byte it moves is still an
+// fp32 byte and the kernels are bound by that staging path; here an operand row of 64 reduction elements is 128 bytes
+// and goes from HBM to LDS as eight 16-byte pieces with no arithmetic in between.
+//
+// Forward and backward-data are ONE kernel: both are gather-GEMMs whose two operands are contiguous along the reduction
+// axis once the weight copy has the right layout — the optimizer's cast pass (k_half_weights, elementwise.hip) writes
+//     w_fwd[k][r][s][c] = q(w[r][s][c][k])                  ("OHWI": a row = everything one output channel multiplies)
+//     w_bwd[r][s][c][k] = q(w[r][s][c][k] * bn_scale[k])    (HWIO with the frozen-BatchNorm scale folded in)
+// so neither pass transposes anything:
+//     forward    y[p][k]  = q( act( sum_{tap,c} x[src(p,tap)][c] * w_fwd[k][tap][c] * scale[k] + shift[k] + res[p][k] ) )
+//     backward   dx[p][c] = q( ( sum_{tap,k} g[dst(p,tap)][k] * w_bwd[tap][c][k] + addend[p][c] ) * act'(x[p][c]) )
+// with act'(x) read from the activation bit mask the forward epilogue of the producing layer wrote (conv_fast.h).
+// Gradients carry the step's loss scale (a power of two chosen by the host, 1 for bf16); the weight gradient divides it
+// out of its fp32 accumulators.
+//
+// Tile: BM x BN outputs, BK = 64 reduction elements per stage, two LDS buffers of [BM + BN][72] halfs (rows padded by
+// 16 bytes: the four 16-lane groups of a ds_read_b128 fragment load hit 16 distinct 4-bank groups), 73.7 KB at 128x128 ->
+// two blocks per CU.  One register set: the loads of stage t+1 fly under the MFMAs of stage t.
+//
+// The weight gradient keeps the staging map of k_conv_bwd_weight_h (both operands are pixel-major, so a thread loads a
+// 4 pixel x 4 channel block and writes four k-contiguous quads) with 8-byte loads and a v_perm transpose instead of
+// 16-byte loads and v_cvt; the per-channel sums of g (dbeta / dbias) are taken from the B tile while it is in LDS.
+#pragma once
+#include "conv_half.h"
+
+#define HS_BK 64
+#define HS_LD (HS_BK + 8)
+
+struct hs_epilogue {
+  const float* scale;        // forward: per output channel (NULL = 1)
+  const float* shift;        // forward: per output channel (NULL = 0)
+  const void* extra;         // forward: residual; backward: addend — [M][Ncols] halfs (NULL = none)
+  const uint32_t* bits_in;   // backward: activation mask of the layer input, [M][Ncols / 32] (NULL = none)
+  uint32_t* bits_out;        // forward: activation mask of y to write (NULL = none)
+  void* out;                 // [M][Ncols] halfs, or floats when out_f32
+  int out_f32;
+  float mul;                 // accumulator multiplier (backward: 1)
+};
+
+template <int DT, int TM, int TN>
+__device__ __forceinline__ void hs_mma_stage(const typename HT<DT>::T* __restrict__ As,
+                                             const typename HT<DT>::T* __restrict__ Bs, f32x16 (&acc)[TM][TN],
+                                             int a_off, int b_off, int lane) {
+  typedef typename HT<DT>::V8 V8;
+  const int l31 = lane & 31, kh = 8 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < HS_BK / 16; ++s) {
+    V8 a[TM], b[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const V8*>(&As[(a_off + t * 32 + l31) * HS_LD + s * 16 + kh]);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const V8*>(&Bs[(b_off + t * 32 + l31) * HS_LD + s * 16 + kh]);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[tm], b[tn], acc[tm][tn]);
+  }
+}
+
+template <int DT, int BM, int BN>
+struct hs_smem {
+  static constexpr int stage = 2 * (BM + BN) * HS_LD / 2, epi = BM * (BN + 4);      // floats
+  static constexpr int floats = stage > epi ? stage : epi;
+};
+
+// BWD = false: forward (A = x, rows of B = output channels of w_fwd);  BWD = true: backward data (A = g, rows of B = input
+// channels of w_bwd).  Needs (reduction channels) % 64 == 0 and (output channels) % 8 == 0.
+template <int DT, int BM, int BN, bool BWD>
+__global__ void __launch_bounds__(256, 2)
+k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typename HT<DT>::T* __restrict__ B,
+          hs_epilogue e) {
+  typedef typename HT<DT>::T HTT;
+  typedef typename HT<DT>::V8 V8;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32, BJ = BN / 32;
+  constexpr int A_SZ = BM * HS_LD, B_SZ = BN * HS_LD;
+  constexpr int LDC = BN + 4;
+  __shared__ __attribute__((aligned(16))) float smem[hs_smem<DT, BM, BN>::floats];
+  HTT* const As = reinterpret_cast<HTT*>(smem);       // [2][BM][HS_LD]
+  HTT* const Bs = As + 2 * A_SZ;                      // [2][BN][HS_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = BWD ? d.N * d.H * d.W : d.N * d.OH * d.OW;
+  const int KR = BWD ? d.K : d.C;                     // reduction channels per tap
+  const int NC = BWD ? d.C : d.K;                     // output channels
+  const int RS = d.R * d.S;
+  const int tiles_n = (NC + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int KC = KR / HS_BK, KT = RS * KC;
+  const int kq = tid & 7, arow = tid >> 3;            // 16-byte piece of a row, row (mod 32)
+  // ---- A rows: output pixels (forward) / input pixels (backward)
+  const int PW = BWD ? d.W : d.OW, PH = BWD ? d.H : d.OH;
+  int a_n[AJ], a_h0[AJ], a_w0[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int p = m0 + arow + 32 * j;
+    if (p < M) {
+      const int t = p / PW, pw = p - t * PW;
+      a_n[j] = t / PH;
+      const int ph = t - a_n[j] * PH;
+      a_h0[j] = BWD ? ph + d.pad_top : ph * d.stride - d.pad_top;
+      a_w0[j] = BWD ? pw + d.pad_left : pw * d.stride - d.pad_left;
+    } else { a_n[j] = -1; a_h0[j] = 0; a_w0[j] = 0; }
+  }
+  const HTT* const zero = reinterpret_cast<const HTT*>(lmh_zero_page);
+  const HTT* pa[AJ];
+  int inca[AJ];
+  auto setup_tap = [&](int rs_) {
+    const int r_ = rs_ / d.S, s_ = rs_ - r_ * d.S;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      bool ok = a_n[j] >= 0;
+      size_t off;
+      if (BWD) {
+        const int th = a_h0[j] - r_ * d.dilation, tw = a_w0[j] - s_ * d.dilation;
+        int oh = th, ow = tw;
+        ok = ok && th >= 0 && tw >= 0;
+        if (d.stride > 1) {
+          oh = th / d.stride; ow = tw / d.stride;
+          ok = ok && (oh * d.stride == th) && (ow * d.stride == tw);
+        }
+        ok = ok && oh < d.OH && ow < d.OW;
+        off = ((size_t)(a_n[j] * d.OH + oh) * d.OW + ow) * KR;
+      } else {
+        const int ih = a_h0[j] + r_ * d.dilation, iw = a_w0[j] + s_ * d.dilation;
+        ok = ok && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+        off = ((size_t)(a_n[j] * d.H + ih) * d.W + iw) * KR;
+      }
+      pa[j] = ok ? A + off + 8 * kq : zero;
+      inca[j] = ok ? HS_BK : 0;
+    }
+  };
+  // ---- B rows: forward w_fwd[k][tap][c] (taps follow each other inside a row); backward w_bwd[tap][c][k]
+  const HTT* pb[BJ];
+  int incb[BJ];
+  size_t tapb[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int row = n0 + arow + 32 * j;
+    const bool ok = row < NC;
+    pb[j] = ok ? B + (size_t)row * (BWD ? (size_t)KR : (size_t)RS * KR) + 8 * kq : zero;
+    incb[j] = ok ? HS_BK : 0;
+    tapb[j] = ok ? (BWD ? (size_t)NC * KR - KR + HS_BK : (size_t)HS_BK) : 0;
+  }
+  V8 ra[AJ], rb[BJ];
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  int rs = 0, kc = 0, ptile = 0;
+  setup_tap(0);
+  auto step = [&]() {
+    if (ptile + 1 >= KT) return;
+    ++ptile;
+    if (++kc == KC) {
+      kc = 0; ++rs;
+      setup_tap(rs);
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) pb[j] += tapb[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) pa[j] += inca[j];
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) pb[j] += incb[j];
+    }
+  };
+  auto load = [&](auto) {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const V8*>(pa[j]);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const V8*>(pb[j]);
+  };
+  auto store = [&](int buf, auto) {
+    HTT* Ad = As + buf * A_SZ;
+    HTT* Bd = Bs + buf * B_SZ;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) *reinterpret_cast<V8*>(&Ad[(arow + 32 * j) * HS_LD + 8 * kq]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) *reinterpret_cast<V8*>(&Bd[(arow + 32 * j) * HS_LD + 8 * kq]) = rb[j];
+  };
+  auto mma = [&](int buf) {
+    hs_mma_stage<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+  };
+  HALF_PIPELINE(1, KT);
+  // ---- epilogue through LDS: a thread owns 8 consecutive output channels of a row (one 16-byte half store)
+  constexpr int CT = BN / 8, RSTEP = 256 / CT;
+  const int c8 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 8 * c8;
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  if (col < NC) {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc[i] = (!BWD && e.scale) ? e.scale[col + i] : 1.f;
+      sh[i] = (!BWD && e.shift) ? e.shift[col + i] : 0.f;
+    }
+    const float act_lo = (!BWD && d.act) ? 0.f : -INFINITY, act_hi = (!BWD && d.act == 2) ? 6.f : INFINITY;
+    const int words = NC >> 5, wcol = col >> 5, bsh = 8 * (c8 & 3);
+    for (int r = r0; r < BM; r += RSTEP) {
+      const int row = m0 + r;
+      if (row >= M) break;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 8 * c8]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 8 * c8 + 4]);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const size_t o = (size_t)row * NC + col;
+      if (BWD) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= e.mul;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+      }
+      if (e.extra) {
+        const V8 x8 = *reinterpret_cast<const V8*>(reinterpret_cast<const HTT*>(e.extra) + o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += (float)x8[i];
+      }
+      if (BWD) {
+        if (e.bits_in) {
+          const uint32_t m = e.bits_in[(size_t)row * words + wcol] >> bsh;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = ((m >> i) & 1u) ? v[i] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(v[i], act_lo), act_hi);
+      }
+      if (e.out_f32) {
+        float* yo = reinterpret_cast<float*>(e.out) + o;
+        *reinterpret_cast<f32x4*>(yo) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(yo + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        V8 h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (HTT)v[i];
+        *reinterpret_cast<V8*>(reinterpret_cast<HTT*>(e.out) + o) = h;
+        // the mask follows the STORED value: a positive sum that rounds to zero (f16 underflow) is a dead unit for
+        // the next layer and for the backward pass alike
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+      }
+      if (!BWD && e.bits_out) {   // 4 adjacent lanes hold the 32 channels of one mask word (same row: active together)
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m |= ((v[i] > 0.f && v[i] < act_hi) ? 1u : 0u) << i;
+        m <<= bsh;
+        m |= __shfl_xor(m, 1);
+        m |= __shfl_xor(m, 2);
+        if ((c8 & 3) == 0) e.bits_out[(size_t)row * words + wcol] = m;
+      }
+    }
+  }
+}
+
+// 4 (pixel) x 4 (channel) block of halfs, one uint2 per pixel -> four k-contiguous quads (one per channel)
+__device__ __forceinline__ uint32_t hs_pack_lo(uint32_t e0, uint32_t e1) { return __builtin_amdgcn_perm(e1, e0, 0x05040100u); }
+template <typename HTT>
+__device__ __forceinline__ void hs_st_km(HTT* __restrict__ S, int col0, int kq4, const uint2 (&r)[4]) {
+  *reinterpret_cast<uint2*>(&S[(col0 + 0) * LDH + 4 * kq4]) = make_uint2(hs_pack_lo(r[0].x, r[1].x), hs_pack_lo(r[2].x, r[3].x));
+  *reinterpret_cast<uint2*>(&S[(col0 + 1) * LDH + 4 * kq4]) = make_uint2(pack_hi(r[0].x, r[1].x), pack_hi(r[2].x, r[3].x));
+  *reinterpret_cast<uint2*>(&S[(col0 + 2) * LDH + 4 * kq4]) = make_uint2(hs_pack_lo(r[0].y, r[1].y), hs_pack_lo(r[2].y, r[3].y));
+  *reinterpret_cast<uint2*>(&S[(col0 + 3) * LDH + 4 * kq4]) = make_uint2(pack_hi(r[0].y, r[1].y), pack_hi(r[2].y, r[3].y));
+}
+
+// backward weight:  dw[rs][c][k] = inv_scale * sum_p x[pix(p,r,s)][c] * g[p][k]  (fp32, RAW: w.r.t. the un-scaled
+// convolution output, like every other weight-gradient kernel here); split over the pixels, slabs reduced by
+// k_splitk_reduce.  colpart [splits][K]: partial per-channel sums of g (already multiplied by inv_scale).
+template <int DT, int BM, int BN>
+__global__ void __launch_bounds__(256, 2)
+k_conv_bwd_weight_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const typename HT<DT>::T* __restrict__ g,
+                     float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh, float inv_scale,
+                     int tiles_x, int tiles_y, int splits, float* __restrict__ colpart) {
+  typedef typename HT<DT>::T HTT;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
+  constexpr int LDC = BN + 4;
+  __shared__ __attribute__((aligned(16))) float smem[half_smem<DT, BM, BN, 1>::floats];
+  HTT* const As = reinterpret_cast<HTT*>(smem);
+  HTT* const Bs = As + 2 * A_SZ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int P = d.N * d.OH * d.OW, K = d.K, C = d.C;
+  const int lin = xcd_remap(blockIdx.x, tiles_x * tiles_y * splits);
+  const int bz = lin / (tiles_x * tiles_y), rem = lin - bz * (tiles_x * tiles_y);
+  const int tiles_c = (C + BM - 1) / BM;
+  const int by = rem / tiles_x, bx = rem - by * tiles_x;
+  const int rs = bx / tiles_c, m0 = (bx % tiles_c) * BM;
+  const int n0 = by * BN;
+  const int r = rs / d.S, s = rs - r * d.S;
+  const int KT_all = (P + BK - 1) / BK;
+  const int kt_begin = bz * kt_per_split;
+  const int kt_end = min(KT_all, kt_begin + kt_per_split);
+  const int dh0 = r * d.dilation - d.pad_top, dw0 = s * d.dilation - d.pad_left;
+  const int kq = tid & 7, cq = tid >> 3;
+  const bool a_act = cq < BM / 4, b_act = cq < BN / 4;
+  const bool a_ok = a_act && (m0 + 4 * cq) < C, b_ok = b_act && (n0 + 4 * cq) < K;
+  const HTT* xb = x + m0 + 4 * cq;
+  const HTT* gb = g + n0 + 4 * cq;
+  const HTT* const zero = reinterpret_cast<const HTT*>(lmh_zero_page);
+  int p0 = kt_begin * BK + 4 * kq;
+  uint2 ra[4], rb[4];
+  auto step = [&]() { p0 += BK; };
+  auto load = [&](auto) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned p = (unsigned)(p0 + i);
+      const unsigned t = lmh_div(p, div_ow), ow = p - t * (unsigned)d.OW;
+      const unsigned n = lmh_div(t, div_oh), oh = t - n * (unsigned)d.OH;
+      const int ih = (int)oh * d.stride + dh0, iw = (int)ow * d.stride + dw0;
+      const bool oka = a_ok && n < (unsigned)d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+      const HTT* pa_ = oka ? xb + ((size_t)((int)n * d.H + ih) * d.W + iw) * C : zero;
+      if (a_act) ra[i] = *reinterpret_cast<const uint2*>(pa_);
+      const bool okb = b_ok && (int)p < P;
+      const HTT* pb_ = okb ? gb + (size_t)p * K : zero;
+      if (b_act) rb[i] = *reinterpret_cast<const uint2*>(pb_);
+    }
+  };
+  auto store = [&](int buf, auto) {
+    if (a_act) hs_st_km<HTT>(As + buf * A_SZ, 4 * cq, kq, ra);
+    if (b_act) hs_st_km<HTT>(Bs + buf * B_SZ, 4 * cq, kq, rb);
+  };
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  const bool do_col = colpart != nullptr && bx == 0 && tid < BN;      // tap 0, first channel tile: one tile column
+  float csum = 0.f;
+  auto mma = [&](int buf) {
+    if (do_col) {
+      const HTT* row = Bs + buf * B_SZ + tid * LDH;
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q) {
+        const typename HT<DT>::V8 v = *reinterpret_cast<const typename HT<DT>::V8*>(row + 8 * q);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) csum += (float)v[i];
+      }
+    }
+    mfma_stage_h<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane, A_SZ, B_SZ);
+  };
+  const int n_st = kt_end - kt_begin;
+  HALF_PIPELINE(1, n_st);
+  if (do_col && n0 + tid < K) colpart[(size_t)bz * K + n0 + tid] = csum * inv_scale;
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  float* o = out + (size_t)bz * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;
+  constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  const int c4 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 4 * c4;
+  if (col < K) {
+    for (int rr = r0; rr < BM; rr += RSTEP) {
+      const int row = m0 + rr;
+      if (row >= C) break;
+      *reinterpret_cast<f32x4*>(o + (size_t)row * K + col) = *reinterpret_cast<const f32x4*>(&smem[rr * LDC + 4 * c4]) * inv_scale;
+    }
+  }
+}

@@ -531,7 +531,115 @@ def bn_param_grads(w, dw_raw, dbeta, mean, rstd, scale, out=None):
     return dgamma
 
 
-def maxpool_fwd(x, ksize, stride, padding='SAME'):
+# ------------------------------------------------- half-storage convolutions ----
+# f16 / bf16 tensors in HBM (include/luminoth_hip.h "Half-STORAGE convolution path", csrc/conv_hs.h): BASELINE configs[4].
+_HALF = {'f16': (1, torch.float16), 'bf16': (2, torch.bfloat16)}
+
+
+def half_type(storage):
+    return _HALF[storage]
+
+
+def half_type_of(t):
+    for code, tdt in _HALF.values():
+        if t.dtype == tdt:
+            return code, tdt
+    raise _lib.LuminothHipError('not a half-storage tensor: %s' % t.dtype)
+
+
+def _half(t, tdt):
+    assert t.dtype == tdt, (t.dtype, tdt)
+    return t
+
+
+def conv_hs_ok(d):
+    return bool(_lib.load().lmh_conv2d_hs_supported(ctypes.byref(d)))
+
+
+def half_weights_batch(jobs, storage):
+    """jobs: [(w (R,S,C,K) fp32, kscale (K,) or None, w_fwd half (K,R,S,C) or None, w_bwd half (R,S,C,K) or None)]: the
+    working copies of every layer in one launch (per 48 layers)."""
+    if not jobs:
+        return
+    code, tdt = half_type(storage)
+    arr = (_lib.HalfWeightJob * len(jobs))()
+    for i, (w, ks, wf, wb) in enumerate(jobs):
+        arr[i].w = _f32(w).data_ptr()
+        arr[i].kscale = ks.data_ptr() if ks is not None else None
+        arr[i].w_fwd = _half(wf, tdt).data_ptr() if wf is not None else None
+        arr[i].w_bwd = _half(wb, tdt).data_ptr() if wb is not None else None
+        arr[i].RS, arr[i].C, arr[i].K = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
+    check(_lib.load().lmh_half_weights_batch(arr, len(jobs), code, _stream()), 'lmh_half_weights_batch')
+
+
+def cast_to_half(x, storage, mul=1.0, bits=None):
+    code, tdt = half_type(storage)
+    C = x.shape[-1]
+    y = torch.empty(x.shape, dtype=tdt, device=x.device)
+    check(_lib.load().lmh_cast_to_half(_p(_f32(x)), x.numel() // C, C, float(mul), _p(bits), _p(y), code, _stream()),
+          'lmh_cast_to_half')
+    return y
+
+
+def cast_to_f32(x, mul=1.0):
+    code, _ = half_type_of(x)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(_lib.load().lmh_cast_to_f32(_p(x), x.numel(), float(mul), _p(y), code, _stream()), 'lmh_cast_to_f32')
+    return y
+
+
+def conv2d_fwd_hs(d, x, w_fwd, scale=None, shift=None, residual=None, out_f32=False, act_bits=None):
+    code, tdt = half_type_of(x)
+    assert code == d.compute, (code, d.compute)
+    y = torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32 if out_f32 else tdt, device=x.device)
+    with _timed(d, 0):
+        check(_lib.load().lmh_conv2d_fwd_hs(ctypes.byref(d), _p(x), _p(_half(w_fwd, tdt)), _p(scale), _p(shift),
+                                            _p(None if residual is None else _half(residual, tdt)), _p(y), int(bool(out_f32)),
+                                            _p(act_bits), _stream()), 'lmh_conv2d_fwd_hs')
+    return y
+
+
+def conv2d_bwd_data_hs(d, g, w_bwd, addend=None, xbits=None):
+    code, tdt = half_type_of(g)
+    assert code == d.compute, (code, d.compute)
+    dx = torch.empty((d.N, d.H, d.W, d.C), dtype=tdt, device=g.device)
+    with _timed(d, 1):
+        check(_lib.load().lmh_conv2d_bwd_data_hs(ctypes.byref(d), _p(g), _p(_half(w_bwd, tdt)),
+                                                 _p(None if addend is None else _half(addend, tdt)), _p(xbits), _p(dx),
+                                                 _stream()), 'lmh_conv2d_bwd_data_hs')
+    return dx
+
+
+def conv2d_bwd_weight_hs(d, x, g, inv_scale, out=None, colsum=None, defer=None):
+    """fp32 RAW weight gradient of half tensors x, g (g carries the loss scale 1 / inv_scale); colsum, defer: as
+    conv2d_bwd_weight."""
+    lib = _lib.load()
+    code, tdt = half_type_of(x)
+    assert code == d.compute and g.dtype == tdt, (code, d.compute, g.dtype)
+    defer = defer if (defer is not None and TAILS.active and d.K % 4 == 0 and d.K <= 4096) else None
+    dw = out if out is not None else torch.empty((d.R, d.S, d.C, d.K), dtype=torch.float32, device=x.device)
+    nbytes = lib.lmh_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
+    ws = _workspace(nbytes, x.device, 'bwd_weight' if defer is None else ('wgslab', defer))
+    if defer is not None:
+        lib.lmh_tail_defer(1)
+    try:
+        with _timed(d, 2):
+            check(lib.lmh_conv2d_bwd_weight_hs(ctypes.byref(d), _p(x), _p(g), float(inv_scale), _p(_f32(dw)), _p(colsum), _p(ws),
+                                               ctypes.c_size_t(ws.numel()), _stream()), 'lmh_conv2d_bwd_weight_hs')
+        if defer is not None:
+            slabs, splits, colpart, colrows = _last_plan()
+            e = TAILS.entry(defer)
+            e.update(dw=dw, slabs=slabs, splits=splits, _ws=ws)
+            if colsum is not None and colrows:
+                e.update(colpart=colpart, colrows=colrows, colsum=colsum)
+    finally:
+        if defer is not None:
+            lib.lmh_tail_defer(0)
+    return dw
+
+
+def maxpool_fwd(x, ksize, stride, padding='SAME', storage=None):
+    """storage 'f16' / 'bf16': the result is a half tensor (x fp32 or that half type) — half-storage trunk."""
     lib = _lib.load()
     N, H, W, C = x.shape
     if padding == 'SAME':
@@ -539,6 +647,13 @@ def maxpool_fwd(x, ksize, stride, padding='SAME'):
         OW, pl = same_pads(W, ksize, stride)
     else:
         OH, OW, pt, pl = (H - ksize) // stride + 1, (W - ksize) // stride + 1, 0, 0
+    if storage is not None or x.dtype != torch.float32:
+        code, tdt = half_type(storage) if storage is not None else half_type_of(x)
+        assert x.dtype in (torch.float32, tdt), (x.dtype, tdt)
+        y = torch.empty((N, OH, OW, C), dtype=tdt, device=x.device)
+        check(lib.lmh_maxpool_fwd_hs(_p(x), int(x.dtype == torch.float32), N, H, W, C, ksize, stride, pt, pl, OH, OW, _p(y),
+                                     code, _stream()), 'lmh_maxpool_fwd_hs')
+        return y, (pt, pl, OH, OW)
     y = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
     check(lib.lmh_maxpool_fwd(_p(x), N, H, W, C, ksize, stride, pt, pl, OH, OW, _p(y), _stream()),
           'lmh_maxpool_fwd')
@@ -564,6 +679,13 @@ def maxpool_bwd(x, y, dy, ksize, stride, geom):
     lib = _lib.load()
     N, H, W, C = x.shape
     pt, pl, OH, OW = geom
+    if dy.dtype != torch.float32:           # half storage: only the 1x1 subsample of a bottleneck shortcut has a backward
+        if ksize != 1:
+            raise NotImplementedError('half-storage max-pool backward: 1x1 subsample only (the 3x3 pool of the ResNet '
+                                      'stem is in the frozen prefix)')
+        dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+        check(lib.lmh_subsample_bwd_hs(_p(dy), N, H, W, C, stride, OH, OW, _p(dx), _stream()), 'lmh_subsample_bwd_hs')
+        return dx
     dx = torch.zeros_like(x)
     check(lib.lmh_maxpool_bwd(_p(x), _p(y), _p(dy), N, H, W, C, ksize, stride, pt, pl, OH, OW, _p(dx),
                               _stream()), 'lmh_maxpool_bwd')

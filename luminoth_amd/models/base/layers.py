@@ -22,6 +22,10 @@ FUSE_ACT = os.environ.get('LUMINOTH_AMD_FUSE_ACT', '0') == '1'
 # streaming pass.  The bit mask is 2 KB per tile and is requested before the accumulator transpose.
 FUSE_MASK = os.environ.get('LUMINOTH_AMD_FUSE_MASK', '1') == '1'
 BN_EPS = 1e-5  # slim resnet_arg_scope batch_norm_epsilon (truncated_base_network.py:69-73)
+# Half-STORAGE trunk (BASELINE configs[4], csrc/conv_hs.h): layers with `storage` 'f16' / 'bf16' keep their activations,
+# activation gradients and working weight copies as 16-bit tensors.  Activation gradients carry a static loss scale (f16
+# has 5 exponent bits: gradients of 1e-7 would flush); the weight-gradient kernels divide it out of their fp32 sums.
+HS_LOSS_SCALE = {'f16': 1024.0, 'bf16': 1.0}
 
 
 # Called by Trunk.backward as hook(nodes, j) once node j's backward (data + weight gradients) is enqueued, and as
@@ -79,6 +83,10 @@ class ConvLayer(object):
         self.trainable = True
         self.compute = None       # MFMA operand arithmetic: None = fp32; 'f16' / 'bf16' = mixed precision (conv_half.h)
         self.compute_wgrad = 'same'   # arithmetic of the weight-gradient GEMM alone ('same' = self.compute)
+        self.storage = None       # 'f16' / 'bf16': half tensors in HBM (then compute is the same type)
+        self.hs_out_f32 = False   # half-storage layer whose OUTPUT is handed on as fp32 (top of the trunk)
+        self.wh = [None, None]    # working copies of the weights: [K,R,S,C] q(w), [R,S,C,K] q(w * bn_scale)
+        self._wh_ready = False
         self.w_name = '%s/%s' % (scope, weight_name)
         self.b_name = '%s/%s' % (scope, bias_name)
         self._desc = {}
@@ -132,6 +140,14 @@ class ConvLayer(object):
         bits = None
         if want_bits and FUSE_MASK and K.act_bits_ok(self.cout, self.act):
             bits = K.new_act_bits(d.N * d.OH * d.OW, self.cout, x.device)
+        if x.dtype != torch.float32:            # half-storage layer
+            assert self.storage is not None and in_sub is None, (self.scope, x.dtype)
+            if not self._wh_ready:
+                prepare_half_weights([self], self.storage)
+            y = K.conv2d_fwd_hs(d, x, self.wh[0], self.scale, self.shift, residual, out_f32=self.hs_out_f32, act_bits=bits)
+            if ACT_TAP is not None:
+                ACT_TAP[self.scope] = y
+            return (y, bits) if want_bits else y
         # a training forward of a trainable Winograd layer keeps B^T x B for its weight gradient (kernels.py)
         y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub, act_bits=bits,
                          keep_v=(want_bits or keep_v) and self.trainable,
@@ -144,7 +160,10 @@ class ConvLayer(object):
         if self.compute_wgrad != 'same':
             d = self.desc(x.shape, wgrad=True)
         key = self.w_name if (K.TAILS.active and self.cout % 4 == 0 and self.cout <= 4096) else None
-        K.conv2d_bwd_weight(d, x, g, out=self.gw, yact=yact, colsum=colsum, defer=key)
+        if x.dtype != torch.float32:
+            K.conv2d_bwd_weight_hs(d, x, g, 1.0 / HS_LOSS_SCALE[self.storage], out=self.gw, colsum=colsum, defer=key)
+        else:
+            K.conv2d_bwd_weight(d, x, g, out=self.gw, yact=yact, colsum=colsum, defer=key)
         if self.norm == 'bn':
             if key is not None:        # queued: reduction + BN scaling + dgamma + dbeta happen in TAILS.flush()
                 e = K.TAILS.entry(key)
@@ -174,7 +193,15 @@ class ConvLayer(object):
         mask_bits: activation bit mask of x (written by the forward kernel of the layer that produced x): the
         returned dx is then dx * act'(x), i.e. THAT layer's g (applied in the bwd_data epilogue)."""
         d = self.desc(x.shape)
-        act_fused, colsum_fused = self._fused_ok(d, tuple(x.shape))
+        hs = x.dtype != torch.float32
+        if hs:
+            # half storage: the gradient arrives as g (masked by the producer's epilogue or by the trunk's entry cast) in
+            # the same 16-bit type, times the loss scale; the channel sums come out of the weight-gradient kernel
+            if not (dy_is_g or not self.act) or dy.dtype != x.dtype:
+                raise NotImplementedError('%s: half-storage backward needs the masked half gradient (FUSE_MASK on)' % self.scope)
+            act_fused, colsum_fused = False, True
+        else:
+            act_fused, colsum_fused = self._fused_ok(d, tuple(x.shape))
         colsum = None
         if self.trainable:
             if self.norm == 'bn':
@@ -196,10 +223,16 @@ class ConvLayer(object):
         if self.trainable:
             SideStream.layers_left -= 1
         dx = None
+        def data_grad():
+            if hs:
+                if not self._wh_ready:
+                    prepare_half_weights([self], self.storage)
+                return K.conv2d_bwd_data_hs(d, g, self.wh[1], addend=addend, xbits=mask_bits)
+            return K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
+                                     addend=addend, yact=yact, xbits=mask_bits,
+                                     wino_u=self._wino_u[1] if self._wino_ready[1] else None)
         if inline and need_dx:        # tail of the backward: data gradient first, weight gradients behind it
-            dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
-                                   addend=addend, yact=yact, xbits=mask_bits,
-                                   wino_u=self._wino_u[1] if self._wino_ready[1] else None)
+            dx = data_grad()
         if self.trainable:
             cs = colsum if colsum_in_wgrad else None
             if SideStream.enabled and not inline:
@@ -213,10 +246,29 @@ class ConvLayer(object):
             else:
                 self._weight_grads(d, x, g, yact, cs)
         if need_dx and not inline:
-            dx = K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
-                                   addend=addend, yact=yact, xbits=mask_bits,
-                                   wino_u=self._wino_u[1] if self._wino_ready[1] else None)
+            dx = data_grad()
         return dx, (g if yact is None else None)
+
+
+def prepare_half_weights(layers, storage):
+    """One launch for the 16-bit working copies of every half-storage layer in `layers` (forward copy q(w) laid out
+    [K][R][S][C], backward copy q(w * bn_scale) in HWIO) from the fp32 master weights and the current BatchNorm scales:
+    the cast pass of the optimizer step.  The copies are used until release_half_weights."""
+    jobs = []
+    _, tdt = K.half_type(storage)
+    for l in layers:
+        if l.wh[0] is None:
+            l.wh[0] = torch.empty((l.cout, l.k, l.k, l.cin), dtype=tdt, device=l.w.device)
+            l.wh[1] = torch.empty((l.k, l.k, l.cin, l.cout), dtype=tdt, device=l.w.device)
+        jobs.append((l.w, l.scale if l.norm == 'bn' else None, l.wh[0], l.wh[1]))
+    K.half_weights_batch(jobs, storage)
+    for l in layers:
+        l._wh_ready = True
+
+
+def release_half_weights(layers):
+    for l in layers:
+        l._wh_ready = False
 
 
 def winograd_candidates(layers):
@@ -359,6 +411,7 @@ class MaxPoolNode(object):
 
     def __init__(self, ksize, stride, padding):
         self.k, self.s, self.p = ksize, stride, padding
+        self.storage = None       # 'f16' / 'bf16': the result is a half tensor (first node of a half-storage trunk)
 
     def out_hw(self, h, w):
         if self.p == 'SAME':
@@ -366,7 +419,7 @@ class MaxPoolNode(object):
         return (h - self.k) // self.s + 1, (w - self.k) // self.s + 1
 
     def forward(self, x, save):
-        y, geom = K.maxpool_fwd(x, self.k, self.s, self.p)
+        y, geom = K.maxpool_fwd(x, self.k, self.s, self.p, storage=self.storage)
         return y, ((x, y, geom) if save else None)
 
     @staticmethod
@@ -474,6 +527,14 @@ class Trunk(object):
     def backward(self, saved, dy, save_from, need_dx_first=False):
         nodes = self.nodes[save_from:]
         dy_is_g = False
+        storage = next((l.storage for n in nodes[::-1] for l in n.layers if l.storage), None)
+        if storage is not None and dy.dtype == torch.float32:
+            # entry of a half-storage trunk: gradient of the fp32 feature map -> g of the top node, times the loss scale
+            top = nodes[-1].out_bits(saved[-1]) if FUSE_MASK else None
+            if nodes[-1].out_act and top is None:
+                raise NotImplementedError('half-storage trunk backward needs the activation bit masks (FUSE_MASK on)')
+            dy = K.cast_to_half(dy, storage, mul=HS_LOSS_SCALE[storage], bits=top)
+            dy_is_g = True
         hook = BACKWARD_HOOK        # data-parallel gradient buckets (utils/training.py); None on one GPU
         if hook is not None:
             hook(nodes, len(nodes))
@@ -489,4 +550,6 @@ class Trunk(object):
             elif j > 2:
                 K.TAILS.maybe_flush_early()
         SideStream.layers_left = 0
+        if dy is not None and dy.dtype != torch.float32:
+            dy = K.cast_to_f32(dy, 1.0 / HS_LOSS_SCALE[storage])
         return dy

@@ -83,11 +83,39 @@ class TruncatedBaseNetwork(BaseNetwork):
         # extension key: model.base_network.compute_dtype in {None, 'f32', 'f16', 'bf16'} — half-precision MFMA
         # operands with fp32 accumulation for every backbone / tail convolution (BASELINE configs[4])
         self.compute_dtype = config.get('compute_dtype')
+        if config.get('storage_dtype') in ('f16', 'bf16') and self.compute_dtype in (None, 'f32', 'fp32', 'float32'):
+            self.compute_dtype = config.get('storage_dtype')         # half storage implies half MFMA operands
         if self.compute_dtype not in (None, 'f32', 'fp32', 'float32'):
             if self.compute_dtype not in K_COMPUTE:
                 raise ValueError('Invalid compute_dtype: "{}"'.format(self.compute_dtype))
             for layer in self._creation_order_layers() + (self.tail.all_layers() if self.tail else []):
                 layer.compute = self.compute_dtype
+        # extension key: model.base_network.storage_dtype in {None, 'f16', 'bf16'} — the trunk keeps its activations,
+        # activation gradients and working weight copies as 16-bit tensors in HBM (csrc/conv_hs.h; SURVEY.md 8(d) config 5:
+        # "fp16 activations/weights with fp32 accumulate + fp32 master weights").  The fp32 stem convolution feeds a
+        # max-pool that writes the half tensor; the last trunk layer hands the feature map on as fp32.
+        self.storage_dtype = config.get('storage_dtype')
+        self._hs_layers = []
+        if self.storage_dtype not in (None, 'f32', 'fp32', 'float32'):
+            if self.storage_dtype not in ('f16', 'bf16'):
+                raise ValueError('Invalid storage_dtype: "{}"'.format(self.storage_dtype))
+            if K_COMPUTE[self.compute_dtype] != K_COMPUTE[self.storage_dtype]:
+                raise ValueError('storage_dtype "{}" needs the same compute_dtype (got "{}")'.format(
+                    self.storage_dtype, self.compute_dtype))
+            if not self.resnet_v1_type or (self.tail is not None and self._use_tail):
+                raise NotImplementedError('storage_dtype: implemented for the resnet_v1 trunks without the block4 tail '
+                                          '(BASELINE configs[4] is ResNet-50)')
+            nodes = self.trunk.nodes
+            if not (isinstance(nodes[1], L.MaxPoolNode) and all(isinstance(n, L.BottleneckNode) for n in nodes[2:])):
+                raise NotImplementedError('storage_dtype: unexpected trunk structure')
+            nodes[1].storage = self.storage_dtype
+            for n in nodes[2:]:
+                for layer in n.layers:
+                    if layer.cin % 64 or layer.cout % 64:
+                        raise NotImplementedError('storage_dtype: channel counts must be multiples of 64 (%s)' % layer.scope)
+                    layer.compute = layer.storage = self.storage_dtype
+                    self._hs_layers.append(layer)
+            nodes[-1].conv3.hs_out_f32 = True
 
     # ---- variables --------------------------------------------------------------
     def _creation_order_layers(self):
@@ -189,6 +217,8 @@ class TruncatedBaseNetwork(BaseNetwork):
             self._bn_fresh = False            # the caller refreshed the table itself (FasterRCNN._train_step)
         else:
             self.bn_table.refresh()
+        if self._hs_layers:
+            L.prepare_half_weights(self._hs_layers, self.storage_dtype)      # the weights may have changed since the last call
         return self._run(self.trunk, inputs.contiguous(), is_training)
 
     @property

@@ -47,6 +47,73 @@ class QuantConvFn(torch.autograd.Function):
         return dx / s, dw / s, None, None, None
 
 
+def _conv_pads(H, W, R, S, stride, dilation, padding):
+    if padding == 'SAME':
+        pt, pb = tf_same_pad(H, R, stride, dilation)
+        pl, pr = tf_same_pad(W, S, stride, dilation)
+    elif padding == 'SAME_EXPLICIT':  # slim resnet_utils.conv2d_same
+        ke_h, ke_w = (R - 1) * dilation + 1, (S - 1) * dilation + 1
+        pt, pl = (ke_h - 1) // 2, (ke_w - 1) // 2
+        pb, pr = ke_h - 1 - pt, ke_w - 1 - pl
+    else:
+        pt = pb = pl = pr = 0
+    return pt, pb, pl, pr
+
+
+class HalfStorageConvFn(torch.autograd.Function):
+    """One layer of the half-STORAGE trunk (luminoth_amd/csrc/conv_hs.h; BASELINE configs[4]) restated: 16-bit tensors in
+    memory, fp32 accumulation, conv + frozen-BatchNorm affine (+ residual) (+ ReLU) fused, the result rounded when stored:
+        forward    y  = q( act( conv(x, q(w)) * scale + shift + residual ) )           (unrounded when out_f32)
+        backward   G  = q( S * dy * act'(y) )                   the 16-bit gradient tensor the kernels hold (S = loss scale)
+                   dx = conv^T(G, q(w * scale)) / S             (rounded like G when `round_dx`: a shortcut convolution's
+                                                                 data gradient is stored on its own before it is added)
+                   dw = corr(x, G) / S * scale,  dscale = sum G * conv / S,  dshift = sum G / S,  dresidual = G / S
+    x and residual are expected to hold half-representable values already (outputs of other half-storage layers).
+    `yk`: that layer's output as the kernels computed it (ReLU branch decisions, oracle/model.py `masks`), or None."""
+
+    @staticmethod
+    def forward(ctx, x, w_hwio, scale, shift, residual, yk, cfg):
+        quant, stride, dil = cfg['quant'], cfg['stride'], cfg['dilation']
+        R, S_ = w_hwio.shape[0], w_hwio.shape[1]
+        pads = _conv_pads(x.shape[1], x.shape[2], R, S_, stride, dil, cfg['padding'])
+        pt, pb, pl, pr = pads
+        xp = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+        z = F.conv2d(xp, _q(w_hwio, quant).permute(3, 2, 0, 1), stride=stride, dilation=dil).permute(0, 2, 3, 1)
+        pre = z * scale + shift
+        if residual is not None:
+            pre = pre + residual
+        if cfg['act'] == 'relu':
+            stored = torch.relu(pre) if cfg['out_f32'] else _q(torch.relu(pre), quant)
+            mask = ((torch.as_tensor(yk).reshape(pre.shape) if yk is not None else stored) > 0).to(pre.dtype)
+            y = pre * mask
+        else:
+            assert not cfg['act'], cfg['act']
+            mask = torch.ones_like(pre)
+            y = pre
+        if not cfg['out_f32']:
+            y = _q(y, quant)
+        ctx.save_for_backward(xp, w_hwio, scale, z, mask)
+        ctx.cfg, ctx.pads, ctx.has_res = cfg, pads, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, w_hwio, scale, z, mask = ctx.saved_tensors
+        cfg = ctx.cfg
+        quant, stride, dil, S = cfg['quant'], cfg['stride'], cfg['dilation'], cfg['loss_scale']
+        pt, pb, pl, pr = ctx.pads
+        G = _q(dy * mask * S, quant)
+        Gt = G.permute(0, 3, 1, 2).contiguous()
+        wb = _q(w_hwio * scale, quant).permute(3, 2, 0, 1).contiguous()
+        dxp, dwt, _ = torch.ops.aten.convolution_backward(Gt, xp, wb, None, [stride, stride], [0, 0], [dil, dil], False,
+                                                          [0, 0], 1, [True, True, False])
+        dx = dxp[:, :, pt:dxp.shape[2] - pb, pl:dxp.shape[3] - pr].permute(0, 2, 3, 1)
+        dx = _q(dx, quant) / S if cfg.get('round_dx') else dx / S
+        dw = dwt.permute(2, 3, 1, 0) / S * scale
+        Gf = G / S
+        return (dx, dw, (Gf * z).sum(dim=(0, 1, 2)), Gf.sum(dim=(0, 1, 2)), Gf if ctx.has_res else None, None, None)
+
+
 def conv2d_nhwc(x, w_hwio, stride=1, dilation=1, padding='SAME', bias=None, quant=None):
     """tf.nn.conv2d / slim conv2d / conv2d_same on NHWC input with HWIO weights.  quant: 'f16' / 'bf16' rounds the two
     operands like the mixed-precision kernels do (QuantConvFn); None = plain fp32."""

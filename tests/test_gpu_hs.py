@@ -1,0 +1,241 @@
+"""Half-STORAGE convolution path (BASELINE configs[4], SURVEY.md 8(d): "fp16 activations/weights with fp32 accumulate + fp32
+master weights"): csrc/conv_hs.h + csrc/halfstore.hip through the C ABI.
+
+What is compared with what, and how tightly (stated here, separately from north_star's fp32 1e-4):
+  * the streaming kernels (casts, weight copies, pooling) move or round values one by one: BIT-exact against numpy / torch;
+  * a convolution's result is a 16-bit tensor: the kernel and the reference (torch conv on the SAME 16-bit operands, fp32
+    accumulation, same fused epilogue, one final rounding) may differ in accumulation order only, i.e. by one rounding step
+    of the stored type on elements whose fp32 value sits next to a rounding boundary: every element within 1 ulp of the
+    16-bit type, at least 99 % bit-identical;
+  * the fp32 results (weight gradients, channel sums, the fp32 feature-map output) within 2e-5 of the tensor's scale;
+  * end to end: the ResNet-50 train step with a half-storage trunk against oracle/model.py `storage=` (HalfStorageConvFn
+    restates the same roundings) with the half-ulp bounds of tests/test_gpu_half.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+F = np.float32
+TORCH_DT = {'f16': torch.float16, 'bf16': torch.bfloat16}
+ULP = {'f16': 2.0 ** -10, 'bf16': 2.0 ** -7}       # spacing of the type relative to a value in [1, 2)
+
+HS_CASES = [
+    # N, H, W, C, K, R, stride, dil, padding, act
+    (2, 16, 16, 64, 128, 1, 1, 1, 'SAME', 'relu'),
+    (1, 20, 24, 128, 64, 3, 1, 1, 'SAME', 'relu'),
+    (1, 17, 19, 64, 192, 3, 2, 1, 'SAME_EXPLICIT', 'relu'),   # odd sizes, stride 2, partial tiles both ways
+    (1, 12, 12, 64, 256, 3, 1, 2, 'SAME', 'relu'),            # dilated
+    (2, 31, 33, 256, 64, 1, 2, 1, 'SAME', None),              # strided 1x1 (bottleneck shortcut), no activation
+    (2, 32, 32, 256, 256, 3, 1, 1, 'SAME', 'relu'),           # 128x128 tiles, several stages per tap
+    (1, 64, 64, 1024, 256, 1, 1, 1, 'SAME', 'relu'),          # block3 conv1 shape: 16 stages, 4096 rows
+]
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def T(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dev())
+
+
+@pytest.fixture(scope='module')
+def K():
+    from luminoth_amd import kernels
+    return kernels
+
+
+def q(t, storage):
+    return t.to(TORCH_DT[storage]).to(torch.float32)
+
+
+def assert_half_close(got, ref, storage, name, frac_exact=0.99):
+    """got: 16-bit tensor from the kernel; ref: fp32 reference BEFORE its final rounding."""
+    ref = ref.float()
+    refq = ref.to(TORCH_DT[storage])
+    g, r = got.float().cpu(), refq.float().cpu()
+    exact = float((g == r).float().mean())
+    # one step of the type at the magnitude of the reference
+    # ... plus fp32 accumulation-order noise of the sum itself (matters where the terms cancel: the value is tiny, its ulp too)
+    step = ULP[storage] * torch.clamp(2.0 ** torch.floor(torch.log2(ref.abs().cpu().clamp_min(1e-30))), min=2.0 ** -14)
+    step = step + 4e-6 * float(ref.abs().max())
+    worst = float(((g - r).abs() / step).max())
+    assert worst <= 1.0 + 1e-6 and exact >= frac_exact, (name, 'ulps', worst, 'exact', exact)
+
+
+@pytest.mark.parametrize('storage', ['f16', 'bf16'])
+def test_cast_pool_subsample_are_exact(K, storage):
+    rs = np.random.RandomState(3)
+    tdt = TORCH_DT[storage]
+    x = T((rs.randn(3, 7, 9, 64) * 3).astype(F))
+    bits_np = rs.rand(3 * 7 * 9, 64) > 0.3
+    bits = T(np.packbits(bits_np.reshape(-1, 2, 32), axis=-1, bitorder='little').view(np.int32).reshape(-1, 2))
+    h = K.cast_to_half(x, storage, mul=4.0, bits=bits)
+    ref = (x * 4.0 * T(bits_np.reshape(3, 7, 9, 64).astype(F))).to(tdt)
+    assert h.dtype == tdt and torch.equal(h, ref)
+    assert torch.equal(K.cast_to_half(x, storage), x.to(tdt))
+    assert torch.equal(K.cast_to_f32(h, 0.25), h.float() * 0.25)
+    # pooling: fp32 input (the stem output) and half input
+    for src in (x, x.to(tdt)):
+        for k, s, pad in ((3, 2, 'SAME'), (1, 2, 'VALID')):
+            y, geom = K.maxpool_fwd(src, k, s, pad, storage=storage)
+            yr, _ = K.maxpool_fwd(src.float().to(tdt).float(), k, s, pad)        # fp32 kernel on the rounded values
+            assert y.dtype == tdt and torch.equal(y.float(), yr)
+    # subsample backward: scatter to the strided positions, zeros elsewhere
+    xs = x.to(tdt)
+    y, geom = K.maxpool_fwd(xs, 1, 2, 'VALID')
+    dy = T(rs.randn(*y.shape).astype(F)).to(tdt)
+    dx = K.maxpool_bwd(xs, y, dy, 1, 2, geom)
+    ref = torch.zeros_like(xs)
+    ref[:, ::2, ::2, :][:, :y.shape[1], :y.shape[2]] = dy
+    assert torch.equal(dx, ref)
+
+
+@pytest.mark.parametrize('storage', ['f16', 'bf16'])
+def test_half_weight_copies_are_exact(K, storage):
+    rs = np.random.RandomState(5)
+    tdt = TORCH_DT[storage]
+    jobs, refs = [], []
+    for (R, C, Kc) in ((1, 64, 256), (3, 128, 128), (1, 1024, 2048), (3, 64, 72), (1, 40, 24)):
+        w = T((rs.randn(R, R, C, Kc) * 0.1).astype(F))
+        ks = T((1 + 0.2 * rs.randn(Kc)).astype(F)) if R == 3 else None
+        wf = torch.empty((Kc, R, R, C), dtype=tdt, device=dev())
+        wb = torch.empty((R, R, C, Kc), dtype=tdt, device=dev())
+        jobs.append((w, ks, wf, wb))
+        # q(w * scale): ONE rounding of the exact product (the compiler emits v_fma_mixlo_f16 for the f16 copy; a product of
+        # two fp32 values is exact in float64, and numpy rounds float64 -> float16 directly); bf16: fp32 product, then RNE
+        if ks is None:
+            rb = w.to(tdt)
+        elif storage == 'f16':
+            rb = T((w.double().cpu().numpy() * ks.double().cpu().numpy()).astype(np.float16))
+        else:
+            rb = (w * ks).to(tdt)
+        refs.append((w.to(tdt).permute(3, 0, 1, 2).contiguous(), rb))
+    K.half_weights_batch(jobs * 12, storage)          # 60 jobs: more than one launch
+    for (w, ks, wf, wb), (rf, rb) in zip(jobs, refs):
+        assert torch.equal(wf, rf) and torch.equal(wb, rb)
+
+
+@pytest.mark.parametrize('storage', ['f16', 'bf16'])
+@pytest.mark.parametrize('case', HS_CASES)
+def test_hs_convolution_kernels(K, case, storage):
+    import oracle.torch_ops as ot
+    N, H, W, C, Kc, R, stride, dil, padding, act = case
+    tdt = TORCH_DT[storage]
+    rs = np.random.RandomState(41 + HS_CASES.index(case))
+    x = torch.tensor(rs.randn(N, H, W, C).astype(F)).to(tdt)
+    w = torch.tensor((rs.randn(R, R, C, Kc) * np.sqrt(2.0 / (R * R * C))).astype(F))
+    scale = torch.tensor((1 + 0.1 * rs.randn(Kc)).astype(F))
+    shift = torch.tensor((0.1 * rs.randn(Kc)).astype(F))
+    d = K.conv_desc(x.shape, w.shape, stride, dil, padding, act, storage)
+    assert K.conv_hs_ok(d)
+    res = torch.tensor(rs.randn(N, d.OH, d.OW, Kc).astype(F)).to(tdt)
+    wf = torch.empty((Kc, R, R, C), dtype=tdt, device=dev())
+    wb = torch.empty((R, R, C, Kc), dtype=tdt, device=dev())
+    K.half_weights_batch([(w.to(dev()), scale.to(dev()), wf, wb)], storage)
+    # ---- forward
+    conv = ot.conv2d_nhwc(x.double(), w.to(tdt).double(), stride, dil, padding)      # float64: the reference adds no noise of its own
+    pre = conv * scale.double() + shift.double() + res.double()
+    ref = torch.relu(pre) if act == 'relu' else pre
+    bits = K.new_act_bits(N * d.OH * d.OW, Kc, dev()) if act else None
+    y = K.conv2d_fwd_hs(d, x.to(dev()), wf, scale.to(dev()), shift.to(dev()), res.to(dev()), act_bits=bits)
+    assert y.dtype == tdt
+    assert_half_close(y, ref, storage, 'fwd')
+    if act:
+        yb = (y.float() > 0).cpu().numpy()
+        ref_bits = np.packbits(yb.reshape(-1, Kc // 32, 32), axis=-1, bitorder='little').view(np.uint32).reshape(-1, Kc // 32)
+        np.testing.assert_array_equal(bits.cpu().numpy().view(np.uint32), ref_bits)
+    y32 = K.conv2d_fwd_hs(d, x.to(dev()), wf, scale.to(dev()), shift.to(dev()), res.to(dev()), out_f32=True)
+    assert y32.dtype == torch.float32
+    np.testing.assert_allclose(y32.cpu().numpy(), ref.float().numpy(), rtol=1e-4, atol=2e-5 * float(ref.abs().max()))
+    y_plain = K.conv2d_fwd_hs(d, x.to(dev()), wf, None, None, None, out_f32=True)
+    plain = torch.relu(conv) if act == 'relu' else conv
+    np.testing.assert_allclose(y_plain.cpu().numpy(), plain.float().numpy(), rtol=1e-4, atol=2e-5 * float(plain.abs().max()))
+    # ---- backward data: dx = q((conv^T(g, q(w * scale)) + addend) * mask)
+    g = torch.tensor((rs.randn(N, d.OH, d.OW, Kc) * 0.05).astype(F)).to(tdt)
+    add = torch.tensor((rs.randn(N, H, W, C) * 0.05).astype(F)).to(tdt)
+    xm = rs.rand(N * H * W, C) > 0.4
+    xbits = T(np.packbits(xm.reshape(-1, C // 32, 32), axis=-1, bitorder='little').view(np.int32).reshape(-1, C // 32))
+    xt = x.double().clone().requires_grad_(True)
+    ot.conv2d_nhwc(xt, wb.cpu().double(), stride, dil, padding).backward(g.double())      # the copy test pins wb itself
+    dx_ref = xt.grad
+    dx = K.conv2d_bwd_data_hs(d, g.to(dev()), wb)
+    assert_half_close(dx, dx_ref, storage, 'bwd_data')
+    dx2 = K.conv2d_bwd_data_hs(d, g.to(dev()), wb, addend=add.to(dev()), xbits=xbits)
+    assert_half_close(dx2, (dx_ref + add.double()) * torch.tensor(xm.reshape(N, H, W, C).astype(np.float64)), storage, 'bwd_data+addend+mask')
+    # ---- weight gradient (fp32): corr(x, g) / loss scale, channel sums of g
+    xt = x.double().clone()
+    wt = w.double().clone().requires_grad_(True)
+    ot.conv2d_nhwc(xt, wt, stride, dil, padding).backward(g.double())
+    inv = 1.0 / 1024.0
+    cs = torch.full((Kc,), 7.0, device=dev())
+    dw = K.conv2d_bwd_weight_hs(d, x.to(dev()), g.to(dev()), inv, colsum=cs)
+    dw_ref = (wt.grad * inv).float().numpy()
+    np.testing.assert_allclose(dw.cpu().numpy(), dw_ref, rtol=1e-4, atol=2e-5 * float(np.abs(dw_ref).max()))
+    cs_ref = (g.double().sum(dim=(0, 1, 2)) * inv).float().numpy()
+    np.testing.assert_allclose(cs.cpu().numpy(), cs_ref, rtol=1e-4, atol=2e-5 * float(np.abs(cs_ref).max()))
+    dw2 = K.conv2d_bwd_weight_hs(d, x.to(dev()), g.to(dev()), inv)
+    assert torch.equal(dw2, dw)
+
+
+def test_hs_entry_points_refuse_what_they_do_not_take(K):
+    from luminoth_amd._lib import LuminothHipError
+    d = K.conv_desc((1, 8, 8, 32, ), (1, 1, 32, 64), 1, 1, 'SAME', None, 'f16')       # C % 64 != 0
+    assert not K.conv_hs_ok(d)
+    x = torch.zeros((1, 8, 8, 32), dtype=torch.float16, device=dev())
+    w = torch.zeros((64, 1, 1, 32), dtype=torch.float16, device=dev())
+    with pytest.raises(LuminothHipError):
+        K.conv2d_fwd_hs(d, x, w)
+    d32 = K.conv_desc((1, 8, 8, 64), (1, 1, 64, 64), 1, 1, 'SAME', None, None)           # fp32 compute
+    assert not K.conv_hs_ok(d32)
+
+
+HS_E2E = {'f16': dict(out_tol=4 * 2.0 ** -11, loss_tol=1e-4, grad_tight=4 * 2.0 ** -11, grad_max=8 * 2.0 ** -11),
+          'bf16': dict(out_tol=4 * 2.0 ** -8, loss_tol=2e-4, grad_tight=4 * 2.0 ** -8, grad_max=8 * 2.0 ** -8)}
+
+
+def _hs_step(storage, H, W, B=2, classes=80):
+    from e2e_util import compare_step_with_oracle, make_config
+    from luminoth_amd.models import get_model
+    import bench
+    cfg = make_config('resnet_v1_50', classes, **{'model.base_network.storage_dtype': storage})
+    model = get_model('fasterrcnn')(cfg)
+    bench.condition_weights(model, 'resnet_v1_50')
+    bn = model.base_network
+    assert bn.storage_dtype == storage and bn.compute_dtype == storage and len(bn._hs_layers) == 3 * 3 + 4 * 3 + 6 * 3 + 3
+    assert bn.trunk.nodes[-1].conv3.hs_out_f32 and model._rpn._rpn.compute == storage
+    images, (gt, cnt) = bench.synth_batch(B, H, W, 8, classes, 100, 'cpu')
+    gts = [gt[b, :int(cnt[b])].numpy() for b in range(B)]
+    stats = {}
+    try:
+        compare_step_with_oracle(model, images, gts, classes, oracle_kwargs={'storage': storage}, stats=stats, **HS_E2E[storage])
+    finally:
+        print('half-storage %s step at %dx%d vs oracle(storage): observed %s' % (storage, H, W, {k: '%.2e' % v for k, v in stats.items()}))
+    # the trunk really ran on 16-bit tensors
+    from luminoth_amd.models.base import layers as L
+    L.ACT_TAP = {}
+    try:
+        with torch.no_grad():
+            model(images)
+        tap = dict(L.ACT_TAP)
+    finally:
+        L.ACT_TAP = None
+    tdt = TORCH_DT[storage]
+    trunk = [k for k in tap if '/block' in k and 'rcnn' not in k]
+    assert trunk and all(tap[k].dtype == tdt for k in trunk if not k.endswith('block3/unit_6/bottleneck_v1/conv3'))
+    assert tap[[k for k in trunk if k.endswith('block3/unit_6/bottleneck_v1/conv3')][0]].dtype == torch.float32
+
+
+@pytest.mark.parametrize('storage', ['f16', 'bf16'])
+def test_half_storage_train_step_vs_oracle(storage):
+    _hs_step(storage, 320, 384)
+
+
+@pytest.mark.parametrize('storage', ['f16', 'bf16'])
+def test_half_storage_train_step_at_config5_shape(storage):
+    """BASELINE configs[4] at its own shape: ResNet-50, 2 x 800 x 1333, 80 classes, 8 gt boxes per image."""
+    _hs_step(storage, 800, 1333)
