@@ -40,7 +40,7 @@ typedef void* lmh_stream_t; /* hipStream_t */
 
 /* Tuning options (process global; defaults are the measured best on MI355X).  Names: bd_parity_small, half_pf,
  * x3_tile_slots, x3_pf, x3_pf_fwd, x3_pf_gb, x3_pf_bd, x3_pf_bw, bd_slots, bw_slots, wgrad_glds, wg_slots, wino_m,
- * roi_cs, roi_mean_cs (csrc/api.hip documents each).  Unknown name: LMH_ERR_INVALID. */
+ * hs_wgrad_tr, roi_cs, roi_mean_cs (csrc/api.hip documents each).  Unknown name: LMH_ERR_INVALID. */
 int lmh_set_option(const char* name, int value);
 int lmh_get_option(const char* name, int* value);
 
@@ -209,7 +209,8 @@ int lmh_maxpool_bwd(const float* x, const float* y, const float* dy, int N, int 
  * are the working copies lmh_half_weights_batch writes from the fp32 HWIO master weights (once per optimizer step).
  *   forward    y  = q( act( conv(x, w_fwd) * scale + shift + residual ) )        (y fp32 and unrounded when y_is_f32)
  *              act_bits (may be NULL): activation mask of the STORED y, layout of lmh_act_bits
- *   backward   dx = q( ( conv^T(g, w_bwd) + addend ) * act'(x) )                act'(x) from xbits (may be NULL)
+ *   backward   dx = q( ( conv^T(g, w_bwd) * mul + addend ) * act'(x) )          act'(x) from xbits (may be NULL); dx fp32 and
+ *              unrounded when dx_is_f32 (a half-storage layer whose input is an fp32 tensor: mul = 1 / loss scale)
  *   weights    dw = inv_scale * corr(x, g)   (fp32, RAW like lmh_conv2d_bwd_weight);  colsum[k] = inv_scale * sum_p g[p][k]
  * g carries the caller's loss scale (a power of two; 1 for bf16): inv_scale removes it.  Workspace of the weight
  * gradient: lmh_conv2d_bwd_weight_workspace_bytes(d); deferred tails (lmh_tail_defer) work as for lmh_conv2d_bwd_weight. */
@@ -217,7 +218,7 @@ int lmh_conv2d_hs_supported(const lmh_conv_desc* d);
 int lmh_conv2d_fwd_hs(const lmh_conv_desc* d, const void* x, const void* w_fwd, const float* scale, const float* shift,
                       const void* residual, void* y, int y_is_f32, uint32_t* act_bits, lmh_stream_t stream);
 int lmh_conv2d_bwd_data_hs(const lmh_conv_desc* d, const void* g, const void* w_bwd, const void* addend,
-                           const uint32_t* xbits, void* dx, lmh_stream_t stream);
+                           const uint32_t* xbits, void* dx, int dx_is_f32, float mul, lmh_stream_t stream);
 int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, const void* g, float inv_scale, float* dw,
                              float* colsum, void* ws, size_t ws_bytes, lmh_stream_t stream);
 typedef struct lmh_half_weight_job {

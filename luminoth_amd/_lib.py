@@ -128,7 +128,7 @@ SIGNATURES = {
     'lmh_maxpool_bwd': (c_i, [c_f, c_f, c_f] + [c_i] * 10 + [c_f, c_f]),
     'lmh_conv2d_hs_supported': (c_i, [P(ConvDesc)]),
     'lmh_conv2d_fwd_hs': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f]),
-    'lmh_conv2d_bwd_data_hs': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_conv2d_bwd_data_hs': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_float, c_f]),
     'lmh_conv2d_bwd_weight_hs': (c_i, [P(ConvDesc), c_f, c_f, ctypes.c_float, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_half_weights_batch': (c_i, [P(HalfWeightJob), c_i, c_i, c_f]),
     'lmh_cast_to_half': (c_i, [c_f, ctypes.c_int64, c_i, ctypes.c_float, c_f, c_f, c_i, c_f]),

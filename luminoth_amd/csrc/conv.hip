@@ -446,6 +446,8 @@ extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
   return bm * 1000 + bn + (bwd_weight_fast(d) ? 0 : 1000000);
 }
 
+static bool wgrad_hs_plan(const lmh_conv_desc* d, int* bm, int* bn, int* splits, int* kt_per_split);
+
 extern "C" size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d) {
   if (!d) return 0;
   int bm, bn, splits, kps;
@@ -461,6 +463,10 @@ extern "C" size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d) 
     return slabs + lmh_align_up((size_t)splits * BK * d->K * sizeof(float), 256);   // <= splits * 32 partial column rows
   }
   bwd_weight_plan(d, &bm, &bn, &splits, &kps);
+  {
+    int hb, hn, hs_splits, hk;
+    if (wgrad_hs_plan(d, &hb, &hn, &hs_splits, &hk) && hs_splits > splits) splits = hs_splits;   // half-storage entry point
+  }
   // split-K slabs, then [splits][K] column-sum partials (fused dbeta / dbias)
   const size_t slabs = splits <= 1 ? 256 : lmh_align_up((size_t)splits * d->R * d->S * d->C * d->K * sizeof(float), 256);
   return slabs + lmh_align_up((size_t)splits * d->K * sizeof(float), 256);
@@ -714,14 +720,38 @@ extern "C" int lmh_conv2d_fwd_hs(const lmh_conv_desc* d, const void* x, const vo
 }
 
 extern "C" int lmh_conv2d_bwd_data_hs(const lmh_conv_desc* d, const void* g, const void* w_bwd, const void* addend,
-                                      const uint32_t* xbits, void* dx, lmh_stream_t stream) {
+                                      const uint32_t* xbits, void* dx, int dx_is_f32, float mul, lmh_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   LMH_CHECK_ARG(g && w_bwd && dx);
   if (!hs_ok(d)) { lmh_set_error("lmh_conv2d_bwd_data_hs: needs compute f16 / bf16, C %% 64 == 0, K %% 64 == 0"); return LMH_ERR_UNSUPPORTED; }
   g_prof_pending_bytes = hs_bytes(d);
-  hs_epilogue e = {nullptr, nullptr, addend, xbits, nullptr, dx, 0, 1.f};
+  hs_epilogue e = {nullptr, nullptr, addend, xbits, nullptr, dx, dx_is_f32, mul};
   return hs_launch<true>(d, g, w_bwd, e, (hipStream_t)stream);
+}
+
+// Plan of k_wgrad_hs_tr (stages of 64 pixels): square tiles, 128 x 128 when both channel counts reach it (half the L2
+// traffic per FLOP of 64 x 64), as many pixel splits as fill the resident-block slots once with >= 4 stages per block.
+static bool wgrad_hs_plan(const lmh_conv_desc* d, int* bm, int* bn, int* splits, int* kt_per_split) {
+  if (!((d->compute == 1 || d->compute == 2) && (d->C % 64) == 0 && (d->K % 64) == 0)) return false;
+  *bm = *bn = (d->C >= 128 && d->K >= 128) ? 128 : 64;
+  if (g_force_bm && g_force_bn) *bm = *bn = (g_force_bm >= 128 && g_force_bn >= 128) ? 128 : 64;
+  const int64_t tiles = (int64_t)d->R * d->S * ((d->C + *bm - 1) / *bm) * ((d->K + *bn - 1) / *bn);
+  const int64_t P = (int64_t)d->N * d->OH * d->OW;
+  const int KT = (int)((P + HSW_BK - 1) / HSW_BK);
+  // 1x1: fill the resident-block slots once.  Gathered (3x3) layers re-read x once per tap and g once per tap and channel
+  // tile, mostly out of the Infinity Cache: they run best cut into ~2000 short blocks (measured, scripts/bench_conv_hs.py:
+  // RPN 3x3 1024->512 386 us unsplit, 250 us with 8 splits; block3 3x3 51 -> 42 us)
+  const bool gather = d->R * d->S > 1 || d->stride > 1;
+  const int slots = gather ? 2048 : ((*bm == 128) ? 256 : 512);
+  int want = (int)((slots + tiles - 1) / tiles);
+  const int max_split = KT / 4 > 0 ? (KT / 4 < 64 ? KT / 4 : 64) : 1;
+  if (want > max_split) want = max_split;
+  if (want < 1) want = 1;
+  if (g_force_splits) want = g_force_splits < KT ? g_force_splits : KT;
+  *kt_per_split = (KT + want - 1) / want;
+  *splits = (KT + *kt_per_split - 1) / *kt_per_split;
+  return true;
 }
 
 extern "C" int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, const void* g, float inv_scale, float* dw,
@@ -731,7 +761,9 @@ extern "C" int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, c
   LMH_CHECK_ARG(x && g && dw);
   if (!hs_ok(d)) { lmh_set_error("lmh_conv2d_bwd_weight_hs: needs compute f16 / bf16, C %% 64 == 0, K %% 64 == 0"); return LMH_ERR_UNSUPPORTED; }
   int bm, bn, splits, kps;
-  bwd_weight_plan(d, &bm, &bn, &splits, &kps);
+  const bool tr = lmh_opt("hs_wgrad_tr") != 0;
+  if (tr) wgrad_hs_plan(d, &bm, &bn, &splits, &kps);
+  else bwd_weight_plan(d, &bm, &bn, &splits, &kps);
   if (ws_bytes < lmh_conv2d_bwd_weight_workspace_bytes(d) || ((splits > 1 || colsum) && !ws)) {
     lmh_set_error("lmh_conv2d_bwd_weight_hs: workspace too small");
     return LMH_ERR_WORKSPACE;
@@ -749,13 +781,32 @@ extern "C" int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, c
                      reinterpret_cast<const HT<DT_>::T*>(x), reinterpret_cast<const HT<DT_>::T*>(g), out, kps, dvw, dvh, \
                      inv_scale, tx, ty, splits, cpart)
 #define LAUNCH_BW_HS_T(BM_, BN_) do { if (d->compute == 1) LAUNCH_BW_HS(1, BM_, BN_); else LAUNCH_BW_HS(2, BM_, BN_); } while (0)
+  // 1x1 / stride 1: source pixel == output pixel, no decode in the loader
+  const bool gather = !(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->OH == d->H &&
+                        d->OW == d->W);
+#define LAUNCH_BW_TR(DT_, BM_, G_)                                                                           \
+  hipLaunchKernelGGL((k_wgrad_hs_tr<DT_, BM_, BM_, G_>), dim3(tx * ty * splits), dim3(256), 0, st, *d,            \
+                     reinterpret_cast<const HT<DT_>::T*>(x), reinterpret_cast<const HT<DT_>::T*>(g), out, kps, dvw, dvh, \
+                     inv_scale, tx, ty, splits, cpart)
+#define LAUNCH_BW_TR_T(BM_)                                                                                  \
+  do {                                                                                                       \
+    if (d->compute == 1) { if (gather) LAUNCH_BW_TR(1, BM_, true); else LAUNCH_BW_TR(1, BM_, false); }        \
+    else { if (gather) LAUNCH_BW_TR(2, BM_, true); else LAUNCH_BW_TR(2, BM_, false); }                        \
+  } while (0)
   prof_begin(st);
-  if (bm == 128 && bn == 128) LAUNCH_BW_HS_T(128, 128);
-  else LAUNCH_BW_HS_T(64, 64);
+  if (tr) {
+    if (bm == 128) LAUNCH_BW_TR_T(128); else LAUNCH_BW_TR_T(64);
+    prof_end(st, desc_flops(d), "k_wgrad_hs_tr<%d, %d, %d, %s>", d->compute, bm, bn, gather ? "true" : "false");
+  } else {
+    if (bm == 128 && bn == 128) LAUNCH_BW_HS_T(128, 128);
+    else LAUNCH_BW_HS_T(64, 64);
+    prof_end(st, desc_flops(d), "k_conv_bwd_weight_hs<%d, %d, %d>", d->compute, bm == 128 && bn == 128 ? 128 : 64,
+             bm == 128 && bn == 128 ? 128 : 64);
+  }
+#undef LAUNCH_BW_TR_T
+#undef LAUNCH_BW_TR
 #undef LAUNCH_BW_HS_T
 #undef LAUNCH_BW_HS
-  prof_end(st, desc_flops(d), "k_conv_bwd_weight_hs<%d, %d, %d>", d->compute, bm == 128 && bn == 128 ? 128 : 64,
-           bm == 128 && bn == 128 ? 128 : 64);
   if (g_lmh_defer_tail) {
     g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;
     g_lmh_last_plan.splits = splits > 1 ? splits : 0;

@@ -16,9 +16,8 @@
 // Gradients carry the step's loss scale (a power of two chosen by the host, 1 for bf16); the weight gradient divides it
 // out of its fp32 accumulators.
 //
-// Tile: BM x BN outputs, BK = 64 reduction elements per stage, two LDS buffers of [BM + BN][72] halfs (rows padded by
-// 16 bytes: the four 16-lane groups of a ds_read_b128 fragment load hit 16 distinct 4-bank groups), 73.7 KB at 128x128 ->
-// two blocks per CU.  One register set: the loads of stage t+1 fly under the MFMAs of stage t.
+// Tile: BM x BN outputs, BK = 64 reduction elements per stage, a ring of 3-4 LDS stages of [BM + BN][64] halfs filled by
+// direct-to-LDS loads (k_conv_hs).
 //
 // The weight gradient keeps the staging map of k_conv_bwd_weight_h (both operands are pixel-major, so a thread loads a
 // 4 pixel x 4 channel block and writes four k-contiguous quads) with 8-byte loads and a v_perm transpose instead of
@@ -27,7 +26,6 @@
 #include "conv_half.h"
 
 #define HS_BK 64
-#define HS_LD (HS_BK + 8)
 
 struct hs_epilogue {
   const float* scale;        // forward: per output channel (NULL = 1)
@@ -40,19 +38,22 @@ struct hs_epilogue {
   float mul;                 // accumulator multiplier (backward: 1)
 };
 
+// One stage out of the swizzled LDS image: row R holds its eight 16-byte k-chunks at chunk position c ^ ((R >> 1) & 7), so
+// the 16 rows a lane group of ds_read_b128 touches ({0-3,12-15,20-27} ...) land on 16 different 4-bank groups.
 template <int DT, int TM, int TN>
 __device__ __forceinline__ void hs_mma_stage(const typename HT<DT>::T* __restrict__ As,
                                              const typename HT<DT>::T* __restrict__ Bs, f32x16 (&acc)[TM][TN],
                                              int a_off, int b_off, int lane) {
   typedef typename HT<DT>::V8 V8;
-  const int l31 = lane & 31, kh = 8 * (lane >> 5);
+  const int l31 = lane & 31, hi = lane >> 5, swz = (l31 >> 1) & 7;      // (tile offsets are multiples of 32 rows)
 #pragma unroll
   for (int s = 0; s < HS_BK / 16; ++s) {
+    const int ch = ((2 * s + hi) ^ swz) * 8;
     V8 a[TM], b[TN];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const V8*>(&As[(a_off + t * 32 + l31) * HS_LD + s * 16 + kh]);
+    for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const V8*>(&As[(a_off + t * 32 + l31) * HS_BK + ch]);
 #pragma unroll
-    for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const V8*>(&Bs[(b_off + t * 32 + l31) * HS_LD + s * 16 + kh]);
+    for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const V8*>(&Bs[(b_off + t * 32 + l31) * HS_BK + ch]);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -60,27 +61,35 @@ __device__ __forceinline__ void hs_mma_stage(const typename HT<DT>::T* __restric
   }
 }
 
-template <int DT, int BM, int BN>
+template <int BM, int BN, int NBUF>
 struct hs_smem {
-  static constexpr int stage = 2 * (BM + BN) * HS_LD / 2, epi = BM * (BN + 4);      // floats
-  static constexpr int floats = stage > epi ? stage : epi;
+  static constexpr int ring = NBUF * (BM + BN) * HS_BK / 2, epi = BM * (BN + 4);      // floats
+  static constexpr int floats = ring > epi ? ring : epi;
 };
+// ring depth by tile: 64 KB (two blocks per CU) for the small tiles, 96 KB (one block) at 128 x 128
+template <int BM, int BN> struct hs_nbuf { static constexpr int value = (BM + BN == 128) ? 4 : 3; };
 
 // BWD = false: forward (A = x, rows of B = output channels of w_fwd);  BWD = true: backward data (A = g, rows of B = input
 // channels of w_bwd).  Needs (reduction channels) % 64 == 0 and (output channels) % 8 == 0.
+// Operand rows go from global memory straight into LDS (global_load_lds_dwordx4: one wave instruction = 8 rows of 128
+// bytes, lane-linear in LDS; the k-chunk a lane FETCHES is permuted so that the image is the swizzled one above), through
+// an NBUF-deep ring with NBUF - 1 stages in flight, one raw s_barrier per stage and counted vmcnt waits
+// (conv_wgrad1x1.h has the same pipeline): at 64 x 64 a stage is only 4 MFMAs per wave, so the kernel lives on how many
+// loads it keeps in the air, not on bandwidth.
 template <int DT, int BM, int BN, bool BWD>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (BM + BN == 256) ? 1 : 2)
 k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typename HT<DT>::T* __restrict__ B,
           hs_epilogue e) {
   typedef typename HT<DT>::T HTT;
   typedef typename HT<DT>::V8 V8;
+  constexpr int NBUF = hs_nbuf<BM, BN>::value, D = NBUF - 1;
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AJ = BM / 32, BJ = BN / 32;
-  constexpr int A_SZ = BM * HS_LD, B_SZ = BN * HS_LD;
+  constexpr int AJ = BM / 32, BJ = BN / 32;           // wave instructions per wave and stage (8 rows each, 4 waves)
+  constexpr int NLD = AJ + BJ;
+  constexpr int A_SZ = BM * HS_BK, STAGE = (BM + BN) * HS_BK;
   constexpr int LDC = BN + 4;
-  __shared__ __attribute__((aligned(16))) float smem[hs_smem<DT, BM, BN>::floats];
-  HTT* const As = reinterpret_cast<HTT*>(smem);       // [2][BM][HS_LD]
-  HTT* const Bs = As + 2 * A_SZ;                      // [2][BN][HS_LD]
+  __shared__ __attribute__((aligned(16))) float smem[hs_smem<BM, BN, NBUF>::floats];
+  HTT* const ring = reinterpret_cast<HTT*>(smem);     // [NBUF][BM + BN][HS_BK]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int M = BWD ? d.N * d.H * d.W : d.N * d.OH * d.OW;
@@ -91,13 +100,17 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int KC = KR / HS_BK, KT = RS * KC;
-  const int kq = tid & 7, arow = tid >> 3;            // 16-byte piece of a row, row (mod 32)
+  // lane -> (row within the instruction's 8 rows, LDS chunk slot); instruction j of this wave covers tile rows
+  // (wave * AJ + j) * 8 .. + 7 (A set) / (wave * BJ + j) * 8 .. + 7 (B set)
+  const int lrow = lane >> 3, slot = lane & 7;
   // ---- A rows: output pixels (forward) / input pixels (backward)
   const int PW = BWD ? d.W : d.OW, PH = BWD ? d.H : d.OH;
-  int a_n[AJ], a_h0[AJ], a_w0[AJ];
+  int a_n[AJ], a_h0[AJ], a_w0[AJ], a_ch[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int p = m0 + arow + 32 * j;
+    const int r = (wave * AJ + j) * 8 + lrow;
+    a_ch[j] = 8 * (slot ^ ((r >> 1) & 7));              // the global k-chunk this lane fetches (halfs)
+    const int p = m0 + r;
     if (p < M) {
       const int t = p / PW, pw = p - t * PW;
       a_n[j] = t / PH;
@@ -130,7 +143,7 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
         ok = ok && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
         off = ((size_t)(a_n[j] * d.H + ih) * d.W + iw) * KR;
       }
-      pa[j] = ok ? A + off + 8 * kq : zero;
+      pa[j] = ok ? A + off + a_ch[j] : zero;
       inca[j] = ok ? HS_BK : 0;
     }
   };
@@ -140,50 +153,64 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
   size_t tapb[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    const int row = n0 + arow + 32 * j;
+    const int r = (wave * BJ + j) * 8 + lrow;
+    const int row = n0 + r;
     const bool ok = row < NC;
-    pb[j] = ok ? B + (size_t)row * (BWD ? (size_t)KR : (size_t)RS * KR) + 8 * kq : zero;
+    pb[j] = ok ? B + (size_t)row * (BWD ? (size_t)KR : (size_t)RS * KR) + 8 * (slot ^ ((r >> 1) & 7)) : zero;
     incb[j] = ok ? HS_BK : 0;
     tapb[j] = ok ? (BWD ? (size_t)NC * KR - KR + HS_BK : (size_t)HS_BK) : 0;
   }
-  V8 ra[AJ], rb[BJ];
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  int rs = 0, kc = 0, ptile = 0;
+  int rs = 0, kc = 0;
   setup_tap(0);
-  auto step = [&]() {
-    if (ptile + 1 >= KT) return;
-    ++ptile;
-    if (++kc == KC) {
-      kc = 0; ++rs;
-      setup_tap(rs);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  // issue the loads of the stage the pointers stand on into ring slot `buf`, then advance the pointers by one stage
+#define HS_ISSUE(buf_)                                                                                     \
+  do {                                                                                                     \
+    HTT* As_ = ring + (buf_) * STAGE;                                                                      \
+    HTT* Bs_ = As_ + A_SZ;                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                         \
+      __builtin_amdgcn_global_load_lds((glb_ptr)pa[j], (lds_ptr)(As_ + (wave * AJ + j) * 8 * HS_BK), 16, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j)                                                         \
+      __builtin_amdgcn_global_load_lds((glb_ptr)pb[j], (lds_ptr)(Bs_ + (wave * BJ + j) * 8 * HS_BK), 16, 0, 0); \
+    if (++kc == KC) {                                                                                      \
+      kc = 0; ++rs;                                                                                        \
+      if (rs < RS) setup_tap(rs);                                                                          \
+      _Pragma("unroll") for (int j = 0; j < BJ; ++j) pb[j] += tapb[j];                                     \
+    } else {                                                                                               \
+      _Pragma("unroll") for (int j = 0; j < AJ; ++j) pa[j] += inca[j];                                     \
+      _Pragma("unroll") for (int j = 0; j < BJ; ++j) pb[j] += incb[j];                                     \
+    }                                                                                                      \
+  } while (0)
 #pragma unroll
-      for (int j = 0; j < BJ; ++j) pb[j] += tapb[j];
+  for (int s = 0; s < D; ++s)
+    if (s < KT) HS_ISSUE(s);
+  int cur = 0;
+  for (int t = 0; t < KT; ++t) {
+    // stage t has landed once at most min(D - 1, KT - 1 - t) younger stages are still in flight
+    if (KT - 1 - t >= D - 1) {
+      if (D - 1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (NLD * (D - 1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (NLD * (D - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (NLD * (D - 1) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (NLD * (D - 1) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (NLD * (D - 1) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-#pragma unroll
-      for (int j = 0; j < AJ; ++j) pa[j] += inca[j];
-#pragma unroll
-      for (int j = 0; j < BJ; ++j) pb[j] += incb[j];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  };
-  auto load = [&](auto) {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) ra[j] = *reinterpret_cast<const V8*>(pa[j]);
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) rb[j] = *reinterpret_cast<const V8*>(pb[j]);
-  };
-  auto store = [&](int buf, auto) {
-    HTT* Ad = As + buf * A_SZ;
-    HTT* Bd = Bs + buf * B_SZ;
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) *reinterpret_cast<V8*>(&Ad[(arow + 32 * j) * HS_LD + 8 * kq]) = ra[j];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) *reinterpret_cast<V8*>(&Bd[(arow + 32 * j) * HS_LD + 8 * kq]) = rb[j];
-  };
-  auto mma = [&](int buf) {
-    hs_mma_stage<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
-  };
-  HALF_PIPELINE(1, KT);
+    // raw barrier (no vmcnt drain): every wave's rows of stage t are in LDS and every wave is done reading the slot of
+    // stage t - 1, which the issue below overwrites
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + D < KT) HS_ISSUE(cur == 0 ? NBUF - 1 : cur - 1);
+    const HTT* As = ring + cur * STAGE;
+    hs_mma_stage<DT, TM, TN>(As, As + A_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    cur = (cur + 1 == NBUF) ? 0 : cur + 1;
+  }
+#undef HS_ISSUE
+  __syncthreads();      // the epilogue tile overlays the ring
   // ---- epilogue through LDS: a thread owns 8 consecutive output channels of a row (one 16-byte half store)
   constexpr int CT = BN / 8, RSTEP = 256 / CT;
   const int c8 = tid % CT, r0 = tid / CT;
@@ -301,9 +328,10 @@ k_conv_bwd_weight_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, 
   const HTT* gb = g + n0 + 4 * cq;
   const HTT* const zero = reinterpret_cast<const HTT*>(lmh_zero_page);
   int p0 = kt_begin * BK + 4 * kq;
-  uint2 ra[4], rb[4];
+  uint2 ra[2][4], rb[2][4];               // two register sets: the loads of tiles t+2 and t+3 fly while tile t is multiplied
   auto step = [&]() { p0 += BK; };
-  auto load = [&](auto) {
+  auto load = [&](auto S) {
+    constexpr int s_ = decltype(S)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned p = (unsigned)(p0 + i);
@@ -312,15 +340,16 @@ k_conv_bwd_weight_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, 
       const int ih = (int)oh * d.stride + dh0, iw = (int)ow * d.stride + dw0;
       const bool oka = a_ok && n < (unsigned)d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
       const HTT* pa_ = oka ? xb + ((size_t)((int)n * d.H + ih) * d.W + iw) * C : zero;
-      if (a_act) ra[i] = *reinterpret_cast<const uint2*>(pa_);
+      if (a_act) ra[s_][i] = *reinterpret_cast<const uint2*>(pa_);
       const bool okb = b_ok && (int)p < P;
       const HTT* pb_ = okb ? gb + (size_t)p * K : zero;
-      if (b_act) rb[i] = *reinterpret_cast<const uint2*>(pb_);
+      if (b_act) rb[s_][i] = *reinterpret_cast<const uint2*>(pb_);
     }
   };
-  auto store = [&](int buf, auto) {
-    if (a_act) hs_st_km<HTT>(As + buf * A_SZ, 4 * cq, kq, ra);
-    if (b_act) hs_st_km<HTT>(Bs + buf * B_SZ, 4 * cq, kq, rb);
+  auto store = [&](int buf, auto S) {
+    constexpr int s_ = decltype(S)::value;
+    if (a_act) hs_st_km<HTT>(As + buf * A_SZ, 4 * cq, kq, ra[s_]);
+    if (b_act) hs_st_km<HTT>(Bs + buf * B_SZ, 4 * cq, kq, rb[s_]);
   };
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
@@ -339,7 +368,7 @@ k_conv_bwd_weight_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, 
     mfma_stage_h<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane, A_SZ, B_SZ);
   };
   const int n_st = kt_end - kt_begin;
-  HALF_PIPELINE(1, n_st);
+  HALF_PIPELINE(2, n_st);
   if (do_col && n0 + tid < K) colpart[(size_t)bz * K + n0 + tid] = csum * inv_scale;
   acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
   __syncthreads();
@@ -354,4 +383,199 @@ k_conv_bwd_weight_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, 
       *reinterpret_cast<f32x4*>(o + (size_t)row * K + col) = *reinterpret_cast<const f32x4*>(&smem[rr * LDC + 4 * c4]) * inv_scale;
     }
   }
+}
+
+// ============================================================================
+// Weight gradient, second form: operands straight into LDS, fragments by the transposing LDS read.
+//
+// Both operands are pixel-major, so a [64 pixel][BM channel] tile of x (and of g) is a set of contiguous row segments — the
+// lane-linear image global_load_lds writes — but an MFMA fragment wants 8 consecutive PIXELS of one channel per lane.
+// gfx950's ds_read_b64_tr_b16 does that transpose on the way out of LDS: the 16 lanes of a group hand in the addresses of
+// the four 8-byte quarters of four rows (lane i: row i / 4, elements 4 (i % 4) .. + 3) and lane i receives column i of that
+// 4 x 16 block (measured: scripts/probes/tr16_probe.hip).  Two such reads make one 32x32x16 operand (k = 8 hi + 0..7).
+// No staging registers, no v_perm, no ds_write: a stage costs each wave 4-8 load instructions and (TM + TN) * 8 LDS reads.
+// Rows are swizzled by 64-byte quarters (the chunk a lane FETCHES is permuted) so that the 4 rows x 64 bytes a 32-lane
+// phase reads fall on 64 different banks: chunk' = chunk ^ 4 ((row >> 1) & 1) for 128-byte rows, ^ 4 (row & 3) for 256.
+// The per-channel sums of g come from the matrix pipe as well: one extra MFMA per k-step against an all-ones operand.
+// ============================================================================
+#define HSW_BK 64      // pixels per stage
+
+template <int BM> __device__ __forceinline__ int hsw_swz(int row) { return BM == 64 ? 4 * ((row >> 1) & 1) : 4 * (row & 3); }
+
+typedef short hs_s16x4 __attribute__((ext_vector_type(4)));
+typedef short hs_s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ hs_s16x4 hs_tr_read(const void* p) {      // 16-bit elements as raw bits: one builtin for f16 and bf16
+  typedef __attribute__((address_space(3))) hs_s16x4* lp;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)p);
+}
+
+template <int DT, int BM, int BN, bool GATHER>
+__global__ void __launch_bounds__(256, (BM + BN == 256) ? 1 : 2)
+k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const typename HT<DT>::T* __restrict__ g,
+              float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh, float inv_scale,
+              int tiles_x, int tiles_y, int splits, float* __restrict__ colpart) {
+  typedef typename HT<DT>::T HTT;
+  typedef typename HT<DT>::V8 V8;
+  constexpr int NBUF = (BM + BN == 128) ? 4 : 3, D = NBUF - 1;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_LPR = BM / 8, B_LPR = BN / 8;              // lanes (16-byte chunks) per tile row
+  constexpr int A_RPI = 64 / A_LPR, B_RPI = 64 / B_LPR;      // tile rows per wave instruction
+  constexpr int A_NI = HSW_BK / A_RPI / 4, B_NI = HSW_BK / B_RPI / 4;     // instructions per wave and stage
+  constexpr int NLD = A_NI + B_NI;
+  constexpr int A_SZ = HSW_BK * BM, STAGE = HSW_BK * (BM + BN);           // halfs
+  __shared__ __attribute__((aligned(16))) typename HT<DT>::T ring[NBUF * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int P = d.N * d.OH * d.OW, K = d.K, C = d.C;
+  const int lin = xcd_remap(blockIdx.x, tiles_x * tiles_y * splits);
+  const int bz = lin / (tiles_x * tiles_y), rem = lin - bz * (tiles_x * tiles_y);
+  const int tiles_c = (C + BM - 1) / BM;
+  const int by = rem / tiles_x, bx = rem - by * tiles_x;
+  const int rs = bx / tiles_c, m0 = (bx % tiles_c) * BM;
+  const int n0 = by * BN;
+  const int r_ = rs / d.S, s_ = rs - r_ * d.S;
+  const int KT_all = (P + HSW_BK - 1) / HSW_BK;
+  const int kt_begin = bz * kt_per_split;
+  const int n_st = min(KT_all, kt_begin + kt_per_split) - kt_begin;
+  const int dh0 = r_ * d.dilation - d.pad_top, dw0 = s_ * d.dilation - d.pad_left;
+  const HTT* const zero = reinterpret_cast<const HTT*>(lmh_zero_page);
+  // ---- loader state: instruction j of this wave covers tile rows (wave * NI + j) * RPI .. + RPI - 1
+  int a_row[A_NI], a_col[A_NI], b_row[B_NI], b_col[B_NI];
+  bool a_cok[A_NI], b_cok[B_NI];
+#pragma unroll
+  for (int j = 0; j < A_NI; ++j) {
+    a_row[j] = (wave * A_NI + j) * A_RPI + lane / A_LPR;
+    a_col[j] = m0 + 8 * ((lane % A_LPR) ^ hsw_swz<BM>(a_row[j]));
+    a_cok[j] = a_col[j] < C;
+  }
+#pragma unroll
+  for (int j = 0; j < B_NI; ++j) {
+    b_row[j] = (wave * B_NI + j) * B_RPI + lane / B_LPR;
+    b_col[j] = n0 + 8 * ((lane % B_LPR) ^ hsw_swz<BN>(b_row[j]));
+    b_cok[j] = b_col[j] < K;
+  }
+  int pst = kt_begin * HSW_BK;           // first pixel of the next stage to issue
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+#define HSW_ISSUE(buf_)                                                                                     \
+  do {                                                                                                      \
+    HTT* As_ = ring + (buf_) * STAGE;                                                                       \
+    HTT* Bs_ = As_ + A_SZ;                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < A_NI; ++j) {                                                      \
+      const unsigned p = (unsigned)(pst + a_row[j]);                                                        \
+      const HTT* src = zero;                                                                                \
+      if (GATHER) {                                                                                         \
+        const unsigned t = lmh_div(p, div_ow), ow = p - t * (unsigned)d.OW;                                 \
+        const unsigned n = lmh_div(t, div_oh), oh = t - n * (unsigned)d.OH;                                 \
+        const int ih = (int)oh * d.stride + dh0, iw = (int)ow * d.stride + dw0;                             \
+        if (a_cok[j] && n < (unsigned)d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)  \
+          src = x + ((size_t)((int)n * d.H + ih) * d.W + iw) * C + a_col[j];                                \
+      } else if (a_cok[j] && (int)p < P) {                                                                  \
+        src = x + (size_t)p * C + a_col[j];                                                                 \
+      }                                                                                                     \
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(As_ + (wave * A_NI + j) * A_RPI * BM), 16, 0, 0); \
+    }                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < B_NI; ++j) {                                                      \
+      const int p = pst + b_row[j];                                                                         \
+      const HTT* src = (b_cok[j] && p < P) ? g + (size_t)p * K + b_col[j] : zero;                           \
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(Bs_ + (wave * B_NI + j) * B_RPI * BN), 16, 0, 0); \
+    }                                                                                                       \
+    pst += HSW_BK;                                                                                          \
+  } while (0)
+
+  // ---- fragment addressing (bytes inside a tile): group gq = lane >> 4 reads rows 8 (gq >> 1) + 4 half + (i >> 2) of the
+  // k-step, channels 16 (gq & 1) + 4 (i & 3) .. + 3 of the 32-channel MFMA tile
+  const int gq = lane >> 4, li = lane & 15;
+  const int frow = 8 * (gq >> 1) + (li >> 2);                  // + 16 s + 4 half
+  const int fch = 16 * (gq & 1) + 4 * (li & 3);                // channel inside the 32-wide tile
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  // per-channel sums of g: blocks of ONE tile column (tap 0, first channel tile), waves wm == 0, on the matrix pipe
+  const bool do_col = colpart != nullptr && bx == 0 && wm == 0;
+  f32x16 cacc[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cacc[t][i] = 0.f;
+  V8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (HTT)1.0f;
+
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < n_st) HSW_ISSUE(s);
+  int cur = 0;
+  for (int t = 0; t < n_st; ++t) {
+    if (n_st - 1 - t >= D - 1) {
+      if (NLD * (D - 1) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (NLD * (D - 1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (NLD * (D - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (NLD * (D - 1) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + D < n_st) HSW_ISSUE(cur == 0 ? NBUF - 1 : cur - 1);
+    const char* As = reinterpret_cast<const char*>(ring + cur * STAGE);
+    const char* Bs = As + A_SZ * 2;
+#pragma unroll
+    for (int s = 0; s < HSW_BK / 16; ++s) {
+      hs_s16x8 ar[TM], br[TN];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = 16 * s + 4 * h + frow;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int c = wm * (BM / 2) + tm * 32 + fch;
+          const hs_s16x4 v = hs_tr_read(As + row * (BM * 2) + (((c >> 3) ^ hsw_swz<BM>(row)) << 4) + ((c & 7) << 1));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ar[tm][4 * h + e] = v[e];
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int c = wn * (BN / 2) + tn * 32 + fch;
+          const hs_s16x4 v = hs_tr_read(Bs + row * (BN * 2) + (((c >> 3) ^ hsw_swz<BN>(row)) << 4) + ((c & 7) << 1));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) br[tn][4 * h + e] = v[e];
+        }
+      }
+      V8 a[TM], b[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) a[tm] = __builtin_bit_cast(V8, ar[tm]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) b[tn] = __builtin_bit_cast(V8, br[tn]);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[tm], b[tn], acc[tm][tn]);
+      if (do_col) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) cacc[tn] = HT<DT>::mfma(ones, b[tn], cacc[tn]);
+      }
+    }
+    cur = (cur + 1 == NBUF) ? 0 : cur + 1;
+  }
+#undef HSW_ISSUE
+  const int l31 = lane & 31, rbase = 4 * (lane >> 5);
+  if (do_col && lane < 32) {          // every row of cacc holds the column sums; row 0 = register 0 of lanes 0..31
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + wn * (BN / 2) + tn * 32 + l31;
+      if (col < K) colpart[(size_t)bz * K + col] = cacc[tn][0] * inv_scale;
+    }
+  }
+  // epilogue: registers -> global; lanes 0..31 of one accumulator register hold 32 consecutive k of one c row
+  float* o = out + (size_t)bz * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + wn * (BN / 2) + tn * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase;
+        if (row < C && col < K) o[(size_t)row * K + col] = acc[tm][tn][i] * inv_scale;
+      }
+    }
 }

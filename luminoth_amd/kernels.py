@@ -599,14 +599,15 @@ def conv2d_fwd_hs(d, x, w_fwd, scale=None, shift=None, residual=None, out_f32=Fa
     return y
 
 
-def conv2d_bwd_data_hs(d, g, w_bwd, addend=None, xbits=None):
+def conv2d_bwd_data_hs(d, g, w_bwd, addend=None, xbits=None, out_f32=False, mul=1.0):
+    """out_f32: the data gradient leaves as an fp32 tensor (mul = 1 / loss scale): a half-storage layer fed by an fp32 one."""
     code, tdt = half_type_of(g)
     assert code == d.compute, (code, d.compute)
-    dx = torch.empty((d.N, d.H, d.W, d.C), dtype=tdt, device=g.device)
+    dx = torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32 if out_f32 else tdt, device=g.device)
     with _timed(d, 1):
         check(_lib.load().lmh_conv2d_bwd_data_hs(ctypes.byref(d), _p(g), _p(_half(w_bwd, tdt)),
                                                  _p(None if addend is None else _half(addend, tdt)), _p(xbits), _p(dx),
-                                                 _stream()), 'lmh_conv2d_bwd_data_hs')
+                                                 int(bool(out_f32)), float(mul), _stream()), 'lmh_conv2d_bwd_data_hs')
     return dx
 
 

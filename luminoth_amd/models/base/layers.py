@@ -85,6 +85,7 @@ class ConvLayer(object):
         self.compute_wgrad = 'same'   # arithmetic of the weight-gradient GEMM alone ('same' = self.compute)
         self.storage = None       # 'f16' / 'bf16': half tensors in HBM (then compute is the same type)
         self.hs_out_f32 = False   # half-storage layer whose OUTPUT is handed on as fp32 (top of the trunk)
+        self.hs_in_f32 = False    # half-storage layer fed by an fp32 tensor (casts it; its data gradient leaves as fp32): RPN conv
         self.wh = [None, None]    # working copies of the weights: [K,R,S,C] q(w), [R,S,C,K] q(w * bn_scale)
         self._wh_ready = False
         self.w_name = '%s/%s' % (scope, weight_name)
@@ -140,11 +141,21 @@ class ConvLayer(object):
         bits = None
         if want_bits and FUSE_MASK and K.act_bits_ok(self.cout, self.act):
             bits = K.new_act_bits(d.N * d.OH * d.OW, self.cout, x.device)
+        if self.storage is not None and self.hs_in_f32 and x.dtype == torch.float32:
+            # fp32 boundary on the input side: one cast pass; the 16-bit copy is kept on x for this layer's weight gradient
+            assert in_sub is None and residual is None, self.scope
+            xh = K.cast_to_half(x, self.storage)
+            x._lmh_half = (x._version, xh)
+            if bits is None and FUSE_MASK and K.act_bits_ok(self.cout, self.act):
+                bits = K.new_act_bits(d.N * d.OH * d.OW, self.cout, x.device)
+            x = xh
         if x.dtype != torch.float32:            # half-storage layer
             assert self.storage is not None and in_sub is None, (self.scope, x.dtype)
             if not self._wh_ready:
                 prepare_half_weights([self], self.storage)
             y = K.conv2d_fwd_hs(d, x, self.wh[0], self.scale, self.shift, residual, out_f32=self.hs_out_f32, act_bits=bits)
+            if self.hs_in_f32:
+                y._lmh_bits = bits               # the backward of this layer masks the incoming fp32 gradient with them
             if ACT_TAP is not None:
                 ACT_TAP[self.scope] = y
             return (y, bits) if want_bits else y
@@ -193,6 +204,19 @@ class ConvLayer(object):
         mask_bits: activation bit mask of x (written by the forward kernel of the layer that produced x): the
         returned dx is then dx * act'(x), i.e. THAT layer's g (applied in the bwd_data epilogue)."""
         d = self.desc(x.shape)
+        boundary = self.storage is not None and self.hs_in_f32 and x.dtype == torch.float32
+        if boundary:
+            # fp32 tensors on both sides of a half-storage layer: g = q(S * dy * act'(y)) in one cast pass, x from the forward
+            assert addend is None and mask_bits is None and dy.dtype == torch.float32, self.scope
+            kept = getattr(x, '_lmh_half', None)
+            xh = kept[1] if (kept is not None and kept[0] == x._version) else K.cast_to_half(x, self.storage)
+            bits = None
+            if self.act and not dy_is_g:
+                bits = getattr(y, '_lmh_bits', None)
+                if bits is None:
+                    bits = K.act_bits(y, self.act)
+            dy = K.cast_to_half(dy, self.storage, mul=HS_LOSS_SCALE[self.storage], bits=bits)
+            x, dy_is_g = xh, True
         hs = x.dtype != torch.float32
         if hs:
             # half storage: the gradient arrives as g (masked by the producer's epilogue or by the trunk's entry cast) in
@@ -227,7 +251,8 @@ class ConvLayer(object):
             if hs:
                 if not self._wh_ready:
                     prepare_half_weights([self], self.storage)
-                return K.conv2d_bwd_data_hs(d, g, self.wh[1], addend=addend, xbits=mask_bits)
+                return K.conv2d_bwd_data_hs(d, g, self.wh[1], addend=addend, xbits=mask_bits, out_f32=boundary,
+                                            mul=1.0 / HS_LOSS_SCALE[self.storage] if boundary else 1.0)
             return K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
                                      addend=addend, yact=yact, xbits=mask_bits,
                                      wino_u=self._wino_u[1] if self._wino_ready[1] else None)

@@ -96,6 +96,8 @@ class TruncatedBaseNetwork(BaseNetwork):
         # max-pool that writes the half tensor; the last trunk layer hands the feature map on as fp32.
         self.storage_dtype = config.get('storage_dtype')
         self._hs_layers = []
+        self.extra_hs_layers = []     # half-storage layers of the heads (the RPN 3x3 convolution): their working weight
+        #                               copies are refreshed in the same launch as the trunk's
         if self.storage_dtype not in (None, 'f32', 'fp32', 'float32'):
             if self.storage_dtype not in ('f16', 'bf16'):
                 raise ValueError('Invalid storage_dtype: "{}"'.format(self.storage_dtype))
@@ -218,7 +220,7 @@ class TruncatedBaseNetwork(BaseNetwork):
         else:
             self.bn_table.refresh()
         if self._hs_layers:
-            L.prepare_half_weights(self._hs_layers, self.storage_dtype)      # the weights may have changed since the last call
+            L.prepare_half_weights(self._hs_layers + self.extra_hs_layers, self.storage_dtype)   # weights may have changed
         return self._run(self.trunk, inputs.contiguous(), is_training)
 
     @property

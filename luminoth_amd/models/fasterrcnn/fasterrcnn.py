@@ -73,6 +73,13 @@ class FasterRCNN(object):
                         debug=self._debug, seed=self._seed, scope=name)
         if self.base_network.compute_dtype not in (None, 'f32', 'fp32', 'float32'):
             self._rpn._rpn.compute = self.base_network.compute_dtype     # the 3x3 RPN conv; the 1x1 heads stay fp32
+            rc = self._rpn._rpn
+            if self.base_network.storage_dtype in ('f16', 'bf16') and rc.cin % 64 == 0 and rc.cout % 64 == 0:
+                # half-storage trunk: the RPN convolution (a quarter of the step's FLOPs) runs on 16-bit operands in HBM
+                # too — it casts the fp32 feature map once and hands fp32 tensors on in both directions
+                rc.storage = self.base_network.storage_dtype
+                rc.hs_in_f32 = rc.hs_out_f32 = True
+                self.base_network.extra_hs_layers.append(rc)
         self._rcnn = None
         if self._with_rcnn:
             self._rcnn = RCNN(self._num_classes, config.model.rcnn, self.base_network.tail_channels,

@@ -165,6 +165,9 @@ def test_hs_convolution_kernels(K, case, storage):
     dx_ref = xt.grad
     dx = K.conv2d_bwd_data_hs(d, g.to(dev()), wb)
     assert_half_close(dx, dx_ref, storage, 'bwd_data')
+    dx32 = K.conv2d_bwd_data_hs(d, g.to(dev()), wb, out_f32=True, mul=0.5)        # fp32 boundary (RPN convolution): unrounded
+    assert dx32.dtype == torch.float32
+    np.testing.assert_allclose(dx32.cpu().numpy(), (dx_ref * 0.5).float().numpy(), rtol=1e-4, atol=2e-5 * float(dx_ref.abs().max()))
     dx2 = K.conv2d_bwd_data_hs(d, g.to(dev()), wb, addend=add.to(dev()), xbits=xbits)
     assert_half_close(dx2, (dx_ref + add.double()) * torch.tensor(xm.reshape(N, H, W, C).astype(np.float64)), storage, 'bwd_data+addend+mask')
     # ---- weight gradient (fp32): corr(x, g) / loss scale, channel sums of g
@@ -207,7 +210,7 @@ def _hs_step(storage, H, W, B=2, classes=80):
     bench.condition_weights(model, 'resnet_v1_50')
     bn = model.base_network
     assert bn.storage_dtype == storage and bn.compute_dtype == storage and len(bn._hs_layers) == 3 * 3 + 4 * 3 + 6 * 3 + 3
-    assert bn.trunk.nodes[-1].conv3.hs_out_f32 and model._rpn._rpn.compute == storage
+    assert bn.trunk.nodes[-1].conv3.hs_out_f32 and model._rpn._rpn.compute == storage and model._rpn._rpn.storage == storage
     images, (gt, cnt) = bench.synth_batch(B, H, W, 8, classes, 100, 'cpu')
     gts = [gt[b, :int(cnt[b])].numpy() for b in range(B)]
     stats = {}
