@@ -164,12 +164,14 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
     if not files:
         return None, None
-    try:
-        table = json.load(open(files[-1]))['kernels']
-        k = table.get(kernel.replace(' ', ''))
-        return (k['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)) if k else (None, None)
-    except Exception:
-        return None, None
+    for f in files[::-1]:           # newest first; a summary covers the kernels of the workload it was taken on
+        try:
+            k = json.load(open(f))['kernels'].get(kernel.replace(' ', ''))
+        except Exception:
+            continue
+        if k:
+            return k['hbm_bytes_per_launch'], os.path.relpath(f, ROOT)
+    return None, None
 
 
 def free_port():

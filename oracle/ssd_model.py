@@ -23,8 +23,11 @@ MAP_AFTER = ('conv7', 'conv8_2', 'conv9_2', 'conv10_2', 'conv11_2')
 class OracleSSD(object):
     def __init__(self, variables, num_classes=20, scope='ssd', anchors_per_point=(4, 6, 6, 6, 4, 4),
                  ratios=(1, 0.5, 2, 0.333, 3), min_scale=0.1, max_scale=0.88, variances=(0.1, 0.2),
-                 weight_decay=5e-4, loc_loss_weight=1.0, target=None, proposals=None):
-        self.v = {k: torch.as_tensor(v).clone().float() for k, v in variables.items()}
+                 weight_decay=5e-4, loc_loss_weight=1.0, target=None, proposals=None, dtype=torch.float32):
+        # dtype=torch.float64 (test-only): the dense path in double precision — is a gradient difference between two fp32
+        # implementations the round-off of an ill-conditioned sum, or a bug?
+        self.dtype = dtype
+        self.v = {k: torch.as_tensor(v).clone().to(dtype) for k, v in variables.items()}
         self.C, self.scope = num_classes, scope
         self.fe = scope + '/ssd_feature_extractor'
         self.app, self.ratios = list(anchors_per_point), np.array(ratios)
@@ -35,6 +38,15 @@ class OracleSSD(object):
         self.prop_cfg = dict(class_nms_threshold=0.45, class_max_detections=100, total_max_detections=100,
                              min_prob_threshold=0.5)
         self.prop_cfg.update(proposals or {})
+        # test-only knob (as oracle/model.py): {layer scope: that layer's output as the HIP kernels computed it} — every
+        # ReLU decision is then the kernels' own, so the reference gradient is the derivative of the branch they were on
+        self.masks = None
+
+    def _relu(self, z, scope):
+        yk = None if self.masks is None else self.masks.get(scope)
+        if yk is None:
+            return torch.relu(z)
+        return z * (torch.as_tensor(yk).reshape(z.shape) > 0).to(z.dtype)
 
     # ---- feature extractor (feature_extractor.py:39-132, truncated_vgg.py:79-121) ------------------------
     def feature_maps(self, image):
@@ -45,7 +57,7 @@ class OracleSSD(object):
         for bi, (name, reps) in enumerate(VGG16_CFG):
             for r in range(reps):
                 s = '%s/%s/%s_%d' % (p, name, name, r + 1)
-                net = torch.relu(ot.conv2d_nhwc(net, v[s + '/weights'], 1, 1, 'SAME', bias=v[s + '/biases']))
+                net = self._relu(ot.conv2d_nhwc(net, v[s + '/weights'], 1, 1, 'SAME', bias=v[s + '/biases']), s)
                 if name == 'conv4' and r == 2:
                     ss = (net * net).sum(dim=3, keepdim=True)
                     norm = net * torch.rsqrt(torch.clamp(ss, min=1e-12))          # tf.nn.l2_normalize
@@ -56,7 +68,7 @@ class OracleSSD(object):
         e = self.fe + '/extra_feature_layers'
         for name, stride, rate, pad in EXTRA:
             s = '%s/%s' % (e, name)
-            net = torch.relu(ot.conv2d_nhwc(net, v[s + '/w'], stride, rate, pad, bias=v[s + '/b']))
+            net = self._relu(ot.conv2d_nhwc(net, v[s + '/w'], stride, rate, pad, bias=v[s + '/b']), s)
             if name in MAP_AFTER:
                 maps.append(net)
         return maps
@@ -74,6 +86,7 @@ class OracleSSD(object):
     def forward_image(self, image, gt=None, overrides=None):
         """image (H,W,3) tensor, gt (G,5) numpy.  overrides: {'labels','targets'} to pin the discrete stage."""
         H, W = image.shape[0], image.shape[1]
+        image = image.to(self.dtype)
         maps = self.feature_maps(image)
         loc_pred, cls_pred = self.heads(maps)
         probs = torch.softmax(cls_pred, dim=1)
@@ -84,10 +97,10 @@ class OracleSSD(object):
             if overrides and 'labels' in overrides:
                 labels, targets = overrides['labels'], overrides['targets']
             else:
-                labels, targets = oss.ssd_target(probs.detach().numpy(), anchors, np.asarray(gt, np.float32),
+                labels, targets = oss.ssd_target(probs.detach().float().numpy(), anchors, np.asarray(gt, np.float32),
                                                  variances=self.variances, **self.target_cfg)
             out['labels'], out['targets'] = labels, targets
-            lt, tt = torch.as_tensor(labels), torch.as_tensor(targets)
+            lt, tt = torch.as_tensor(labels), torch.as_tensor(targets).to(self.dtype)
             keep = lt >= 0
             pos = lt > 0
             ce = torch.nn.functional.cross_entropy(cls_pred[keep], lt[keep].long(), reduction='sum')

@@ -8,6 +8,13 @@ timeout 300 python bench.py --alt --no-cpu-baseline --no-roofline > gpurun_out/e
 for dt in f32 f16 bf16 bf16x3; do
   timeout 200 python bench.py --workload frcnn_r50_coco --dtype $dt --no-cpu-baseline > gpurun_out/ev/r03_bench_frcnn_r50_coco_$dt.json 2>/dev/null
 done
+# half-storage trunk (round 3): the f16 / bf16 lines above use it; the round-2 path and a larger per-GPU batch beside them
+timeout 200 python bench.py --workload frcnn_r50_coco --dtype f16 --fp32-storage --no-cpu-baseline > gpurun_out/ev/r03_bench_frcnn_r50_coco_f16_fp32storage.json 2>/dev/null
+for dt in f32 f16 bf16; do
+  timeout 200 python bench.py --workload frcnn_r50_coco --dtype $dt --batch 8 --no-cpu-baseline > gpurun_out/ev/r03_bench_frcnn_r50_coco_${dt}_batch8.json 2>/dev/null
+done
+timeout 300 python scripts/bench_conv_hs.py f16 > gpurun_out/ev/r03_per_layer_conv_hs.log 2>/dev/null; tail -3 gpurun_out/ev/r03_per_layer_conv_hs.log
+timeout 300 python scripts/bench_conv_hs.py bf16 >> gpurun_out/ev/r03_per_layer_conv_hs.log 2>/dev/null
 timeout 300 python bench.py --workload frcnn_vgg16 --cpu-steps 3 > gpurun_out/ev/r03_bench_frcnn_vgg16_f32.json 2>/dev/null
 timeout 300 python bench.py --workload ssd300_b32 --no-cpu-baseline > gpurun_out/ev/r03_bench_ssd300_b32_f32.json 2>/dev/null
 timeout 300 python bench.py --workload frcnn_r101 --no-cpu-baseline > gpurun_out/ev/r03_bench_frcnn_r101_f32.json 2>/dev/null

@@ -157,9 +157,15 @@ def ssd_setup():
     return cfg, model, images, gts
 
 
-def _ssd_step_vs_oracle(model, images, gts):
+def _ssd_step_vs_oracle(model, images, gts, grad_max=4e-3):
+    from luminoth_amd.models.base import layers as L
     B = images.shape[0]
-    pred = model(images, gts, is_training=True)
+    L.ACT_TAP = {}
+    try:
+        pred = model(images, gts, is_training=True)
+        tap = {k: v.detach().cpu() for k, v in L.ACT_TAP.items()}
+    finally:
+        L.ACT_TAP = None
     losses = model.loss(pred, return_all=True)
     model.backward(losses['total_loss'])
     torch.cuda.synchronize()
@@ -172,6 +178,10 @@ def _ssd_step_vs_oracle(model, images, gts):
         # discrete stage pinned to the kernel's labels/targets (they depend on the kernel's own probs; the kernel
         # itself is checked bit-exactly against the oracle in test_ssd_target_* and against the reference's own graph
         # code in test_gpu_ref_tf_golden.py): the dense path is what is compared
+        # ReLU branches pinned to the kernels' own activations (as tests/e2e_util.py does for Faster R-CNN): both sides
+        # differentiate the same piecewise-linear function
+        oracle.masks = {k: v[b:b + 1] for k, v in tap.items() if v.shape[0] == B}
+        assert len(oracle.masks) >= 13 + 8
         o = oracle.forward_image(images[b], gts[b], overrides={'labels': pred['target']['cls'][b].cpu().numpy(),
                                                                 'targets': pred['target']['bbox_offsets'][b].cpu().numpy()})
         scale = max(1.0, float(o['cls_pred'].abs().max()))
@@ -188,6 +198,12 @@ def _ssd_step_vs_oracle(model, images, gts):
     np.testing.assert_allclose(float(losses['total_loss']), tot / B + float(reg), rtol=1e-4)
     grads = model.store.grads
     worst = 0.0
+    suspects = []
+
+    def ok(e):
+        # every element within `grad_max` of its tensor's scale, 99.9 % of a large tensor within 1e-3
+        return e.max() < grad_max and (e.size < 4096 or (e <= 1e-3).mean() >= 0.999)
+
     for n, gk in grads.items():
         go = oracle.v[n].grad
         if go is None:
@@ -196,18 +212,48 @@ def _ssd_step_vs_oracle(model, images, gts):
         scale = max(1e-6, np.abs(go).max())
         e = np.abs(gk.cpu().numpy() - go) / scale
         worst = max(worst, float(e.max()))
-        # ReLU branches are NOT pinned here (unlike tests/e2e_util.py): an activation within round-off of 0 may take
-        # the other branch on one side and moves isolated elements — 99.9 % of every tensor within 5e-4 of its
-        # scale, the single worst element within 2e-3 at batch 2 and 1e-2 at batch 32 (16x the elements)
-        if e.size >= 4096:            # (bias vectors are sums over every pixel: their few elements all carry the flips)
-            assert (e <= 5e-4).mean() >= 0.999, (n, float((e <= 5e-4).mean()))
-        assert e.max() < (2e-3 if B <= 2 else 1e-2), (n, float(e.max()))
+        # ReLU branches are pinned, so what is left is arithmetic: accumulation order and the rounding of the Winograd
+        # transforms, amplified by how ill-conditioned a gradient sum is (conv1_1 on zero-mean synthetic images: 180 000
+        # signed products per element).  A tensor outside the bound is settled against a float64 oracle: the fp32 CPU
+        # oracle is not exact either (observed up to 4.9e-3 of scale on conv5_3 from run to run — multi-threaded sums).
+        if not ok(e):
+            suspects.append(n)
+    if suspects:
+        assert B <= 2, suspects                      # (the float64 pass is only affordable on the small batch)
+        o64 = OracleSSD(model.state_dict(), num_classes=20, dtype=torch.float64)
+        for n in suspects:
+            o64.v[n].requires_grad_(True)
+        for b in range(B):
+            o64.masks = {k: v[b:b + 1] for k, v in tap.items() if v.shape[0] == B}
+            r = o64.forward_image(images[b], gts[b], overrides={'labels': pred['target']['cls'][b].cpu().numpy(),
+                                                                'targets': pred['target']['bbox_offsets'][b].cpu().numpy()})
+            (r['loss'] / B).backward()
+        for n in suspects:
+            exact = o64.v[n].grad.numpy().reshape(grads[n].shape)
+            scale = max(1e-6, np.abs(exact).max())
+            e_kernel = np.abs(grads[n].cpu().numpy() - exact) / scale
+            e_oracle = np.abs(oracle.v[n].grad.numpy().reshape(exact.shape) - exact).max() / scale
+            print('%s: kernels %.2e, fp32 CPU oracle %.2e of scale from the float64 gradient' % (n, e_kernel.max(), e_oracle))
+            assert ok(e_kernel) or e_kernel.max() <= e_oracle, (n, float(e_kernel.max()), float(e_oracle))
     assert worst > 0
 
 
+# Gradient bounds by Winograd variant (the 3x3 layers of the VGG trunk): F(4x4,3x3) — the default since round 3, 2x fewer GEMM
+# FLOPs than F(2x2,3x3) — has transforms that round at ~1e-5 of the tile scale instead of ~1e-6; on this un-normalised
+# random-init network the difference shows as single gradient elements at 1e-3 .. 3e-3 of their tensor's scale (F4) against
+# < 1e-3 (F2).  Losses and predictions hold the fp32 contract (1e-4) in both.
 def test_ssd_train_step_matches_oracle(ssd_setup):
     cfg, model, images, gts = ssd_setup
-    _ssd_step_vs_oracle(model, images, gts)
+    _ssd_step_vs_oracle(model, images, gts, grad_max=4e-3)
+
+
+def test_ssd_train_step_matches_oracle_with_winograd_f2(ssd_setup, K):
+    cfg, model, images, gts = ssd_setup
+    K.set_option('wino_m', 2)
+    try:
+        _ssd_step_vs_oracle(model, images, gts, grad_max=1e-3)
+    finally:
+        K.set_option('wino_m', 4)
 
 
 def test_ssd_train_step_matches_oracle_at_config3_batch32(ssd_setup):

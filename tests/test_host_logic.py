@@ -90,6 +90,57 @@ def test_trainable_variable_selection_resnet():
         TruncatedBaseNetwork(C.Config({'architecture': 'lenet'}))
 
 
+def test_storage_dtype_key_selects_the_half_storage_layers():
+    """Extension key model.base_network.storage_dtype (BASELINE configs[4]; SURVEY.md 8(d): fp16 activations / weights, fp32
+    master weights): which layers become half-storage layers is host logic."""
+    from luminoth_amd.models.base import layers as L
+    from luminoth_amd.models.base.truncated_base_network import TruncatedBaseNetwork
+    base = {'architecture': 'resnet_v1_50', 'storage_dtype': 'bf16'}
+    net = TruncatedBaseNetwork(C.get_config({'model': {'type': 'fasterrcnn', 'base_network': base}}).model.base_network)
+    assert net.storage_dtype == 'bf16' and net.compute_dtype == 'bf16'          # half storage implies half MFMA operands
+    nodes = net.trunk.nodes
+    assert nodes[0].layer.storage is None and nodes[0].layer.cin == 3            # the fp32 stem convolution
+    assert isinstance(nodes[1], L.MaxPoolNode) and nodes[1].storage == 'bf16'    # the pool writes the first 16-bit tensor
+    hs = [l for n in nodes[2:] for l in n.layers]
+    assert hs == net._hs_layers and len(hs) == 42 and all(l.storage == 'bf16' and l.compute == 'bf16' for l in hs)
+    assert [l.hs_out_f32 for l in hs].count(True) == 1 and nodes[-1].conv3.hs_out_f32      # fp32 feature map handed on
+    assert L.HS_LOSS_SCALE == {'f16': 1024.0, 'bf16': 1.0}
+    plain = TruncatedBaseNetwork(C.get_config({'model': {'type': 'fasterrcnn', 'base_network': {
+        'architecture': 'resnet_v1_50'}}}).model.base_network)
+    assert plain.storage_dtype is None and not plain._hs_layers and all(l.storage is None for l in plain.trunk.all_layers())
+    with pytest.raises(ValueError):
+        TruncatedBaseNetwork(C.Config({'architecture': 'resnet_v1_50', 'storage_dtype': 'fp8'}))
+    with pytest.raises(ValueError):               # storage and compute types must agree
+        TruncatedBaseNetwork(C.Config({'architecture': 'resnet_v1_50', 'storage_dtype': 'f16', 'compute_dtype': 'bf16'}))
+    with pytest.raises(NotImplementedError):      # VGG trunks / the R101 tail keep fp32 tensors
+        TruncatedBaseNetwork(C.Config({'architecture': 'vgg_16', 'storage_dtype': 'f16'}))
+    with pytest.raises(NotImplementedError):
+        TruncatedBaseNetwork(C.get_config({'model': {'type': 'fasterrcnn', 'base_network': {
+            'storage_dtype': 'f16'}}}).model.base_network)
+
+
+def test_oracle_half_storage_layer_rounds_where_the_kernels_round():
+    """oracle/torch_ops.py HalfStorageConvFn (the restatement csrc/conv_hs.h is compared with): stored tensors are 16-bit
+    values, the loss scale is exact, and with rounding switched off it is the plain fp32 layer."""
+    import oracle.torch_ops as ot
+    torch.manual_seed(0)
+    x = torch.randn(1, 6, 7, 64).to(torch.float16).float().requires_grad_(True)
+    w = (torch.randn(3, 3, 64, 64) * 0.05).requires_grad_(True)
+    scale = (1 + 0.1 * torch.randn(64)).requires_grad_(True)
+    shift = (0.1 * torch.randn(64)).requires_grad_(True)
+    cfg = dict(quant='f16', stride=1, dilation=1, padding='SAME', act='relu', out_f32=False, round_dx=True, loss_scale=1024.0)
+    y = ot.HalfStorageConvFn.apply(x, w, scale, shift, None, None, cfg)
+    assert torch.equal(y, y.to(torch.float16).float())                      # the stored activation is an f16 value
+    gy = torch.randn_like(y) * 1e-6                                          # gradient-sized: below f16's normal range unscaled
+    dx, dw = torch.autograd.grad(y, [x, w], gy)
+    assert torch.equal(dx * 1024.0, (dx * 1024.0).to(torch.float16).float())   # round_dx: a 16-bit tensor times 2^-10
+    y32 = torch.relu(ot.conv2d_nhwc(x, w.to(torch.float16).float(), 1, 1, 'SAME') * scale + shift)
+    assert float((y - y32).abs().max()) <= 2.0 ** -11 * float(y32.abs().max()) * 1.001
+    dx32, dw32 = torch.autograd.grad(y32, [x, w], gy)
+    assert float((dw - dw32).abs().max()) <= 2e-3 * float(dw32.abs().max())    # operand rounding only: the scale kept 1e-6 alive
+    assert float(dw.abs().max()) > 0
+
+
 def test_param_store_layout_cpu():
     from luminoth_amd.params import ParamStore
     st = ParamStore()
