@@ -136,6 +136,8 @@ const char* lmh_conv2d_profile_last(double* flops);
 /* Compulsory HBM bytes of that launch: every operand tensor read once + the result written once (fp32). */
 double lmh_conv2d_profile_last_bytes(void);
 /* HIP events for hosts without a HIP binding (ctypes): create / destroy / elapsed ms (synchronises on e1). */
+/* `waiter` waits for everything enqueued on `signaler` so far (event record + stream wait on an internal event ring). */
+int lmh_stream_wait_stream(lmh_stream_t waiter, lmh_stream_t signaler);
 void* lmh_event_create(void);
 void lmh_event_destroy(void* e);
 float lmh_event_elapsed_ms(void* e0, void* e1);

@@ -126,6 +126,7 @@ SIGNATURES = {
     'lmh_bn_param_grads': (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i64, c_i, c_f, c_f, c_sz, c_f]),
     'lmh_maxpool_fwd': (c_i, [c_f] + [c_i] * 10 + [c_f, c_f]),
     'lmh_maxpool_bwd': (c_i, [c_f, c_f, c_f] + [c_i] * 10 + [c_f, c_f]),
+    'lmh_stream_wait_stream': (c_i, [c_f, c_f]),
     'lmh_conv2d_hs_supported': (c_i, [P(ConvDesc)]),
     'lmh_conv2d_fwd_hs': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f]),
     'lmh_conv2d_bwd_data_hs': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_float, c_f]),

@@ -30,8 +30,40 @@ def _p(t):
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)   # ~10x cheaper than current_stream()
 
 
+_stream_override = None      # raw hipStream_t every launch of this module goes to while set (launch_on)
+_stream_override_obj = None  # ... and its torch.cuda.Stream (allocations that must belong to that stream)
+
+
+class launch_on(object):
+    """`with launch_on(stream):` — the kernels of this module launched inside go to `stream` (a torch.cuda.Stream) WITHOUT
+    making it torch's current stream: ~5 us cheaper per use than `with torch.cuda.stream(...)`, which the train step would
+    pay once per trainable layer.  Only for code that launches through this module and allocates nothing stream-bound
+    (persistent workspaces are keyed by the effective stream)."""
+    __slots__ = ('h', 'stream', 'prev')
+
+    def __init__(self, stream):
+        self.h, self.stream = stream.cuda_stream, stream
+
+    def __enter__(self):
+        global _stream_override, _stream_override_obj
+        self.prev = (_stream_override, _stream_override_obj)
+        _stream_override, _stream_override_obj = self.h, self.stream
+
+    def __exit__(self, *a):
+        global _stream_override, _stream_override_obj
+        _stream_override, _stream_override_obj = self.prev
+
+
+def stream_wait(waiter, signaler):
+    """waiter.wait_stream(signaler) through the C library (one ctypes call, no Event object)."""
+    check(_lib.load().lmh_stream_wait_stream(ctypes.c_void_p(waiter.cuda_stream), ctypes.c_void_p(signaler.cuda_stream)),
+          'lmh_stream_wait_stream')
+
+
 def _stream_id(device=None):
     """Raw hipStream_t (int) of torch's CURRENT stream on `device` (default: current device)."""
+    if _stream_override is not None:
+        return _stream_override
     if _raw_stream is not None:
         idx = torch.cuda.current_device() if device is None or device.index is None else device.index
         return _raw_stream(idx)
@@ -64,7 +96,13 @@ def _workspace(nbytes, device, tag):
     key = (tag, device, _stream_id(device))
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        # (re)allocated from the pool of the stream that uses it: the block a grown workspace replaces is then only ever
+        # recycled in that stream's order — under launch_on torch's current stream is not the launch stream
+        if _stream_override_obj is not None:
+            with torch.cuda.stream(_stream_override_obj):
+                ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        else:
+            ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
 

@@ -52,6 +52,9 @@ class SideStream(object):
     inline_layers = int(os.environ.get('LUMINOTH_AMD_INLINE_LAYERS', '4'))
     layers_left = 0
     _streams = {}      # (device, issuing stream) -> stream (the fused train step issues from two streams)
+    # tensors a side stream still reads (x, g of a layer whose weight gradient is queued there): references held until
+    # join() instead of three tensor.record_stream calls per layer — nothing is freed, so nothing can be recycled early
+    _held = []
 
     @classmethod
     def get(cls, device):
@@ -66,6 +69,10 @@ class SideStream(object):
     def join(cls):
         for st in cls._streams.values():
             torch.cuda.current_stream(st.device).wait_stream(st)
+        # the joining stream is now ordered behind every side-stream reader, so the allocator may have the tensors back: a
+        # freed block is only reused by later allocations of its OWN stream — the stream that just joined, or the proposal
+        # stream, which waits for the joining stream before it allocates again (start of the next step)
+        cls._held = []
 
 
 class ConvLayer(object):
@@ -263,11 +270,10 @@ class ConvLayer(object):
             if SideStream.enabled and not inline:
                 main = torch.cuda.current_stream(x.device)
                 side = SideStream.get(x.device)
-                side.wait_stream(main)                  # dy / g are ready once `main` gets here
-                with torch.cuda.stream(side):
+                K.stream_wait(side, main)               # dy / g are ready once `main` gets here
+                with K.launch_on(side):
                     self._weight_grads(d, x, g, yact, cs)
-                for t in (x, g, yact):                  # keep the buffers alive for the side stream
-                    K.keep_alive(t, side)
+                SideStream._held.append((x, g, yact))   # keep the buffers alive for the side stream (until join)
             else:
                 self._weight_grads(d, x, g, yact, cs)
         if need_dx and not inline:
