@@ -689,7 +689,11 @@ static int hs_launch(const lmh_conv_desc* d, const void* A, const void* B, const
   const int64_t M = BWD ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->OH * d->OW;
   const int NC = BWD ? d->C : d->K;
   int bm, bn;
-  pick_tile(M, NC, &bm, &bn, 512);      // two resident blocks per CU
+  // 128 x 64 once it still gives every CU a block (fewer, longer tiles: the RPN 3x3 backward 161 -> 141 us, block3
+  // 256->1024 forward 16.2 -> 14.5 us), else 64 x 64; 128 x 128 (one block per CU) never won (scripts/bench_conv_hs.py --sweep)
+  if (g_force_bm && g_force_bn) { bm = g_force_bm; bn = g_force_bn; }
+  else if (((M + 127) / 128) * ((NC + 63) / 64) >= 256) { bm = 128; bn = 64; }
+  else { bm = 64; bn = 64; }
   const int grid = (int)(((M + bm - 1) / bm) * ((NC + bn - 1) / bn));
 #define LAUNCH_HS(DT_, BM_, BN_)                                                                             \
   hipLaunchKernelGGL((k_conv_hs<DT_, BM_, BN_, BWD>), dim3(grid), dim3(256), 0, st, *d,                         \
@@ -747,6 +751,14 @@ static bool wgrad_hs_plan(const lmh_conv_desc* d, int* bm, int* bn, int* splits,
   int want = (int)((slots + tiles - 1) / tiles);
   const int max_split = KT / 4 > 0 ? (KT / 4 < 64 ? KT / 4 : 64) : 1;
   if (want > max_split) want = max_split;
+  // every split writes an fp32 slab of the whole gradient, and the tail reads it again: keep the slabs within 4x the
+  // operand bytes (RPN 3x3: 18.9 MB per split against 25.8 MB of operands -> 5 splits; k_tail_reduce fetched 554 MB per
+  // launch before this cap, profiles/r03_f16hs_pmc_traffic.json)
+  const double operand_bytes = 2.0 * (double)P * (d->C + d->K);
+  const double slab_bytes = 4.0 * d->R * d->S * (double)d->C * d->K;
+  const int capf = lmh_opt("hs_slab_cap");          // 0: no cap
+  const int cap = (int)((double)capf * operand_bytes / slab_bytes);
+  if (capf > 0 && want > cap) want = cap;
   if (want < 1) want = 1;
   if (g_force_splits) want = g_force_splits < KT ? g_force_splits : KT;
   *kt_per_split = (KT + want - 1) / want;
