@@ -35,7 +35,6 @@ __device__ __attribute__((aligned(64))) float lmh_zero_page[16];  // zero-initia
 
 #include "conv_fast.h"
 #include "conv_wgrad1x1.h"
-#include "conv_fc_small.h"
 #include "conv_half.h"
 
 // ============================================================================
@@ -234,15 +233,6 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
     LMH_CHECK_LAUNCH();
     return LMH_OK;
   }
-  if (fc_small_ok(d) && in_sub == nullptr && !g_force_bm) {       // skinny Linear layer (conv_fc_small.h)
-    const int Mr = d->N * d->H * d->W;
-    prof_begin(st);
-    hipLaunchKernelGGL(k_fc_small_fwd, dim3((Mr + FCS_ROWS - 1) / FCS_ROWS), dim3(256), (size_t)FCS_ROWS * d->C * sizeof(float),
-                       st, x, w, scale, shift, residual, Mr, d->C, d->K, d->act, y);
-    prof_end(st, desc_flops(d), "k_fc_small_fwd");
-    LMH_CHECK_LAUNCH();
-    return LMH_OK;
-  }
 #define LAUNCH_FWD(BM_, BN_)                                                                              \
   do {                                                                                                    \
     if (fast)                                                                                             \
@@ -321,15 +311,6 @@ static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const
 #undef LAUNCH_BD_HT
 #undef LAUNCH_BD_H
     prof_end(st, desc_flops(d), "k_conv_bwd_data_h<%d, %d, %d>", d->compute, bm, bn);
-    LMH_CHECK_LAUNCH();
-    return LMH_OK;
-  }
-  if (fc_small_ok(d) && !yact && !g_force_bm) {
-    const int Mr = d->N * d->H * d->W;
-    prof_begin(st);
-    hipLaunchKernelGGL(k_fc_small_bwd_data, dim3((Mr + FCS_ROWS - 1) / FCS_ROWS), dim3(256),
-                       (size_t)FCS_ROWS * d->K * sizeof(float), st, dy, w, kscale, addend, Mr, d->C, d->K, dx);
-    prof_end(st, desc_flops(d), "k_fc_small_bwd_data");
     LMH_CHECK_LAUNCH();
     return LMH_OK;
   }
@@ -420,7 +401,7 @@ static void wgrad_1x1_plan(const lmh_conv_desc* d, int* bm, int* bn, int* nbuf, 
 }
 
 extern "C" int lmh_conv2d_bwd_weight_fuses_colsum(const lmh_conv_desc* d) {
-  return d && ((bwd_weight_fast(d) && (d->compute == 0 || d->compute == 3)) || fc_small_ok(d)) ? 1 : 0;
+  return d && bwd_weight_fast(d) && (d->compute == 0 || d->compute == 3) ? 1 : 0;
 }
 
 extern "C" int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op) {
@@ -491,16 +472,6 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
   g_prof_pending_bytes = gb ? 4.0 * d->R * d->S * ((double)d->H * d->C + (double)d->H * d->K + (double)d->C * d->K)
                             : desc_bytes(d);
   int bm, bn, splits, kps;
-  if (!gb && !yact && fc_small_ok(d) && !g_force_bm) {      // skinny Linear layer: one thread per weight
-    const int Mr = d->N * d->H * d->W;
-    prof_begin(stream);
-    hipLaunchKernelGGL(k_fc_small_bwd_weight, dim3((d->C * d->K + 255) / 256, colsum ? 2 : 1), dim3(256), 0, stream, x, dy,
-                       Mr, d->C, d->K, dw, colsum);
-    prof_end(stream, desc_flops(d), "k_fc_small_bwd_weight");
-    if (g_lmh_defer_tail) g_lmh_last_plan = lmh_tail_plan{nullptr, 0, nullptr, 0};
-    LMH_CHECK_LAUNCH();
-    return LMH_OK;
-  }
   if (!gb && !yact && wgrad_1x1_ok(d)) {       // pure TN GEMM: direct-to-LDS kernel
     int nbuf;
     wgrad_1x1_plan(d, &bm, &bn, &nbuf, &splits, &kps);

@@ -502,7 +502,7 @@ CONV_CASES = [
     (1, 5, 5, 128, 256, 3, 1, 1, 'VALID', 'relu'),
     (1, 1, 512, 1024, 81, 1, 1, 1, 'VALID', None),      # fc_classifier: K % 4 != 0 scalar paths
     (1, 1, 500, 1024, 320, 1, 1, 1, 'VALID', 'relu'),
-    (2, 1, 301, 1024, 81, 1, 1, 1, 'VALID', None),      # skinny-Linear kernels (conv_fc_small.h): rows % 8 != 0, odd row count
+    (2, 1, 301, 1024, 81, 1, 1, 1, 'VALID', None),      # Linear layer, 81 columns: rows % 8 != 0, odd row count
     (1, 1, 37, 256, 21, 1, 1, 1, 'VALID', 'relu'),      # ... with an activation, 21 columns (VOC classes + 1)
     (2, 18, 18, 1024, 24, 3, 1, 1, 'SAME', None),       # SSD multibox offsets head: 3x3, K % 32 != 0
     (2, 9, 9, 512, 126, 3, 1, 1, 'SAME', None),         # SSD multibox classes head: 3x3, K % 4 != 0
