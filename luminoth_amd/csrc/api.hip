@@ -28,8 +28,7 @@ static lmh_option g_options[] = {
     {"wgrad_glds", 1},        // 1x1 weight gradient: operands straight into LDS (conv_wgrad1x1.h)
     {"wg_slots", 512},        // ... its block count target
     {"wino_m", 4},            // Winograd output tile: 4 = F(4x4,3x3) (round 3 default), 2 = F(2x2,3x3)
-    {"hs_wgrad_tr", 1},       // half-storage weight gradient: 1 = direct-to-LDS + transposing LDS reads, 0 = register-staged
-    {"hs_slab_cap", 2},       // ... its split-K slabs stay within this multiple of the operand bytes (0: no cap)
+    {"hs_slab_cap", 2},       // half-storage weight gradient: split-K slabs stay within this multiple of the operand bytes (0: no cap)
     {"roi_cs", 0},            // ROI backward slab width (0: automatic, 4: force the 4-channel slab)
     {"roi_mean_cs", -1},      // fused ROI pool+mean (-1: automatic, 0: report unsupported, 4: force 4 channels)
 };

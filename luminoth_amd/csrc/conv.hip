@@ -744,9 +744,7 @@ extern "C" int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, c
   LMH_CHECK_ARG(x && g && dw);
   if (!hs_ok(d)) { lmh_set_error("lmh_conv2d_bwd_weight_hs: needs compute f16 / bf16, C %% 64 == 0, K %% 64 == 0"); return LMH_ERR_UNSUPPORTED; }
   int bm, bn, splits, kps;
-  const bool tr = lmh_opt("hs_wgrad_tr") != 0;
-  if (tr) wgrad_hs_plan(d, &bm, &bn, &splits, &kps);
-  else bwd_weight_plan(d, &bm, &bn, &splits, &kps);
+  wgrad_hs_plan(d, &bm, &bn, &splits, &kps);
   if (ws_bytes < lmh_conv2d_bwd_weight_workspace_bytes(d) || ((splits > 1 || colsum) && !ws)) {
     lmh_set_error("lmh_conv2d_bwd_weight_hs: workspace too small");
     return LMH_ERR_WORKSPACE;
@@ -759,11 +757,6 @@ extern "C" int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, c
   float* cpart = colsum ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + slab_bytes) : nullptr;
   const int tx = d->R * d->S * ((d->C + bm - 1) / bm), ty = (d->K + bn - 1) / bn;
   const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
-#define LAUNCH_BW_HS(DT_, BM_, BN_)                                                                          \
-  hipLaunchKernelGGL((k_conv_bwd_weight_hs<DT_, BM_, BN_>), dim3(tx * ty * splits), dim3(256), 0, st, *d,         \
-                     reinterpret_cast<const HT<DT_>::T*>(x), reinterpret_cast<const HT<DT_>::T*>(g), out, kps, dvw, dvh, \
-                     inv_scale, tx, ty, splits, cpart)
-#define LAUNCH_BW_HS_T(BM_, BN_) do { if (d->compute == 1) LAUNCH_BW_HS(1, BM_, BN_); else LAUNCH_BW_HS(2, BM_, BN_); } while (0)
   // 1x1 / stride 1: source pixel == output pixel, no decode in the loader
   const bool gather = !(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->OH == d->H &&
                         d->OW == d->W);
@@ -777,19 +770,10 @@ extern "C" int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, c
     else { if (gather) LAUNCH_BW_TR(2, BM_, true); else LAUNCH_BW_TR(2, BM_, false); }                        \
   } while (0)
   prof_begin(st);
-  if (tr) {
-    if (bm == 128) LAUNCH_BW_TR_T(128); else LAUNCH_BW_TR_T(64);
-    prof_end(st, desc_flops(d), "k_wgrad_hs_tr<%d, %d, %d, %s>", d->compute, bm, bn, gather ? "true" : "false");
-  } else {
-    if (bm == 128 && bn == 128) LAUNCH_BW_HS_T(128, 128);
-    else LAUNCH_BW_HS_T(64, 64);
-    prof_end(st, desc_flops(d), "k_conv_bwd_weight_hs<%d, %d, %d>", d->compute, bm == 128 && bn == 128 ? 128 : 64,
-             bm == 128 && bn == 128 ? 128 : 64);
-  }
+  if (bm == 128) LAUNCH_BW_TR_T(128); else LAUNCH_BW_TR_T(64);
+  prof_end(st, desc_flops(d), "k_wgrad_hs_tr<%d, %d, %d, %s>", d->compute, bm, bn, gather ? "true" : "false");
 #undef LAUNCH_BW_TR_T
 #undef LAUNCH_BW_TR
-#undef LAUNCH_BW_HS_T
-#undef LAUNCH_BW_HS
   if (g_lmh_defer_tail) {
     g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;
     g_lmh_last_plan.splits = splits > 1 ? splits : 0;

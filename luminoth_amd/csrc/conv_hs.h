@@ -19,9 +19,9 @@
 // Tile: BM x BN outputs, BK = 64 reduction elements per stage, a ring of 3-4 LDS stages of [BM + BN][64] halfs filled by
 // direct-to-LDS loads (k_conv_hs).
 //
-// The weight gradient keeps the staging map of k_conv_bwd_weight_h (both operands are pixel-major, so a thread loads a
-// 4 pixel x 4 channel block and writes four k-contiguous quads) with 8-byte loads and a v_perm transpose instead of
-// 16-byte loads and v_cvt; the per-channel sums of g (dbeta / dbias) are taken from the B tile while it is in LDS.
+// The weight gradient (k_wgrad_hs_tr, below) reduces over pixels: both operands are pixel-major, its tiles land in LDS
+// lane-linearly and are transposed by the LDS read itself.  (A first version transposed 4 x 4 blocks in registers with
+// v_perm, the staging map of k_conv_bwd_weight_h: 880 us over the 17 distinct layers against 650 us now.)
 #pragma once
 #include "conv_half.h"
 
@@ -282,111 +282,8 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
   }
 }
 
-// 4 (pixel) x 4 (channel) block of halfs, one uint2 per pixel -> four k-contiguous quads (one per channel)
-__device__ __forceinline__ uint32_t hs_pack_lo(uint32_t e0, uint32_t e1) { return __builtin_amdgcn_perm(e1, e0, 0x05040100u); }
-template <typename HTT>
-__device__ __forceinline__ void hs_st_km(HTT* __restrict__ S, int col0, int kq4, const uint2 (&r)[4]) {
-  *reinterpret_cast<uint2*>(&S[(col0 + 0) * LDH + 4 * kq4]) = make_uint2(hs_pack_lo(r[0].x, r[1].x), hs_pack_lo(r[2].x, r[3].x));
-  *reinterpret_cast<uint2*>(&S[(col0 + 1) * LDH + 4 * kq4]) = make_uint2(pack_hi(r[0].x, r[1].x), pack_hi(r[2].x, r[3].x));
-  *reinterpret_cast<uint2*>(&S[(col0 + 2) * LDH + 4 * kq4]) = make_uint2(hs_pack_lo(r[0].y, r[1].y), hs_pack_lo(r[2].y, r[3].y));
-  *reinterpret_cast<uint2*>(&S[(col0 + 3) * LDH + 4 * kq4]) = make_uint2(pack_hi(r[0].y, r[1].y), pack_hi(r[2].y, r[3].y));
-}
-
-// backward weight:  dw[rs][c][k] = inv_scale * sum_p x[pix(p,r,s)][c] * g[p][k]  (fp32, RAW: w.r.t. the un-scaled
-// convolution output, like every other weight-gradient kernel here); split over the pixels, slabs reduced by
-// k_splitk_reduce.  colpart [splits][K]: partial per-channel sums of g (already multiplied by inv_scale).
-template <int DT, int BM, int BN>
-__global__ void __launch_bounds__(256, 2)
-k_conv_bwd_weight_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const typename HT<DT>::T* __restrict__ g,
-                     float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh, float inv_scale,
-                     int tiles_x, int tiles_y, int splits, float* __restrict__ colpart) {
-  typedef typename HT<DT>::T HTT;
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;
-  constexpr int LDC = BN + 4;
-  __shared__ __attribute__((aligned(16))) float smem[half_smem<DT, BM, BN, 1>::floats];
-  HTT* const As = reinterpret_cast<HTT*>(smem);
-  HTT* const Bs = As + 2 * A_SZ;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int P = d.N * d.OH * d.OW, K = d.K, C = d.C;
-  const int lin = xcd_remap(blockIdx.x, tiles_x * tiles_y * splits);
-  const int bz = lin / (tiles_x * tiles_y), rem = lin - bz * (tiles_x * tiles_y);
-  const int tiles_c = (C + BM - 1) / BM;
-  const int by = rem / tiles_x, bx = rem - by * tiles_x;
-  const int rs = bx / tiles_c, m0 = (bx % tiles_c) * BM;
-  const int n0 = by * BN;
-  const int r = rs / d.S, s = rs - r * d.S;
-  const int KT_all = (P + BK - 1) / BK;
-  const int kt_begin = bz * kt_per_split;
-  const int kt_end = min(KT_all, kt_begin + kt_per_split);
-  const int dh0 = r * d.dilation - d.pad_top, dw0 = s * d.dilation - d.pad_left;
-  const int kq = tid & 7, cq = tid >> 3;
-  const bool a_act = cq < BM / 4, b_act = cq < BN / 4;
-  const bool a_ok = a_act && (m0 + 4 * cq) < C, b_ok = b_act && (n0 + 4 * cq) < K;
-  const HTT* xb = x + m0 + 4 * cq;
-  const HTT* gb = g + n0 + 4 * cq;
-  const HTT* const zero = reinterpret_cast<const HTT*>(lmh_zero_page);
-  int p0 = kt_begin * BK + 4 * kq;
-  uint2 ra[2][4], rb[2][4];               // two register sets: the loads of tiles t+2 and t+3 fly while tile t is multiplied
-  auto step = [&]() { p0 += BK; };
-  auto load = [&](auto S) {
-    constexpr int s_ = decltype(S)::value;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned p = (unsigned)(p0 + i);
-      const unsigned t = lmh_div(p, div_ow), ow = p - t * (unsigned)d.OW;
-      const unsigned n = lmh_div(t, div_oh), oh = t - n * (unsigned)d.OH;
-      const int ih = (int)oh * d.stride + dh0, iw = (int)ow * d.stride + dw0;
-      const bool oka = a_ok && n < (unsigned)d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-      const HTT* pa_ = oka ? xb + ((size_t)((int)n * d.H + ih) * d.W + iw) * C : zero;
-      if (a_act) ra[s_][i] = *reinterpret_cast<const uint2*>(pa_);
-      const bool okb = b_ok && (int)p < P;
-      const HTT* pb_ = okb ? gb + (size_t)p * K : zero;
-      if (b_act) rb[s_][i] = *reinterpret_cast<const uint2*>(pb_);
-    }
-  };
-  auto store = [&](int buf, auto S) {
-    constexpr int s_ = decltype(S)::value;
-    if (a_act) hs_st_km<HTT>(As + buf * A_SZ, 4 * cq, kq, ra[s_]);
-    if (b_act) hs_st_km<HTT>(Bs + buf * B_SZ, 4 * cq, kq, rb[s_]);
-  };
-  f32x16 acc[TM][TN];
-  zero_acc<TM, TN>(acc);
-  const bool do_col = colpart != nullptr && bx == 0 && tid < BN;      // tap 0, first channel tile: one tile column
-  float csum = 0.f;
-  auto mma = [&](int buf) {
-    if (do_col) {
-      const HTT* row = Bs + buf * B_SZ + tid * LDH;
-#pragma unroll
-      for (int q = 0; q < BK / 8; ++q) {
-        const typename HT<DT>::V8 v = *reinterpret_cast<const typename HT<DT>::V8*>(row + 8 * q);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) csum += (float)v[i];
-      }
-    }
-    mfma_stage_h<DT, TM, TN>(As + buf * A_SZ, Bs + buf * B_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane, A_SZ, B_SZ);
-  };
-  const int n_st = kt_end - kt_begin;
-  HALF_PIPELINE(2, n_st);
-  if (do_col && n0 + tid < K) colpart[(size_t)bz * K + n0 + tid] = csum * inv_scale;
-  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
-  __syncthreads();
-  float* o = out + (size_t)bz * ((size_t)d.R * d.S * C * K) + (size_t)rs * C * K;
-  constexpr int CT = BN / 4, RSTEP = 256 / CT;
-  const int c4 = tid % CT, r0 = tid / CT;
-  const int col = n0 + 4 * c4;
-  if (col < K) {
-    for (int rr = r0; rr < BM; rr += RSTEP) {
-      const int row = m0 + rr;
-      if (row >= C) break;
-      *reinterpret_cast<f32x4*>(o + (size_t)row * K + col) = *reinterpret_cast<const f32x4*>(&smem[rr * LDC + 4 * c4]) * inv_scale;
-    }
-  }
-}
-
 // ============================================================================
-// Weight gradient, second form: operands straight into LDS, fragments by the transposing LDS read.
+// Weight gradient: operands straight into LDS, fragments by the transposing LDS read.
 //
 // Both operands are pixel-major, so a [64 pixel][BM channel] tile of x (and of g) is a set of contiguous row segments — the
 // lane-linear image global_load_lds writes — but an MFMA fragment wants 8 consecutive PIXELS of one channel per lane.
