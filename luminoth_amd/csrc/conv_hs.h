@@ -6,7 +6,7 @@
 // and goes from HBM to LDS as eight 16-byte pieces with no arithmetic in between.
 //
 // Forward and backward-data are ONE kernel: both are gather-GEMMs whose two operands are contiguous along the reduction
-// axis once the weight copy has the right layout — the optimizer's cast pass (k_half_weights, elementwise.hip) writes
+// axis once the weight copy has the right layout — the cast pass of the optimizer step (k_half_weights, halfstore.hip) writes
 //     w_fwd[k][r][s][c] = q(w[r][s][c][k])                  ("OHWI": a row = everything one output channel multiplies)
 //     w_bwd[r][s][c][k] = q(w[r][s][c][k] * bn_scale[k])    (HWIO with the frozen-BatchNorm scale folded in)
 // so neither pass transposes anything:
