@@ -103,6 +103,36 @@ k_sort_global(uint64_t* __restrict__ keys, int n_pad, int k, int j) {
   if ((a > b) == asc) { kb[i] = b; kb[i + j] = a; }
 }
 
+// S consecutive global compare-exchange passes of merge step k (strides j, j/2, ..., j >> (S-1), all >= chunk) in ONE launch:
+// a thread owns the 2^S keys that differ in exactly those S index bits and runs the S passes on them in registers.  The
+// proposal sort of 65 536 keys needs 10 global passes; with up to 4 per launch they are 4 launches instead of 10 on the
+// latency chain the main stream waits for.
+template <int S>
+__global__ void __launch_bounds__(256)
+k_sort_global_multi(uint64_t* __restrict__ keys, int n_pad, int k, int j) {
+  __builtin_amdgcn_s_setprio(3);
+  constexpr int E = 1 << S;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_pad / E) return;
+  uint64_t* kb = keys + (size_t)blockIdx.y * n_pad;
+  const int jl = j >> (S - 1);                          // lowest stride of the group
+  const int low = t & (jl - 1);
+  const int base = ((t - low) << S) | low;              // index with the S bits log2(jl) .. log2(j) clear
+  const bool asc = ((base & k) == 0);                   // bit k lies above every stride of the step
+  uint64_t v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = kb[base + e * jl];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int bit = 1 << (S - 1 - s);                   // element-index bit of stride j >> s
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (!(e & bit)) cmp_swap(v[e], v[e | bit], asc);
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) kb[base + e * jl] = v[e];
+}
+
 // Finish merge step k inside each chunk (strides chunk/2 .. 1) in LDS.
 __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_merge_local(uint64_t* __restrict__ keys, int n_pad, int chunk, int k) {
@@ -130,9 +160,17 @@ int lmh_sort_u64_impl(uint64_t* keys, int B, int n_pad, hipStream_t st) {
   dim3 gl(n_pad / chunk, B);
   hipLaunchKernelGGL(k_sort_local, gl, dim3(SORT_THREADS), lds, st, keys, n_pad, chunk);
   for (int k = chunk * 2; k <= n_pad; k <<= 1) {
-    for (int j = k >> 1; j >= chunk; j >>= 1) {
-      dim3 gg((n_pad / 2 + 255) / 256, B);
-      hipLaunchKernelGGL(k_sort_global, gg, dim3(256), 0, st, keys, n_pad, k, j);
+    int j = k >> 1;
+    while (j >= chunk) {
+      int ns = 0;                                       // passes left in this step: strides j, j/2, ..., chunk
+      for (int q = j; q >= chunk; q >>= 1) ++ns;
+      const int S = ns >= 4 ? 4 : ns;
+      dim3 gg((n_pad / (1 << S) + 255) / 256, B);
+      if (S == 4) hipLaunchKernelGGL(k_sort_global_multi<4>, gg, dim3(256), 0, st, keys, n_pad, k, j);
+      else if (S == 3) hipLaunchKernelGGL(k_sort_global_multi<3>, gg, dim3(256), 0, st, keys, n_pad, k, j);
+      else if (S == 2) hipLaunchKernelGGL(k_sort_global_multi<2>, gg, dim3(256), 0, st, keys, n_pad, k, j);
+      else hipLaunchKernelGGL(k_sort_global, gg, dim3(256), 0, st, keys, n_pad, k, j);
+      j >>= S;
     }
     hipLaunchKernelGGL(k_sort_merge_local, gl, dim3(SORT_THREADS), lds, st, keys, n_pad, chunk, k);
   }

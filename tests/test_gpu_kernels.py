@@ -40,7 +40,7 @@ def K():
 
 
 # ------------------------------------------------------------------ sort ----
-@pytest.mark.parametrize('n', [2, 64, 4096, 8192, 65536])
+@pytest.mark.parametrize('n', [2, 64, 4096, 8192, 16384, 32768, 65536, 262144])   # 1, 2, 3, 4 and 4 + 2 fused global passes
 def test_sort_u64(K, n):
     rs = np.random.RandomState(n)
     keys = rs.randint(0, 2 ** 62, size=(3, n), dtype=np.int64)
