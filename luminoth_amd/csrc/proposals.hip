@@ -267,9 +267,9 @@ k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts,
 //          REGISTERS (one 128-byte read per row, issued before anything depends on it);
 //      (2) the removed-words of the super-chunk start as the OR of those 16 words over every row kept so far
 //          (<= max_out rows x 128 contiguous bytes: one fully parallel gather per super-chunk, not per chunk);
-//      (3) the 16 chunks are then resolved back to back without touching global memory: wave c resolves chunk c (its
-//          lanes hold exactly the diagonal word of their rows), kept lanes OR their later words into the LDS bitmap
-//          with ds_or_b64, one block barrier per chunk.
+//      (3) the 16 chunks are then resolved back to back without touching global memory by ONE wave that reads the rows'
+//          words out of LDS (stored word-major: lane-consecutive, conflict-free); kept lanes OR their later words into the
+//          LDS bitmap with ds_or_b64.  No block barrier inside a super-chunk (round 2 had one per chunk).
 //    Global round trips: 2 per 1024 candidates instead of 1 per 64.
 #define NMS_RED_THREADS 1024
 #define NMS_SC_WORDS 16
@@ -283,6 +283,7 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
   __shared__ int s_tot[NMS_SC_WORDS];          // running total AFTER chunk c of the current super-chunk (one slot per chunk:
                                                // no slot is rewritten before every wave has read it and passed a barrier)
   __shared__ int32_t s_kidx[NMS_LDS_KEEP];     // LDS mirror of the kept indices (one global latency less in (2))
+  __shared__ unsigned long long sdT[NMS_SC_WORDS * NMS_RED_THREADS];   // [word][row] of the current super-chunk: 128 KB
   const bool lds_keep = max_out <= NMS_LDS_KEEP;
   const int b = blockIdx.x;
   const int cnt = min(counts[b], K);
@@ -304,6 +305,9 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
       const bool ok = row < cnt && j < nw && (w0 + j) >= (row >> 6);
       d[j] = ok ? mb[(size_t)row * W + w0 + j] : 0ull;
     }
+    // (1b) ... and leaves them in LDS word-major (lane-consecutive: conflict-free) for the wave that resolves the chunks
+#pragma unroll
+    for (int j = 0; j < NMS_SC_WORDS; ++j) sdT[j * NMS_RED_THREADS + tid] = d[j];
     // (2) removed-words of this super-chunk from every row kept so far (rows < r0: all their words here are valid)
     if (tid < NMS_SC_WORDS) rem[tid] = 0ull;
     __syncthreads();
@@ -326,13 +330,16 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
         if (v[u]) atomicOr(&rem[wj[u]], (unsigned long long)v[u]);
     }
     __syncthreads();
-    // (3) the chunks of this super-chunk, wave c resolves chunk c
+    // (3) the chunks of this super-chunk, resolved back to back by ONE wave out of LDS — no block barrier per chunk (round 3:
+    //     16 barriers of a 1024-thread block per super-chunk were most of what was left of this kernel)
     bool done = false;
-    for (int c = 0; c < nw; ++c) {
-      if (wave == c) {
-        const uint64_t diag = d[c];
+    if (wave == 0) {
+      int tot = total;
+      for (int c = 0; c < nw; ++c) {
+        const int rl = c * 64 + lane;                       // this lane's row inside the super-chunk
+        const uint64_t diag = sdT[c * NMS_RED_THREADS + rl];
         const int nin = min(64, cnt - (w0 + c) * 64);
-        uint64_t alive_v = ~rem[c];
+        uint64_t alive_v = ~(*reinterpret_cast<volatile unsigned long long*>(&rem[c]));
         if (nin < 64) alive_v &= ((1ull << nin) - 1ull);
         // Greedy NMS inside the chunk as a parallel fixed point instead of a 64-step serial scan (a dependent chain
         // of ~200 cycles per kept box on one wave: 2000 keeps = the whole 360 us of round 1's kernel).  Candidate i is
@@ -349,25 +356,26 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
           if (next == kept) break;
           kept = next;
         }
-        const int base = total;
-        const int room = max_out - base;
+        const int room = max_out - tot;
         if (__popcll(kept) > room)                      // the scan stops at max_out: keep the first `room` of them
           kept = __ballot(((kept >> lane) & 1ull) && __popcll(kept & below) < room);
-        const int new_total = base + __popcll(kept);
         if ((kept >> lane) & 1ull) {
-          const int slot = base + __popcll(kept & ((1ull << lane) - 1ull));
+          const int slot = tot + __popcll(kept & below);
           kidx[slot] = (w0 + c) * 64 + lane;              // kept indices, in order
           if (lds_keep) s_kidx[slot] = (w0 + c) * 64 + lane;
-#pragma unroll
-          for (int j = 0; j < NMS_SC_WORDS; ++j)          // suppress later candidates of this super-chunk
-            if (j > c && d[j]) atomicOr(&rem[j], (unsigned long long)d[j]);
+          for (int j = c + 1; j < nw; ++j) {              // suppress later candidates of this super-chunk
+            const uint64_t v = sdT[j * NMS_RED_THREADS + rl];
+            if (v) atomicOr(&rem[j], (unsigned long long)v);
+          }
         }
-        if (lane == 0) s_tot[c] = new_total;
+        tot += __popcll(kept);
+        if (tot >= max_out) break;
       }
-      __syncthreads();
-      total = s_tot[c];
-      if (total >= max_out) { done = true; break; }
+      if (lane == 0) s_tot[0] = tot;
     }
+    __syncthreads();
+    total = s_tot[0];
+    done = total >= max_out;
     if (done) break;
     // the kept indices written above are read back (kidx) by the next super-chunk's gather: same block, global memory
     __threadfence_block();
