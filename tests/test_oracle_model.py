@@ -66,3 +66,34 @@ def test_oracle_fp64_and_pinned_masks(arch, okw):
     a3 = o32.forward_image(images[0], gts[0], seed, overrides=ov)
     np.testing.assert_array_equal(a2['feat'].detach().numpy(), a3['feat'].detach().numpy())
     np.testing.assert_array_equal(a2['rcnn_cls_score'].detach().numpy(), a3['rcnn_cls_score'].detach().numpy())
+
+
+@pytest.mark.parametrize('storage,loss_tol,cos_tol', [('f16', 5e-3, 0.999), ('bf16', 4e-2, 0.99)])
+def test_oracle_half_storage_mode_tracks_the_fp32_oracle(storage, loss_tol, cos_tol):
+    """oracle/model.py `storage=` (the restatement of the half-storage trunk, csrc/conv_hs.h): same variables and trainable
+    set as the fp32 oracle, losses within the rounding of 16-bit activations, trunk gradients pointing the same way — and the
+    model side of the same switch (`model.base_network.storage_dtype`) selects the same 42 trunk layers + the RPN convolution."""
+    model = _model('resnet_v1_50', 20, **{'model.base_network.storage_dtype': storage})
+    assert model.base_network.storage_dtype == storage and len(model.base_network._hs_layers) == 42
+    assert model._rpn._rpn.storage == storage and model.base_network.extra_hs_layers == [model._rpn._rpn]
+    sd = model.state_dict()
+    sd['truncated_base_network/resnet_v1_50/conv1/BatchNorm/moving_variance'].fill_(73.6 ** 2 * 2)
+    images, gts = synth(1, 96, 128, 2, 20, 11)
+    seed = orng.image_seed(0, 0, 0)
+    o32 = OracleFasterRCNN(sd, arch='resnet_v1_50', num_classes=20, seed=0)
+    oh = OracleFasterRCNN(sd, arch='resnet_v1_50', num_classes=20, seed=0, storage=storage)
+    assert oh.compute == storage and sorted(oh.trainable_names()) == sorted(o32.trainable_names())
+    name = 'truncated_base_network/resnet_v1_50/block3/unit_2/bottleneck_v1/conv2/weights'
+    for o in (o32, oh):
+        o.v[name].requires_grad_(True)
+    a = o32.forward_image(images[0], gts[0], seed)
+    ov = dict(rois=a['rois'], roi_labels=a['roi_labels'], roi_targets=a['roi_targets'], proposals=a.get('proposals'))
+    ov = {k: v for k, v in ov.items() if v is not None}
+    b = oh.forward_image(images[0], gts[0], seed, overrides=ov)
+    assert b['feat'].dtype == torch.float32
+    for k in ('rpn_cls_loss', 'rpn_reg_loss', 'rcnn_cls_loss', 'rcnn_reg_loss'):
+        assert abs(float(a[k]) - float(b[k])) <= loss_tol * max(1.0, abs(float(a[k]))), (k, float(a[k]), float(b[k]))
+    ga, = torch.autograd.grad(a['rpn_cls_loss'] + a['rcnn_cls_loss'], [o32.v[name]])
+    gb, = torch.autograd.grad(b['rpn_cls_loss'] + b['rcnn_cls_loss'], [oh.v[name]])
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert cos >= cos_tol, cos
