@@ -1,3 +1,6 @@
+"""Accuracy of the half-storage convolution kernels (csrc/conv_hs.h) against float64 references on the SAME 16-bit operands,
+beside the native fp32-MFMA kernel on those operands: the f16 / bf16 MFMA accumulates at least as accurately as the fp32 one
+(forward 5e-7 vs 1.8e-6 of the output scale), and 99.9 % of the stored 16-bit results equal the rounded float64 result."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
