@@ -141,6 +141,29 @@ def test_oracle_half_storage_layer_rounds_where_the_kernels_round():
     assert float(dw.abs().max()) > 0
 
 
+def test_launch_stream_override_nests_and_restores():
+    """kernels.launch_on: the launch-stream override used for the weight-gradient stream (no torch stream context) nests,
+    restores on exceptions, and is what every launch of the module resolves its stream from."""
+    from luminoth_amd import kernels as K
+
+    class FakeStream(object):
+        def __init__(self, h):
+            self.cuda_stream = h
+
+    a, b = FakeStream(0x1000), FakeStream(0x2000)
+    assert K._stream_override is None
+    with K.launch_on(a):
+        assert K._stream_id() == 0x1000 and K._stream().value == 0x1000 and K._stream_override_obj is a
+        with K.launch_on(b):
+            assert K._stream_id() == 0x2000 and K._stream_override_obj is b
+        assert K._stream_id() == 0x1000 and K._stream_override_obj is a
+        with pytest.raises(RuntimeError):
+            with K.launch_on(b):
+                raise RuntimeError('inside')
+        assert K._stream_id() == 0x1000
+    assert K._stream_override is None and K._stream_override_obj is None
+
+
 def test_param_store_layout_cpu():
     from luminoth_amd.params import ParamStore
     st = ParamStore()
