@@ -174,6 +174,30 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def rocprof_avg_ms(kernel):
+    """Average duration (ms) of `kernel` in the newest committed rocprofv3 kernel trace of the serialised profiling steps
+    (profiles/*_bench_roofline_steps_kernel_stats.csv: `rocprofv3 --kernel-trace --stats -- python bench.py`, reduced by
+    scripts/make_profile_summary.py) — printed beside the live HIP-event figure so that the two can be compared on the
+    line itself.  (None, None) if absent."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_bench_roofline_steps_kernel_stats.csv')))
+    want = kernel.replace(' ', '')
+    for f in files[::-1]:
+        try:
+            for row in csv.DictReader(open(f)):
+                name = (row.get('Name') or row.get('name') or row.get('kernel') or '').replace(' ', '')
+                if name.startswith('void'):
+                    name = name[4:]
+                if name.split('(')[0] == want:
+                    avg = row.get('AverageNs') or row.get('avg_ns') or row.get('Average')
+                    if avg:
+                        return float(avg) * 1e-6, os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -208,6 +232,9 @@ def main():
                     help='also re-run the step with bf16x3 convolutions and report it as `alt_arithmetic` (opt-in since '
                          'round 3: its gain did not reproduce on the driver\'s box)')
     ap.add_argument('--no-alt', action='store_true', help='(accepted for compatibility; the alt run is opt-in now)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the BASELINE configs[4] leg (f16 half-storage step at 800x1333) the default run adds as '
+                         '`other_configs.frcnn_r50_coco_f16`')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=5)
@@ -245,23 +272,11 @@ def main():
             dist.init_process_group(backend)
 
     from luminoth_amd import kernels as K
+    from luminoth_amd import plan as P
     from luminoth_amd.models.base import layers as L
     from luminoth_amd.utils import training as T
 
     T.issue_from_high_priority_stream(device)      # what luminoth_amd.train.run does: critical path first at the dispatcher
-
-    wl = dict(WORKLOADS[args.workload])
-    if args.batch:
-        wl['batch'] = args.batch
-    cfg, model = build(wl, device, args.dtype, half_storage=not args.fp32_storage)
-    T.broadcast_parameters(model)
-    sd0 = model.state_dict() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    opt = T.get_optimizer(cfg.train, model)
-    images, gts = inputs(wl, 100 + rank, device)
-    # a second synthetic batch: steps alternate between the two like a data loader handing over batch after batch, and
-    # each step is told which batch comes next (the look-ahead luminoth_amd.train.run gives the model)
-    batches = [(images, gts), inputs(wl, 1000 + rank, device)]
-    counter = [0]
 
     def serialise(on):
         T.FUSED_STEP = not on
@@ -272,103 +287,159 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    serialise(args.serial)
-    def step_fn():
-        i = counter[0]
-        counter[0] += 1
-        cur, nxt = batches[i % 2], batches[(i + 1) % 2]
-        if args.no_lookahead:
-            return T.train_step(model, opt, cur[0], cur[1])
-        return T.train_step(model, opt, cur[0], cur[1], next_image=nxt[0], next_gt=nxt[1])
+    def run_workload(name, dtype, steps, warmup, batch=None, want_roofline=True, phases_n=0, keep_sd=False):
+        """Build the workload's model, run `warmup` untimed + `steps` timed train steps (barrier + synchronize on both
+        sides of the timed block), then the optional diagnostic legs.  -> dict of measurements."""
+        wl = dict(WORKLOADS[name])
+        if batch:
+            wl['batch'] = batch
+        cfg, model = build(wl, device, dtype, half_storage=not args.fp32_storage)
+        T.broadcast_parameters(model)
+        sd0 = model.state_dict() if keep_sd else None
+        opt = T.get_optimizer(cfg.train, model)
+        images, gts = inputs(wl, 100 + rank, device)
+        # a second synthetic batch: steps alternate between the two like a data loader handing over batch after batch,
+        # and each step is told which batch comes next (the look-ahead luminoth_amd.train.run gives the model)
+        batches = [(images, gts), inputs(wl, 1000 + rank, device)]
+        counter = [0]
 
-    schedule = 'eager, three streams' + ('' if args.no_lookahead or args.serial else
-                                        '; the frozen trunk prefix (conv1 + block1) and the anchor targets of the NEXT batch are computed in '
-                                        'idle slots of the step (main stream waiting for the RCNN branch / idle proposal stream): one '
-                                        'prefix and one target pass per step, every step')
-    for _ in range(args.warmup):
-        step_fn()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        total, _ = step_fn()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    loss_val = float(total.detach())
-    assert np.isfinite(loss_val), 'train step diverged (loss %r)' % loss_val
+        def step_fn():
+            i = counter[0]
+            counter[0] += 1
+            cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+            if args.no_lookahead:
+                return T.train_step(model, opt, cur[0], cur[1])
+            return T.train_step(model, opt, cur[0], cur[1], next_image=nxt[0], next_gt=nxt[1])
 
-    phases = None
-    if args.phases > 0 and hasattr(model, 'record_phases') and not args.serial:
-        model.record_phases(args.phases)
-        for _ in range(args.phases):
-            step_fn()
-        phases = {k: round(v, 3) for k, v in sorted(model.phase_times().items(), key=lambda kv: kv[1])}
-
-    roofline = None
-    nprof = min(args.steps, 3)
-    if not args.no_roofline:
-        # every rank takes the profiling steps (they contain the gradient all-reduce); rank 0 records
-        serialise(True)
-        T.train_step(model, opt, images, gts)          # settle allocations of the serial schedule
-        torch.cuda.synchronize()
-        if rank == 0:
-            K._Profile.start()
-        for _ in range(nprof):
-            T.train_step(model, opt, images, gts)
-        prof = K._Profile.stop() if rank == 0 else None
         serialise(args.serial)
-        if rank == 0 and prof:
-            peak = PEAK_TFLOPS[args.dtype]
-            name = max(prof, key=lambda k: prof[k]['ms'])          # the dominant kernel class, whichever pass it is in
-            step_flops = sum(v['direct_flops'] for v in prof.values()) / nprof
-            exec_flops = sum(v['flops'] for v in prof.values()) / nprof
-            r = prof[name]
-            fl = r['flops'] / r['launches']
-            by = r['bytes'] / r['launches']
-            ms = r['ms'] / r['launches']
-            achieved = fl / (ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic(name)
-            # which roofline bounds this kernel: the larger of its two ideal times (fp32 convolutions are always
-            # matrix-bound; with f16 / bf16 operands the fp32 tensors in HBM become the limit)
-            t_mfma, t_hbm = fl / (peak * 1e12), by / (PEAK_HBM_GBS * 1e9)
-            if t_hbm > t_mfma:
-                bound = {'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                         'frac': by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 'mfma_tflops': achieved}
-            else:
-                bound = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak}
-            roofline = dict(bound, **{
-                'kernel': name, 'traffic': traffic, 'algorithmic_bytes_per_launch': by,
-                'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes)',
-                'traffic_source': traffic_src,
-                'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
-                'ms_per_launch_raw_event_interval': r['ms_raw'] / r['launches'],
-                'event_pair_overhead_ms': K._Profile.overhead_ms,
-                'ms_per_step': r['ms'] / nprof,
-                'timing': 'HIP events around the kernel on its launch stream, %d serialised profiling steps; minus the '
-                          'interval of an event pair around an EMPTY kernel (dispatch latency, calibrated in this process): '
-                          'comparable with rocprofv3 kernel durations (profiles/r03_bench_roofline_steps_summary.md)' % nprof,
-                # conv_flops = the ALGORITHMIC count of SURVEY.md 8(d) (direct convolution); executed_flops = what the
-                # launched kernels actually multiply (Winograd F(2x2,3x3) layers do 2.25x fewer): the second is the honest
-                # measure of how busy the matrix pipe is, the first of how fast the step's defined work gets done
-                'whole_step': {'conv_flops': step_flops, 'tflops': step_flops / dt * args.steps / 1e12,
-                               'frac': step_flops / dt * args.steps / 1e12 / peak,
-                               'executed_flops': exec_flops,
-                               'executed_tflops': exec_flops / dt * args.steps / 1e12,
-                               'executed_frac': exec_flops / dt * args.steps / 1e12 / peak,
-                               'conv_kernel_ms_per_step': sum(v['ms'] for v in prof.values()) / nprof,
-                               'executed_frac_of_conv_kernel_time':
-                                   exec_flops / (sum(v['ms'] for v in prof.values()) / nprof * 1e-3) / 1e12 / peak},
-                'all_conv_kernels': {k: {'launches_per_step': v['launches'] / nprof,
-                                         'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
-                                         'gbs': v['bytes'] / (v['ms'] * 1e-3) / 1e9,
-                                         'ms_per_step': v['ms'] / nprof}
-                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}})
-    if world > 1:
-        dist.barrier()
+        for _ in range(warmup):
+            step_fn()
+        sync()
+        # per-step times: one HIP event per step boundary on the issuing stream (SURVEY.md 8(d): the MEDIAN step time is
+        # reported beside the block mean; the events cost ~2 us of host time each and no GPU time)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            total, _ = step_fn()
+            marks[i + 1].record()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        loss_val = float(total.detach())
+        assert np.isfinite(loss_val), 'train step diverged (loss %r)' % loss_val
+        res = {'wl': wl, 'dt': dt, 'steps': steps, 'warmup': warmup, 'loss': loss_val, 'model': model, 'sd0': sd0,
+               'ms_per_step': dt / steps * 1e3, 'ms_per_step_median': float(np.median(per_step)),
+               'ms_per_step_min': float(np.min(per_step)), 'ms_per_step_max': float(np.max(per_step))}
+        plans = [pl for S in getattr(model, '_step_state', {}).values() for pl in S['plans'].values()]
+        res['launch_plan'] = {'enabled': bool(P.ENABLED and plans), 'plans': len(plans),
+                              'kernel_launches_per_step': max([pl.n_kernels for pl in plans] or [0]),
+                              'plan_nodes_per_step': max([pl.n_nodes for pl in plans] or [0])}
+
+        if phases_n > 0 and hasattr(model, 'record_phases') and not args.serial:
+            # timeline marks (library events inside the step, part of the launch plan): the first steps after arming
+            # re-record the plans with the marks in them and are not counted
+            model.record_phases(phases_n + 6)
+            for _ in range(6):
+                step_fn()
+            torch.cuda.synchronize()
+            model._phase_sum, model._phase_n, model._phase_next_n = {}, 0, 0
+            for S in model._step_state.values():
+                S.get('pending', {}).clear()
+            for _ in range(phases_n):
+                step_fn()
+            res['phases'] = {k: round(v, 3) for k, v in sorted(model.phase_times().items(), key=lambda kv: kv[1])}
+
+        nprof = min(steps, 3)
+        if want_roofline:
+            # every rank takes the profiling steps (they contain the gradient all-reduce); rank 0 records
+            serialise(True)
+            T.train_step(model, opt, images, gts)          # settle allocations of the serial schedule
+            torch.cuda.synchronize()
+            if rank == 0:
+                K._Profile.start()
+            for _ in range(nprof):
+                T.train_step(model, opt, images, gts)
+            prof = K._Profile.stop() if rank == 0 else None
+            serialise(args.serial)
+            if rank == 0 and prof:
+                res['roofline'] = roofline_of(prof, nprof, dtype, dt, steps)
+        if world > 1:
+            dist.barrier()
+        return res
+
+    def roofline_of(prof, nprof, dtype, dt, steps):
+        peak = PEAK_TFLOPS[dtype]
+        name = max(prof, key=lambda k: prof[k]['ms'])          # the dominant kernel class, whichever pass it is in
+        step_flops = sum(v['direct_flops'] for v in prof.values()) / nprof
+        exec_flops = sum(v['flops'] for v in prof.values()) / nprof
+        r = prof[name]
+        fl = r['flops'] / r['launches']
+        by = r['bytes'] / r['launches']
+        ms = r['ms'] / r['launches']
+        ms_raw = r['ms_raw'] / r['launches']
+        achieved = fl / (ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(name)
+        rp_ms, rp_src = rocprof_avg_ms(name)
+        # which roofline bounds this kernel: the larger of its two ideal times (fp32 convolutions are always
+        # matrix-bound; with f16 / bf16 operands the tensors in HBM become the limit on the thin layers)
+        t_mfma, t_hbm = fl / (peak * 1e12), by / (PEAK_HBM_GBS * 1e9)
+        if t_hbm > t_mfma:
+            unit, pk, per_launch = 'GB/s', PEAK_HBM_GBS, by / 1e9
+            bound = {'bound': 'hbm', 'mfma_tflops': achieved}
+        else:
+            unit, pk, per_launch = 'TFLOP/s', peak, fl / 1e12
+            bound = {'bound': 'mfma'}
+        bound.update({'achieved': per_launch / (ms * 1e-3), 'peak': pk, 'unit': unit, 'frac': per_launch / (ms * 1e-3) / pk,
+                      # the same figure from the event interval as measured (no calibration: a lower bound) and from the
+                      # committed rocprofv3 summary of this command (kernel begin / end timestamps)
+                      'frac_raw_event_interval': per_launch / (ms_raw * 1e-3) / pk,
+                      'frac_rocprofv3': (per_launch / (rp_ms * 1e-3) / pk) if rp_ms else None,
+                      'rocprofv3_avg_ms': rp_ms, 'rocprofv3_source': rp_src})
+        return dict(bound, **{
+            'kernel': name, 'traffic': traffic, 'algorithmic_bytes_per_launch': by,
+            'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes)',
+            'traffic_source': traffic_src,
+            'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
+            'ms_per_launch_raw_event_interval': ms_raw,
+            'event_pair_overhead_ms': K._Profile.overhead_ms,
+            'ms_per_step': r['ms'] / nprof,
+            'timing': 'HIP events around the kernel on its launch stream, %d serialised profiling steps; `frac` = minus the '
+                      'interval of an event pair around an EMPTY kernel (dispatch latency, calibrated in this process), '
+                      '`frac_raw_event_interval` = as measured, `frac_rocprofv3` = from the committed kernel trace' % nprof,
+            # conv_flops = the ALGORITHMIC count of SURVEY.md 8(d) (direct convolution); executed_flops = what the
+            # launched kernels actually multiply (Winograd F(4x4,3x3) layers do 4x fewer): the second is the honest
+            # measure of how busy the matrix pipe is, the first of how fast the step's defined work gets done
+            'whole_step': {'conv_flops': step_flops, 'tflops': step_flops / dt * steps / 1e12,
+                           'frac': step_flops / dt * steps / 1e12 / peak,
+                           'executed_flops': exec_flops,
+                           'executed_tflops': exec_flops / dt * steps / 1e12,
+                           'executed_frac': exec_flops / dt * steps / 1e12 / peak,
+                           'conv_kernel_ms_per_step': sum(v['ms'] for v in prof.values()) / nprof,
+                           'executed_frac_of_conv_kernel_time':
+                               exec_flops / (sum(v['ms'] for v in prof.values()) / nprof * 1e-3) / 1e12 / peak},
+            'all_conv_kernels': {k: {'launches_per_step': v['launches'] / nprof,
+                                     'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
+                                     'gbs': v['bytes'] / (v['ms'] * 1e-3) / 1e9,
+                                     'ms_per_step': v['ms'] / nprof}
+                                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}})
+
+    head = run_workload(args.workload, args.dtype, args.steps, args.warmup, batch=args.batch,
+                        want_roofline=not args.no_roofline, phases_n=args.phases,
+                        keep_sd=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+    wl, dt, model = head['wl'], head['dt'], head['model']
+    plan_on = head['launch_plan']['enabled']
+    schedule = ('three streams; ' + ('recorded launch plan replayed with one host call per step (%d kernel launches per step, '
+                                      'identical to the eager step)' % head['launch_plan']['kernel_launches_per_step']
+                                      if plan_on else 'eager launches') +
+                ('' if args.no_lookahead or args.serial else
+                 '; the frozen trunk prefix (conv1 + block1) and the anchor targets of the NEXT batch are computed in idle '
+                 'slots of the step (main stream waiting for the RCNN branch / idle proposal stream): one prefix and one '
+                 'target pass per step, every step'))
 
     if rank == 0:
         gb = wl['batch'] * world
@@ -378,58 +449,68 @@ def main():
         out = {
             'metric': metric,
             'value': gb * args.steps / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'ms_per_step_median': head['ms_per_step_median'], 'ms_per_step_min': head['ms_per_step_min'],
+            'ms_per_step_max': head['ms_per_step_max'], 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[%d] (%s): %s %s, %dx%d (HxW) synthetic, batch %d/GPU, %d classes, '
                                    '%d gt/image, fwd+loss+bwd+optimizer update%s'
                                    % (wl['cfg'], args.workload, wl['model'], wl['arch'], wl['H'], wl['W'], wl['batch'],
                                       wl['classes'], wl['G'], ' [single-stream schedule]' if args.serial else ''),
-                       'global_batch': gb, 'parallelism': 'dp%d' % world, 'final_total_loss': loss_val,
+                       'global_batch': gb, 'parallelism': 'dp%d' % world, 'final_total_loss': head['loss'],
                        'storage': (getattr(getattr(model, 'base_network', None), 'storage_dtype', None) or 'f32') +
                                   (' trunk activations / gradients / working weights in HBM, fp32 master weights'
                                    if getattr(getattr(model, 'base_network', None), 'storage_dtype', None) else ''),
-                       'schedule': schedule},
-            'roofline': roofline,
+                       'schedule': schedule, 'launch_plan': head['launch_plan']},
+            'roofline': head.get('roofline'),
             # what the collective layer saw (SCALE_rNN.json can show that RCCL ran with N ranks)
             'dist': {'world_size': dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
                      'backend': dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None,
                      'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version())
-                     if hasattr(torch.cuda, 'nccl') else None},
+                     if hasattr(torch.cuda, 'nccl') else None,
+                     'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
+                     'streams': 'issue (high priority), proposal/RCNN (high priority), weight-gradient x2' +
+                                (', gradient-bucket, RCCL internal' if world > 1 else ''),
+                     'buckets': getattr(T.ACTIVE_BUCKETS, 'describe', lambda: None)()},
         }
-        if phases:
-            out['phases_ms'] = phases
+        if head.get('phases'):
+            out['phases_ms'] = head['phases']
+    sd0 = head['sd0']
+    del head, model
+    other = {}
+    if args.workload == 'frcnn_r50' and args.dtype == 'f32' and not args.serial and not args.no_other_configs:
+        # BASELINE configs[4] ("fp16 MFMA path, 1333x800 COCO shapes") on the same record: the half-storage trunk at its own
+        # geometry, 15 + 60 steps (~0.4 s of GPU time), with its own roofline leg.  Every rank runs it (it contains the
+        # gradient exchange); reported BESIDE `value`, never as it.
+        torch.cuda.empty_cache()
+        o = run_workload('frcnn_r50_coco', 'f16', 60, 15, want_roofline=not args.no_roofline)
+        if rank == 0:
+            owl = o['wl']
+            other['frcnn_r50_coco_f16'] = {
+                'config': 'BASELINE configs[4] (frcnn_r50_coco): fasterrcnn resnet_v1_50, %dx%d (HxW) synthetic, batch %d/GPU, '
+                          'f16 MFMA operands, 16-bit trunk activations / gradients / working weights in HBM, fp32 master '
+                          'weights and accumulation' % (owl['H'], owl['W'], owl['batch']),
+                'value': owl['batch'] * world * o['steps'] / o['dt'], 'unit': 'images/sec', 'dtype': 'f16',
+                'ms_per_step': o['ms_per_step'], 'ms_per_step_median': o['ms_per_step_median'], 'steps': o['steps'],
+                'warmup': o['warmup'], 'final_total_loss': o['loss'], 'launch_plan': o['launch_plan'],
+                'roofline': {k: v for k, v in (o.get('roofline') or {}).items() if k != 'all_conv_kernels'} or None}
+        del o
+    if rank == 0:
+        if other:
+            out['other_configs'] = other
         if args.dtype == 'f32' and world == 1 and args.alt and wl['model'] != 'ssd' and not args.serial:
             # the same step with the convolutions in bf16x3 (fp32 arithmetic on the bf16 matrix pipe),
             # measured in this process right after the headline run: reported BESIDE `value`, never as it
-            cfg2, model2 = build(wl, device, 'bf16x3')
-            opt2 = T.get_optimizer(cfg2.train, model2)
-            n2 = [0]
-
-            def step2():
-                i = n2[0]
-                n2[0] += 1
-                cur, nxt = batches[i % 2], batches[(i + 1) % 2]
-                if args.no_lookahead:
-                    return T.train_step(model2, opt2, cur[0], cur[1])
-                return T.train_step(model2, opt2, cur[0], cur[1], next_image=nxt[0], next_gt=nxt[1])
-
-            for _ in range(args.warmup):
-                step2()
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                total2, _ = step2()
-            sync()
-            dt2 = time.perf_counter() - t0
+            a = run_workload(args.workload, 'bf16x3', args.steps, args.warmup, batch=args.batch, want_roofline=False)
             out['alt_arithmetic'] = {
-                'dtype': 'bf16x3', 'value': gb * args.steps / dt2, 'unit': 'images/sec',
-                'ms_per_step': 1e3 * dt2 / args.steps, 'steps': args.steps, 'warmup': args.warmup,
-                'final_total_loss': float(total2.detach()),
+                'dtype': 'bf16x3', 'value': gb * args.steps / a['dt'], 'unit': 'images/sec',
+                'ms_per_step': a['ms_per_step'], 'steps': args.steps, 'warmup': args.warmup,
+                'final_total_loss': a['loss'],
                 'note': 'same workload, schedule, tensors and tolerances; every fp32 convolution operand split exactly into '
                         'three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate (bit-exact with the '
                         'native kernels on integer data, same error against float64: tests/test_gpu_x3.py).  Not the headline: '
                         '`value` above is the native fp32-MFMA path.'}
-            del model2, opt2
+            del a
         if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
             cb = cpu_baseline(wl, sd0, args.cpu_steps)
             if cb is not None:

@@ -138,6 +138,37 @@ double lmh_conv2d_profile_last_bytes(void);
 /* HIP events for hosts without a HIP binding (ctypes): create / destroy / elapsed ms (synchronises on e1). */
 /* `waiter` waits for everything enqueued on `signaler` so far (event record + stream wait on an internal event ring). */
 int lmh_stream_wait_stream(lmh_stream_t waiter, lmh_stream_t signaler);
+/* Record a caller-owned event (lmh_event_create) on a stream / make a stream wait for it; async memset and
+ * device-to-device copy.  The forms of these HIP calls that a launch plan (below) can record. */
+int lmh_event_record(void* event, lmh_stream_t stream);
+int lmh_stream_wait_event(lmh_stream_t stream, void* event);
+int lmh_memset(void* ptr, int value, size_t bytes, lmh_stream_t stream);
+int lmh_memcpy_d2d(void* dst, const void* src, size_t bytes, lmh_stream_t stream);
+/* Launch plans (csrc/plan.hip) — the counterpart of the reference's ONE host call per train step
+ * (`sess.run(train_op)`, train.py:235-247, over a graph built once).  Between lmh_plan_begin and lmh_plan_end every
+ * kernel launch, memset, copy, event record and stream wait this library issues on the calling thread is executed as
+ * usual AND recorded with a private copy of its argument values; lmh_plan_run(plan, first, last) re-issues nodes
+ * [first, last) (last < 0: to the end) — the same kernels with the same arguments on the same streams — from C.
+ * The caller keeps every recorded device pointer valid and meaning the same thing (luminoth_amd/plan.py).
+ * lmh_plan_position: nodes recorded so far (-1: not recording), for callers that interleave host work (collectives)
+ * between two parts of a plan. */
+int lmh_plan_begin(void);
+void* lmh_plan_end(void);
+void lmh_plan_abort(void);
+void lmh_plan_destroy(void* plan);
+int lmh_plan_recording(void);
+int lmh_plan_position(void);
+int lmh_plan_size(void* plan);
+int lmh_plan_kernel_count(void* plan, int first, int last);
+int lmh_plan_run(void* plan, int first, int last);
+/* scale = gamma * rstd, shift = beta - mean * scale over n channels: the frozen-statistics BatchNorm of every layer
+ * (base_network.py:84-89) folded into per-channel scale / shift for the convolution epilogues, refreshed once a step. */
+int lmh_bn_refresh(const float* gamma, const float* beta, const float* mean, const float* rstd, int64_t n,
+                   float* scale, float* shift, lmh_stream_t stream);
+/* total_loss bookkeeping of fasterrcnn.py:203-259 on the device: out[1] = no_reg = sum of the n (<= 8) weighted loss
+ * scalars in order, out[2] = regularization = reg_a + reg_b (NULL = 0), out[0] = total = no_reg + regularization. */
+int lmh_loss_sums(const float* const* terms, int n, const float* reg_a, const float* reg_b, float* out,
+                  lmh_stream_t stream);
 void* lmh_event_create(void);
 void lmh_event_destroy(void* e);
 float lmh_event_elapsed_ms(void* e0, void* e1);
@@ -387,11 +418,13 @@ int lmh_ssd_proposal(const lmh_rcnn_proposal_desc* d, const float* anchors, cons
 int lmh_roi_pool_fwd(const float* feat, const float* rois, const int32_t* roi_count, int B, int R,
                      int FH, int FW, int C, float im_h, float im_w, int ph, int pw, float* out,
                      uint8_t* argmax, lmh_stream_t stream);
-/* dfeat is OVERWRITTEN with the full gradient (CropAndResizeGradImage scatter-add, done in LDS slabs). */
+/* dfeat is OVERWRITTEN with the full gradient (CropAndResizeGradImage scatter-add, done in LDS slabs) PLUS `addend`
+ * (same shape, may be NULL, must not alias dfeat): the gradient the RPN branch left for the same feature map — the
+ * sum TF's autodiff forms for a tensor with two consumers (fasterrcnn.py:129-147) leaves in the slab's one store. */
 size_t lmh_roi_pool_bwd_workspace_bytes(int B, int R, int ph, int pw);
 int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const float* rois,
                      const int32_t* roi_count, int B, int R, int FH, int FW, int C, float im_h,
-                     float im_w, int ph, int pw, float* dfeat, void* ws, size_t ws_bytes,
+                     float im_w, int ph, int pw, const float* addend, float* dfeat, void* ws, size_t ws_bytes,
                      lmh_stream_t stream);
 /* ROI pooling fused with tf.reduce_mean(pooled, [1, 2]) (rcnn.py:185-188, `use_mean` with no pooled tail between:
  * ResNet-50 / VGG configurations): mean (B*R, C) is what lmh_roi_pool_fwd + lmh_spatial_mean_fwd return, bit for
@@ -404,8 +437,8 @@ int lmh_roi_pool_mean_fwd(const float* feat, const float* rois, const int32_t* r
                           int FW, int C, float im_h, float im_w, int ph, int pw, float* mean, uint8_t* argmax,
                           lmh_stream_t stream);
 int lmh_roi_pool_mean_bwd(const float* dmean, const uint8_t* argmax, const float* rois, const int32_t* roi_count,
-                          int B, int R, int FH, int FW, int C, float im_h, float im_w, int ph, int pw, float* dfeat,
-                          void* ws, size_t ws_bytes, lmh_stream_t stream);
+                          int B, int R, int FH, int FW, int C, float im_h, float im_w, int ph, int pw,
+                          const float* addend, float* dfeat, void* ws, size_t ws_bytes, lmh_stream_t stream);
 /* tf.reduce_mean(features, [1,2]) (rcnn.py:185-188): x (M,S,C) -> y (M,C). */
 int lmh_spatial_mean_fwd(const float* x, int64_t M, int S, int C, float* y, lmh_stream_t stream);
 int lmh_spatial_mean_bwd(const float* dy, int64_t M, int S, int C, float* dx, lmh_stream_t stream);

@@ -127,6 +127,21 @@ SIGNATURES = {
     'lmh_maxpool_fwd': (c_i, [c_f] + [c_i] * 10 + [c_f, c_f]),
     'lmh_maxpool_bwd': (c_i, [c_f, c_f, c_f] + [c_i] * 10 + [c_f, c_f]),
     'lmh_stream_wait_stream': (c_i, [c_f, c_f]),
+    'lmh_event_record': (c_i, [c_f, c_f]),
+    'lmh_stream_wait_event': (c_i, [c_f, c_f]),
+    'lmh_memset': (c_i, [c_f, c_i, c_sz, c_f]),
+    'lmh_memcpy_d2d': (c_i, [c_f, c_f, c_sz, c_f]),
+    'lmh_plan_begin': (c_i, []),
+    'lmh_plan_end': (ctypes.c_void_p, []),
+    'lmh_plan_abort': (None, []),
+    'lmh_plan_destroy': (None, [c_f]),
+    'lmh_plan_recording': (c_i, []),
+    'lmh_plan_position': (c_i, []),
+    'lmh_plan_size': (c_i, [c_f]),
+    'lmh_plan_kernel_count': (c_i, [c_f, c_i, c_i]),
+    'lmh_plan_run': (c_i, [c_f, c_i, c_i]),
+    'lmh_bn_refresh': (c_i, [c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f]),
+    'lmh_loss_sums': (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_f, c_f, c_f, c_f]),
     'lmh_conv2d_hs_supported': (c_i, [P(ConvDesc)]),
     'lmh_conv2d_fwd_hs': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f]),
     'lmh_conv2d_bwd_data_hs': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_i, ctypes.c_float, c_f]),
@@ -152,10 +167,10 @@ SIGNATURES = {
     'lmh_ssd_proposal': (c_i, [P(RcnnProposalDesc)] + [c_f] * 12 + [c_sz, c_f]),
     'lmh_roi_pool_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_f]),
     'lmh_roi_pool_bwd_workspace_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
-    'lmh_roi_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_sz, c_f]),
+    'lmh_roi_pool_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_roi_pool_mean_supported': (c_i, [c_i, c_i, c_i]),
     'lmh_roi_pool_mean_fwd': (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_f]),
-    'lmh_roi_pool_mean_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_sz, c_f]),
+    'lmh_roi_pool_mean_bwd': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_fl, c_i, c_i, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_spatial_mean_fwd': (c_i, [c_f, c_i64, c_i, c_i, c_f, c_f]),
     'lmh_spatial_mean_bwd': (c_i, [c_f, c_i64, c_i, c_i, c_f, c_f]),
     'lmh_rpn_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),

@@ -91,9 +91,9 @@ extern "C" float lmh_event_pair_overhead_ms(int reps, lmh_stream_t stream) {
     if (hipEventCreate(&e0[i]) != hipSuccess || hipEventCreate(&e1[i]) != hipSuccess) return -1.f;
   }
   for (int i = 0; i < reps; ++i) {
-    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st);       // something in front, like in a real step
+    lmh_launch(k_noop, dim3(1), dim3(64), 0, st);       // something in front, like in a real step
     (void)hipEventRecord(e0[i], st);
-    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, st);
+    lmh_launch(k_noop, dim3(1), dim3(64), 0, st);
     (void)hipEventRecord(e1[i], st);
   }
   if (hipStreamSynchronize(st) != hipSuccess) return -1.f;
@@ -121,20 +121,4 @@ extern "C" void lmh_tail_last_plan(const float** slabs, int* splits, const float
   if (colrows) *colrows = g_lmh_last_plan.colrows;
 }
 
-// `waiter` waits for everything enqueued on `signaler` so far (hipEventRecord + hipStreamWaitEvent on a small ring of
-// timing-disabled events: a wait captures the event's state when it is enqueued, so re-recording an event 32 calls later
-// does not disturb it).  The host-side cost of the same thing through torch (Stream.wait_stream: a fresh Event object
-// each time) is ~9 us; the train step does it once per trainable layer.
-extern "C" int lmh_stream_wait_stream(lmh_stream_t waiter, lmh_stream_t signaler) {
-  static thread_local hipEvent_t ring[32];
-  static thread_local int pos = 0, ready = 0;
-  if (!ready) {
-    for (int i = 0; i < 32; ++i) LMH_CHECK_HIP(hipEventCreateWithFlags(&ring[i], hipEventDisableTiming));
-    ready = 1;
-  }
-  hipEvent_t e = ring[pos];
-  pos = (pos + 1) & 31;
-  LMH_CHECK_HIP(hipEventRecord(e, (hipStream_t)signaler));
-  LMH_CHECK_HIP(hipStreamWaitEvent((hipStream_t)waiter, e, 0));
-  return LMH_OK;
-}
+// lmh_stream_wait_stream, lmh_event_record, lmh_stream_wait_event, lmh_memset and the launch plans: plan.hip

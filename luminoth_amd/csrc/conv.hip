@@ -201,7 +201,7 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
     const int ntiles = d->N * tiles_h * tiles_w;
     const int grid1 = ntiles < 512 ? ntiles : 512;   // 2 resident blocks per CU (61 KB LDS each)
     prof_begin(st);
-    hipLaunchKernelGGL(k_conv_stem7x7s2<0>, dim3(grid1), dim3(256), 0, st, *d, x, w, scale, shift, in_sub, y, tiles_h,
+    lmh_launch(k_conv_stem7x7s2<0>, dim3(grid1), dim3(256), 0, st, *d, x, w, scale, shift, in_sub, y, tiles_h,
                        tiles_w);
     prof_end(st, desc_flops(d), "k_conv_stem7x7s2<0>");
     LMH_CHECK_LAUNCH();
@@ -212,17 +212,17 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
     if (d->compute == 3 && x3_tile_pick) pick_tile(M, d->K, &bm, &bn, x3_tile_pick); else half_tile(M, d->K, &bm, &bn);
     const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
 #define LAUNCH_FWD_H(DT_, BM_, BN_)                                                                       \
-    do { if (half_pf == 4) hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 4>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y); \
-         else if (half_pf == 3) hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 3>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y); \
-         else if (half_pf == 2) hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 2>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
-         else hipLaunchKernelGGL((k_conv_fwd_h<DT_, BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); } while (0)
+    do { if (half_pf == 4) lmh_launch((k_conv_fwd_h<DT_, BM_, BN_, 4>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y, 1); \
+         else if (half_pf == 3) lmh_launch((k_conv_fwd_h<DT_, BM_, BN_, 3>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y, 1); \
+         else if (half_pf == 2) lmh_launch((k_conv_fwd_h<DT_, BM_, BN_, 2>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y, 1); \
+         else lmh_launch((k_conv_fwd_h<DT_, BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y, 1); } while (0)
 #define LAUNCH_FWD_HT(BM_, BN_)                                                                           \
     do { if (d->compute == 1) LAUNCH_FWD_H(1, BM_, BN_); else if (d->compute == 2) LAUNCH_FWD_H(2, BM_, BN_);                \
-         else if (x3_pf_fwd == 4) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 4>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y); \
-         else if (x3_pf_fwd == 3) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 3>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y); \
-         else if (x3_pf_fwd == 0) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 0>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
-         else if (x3_pf_fwd == 1) hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); \
-         else hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 2>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y); } while (0)
+         else if (x3_pf_fwd == 4) lmh_launch((k_conv_fwd_h<3, BM_, BN_, 4>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y, 1); \
+         else if (x3_pf_fwd == 3) lmh_launch((k_conv_fwd_h<3, BM_, BN_, 3>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y, 1); \
+         else if (x3_pf_fwd == 0) lmh_launch((k_conv_fwd_h<3, BM_, BN_, 0>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y, 1); \
+         else if (x3_pf_fwd == 1) lmh_launch((k_conv_fwd_h<3, BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y, 1); \
+         else lmh_launch((k_conv_fwd_h<3, BM_, BN_, 2>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual, y, 1); } while (0)
     prof_begin(st);
     if (bm == 128 && bn == 128) LAUNCH_FWD_HT(128, 128);
     else if (bm == 128) LAUNCH_FWD_HT(128, 64);
@@ -236,13 +236,13 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
 #define LAUNCH_FWD(BM_, BN_)                                                                              \
   do {                                                                                                    \
     if (fast)                                                                                             \
-      hipLaunchKernelGGL((k_conv_fwd<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift,    \
+      lmh_launch((k_conv_fwd<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift,    \
                          residual, y, 1, act_bits);                                                       \
     else if ((d->C % BK) != 0)                                                                            \
-      hipLaunchKernelGGL((k_conv_fwd_gen<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, \
+      lmh_launch((k_conv_fwd_gen<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, \
                          shift, residual, in_sub, y);                                                     \
     else                                                                                                  \
-      hipLaunchKernelGGL((k_conv_fwd_gen<BM_, BN_, false>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, \
+      lmh_launch((k_conv_fwd_gen<BM_, BN_, false>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, \
                          shift, residual, in_sub, y);                                                     \
   } while (0)
   prof_begin(st);
@@ -294,16 +294,16 @@ static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const
     const int gridh = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
     const float gs = half_gscale(d);
 #define LAUNCH_BD_H(DT_, BM_, BN_)                                                                        \
-    do { if (half_pf == 4) hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 4>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
-         else if (half_pf == 3) hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 3>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
-         else hipLaunchKernelGGL((k_conv_bwd_data_h<DT_, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); } while (0)
+    do { if (half_pf == 4) lmh_launch((k_conv_bwd_data_h<DT_, BM_, BN_, 4>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else if (half_pf == 3) lmh_launch((k_conv_bwd_data_h<DT_, BM_, BN_, 3>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else lmh_launch((k_conv_bwd_data_h<DT_, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); } while (0)
 #define LAUNCH_BD_HT(BM_, BN_)                                                                            \
     do { if (d->compute == 1) LAUNCH_BD_H(1, BM_, BN_); else if (d->compute == 2) LAUNCH_BD_H(2, BM_, BN_);                  \
-         else if (x3_pf_bd == 4) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 4>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
-         else if (x3_pf_bd == 3) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 3>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
-         else if (x3_pf_bd == 0) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 0>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); \
-         else if (x3_pf_bd == 1) hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); \
-         else hipLaunchKernelGGL((k_conv_bwd_data_h<3, BM_, BN_, 2>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); } while (0)
+         else if (x3_pf_bd == 4) lmh_launch((k_conv_bwd_data_h<3, BM_, BN_, 4>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else if (x3_pf_bd == 3) lmh_launch((k_conv_bwd_data_h<3, BM_, BN_, 3>), dim3(gridh), dim3(512), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else if (x3_pf_bd == 0) lmh_launch((k_conv_bwd_data_h<3, BM_, BN_, 0>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else if (x3_pf_bd == 1) lmh_launch((k_conv_bwd_data_h<3, BM_, BN_, 1>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); \
+         else lmh_launch((k_conv_bwd_data_h<3, BM_, BN_, 2>), dim3(gridh), dim3(256), 0, st, *d, dy, w, kscale, addend, gs, dx); } while (0)
     prof_begin(st);
     if (bm == 128 && bn == 128) LAUNCH_BD_HT(128, 128);
     else if (bm == 128) LAUNCH_BD_HT(128, 64);
@@ -318,13 +318,13 @@ static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const
 #define LAUNCH_BD(BM_, BN_)                                                                                 \
   do {                                                                                                      \
     if (fast && yact)                                                                                       \
-      hipLaunchKernelGGL((k_conv_bwd_data<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, \
+      lmh_launch((k_conv_bwd_data<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, \
                          addend, yact, xbits, dx);                                                          \
     else if (fast)                                                                                          \
-      hipLaunchKernelGGL((k_conv_bwd_data<BM_, BN_, false>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, \
+      lmh_launch((k_conv_bwd_data<BM_, BN_, false>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, \
                          addend, yact, xbits, dx);                                                          \
     else                                                                                                    \
-      hipLaunchKernelGGL((k_conv_bwd_data_gen<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale,  \
+      lmh_launch((k_conv_bwd_data_gen<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale,  \
                          addend, dx);                                                                       \
   } while (0)
   prof_begin(st);
@@ -488,7 +488,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     float* cpart1 = colsum ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + slab_b) : nullptr;
     const dim3 grid1(tc * tk * splits);
 #define LAUNCH_WG1(BM_, BN_, NB_)                                                                              \
-    hipLaunchKernelGGL((k_wgrad_1x1<BM_, BN_, NB_>), grid1, dim3(256), 0, stream, x, dy, o, P, d->C, d->K, kps, tc, \
+    lmh_launch((k_wgrad_1x1<BM_, BN_, NB_>), grid1, dim3(256), 0, stream, x, dy, o, P, d->C, d->K, kps, tc, \
                        tk, splits, cpart1)
 #define LAUNCH_WG1_T(BM_, BN_)                                                                                 \
     do { if (nbuf == 2) LAUNCH_WG1(BM_, BN_, 2); else if (nbuf == 3) LAUNCH_WG1(BM_, BN_, 3); else LAUNCH_WG1(BM_, BN_, 4); } while (0)
@@ -509,7 +509,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
       const int64_t n = splits > 1 ? (int64_t)d->C * d->K : 0;
       const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;
       const int nb_col = colsum ? (d->K + 31) / 32 : 0;
-      hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, stream,
+      lmh_launch(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, stream,
                          reinterpret_cast<const float*>(ws), n, splits, dw, (const float*)cpart1, colsum, d->K, nb_slab,
                          crows);
     }
@@ -533,8 +533,8 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
   if (d->compute == 3 && fast && gb && !yact && !colsum) {      // Winograd weight gradient, 16 stacked GEMMs in bf16x3
     const int nblk = (int)(grid.x * grid.y * grid.z);
 #define LAUNCH_BW_G(BM_, BN_)                                                                              \
-    hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 0, true>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
-                       dvh, 1.f, (int)grid.x, (int)grid.y, (int)grid.z)
+    lmh_launch((k_conv_bwd_weight_h<3, BM_, BN_, 0, true>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
+                       dvh, 1.f, (int)grid.x, (int)grid.y, (int)grid.z, (float*)nullptr)
     prof_begin(st);
     if (bm == 128 && bn == 128) LAUNCH_BW_G(128, 128);
     else if (bm == 128) LAUNCH_BW_G(128, 64);
@@ -545,7 +545,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     if (splits > 1) {
       const int64_t n = (int64_t)d->R * d->S * d->C * d->K;
       const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
-      hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
+      lmh_launch(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
                          splits, dw, (const float*)nullptr, (float*)nullptr, d->K, nb_slab, 0);
     }
     LMH_CHECK_LAUNCH();
@@ -556,25 +556,25 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     float* cpart_h = (colsum && d->compute == 3) ? cpart : nullptr;      // fused channel sums: bf16x3 only (exact)
     const int nblk = (int)(grid.x * grid.y * grid.z);
 #define LAUNCH_BW_H(DT_, BM_, BN_)                                                                         \
-    do { if (half_pf == 4) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 4>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw,   \
+    do { if (half_pf == 4) lmh_launch((k_conv_bwd_weight_h<DT_, BM_, BN_, 4>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw,   \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
-         else if (half_pf == 3) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 3>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw,   \
+         else if (half_pf == 3) lmh_launch((k_conv_bwd_weight_h<DT_, BM_, BN_, 3>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw,   \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
-         else if (half_pf == 2) hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
+         else if (half_pf == 2) lmh_launch((k_conv_bwd_weight_h<DT_, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
-         else hipLaunchKernelGGL((k_conv_bwd_weight_h<DT_, BM_, BN_, 1>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
+         else lmh_launch((k_conv_bwd_weight_h<DT_, BM_, BN_, 1>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw,   \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h); } while (0)
 #define LAUNCH_BW_HT(BM_, BN_)                                                                             \
     do { if (d->compute == 1) LAUNCH_BW_H(1, BM_, BN_); else if (d->compute == 2) LAUNCH_BW_H(2, BM_, BN_);                  \
-         else if (x3_pf_bw == 4) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 4>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw, \
+         else if (x3_pf_bw == 4) lmh_launch((k_conv_bwd_weight_h<3, BM_, BN_, 4>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw, \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
-         else if (x3_pf_bw == 3) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 3>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw, \
+         else if (x3_pf_bw == 3) lmh_launch((k_conv_bwd_weight_h<3, BM_, BN_, 3>), dim3(nblk), dim3(512), 0, st, *d, x, dy, out, kps, dvw, \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
-         else if (x3_pf_bw == 0) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 0>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
+         else if (x3_pf_bw == 0) lmh_launch((k_conv_bwd_weight_h<3, BM_, BN_, 0>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
-         else if (x3_pf_bw == 1) hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 1>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
+         else if (x3_pf_bw == 1) lmh_launch((k_conv_bwd_weight_h<3, BM_, BN_, 1>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h);                                    \
-         else hipLaunchKernelGGL((k_conv_bwd_weight_h<3, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
+         else lmh_launch((k_conv_bwd_weight_h<3, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h); } while (0)
     prof_begin(st);
     if (bm == 128 && bn == 128) LAUNCH_BW_HT(128, 128);
@@ -593,7 +593,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
       const int64_t n = splits > 1 ? (int64_t)d->R * d->S * d->C * d->K : 0;
       const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;
       const int nb_col = cpart_h ? (d->K + 31) / 32 : 0;
-      hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
+      lmh_launch(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
                          splits, dw, (const float*)cpart_h, cpart_h ? colsum : (float*)nullptr, d->K, nb_slab, splits);
     }
     LMH_CHECK_LAUNCH();
@@ -602,16 +602,16 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
 #define LAUNCH_BW(BM_, BN_)                                                                              \
   do {                                                                                                   \
     if (gb)                                                                                              \
-      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, false, true>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, st, \
+      lmh_launch((k_conv_bwd_weight<BM_, BN_, false, true>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, st, \
                          *d, x, dy, out, kps, dvw, dvh, yact, cpart, (int)grid.x, (int)grid.y, (int)grid.z); \
     else if (fast && yact)                                                                               \
-      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, true>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, st, \
+      lmh_launch((k_conv_bwd_weight<BM_, BN_, true>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, st, \
                          *d, x, dy, out, kps, dvw, dvh, yact, cpart, (int)grid.x, (int)grid.y, (int)grid.z); \
     else if (fast)                                                                                       \
-      hipLaunchKernelGGL((k_conv_bwd_weight<BM_, BN_, false>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, st, \
+      lmh_launch((k_conv_bwd_weight<BM_, BN_, false>), dim3(grid.x * grid.y * grid.z), dim3(256), 0, st, \
                          *d, x, dy, out, kps, dvw, dvh, yact, cpart, (int)grid.x, (int)grid.y, (int)grid.z); \
     else                                                                                                 \
-      hipLaunchKernelGGL((k_conv_bwd_weight_gen<BM_, BN_>), grid, dim3(256), 0, st, *d, x, dy, out, kps); \
+      lmh_launch((k_conv_bwd_weight_gen<BM_, BN_>), grid, dim3(256), 0, st, *d, x, dy, out, kps); \
   } while (0)
   prof_begin(st);
   if (bm == 128 && bn == 128) LAUNCH_BW(128, 128);
@@ -631,7 +631,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     const int64_t n = splits > 1 ? (int64_t)d->R * d->S * d->C * d->K : 0;
     const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;
     const int nb_col = colsum ? (d->K + 31) / 32 : 0;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, st, reinterpret_cast<const float*>(ws),
+    lmh_launch(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, st, reinterpret_cast<const float*>(ws),
                        n, splits, dw, cpart, colsum, d->K, nb_slab, splits);
   }
   LMH_CHECK_LAUNCH();
@@ -667,7 +667,7 @@ static int hs_launch(const lmh_conv_desc* d, const void* A, const void* B, const
   else { bm = 64; bn = 64; }
   const int grid = (int)(((M + bm - 1) / bm) * ((NC + bn - 1) / bn));
 #define LAUNCH_HS(DT_, BM_, BN_)                                                                             \
-  hipLaunchKernelGGL((k_conv_hs<DT_, BM_, BN_, BWD>), dim3(grid), dim3(256), 0, st, *d,                         \
+  lmh_launch((k_conv_hs<DT_, BM_, BN_, BWD>), dim3(grid), dim3(256), 0, st, *d,                         \
                      reinterpret_cast<const HT<DT_>::T*>(A), reinterpret_cast<const HT<DT_>::T*>(B), e)
 #define LAUNCH_HS_T(BM_, BN_) do { if (d->compute == 1) LAUNCH_HS(1, BM_, BN_); else LAUNCH_HS(2, BM_, BN_); } while (0)
   prof_begin(st);
@@ -761,7 +761,7 @@ extern "C" int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, c
   const bool gather = !(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->OH == d->H &&
                         d->OW == d->W);
 #define LAUNCH_BW_TR(DT_, BM_, G_)                                                                           \
-  hipLaunchKernelGGL((k_wgrad_hs_tr<DT_, BM_, BM_, G_>), dim3(tx * ty * splits), dim3(256), 0, st, *d,            \
+  lmh_launch((k_wgrad_hs_tr<DT_, BM_, BM_, G_>), dim3(tx * ty * splits), dim3(256), 0, st, *d,            \
                      reinterpret_cast<const HT<DT_>::T*>(x), reinterpret_cast<const HT<DT_>::T*>(g), out, kps, dvw, dvh, \
                      inv_scale, tx, ty, splits, cpart)
 #define LAUNCH_BW_TR_T(BM_)                                                                                  \
@@ -783,7 +783,7 @@ extern "C" int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, c
     const int64_t n = splits > 1 ? (int64_t)d->R * d->S * d->C * d->K : 0;
     const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;
     const int nb_col = cpart ? (d->K + 31) / 32 : 0;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
+    lmh_launch(k_splitk_reduce, dim3(nb_slab + nb_col), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
                        splits, dw, (const float*)cpart, colsum, d->K, nb_slab, splits);
   }
   LMH_CHECK_LAUNCH();

@@ -578,10 +578,10 @@ static int wino_run(const lmh_conv_desc* d, int mo, const float* in, int Cg, int
   const int T = (int)wino_tiles(d, mo), P2 = (mo + 2) * (mo + 2);
   if (mo == 4) {
     const int64_t n = (int64_t)T * (Cg / 2);
-    hipLaunchKernelGGL(k_wino4_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, d->N, d->H, d->W, Cg, V);
+    lmh_launch(k_wino4_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, d->N, d->H, d->W, Cg, V);
   } else {
     const int64_t n = (int64_t)T * (Cg / 4);
-    hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, d->N, d->H, d->W, Cg, V);
+    lmh_launch(k_wino_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, d->N, d->H, d->W, Cg, V);
   }
   // P2 GEMMs [T x Cg] x [Cg x Kg] as ONE grid of the forward kernel (a 1x1 convolution over T "pixels")
   lmh_conv_desc g = *d;
@@ -594,14 +594,15 @@ static int wino_run(const lmh_conv_desc* d, int mo, const float* in, int Cg, int
 #define LAUNCH_WG(BM_, BN_)                                                                           \
   do {                                                                                                \
     if (x3 && x3_pf_gb == 3)                                                                          \
-      hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 3, true>), dim3(grid), dim3(512), 0, st, g, (const float*)V, U, \
+      lmh_launch((k_conv_fwd_h<3, BM_, BN_, 3, true>), dim3(grid), dim3(512), 0, st, g, (const float*)V, U, \
                          (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, P2);  \
     else if (x3)                                                                                      \
-      hipLaunchKernelGGL((k_conv_fwd_h<3, BM_, BN_, 0, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U, \
+      lmh_launch((k_conv_fwd_h<3, BM_, BN_, 0, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U, \
                          (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, P2);  \
     else                                                                                              \
-      hipLaunchKernelGGL((k_conv_fwd<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U,  \
-                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, P2);  \
+      lmh_launch((k_conv_fwd<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, g, (const float*)V, U,  \
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, P2,   \
+                         (uint32_t*)nullptr);                                                         \
   } while (0)
   g_prof_pending_bytes = (double)P2 * 4.0 * ((double)T * Cg + (double)Cg * Kg + (double)T * Kg);
   prof_begin(st);
@@ -613,11 +614,11 @@ static int wino_run(const lmh_conv_desc* d, int mo, const float* in, int Cg, int
   else prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd<%d, %d, true>", bm, bn);
   if (mo == 4) {
     const int64_t n = (int64_t)T * (Kg / 2);
-    hipLaunchKernelGGL(k_wino4_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,
+    lmh_launch(k_wino4_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,
                        d->H, d->W, Kg, scale, shift, extra, act_lo, act_hi, out, bits_out, bits_in);
   } else {
     const int64_t n = (int64_t)T * (Kg / 4);
-    hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,
+    lmh_launch(k_wino_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,
                        d->H, d->W, Kg, scale, shift, extra, act_lo, act_hi, out, bits_out, bits_in);
   }
   LMH_CHECK_LAUNCH();
@@ -651,17 +652,17 @@ static void wino_weights(const lmh_conv_desc* d, int mo, const float* w, const f
   if (mo == 4) {
     if (backward) {
       const int n = d->K * (d->C / 2);
-      hipLaunchKernelGGL(k_wino4_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, u);
+      lmh_launch(k_wino4_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, u);
     } else {
       const int n = d->C * (d->K / 2);
-      hipLaunchKernelGGL(k_wino4_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, u);
+      lmh_launch(k_wino4_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, u);
     }
   } else if (backward) {
     const int n = d->K * (d->C / 4);
-    hipLaunchKernelGGL(k_wino_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, u);
+    lmh_launch(k_wino_weight_bwd, dim3((n + 255) / 256), dim3(256), 0, st, w, kscale, d->C, d->K, u);
   } else {
     const int n = d->C * (d->K / 4);
-    hipLaunchKernelGGL(k_wino_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, u);
+    lmh_launch(k_wino_weight_fwd, dim3((n + 255) / 256), dim3(256), 0, st, w, d->C, d->K, u);
   }
 }
 
@@ -708,7 +709,7 @@ extern "C" int lmh_winograd_transform_weights_batch(const lmh_wino_weight_job* j
       blocks += (j.C * (j.K / 2) + 255) / 256;       // (c, k2) forward / (k, c2) backward: the same count
     }
     b.first_block[b.n] = blocks;
-    hipLaunchKernelGGL(k_wino4_weight_batch, dim3(blocks), dim3(256), 0, st, b);
+    lmh_launch(k_wino4_weight_batch, dim3(blocks), dim3(256), 0, st, b);
   }
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -806,15 +807,15 @@ extern "C" int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const floa
   if (mo == 4) {
     const int64_t n = (int64_t)T * (d->C / 2);
     if (!v_cached)
-      hipLaunchKernelGGL(k_wino4_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
+      lmh_launch(k_wino4_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
     const int64_t m = (int64_t)T * (d->K / 2);
-    hipLaunchKernelGGL(k_wino4_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
+    lmh_launch(k_wino4_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
   } else {
     const int64_t n = (int64_t)T * (d->C / 4);
     if (!v_cached)
-      hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
+      lmh_launch(k_wino_input, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d->N, d->H, d->W, d->C, V);
     const int64_t m = (int64_t)T * (d->K / 4);
-    hipLaunchKernelGGL(k_wino_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
+    lmh_launch(k_wino_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
   }
   if (colsum) {      // plane (1,1) = index (mo+2)*1 + 1: the tiles' pixel sums
     rc = lmh_colsum_rows_impl(dM + (size_t)(mo + 3) * T * d->K, T, d->K, colsum, st);
@@ -825,10 +826,10 @@ extern "C" int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const floa
   if (rc) return rc;
   if (mo == 4) {
     const int n = d->C * (d->K / 2);
-    hipLaunchKernelGGL(k_wino4_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);
+    lmh_launch(k_wino4_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);
   } else {
     const int n = d->C * (d->K / 4);
-    hipLaunchKernelGGL(k_wino_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);
+    lmh_launch(k_wino_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);
   }
   LMH_CHECK_LAUNCH();
   return LMH_OK;

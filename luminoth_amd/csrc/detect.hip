@@ -154,23 +154,23 @@ static int det_run(const lmh_rcnn_proposal_desc* d, const float* proposals,
   hipStream_t st = (hipStream_t)stream;
   const int BC = d->B * d->C, Rpad = lmh_next_pow2(d->R);
   const int Tpad = lmh_next_pow2(d->C * d->class_max_detections);
-  LMH_CHECK_HIP(hipMemsetAsync(w.n_valid, 0, sizeof(int32_t) * BC, st));
-  LMH_CHECK_HIP(hipMemsetAsync(w.n_total, 0, sizeof(int32_t) * d->B, st));
-  hipLaunchKernelGGL(k_class_decode, dim3((Rpad + 255) / 256, BC), dim3(256), 0, st, *d, Rpad,
+  LMH_CHECK_HIP(lmh_memset_async(w.n_valid, 0, sizeof(int32_t) * BC, st));
+  LMH_CHECK_HIP(lmh_memset_async(w.n_total, 0, sizeof(int32_t) * d->B, st));
+  lmh_launch(k_class_decode, dim3((Rpad + 255) / 256, BC), dim3(256), 0, st, *d, Rpad,
                      reinterpret_cast<const float4*>(proposals), prop_count, bbox_pred, cls_prob, w.boxes,
                      w.keys, w.n_valid);
   int rc = lmh_sort_u64_impl(w.keys, BC, Rpad, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_class_gather, dim3((d->R + 255) / 256, BC), dim3(256), 0, st, *d, Rpad, w.keys,
+  lmh_launch(k_class_gather, dim3((d->R + 255) / 256, BC), dim3(256), 0, st, *d, Rpad, w.keys,
                      w.boxes, w.n_valid, w.sorted_boxes, w.sorted_src);
   rc = lmh_nms_impl(reinterpret_cast<const float*>(w.sorted_boxes), w.n_valid, BC, d->R,
                     d->class_nms_threshold, d->class_max_detections, w.keep_idx, w.keep_count, w.nms_ws, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_final_keys, dim3((Tpad + 255) / 256, d->B), dim3(256), 0, st, *d, Tpad, w.keep_idx,
+  lmh_launch(k_final_keys, dim3((Tpad + 255) / 256, d->B), dim3(256), 0, st, *d, Tpad, w.keep_idx,
                      w.keep_count, w.sorted_src, cls_prob, w.fkeys, w.n_total);
   rc = lmh_sort_u64_impl(w.fkeys, d->B, Tpad, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_final_gather, dim3((d->total_max_detections + 255) / 256, d->B), dim3(256), 0, st, *d,
+  lmh_launch(k_final_gather, dim3((d->total_max_detections + 255) / 256, d->B), dim3(256), 0, st, *d,
                      Tpad, w.fkeys, w.n_total, w.keep_idx, w.sorted_src, w.sorted_boxes, cls_prob,
                      reinterpret_cast<float4*>(objects), labels, probs, num_objects);
   LMH_CHECK_LAUNCH();
@@ -291,10 +291,10 @@ extern "C" int lmh_ssd_proposal(const lmh_rcnn_proposal_desc* d, const float* an
   det_ws w = det_layout(d, ws);
   hipStream_t st = (hipStream_t)stream;
   const int Tpad = lmh_next_pow2(d->C * d->class_max_detections);
-  hipLaunchKernelGGL(k_ssd_raw_proposals, dim3(d->B), dim3(1024), 0, st, *d, reinterpret_cast<const float4*>(anchors),
+  lmh_launch(k_ssd_raw_proposals, dim3(d->B), dim3(1024), 0, st, *d, reinterpret_cast<const float4*>(anchors),
                      anchor_count, reinterpret_cast<const float4*>(loc_pred), cls_prob,
                      reinterpret_cast<float4*>(raw_proposals), raw_count);
-  hipLaunchKernelGGL(k_ssd_det_anchors, dim3(d->total_max_detections, d->B), dim3(64), 0, st, *d, Tpad, w.fkeys,
+  lmh_launch(k_ssd_det_anchors, dim3(d->total_max_detections, d->B), dim3(64), 0, st, *d, Tpad, w.fkeys,
                      w.n_total, w.keep_count, w.n_valid, reinterpret_cast<const float4*>(anchors), anchor_count,
                      reinterpret_cast<const float4*>(loc_pred), cls_prob, reinterpret_cast<float4*>(det_anchors));
   LMH_CHECK_LAUNCH();

@@ -104,7 +104,7 @@ k_colsum_finish(const float* __restrict__ partial, int nb, int K, float* __restr
 // per-channel sums of `nb` rows of K floats (deterministic, fixed order) — used by the Winograd weight gradient, whose
 // transformed-gradient plane (1,1) holds every tile's pixel sum (conv_winograd.h)
 int lmh_colsum_rows_impl(const float* rows_, int nb, int K, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, rows_, nb, K, out);
+  lmh_launch(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, rows_, nb, K, out);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -142,14 +142,14 @@ extern "C" int lmh_act_bwd(const float* dy, const float* y, int act, int64_t row
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = partial ? (size_t)ACT_MAX_K * sizeof(float) : 0;
   if ((K & 3) != 0)
-    hipLaunchKernelGGL((k_act_bwd<false>), dim3(nb), dim3(256), lds, st, dy, y, act, rows, K, g, partial, rpb);
+    lmh_launch((k_act_bwd<false>), dim3(nb), dim3(256), lds, st, dy, y, act, rows, K, g, partial, rpb);
   else
-    hipLaunchKernelGGL((k_act_bwd<true>), dim3(nb), dim3(256), lds, st, dy, y, act, rows, K, g, partial, rpb);
+    lmh_launch((k_act_bwd<true>), dim3(nb), dim3(256), lds, st, dy, y, act, rows, K, g, partial, rpb);
   if (colsum && g_lmh_defer_tail) {
     g_lmh_last_plan.colpart = partial;
     g_lmh_last_plan.colrows = nb;
   } else if (colsum) {
-    hipLaunchKernelGGL(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, partial, nb, K, colsum);
+    lmh_launch(k_colsum_finish, dim3((K + 31) / 32), dim3(256), 0, st, partial, nb, K, colsum);
   }
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -188,7 +188,7 @@ k_apply_act_bits(float* __restrict__ dx, const uint32_t* __restrict__ bits, int6
 int lmh_act_bits_impl(const float* y, int act, int64_t rows, int K, uint32_t* bits, hipStream_t st) {
   LMH_CHECK_ARG(y && bits && rows > 0 && K > 0 && (K & 31) == 0 && (act == 1 || act == 2));
   const int64_t n4 = rows * (K >> 2);
-  hipLaunchKernelGGL(k_act_bits, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, y, act == 2 ? 6.f : INFINITY, n4,
+  lmh_launch(k_act_bits, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, y, act == 2 ? 6.f : INFINITY, n4,
                      bits);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -196,7 +196,7 @@ int lmh_act_bits_impl(const float* y, int act, int64_t rows, int K, uint32_t* bi
 int lmh_apply_act_bits_impl(float* dx, const uint32_t* bits, int64_t rows, int C, hipStream_t st) {
   LMH_CHECK_ARG(dx && bits && rows > 0 && C > 0 && (C & 31) == 0);
   const int64_t n4 = rows * (C >> 2);
-  hipLaunchKernelGGL(k_apply_act_bits, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dx, bits, n4);
+  lmh_launch(k_apply_act_bits, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dx, bits, n4);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -285,8 +285,8 @@ extern "C" int lmh_bn_param_grads(const float* w, float* dw_raw_inout, const flo
   const int nb = bn_blocks(rsc, K, &rpb);
   hipStream_t st = (hipStream_t)stream;
   float* partial = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(k_bn_wdot, dim3(nb), dim3(256), 0, st, w, dw_raw_inout, scale, rsc, K, partial, rpb);
-  hipLaunchKernelGGL(k_bn_finish, dim3((K + 31) / 32), dim3(256), 0, st, partial, nb, K, dbeta, mean, rstd,
+  lmh_launch(k_bn_wdot, dim3(nb), dim3(256), 0, st, w, dw_raw_inout, scale, rsc, K, partial, rpb);
+  lmh_launch(k_bn_finish, dim3((K + 31) / 32), dim3(256), 0, st, partial, nb, K, dbeta, mean, rstd,
                      dgamma);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -353,7 +353,7 @@ extern "C" int lmh_maxpool_fwd(const float* x, int N, int H, int W, int C, int k
   LMH_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && ksize > 0 && stride > 0);
   const int64_t total = (int64_t)N * OH * OW * (C / 4);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(k_maxpool_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ksize,
+  lmh_launch(k_maxpool_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ksize,
                      stride, pad_top, pad_left, OH, OW, y);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -365,7 +365,7 @@ extern "C" int lmh_maxpool_bwd(const float* x, const float* y, const float* dy, 
   LMH_CHECK_ARG(x && y && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && ksize > 0 && stride > 0);
   const int64_t total = (int64_t)N * OH * OW * C;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(k_maxpool_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, dy, N, H, W, C,
+  lmh_launch(k_maxpool_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, dy, N, H, W, C,
                      ksize, stride, pad_top, pad_left, OH, OW, dx);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -413,10 +413,10 @@ extern "C" int lmh_resize_bilinear(const void* src, int src_is_u8, int H, int W,
   const int64_t total = (int64_t)OH * OW;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (src_is_u8)
-    hipLaunchKernelGGL(k_resize_bilinear<uint8_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    lmh_launch(k_resize_bilinear<uint8_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t*)src, H, W, C, dst, OH, OW, hscale, wscale, flip_lr, flip_ud);
   else
-    hipLaunchKernelGGL(k_resize_bilinear<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    lmh_launch(k_resize_bilinear<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const float*)src, H, W, C, dst, OH, OW, hscale, wscale, flip_lr, flip_ud);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -440,7 +440,57 @@ extern "C" int lmh_dropout(const float* x, int64_t n, float keep_prob, uint32_t 
   const double t = (double)keep_prob * 4294967296.0;
   const uint32_t thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  hipLaunchKernelGGL(k_dropout, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, seed, thr, 1.f / keep_prob, y);
+  lmh_launch(k_dropout, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, seed, thr, 1.f / keep_prob, y);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+// ---- BatchNorm table refresh + loss scalars: the last host-framework arithmetic of the train step ------------------
+// scale = gamma * rstd, shift = beta - mean * scale for every frozen-statistics BatchNorm layer of a network at once
+// (slim batch_norm in inference mode folded into the convolution epilogues, base_network.py:84-89); same three
+// roundings as the mul / mul / sub it replaces (the file is compiled with -ffp-contract=off).
+__global__ void __launch_bounds__(256)
+k_bn_refresh(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+             const float* __restrict__ rstd, int64_t n, float* __restrict__ scale, float* __restrict__ shift) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float s = gamma[i] * rstd[i];
+  const float t = mean[i] * s;
+  scale[i] = s;
+  shift[i] = beta[i] - t;
+}
+extern "C" int lmh_bn_refresh(const float* gamma, const float* beta, const float* mean, const float* rstd, int64_t n,
+                              float* scale, float* shift, lmh_stream_t stream) {
+  LMH_CHECK_ARG(gamma && beta && mean && rstd && scale && shift && n > 0);
+  lmh_launch(k_bn_refresh, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, rstd,
+             n, scale, shift);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+// total_loss of fasterrcnn.py:203-259: no_reg = ((t0 + t1) + t2) + ... over the weighted loss terms in the order the
+// reference sums them, regularization = reg_a + reg_b (trainable + frozen regularised variables), total = no_reg + reg.
+// out[0] = total, out[1] = no_reg, out[2] = regularization.  One thread: five additions.
+struct lmh_loss_terms { const float* t[8]; };
+__global__ void k_loss_sums(lmh_loss_terms terms, int n, const float* __restrict__ reg_a, const float* __restrict__ reg_b,
+                            float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = terms.t[0][0];
+  for (int i = 1; i < n; ++i) s = s + terms.t[i][0];
+  const float r = (reg_a ? reg_a[0] : 0.f) + (reg_b ? reg_b[0] : 0.f);
+  out[0] = s + r;
+  out[1] = s;
+  out[2] = r;
+}
+extern "C" int lmh_loss_sums(const float* const* terms, int n, const float* reg_a, const float* reg_b, float* out,
+                             lmh_stream_t stream) {
+  LMH_CHECK_ARG(terms && n >= 1 && n <= 8 && out);
+  lmh_loss_terms t{};
+  for (int i = 0; i < n; ++i) {
+    LMH_CHECK_ARG(terms[i] != nullptr);
+    t.t[i] = terms[i];
+  }
+  lmh_launch(k_loss_sums, dim3(1), dim3(64), 0, (hipStream_t)stream, t, n, reg_a, reg_b, out);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

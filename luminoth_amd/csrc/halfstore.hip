@@ -58,7 +58,7 @@ extern "C" int lmh_cast_to_half(const float* x, int64_t rows, int C, float mul, 
   LMH_CHECK_ARG(x && y && rows > 0 && C > 0 && (C & 7) == 0 && (dtype == 1 || dtype == 2));
   LMH_CHECK_ARG(bits == nullptr || (C & 31) == 0);
   const int64_t total = rows * (C >> 3);
-#define CALL(DT_) hipLaunchKernelGGL(k_cast_to_half<DT_>, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, \
+#define CALL(DT_) lmh_launch(k_cast_to_half<DT_>, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, \
                                      rows, C, mul, bits, reinterpret_cast<HS<DT_>::T*>(y))
   HS_DISPATCH(dtype, CALL);
 #undef CALL
@@ -68,7 +68,7 @@ extern "C" int lmh_cast_to_half(const float* x, int64_t rows, int C, float mul, 
 
 extern "C" int lmh_cast_to_f32(const void* x, int64_t n, float mul, float* y, int dtype, lmh_stream_t stream) {
   LMH_CHECK_ARG(x && y && n > 0 && (n & 7) == 0 && (dtype == 1 || dtype == 2));
-#define CALL(DT_) hipLaunchKernelGGL(k_cast_to_f32<DT_>, dim3(stream_blocks(n >> 3)), dim3(256), 0, (hipStream_t)stream, \
+#define CALL(DT_) lmh_launch(k_cast_to_f32<DT_>, dim3(stream_blocks(n >> 3)), dim3(256), 0, (hipStream_t)stream, \
                                      reinterpret_cast<const HS<DT_>::T*>(x), n >> 3, mul, y)
   HS_DISPATCH(dtype, CALL);
 #undef CALL
@@ -133,7 +133,7 @@ extern "C" int lmh_half_weights_batch(const lmh_half_weight_job* jobs, int n, in
       blocks += ((jb.RS * jb.C + 63) / 64) * ((jb.K + 63) / 64);
     }
     b.first_block[b.n] = blocks;
-#define CALL(DT_) hipLaunchKernelGGL(k_half_weights<DT_>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b)
+#define CALL(DT_) lmh_launch(k_half_weights<DT_>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b)
     HS_DISPATCH(dtype, CALL);
 #undef CALL
   }
@@ -192,9 +192,9 @@ extern "C" int lmh_maxpool_fwd_hs(const void* x, int x_is_f32, int N, int H, int
   const int64_t total = (int64_t)N * OH * OW * (C / 8);
 #define CALL(DT_)                                                                                                        \
   do {                                                                                                                   \
-    if (x_is_f32) hipLaunchKernelGGL((k_maxpool_fwd_hs<DT_, true>), dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, \
+    if (x_is_f32) lmh_launch((k_maxpool_fwd_hs<DT_, true>), dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, \
                                      x, N, H, W, C, ksize, stride, pad_top, pad_left, OH, OW, reinterpret_cast<HS<DT_>::T*>(y)); \
-    else hipLaunchKernelGGL((k_maxpool_fwd_hs<DT_, false>), dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, N, \
+    else lmh_launch((k_maxpool_fwd_hs<DT_, false>), dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, N, \
                             H, W, C, ksize, stride, pad_top, pad_left, OH, OW, reinterpret_cast<HS<DT_>::T*>(y));          \
   } while (0)
   HS_DISPATCH(dtype, CALL);
@@ -225,7 +225,7 @@ extern "C" int lmh_subsample_bwd_hs(const void* dy, int N, int H, int W, int C, 
                                     lmh_stream_t stream) {
   LMH_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && stride > 0 && OH > 0 && OW > 0);
   const int64_t total = (int64_t)N * H * W * (C / 8);
-  hipLaunchKernelGGL(k_subsample_bwd_hs, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+  lmh_launch(k_subsample_bwd_hs, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const uint4*>(dy), N, H, W, C / 8, stride, OH, OW, reinterpret_cast<uint4*>(dx));
   LMH_CHECK_LAUNCH();
   return LMH_OK;

@@ -46,6 +46,38 @@ extern thread_local lmh_tail_plan g_lmh_last_plan;
 
 #define LMH_CHECK_LAUNCH() LMH_CHECK_HIP(hipGetLastError())
 
+// ---- launch plans (plan.hip): every kernel launch, memset and stream-to-stream wait of this library goes through the
+// three functions below.  Normally they just issue the HIP call.  While the calling thread RECORDS a plan
+// (lmh_plan_begin ... lmh_plan_end) they also append the launch — function, geometry, stream and a private copy of the
+// argument values — to the plan, so that lmh_plan_run can re-issue the identical sequence later without going through
+// the host code above it (one C call per train step instead of ~250 Python -> ctypes round trips).
+void lmh_launch_raw(const void* fn, dim3 grid, dim3 block, unsigned shmem, hipStream_t st, void** args,
+                    const size_t* sizes, const size_t* aligns, int nargs);
+hipError_t lmh_memset_async(void* ptr, int value, size_t bytes, hipStream_t st);
+hipError_t lmh_memcpy_d2d_async(void* dst, const void* src, size_t bytes, hipStream_t st);
+
+#ifdef __HIPCC__
+#include <tuple>
+#include <utility>
+template <typename Tuple, size_t... I>
+inline void lmh_launch_tuple_(const void* fn, dim3 grid, dim3 block, unsigned shmem, hipStream_t st, Tuple& vals,
+                              std::index_sequence<I...>) {
+  void* ptrs[sizeof...(I) + 1] = {(void*)&std::get<I>(vals)..., nullptr};
+  const size_t sizes[sizeof...(I) + 1] = {sizeof(std::tuple_element_t<I, Tuple>)..., 0};
+  const size_t aligns[sizeof...(I) + 1] = {alignof(std::tuple_element_t<I, Tuple>)..., 0};
+  lmh_launch_raw(fn, grid, block, shmem, st, ptrs, sizes, aligns, (int)sizeof...(I));
+}
+// Drop-in for lmh_launch(kernel, grid, block, shmem, stream, args...): arguments are converted to the kernel's
+// parameter types exactly like a call would.
+template <typename... KArgs, typename... Args>
+inline void lmh_launch(void (*kern)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t st, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+  std::tuple<KArgs...> vals{static_cast<KArgs>(std::forward<Args>(args))...};
+  lmh_launch_tuple_(reinterpret_cast<const void*>(kern), grid, block, shmem, st, vals,
+                    std::index_sequence_for<KArgs...>{});
+}
+#endif
+
 static inline size_t lmh_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int lmh_next_pow2(int v) {
   int p = 1;

@@ -144,12 +144,12 @@ extern "C" int lmh_rpn_loss(const float* cls_score, const float* bbox_pred, cons
   LMH_CHECK_ARG(cls_score && bbox_pred && labels && bbox_targets && losses && per_image);
   LMH_CHECK_ARG(B > 0 && N > 0);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_rpn_loss, dim3(B), dim3(LOSS_THREADS), 0, st, cls_score, bbox_pred, labels,
+  lmh_launch(k_rpn_loss, dim3(B), dim3(LOSS_THREADS), 0, st, cls_score, bbox_pred, labels,
                      bbox_targets, B, N, sigma * sigma, per_image);
   if (d_cls_score || d_bbox_pred)
-    hipLaunchKernelGGL(k_rpn_loss_grad, dim3((N + 255) / 256, B), dim3(256), 0, st, cls_score, bbox_pred, labels,
+    lmh_launch(k_rpn_loss_grad, dim3((N + 255) / 256, B), dim3(256), 0, st, cls_score, bbox_pred, labels,
                        bbox_targets, B, N, sigma * sigma, w_cls, w_reg, per_image, d_cls_score, d_bbox_pred);
-  hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, w_cls, w_reg, losses);
+  lmh_launch(k_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, w_cls, w_reg, losses);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -252,13 +252,13 @@ extern "C" int lmh_rcnn_loss(const float* cls_score, const float* bbox_offsets, 
   LMH_CHECK_ARG(cls_score && bbox_offsets && labels && targets && losses && per_image);
   LMH_CHECK_ARG(B > 0 && R > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_rcnn_loss, dim3(B), dim3(LOSS_THREADS), 0, st, cls_score, bbox_offsets, labels,
+  lmh_launch(k_rcnn_loss, dim3(B), dim3(LOSS_THREADS), 0, st, cls_score, bbox_offsets, labels,
                      targets, B, R, C, sigma * sigma, per_image);
   if (d_cls_score || d_bbox_offsets)
-    hipLaunchKernelGGL(k_rcnn_loss_grad, dim3((unsigned)(((int64_t)B * R + 3) / 4)), dim3(256), 0, st, cls_score,
+    lmh_launch(k_rcnn_loss_grad, dim3((unsigned)(((int64_t)B * R + 3) / 4)), dim3(256), 0, st, cls_score,
                        bbox_offsets, labels, targets, B, R, C, sigma * sigma, w_cls, w_reg, per_image, d_cls_score,
                        d_bbox_offsets);
-  hipLaunchKernelGGL(k_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, w_cls, w_reg, losses);
+  lmh_launch(k_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, w_cls, w_reg, losses);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -280,7 +280,7 @@ k_softmax(const float* __restrict__ x, int64_t rows, int C, float* __restrict__ 
 }
 extern "C" int lmh_softmax(const float* x, int64_t rows, int C, float* y, lmh_stream_t stream) {
   LMH_CHECK_ARG(x && y && rows > 0 && C > 0);
-  hipLaunchKernelGGL(k_softmax, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+  lmh_launch(k_softmax, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
                      rows, C, y);
   LMH_CHECK_LAUNCH();
   return LMH_OK;

@@ -67,7 +67,7 @@ extern "C" int lmh_sgd_momentum(float* w, const float* g, float* v, int64_t n, c
   LMH_CHECK_ARG(w && g && v && seg_offset && seg_wd && n > 0 && nseg > 0 && nseg <= OPT_MAX_SEG);
   const int64_t n4 = n >> 2;
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 + 1 : 2048);
-  hipLaunchKernelGGL(k_sgd_momentum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, v, n,
+  lmh_launch(k_sgd_momentum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, v, n,
                      seg_offset, seg_wd, nseg, lr, momentum, gscale);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -113,7 +113,7 @@ extern "C" int lmh_l2_reg_loss(const float* w, int64_t n, const int64_t* seg_off
   LMH_CHECK_ARG(w && seg_offset && seg_wd && out && n > 0 && nseg > 0 && nseg <= OPT_MAX_SEG);
   const int64_t n4 = n >> 2;
   const int blocks = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 + 1 : 1024);
-  hipLaunchKernelGGL(k_l2_reg, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, n, seg_offset,
+  lmh_launch(k_l2_reg, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, n, seg_offset,
                      seg_wd, nseg, out);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -169,10 +169,10 @@ extern "C" int lmh_grad_clip_factors(const float* w, const float* g, int64_t n, 
   LMH_CHECK_ARG(clip_norm > 0.f && ws_bytes >= lmh_grad_clip_workspace_bytes(nseg));
   hipStream_t st = (hipStream_t)stream;
   double* ss = reinterpret_cast<double*>(ws);
-  LMH_CHECK_HIP(hipMemsetAsync(ss, 0, sizeof(double) * nseg, st));
+  LMH_CHECK_HIP(lmh_memset_async(ss, 0, sizeof(double) * nseg, st));
   const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-  hipLaunchKernelGGL(k_seg_sqnorm, dim3(blocks), dim3(256), 0, st, w, g, n, seg_offset, seg_wd, nseg, gscale, ss);
-  hipLaunchKernelGGL(k_clip_factor, dim3((nseg + 255) / 256), dim3(256), 0, st, (const double*)ss, nseg, clip_norm,
+  lmh_launch(k_seg_sqnorm, dim3(blocks), dim3(256), 0, st, w, g, n, seg_offset, seg_wd, nseg, gscale, ss);
+  lmh_launch(k_clip_factor, dim3((nseg + 255) / 256), dim3(256), 0, st, (const double*)ss, nseg, clip_norm,
                      factors);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -228,7 +228,7 @@ extern "C" int lmh_optimizer_step(int kind, float* w, const float* g, float* slo
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_OPT(K_)                                                                                          \
-  hipLaunchKernelGGL((k_optimizer<K_>), dim3(blocks), dim3(256), 0, st, w, g, slot1, slot2, n, seg_offset, seg_wd, \
+  lmh_launch((k_optimizer<K_>), dim3(blocks), dim3(256), 0, st, w, g, slot1, slot2, n, seg_offset, seg_wd, \
                      seg_factor, nseg, lr, p1, p2, eps, gscale)
   if (kind == 0) LAUNCH_OPT(0);
   else if (kind == 1) LAUNCH_OPT(1);

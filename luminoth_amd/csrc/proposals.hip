@@ -158,7 +158,7 @@ int lmh_sort_u64_impl(uint64_t* keys, int B, int n_pad, hipStream_t st) {
   const int chunk = n_pad < SORT_CHUNK ? n_pad : SORT_CHUNK;
   const size_t lds = (size_t)chunk * sizeof(uint64_t);
   dim3 gl(n_pad / chunk, B);
-  hipLaunchKernelGGL(k_sort_local, gl, dim3(SORT_THREADS), lds, st, keys, n_pad, chunk);
+  lmh_launch(k_sort_local, gl, dim3(SORT_THREADS), lds, st, keys, n_pad, chunk);
   for (int k = chunk * 2; k <= n_pad; k <<= 1) {
     int j = k >> 1;
     while (j >= chunk) {
@@ -166,13 +166,13 @@ int lmh_sort_u64_impl(uint64_t* keys, int B, int n_pad, hipStream_t st) {
       for (int q = j; q >= chunk; q >>= 1) ++ns;
       const int S = ns >= 4 ? 4 : ns;
       dim3 gg((n_pad / (1 << S) + 255) / 256, B);
-      if (S == 4) hipLaunchKernelGGL(k_sort_global_multi<4>, gg, dim3(256), 0, st, keys, n_pad, k, j);
-      else if (S == 3) hipLaunchKernelGGL(k_sort_global_multi<3>, gg, dim3(256), 0, st, keys, n_pad, k, j);
-      else if (S == 2) hipLaunchKernelGGL(k_sort_global_multi<2>, gg, dim3(256), 0, st, keys, n_pad, k, j);
-      else hipLaunchKernelGGL(k_sort_global, gg, dim3(256), 0, st, keys, n_pad, k, j);
+      if (S == 4) lmh_launch(k_sort_global_multi<4>, gg, dim3(256), 0, st, keys, n_pad, k, j);
+      else if (S == 3) lmh_launch(k_sort_global_multi<3>, gg, dim3(256), 0, st, keys, n_pad, k, j);
+      else if (S == 2) lmh_launch(k_sort_global_multi<2>, gg, dim3(256), 0, st, keys, n_pad, k, j);
+      else lmh_launch(k_sort_global, gg, dim3(256), 0, st, keys, n_pad, k, j);
       j >>= S;
     }
-    hipLaunchKernelGGL(k_sort_merge_local, gl, dim3(SORT_THREADS), lds, st, keys, n_pad, chunk, k);
+    lmh_launch(k_sort_merge_local, gl, dim3(SORT_THREADS), lds, st, keys, n_pad, chunk, k);
   }
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -395,9 +395,9 @@ int lmh_nms_impl(const float* boxes, const int32_t* counts, int B, int K, float 
   const int W = (K + 63) / 64;
   uint64_t* mask = reinterpret_cast<uint64_t*>(ws);
   dim3 g(W, W, B);
-  hipLaunchKernelGGL(k_nms_mask, g, dim3(64), 0, st, reinterpret_cast<const float4*>(boxes), counts,
+  lmh_launch(k_nms_mask, g, dim3(64), 0, st, reinterpret_cast<const float4*>(boxes), counts,
                      K, W, thr, mask);
-  hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts,
+  lmh_launch(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts,
                      K, W, max_out, keep_idx, keep_count);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -510,22 +510,22 @@ extern "C" int lmh_rpn_proposal(const lmh_rpn_proposal_desc* d, const float* cls
   hipStream_t st = (hipStream_t)stream;
   const int B = d->B, K = d->pre_nms_top_n;
   const int P = d->apply_nms ? d->post_nms_top_n : d->pre_nms_top_n;  // no post cap without NMS (rpn_proposal.py:172-174)
-  LMH_CHECK_HIP(hipMemsetAsync(w.n_valid, 0, sizeof(int32_t) * B, st));
-  hipLaunchKernelGGL(k_rpn_decode, dim3((Npad + 255) / 256, B), dim3(256), 0, st, *d, N, Npad,
+  LMH_CHECK_HIP(lmh_memset_async(w.n_valid, 0, sizeof(int32_t) * B, st));
+  lmh_launch(k_rpn_decode, dim3((Npad + 255) / 256, B), dim3(256), 0, st, *d, N, Npad,
                      cls_score, bbox_pred, anchor_ref, cls_prob, w.boxes, w.keys, w.n_valid);
   int rc = lmh_sort_u64_impl(w.keys, B, Npad, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_gather_topk, dim3((K + 255) / 256, B), dim3(256), 0, st, w.keys, w.boxes,
+  lmh_launch(k_gather_topk, dim3((K + 255) / 256, B), dim3(256), 0, st, w.keys, w.boxes,
                      cls_prob, w.n_valid, N, Npad, K, w.top_boxes, w.top_scores, w.top_count);
   if (d->apply_nms) {
     rc = lmh_nms_impl(reinterpret_cast<const float*>(w.top_boxes), w.top_count, B, K, d->nms_threshold,
                   P, w.keep_idx, w.keep_count, w.nms_ws, st);
     if (rc) return rc;
   } else {
-    hipLaunchKernelGGL(k_iota_keep, dim3((P + 255) / 256, B), dim3(256), 0, st, w.top_count, P,
+    lmh_launch(k_iota_keep, dim3((P + 255) / 256, B), dim3(256), 0, st, w.top_count, P,
                        w.keep_idx, w.keep_count);
   }
-  hipLaunchKernelGGL(k_gather_keep, dim3((P + 255) / 256, B), dim3(256), 0, st, w.top_boxes,
+  lmh_launch(k_gather_keep, dim3((P + 255) / 256, B), dim3(256), 0, st, w.top_boxes,
                      w.top_scores, w.keep_idx, w.keep_count, K, P, d->clip_after_nms, d->im_h,
                      d->im_w, reinterpret_cast<float4*>(proposals), scores, num_proposals);
   LMH_CHECK_LAUNCH();

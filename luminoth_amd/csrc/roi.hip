@@ -171,7 +171,7 @@ extern "C" int lmh_roi_pool_fwd(const float* feat, const float* rois, const int3
   LMH_CHECK_ARG(feat && rois && roi_count && out);
   LMH_CHECK_ARG(B > 0 && R > 0 && FH > 0 && FW > 0 && C > 0 && (C % 4) == 0 && ph > 0 && pw > 0);
   const int threads = (C / 4) < 256 ? ((C / 4 + 63) / 64 * 64) : 256;
-  hipLaunchKernelGGL(k_roi_pool_fwd, dim3(B * R * ph), dim3(threads), 0, (hipStream_t)stream, feat,
+  lmh_launch(k_roi_pool_fwd, dim3(B * R * ph), dim3(threads), 0, (hipStream_t)stream, feat,
                      reinterpret_cast<const float4*>(rois), roi_count, R, B * R, FH, FW, C, im_h, im_w,
                      ph, pw, out, argmax);
   LMH_CHECK_LAUNCH();
@@ -240,7 +240,7 @@ template <int CS, bool MEAN>
 __global__ void __launch_bounds__(1024)
 k_roi_pool_bwd_slab(const float* __restrict__ dout, const uint8_t* __restrict__ argmax,
                     const roi_sample_rec* __restrict__ table, const int32_t* __restrict__ roi_count, int R,
-                    int FH, int FW, int C, int cells, float* __restrict__ dfeat) {
+                    int FH, int FW, int C, int cells, const float* __restrict__ addend, float* __restrict__ dfeat) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long slab[];   // [npix][CS] fixed point
   const int b = blockIdx.y, c0 = roi_slab_of_block(blockIdx.x, gridDim.x) * CS;
   const int npix = FH * FW;
@@ -273,6 +273,10 @@ k_roi_pool_bwd_slab(const float* __restrict__ dout, const uint8_t* __restrict__ 
     v.y = (float)((double)(long long)p4[1] * ROI_FX_INV);
     v.z = (float)((double)(long long)p4[2] * ROI_FX_INV);
     v.w = (float)((double)(long long)p4[3] * ROI_FX_INV);
+    if (addend) {       // the other branch's gradient of the same feature map (RPN): the sum leaves in this one store
+      const float4 a = *reinterpret_cast<const float4*>(addend + (size_t)b * npix * C + c0 + (size_t)pix * C + 4 * part);
+      v.x = a.x + v.x; v.y = a.y + v.y; v.z = a.z + v.z; v.w = a.w + v.w;
+    }
     *reinterpret_cast<float4*>(fb + (size_t)pix * C + 4 * part) = v;
   }
 }
@@ -283,17 +287,17 @@ extern "C" size_t lmh_roi_pool_bwd_workspace_bytes(int B, int R, int ph, int pw)
 
 template <int CS, bool MEAN>
 static int roi_bwd_slab_launch(const float* dout, const uint8_t* argmax, const roi_sample_rec* table,
-                               const int32_t* roi_count, int B, int R, int FH, int FW, int C, int cells, float* dfeat,
-                               hipStream_t st) {
+                               const int32_t* roi_count, int B, int R, int FH, int FW, int C, int cells,
+                               const float* addend, float* dfeat, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
     LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_bwd_slab<CS, MEAN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  hipLaunchKernelGGL((k_roi_pool_bwd_slab<CS, MEAN>), dim3(C / CS, B), dim3(1024),
+  lmh_launch((k_roi_pool_bwd_slab<CS, MEAN>), dim3(C / CS, B), dim3(1024),
                      (size_t)FH * FW * CS * sizeof(unsigned long long), st, dout, argmax, table, roi_count, R, FH, FW, C,
-                     cells, dfeat);
+                     cells, addend, dfeat);
   return LMH_OK;
 }
 
@@ -306,11 +310,12 @@ static int roi_slab_width(int FH, int FW, int C) {      // channels per LDS slab
   return 0;
 }
 
-// dfeat is OVERWRITTEN (it does not need to be zeroed by the caller).
+// dfeat is OVERWRITTEN (it does not need to be zeroed by the caller) with the gradient, plus `addend` (same shape,
+// may be NULL; must not alias dfeat) — the gradient another branch left for the same feature map.
 extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const float* rois,
                                 const int32_t* roi_count, int B, int R, int FH, int FW, int C,
-                                float im_h, float im_w, int ph, int pw, float* dfeat, void* ws, size_t ws_bytes,
-                                lmh_stream_t stream) {
+                                float im_h, float im_w, int ph, int pw, const float* addend, float* dfeat, void* ws,
+                                size_t ws_bytes, lmh_stream_t stream) {
   LMH_CHECK_ARG(dout && argmax && rois && roi_count && dfeat);
   LMH_CHECK_ARG(B > 0 && R > 0 && FH > 0 && FW > 0 && C > 0 && ph > 0 && pw > 0);
   hipStream_t st = (hipStream_t)stream;
@@ -323,15 +328,16 @@ extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const 
     }
     roi_sample_rec* table = reinterpret_cast<roi_sample_rec*>(ws);
     const int cells = ph * pw;
-    hipLaunchKernelGGL(k_roi_sample_table, dim3((B * R * cells + 255) / 256), dim3(256), 0, st,
+    lmh_launch(k_roi_sample_table, dim3((B * R * cells + 255) / 256), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(rois), roi_count, B, R, FH, FW, im_h, im_w, ph, pw, table);
-    const int rc = cs == 8 ? roi_bwd_slab_launch<8, false>(dout, argmax, table, roi_count, B, R, FH, FW, C, cells, dfeat, st)
-                           : roi_bwd_slab_launch<4, false>(dout, argmax, table, roi_count, B, R, FH, FW, C, cells, dfeat, st);
+    const int rc = cs == 8 ? roi_bwd_slab_launch<8, false>(dout, argmax, table, roi_count, B, R, FH, FW, C, cells, addend, dfeat, st)
+                           : roi_bwd_slab_launch<4, false>(dout, argmax, table, roi_count, B, R, FH, FW, C, cells, addend, dfeat, st);
     if (rc != LMH_OK) return rc;
   } else {   // very large feature maps: global scatter-add
-    LMH_CHECK_HIP(hipMemsetAsync(dfeat, 0, (size_t)B * npix * C * sizeof(float), st));
+    if (addend) LMH_CHECK_HIP(lmh_memcpy_d2d_async(dfeat, addend, (size_t)B * npix * C * sizeof(float), st));
+    else LMH_CHECK_HIP(lmh_memset_async(dfeat, 0, (size_t)B * npix * C * sizeof(float), st));
     const int threads = C < 256 ? ((C + 63) / 64 * 64) : 256;
-    hipLaunchKernelGGL(k_roi_pool_bwd, dim3(ph * pw, B * R), dim3(threads), 0, st, dout, argmax,
+    lmh_launch(k_roi_pool_bwd, dim3(ph * pw, B * R), dim3(threads), 0, st, dout, argmax,
                        reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, dfeat);
   }
   LMH_CHECK_LAUNCH();
@@ -433,7 +439,7 @@ extern "C" int lmh_roi_pool_mean_fwd(const float* feat, const float* rois, const
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr = true;
     }
-    hipLaunchKernelGGL((k_roi_pool_mean_fwd<8>), dim3(C / 8, B), dim3(1024), lds, st, feat,
+    lmh_launch((k_roi_pool_mean_fwd<8>), dim3(C / 8, B), dim3(1024), lds, st, feat,
                        reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, mean, argmax);
   } else {
     static bool attr = false;
@@ -442,7 +448,7 @@ extern "C" int lmh_roi_pool_mean_fwd(const float* feat, const float* rois, const
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr = true;
     }
-    hipLaunchKernelGGL((k_roi_pool_mean_fwd<4>), dim3(C / 4, B), dim3(1024), lds, st, feat,
+    lmh_launch((k_roi_pool_mean_fwd<4>), dim3(C / 4, B), dim3(1024), lds, st, feat,
                        reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, mean, argmax);
   }
   LMH_CHECK_LAUNCH();
@@ -452,8 +458,8 @@ extern "C" int lmh_roi_pool_mean_fwd(const float* feat, const float* rois, const
 // dmean (B*R, C): gradient of the means; dfeat is OVERWRITTEN.
 extern "C" int lmh_roi_pool_mean_bwd(const float* dmean, const uint8_t* argmax, const float* rois,
                                      const int32_t* roi_count, int B, int R, int FH, int FW, int C, float im_h,
-                                     float im_w, int ph, int pw, float* dfeat, void* ws, size_t ws_bytes,
-                                     lmh_stream_t stream) {
+                                     float im_w, int ph, int pw, const float* addend, float* dfeat, void* ws,
+                                     size_t ws_bytes, lmh_stream_t stream) {
   LMH_CHECK_ARG(dmean && argmax && rois && roi_count && dfeat);
   LMH_CHECK_ARG(B > 0 && R > 0 && FH > 0 && FW > 0 && C > 0 && ph > 0 && pw > 0);
   const int cs = roi_slab_width(FH, FW, C);
@@ -468,10 +474,10 @@ extern "C" int lmh_roi_pool_mean_bwd(const float* dmean, const uint8_t* argmax, 
   hipStream_t st = (hipStream_t)stream;
   roi_sample_rec* table = reinterpret_cast<roi_sample_rec*>(ws);
   const int cells = ph * pw;
-  hipLaunchKernelGGL(k_roi_sample_table, dim3((B * R * cells + 255) / 256), dim3(256), 0, st,
+  lmh_launch(k_roi_sample_table, dim3((B * R * cells + 255) / 256), dim3(256), 0, st,
                      reinterpret_cast<const float4*>(rois), roi_count, B, R, FH, FW, im_h, im_w, ph, pw, table);
-  const int rc = cs == 8 ? roi_bwd_slab_launch<8, true>(dmean, argmax, table, roi_count, B, R, FH, FW, C, cells, dfeat, st)
-                         : roi_bwd_slab_launch<4, true>(dmean, argmax, table, roi_count, B, R, FH, FW, C, cells, dfeat, st);
+  const int rc = cs == 8 ? roi_bwd_slab_launch<8, true>(dmean, argmax, table, roi_count, B, R, FH, FW, C, cells, addend, dfeat, st)
+                         : roi_bwd_slab_launch<4, true>(dmean, argmax, table, roi_count, B, R, FH, FW, C, cells, addend, dfeat, st);
   if (rc != LMH_OK) return rc;
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -499,14 +505,14 @@ k_spatial_mean_bwd(const float* __restrict__ dy, int S, int C, float* __restrict
 }
 extern "C" int lmh_spatial_mean_fwd(const float* x, int64_t M, int S, int C, float* y, lmh_stream_t stream) {
   LMH_CHECK_ARG(x && y && M > 0 && S > 0 && C > 0);
-  hipLaunchKernelGGL(k_spatial_mean_fwd, dim3((C + 255) / 256, (unsigned)M), dim3(256), 0,
+  lmh_launch(k_spatial_mean_fwd, dim3((C + 255) / 256, (unsigned)M), dim3(256), 0,
                      (hipStream_t)stream, x, S, C, y);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
 extern "C" int lmh_spatial_mean_bwd(const float* dy, int64_t M, int S, int C, float* dx, lmh_stream_t stream) {
   LMH_CHECK_ARG(dy && dx && M > 0 && S > 0 && C > 0);
-  hipLaunchKernelGGL(k_spatial_mean_bwd, dim3((C + 255) / 256, (unsigned)M), dim3(256), 0,
+  lmh_launch(k_spatial_mean_bwd, dim3((C + 255) / 256, (unsigned)M), dim3(256), 0,
                      (hipStream_t)stream, dy, S, C, dx);
   LMH_CHECK_LAUNCH();
   return LMH_OK;

@@ -123,7 +123,7 @@ static int l2n_blocks(int64_t P) { return (int)((P + 3) / 4 < 512 ? (P + 3) / 4 
 extern "C" int lmh_l2norm_scale_fwd(const float* x, const float* gamma, int64_t P, int C, float eps, float* y,
                                     lmh_stream_t stream) {
   LMH_CHECK_ARG(x && gamma && y && P > 0 && C > 0 && (C & 3) == 0 && C <= 256 * L2N_MAX_C4);
-  hipLaunchKernelGGL(k_l2norm_fwd, dim3(l2n_blocks(P)), dim3(256), 0, (hipStream_t)stream, x, gamma, P, C, eps, y);
+  lmh_launch(k_l2norm_fwd, dim3(l2n_blocks(P)), dim3(256), 0, (hipStream_t)stream, x, gamma, P, C, eps, y);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -142,8 +142,8 @@ extern "C" int lmh_l2norm_scale_bwd(const float* x, const float* dy, const float
   hipStream_t st = (hipStream_t)stream;
   const int nb = l2n_blocks(P);
   float* part = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(k_l2norm_bwd, dim3(nb), dim3(256), 0, st, x, dy, gamma, P, C, eps, dx, part);
-  hipLaunchKernelGGL(k_l2norm_finish, dim3((C + 31) / 32), dim3(256), 0, st, part, nb, C, dgamma);
+  lmh_launch(k_l2norm_bwd, dim3(nb), dim3(256), 0, st, x, dy, gamma, P, C, eps, dx, part);
+  lmh_launch(k_l2norm_finish, dim3((C + 31) / 32), dim3(256), 0, st, part, nb, C, dgamma);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
@@ -269,16 +269,16 @@ extern "C" int lmh_ssd_target(const lmh_ssd_target_desc* d, const float* anchors
   const int Npad = lmh_next_pow2(d->N);
   ssd_ws w;
   ssd_ws_layout(d->B, d->N, Npad, d->Gmax, ws, &w);
-  LMH_CHECK_HIP(hipMemsetAsync(w.gt_best, 0, (size_t)d->B * d->Gmax * 8, st));
-  LMH_CHECK_HIP(hipMemsetAsync(w.num_fg, 0, (size_t)d->B * 4, st));
+  LMH_CHECK_HIP(lmh_memset_async(w.gt_best, 0, (size_t)d->B * d->Gmax * 8, st));
+  LMH_CHECK_HIP(lmh_memset_async(w.num_fg, 0, (size_t)d->B * 4, st));
   const dim3 gn((d->N + 255) / 256, d->B), gp((Npad + 255) / 256, d->B);
-  hipLaunchKernelGGL(k_ssd_target_a, gn, dim3(256), 0, st, *d, reinterpret_cast<const float4*>(anchors), gt, gt_count,
+  lmh_launch(k_ssd_target_a, gn, dim3(256), 0, st, *d, reinterpret_cast<const float4*>(anchors), gt, gt_count,
                      labels, max_overlaps, w);
-  hipLaunchKernelGGL(k_ssd_target_b, gp, dim3(256), 0, st, *d, Npad, gt, gt_count, probs, labels, max_overlaps, w);
+  lmh_launch(k_ssd_target_b, gp, dim3(256), 0, st, *d, Npad, gt, gt_count, probs, labels, max_overlaps, w);
   int rc = lmh_sort_u64_impl(w.keys, d->B, Npad, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_ssd_target_c, gp, dim3(256), 0, st, *d, Npad, labels, w);
-  hipLaunchKernelGGL(k_ssd_target_d, gn, dim3(256), 0, st, *d, reinterpret_cast<const float4*>(anchors), gt, labels,
+  lmh_launch(k_ssd_target_c, gp, dim3(256), 0, st, *d, Npad, labels, w);
+  lmh_launch(k_ssd_target_d, gn, dim3(256), 0, st, *d, reinterpret_cast<const float4*>(anchors), gt, labels,
                      reinterpret_cast<float4*>(bbox_targets), w);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -379,9 +379,9 @@ extern "C" int lmh_ssd_loss(const float* cls_pred, const float* loc_pred, const 
                             float* d_cls_pred, float* d_loc_pred, lmh_stream_t stream) {
   LMH_CHECK_ARG(cls_pred && loc_pred && labels && targets && losses && per_image && B > 0 && N > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_ssd_loss, dim3(B), dim3(SSD_LOSS_THREADS), 0, st, cls_pred, loc_pred, labels, targets, B, N, C,
+  lmh_launch(k_ssd_loss, dim3(B), dim3(SSD_LOSS_THREADS), 0, st, cls_pred, loc_pred, labels, targets, B, N, C,
                      sigma * sigma, w_loc, per_image, d_cls_pred, d_loc_pred);
-  hipLaunchKernelGGL(k_ssd_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, losses);
+  lmh_launch(k_ssd_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, losses);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

@@ -187,8 +187,8 @@ extern "C" int lmh_wgrad_tail_batch(const lmh_wgrad_tail* tails, int count, void
     // part0[n] closes the last layer's partial range (k_tail_finish derives the row count from the difference)
     ra.part0[n] = part_off;
     fa.part0[n] = part_off;
-    if (nb_r > 0) hipLaunchKernelGGL(k_tail_reduce, dim3(nb_r), dim3(256), 0, st, ra, partial);
-    if (nb_f > 0) hipLaunchKernelGGL(k_tail_finish, dim3(nb_f), dim3(256), 0, st, fa, (const float*)partial);
+    if (nb_r > 0) lmh_launch(k_tail_reduce, dim3(nb_r), dim3(256), 0, st, ra, partial);
+    if (nb_f > 0) lmh_launch(k_tail_finish, dim3(nb_f), dim3(256), 0, st, fa, (const float*)partial);
   }
   LMH_CHECK_LAUNCH();
   return LMH_OK;

@@ -359,17 +359,17 @@ extern "C" int lmh_rpn_target(const lmh_rpn_target_desc* d, const int32_t* ancho
   int32_t* argmax = reinterpret_cast<int32_t*>(ws);
   uint32_t* gt_max = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) +
                                                  lmh_align_up((size_t)d->B * N * 4, 256));
-  LMH_CHECK_HIP(hipMemsetAsync(gt_max, 0, (size_t)d->B * d->Gmax * 4, st));
+  LMH_CHECK_HIP(lmh_memset_async(gt_max, 0, (size_t)d->B * d->Gmax * 4, st));
   dim3 g((N + 255) / 256, d->B);
-  hipLaunchKernelGGL(k_rpn_target_rowmax, g, dim3(256), 0, st, *d, N, anchor_ref, gt, gt_count,
+  lmh_launch(k_rpn_target_rowmax, g, dim3(256), 0, st, *d, N, anchor_ref, gt, gt_count,
                      max_overlaps, argmax, gt_max);
-  hipLaunchKernelGGL(k_rpn_target_labels, g, dim3(256), 0, st, *d, N, anchor_ref, gt, gt_count,
+  lmh_launch(k_rpn_target_labels, g, dim3(256), 0, st, *d, N, anchor_ref, gt, gt_count,
                      max_overlaps, argmax, gt_max, labels, labels_pre);
   if (N <= RT_LDS_MAX_N)
-    hipLaunchKernelGGL(k_rpn_target_subsample, dim3(d->B), dim3(RT_SUB_THREADS), 0, st, *d, N,
+    lmh_launch(k_rpn_target_subsample, dim3(d->B), dim3(RT_SUB_THREADS), 0, st, *d, N,
                      anchor_ref, gt, gt_count, seeds, argmax, labels, bbox_targets);
   else
-    hipLaunchKernelGGL(k_rpn_target_subsample_global, dim3(d->B), dim3(RT_SUB_THREADS), 0, st, *d, N,
+    lmh_launch(k_rpn_target_subsample_global, dim3(d->B), dim3(RT_SUB_THREADS), 0, st, *d, N,
                      anchor_ref, gt, gt_count, seeds, argmax, labels, bbox_targets);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
@@ -609,11 +609,11 @@ extern "C" int lmh_rcnn_target(const lmh_rcnn_target_desc* d, const float* propo
     return LMH_ERR_WORKSPACE;
   }
   if (d->P <= CT_LDS_MAX_P)
-    hipLaunchKernelGGL(k_rcnn_target<false>, dim3(d->B), dim3(CT_THREADS), 0, (hipStream_t)stream, *d,
+    lmh_launch(k_rcnn_target<false>, dim3(d->B), dim3(CT_THREADS), 0, (hipStream_t)stream, *d,
                        proposals, prop_count, gt, gt_count, seeds, labels, bbox_targets, labels_pre, rois,
                        roi_labels, roi_targets, roi_count, reinterpret_cast<unsigned char*>(ws));
   else
-    hipLaunchKernelGGL(k_rcnn_target<true>, dim3(d->B), dim3(CT_THREADS), 0, (hipStream_t)stream, *d,
+    lmh_launch(k_rcnn_target<true>, dim3(d->B), dim3(CT_THREADS), 0, (hipStream_t)stream, *d,
                        proposals, prop_count, gt, gt_count, seeds, labels, bbox_targets, labels_pre, rois,
                        roi_labels, roi_targets, roi_count, reinterpret_cast<unsigned char*>(ws));
   LMH_CHECK_LAUNCH();

@@ -16,9 +16,23 @@ from ._lib import (ConvDesc, RpnProposalDesc, RpnTargetDesc, RcnnTargetDesc, Rcn
 ACT = {None: 0, 'none': 0, 'relu': 1, 'relu6': 2}
 
 
+# While a launch plan is being recorded (luminoth_amd/plan.py) every tensor whose address enters a launch is appended
+# here and kept alive by the plan: a recorded pointer must stay valid — and must never be handed to another tensor —
+# for as long as the plan is replayed.
+_PLAN_KEEP = None
+
+
+def plan_keep(*tensors):
+    """Tensors whose data_ptr() goes into a launch without passing through _p (descriptor arrays)."""
+    if _PLAN_KEEP is not None:
+        _PLAN_KEEP.extend(t for t in tensors if t is not None)
+
+
 def _p(t):
     if t is None:
         return None
+    if _PLAN_KEEP is not None:
+        _PLAN_KEEP.append(t)
     if not t.is_cuda:
         raise _lib.LuminothHipError('luminoth_amd kernels need ROCm device tensors (got %s); '
                                     'there is no CPU fallback' % t.device)
@@ -60,6 +74,48 @@ def stream_wait(waiter, signaler):
           'lmh_stream_wait_stream')
 
 
+def event_record(event, stream):
+    """hipEventRecord of a library event (lmh_event_create handle) on a torch stream — recordable in a launch plan."""
+    check(_lib.load().lmh_event_record(ctypes.c_void_p(event), ctypes.c_void_p(stream.cuda_stream)), 'lmh_event_record')
+
+
+def stream_wait_event(stream, event):
+    check(_lib.load().lmh_stream_wait_event(ctypes.c_void_p(stream.cuda_stream), ctypes.c_void_p(event)),
+          'lmh_stream_wait_event')
+
+
+def zero_(t):
+    """t <- 0 on the launch stream (async memset through the library: recordable, no framework fill kernel)."""
+    assert t.is_contiguous()
+    check(_lib.load().lmh_memset(_p(t), 0, ctypes.c_size_t(t.numel() * t.element_size()), _stream()), 'lmh_memset')
+    return t
+
+
+def copy_(dst, src):
+    """dst <- src (same dtype / number of elements, both contiguous device tensors) on the launch stream."""
+    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel(), \
+        (dst.shape, src.shape, dst.dtype, src.dtype)
+    check(_lib.load().lmh_memcpy_d2d(_p(dst), _p(src), ctypes.c_size_t(dst.numel() * dst.element_size()), _stream()),
+          'lmh_memcpy_d2d')
+    return dst
+
+
+def bn_refresh(gamma, beta, mean, rstd, scale, shift):
+    check(_lib.load().lmh_bn_refresh(_p(gamma), _p(beta), _p(mean), _p(rstd), gamma.numel(), _p(scale), _p(shift),
+                                     _stream()), 'lmh_bn_refresh')
+
+
+def loss_sums(terms, reg_a=None, reg_b=None, out=None):
+    """-> out (3,) = [total, no_reg, regularization]: no_reg = ((t0 + t1) + t2) + ..., regularization = reg_a + reg_b
+    (fasterrcnn.py:203-259) in ONE single-thread launch.  `terms`: 0-d / 1-element device tensors."""
+    dev = terms[0].device
+    out = out if out is not None else torch.empty((3,), dtype=torch.float32, device=dev)
+    arr = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+    plan_keep(*terms)
+    check(_lib.load().lmh_loss_sums(arr, len(terms), _p(reg_a), _p(reg_b), _p(out), _stream()), 'lmh_loss_sums')
+    return out
+
+
 def _stream_id(device=None):
     """Raw hipStream_t (int) of torch's CURRENT stream on `device` (default: current device)."""
     if _stream_override is not None:
@@ -72,6 +128,12 @@ def _stream_id(device=None):
 
 def _stream():
     return ctypes.c_void_p(_stream_id())
+
+
+def effective_stream(device=None):
+    """The torch.cuda.Stream launches of this module go to right now: the launch_on override when one is set, else torch's
+    current stream (what record_stream-style protection must be issued against)."""
+    return _stream_override_obj if _stream_override_obj is not None else torch.cuda.current_stream(device)
 
 
 def _f32(t):
@@ -139,10 +201,10 @@ class TailQueue(object):
         if self.early is None or len(self.order) < self.EARLY_MIN:
             return
         stream, producers = self.early
-        stream.wait_stream(torch.cuda.current_stream(stream.device))
+        stream_wait(stream, torch.cuda.current_stream(stream.device))
         for st in producers():
-            stream.wait_stream(st)
-        with torch.cuda.stream(stream):
+            stream_wait(stream, st)
+        with launch_on(stream):
             self.flush()
         self.early_used = True
 
@@ -183,6 +245,8 @@ class TailQueue(object):
             t.colpart, t.colrows = e.get('colpart', 0) or 0, e.get('colrows', 0)
             cs = e.get('colsum')
             t.colsum = cs.data_ptr() if cs is not None else 0
+            if _PLAN_KEEP is not None:
+                plan_keep(dw, cs, e.get('_ws'), e.get('_cws'), *(bn.values() if bn is not None else ()))
         ws = _workspace(lib.lmh_wgrad_tail_batch_workspace_bytes(arr, n), dev, 'tails')
         check(lib.lmh_wgrad_tail_batch(arr, n, _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_wgrad_tail_batch')
         self.entries, self.order = {}, []
@@ -336,7 +400,12 @@ def winograd_transform_weights(d, w, kscale, backward, out):
 
 def set_option(name, value):
     """Process-global tuning option of the C library (include/luminoth_hip.h: lmh_set_option)."""
+    global OPTION_VERSION
     check(_lib.load().lmh_set_option(name.encode(), int(value)), 'lmh_set_option')
+    OPTION_VERSION += 1
+
+
+OPTION_VERSION = 0      # bumped by every set_option: launch plans recorded under other options are not replayed
 
 
 def get_option(name):
@@ -368,6 +437,7 @@ def winograd_weights_batch(jobs, backward):
         arr[i].w, arr[i].u = w.data_ptr(), u.data_ptr()
         arr[i].kscale = ks.data_ptr() if ks is not None else None
         arr[i].C, arr[i].K = w.shape[2], w.shape[3]
+        plan_keep(w, ks, u)
     check(_lib.load().lmh_winograd_transform_weights_batch(arr, len(jobs), int(bool(backward)), _stream()),
           'lmh_winograd_transform_weights_batch')
 
@@ -427,7 +497,7 @@ def conv2d_bwd_weight_winograd(d, x, dy, out=None, colsum=None):
         same = all(a == b for a, b, (f, _) in zip(kept[0], dk, d._fields_) if f not in ('act', 'compute'))
         if same and kept[1] == get_option('wino_m') and kept[2] == x._version:
             v = kept[3]
-            keep_alive(v, torch.cuda.current_stream(x.device))
+            keep_alive(v, effective_stream(x.device))
     with _timed(d, 2, wino=True):
         check(lib.lmh_conv2d_bwd_weight_winograd(ctypes.byref(d), _p(_f32(x)), _p(_f32(dy)), _p(dw), _p(v), _p(colsum),
                                                  _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
@@ -607,6 +677,7 @@ def half_weights_batch(jobs, storage):
         arr[i].w_fwd = _half(wf, tdt).data_ptr() if wf is not None else None
         arr[i].w_bwd = _half(wb, tdt).data_ptr() if wb is not None else None
         arr[i].RS, arr[i].C, arr[i].K = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
+        plan_keep(w, ks, wf, wb)
     check(_lib.load().lmh_half_weights_batch(arr, len(jobs), code, _stream()), 'lmh_half_weights_batch')
 
 
@@ -626,10 +697,12 @@ def cast_to_f32(x, mul=1.0):
     return y
 
 
-def conv2d_fwd_hs(d, x, w_fwd, scale=None, shift=None, residual=None, out_f32=False, act_bits=None):
+def conv2d_fwd_hs(d, x, w_fwd, scale=None, shift=None, residual=None, out_f32=False, act_bits=None, out=None):
     code, tdt = half_type_of(x)
     assert code == d.compute, (code, d.compute)
-    y = torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32 if out_f32 else tdt, device=x.device)
+    y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32 if out_f32 else tdt,
+                                                device=x.device)
+    assert y.dtype == (torch.float32 if out_f32 else tdt) and tuple(y.shape) == (d.N, d.OH, d.OW, d.K)
     with _timed(d, 0):
         check(_lib.load().lmh_conv2d_fwd_hs(ctypes.byref(d), _p(x), _p(_half(w_fwd, tdt)), _p(scale), _p(shift),
                                             _p(None if residual is None else _half(residual, tdt)), _p(y), int(bool(out_f32)),
@@ -725,7 +798,7 @@ def maxpool_bwd(x, y, dy, ksize, stride, geom):
         dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
         check(lib.lmh_subsample_bwd_hs(_p(dy), N, H, W, C, stride, OH, OW, _p(dx), _stream()), 'lmh_subsample_bwd_hs')
         return dx
-    dx = torch.zeros_like(x)
+    dx = zero_(torch.empty_like(x))
     check(lib.lmh_maxpool_bwd(_p(x), _p(y), _p(dy), N, H, W, C, ksize, stride, pt, pl, OH, OW, _p(dx),
                               _stream()), 'lmh_maxpool_bwd')
     return dx
@@ -780,7 +853,8 @@ def nms(boxes, counts, iou_threshold, max_out):
 # --------------------------------------------------------------- targets ----
 def rpn_target(anchor_ref_i32, feat_h, feat_w, stride, gt, gt_count, seeds, im_shape, allowed_border=0,
                clobber_positives=False, foreground_threshold=0.7, background_threshold_high=0.3,
-               foreground_fraction=0.5, minibatch_size=256, want_pre=False):
+               foreground_fraction=0.5, minibatch_size=256, want_pre=False, out=None):
+    """out: optional (labels, targets, max_ov) tensors to write into (fixed addresses for the cross-step prefetch)."""
     lib = _lib.load()
     B, Gmax, _ = gt.shape
     A = anchor_ref_i32.shape[0]
@@ -789,9 +863,13 @@ def rpn_target(anchor_ref_i32, feat_h, feat_w, stride, gt, gt_count, seeds, im_s
                       int(allowed_border), int(bool(clobber_positives)), float(foreground_threshold),
                       float(background_threshold_high), float(foreground_fraction), int(minibatch_size))
     dev = gt.device
-    labels = torch.empty((B, N), dtype=torch.float32, device=dev)
-    targets = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
-    max_ov = torch.empty((B, N), dtype=torch.float32, device=dev)
+    if out is not None:
+        labels, targets, max_ov = out
+        assert labels.shape == (B, N) and targets.shape == (B, N, 4) and max_ov.shape == (B, N)
+    else:
+        labels = torch.empty((B, N), dtype=torch.float32, device=dev)
+        targets = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+        max_ov = torch.empty((B, N), dtype=torch.float32, device=dev)
     pre = torch.empty((B, N), dtype=torch.float32, device=dev) if want_pre else None
     ws = _workspace(lib.lmh_rpn_target_workspace_bytes(ctypes.byref(d)), dev, 'rpn_target')
     check(lib.lmh_rpn_target(ctypes.byref(d), _p(anchor_ref_i32), _p(gt), _p(gt_count), _p(seeds), _p(labels),
@@ -892,14 +970,15 @@ def roi_pool_fwd(feat, rois, roi_count, im_shape, ph=7, pw=7):
     return out, argmax
 
 
-def roi_pool_bwd(dout, argmax, rois, roi_count, feat_shape, im_shape, ph=7, pw=7, out=None):
+def roi_pool_bwd(dout, argmax, rois, roi_count, feat_shape, im_shape, ph=7, pw=7, out=None, addend=None):
+    """addend (feat_shape, optional): added to the result in the same store (the other consumer's gradient of the map)."""
     lib = _lib.load()
     B, FH, FW, C = feat_shape
     R = rois.shape[1]
     dfeat = out if out is not None else torch.empty(feat_shape, dtype=torch.float32, device=dout.device)   # overwritten
     ws = _workspace(lib.lmh_roi_pool_bwd_workspace_bytes(B, R, ph, pw), dout.device, 'roi_bwd')
     check(lib.lmh_roi_pool_bwd(_p(dout), _p(argmax), _p(rois), _p(roi_count), B, R, FH, FW, C,
-                               float(im_shape[0]), float(im_shape[1]), ph, pw, _p(dfeat), _p(ws),
+                               float(im_shape[0]), float(im_shape[1]), ph, pw, _p(addend), _p(dfeat), _p(ws),
                                ctypes.c_size_t(ws.numel()), _stream()), 'lmh_roi_pool_bwd')
     return dfeat
 
@@ -921,14 +1000,14 @@ def roi_pool_mean_fwd(feat, rois, roi_count, im_shape, ph=7, pw=7):
     return mean, argmax
 
 
-def roi_pool_mean_bwd(dmean, argmax, rois, roi_count, feat_shape, im_shape, ph=7, pw=7):
+def roi_pool_mean_bwd(dmean, argmax, rois, roi_count, feat_shape, im_shape, ph=7, pw=7, addend=None):
     lib = _lib.load()
     B, FH, FW, C = feat_shape
     R = rois.shape[1]
     dfeat = torch.empty(feat_shape, dtype=torch.float32, device=dmean.device)   # overwritten
     ws = _workspace(lib.lmh_roi_pool_bwd_workspace_bytes(B, R, ph, pw), dmean.device, 'roi_bwd')
     check(lib.lmh_roi_pool_mean_bwd(_p(dmean), _p(argmax), _p(rois), _p(roi_count), B, R, FH, FW, C,
-                                    float(im_shape[0]), float(im_shape[1]), ph, pw, _p(dfeat), _p(ws),
+                                    float(im_shape[0]), float(im_shape[1]), ph, pw, _p(addend), _p(dfeat), _p(ws),
                                     ctypes.c_size_t(ws.numel()), _stream()), 'lmh_roi_pool_mean_bwd')
     return dfeat
 
@@ -1021,9 +1100,9 @@ def dropout(x, keep_prob, seed):
     return y
 
 
-def l2_reg_loss(w, seg_offset, seg_wd):
+def l2_reg_loss(w, seg_offset, seg_wd, out=None):
     lib = _lib.load()
-    out = torch.zeros((1,), dtype=torch.float32, device=w.device)
+    out = zero_(out if out is not None else torch.empty((1,), dtype=torch.float32, device=w.device))
     check(lib.lmh_l2_reg_loss(_p(w), w.numel(), _p(seg_offset), _p(seg_wd), seg_wd.numel(), _p(out),
                               _stream()), 'lmh_l2_reg_loss')
     return out

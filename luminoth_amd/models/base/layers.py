@@ -68,7 +68,7 @@ class SideStream(object):
     @classmethod
     def join(cls):
         for st in cls._streams.values():
-            torch.cuda.current_stream(st.device).wait_stream(st)
+            K.stream_wait(torch.cuda.current_stream(st.device), st)
         # the joining stream is now ordered behind every side-stream reader, so the allocator may have the tensors back: a
         # freed block is only reused by later allocations of its OWN stream — the stream that just joined, or the proposal
         # stream, which waits for the joining stream before it allocates again (start of the next step)
@@ -141,9 +141,10 @@ class ConvLayer(object):
             self._desc[key] = d
         return d
 
-    def forward(self, x, residual=None, in_sub=None, want_bits=False, keep_v=False):
+    def forward(self, x, residual=None, in_sub=None, want_bits=False, keep_v=False, out=None):
         """want_bits: also return the activation bit mask of y (None when the layer has no activation or a channel
-        count that is not a multiple of 32) -> (y, bits)."""
+        count that is not a multiple of 32) -> (y, bits).  out: tensor the result is written to (a buffer at a fixed
+        address: the frozen trunk prefix computed one step ahead)."""
         d = self.desc(x.shape)
         bits = None
         if want_bits and FUSE_MASK and K.act_bits_ok(self.cout, self.act):
@@ -160,14 +161,15 @@ class ConvLayer(object):
             assert self.storage is not None and in_sub is None, (self.scope, x.dtype)
             if not self._wh_ready:
                 prepare_half_weights([self], self.storage)
-            y = K.conv2d_fwd_hs(d, x, self.wh[0], self.scale, self.shift, residual, out_f32=self.hs_out_f32, act_bits=bits)
+            y = K.conv2d_fwd_hs(d, x, self.wh[0], self.scale, self.shift, residual, out_f32=self.hs_out_f32, act_bits=bits,
+                                out=out)
             if self.hs_in_f32:
                 y._lmh_bits = bits               # the backward of this layer masks the incoming fp32 gradient with them
             if ACT_TAP is not None:
                 ACT_TAP[self.scope] = y
             return (y, bits) if want_bits else y
         # a training forward of a trainable Winograd layer keeps B^T x B for its weight gradient (kernels.py)
-        y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub, act_bits=bits,
+        y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub, out=out, act_bits=bits,
                          keep_v=(want_bits or keep_v) and self.trainable,
                          wino_u=self._wino_u[0] if self._wino_ready[0] else None)
         if ACT_TAP is not None:
@@ -375,8 +377,7 @@ class BNTable(object):
             rstd = torch.rsqrt(var + BN_EPS)
             scale = torch.empty(total, dtype=torch.float32, device=dev)
             shift = torch.empty(total, dtype=torch.float32, device=dev)
-            grp = dict(gamma=gamma, beta=beta, mean=mean, rstd=rstd, scale=scale, shift=shift,
-                       trainable=tr, tmp=torch.empty_like(scale))
+            grp = dict(gamma=gamma, beta=beta, mean=mean, rstd=rstd, scale=scale, shift=shift, trainable=tr)
             self.groups.append(grp)
             o = 0
             for s, k in ls:
@@ -399,9 +400,12 @@ class BNTable(object):
     def refresh(self, force=False):
         for grp in self.groups:
             if grp['trainable'] or force:
-                torch.mul(grp['gamma'], grp['rstd'], out=grp['scale'])
-                torch.mul(grp['mean'], grp['scale'], out=grp['tmp'])
-                torch.sub(grp['beta'], grp['tmp'], out=grp['shift'])
+                # scale = gamma * rstd; shift = beta - mean * scale: one launch of the library per group
+                if grp['gamma'].is_cuda:
+                    K.bn_refresh(grp['gamma'], grp['beta'], grp['mean'], grp['rstd'], grp['scale'], grp['shift'])
+                else:       # a model laid out on the host (layout / sharding logic in the CPU tests): nothing runs on it
+                    torch.mul(grp['gamma'], grp['rstd'], out=grp['scale'])
+                    torch.sub(grp['beta'], grp['mean'] * grp['scale'], out=grp['shift'])
 
     def views(self, scope):
         return self._views[scope]
@@ -413,10 +417,10 @@ class ConvNode(object):
         self.layer, self.in_sub = layer, in_sub
         self.layers = [layer]
 
-    def forward(self, x, save):
+    def forward(self, x, save, out=None):
         if not save:
-            return self.layer.forward(x, in_sub=self.in_sub), None
-        y, bits = self.layer.forward(x, in_sub=self.in_sub, want_bits=True)
+            return self.layer.forward(x, in_sub=self.in_sub, out=out), None
+        y, bits = self.layer.forward(x, in_sub=self.in_sub, want_bits=True, out=out)
         return y, (x, y, bits)
 
     out_act = property(lambda self: self.layer.act)
@@ -449,7 +453,9 @@ class MaxPoolNode(object):
             return -(-h // self.s), -(-w // self.s)
         return (h - self.k) // self.s + 1, (w - self.k) // self.s + 1
 
-    def forward(self, x, save):
+    def forward(self, x, save, out=None):
+        if out is not None:
+            raise NotImplementedError('MaxPoolNode: no preallocated output')
         y, geom = K.maxpool_fwd(x, self.k, self.s, self.p, storage=self.storage)
         return y, ((x, y, geom) if save else None)
 
@@ -482,7 +488,7 @@ class BottleneckNode(object):
         # TF creation order inside a unit: shortcut, conv1, conv2, conv3
         self.layers = ([self.shortcut] if self.shortcut else []) + [self.conv1, self.conv2, self.conv3]
 
-    def forward(self, x, save):
+    def forward(self, x, save, out=None):
         geom = None
         if self.shortcut is not None:
             sc = self.shortcut.forward(x)
@@ -493,10 +499,10 @@ class BottleneckNode(object):
         if not save:
             a = self.conv1.forward(x)
             b = self.conv2.forward(a)
-            return self.conv3.forward(b, residual=sc), None
+            return self.conv3.forward(b, residual=sc, out=out), None
         a, ba = self.conv1.forward(x, want_bits=True)
         b, bb = self.conv2.forward(a, want_bits=True)
-        y, by = self.conv3.forward(b, residual=sc, want_bits=True)
+        y, by = self.conv3.forward(b, residual=sc, want_bits=True, out=out)
         return y, (x, sc, a, b, y, geom, ba, bb, by)
 
     @staticmethod
@@ -546,11 +552,13 @@ class Trunk(object):
                 return i
         return len(self.nodes)
 
-    def forward(self, x, save_from=None):
+    def forward(self, x, save_from=None, out=None):
+        """out: tensor the LAST node writes its result to."""
         saved = []
+        last = len(self.nodes) - 1
         for i, n in enumerate(self.nodes):
             save = save_from is not None and i >= save_from
-            x, s = n.forward(x, save)
+            x, s = n.forward(x, save, out=out) if (i == last and out is not None) else n.forward(x, save)
             if save:
                 saved.append(s)
         return x, saved

@@ -185,29 +185,11 @@ class TruncatedBaseNetwork(BaseNetwork):
             return y
         if not x.requires_grad:
             # frozen prefix: forward only, nothing saved
-            pf, self._prefetched = getattr(self, '_prefetched', None), None
-            if pf is not None and trunk is self.trunk and pf[0] is x and pf[1] == (x._version, self.store.frozen._version):
-                x = pf[2]                                   # computed during the previous step (prefetch_prefix)
-            else:
-                pre = L.Trunk(trunk.nodes[:start])
-                x, _ = pre.forward(x, save_from=None)
+            pre = L.Trunk(trunk.nodes[:start])
+            x, _ = pre.forward(x, save_from=None)
             sub = L.Trunk(trunk.nodes[start:])
             return _TrunkFn.apply(x, self._anchor, sub, 0, False)
         return _TrunkFn.apply(x, self._anchor, trunk, 0, True)
-
-    def prefetch_prefix(self, inputs):
-        """Run the FROZEN prefix of the trunk (conv1 + the fixed blocks: nothing the optimizer writes, BatchNorm frozen)
-        for an input batch of a later step, on the current stream; the next `__call__` on this very tensor (same
-        object, not modified since) continues from the cached activation instead of recomputing it.  Returns False
-        when there is no frozen prefix."""
-        start = self.trunk.first_trainable()
-        self._prefetched = None
-        if start == 0 or self._config.get('train_batch_norm'):
-            return False
-        with torch.no_grad():
-            y, _ = L.Trunk(self.trunk.nodes[:start]).forward(inputs, save_from=None)
-        self._prefetched = (inputs, (inputs._version, self.store.frozen._version), y)
-        return True
 
     def feature_hw(self, H, W):
         """Spatial size of the feature map for an (H, W) input (no launch)."""
@@ -215,10 +197,7 @@ class TruncatedBaseNetwork(BaseNetwork):
 
     def __call__(self, inputs, is_training=False):
         """inputs (B,H,W,3) fp32 RGB 0..255 -> feature map (B,fh,fw,C)."""
-        if getattr(self, '_bn_fresh', False):
-            self._bn_fresh = False            # the caller refreshed the table itself (FasterRCNN._train_step)
-        else:
-            self.bn_table.refresh()
+        self.bn_table.refresh()
         if self._hs_layers:
             L.prepare_half_weights(self._hs_layers + self.extra_hs_layers, self.storage_dtype)   # weights may have changed
         return self._run(self.trunk, inputs.contiguous(), is_training)

@@ -16,6 +16,7 @@ per-image counts (`num_proposals`, `num_objects`) so that the train step never
 synchronises with the host.  For un-batched inference calls the results are
 truncated to the reference's exact shapes.
 """
+import ctypes
 import os
 import time
 
@@ -202,11 +203,8 @@ class FasterRCNN(object):
     def regularization_loss(self):
         """tf.losses.get_regularization_loss(): sum_w scale * sum(w^2)/2 over every
         regularised weight, frozen ones included (fasterrcnn.py:223)."""
-        if self._frozen_reg is None:
-            st = self.store
-            self._frozen_reg = K.l2_reg_loss(st.frozen, st.frozen_seg_offset, st.frozen_seg_wd)
         st = self.store
-        return (K.l2_reg_loss(st.flat, st.seg_offset, st.seg_wd) + self._frozen_reg)[0]
+        return (K.l2_reg_loss(st.flat, st.seg_offset, st.seg_wd) + self._frozen_reg_tensor())[0]
 
     def loss(self, prediction_dict, return_all=False):
         """fasterrcnn.py:158-259.  Mutates prediction_dict (adds rpn_loss_dict / rcnn_loss_dict)."""
@@ -255,14 +253,24 @@ class FasterRCNN(object):
         return image.to(self.device, torch.float32).contiguous()
 
     def train_step(self, image, gt_boxes, next_image=None, next_gt=None):
-        """`_train_step` with the process-global tail queue guarded: if anything raises mid-step (an argument check of a
-        kernel, an out-of-memory) the queue is left inactive and empty, not silently swallowing the tails of whatever
-        backward runs next."""
+        """forward + loss + backward of ONE train step (train.py:66-91): same arithmetic as
+        `__call__(is_training=True)` -> `loss()` -> `backward()`, issued as plain kernel calls (no torch.autograd, no
+        framework arithmetic) on three HIP streams (`_step_body`), and — once a shape has been seen — re-issued from a
+        recorded launch plan with one host call (luminoth_amd/plan.py).  Returns (total_loss, prediction_dict);
+        gradients are complete in `self.store.grad` when the caller's stream reaches this point.
+
+        The process-global tail queue is guarded: if anything raises mid-step (an argument check of a kernel, an
+        out-of-memory) it is left inactive and empty, not silently swallowing the tails of whatever backward runs next."""
         try:
-            return self._train_step(image, gt_boxes, next_image=next_image, next_gt=next_gt)
+            if not self._with_rcnn or self._debug:
+                pred = self(image, gt_boxes, is_training=True)
+                total = self.loss(pred)
+                self.backward(total)
+                return total, pred
+            return self._planned_step(image, gt_boxes, next_image, next_gt)
         except BaseException:
             K.TAILS.abort()
-            self._prefetch = self._tgt_prefetch = None
+            self._step_state = {}
             raise
         finally:
             L.release_winograd_weights(self._winograd_layers())
@@ -274,218 +282,340 @@ class FasterRCNN(object):
             wl = self._wino_layers = L.winograd_candidates(layers)
         return wl
 
-    def _train_step(self, image, gt_boxes, next_image=None, next_gt=None):
-        """forward + loss + backward of ONE train step (train.py:66-91), same arithmetic as
-        `__call__(is_training=True)` -> `loss()` -> `backward()`, scheduled on two HIP streams:
+    # ---- per-shape state of the fused step: buffers at fixed addresses + the recorded plans -------------------------
+    def _state_for(self, B, H, W, G):
+        """What one step hands to the next and what the caller hands to a step lives at FIXED addresses, double-buffered
+        by step parity p (step n uses slot n % 2 as "current" and fills slot 1 - p for step n + 1): images, gt boxes,
+        seeds, the frozen trunk prefix computed one step ahead and the anchor targets computed one step ahead.  A
+        recorded step can therefore be replayed: the addresses it reads and writes mean the same thing every time."""
+        main = torch.cuda.current_stream(self.device)
+        from luminoth_amd.utils import training as _tr
+        key = (B, H, W, G, main.cuda_stream, K.OPTION_VERSION, id(_tr.ACTIVE_BUCKETS), L.SideStream.enabled,
+               getattr(self, '_phase_left', 0) > 0)
+        states = getattr(self, '_step_state', None)
+        if states is None:
+            states = self._step_state = {}
+        S = states.get(key)
+        if S is not None:
+            return S
+        if len(states) >= 4:          # a data loader with many shapes: keep the plans of the most recent ones only
+            states.pop(next(iter(states)))
+        dev = self.device
+        bn = self.base_network
+        fh, fw = bn.feature_hw(H, W)
+        N = fh * fw * self._num_anchors
+        start = bn.trunk.first_trainable()
+        f32 = dict(dtype=torch.float32, device=dev)
+        S = dict(key=key, n=0, plans={}, seen={}, pf=None,
+                 images=[torch.empty((B, H, W, 3), **f32) for _ in range(2)],
+                 gt=[torch.zeros((B, G, 5), **f32) for _ in range(2)],
+                 cnt=[torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(2)],
+                 seeds=[torch.zeros((B,), dtype=torch.int32, device=dev) for _ in range(2)],
+                 tgt=[(torch.empty((B, N), **f32), torch.empty((B, N, 4), **f32), torch.empty((B, N), **f32))
+                      for _ in range(2)],
+                 prefix=None, start=start)
+        if 0 < start:
+            ph, pw = L.Trunk(bn.trunk.nodes[:start]).out_hw(H, W)
+            last = bn.trunk.nodes[start - 1]
+            ch = last.conv3.cout if hasattr(last, 'conv3') else last.layer.cout
+            pdt = torch.float32
+            if bn.storage_dtype in ('f16', 'bf16') and start > 1:
+                pdt = K.half_type(bn.storage_dtype)[1]
+            S['prefix'] = [torch.empty((B, ph, pw, ch), dtype=pdt, device=dev) for _ in range(2)]
+        states[key] = S
+        return S
 
-            main: trunk fwd -> RPN convs -> RPN targets -> RPN loss -> RPN backward ------> trunk backward
-            aux :               '-> proposals (sort + NMS) -> RCNN targets -> ROI pool -> FCs
-                                    -> RCNN loss -> RCNN backward -> ROI-pool backward ----'
-
-        The proposal chain is a sequence of latency-bound launches that occupy a handful of CUs; it now
-        runs beside the RPN backward (the largest MFMA kernels of the step) instead of in front of it.
-        Returns (total_loss, prediction_dict); gradients are complete in `self.store.grad` when the
-        caller's stream reaches this point."""
-        if not self._with_rcnn:
-            pred = self(image, gt_boxes, is_training=True)
-            total = self.loss(pred)
-            self.backward(total)
-            return total, pred
-        pf, self._prefetch = getattr(self, '_prefetch', None), None
-        if pf is not None and pf[0] is image and pf[1] == image._version:
-            image = pf[2]            # uploaded (and its frozen trunk prefix computed) during the previous step
-        else:
-            image = self._device_image(image)
+    def _planned_step(self, image, gt_boxes, next_image, next_gt):
+        from luminoth_amd import plan as P
+        image_src = image
+        image = torch.as_tensor(image)
+        if image.dim() == 3:
+            image = image.unsqueeze(0)
         B, H, W, _ = image.shape
         gt, gt_count = self._pack_gt(gt_boxes, B)
-        seeds = self._image_seeds(B)
-        pt, self._tgt_prefetch = getattr(self, '_tgt_prefetch', None), None
-        if pt is not None and not (pt['src'] is gt_boxes and pt['key'] == (self._step, B, H, W)):
-            pt = None            # another batch arrived than the one announced: compute the targets now
+        G = gt.shape[1]
+        S = self._state_for(B, H, W, G)
+        p = S['n'] & 1
+        S['n'] += 1
+        main = torch.cuda.current_stream(self.device)
+        # ---- this step's inputs: already in slot p if the previous step was told about them, else copied there now
+        pf, S['pf'] = S['pf'], None
+        have_pf = (pf is not None and pf['slot'] == p and pf['image'] is image_src and pf['image_v'] == image_src._version
+                   and pf['gt'] is gt_boxes and pf['step'] == self._step)
+        if not have_pf:
+            S['images'][p].copy_(image, non_blocking=True)
+            S['gt'][p].copy_(gt)
+            S['cnt'][p].copy_(gt_count)
+            S['seeds'][p].copy_(self._image_seeds(B))
         self._step += 1
+        # ---- the next step's inputs into slot 1 - p (its prefix / anchor targets are computed inside this step)
+        produce = (next_image is not None and next_gt is not None and PREFETCH_PREFIX and torch.is_tensor(next_image))
+        if produce:
+            nimg = next_image if next_image.dim() == 4 else next_image.unsqueeze(0)
+            ngt, ncnt = self._pack_gt(next_gt, nimg.shape[0])
+            produce = tuple(nimg.shape) == (B, H, W, 3) and ngt.shape[1] == G
+        if produce:
+            q = 1 - p
+            S['images'][q].copy_(nimg, non_blocking=True)
+            S['gt'][q].copy_(ngt)
+            S['cnt'][q].copy_(ncnt)
+            S['seeds'][q].copy_(self._image_seeds(B))       # self._step already counts this step: the NEXT step's seeds
+            S['pf'] = dict(slot=q, image=next_image, image_v=next_image._version, gt=next_gt, step=self._step)
+        variant = (p, bool(have_pf), bool(produce))
+        plannable = P.ENABLED and self._rcnn._dropout_keep_prob in (None, 1, 1.0)
+        plan = S['plans'].get(variant) if plannable else None
+        if plan is not None:
+            self._phase_collect(S, p)
+            out = plan.run()
+            self._last_losses = out[2]
+            self._phase_host_done(S, p)
+            return out[0], out[1]
+        seen = S['seen'].get(variant, 0)
+        S['seen'][variant] = seen + 1
+        if plannable and seen >= P.WARM_STEPS:
+            plan = P.StepPlan()
+            with plan:
+                out = self._step_body(S, p, have_pf, produce, B, H, W)
+                plan.result = out
+                plan.keep.append(out)
+            S['plans'][variant] = plan
+        else:
+            out = self._step_body(S, p, have_pf, produce, B, H, W)
+        self._last_losses = out[2]
+        return out[0], out[1]
+
+    def _step_body(self, S, p, have_pf, produce, B, H, W):
+        """The device work of one train step on three HIP streams, from / into the fixed-address buffers of `S`:
+
+            main : trunk fwd -> RPN convs -> RPN targets -> RPN loss -> RPN backward -> [next batch: frozen prefix] -> trunk backward -> tails
+            aux  :               '-> proposals (sort + NMS) -> RCNN targets -> ROI pool -> FCs -> RCNN loss
+                                     -> RCNN backward -> ROI-pool backward (+ the RPN branch's gradient) --'  [next batch: anchor targets]
+            side : every layer's weight-gradient kernel beside that layer's data gradient
+
+        Everything here launches through luminoth_amd.kernels (recordable by a launch plan); cross-stream order is
+        made with K.stream_wait only.  -> (total_loss, prediction_dict, losses dict)."""
+        image, gt, gt_count, seeds = S['images'][p], S['gt'][p], S['cnt'][p], S['seeds'][p]
         im_shape = (H, W)
         main = torch.cuda.current_stream(self.device)
         aux = self._aux_stream()
-        self._phase_begin()
-        # Winograd weight transforms of the whole step: the forward set in one launch here, the backward set in one launch
-        # on the (idle) weight-gradient stream while the forward pass runs — instead of one small launch inside each of
-        # the ~20 Winograd convolution calls.  Nothing writes the weights or the BatchNorm scales before the update.
-        self.base_network.bn_table.refresh()
-        self.base_network._bn_fresh = True
+        bn = self.base_network
+        rpn, rcnn = self._rpn, self._rcnn
+        self._phase_begin(S, p)
+        # BatchNorm scale / shift of every layer, 16-bit working weights, Winograd weight transforms of the whole step: the
+        # forward set here, the backward set on the (idle) weight-gradient stream while the forward pass runs.  Nothing
+        # writes the weights or the BatchNorm scales before the update.
+        bn.bn_table.refresh()
+        if bn._hs_layers:
+            L.prepare_half_weights(bn._hs_layers + bn.extra_hs_layers, bn.storage_dtype)
         wl = self._winograd_layers() if WINO_BATCH else []
-        wino_bwd_ready = None
+        wino_bwd_side = None
         if wl:
             L.prepare_winograd_weights(wl, backward=False)
-            side0 = SideStream.get(self.device)
-            side0.wait_stream(main)
-            with torch.cuda.stream(side0):
+            wino_bwd_side = SideStream.get(self.device)
+            K.stream_wait(wino_bwd_side, main)
+            with K.launch_on(wino_bwd_side):
                 L.prepare_winograd_weights([l for l in wl if l.trainable], backward=True)
-                wino_bwd_ready = torch.cuda.Event()
-                wino_bwd_ready.record(side0)
-        self.store.grad.zero_()
+        K.zero_(self.store.grad)
         from luminoth_amd.utils import training as _tr
         # the aux stream is idle once the RCNN branch is done: weight-gradient tails of the trunk backward are finished
         # there in batches while the MFMA kernels run (not with gradient buckets: those flush on their own stream)
         K.TAILS.begin(early=None if _tr.ACTIVE_BUCKETS is not None else (aux, lambda: list(SideStream._streams.values())))
-        with torch.enable_grad():
-            fh, fw = self.base_network.feature_hw(H, W)
-            rpn = self._rpn
-            rpn_tgt = {}
-            for t in (gt, gt_count, seeds):
-                K.keep_alive(t, aux)
-            feat = self.base_network(image, is_training=True)
-            assert (feat.shape[1], feat.shape[2]) == (fh, fw)
-            self._mark('trunk_fwd_done')
-            f_rpn = feat.detach().requires_grad_(True)
-            f_rcnn = feat.detach().requires_grad_(True)
-            rpn_pred = rpn.heads(f_rpn)
-            self._mark('rpn_heads_done')
-            # Host enqueue order matters while the host is not far ahead of the GPU: the proposal chain is
-            # ONE C call (cheap to enqueue, long to run), so it goes first; then the RPN branch of the main
-            # stream; the RCNN part of the aux stream last (it cannot start before the NMS finishes anyway).
-            # ---- aux stream: proposals
-            aux.wait_stream(main)
-            with torch.cuda.stream(aux):
-                prop = rpn._proposal(rpn_pred['rpn_cls_score'].detach(), rpn_pred['rpn_bbox_pred'].detach(),
-                                     self._anchor_ref_i32, (fh, fw), self._anchor_stride, im_shape)
-                self._mark('aux:proposals_done')
-                rcnn_tgt = self._rcnn.targets(prop['proposals'], prop['num_proposals'], gt, gt_count, seeds)
-                self._mark('aux:rcnn_targets_done')
-            for t in (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred'], feat):
-                K.keep_alive(t, aux)
-            # ---- main stream: RPN targets -> RPN loss -> RPN backward
-            if pt is not None:       # anchor targets of this batch were computed on the aux stream during the previous step
-                main.wait_event(pt['event'])
-                rpn_tgt = pt['tgt']
-                for t in rpn_tgt.values():
-                    K.keep_alive(t, main)
+        fh, fw = bn.feature_hw(H, W)
+        # ---- trunk forward: the frozen prefix (conv1 + fixed blocks) of THIS batch was computed during the previous step
+        start = S['start']
+        nodes = bn.trunk.nodes
+        x0 = image
+        if start > 0:
+            if have_pf:
+                x0 = S['prefix'][p]
             else:
-                rpn.targets(rpn_tgt, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape)
-            rpn_pred.update(rpn_tgt)
-            rpn_losses, rpn_g = rpn.loss_and_grads(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
-            rpn_loss_done = torch.cuda.Event()
-            rpn_loss_done.record(main)
-            if wino_bwd_ready is not None:
-                main.wait_event(wino_bwd_ready)      # (recorded before the forward pass was even enqueued: long done)
-            torch.autograd.backward([rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred']],
-                                    [g.view_as(t) for g, t in zip(rpn_g, (rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred']))])
-            self._mark('rpn_bwd_done')
-            # ---- aux stream: RCNN forward -> RCNN loss -> RCNN backward
-            with torch.cuda.stream(aux):
-                self._mark('aux:rcnn_enqueue')      # later than aux:rcnn_targets_done = the host was not ahead here
-                cp = self._rcnn(f_rcnn, prop['proposals'], prop['num_proposals'], im_shape, self.base_network,
-                                gt_boxes=gt, gt_count=gt_count, seeds=seeds, is_training=True, targets=rcnn_tgt)
-                rcnn_losses, rcnn_g = self._rcnn.loss_and_grads(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
-                self._mark('aux:rcnn_loss_done')
-                torch.autograd.backward([cp['rcnn']['cls_score'], cp['rcnn']['bbox_offsets']],
-                                        [g.view_as(t) for g, t in zip(rcnn_g, (cp['rcnn']['cls_score'], cp['rcnn']['bbox_offsets']))])
-                self._mark('aux:rcnn_bwd_done')
-                rcnn_done = torch.cuda.Event()
-                rcnn_done.record(aux)          # the join below waits for THIS, not for what the aux stream is given next
-                # the loss scalars (sums, L2 regulariser: a handful of tiny launches) are only reported: they are built here,
-                # on the stream that has nothing else to do, not in front of the trunk backward
-                aux.wait_event(rpn_loss_done)
-                no_reg_loss = (rpn_losses['rpn_cls_loss'] + rpn_losses['rpn_reg_loss'] +
-                               rcnn_losses['rcnn_cls_loss'] + rcnn_losses['rcnn_reg_loss'])
-                regularization_loss = self.regularization_loss()
-                total_loss = no_reg_loss + regularization_loss
-                # the aux stream is idle from here to the end of the step: the anchor targets of the NEXT batch (they
-                # depend on its gt boxes and this model's seeds only, not on any weight) leave the next step's critical path
-                if next_gt is not None and next_image is not None and PREFETCH_PREFIX and torch.is_tensor(next_image):
-                    nshape = tuple(next_image.shape) if next_image.dim() == 4 else (1,) + tuple(next_image.shape)
-                    Bn, Hn, Wn = nshape[0], nshape[1], nshape[2]
-                    ngt, ncnt = self._pack_gt(next_gt, Bn)
-                    nseeds = self._image_seeds(Bn)             # self._step already counts this step: the next step's seeds
-                    ntgt = {}
-                    rpn.targets(ntgt, self._anchor_ref_i32, self.base_network.feature_hw(Hn, Wn), self._anchor_stride,
-                                ngt, ncnt, nseeds, (Hn, Wn))
-                    ev = torch.cuda.Event()
-                    ev.record(aux)
-                    self._tgt_prefetch = dict(src=next_gt, key=(self._step, Bn, Hn, Wn), tgt=ntgt, event=ev,
-                                              keep=(ngt, ncnt, nseeds))
-                    self._mark('aux:next_targets_done')
-            # ---- the main stream has nothing left but to wait for the RCNN branch (0.3-0.4 ms at config 2): the slot
-            # for the frozen trunk prefix of the NEXT step's images (conv1 + block1: nothing this step's update writes)
-            if next_image is not None and PREFETCH_PREFIX and torch.is_tensor(next_image):
-                nxt = self._device_image(next_image)
-                if self.base_network.prefetch_prefix(nxt):
-                    self._prefetch = (next_image, next_image._version, nxt)
-                self._mark('next_prefix_done')
-            # ---- join, trunk backward
-            main.wait_event(rcnn_done)
-            self._mark('joined')
-            K.keep_alive(f_rcnn.grad, main)
-            for t in (rpn_losses['rpn_cls_loss'], rpn_losses['rpn_reg_loss']):
-                K.keep_alive(t, aux)
-            # data parallel: head gradients (RPN on main/side, RCNN joined from aux) are complete here, so the
-            # gradient buckets may start all-reducing under the trunk backward (utils/training.py)
-            from luminoth_amd.utils import training as _tr
+                x0, _ = self._sub_trunk(0, start).forward(image, save_from=None, out=S['prefix'][p])
+        saved = None
+        if start < len(nodes):
+            feat, saved = self._sub_trunk(start, len(nodes)).forward(x0, save_from=0)
+        else:
+            feat = x0
+        assert (feat.shape[1], feat.shape[2]) == (fh, fw)
+        self._mark('trunk_fwd_done')
+        rpn_pred, rpn_ctx = rpn.heads_fwd(feat)
+        self._mark('rpn_heads_done')
+        # Host enqueue order matters while the host is not far ahead of the GPU (eager steps): the proposal chain is
+        # ONE C call (cheap to enqueue, long to run), so it goes first; then the RPN branch of the main stream; the
+        # RCNN part of the aux stream last (it cannot start before the NMS finishes anyway).
+        K.stream_wait(aux, main)
+        with torch.cuda.stream(aux):
+            prop = rpn._proposal(rpn_pred['rpn_cls_score'], rpn_pred['rpn_bbox_pred'], self._anchor_ref_i32, (fh, fw),
+                                 self._anchor_stride, im_shape)
+            self._mark('aux:proposals_done')
+            rcnn_tgt = rcnn.targets(prop['proposals'], prop['num_proposals'], gt, gt_count, seeds)
+            self._mark('aux:rcnn_targets_done')
+        # ---- main stream: RPN targets -> RPN loss -> RPN backward
+        rpn_tgt = {}
+        if have_pf:          # computed on the aux stream during the previous step, which the main stream joined at its end
+            rpn_tgt['rpn_cls_target'], rpn_tgt['rpn_bbox_target'] = S['tgt'][p][0], S['tgt'][p][1]
+        else:
+            rpn.targets(rpn_tgt, self._anchor_ref_i32, (fh, fw), self._anchor_stride, gt, gt_count, seeds, im_shape,
+                        out=S['tgt'][p])
+        rpn_pred.update(rpn_tgt)
+        rpn_losses, rpn_g = rpn.loss_and_grads(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
+        if wino_bwd_side is not None:
+            K.stream_wait(main, wino_bwd_side)      # transformed backward weights (enqueued before the forward pass: long done)
+        SideStream.layers_left = 0
+        d_feat_rpn = rpn.heads_bwd(rpn_ctx, rpn_g[0], rpn_g[1])
+        self._mark('rpn_bwd_done')
+        # ---- aux stream: RCNN forward -> RCNN loss -> RCNN backward; the ROI-pooling backward adds the RPN branch's
+        # gradient of the feature map in its store (TF: AddN over the two consumers of conv_feature_map)
+        with torch.cuda.stream(aux):
+            self._mark('aux:rcnn_enqueue')
+            cp, rcnn_ctx = rcnn.train_fwd(feat, rcnn_tgt, im_shape, bn)
+            rcnn_losses, rcnn_g = rcnn.loss_and_grads(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
+            self._mark('aux:rcnn_loss_done')
+            d_feat = rcnn.train_bwd(rcnn_ctx, rcnn_g[0], rcnn_g[1], addend=d_feat_rpn,
+                                    before_pool_bwd=lambda: K.stream_wait(aux, main))
+            self._mark('aux:rcnn_bwd_done')
+        # ---- the main stream has nothing left but to wait for the RCNN branch: the slot for the frozen trunk prefix of
+        # the NEXT step's images (conv1 + fixed blocks: nothing this step's update writes)
+        if produce and start > 0:
+            self._sub_trunk(0, start).forward(S['images'][1 - p], save_from=None, out=S['prefix'][1 - p])
+            self._mark('next_prefix_done')
+        # ---- join (the wait captures the aux stream as of NOW: what is queued there below does not delay the trunk backward)
+        K.stream_wait(main, aux)
+        self._mark('joined')
+        with torch.cuda.stream(aux):
+            # the loss scalars are only reported: built on the stream that has nothing else to do
+            reg = K.l2_reg_loss(self.store.flat, self.store.seg_offset, self.store.seg_wd)
+            sums = K.loss_sums([rpn_losses['rpn_cls_loss'], rpn_losses['rpn_reg_loss'],
+                                rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']], reg, self._frozen_reg_tensor())
+            # ... and the anchor targets of the NEXT batch (they depend on its gt boxes and this model's seeds only)
+            if produce:
+                q = 1 - p
+                rpn.targets({}, self._anchor_ref_i32, (fh, fw), self._anchor_stride, S['gt'][q], S['cnt'][q], S['seeds'][q],
+                            im_shape, out=S['tgt'][q])
+                self._mark('aux:next_targets_done')
+        total_loss, no_reg_loss, regularization_loss = sums[0], sums[1], sums[2]
+        # ---- trunk backward.  Data parallel: the head gradients (RPN on main / side, RCNN joined from aux) are complete
+        # here, so the gradient buckets may start all-reducing under the trunk backward (utils/training.py)
+        if saved is not None:
             buckets = _tr.ACTIVE_BUCKETS
             if buckets is not None and buckets.store is self.store:
-                buckets.arm(self.base_network.trunk)
-            feat.backward(f_rpn.grad + f_rcnn.grad)
+                buckets.arm(bn.trunk)
+            self._sub_trunk(start, len(nodes)).backward(saved, d_feat, 0, need_dx_first=False)
             if buckets is not None:
                 buckets.disarm()
-            self._mark('trunk_bwd_data_done')
+        self._mark('trunk_bwd_data_done')
         SideStream.join()
         self._mark('wgrad_stream_joined')
         K.TAILS.flush()          # what is left of the weight-gradient tails (RPN, RCNN, trunk) in two launches
         K.TAILS.active = False
-        main.wait_stream(aux)        # early tail batches and the loss scalars; long finished by now
-        for t in (total_loss, no_reg_loss, regularization_loss, rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']):
-            K.keep_alive(t, main)
+        K.stream_wait(main, aux)     # early tail batches, the loss scalars, the next batch's anchor targets
         K.TAILS.early = None
         self._mark('tails_done')
         rpn_pred.update({k: prop[k] for k in ('rpn_cls_prob', 'proposals', 'scores')})
         rpn_pred['num_proposals'] = prop['num_proposals']
-        self._last_losses = dict(rpn_losses, total_loss=total_loss, no_reg_loss=no_reg_loss,
-                                 regularization_loss=regularization_loss, **rcnn_losses)
+        losses = dict(rpn_losses, total_loss=total_loss, no_reg_loss=no_reg_loss,
+                      regularization_loss=regularization_loss, **rcnn_losses)
         pred = {'rpn_prediction': rpn_pred, 'classification_prediction': cp, 'rpn_loss_dict': rpn_losses,
                 'rcnn_loss_dict': rcnn_losses, '_batch': {'B': B, 'unbatched': False}}
-        return total_loss, pred
+        return total_loss, pred, losses
+
+    def _sub_trunk(self, lo, hi):
+        c = getattr(self, '_sub_trunks', None)
+        if c is None:
+            c = self._sub_trunks = {}
+        t = c.get((lo, hi))
+        if t is None:
+            t = c[(lo, hi)] = L.Trunk(self.base_network.trunk.nodes[lo:hi])
+        return t
+
+    def _frozen_reg_tensor(self):
+        if self._frozen_reg is None:
+            st = self.store
+            self._frozen_reg = K.l2_reg_loss(st.frozen, st.frozen_seg_offset, st.frozen_seg_wd)
+        return self._frozen_reg
 
     # -------------------------------------------------------------- diagnostics --
     def record_phases(self, steps):
         """Arm HIP-event marks for the next `steps` train steps (bench.py --phases): the un-profiled timeline of the
-        three-stream schedule.  rocprofv3 slows the launch path enough to make the step host-bound where it forks, so
-        the gaps in a kernel trace are not the gaps of the real step; a handful of event records are."""
+        three-stream schedule.  rocprofv3 slows the launch path enough to change where the step waits, so the gaps in a
+        kernel trace are not the gaps of the real step; a handful of event records are.  The marks are library events
+        recorded through the C ABI, so they are part of a launch plan and are re-recorded at every replay; a slot's marks
+        are read back right before the slot is used again (two steps later: the host never waits for the GPU's current
+        step)."""
         self._phase_left = steps
-        self._phase_log = []
+        self._phase_sum, self._phase_n, self._phase_next_n = {}, 0, 0
 
-    def _mark(self, name, stream=None):
+    def _phase_begin(self, S, p):
+        self._phase_cur = None
+        if not S['key'][-1]:
+            return
+        self._phase_collect(S, p)
+        self._phase_left = max(0, getattr(self, '_phase_left', 0) - 1)
+        self._phase_cur = S.setdefault('marks', {}).setdefault(p, [])
+        del self._phase_cur[:]
+        S.setdefault('pending', {})[p] = True
+        self._mark('step_start')
+
+    def _mark(self, name):
         cur = getattr(self, '_phase_cur', None)
         if cur is None:
             return
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
+        from luminoth_amd import plan as P
+        if P.recording():
+            ev = P._ACTIVE.new_event()
+        else:
+            ev = _lib.load().lmh_event_create()
+        K.event_record(ev, torch.cuda.current_stream(self.device))
         cur.append((name, ev, time.perf_counter()))
 
-    def _phase_begin(self):
-        left = getattr(self, '_phase_left', 0)
-        self._phase_cur = None
-        if left > 0:
-            self._phase_left = left - 1
-            self._phase_cur = []
-            self._phase_log.append(self._phase_cur)
-            self._mark('step_start')
+    def _phase_host_done(self, S, p):
+        """A replayed step: its marks were re-recorded by the plan; what the host can say is when it was done enqueueing."""
+        if S['key'][-1] and S.get('marks', {}).get(p):
+            self._phase_left = max(0, getattr(self, '_phase_left', 0) - 1)
+            S.setdefault('pending', {})[p] = True
+            S.setdefault('host_done', {})[p] = time.perf_counter()
+
+    def _phase_collect(self, S, p):
+        """Read the marks slot p recorded two steps ago (synchronises with THAT step only) into the running sums."""
+        if not S['key'][-1] or not S.get('pending', {}).get(p):
+            if S['key'][-1]:
+                S.setdefault('host_t0', {})[p] = time.perf_counter()
+            return
+        lib = _lib.load()
+        marks = S['marks'][p]
+        acc = self._phase_sum
+        e0, h0 = marks[0][1], marks[0][2]
+        replayed = p in S.get('host_done', {})
+        for name, ev, host_t in marks[1:]:
+            acc[name] = acc.get(name, 0.0) + lib.lmh_event_elapsed_ms(ctypes.c_void_p(e0), ctypes.c_void_p(ev))
+            if not replayed:
+                # when the HOST enqueued the mark, relative to the step's first enqueue
+                acc['host:' + name] = acc.get('host:' + name, 0.0) + (host_t - h0) * 1e3
+        if replayed:
+            acc['host:step_enqueued'] = acc.get('host:step_enqueued', 0.0) + \
+                (S['host_done'].pop(p) - S.get('host_t0', {}).get(p, h0)) * 1e3
+        other = S['marks'].get(1 - p)
+        if other and S['pending'].get(1 - p):       # the following step's start, recorded by the other slot
+            dt = lib.lmh_event_elapsed_ms(ctypes.c_void_p(e0), ctypes.c_void_p(other[0][1]))
+            if dt > 0:
+                acc['next_step_start'] = acc.get('next_step_start', 0.0) + dt
+                self._phase_next_n += 1
+        self._phase_n += 1
+        S['pending'][p] = False
+        S.setdefault('host_t0', {})[p] = time.perf_counter()
 
     def phase_times(self):
         """-> {mark: mean ms after step_start} over the recorded steps (synchronises), plus 'next_step_start'."""
         torch.cuda.synchronize(self.device)
-        log = getattr(self, '_phase_log', [])
-        out, n = {}, 0
-        for i, marks in enumerate(log):
-            t0 = marks[0][1]
-            for name, ev, host_t in marks[1:]:
-                out[name] = out.get(name, 0.0) + t0.elapsed_time(ev)
-                # when the HOST enqueued the mark, relative to the step's first enqueue: a mark whose host time is
-                # later than its GPU time was waited for by the GPU (the step is host-bound there)
-                out['host:' + name] = out.get('host:' + name, 0.0) + (host_t - marks[0][2]) * 1e3
-            if i + 1 < len(log):
-                out['next_step_start'] = out.get('next_step_start', 0.0) + t0.elapsed_time(log[i + 1][0][1])
-                n += 1
-        res = {k: v / (n if k == 'next_step_start' else len(log)) for k, v in out.items()}
-        self._phase_log, self._phase_cur = [], None
+        for S in getattr(self, '_step_state', {}).values():
+            if S['key'][-1]:
+                order = sorted(S.get('pending', {}), key=lambda q: (S['n'] - 1 - q) & 1, reverse=True)
+                for q in order:          # older slot first, so that it still sees the newer slot's step_start
+                    self._phase_collect(S, q)
+        n = max(1, getattr(self, '_phase_n', 0))
+        res = {k: v / (max(1, self._phase_next_n) if k == 'next_step_start' else n)
+               for k, v in getattr(self, '_phase_sum', {}).items()}
+        self._phase_cur = None
+        self._phase_left = 0
         return res
 
     _AUX_STREAMS = {}      # device -> stream, shared by every model of the process

@@ -129,6 +129,96 @@ class RCNN(object):
             pred['num_objects'] = det['num_objects']
         return pred
 
+    # ---- the fused train step drives the head without torch.autograd (FasterRCNN._step_body) -----------------------
+    def _linear_fwd(self, layer, x2d):
+        y = layer.forward(x2d.view(1, 1, x2d.shape[0], x2d.shape[1]))
+        return y.view(x2d.shape[0], layer.cout)
+
+    def _linear_bwd(self, layer, x2d, y2d, dy2d, addend=None):
+        M = x2d.shape[0]
+        dx, _ = layer.backward(x2d.view(1, 1, M, layer.cin), y2d.view(1, 1, M, layer.cout),
+                               dy2d.contiguous().view(1, 1, M, layer.cout), need_dx=True,
+                               addend=None if addend is None else addend.view(1, 1, M, layer.cin))
+        return dx.view(M, layer.cin)
+
+    def train_fwd(self, feat, tgt, im_shape, base_network):
+        """The training forward of `__call__` on the compacted ROIs of `tgt` (rcnn.py:156-239) as plain kernel calls:
+        -> (classification_prediction dict, ctx for train_bwd)."""
+        B = feat.shape[0]
+        rois, roi_count = tgt['rois'], tgt['roi_count']
+        R = rois.shape[1]
+        pred = {'_debug': {}, 'target': {'cls': tgt['roi_labels'], 'bbox_offsets': tgt['roi_targets']}}
+        rp = self._roi_pool
+        if rp._pooling_mode != 'crop':
+            raise NotImplementedError()
+        ph, pw = rp._pooled_height, rp._pooled_width
+        ims = (float(im_shape[0]), float(im_shape[1]))
+        ctx = {'feat_shape': tuple(feat.shape), 'rois': rois, 'roi_count': roi_count, 'ims': ims, 'ph': ph, 'pw': pw}
+        if self._use_mean and not base_network.has_tail and K.roi_pool_mean_supported(feat.shape):
+            net, argmax = K.roi_pool_mean_fwd(feat, rois, roi_count, ims, ph, pw)
+            ctx.update(mode='mean', argmax=argmax)
+        else:
+            pooled, argmax = K.roi_pool_fwd(feat, rois, roi_count, ims, ph, pw)
+            ctx.update(mode='pool', argmax=argmax)
+            features = pooled
+            if base_network.has_tail:
+                features, saved = base_network.tail.forward(pooled, save_from=0)
+                ctx.update(tail=base_network.tail, tail_saved=saved)
+            ctx['features_shape'] = tuple(features.shape)
+            net = K.spatial_mean_fwd(features) if self._use_mean else features.reshape(features.shape[0], -1)
+        steps = []
+        kp = self._dropout_keep_prob
+
+        def drop(x):
+            if kp in (None, 1, 1.0):
+                return x
+            from luminoth_amd.utils import rng
+            self._dropout_calls += 1
+            seed = rng.hash_u32(0 if self._seed is None else int(self._seed), 0xD509, self._dropout_calls & 0xFFFFFFFF)
+            steps.append(('drop', float(kp), seed))
+            return K.dropout(x, float(kp), seed)
+        net = drop(net)
+        for layer in self._layers:
+            y = self._linear_fwd(layer, net)
+            steps.append(('fc', layer, net, y))
+            net = drop(y)
+        cls_score = self._linear_fwd(self._classifier_layer, net)
+        bbox_offsets = self._linear_fwd(self._bbox_layer, net)
+        cls_prob = K.softmax(cls_score)
+        C = self._num_classes
+        pred['rcnn'] = {'cls_score': cls_score.view(B, R, C + 1), 'cls_prob': cls_prob.view(B, R, C + 1),
+                        'bbox_offsets': bbox_offsets.view(B, R, 4 * C)}
+        pred['proposals'] = rois
+        pred['num_proposals'] = roi_count
+        ctx.update(net=net, cls_score=cls_score, bbox_offsets=bbox_offsets, steps=steps)
+        return pred, ctx
+
+    def train_bwd(self, ctx, d_cls, d_off, addend=None, before_pool_bwd=None):
+        """-> gradient of the feature map (+ `addend`: the RPN branch's gradient of the same map, added in the store of
+        the ROI-pooling backward).  `before_pool_bwd()`: called right before that last launch (the caller orders this
+        stream behind the producer of `addend` there)."""
+        net = ctx['net']
+        M = net.shape[0]
+        d1 = self._linear_bwd(self._classifier_layer, net, ctx['cls_score'], d_cls.view(M, -1))
+        d = self._linear_bwd(self._bbox_layer, net, ctx['bbox_offsets'], d_off.view(M, -1), addend=d1)
+        for st in reversed(ctx['steps']):
+            if st[0] == 'drop':
+                d = K.dropout(d.contiguous(), st[1], st[2])
+            else:
+                _, layer, x_in, y = st
+                d = self._linear_bwd(layer, x_in, y, d)
+        if before_pool_bwd is not None:
+            before_pool_bwd()
+        if ctx['mode'] == 'mean':
+            return K.roi_pool_mean_bwd(d.contiguous(), ctx['argmax'], ctx['rois'], ctx['roi_count'], ctx['feat_shape'],
+                                       ctx['ims'], ctx['ph'], ctx['pw'], addend=addend)
+        fshape = ctx['features_shape']
+        dfeatures = K.spatial_mean_bwd(d.contiguous(), fshape) if self._use_mean else d.reshape(fshape)
+        if 'tail' in ctx:
+            dfeatures = ctx['tail'].backward(ctx['tail_saved'], dfeatures.contiguous(), 0, need_dx_first=True)
+        return K.roi_pool_bwd(dfeatures.contiguous(), ctx['argmax'], ctx['rois'], ctx['roi_count'], ctx['feat_shape'],
+                              ctx['ims'], ctx['ph'], ctx['pw'], addend=addend)
+
     def loss_and_grads(self, prediction_dict, w_cls=1.0, w_reg=1.0):
         """loss() plus d(cls + reg)/d(cls_score, bbox_offsets) from the same kernel launch, outside autograd (see
         RPN.loss_and_grads)."""

@@ -58,9 +58,30 @@ class RPN(object):
             pred['rpn_feature'] = rpn_feature
         return pred
 
-    def targets(self, pred, anchor_ref_i32, feat_hw, stride, gt_boxes, gt_count, seeds, im_shape):
+    # ---- the fused train step drives the head without torch.autograd (FasterRCNN._step_body) -----------------------
+    def heads_fwd(self, feat):
+        """`heads` as plain kernel calls: -> (pred dict, ctx for heads_bwd)."""
+        B = feat.shape[0]
+        rf, bits = self._rpn.forward(feat, want_bits=True, keep_v=True)
+        cls = self._rpn_cls.forward(rf)
+        bbox = self._rpn_bbox.forward(rf)
+        pred = {'rpn_cls_score': cls.reshape(B, -1, 2), 'rpn_bbox_pred': bbox.reshape(B, -1, 4)}
+        return pred, (feat, rf, bits, cls, bbox)
+
+    def heads_bwd(self, ctx, d_cls, d_bbox):
+        """Gradient of the feature map through the three convolutions (their parameter gradients go to the flat
+        buffer).  The two 1x1 heads read the same tensor: the second one's data gradient takes the first one's as its
+        `addend` and applies the activation bit mask of the 3x3 convolution's output in the same epilogue, so what
+        reaches the 3x3 layer already is g = (dx_cls + dx_bbox) * act'(rf) — TF's AddN + ReluGrad without a pass."""
+        feat, rf, bits, cls, bbox = ctx
+        d1, _ = self._rpn_cls.backward(rf, cls, d_cls.view_as(cls), need_dx=True)
+        g, _ = self._rpn_bbox.backward(rf, bbox, d_bbox.view_as(bbox), need_dx=True, addend=d1, mask_bits=bits)
+        d_feat, _ = self._rpn.backward(feat, rf, g, need_dx=True, dy_is_g=bits is not None)
+        return d_feat
+
+    def targets(self, pred, anchor_ref_i32, feat_hw, stride, gt_boxes, gt_count, seeds, im_shape, out=None):
         labels, targets, max_ov = self._anchor_target(anchor_ref_i32, feat_hw, stride, gt_boxes, gt_count,
-                                                      seeds, im_shape)
+                                                      seeds, im_shape, out=out)
         pred['rpn_cls_target'] = labels
         pred['rpn_bbox_target'] = targets
         if self._debug:

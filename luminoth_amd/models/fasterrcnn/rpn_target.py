@@ -14,11 +14,11 @@ class RPNTarget(object):
         self._minibatch_size = config.minibatch_size
         self._seed = seed
 
-    def __call__(self, anchor_ref_i32, feat_hw, stride, gt_boxes, gt_count, seeds, im_shape):
+    def __call__(self, anchor_ref_i32, feat_hw, stride, gt_boxes, gt_count, seeds, im_shape, out=None):
         """Returns labels (B,N) in {-1,0,1}, bbox_targets (B,N,4), max_overlaps (B,N)."""
         labels, targets, max_ov, _ = K.rpn_target(
             anchor_ref_i32, feat_hw[0], feat_hw[1], stride, gt_boxes, gt_count, seeds, im_shape,
             allowed_border=self._allowed_border, clobber_positives=self._clobber_positives,
             foreground_threshold=self._positive_overlap, background_threshold_high=self._negative_overlap,
-            foreground_fraction=self._foreground_fraction, minibatch_size=self._minibatch_size)
+            foreground_fraction=self._foreground_fraction, minibatch_size=self._minibatch_size, out=out)
         return labels, targets, max_ov

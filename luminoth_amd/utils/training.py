@@ -69,7 +69,14 @@ class GradientBuckets(object):
         self.store = store
         self.reduce_fn = reduce_fn or self._all_reduce
         if bucket_bytes is None:
-            bucket_bytes = int(os.environ.get('LUMINOTH_AMD_BUCKET_MB', '12')) << 20
+            mb = os.environ.get('LUMINOTH_AMD_BUCKET_MB')
+            if mb is None:
+                # a ring all-reduce over N ranks pays 2 (N - 1) hop latencies per collective whatever its size, so the
+                # bucket that amortises them grows with the ring: 6 MB at 2 ranks, 12 MB at 4, 24 MB at 8 (xGMI is
+                # point to point: ~100 GB/s per link in each direction; 2 (N-1) x ~10 us against 2 (N-1)/N x bytes / BW)
+                world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+                mb = min(24, max(6, 3 * world))
+            bucket_bytes = int(mb) << 20
         self.bucket_bytes = int(bucket_bytes)
         self._armed = None
         self._plans = {}
@@ -126,6 +133,13 @@ class GradientBuckets(object):
         self._plans[key] = plan
         return plan
 
+    def describe(self):
+        """What the exchange looks like (bench.py prints it into the JSON line's `dist`)."""
+        return {'bucket_mb': self.bucket_bytes / float(1 << 20),
+                'early_ranges_mb': [[round((hi - lo) * 4 / float(1 << 20), 2) for lo, hi in
+                                     sorted(plan.values(), key=lambda r: -r[0])] for plan in self._plans.values()],
+                'grad_mb': round(int(self.store.grad.numel()) * 4 / float(1 << 20), 2)}
+
     # ---- per step ----------------------------------------------------------------------------
     def arm(self, trunk):
         """Early buckets are allowed for the next backward of `trunk` (or of a suffix of its nodes)."""
@@ -148,17 +162,24 @@ class GradientBuckets(object):
             self._works.append(self.reduce_fn(grad[lo:hi]) or _Done())
             self._done.append((lo, hi))
             return
+        from luminoth_amd import plan as P
         cur = torch.cuda.current_stream(grad.device)
         if self._comm is None:
             self._comm = torch.cuda.Stream(device=grad.device)
         comm = self._comm
-        comm.wait_stream(cur)                         # data-gradient stream up to this node
+        K.stream_wait(comm, cur)                      # data-gradient stream up to this node
         for st in SideStream._streams.values():       # every weight-gradient chain enqueued so far
-            comm.wait_stream(st)
-        with torch.cuda.stream(comm):
+            K.stream_wait(comm, st)
+        with K.launch_on(comm):
             K.TAILS.flush()       # the queued split-K / BatchNorm tails of everything enqueued so far, on the comm stream
-            self._works.append(self.reduce_fn(grad[lo:hi]) or _Done())
-        self._done.append((lo, hi))
+
+        def exchange():
+            # the collective is not a launch of the kernel library: under a recorded launch plan the plan is cut here
+            # and this runs between its two parts at every replay (luminoth_amd/plan.py: host_call)
+            with torch.cuda.stream(comm):
+                self._works.append(self.reduce_fn(grad[lo:hi]) or _Done())
+            self._done.append((lo, hi))
+        P.host_call(exchange)
 
     def finish(self):
         """Called on the update stream after the backward (side streams joined): waits for the early buckets and

@@ -60,29 +60,36 @@ def _stat(stats, name, got, ref):
         stats[name] = max(stats.get(name, 0.0), float(np.abs(got - ref).max() / max(1.0, np.abs(got).max())))
 
 
-def run_step_with_tap(model, images, gts):
-    """model(...) -> loss -> backward with every conv layer's output recorded (CPU copies)."""
+def run_step_with_tap(model, images, gts, fused=False):
+    """model(...) -> loss -> backward with every conv layer's output recorded (CPU copies).  fused: through
+    `model.train_step` instead — the production schedule (three streams, no torch.autograd: FasterRCNN._step_body)."""
     from luminoth_amd.models.base import layers as L
     model._step = 0
     L.ACT_TAP = {}
     try:
-        pred = model(images, gts, is_training=True)
+        if fused:
+            model._step_state = {}          # a fresh (eager) step: the activation tap is host code
+            _, pred = model.train_step(images, gts)
+            losses = dict(model._last_losses)
+        else:
+            pred = model(images, gts, is_training=True)
         tap = {k: v.detach().cpu() for k, v in L.ACT_TAP.items()}
     finally:
         L.ACT_TAP = None
-    losses = model.loss(pred, return_all=True)
-    model.backward(losses['total_loss'])
+    if not fused:
+        losses = model.loss(pred, return_all=True)
+        model.backward(losses['total_loss'])
     torch.cuda.synchronize()
     return pred, losses, tap
 
 
 def compare_step_with_oracle(model, images, gts, num_classes, arch='resnet_v1_50', oracle_kwargs=None,
                              check_grads=True, min_checked=100, out_tol=1e-4, loss_tol=1e-4, grad_tight=2e-4,
-                             grad_max=1e-3, stats=None):
+                             grad_max=1e-3, stats=None, fused=False):
     """out_tol / loss_tol / grad_tight / grad_max: the fp32 bounds by default; the mixed-precision tests pass theirs
     (stated in tests/test_gpu_half.py).  stats (dict, optional): filled with the errors actually observed."""
     B, H, W = images.shape[0], images.shape[1], images.shape[2]
-    pred, losses, tap = run_step_with_tap(model, images, gts)
+    pred, losses, tap = run_step_with_tap(model, images, gts, fused=fused)
     oracle = OracleFasterRCNN(model.state_dict(), arch=arch, num_classes=num_classes, seed=0,
                               **(oracle_kwargs or {}))
     rp, cp = pred['rpn_prediction'], pred['classification_prediction']

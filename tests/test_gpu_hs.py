@@ -215,7 +215,7 @@ def _hs_step(storage, H, W, B=2, classes=80):
     gts = [gt[b, :int(cnt[b])].numpy() for b in range(B)]
     stats = {}
     try:
-        compare_step_with_oracle(model, images, gts, classes, oracle_kwargs={'storage': storage}, stats=stats, **HS_E2E[storage])
+        compare_step_with_oracle(model, images, gts, classes, oracle_kwargs={'storage': storage}, stats=stats, fused=True, **HS_E2E[storage])
     finally:
         print('half-storage %s step at %dx%d vs oracle(storage): observed %s' % (storage, H, W, {k: '%.2e' % v for k, v in stats.items()}))
     # the trunk really ran on 16-bit tensors

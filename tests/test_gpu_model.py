@@ -38,14 +38,17 @@ def _winograd_everywhere(monkeypatch, on):
     monkeypatch.setattr(KK, 'WINOGRAD_WGRAD_MIN_CK', 64 * 64)
 
 
+@pytest.mark.parametrize('fused', [False, True], ids=['module_api', 'train_step'])
 @pytest.mark.parametrize('winograd', [False, True], ids=['direct', 'winograd'])
-def test_train_step_matches_oracle(setup, winograd, monkeypatch):
+def test_train_step_matches_oracle(setup, winograd, fused, monkeypatch):
     """Whole step against the oracle, once with the direct 3x3 kernels and once with the Winograd F(2x2,3x3) path
     on every layer it covers (the default routes RPN + block3 through it).  Gradients with pinned ReLU branches:
     every element within 1e-3 of the tensor's scale on BOTH paths (tests/e2e_util.py)."""
     _winograd_everywhere(monkeypatch, winograd)
     cfg, model, images, gts = setup
-    compare_step_with_oracle(model, images, gts, 80)
+    # module_api: model(...) -> loss() -> backward() (torch.autograd routes the activation gradients); train_step: the
+    # production step (plain kernel calls on three streams, what bench.py and luminoth_amd.train.run issue)
+    compare_step_with_oracle(model, images, gts, 80, fused=fused)
 
 
 def test_train_step_matches_oracle_at_benchmark_shape():
@@ -58,7 +61,7 @@ def test_train_step_matches_oracle_at_benchmark_shape():
     bench.condition_weights(model, 'resnet_v1_50')
     images, (gt, cnt) = bench.synth_batch(2, 1024, 1024, 8, 80, 100, 'cpu')
     gts = [gt[b, :int(cnt[b])].numpy() for b in range(2)]
-    compare_step_with_oracle(model, images, gts, 80)
+    compare_step_with_oracle(model, images, gts, 80, fused=True)      # the production step: what bench.py times
 
 
 def test_free_running_agreement_at_benchmark_shape():
@@ -106,7 +109,7 @@ def test_resnet101_block4_tail_matches_oracle(winograd, monkeypatch):
     model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_101')
     assert model.base_network.tail is not None and model.base_network.tail_channels == 2048
     images, gts = synth(2, 256, 320, 3, 20, 5)
-    compare_step_with_oracle(model, images, gts, 20, arch='resnet_v1_101')
+    compare_step_with_oracle(model, images, gts, 20, arch='resnet_v1_101', fused=winograd)   # direct: module API; winograd: train_step
     # the tail's variables are trained (use_tail, not freeze_tail): their gradients were part of the check
     g = model.store.grads['truncated_base_network/resnet_v1_101/block4/unit_3/bottleneck_v1/conv2/weights']
     assert float(g.abs().max()) > 0
@@ -125,7 +128,7 @@ def test_vgg16_fasterrcnn_matches_oracle(hw, winograd, monkeypatch):
     model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'vgg_16')
     images, gts = synth(1, hw[0], hw[1], 3, 20, 7)
     compare_step_with_oracle(model, images, gts, 20, arch='vgg_16', oracle_kwargs={'fine_tune_from': 'conv3'},
-                             min_checked=20)
+                             min_checked=20, fused=winograd)        # direct: module API; winograd: train_step
     frozen = 'truncated_base_network/vgg_16/conv2/conv2_2/weights'
     assert frozen not in model.get_trainable_vars()
 
@@ -333,15 +336,15 @@ def test_next_image_prefetch_equals_plain_steps(setup):
         for i, x in enumerate(seq):
             nxt = seq[i + 1] if i + 1 < len(seq) else a
             ahead.append(float(T.train_step(model, opt, x, gts, next_image=nxt, next_gt=gts)[0]))
-            assert model.base_network._prefetched is not None and model.base_network._prefetched[0] is nxt
-            assert model._tgt_prefetch is not None and model._tgt_prefetch['src'] is gts      # next step's anchor targets
+            st = [S for S in model._step_state.values() if S['pf'] is not None]
+            assert len(st) == 1 and st[0]['pf']['image'] is nxt and st[0]['pf']['gt'] is gts     # next step's prefix + anchor targets
         assert ahead == plain
         assert torch.equal(model.store.flat, want)
         # announced `a` with one gt list, but `b` arrives with another list object (same values): nothing stale is used
         reset()
         T.train_step(model, opt, a, gts, next_image=a, next_gt=gts)
         l_b = float(T.train_step(model, opt, b, [g.copy() for g in gts])[0])
-        assert model.base_network._prefetched is None and model._tgt_prefetch is None
+        assert all(S['pf'] is None for S in model._step_state.values())
         assert l_b == plain[1]
         # announced tensor modified in place afterwards
         reset()
@@ -352,9 +355,7 @@ def test_next_image_prefetch_equals_plain_steps(setup):
     finally:
         model.load_state_dict(sd0)
         model.store.mom.zero_()
-        model._prefetch = None
-        model._tgt_prefetch = None
-        model.base_network._prefetched = None
+        model._step_state = {}
 
 
 def test_non_default_config_surface_trains(monkeypatch):

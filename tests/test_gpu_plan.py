@@ -1,0 +1,178 @@
+"""Launch plans (csrc/plan.hip, luminoth_amd/plan.py): a recorded train step re-issued with one host call must be the
+step the host code issues eagerly — same kernels, same arguments, same cross-stream order.  Pinned here by running the
+SAME sequence of steps with plans on and off and demanding bit-identical weights, and by the data-parallel stand-in of
+tests/test_gpu_model.py under replay.  Run with `-m gpu`."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+from e2e_util import condition_like_pretrained, make_config, synth      # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from luminoth_amd.models import get_model
+    cfg = make_config(**{'train.learning_rate.learning_rate': 1e-5})     # 12 updates of this random-init model stay finite
+    model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_50')
+    a, gts_a = synth(2, 320, 384, 4, 80, 3)
+    b, gts_b = synth(2, 320, 384, 4, 80, 5)
+    dev = model.device
+    return cfg, model, [(a.to(dev), gts_a), (b.to(dev), gts_b)]
+
+
+def _run(model, cfg, batches, steps, plan_on, lookahead=True):
+    from luminoth_amd import plan as P
+    from luminoth_amd.utils import training as T
+    P.ENABLED = plan_on
+    model._step_state = {}
+    model._step = 0
+    model.store.mom.zero_()
+    opt = T.get_optimizer(cfg.train, model)
+    losses = []
+    for i in range(steps):
+        cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+        if lookahead:
+            total, _ = T.train_step(model, opt, cur[0], cur[1], next_image=nxt[0], next_gt=nxt[1])
+        else:
+            total, _ = T.train_step(model, opt, cur[0], cur[1])
+        losses.append(dict((k, float(v)) for k, v in model._last_losses.items()))
+    torch.cuda.synchronize()
+    plans = [pl for S in model._step_state.values() for pl in S['plans'].values()]
+    return model.store.flat.clone(), losses, plans
+
+
+@pytest.mark.parametrize('lookahead', [True, False], ids=['lookahead', 'plain'])
+def test_replayed_steps_equal_eager_steps(setup, lookahead):
+    """12 steps over two alternating batches: with launch plans the first steps run eagerly, two are recorded (one per
+    step parity) and the rest are replays — weights after the last update bit-identical to 12 eager steps, every loss
+    equal (the reported L2 term is an fp32 atomic sum: 1e-6)."""
+    from luminoth_amd import plan as P
+    cfg, model, batches = setup
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    try:
+        w_eager, l_eager, plans0 = _run(model, cfg, batches, 12, False, lookahead)
+        assert plans0 == []
+        model.load_state_dict(sd0)
+        w_plan, l_plan, plans = _run(model, cfg, batches, 12, True, lookahead)
+        assert len(plans) == 2 and all(pl.replays >= 3 for pl in plans), [(pl.replays, pl.n_kernels) for pl in plans]
+        assert all(150 < pl.n_kernels < 400 for pl in plans), [pl.n_kernels for pl in plans]
+        assert bool(torch.isfinite(w_eager).all()) and torch.equal(w_plan, w_eager)
+        for a, b in zip(l_plan, l_eager):
+            for k in a:
+                assert abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    finally:
+        P.ENABLED = True
+        model.load_state_dict(sd0)
+        model._step_state = {}
+
+
+def test_unannounced_batch_falls_back_to_its_own_prefix(setup):
+    """A replayed step that was promised batch B but receives another tensor copies it in and computes its own prefix /
+    anchor targets (another plan variant): same weights as eager steps over the same sequence."""
+    from luminoth_amd import plan as P
+    from luminoth_amd.utils import training as T
+    cfg, model, batches = setup
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    (a, ga), (b, gb) = batches
+    c = torch.flip(a, dims=[2]).contiguous()
+    seq = [(a, ga, b, gb), (b, gb, a, ga), (a, ga, b, gb), (b, gb, a, ga), (a, ga, b, gb), (b, gb, a, ga),
+           (c, ga, b, gb),          # announced `a`, `c` arrives
+           (b, gb, a, ga), (a, ga, b, gb)]
+
+    def run(plan_on):
+        P.ENABLED = plan_on
+        model.load_state_dict(sd0)
+        model._step_state, model._step = {}, 0
+        model.store.mom.zero_()
+        opt = T.get_optimizer(cfg.train, model)
+        for x, g, nx, ng in seq:
+            T.train_step(model, opt, x, g, next_image=nx, next_gt=ng)
+        torch.cuda.synchronize()
+        return model.store.flat.clone()
+
+    try:
+        want = run(False)
+        got = run(True)
+        assert bool(torch.isfinite(want).all()) and torch.equal(got, want)
+    finally:
+        P.ENABLED = True
+        model.load_state_dict(sd0)
+        model._step_state = {}
+
+
+def test_gradient_buckets_under_replay(setup):
+    """The data-parallel exchange is host work between two parts of a plan (plan.host_call): with a stand-in reduce that
+    doubles its range, replayed steps must leave exactly 2 x the plain gradient — every element handed over once per
+    step, never before its producers finished — like the eager protocol (tests/test_gpu_model.py)."""
+    from luminoth_amd import plan as P
+    from luminoth_amd.utils import training as T
+    cfg, model, batches = setup
+    x, g = batches[0]
+    P.ENABLED = False
+    model._step_state, model._step = {}, 0
+    model.train_step(x, g)
+    torch.cuda.synchronize()
+    ref = model.store.grad.clone()
+    calls = []
+
+    def doubling(t):
+        calls.append(int(t.numel()))
+        t.mul_(2.0)
+
+    buckets = T.GradientBuckets(model.store, reduce_fn=doubling, bucket_bytes=4 << 20)
+    T.install_buckets(buckets)
+    P.ENABLED = True
+    try:
+        for rep in range(8):
+            model._step = 0
+            del calls[:]
+            model.train_step(x, g)
+            early = len(calls)
+            buckets.finish()
+            torch.cuda.synchronize()
+            assert early >= 3 and len(calls) > early, (rep, early, len(calls))
+            assert sum(calls) == model.store.grad.numel()
+            scale = float(ref.abs().max())
+            np.testing.assert_allclose(model.store.grad.cpu().numpy(), 2.0 * ref.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+        plans = [pl for S in model._step_state.values() for pl in S['plans'].values()]
+        assert plans and sum(pl.replays for pl in plans) >= 4 and all(len(pl.cuts) >= 3 for pl in plans)
+    finally:
+        T.install_buckets(None)
+        P.ENABLED = True
+        model._step_state = {}
+
+
+def test_plan_c_abi_records_and_replays_a_memset_and_a_kernel():
+    """The C ABI alone: record {memset, bn_refresh kernel, stream wait}, change the inputs, replay -> the outputs follow."""
+    from luminoth_amd import _lib, kernels as K
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    n = 1000
+    gamma, beta, mean, rstd = (torch.rand(n, device=dev) + 0.5 for _ in range(4))
+    scale, shift = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    junk = torch.ones(64, device=dev)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    assert lib.lmh_plan_recording() == 0 and lib.lmh_plan_position() == -1
+    assert lib.lmh_plan_begin() == 0
+    K.zero_(junk)
+    K.bn_refresh(gamma, beta, mean, rstd, scale, shift)
+    K.stream_wait(side, torch.cuda.current_stream())
+    assert lib.lmh_plan_position() == 4          # memset, kernel, event record, stream wait
+    plan = lib.lmh_plan_end()
+    assert plan and lib.lmh_plan_size(ctypes.c_void_p(plan)) == 4
+    assert lib.lmh_plan_kernel_count(ctypes.c_void_p(plan), 0, -1) == 1
+    gamma.mul_(3.0)
+    junk.fill_(7.0)
+    assert lib.lmh_plan_run(ctypes.c_void_p(plan), 0, -1) == 0
+    torch.cuda.synchronize()
+    s = gamma * rstd
+    assert torch.equal(scale, s) and torch.equal(shift, beta - mean * s) and float(junk.abs().max()) == 0.0
+    lib.lmh_plan_destroy(ctypes.c_void_p(plan))
