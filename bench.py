@@ -278,9 +278,11 @@ def main():
 
     T.issue_from_high_priority_stream(device)      # what luminoth_amd.train.run does: critical path first at the dispatcher
 
+    side_default = L.SideStream.enabled        # LUMINOTH_AMD_SIDE_STREAM=0: weight gradients on the issuing stream
+
     def serialise(on):
         T.FUSED_STEP = not on
-        L.SideStream.enabled = not on
+        L.SideStream.enabled = side_default and not on
 
     def sync():
         if world > 1:

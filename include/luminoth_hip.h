@@ -161,6 +161,10 @@ int lmh_plan_position(void);
 int lmh_plan_size(void* plan);
 int lmh_plan_kernel_count(void* plan, int first, int last);
 int lmh_plan_run(void* plan, int first, int last);
+/* A stream restricted to the compute units {i : i % period < keep} (hipExtStreamCreateWithCUMask) — the
+ * backward-overlap experiment of DESIGN.md §4; NULL on failure. */
+lmh_stream_t lmh_stream_create_cu_mask(int period, int keep);
+void lmh_stream_destroy(lmh_stream_t stream);
 /* scale = gamma * rstd, shift = beta - mean * scale over n channels: the frozen-statistics BatchNorm of every layer
  * (base_network.py:84-89) folded into per-channel scale / shift for the convolution epilogues, refreshed once a step. */
 int lmh_bn_refresh(const float* gamma, const float* beta, const float* mean, const float* rstd, int64_t n,

@@ -140,6 +140,8 @@ SIGNATURES = {
     'lmh_plan_size': (c_i, [c_f]),
     'lmh_plan_kernel_count': (c_i, [c_f, c_i, c_i]),
     'lmh_plan_run': (c_i, [c_f, c_i, c_i]),
+    'lmh_stream_create_cu_mask': (ctypes.c_void_p, [c_i, c_i]),
+    'lmh_stream_destroy': (None, [c_f]),
     'lmh_bn_refresh': (c_i, [c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f]),
     'lmh_loss_sums': (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_f, c_f, c_f, c_f]),
     'lmh_conv2d_hs_supported': (c_i, [P(ConvDesc)]),

@@ -274,3 +274,36 @@ extern "C" int lmh_plan_run(void* plan, int first, int last) {
   }
   return LMH_OK;
 }
+
+// A HIP stream whose kernels may only occupy a subset of the compute units: of every XCD's CUs c = 0..31 those with
+// c % period < keep.  Used for the backward-overlap experiment (weight-gradient stream on a fraction of the chip
+// beside the data-gradient stream); returns NULL on failure.  Destroy with lmh_stream_destroy.
+extern "C" lmh_stream_t lmh_stream_create_cu_mask(int period, int keep) {
+  if (period < 1 || keep < 1 || keep > period) {
+    lmh_set_error("lmh_stream_create_cu_mask: need 1 <= keep <= period");
+    return nullptr;
+  }
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      ncu <= 0) {
+    lmh_set_error("lmh_stream_create_cu_mask: cannot query the device");
+    return nullptr;
+  }
+  const int words = (ncu + 31) / 32;
+  std::vector<uint32_t> mask(words, 0u);
+  // Measured on MI355X (scripts/probe_cu_mask.py): mask bit i is CU (i / 8) of XCD (i % 8) — a mask that leaves an XCD
+  // without any CU is ignored by the runtime (patterns with a power-of-two stride ran at full speed), so the subset is
+  // chosen on the per-XCD index and every XCD keeps keep / period of its CUs.
+  const int xcds = 8;
+  for (int i = 0; i < ncu; ++i)
+    if ((i / xcds) % period < keep) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()) != hipSuccess) {
+    lmh_set_error("hipExtStreamCreateWithCUMask failed");
+    return nullptr;
+  }
+  return (lmh_stream_t)st;
+}
+extern "C" void lmh_stream_destroy(lmh_stream_t stream) {
+  if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+}

@@ -51,6 +51,7 @@ class SideStream(object):
     # gradient (10.43 -> 10.13 ms/step).
     inline_layers = int(os.environ.get('LUMINOTH_AMD_INLINE_LAYERS', '4'))
     layers_left = 0
+    cu_mask = os.environ.get('LUMINOTH_AMD_SIDE_CU_MASK', '')      # 'period:keep', e.g. '4:1' = a quarter of the CUs
     _streams = {}      # (device, issuing stream) -> stream (the fused train step issues from two streams)
     # tensors a side stream still reads (x, g of a layer whose weight gradient is queued there): references held until
     # join() instead of three tensor.record_stream calls per layer — nothing is freed, so nothing can be recycled early
@@ -61,7 +62,15 @@ class SideStream(object):
         key = (device, K._stream_id(device))
         st = cls._streams.get(key)
         if st is None:
-            st = torch.cuda.Stream(device=device)
+            if cls.cu_mask:
+                # experiment: the weight-gradient stream confined to keep / period of the compute units
+                period, keep = (int(v) for v in cls.cu_mask.split(':'))
+                h = K._lib.load().lmh_stream_create_cu_mask(period, keep)
+                if not h:
+                    raise K._lib.LuminothHipError('lmh_stream_create_cu_mask(%d, %d) failed' % (period, keep))
+                st = torch.cuda.ExternalStream(h, device=device)
+            else:
+                st = torch.cuda.Stream(device=device)
             cls._streams[key] = st
         return st
 

@@ -38,6 +38,12 @@ from luminoth_amd.utils.anchors import generate_anchors_reference, truncate_refe
 
 # software pipelining across steps (train_step(next_image=...)); LUMINOTH_AMD_PREFETCH_PREFIX=0 turns it off
 PREFETCH_PREFIX = os.environ.get('LUMINOTH_AMD_PREFETCH_PREFIX', '1') != '0'
+# RPN backward on the weight-gradient stream (idle until the trunk backward): '1' / '0' force it; default: on for fp32
+# tensors (6.95 against 7.06 ms per step), off for the half-storage trunk (4.26 against 4.17 ms) — measured, one box
+RPN_BWD_SIDE = os.environ.get('LUMINOTH_AMD_RPN_BWD_SIDE', 'auto')
+# where the next batch's frozen prefix runs: 'middle' = main stream while it waits for the RCNN branch (rounds 2-3);
+# 'side' / 'aux' = at the START of the step on the weight-gradient / proposal stream, under the trunk forward
+PREFIX_AT = os.environ.get('LUMINOTH_AMD_PREFIX_AT', 'middle')
 WINO_BATCH = os.environ.get('LUMINOTH_AMD_WINO_BATCH', '1') != '0'      # transformed Winograd weights of the whole step in two launches
 
 
@@ -416,13 +422,20 @@ class FasterRCNN(object):
             with K.launch_on(wino_bwd_side):
                 L.prepare_winograd_weights([l for l in wl if l.trainable], backward=True)
         K.zero_(self.store.grad)
+        start = S['start']
+        if produce and start > 0 and PREFIX_AT in ('side', 'aux') and SideStream.enabled:
+            # HBM-bound (conv1 + block1 on 256-channel fp32 maps) beside the MFMA-bound trunk forward
+            early = SideStream.get(self.device) if PREFIX_AT == 'side' else aux
+            K.stream_wait(early, main)
+            with torch.cuda.stream(early):
+                self._sub_trunk(0, start).forward(S['images'][1 - p], save_from=None, out=S['prefix'][1 - p])
+                self._mark('early:next_prefix_done')
         from luminoth_amd.utils import training as _tr
         # the aux stream is idle once the RCNN branch is done: weight-gradient tails of the trunk backward are finished
         # there in batches while the MFMA kernels run (not with gradient buckets: those flush on their own stream)
         K.TAILS.begin(early=None if _tr.ACTIVE_BUCKETS is not None else (aux, lambda: list(SideStream._streams.values())))
         fh, fw = bn.feature_hw(H, W)
         # ---- trunk forward: the frozen prefix (conv1 + fixed blocks) of THIS batch was computed during the previous step
-        start = S['start']
         nodes = bn.trunk.nodes
         x0 = image
         if start > 0:
@@ -460,9 +473,22 @@ class FasterRCNN(object):
         rpn_losses, rpn_g = rpn.loss_and_grads(rpn_pred, self._rpn_cls_loss_weight, self._rpn_reg_loss_weight)
         if wino_bwd_side is not None:
             K.stream_wait(main, wino_bwd_side)      # transformed backward weights (enqueued before the forward pass: long done)
-        SideStream.layers_left = 0
-        d_feat_rpn = rpn.heads_bwd(rpn_ctx, rpn_g[0], rpn_g[1])
-        self._mark('rpn_bwd_done')
+        rpn_bwd_stream = main
+        if SideStream.enabled and (RPN_BWD_SIDE == '1' or (RPN_BWD_SIDE == 'auto' and not bn._hs_layers)):
+            # the RPN backward (MFMA-bound) on the weight-gradient stream, which is idle until the trunk backward starts:
+            # it then runs beside the next batch's prefix (HBM-bound) on the main stream and the proposal chain
+            # (latency-bound) on the aux stream instead of in front of the prefix
+            rpn_bwd_stream = SideStream.get(self.device)
+            K.stream_wait(rpn_bwd_stream, main)
+            with torch.cuda.stream(rpn_bwd_stream):
+                SideStream.layers_left = 3          # its weight gradients follow their data gradients on that stream
+                d_feat_rpn = rpn.heads_bwd(rpn_ctx, rpn_g[0], rpn_g[1])
+                SideStream.layers_left = 0
+                self._mark('side:rpn_bwd_done')
+        else:
+            SideStream.layers_left = 0
+            d_feat_rpn = rpn.heads_bwd(rpn_ctx, rpn_g[0], rpn_g[1])
+            self._mark('rpn_bwd_done')
         # ---- aux stream: RCNN forward -> RCNN loss -> RCNN backward; the ROI-pooling backward adds the RPN branch's
         # gradient of the feature map in its store (TF: AddN over the two consumers of conv_feature_map)
         with torch.cuda.stream(aux):
@@ -471,11 +497,11 @@ class FasterRCNN(object):
             rcnn_losses, rcnn_g = rcnn.loss_and_grads(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
             self._mark('aux:rcnn_loss_done')
             d_feat = rcnn.train_bwd(rcnn_ctx, rcnn_g[0], rcnn_g[1], addend=d_feat_rpn,
-                                    before_pool_bwd=lambda: K.stream_wait(aux, main))
+                                    before_pool_bwd=lambda: K.stream_wait(aux, rpn_bwd_stream))
             self._mark('aux:rcnn_bwd_done')
         # ---- the main stream has nothing left but to wait for the RCNN branch: the slot for the frozen trunk prefix of
         # the NEXT step's images (conv1 + fixed blocks: nothing this step's update writes)
-        if produce and start > 0:
+        if produce and start > 0 and not (PREFIX_AT in ('side', 'aux') and SideStream.enabled):
             self._sub_trunk(0, start).forward(S['images'][1 - p], save_from=None, out=S['prefix'][1 - p])
             self._mark('next_prefix_done')
         # ---- join (the wait captures the aux stream as of NOW: what is queued there below does not delay the trunk backward)

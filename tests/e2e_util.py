@@ -60,6 +60,20 @@ def _stat(stats, name, got, ref):
         stats[name] = max(stats.get(name, 0.0), float(np.abs(got - ref).max() / max(1.0, np.abs(got).max())))
 
 
+def _log_stats(model, images, arch, fused, oracle_kwargs, stats):
+    """The errors this comparison observed -> tests/parity_log.py (profiles/r04_parity_observed.json)."""
+    from parity_log import note
+    bn = model.base_network
+    tag = 'e2e/%s/%dx%dx%d/%s%s%s' % (arch, images.shape[0], images.shape[1], images.shape[2],
+                                       'train_step' if fused else 'module_api',
+                                       '/storage_' + bn.storage_dtype if getattr(bn, 'storage_dtype', None) else '',
+                                       '/compute_' + str(bn.compute_dtype) if getattr(bn, 'compute_dtype', None) else '')
+    from luminoth_amd import kernels as KK
+    tag += '/winograd' if KK.WINOGRAD else '/direct'
+    for k, v in stats.items():
+        note('%s/%s' % (tag, k), v if k != 'grad_tight_min' else 1.0 - v)
+
+
 def run_step_with_tap(model, images, gts, fused=False):
     """model(...) -> loss -> backward with every conv layer's output recorded (CPU copies).  fused: through
     `model.train_step` instead — the production schedule (three streams, no torch.autograd: FasterRCNN._step_body)."""
@@ -89,6 +103,8 @@ def compare_step_with_oracle(model, images, gts, num_classes, arch='resnet_v1_50
     """out_tol / loss_tol / grad_tight / grad_max: the fp32 bounds by default; the mixed-precision tests pass theirs
     (stated in tests/test_gpu_half.py).  stats (dict, optional): filled with the errors actually observed."""
     B, H, W = images.shape[0], images.shape[1], images.shape[2]
+    stats_local = stats if stats is not None else {}
+    stats = stats_local
     pred, losses, tap = run_step_with_tap(model, images, gts, fused=fused)
     oracle = OracleFasterRCNN(model.state_dict(), arch=arch, num_classes=num_classes, seed=0,
                               **(oracle_kwargs or {}))
@@ -157,6 +173,7 @@ def compare_step_with_oracle(model, images, gts, num_classes, arch='resnet_v1_50
     total = sum(per.values())
     assert abs(float(losses['no_reg_loss']) - float(total)) <= loss_tol * max(1.0, float(total))
     if not check_grads:
+        _log_stats(model, images, arch, fused, oracle_kwargs, stats_local)
         return losses, per
     # gradients (data loss only; the L2 term is folded into the optimizer kernel), ReLU branches pinned
     total.backward()
@@ -179,6 +196,7 @@ def compare_step_with_oracle(model, images, gts, num_classes, arch='resnet_v1_50
             worst = (float(err.max() / scale), n)
         checked += 1
     assert checked >= min_checked, checked
+    _log_stats(model, images, arch, fused, oracle_kwargs, stats_local)
     return losses, per
 
 

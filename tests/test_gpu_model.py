@@ -78,9 +78,19 @@ def test_free_running_agreement_at_benchmark_shape():
     rep = free_running_agreement(model, images, gts, 80)
     print('free-running agreement @ 2x1024^2: proposals at the same rank %s, as sets %s, sampled ROI sets %s, losses %s'
           % (rep['same_rank'], rep['same_set'], rep['roi_set'], rep['losses']))
+    from parity_log import note
+    note('free_running@2x1024x1024/proposals_not_at_same_rank', 1.0 - min(rep['same_rank']))
+    note('free_running@2x1024x1024/proposal_set_mismatch', 1.0 - min(rep['same_set']), 0.02)
+    note('free_running@2x1024x1024/sampled_roi_set_mismatch', 1.0 - min(rep['roi_set']), 0.05)
     assert min(rep['same_set']) >= 0.98 and min(rep['roi_set']) >= 0.95
     for k, (got, ref) in rep['losses'].items():
-        assert abs(got - ref) <= 1e-3 * max(1.0, abs(ref)), (k, got, ref)
+        # RPN losses see no discrete decision of the free run (anchor targets depend on gt only): the fp32 bound 1e-4.
+        # RCNN losses are means over the SAMPLED ROI set: a proposal pair within an ulp of the NMS threshold, or two
+        # scores equal to the last bit, swaps a few of the 256 ROIs of an image (roi_set above: the count), and each
+        # swapped ROI moves the mean by up to |loss_i| / 256 — bounded at 1e-3, the observed value is recorded
+        tol = 1e-4 if k.startswith('rpn') else 1e-3
+        note('free_running@2x1024x1024/loss:' + k, abs(got - ref) / max(1.0, abs(ref)), tol)
+        assert abs(got - ref) <= tol * max(1.0, abs(ref)), (k, got, ref)
 
 
 def test_resnet101_tail_at_config4_size():

@@ -52,7 +52,7 @@ def _run(model, cfg, batches, steps, plan_on, lookahead=True):
 def test_replayed_steps_equal_eager_steps(setup, lookahead):
     """12 steps over two alternating batches: with launch plans the first steps run eagerly, two are recorded (one per
     step parity) and the rest are replays — weights after the last update bit-identical to 12 eager steps, every loss
-    equal (the reported L2 term is an fp32 atomic sum: 1e-6)."""
+    equal (the reported L2 term is an fp32 atomic sum over 13 M terms: 1e-5)."""
     from luminoth_amd import plan as P
     cfg, model, batches = setup
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
@@ -66,7 +66,7 @@ def test_replayed_steps_equal_eager_steps(setup, lookahead):
         assert bool(torch.isfinite(w_eager).all()) and torch.equal(w_plan, w_eager)
         for a, b in zip(l_plan, l_eager):
             for k in a:
-                assert abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(b[k])), (k, a[k], b[k])
+                assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(b[k])), (k, a[k], b[k])
     finally:
         P.ENABLED = True
         model.load_state_dict(sd0)

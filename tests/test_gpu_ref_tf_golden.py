@@ -1,12 +1,17 @@
 """The HIP kernels (through the C ABI) against fixtures produced by RUNNING the reference's TensorFlow-graph code
 (tests/golden/make_golden_ref_tf.py; the oracle replays the same file in tests/test_ref_tf_golden.py).  Nothing here
 goes through oracle/: the expected values are the reference's own outputs.  Labels, indices, keep lists, IoUs:
-bit-exact.  fp32 values that pass through expf / logf on the device: 1e-5 relative (tolerance at each assert)."""
+bit-exact.  fp32 values that pass through expf / logf on the device: 1e-5 relative; box coordinates: north_star's 1e-4
+(absolute, in pixels) — the largest errors observed are written to profiles/r04_parity_observed.json (parity_log.py)."""
 import os
+import sys
 
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from parity_log import check_close      # noqa: E402
 
 pytestmark = pytest.mark.gpu
 F = np.float32
@@ -93,7 +98,8 @@ def test_rpn_proposal_kernel_matches_reference_graph(G, K, name):
     n = G[k + 'proposals'].shape[0]
     assert int(cnt[0]) == n
     np.testing.assert_allclose(scores[0, :n].cpu().numpy(), G[k + 'scores'], rtol=1e-5)
-    np.testing.assert_allclose(props[0, :n].cpu().numpy(), G[k + 'proposals'], rtol=1e-5, atol=1e-3)   # expf * width
+    # north_star: box coordinates within 1e-4 (decode = expf(dw) * width: the device's expf and numpy's differ by an ulp)
+    check_close('ref_tf_golden/rpn_proposal/%s/proposals' % name, props[0, :n].cpu().numpy(), G[k + 'proposals'], rtol=1e-6, atol=1e-4)
 
 
 @pytest.mark.parametrize('name', names('rcnn_proposal'))
@@ -109,7 +115,7 @@ def test_rcnn_proposal_kernel_matches_reference_graph(G, K, name):
     assert int(num[0]) == n
     np.testing.assert_array_equal(labels[0, :n].cpu().numpy(), G[k + 'labels'])
     np.testing.assert_array_equal(probs[0, :n].cpu().numpy(), G[k + 'probs'])     # probabilities are inputs here
-    np.testing.assert_allclose(objects[0, :n].cpu().numpy(), G[k + 'objects'], rtol=1e-5, atol=1e-3)
+    check_close('ref_tf_golden/rcnn_proposal/%s/objects' % name, objects[0, :n].cpu().numpy(), G[k + 'objects'], rtol=1e-6, atol=1e-4)
 
 
 def test_roi_pool_kernel_matches_reference_graph(G, K):
@@ -157,11 +163,12 @@ def test_ssd_proposal_kernel_matches_reference_graph(G, K, name):
     assert int(r['num_objects'][0]) == n
     np.testing.assert_array_equal(r['labels'][0, :n].cpu().numpy(), G[k + 'labels'])
     np.testing.assert_array_equal(r['probs'][0, :n].cpu().numpy(), G[k + 'probs'])
-    np.testing.assert_allclose(r['objects'][0, :n].cpu().numpy(), G[k + 'objects'], rtol=1e-5, atol=1e-3)
+    check_close('ref_tf_golden/ssd_proposal/%s/objects' % name, r['objects'][0, :n].cpu().numpy(), G[k + 'objects'], rtol=1e-6, atol=1e-4)
     np.testing.assert_array_equal(r['anchors'][0, :n].cpu().numpy(), G[k + 'anchors_out'])      # proposal.py:162 quirk
     m = G[k + 'raw_proposals'].shape[0]
     assert int(r['num_raw_proposals'][0]) == m
-    np.testing.assert_allclose(r['raw_proposals'][0, :m].cpu().numpy(), G[k + 'raw_proposals'], rtol=1e-5, atol=1e-3)
+    check_close('ref_tf_golden/ssd_proposal/%s/raw_proposals' % name, r['raw_proposals'][0, :m].cpu().numpy(), G[k + 'raw_proposals'],
+                rtol=1e-6, atol=1e-4)
 
 
 @pytest.mark.parametrize('name', ['mixed', 'no_positives'])
