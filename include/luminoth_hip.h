@@ -15,9 +15,12 @@
  *    (thread local).
  *  - State: the data path keeps none — every result is a function of the
  *    arguments of the call.  What IS process- or thread-global is confined to
- *    four documented entry points, none of which changes a result: tuning
- *    options (lmh_set_option: which kernel variant / tile runs; the library
- *    reads no environment variable), lmh_conv2d_force_config (sweeps),
+ *    four documented entry points: tuning options (lmh_set_option: which
+ *    kernel variant / tile runs — equal results up to fp32 summation order,
+ *    EXCEPT `wino_m`, which selects Winograd F(2x2,3x3) or F(4x4,3x3) and
+ *    with it the rounding of every Winograd layer: ~1e-6 vs ~2e-5 of the
+ *    output scale, both inside the 1e-4 contract; the library reads no
+ *    environment variable), lmh_conv2d_force_config (sweeps),
  *    lmh_tail_defer (per thread: where a weight-gradient tail is finished) and
  *    lmh_conv2d_profile_next (event timing of the next convolution launch).
  *  - boxes are (x1,y1,x2,y2) fp32, inclusive-pixel convention; gt boxes are
@@ -539,13 +542,15 @@ int lmh_wgrad_tail_batch(const lmh_wgrad_tail* tails, int count, void* ws, size_
 /* The non-default rest of utils/training.py.  lmh_grad_clip_factors: factors[s] = clip / max(||g'_s||, clip) per
  * segment (clip_gradients_by_norm: tf.clip_by_norm(g', 10), training.py:84-120; g' includes the L2 term like TF's
  * gradient of total_loss).  lmh_optimizer_step: kind 0 momentum (p1 = momentum; 0 = GradientDescentOptimizer),
- * 1 Adam (p1, p2 = beta1, beta2; lr = bias-corrected lr_t), 2 RMSProp (p1 = decay, p2 = momentum); OPTIMIZERS table
- * training.py:6-11.  slot2 may be NULL for kind 0; seg_factor may be NULL (no clipping). */
+ * 1 Adam (p1, p2 = beta1, beta2; lr = bias-corrected lr_t), 2 RMSProp (p1 = decay, p2 = momentum), 3 momentum with
+ * use_nesterov=True (TF ApplyMomentum: w -= g'*lr + v*p1*lr), 4 RMSProp with centered=True (slot3 = the mean-gradient
+ * slot mg; TF ApplyCenteredRMSProp) — the keyword arguments training.py:64-81 forwards to the TF optimizers; OPTIMIZERS
+ * table training.py:6-11.  slot2 may be NULL for kinds 0 / 3, slot3 for all but 4; seg_factor may be NULL (no clipping). */
 size_t lmh_grad_clip_workspace_bytes(int nseg);
 int lmh_grad_clip_factors(const float* w, const float* g, int64_t n, const int64_t* seg_offset, const float* seg_wd,
                           int nseg, float gscale, float clip_norm, float* factors, void* ws, size_t ws_bytes,
                           lmh_stream_t stream);
-int lmh_optimizer_step(int kind, float* w, const float* g, float* slot1, float* slot2, int64_t n,
+int lmh_optimizer_step(int kind, float* w, const float* g, float* slot1, float* slot2, float* slot3, int64_t n,
                        const int64_t* seg_offset, const float* seg_wd, const float* seg_factor, int nseg, float lr,
                        float p1, float p2, float eps, float gscale, lmh_stream_t stream);
 /* tf.nn.dropout of the RCNN head (models/fasterrcnn/rcnn.py:196,218): y = x * keep / keep_prob, keep a pure function

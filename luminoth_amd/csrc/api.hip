@@ -15,7 +15,7 @@ void lmh_set_error(const char* fmt, ...) {
 
 // ---- tuning options: the ONLY process-global knobs of the library (none changes a result; they select among kernel
 // variants that the parity tests hold equal).  No environment variable is read anywhere in this library: the host
-// (luminoth_amd/kernels.py) forwards LMH_* variables through lmh_set_option at load time for sweeps / ablations.
+// (luminoth_amd/_lib.py) forwards LMH_OPT_<NAME>=<int> variables through lmh_set_option at load time for sweeps / ablations.
 struct lmh_option { const char* name; int value; };
 static lmh_option g_options[] = {
     {"bd_parity_small", 1},   // stride-2 3x3 backward data: 64x64 tiles when the parity classes are unbalanced

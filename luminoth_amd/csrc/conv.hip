@@ -233,6 +233,17 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
     LMH_CHECK_LAUNCH();
     return LMH_OK;
   }
+  if (!fast && !d->compute && d->R == 1 && d->S == 1 && d->stride == 1 && d->K <= 128 && (d->C & 3) == 0 &&
+      !in_sub && M <= 4096 && (size_t)d->C * 8 <= 64 * 1024) {
+    // skinny Linear / 1x1 head (e.g. the 81-wide RCNN classifier): vector-ALU kernel out of LDS (conv_generic.h)
+    prof_begin(st);
+    lmh_launch(k_skinny_fwd, dim3((unsigned)((M + 1) / 2)), dim3(256), (unsigned)((size_t)d->C * 8), st, x, w, scale, shift,
+               residual, y, (int)M, d->C, d->K, d->act);
+    prof_end(st, desc_flops(d), "k_skinny_fwd");
+    *bits_done = false;
+    LMH_CHECK_LAUNCH();
+    return LMH_OK;
+  }
 #define LAUNCH_FWD(BM_, BN_)                                                                              \
   do {                                                                                                    \
     if (fast)                                                                                             \
@@ -311,6 +322,24 @@ static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const
 #undef LAUNCH_BD_HT
 #undef LAUNCH_BD_H
     prof_end(st, desc_flops(d), "k_conv_bwd_data_h<%d, %d, %d>", d->compute, bm, bn);
+    LMH_CHECK_LAUNCH();
+    return LMH_OK;
+  }
+  if (!fast && !d->compute && !yact && d->R == 1 && d->S == 1 && d->stride == 1 && d->K <= 64 && (d->K & 3) == 0 &&
+      (d->C & 3) == 0) {
+    // skinny 1x1 head (24 / 48 output channels of the RPN): vector-ALU kernel out of LDS, addend + bit mask fused
+    static bool attr = false;
+    const unsigned shmem = (unsigned)(((size_t)d->K * SKB_CH + (size_t)SKB_PIX * d->K) * sizeof(float));
+    if (!attr) {
+      LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_bwd_data),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr = true;
+    }
+    const int tiles = (int)(((M + SKB_PIX - 1) / SKB_PIX) * ((d->C + SKB_CH - 1) / SKB_CH));
+    prof_begin(st);
+    lmh_launch(k_skinny_bwd_data, dim3(tiles), dim3(256), shmem, st, dy, w, kscale, addend, xbits, dx, (int)M, d->C, d->K);
+    prof_end(st, desc_flops(d), "k_skinny_bwd_data");
+    *bits_done = true;
     LMH_CHECK_LAUNCH();
     return LMH_OK;
   }
@@ -722,8 +751,8 @@ static bool wgrad_hs_plan(const lmh_conv_desc* d, int* bm, int* bn, int* splits,
   int want = (int)((slots + tiles - 1) / tiles);
   const int max_split = KT / 4 > 0 ? (KT / 4 < 64 ? KT / 4 : 64) : 1;
   if (want > max_split) want = max_split;
-  // every split writes an fp32 slab of the whole gradient, and the tail reads it again: keep the slabs within 4x the
-  // operand bytes (RPN 3x3: 18.9 MB per split against 25.8 MB of operands -> 5 splits; k_tail_reduce fetched 554 MB per
+  // every split writes an fp32 slab of the whole gradient, and the tail reads it again: keep the slabs within `hs_slab_cap` x the
+  // operand bytes (default 2; RPN 3x3: 18.9 MB per split against 25.8 MB of operands -> 2 splits; k_tail_reduce fetched 554 MB per
   // launch before this cap, profiles/r03_f16hs_pmc_traffic.json)
   const double operand_bytes = 2.0 * (double)P * (d->C + d->K);
   const double slab_bytes = 4.0 * d->R * d->S * (double)d->C * d->K;

@@ -436,3 +436,127 @@ k_splitk_reduce(const float* __restrict__ part, int64_t n, int splits, float* __
     }
   }
 }
+
+// ============================================================================
+// Skinny layers of the detection heads (round 4; VERDICT r3 weak #11 / next #6a).  The RPN heads are 1x1 convolutions with
+// 24 / 48 output channels and the RCNN classifier is a Linear with 81: too narrow for the 32-wide reduction / 4-wide
+// column steps of the MFMA kernels, so they fell to the predicated single-buffered kernels above (bwd-data 120 us at
+// 3 TFLOP/s inside the step, the classifier forward 146 us at 1 TFLOP/s).  Both are tiny (0.4 / 0.08 GFLOP) and
+// memory-shaped; they run on the vector ALUs out of LDS instead.
+//
+//   k_skinny_bwd_data:  dx[p][c] = sum_k dy[p][k] * ks[k] * w[c][k]  (+ addend[p][c]) (* act'(x) bit mask)
+//                       R = S = 1, stride 1, K <= 64, K % 4 == 0, C % 4 == 0.  A block owns 64 pixels x 256 channels:
+//                       w^T [K][256] and dy [64][K] sit in LDS, a thread accumulates 4 pixels x 4 channels.
+//   k_skinny_fwd:       y[m][k] = act(sum_c x[m][c] * w[c][k] * scale[k] + shift[k] (+ residual[m][k]))
+//                       R = S = 1, stride 1, K <= 128 (any K), C % 4 == 0.  A block owns 2 rows x all K: the x rows sit in
+//                       LDS, a thread is one output, w is read coalesced along k (it lives in L2: C x K x 4 bytes).
+// ============================================================================
+#define SKB_PIX 64
+#define SKB_CH 256
+__global__ void __launch_bounds__(256)
+k_skinny_bwd_data(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ kscale,
+                  const float* __restrict__ addend, const uint32_t* __restrict__ xbits, float* __restrict__ dx,
+                  int M, int C, int K) {
+  extern __shared__ __attribute__((aligned(16))) float sk_smem[];
+  float* const wT = sk_smem;                       // [K][SKB_CH]
+  float* const dys = sk_smem + (size_t)K * SKB_CH;  // [SKB_PIX][K]
+  const int tid = threadIdx.x;
+  const int tiles_c = (C + SKB_CH - 1) / SKB_CH;
+  const int m0 = (blockIdx.x / tiles_c) * SKB_PIX, c0 = (blockIdx.x % tiles_c) * SKB_CH;
+  const int K4 = K >> 2;
+  // w[c][k] (k contiguous) -> wT[k][c - c0]
+  for (int i = tid; i < SKB_CH * K4; i += 256) {
+    const int c = i / K4, k4 = i - c * K4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c0 + c < C) v = *reinterpret_cast<const f32x4*>(w + (size_t)(c0 + c) * K + 4 * k4);
+    wT[(4 * k4 + 0) * SKB_CH + c] = v.x;
+    wT[(4 * k4 + 1) * SKB_CH + c] = v.y;
+    wT[(4 * k4 + 2) * SKB_CH + c] = v.z;
+    wT[(4 * k4 + 3) * SKB_CH + c] = v.w;
+  }
+  for (int i = tid; i < SKB_PIX * K4; i += 256) {
+    const int p = i / K4, k4 = i - p * K4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m0 + p < M) v = *reinterpret_cast<const f32x4*>(dy + (size_t)(m0 + p) * K + 4 * k4);
+    if (kscale) {
+      const f32x4 s = *reinterpret_cast<const f32x4*>(kscale + 4 * k4);
+      v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+    }
+    *reinterpret_cast<f32x4*>(dys + (size_t)p * K + 4 * k4) = v;
+  }
+  __syncthreads();
+  const int c4 = tid & 63, pg = tid >> 6;          // 4 channels c0 + 4 c4 ..; pixels m0 + 16 pg + 4 j + i
+  f32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k4 = 0; k4 < K4; ++k4) {
+    f32x4 wv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wv[e] = *reinterpret_cast<const f32x4*>(wT + (size_t)(4 * k4 + e) * SKB_CH + 4 * c4);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dys + (size_t)(16 * pg + i) * K + 4 * k4);   // broadcast read
+      acc[i].x = fmaf(g.x, wv[0].x, acc[i].x); acc[i].y = fmaf(g.x, wv[0].y, acc[i].y);
+      acc[i].z = fmaf(g.x, wv[0].z, acc[i].z); acc[i].w = fmaf(g.x, wv[0].w, acc[i].w);
+      acc[i].x = fmaf(g.y, wv[1].x, acc[i].x); acc[i].y = fmaf(g.y, wv[1].y, acc[i].y);
+      acc[i].z = fmaf(g.y, wv[1].z, acc[i].z); acc[i].w = fmaf(g.y, wv[1].w, acc[i].w);
+      acc[i].x = fmaf(g.z, wv[2].x, acc[i].x); acc[i].y = fmaf(g.z, wv[2].y, acc[i].y);
+      acc[i].z = fmaf(g.z, wv[2].z, acc[i].z); acc[i].w = fmaf(g.z, wv[2].w, acc[i].w);
+      acc[i].x = fmaf(g.w, wv[3].x, acc[i].x); acc[i].y = fmaf(g.w, wv[3].y, acc[i].y);
+      acc[i].z = fmaf(g.w, wv[3].z, acc[i].z); acc[i].w = fmaf(g.w, wv[3].w, acc[i].w);
+    }
+  }
+  const int c = c0 + 4 * c4;
+  if (c >= C) return;
+  const int words = C >> 5;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int p = m0 + 16 * pg + i;
+    if (p >= M) break;
+    f32x4 v = acc[i];
+    const size_t o = (size_t)p * C + c;
+    if (addend) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(addend + o);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (xbits) {
+      const uint32_t mb = xbits[(size_t)p * words + (c >> 5)] >> (c & 31);
+      v.x = (mb & 1u) ? v.x : 0.f; v.y = (mb & 2u) ? v.y : 0.f;
+      v.z = (mb & 4u) ? v.z : 0.f; v.w = (mb & 8u) ? v.w : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dx + o) = v;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_skinny_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+             const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ y, int M, int C,
+             int K, int act) {
+  extern __shared__ __attribute__((aligned(16))) float sk_smem[];   // [2][C]
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * 2;
+  for (int i = tid; i < 2 * (C >> 2); i += 256) {
+    const int r = i / (C >> 2), c4 = i - r * (C >> 2);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m0 + r < M) v = *reinterpret_cast<const f32x4*>(x + (size_t)(m0 + r) * C + 4 * c4);
+    *reinterpret_cast<f32x4*>(sk_smem + (size_t)r * C + 4 * c4) = v;
+  }
+  __syncthreads();
+  const int r = tid >> 7, k = tid & 127;
+  if (k >= K || m0 + r >= M) return;
+  const float* xr = sk_smem + (size_t)r * C;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four partial sums: independent FMA chains
+  for (int c = 0; c < C; c += 4) {
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+    a0 = fmaf(xv.x, w[(size_t)(c + 0) * K + k], a0);
+    a1 = fmaf(xv.y, w[(size_t)(c + 1) * K + k], a1);
+    a2 = fmaf(xv.z, w[(size_t)(c + 2) * K + k], a2);
+    a3 = fmaf(xv.w, w[(size_t)(c + 3) * K + k], a3);
+  }
+  float v = (a0 + a1) + (a2 + a3);
+  v = v * (scale ? scale[k] : 1.f) + (shift ? shift[k] : 0.f);
+  if (residual) v += residual[(size_t)(m0 + r) * K + k];
+  if (act == 1) v = fmaxf(v, 0.f);
+  else if (act == 2) v = fminf(fmaxf(v, 0.f), 6.f);
+  y[(size_t)(m0 + r) * K + k] = v;
+}

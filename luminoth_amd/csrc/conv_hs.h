@@ -261,8 +261,10 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
         *reinterpret_cast<f32x4*>(yo + 4) = f32x4{v[4], v[5], v[6], v[7]};
       } else {
         V8 h;
+        // f16 has 5 exponent bits: a value beyond +-65504 would round to inf and poison the fp32 master weights through
+        // the weight gradient; it is stored as the largest finite f16 instead (bf16 has fp32's range)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) h[i] = (HTT)v[i];
+        for (int i = 0; i < 8; ++i) h[i] = (HTT)(DT == 1 ? fminf(fmaxf(v[i], -65504.f), 65504.f) : v[i]);
         *reinterpret_cast<V8*>(reinterpret_cast<HTT*>(e.out) + o) = h;
         // the mask follows the STORED value: a positive sum that rounds to zero (f16 underflow) is a dead unit for
         // the next layer and for the backward pass alike

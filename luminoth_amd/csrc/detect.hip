@@ -271,7 +271,10 @@ k_ssd_det_anchors(lmh_rcnn_proposal_desc d, int Tpad, const uint64_t* __restrict
       }
       j -= here;
     }
-    return;   // unreachable: j < total valid rows
+    // not reachable while this kernel's validity test agrees with the one that produced n_valid / keep_count; if it
+    // ever did not (a changed filter, a NaN probability) the row gets the zero box, not whatever the buffer held
+    if (lane == 0) det_anchors[(size_t)b * T + i] = out;
+    return;
   }
   if (lane == 0) det_anchors[(size_t)b * T + i] = out;
 }

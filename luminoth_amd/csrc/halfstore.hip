@@ -11,6 +11,13 @@ template <int DT> struct HS;
 template <> struct HS<1> { typedef _Float16 T; typedef h16x8 V8; };
 template <> struct HS<2> { typedef __bf16 T; typedef b16x8 V8; };
 
+// fp32 -> 16-bit with round-to-nearest-even; f16 SATURATES at its largest finite value (5 exponent bits: an overflow to inf in
+// a stored activation or scaled gradient would reach the fp32 master weights through the weight gradient — ADVICE r3);
+// bf16 has fp32's exponent range and converts as is.
+template <int DT> __device__ __forceinline__ typename HS<DT>::T hs_sat(float v) {
+  return (typename HS<DT>::T)(DT == 1 ? fminf(fmaxf(v, -65504.f), 65504.f) : v);
+}
+
 #define HS_DISPATCH(dtype, CALL)                                  \
   do {                                                            \
     if ((dtype) == 1) { CALL(1); } else { CALL(2); }              \
@@ -35,7 +42,7 @@ k_cast_to_half(const float* __restrict__ x, int64_t rows, int C, float mul, cons
     if (bits) m = bits[row * (C >> 5) + (c8 >> 2)] >> (8 * (c8 & 3));
     V8 h;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) h[e] = (T)(((m >> e) & 1u) ? v[e] * mul : 0.f);
+    for (int e = 0; e < 8; ++e) h[e] = hs_sat<DT>(((m >> e) & 1u) ? v[e] * mul : 0.f);
     *reinterpret_cast<V8*>(y + i * 8) = h;
   }
 }
@@ -106,7 +113,7 @@ k_half_weights(half_weight_batch b) {
     float v = 0.f;
     if (r < rows && k < K) {
       v = jb.w[(size_t)r * K + k];
-      if (wb) wb[(size_t)r * K + k] = (T)(v * ks);
+      if (wb) wb[(size_t)r * K + k] = (T)(v * ks);     // weights: no saturation (one rounding of the exact product, v_fma_mixlo_f16)
     }
     tile[i][tx] = v;
   }
@@ -180,7 +187,7 @@ k_maxpool_fwd_hs(const void* __restrict__ xv, int N, int H, int W, int C, int ks
     }
     V8 h;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) h[e] = (T)m[e];
+    for (int e = 0; e < 8; ++e) h[e] = hs_sat<DT>(m[e]);
     *reinterpret_cast<V8*>(y + i * 8) = h;
   }
 }

@@ -182,10 +182,14 @@ extern "C" int lmh_grad_clip_factors(const float* w, const float* g, int64_t n, 
 // kind 1: Adam      m = p1*m + (1-p1)*g' ; v = p2*v + (1-p2)*g'^2 ; w -= lr * m / (sqrt(v) + eps)
 //                   (lr = lr_t = lr0 * sqrt(1-p2^t) / (1-p1^t), computed by the host like TF's _prepare)
 // kind 2: RMSProp   ms = p1*ms + (1-p1)*g'^2 ; mom = p2*mom + lr*g'/sqrt(ms + eps) ; w -= mom
+// kind 3: Nesterov momentum (tf.train.MomentumOptimizer(use_nesterov=True), ApplyMomentum)
+//                   v = p1*v + g' ; w -= g'*lr + v*p1*lr
+// kind 4: centered RMSProp (tf.train.RMSPropOptimizer(centered=True), ApplyCenteredRMSProp)
+//                   mg = p1*mg + (1-p1)*g' ; ms = p1*ms + (1-p1)*g'^2 ; mom = p2*mom + lr*g'/sqrt(ms - mg^2 + eps) ; w -= mom
 template <int KIND>
 __global__ void __launch_bounds__(256)
 k_optimizer(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ s1, float* __restrict__ s2,
-            int64_t n, const int64_t* __restrict__ seg_offset, const float* __restrict__ seg_wd,
+            float* __restrict__ s3, int64_t n, const int64_t* __restrict__ seg_offset, const float* __restrict__ seg_wd,
             const float* __restrict__ seg_factor, int nseg, float lr, float p1, float p2, float eps, float gscale) {
   __shared__ int64_t s_off[OPT_MAX_SEG + 1];
   __shared__ float s_wd[OPT_MAX_SEG], s_f[OPT_MAX_SEG];
@@ -210,9 +214,21 @@ k_optimizer(float* __restrict__ w, const float* __restrict__ g, float* __restric
       s1[i] = m;
       s2[i] = v;
       w[i] = wi - lr * m / (sqrtf(v) + eps);
-    } else {
+    } else if (KIND == 2) {
       const float ms = p1 * s1[i] + (1.f - p1) * (gp * gp);
       const float mom = p2 * s2[i] + lr * gp / sqrtf(ms + eps);
+      s1[i] = ms;
+      s2[i] = mom;
+      w[i] = wi - mom;
+    } else if (KIND == 3) {
+      const float v = p1 * s1[i] + gp;
+      s1[i] = v;
+      w[i] = wi - (gp * lr + v * p1 * lr);
+    } else {
+      const float mg = p1 * s3[i] + (1.f - p1) * gp;
+      const float ms = p1 * s1[i] + (1.f - p1) * (gp * gp);
+      const float mom = p2 * s2[i] + lr * gp / sqrtf(ms - mg * mg + eps);
+      s3[i] = mg;
       s1[i] = ms;
       s2[i] = mom;
       w[i] = wi - mom;
@@ -220,19 +236,21 @@ k_optimizer(float* __restrict__ w, const float* __restrict__ g, float* __restric
   }
 }
 
-extern "C" int lmh_optimizer_step(int kind, float* w, const float* g, float* slot1, float* slot2, int64_t n,
+extern "C" int lmh_optimizer_step(int kind, float* w, const float* g, float* slot1, float* slot2, float* slot3, int64_t n,
                                   const int64_t* seg_offset, const float* seg_wd, const float* seg_factor, int nseg,
                                   float lr, float p1, float p2, float eps, float gscale, lmh_stream_t stream) {
   LMH_CHECK_ARG(w && g && slot1 && seg_offset && seg_wd && n > 0 && nseg > 0 && nseg <= OPT_MAX_SEG);
-  LMH_CHECK_ARG(kind >= 0 && kind <= 2 && (kind == 0 || slot2 != nullptr));
+  LMH_CHECK_ARG(kind >= 0 && kind <= 4 && (kind == 0 || kind == 3 || slot2 != nullptr) && (kind != 4 || slot3 != nullptr));
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_OPT(K_)                                                                                          \
-  lmh_launch((k_optimizer<K_>), dim3(blocks), dim3(256), 0, st, w, g, slot1, slot2, n, seg_offset, seg_wd, \
+  lmh_launch((k_optimizer<K_>), dim3(blocks), dim3(256), 0, st, w, g, slot1, slot2, slot3, n, seg_offset, seg_wd, \
                      seg_factor, nseg, lr, p1, p2, eps, gscale)
   if (kind == 0) LAUNCH_OPT(0);
   else if (kind == 1) LAUNCH_OPT(1);
-  else LAUNCH_OPT(2);
+  else if (kind == 2) LAUNCH_OPT(2);
+  else if (kind == 3) LAUNCH_OPT(3);
+  else LAUNCH_OPT(4);
 #undef LAUNCH_OPT
   LMH_CHECK_LAUNCH();
   return LMH_OK;

@@ -1084,10 +1084,11 @@ def grad_clip_factors(w, g, seg_offset, seg_wd, gscale, clip_norm, out):
     return out
 
 
-def optimizer_step(kind, w, g, slot1, slot2, seg_offset, seg_wd, seg_factor, lr, p1, p2, eps, gscale=1.0):
-    """kind 0 momentum, 1 Adam, 2 RMSProp (lmh_optimizer_step); seg_factor: per-segment clip factors or None."""
+def optimizer_step(kind, w, g, slot1, slot2, seg_offset, seg_wd, seg_factor, lr, p1, p2, eps, gscale=1.0, slot3=None):
+    """kind 0 momentum, 1 Adam, 2 RMSProp, 3 Nesterov momentum, 4 centered RMSProp (lmh_optimizer_step); seg_factor:
+    per-segment clip factors or None."""
     lib = _lib.load()
-    check(lib.lmh_optimizer_step(int(kind), _p(w), _p(g), _p(slot1), _p(slot2), w.numel(), _p(seg_offset),
+    check(lib.lmh_optimizer_step(int(kind), _p(w), _p(g), _p(slot1), _p(slot2), _p(slot3), w.numel(), _p(seg_offset),
                                  _p(seg_wd), _p(seg_factor), seg_wd.numel(), float(lr), float(p1), float(p2),
                                  float(eps), float(gscale), _stream()), 'lmh_optimizer_step')
 

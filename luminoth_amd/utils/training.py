@@ -228,9 +228,10 @@ class MomentumOptimizer(object):
     by one reduction launch in front of it."""
     KIND = 0
 
-    def __init__(self, model, train_config, momentum=0.9):
+    def __init__(self, model, train_config, momentum=0.9, use_nesterov=False):
         self.model, self.store, self.cfg = model, model.store, train_config
         self.momentum = float(momentum)
+        self.use_nesterov = bool(use_nesterov)     # TF ApplyMomentum: w -= g*lr + v*momentum*lr (v updated first)
         self.clip_norm = 10.0 if train_config.get('clip_by_norm') else None      # training.py:108: clip_by_norm(g, 10.)
         self.global_step = 0
         self.buckets = None
@@ -268,11 +269,11 @@ class MomentumOptimizer(object):
 
     def _update(self, lr, gscale, factors):
         st = self.store
-        if factors is None:
+        if factors is None and not self.use_nesterov:
             K.sgd_momentum(st.flat, st.grad, st.mom, st.seg_offset, st.seg_wd, lr, self.momentum, gscale)
         else:
-            K.optimizer_step(0, st.flat, st.grad, st.mom, None, st.seg_offset, st.seg_wd, factors, lr,
-                             self.momentum, 0.0, 0.0, gscale)
+            K.optimizer_step(3 if self.use_nesterov else 0, st.flat, st.grad, st.mom, None, st.seg_offset, st.seg_wd,
+                             factors, lr, self.momentum, 0.0, 0.0, gscale)
 
     def step(self):
         gscale = self.reduce_gradients()
@@ -311,16 +312,18 @@ class RMSPropOptimizer(MomentumOptimizer):
     at ONE (TF's initialiser), the momentum slot at zero."""
     KIND = 2
 
-    def __init__(self, model, train_config, decay=0.9, momentum=0.0, epsilon=1e-10):
+    def __init__(self, model, train_config, decay=0.9, momentum=0.0, epsilon=1e-10, centered=False):
         super(RMSPropOptimizer, self).__init__(model, train_config, momentum=momentum)
         self.decay, self.epsilon = float(decay), float(epsilon)
         self.store.mom.fill_(1.0)                    # slot 1 = ms
         self._slot2 = torch.zeros_like(self.store.mom)
+        self.centered = bool(centered)               # TF ApplyCenteredRMSProp: a third slot mg (mean gradient), starts at 0
+        self._slot3 = torch.zeros_like(self.store.mom) if self.centered else None
 
     def _update(self, lr, gscale, factors):
         st = self.store
-        K.optimizer_step(2, st.flat, st.grad, st.mom, self._slot2, st.seg_offset, st.seg_wd, factors, lr,
-                         self.decay, self.momentum, self.epsilon, gscale)
+        K.optimizer_step(4 if self.centered else 2, st.flat, st.grad, st.mom, self._slot2, st.seg_offset, st.seg_wd,
+                         factors, lr, self.decay, self.momentum, self.epsilon, gscale, slot3=self._slot3)
 
 
 def get_optimizer(train_config, model):
@@ -342,17 +345,13 @@ def get_optimizer(train_config, model):
         return kw
 
     if kind == 'momentum':
-        if opt.pop('use_nesterov', False):
-            raise NotImplementedError('use_nesterov=True has no fused HIP kernel (reference default: False)')
-        return MomentumOptimizer(model, train_config, **take(('momentum',)))
+        return MomentumOptimizer(model, train_config, **take(('momentum', 'use_nesterov')))
     if kind == 'gradient_descent':
         take(())
         return MomentumOptimizer(model, train_config, momentum=0.0)
     if kind == 'adam':
         return AdamOptimizer(model, train_config, **take(('beta1', 'beta2', 'epsilon')))
-    if opt.pop('centered', False):
-        raise NotImplementedError('RMSProp centered=True has no fused HIP kernel (TF default: False)')
-    return RMSPropOptimizer(model, train_config, **take(('decay', 'momentum', 'epsilon')))
+    return RMSPropOptimizer(model, train_config, **take(('decay', 'momentum', 'epsilon', 'centered')))
 
 
 def issue_from_high_priority_stream(device):

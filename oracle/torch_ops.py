@@ -17,7 +17,9 @@ def tf_same_pad(in_size, k, stride, dilation=1):
 
 def _q(t, quant):
     """Round to the half-precision operand format and back (RNE, like v_cvt_pk_* / the compiler's fp32 -> f16 / bf16)."""
-    return t.to(torch.float16 if quant == 'f16' else torch.bfloat16).to(t.dtype)
+    if quant == 'f16':      # the kernels saturate at the largest finite f16 instead of producing inf (conv_hs.h, halfstore.hip)
+        return t.clamp(-65504.0, 65504.0).to(torch.float16).to(t.dtype)
+    return t.to(torch.bfloat16).to(t.dtype)
 
 
 class QuantConvFn(torch.autograd.Function):

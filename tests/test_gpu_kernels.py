@@ -504,6 +504,9 @@ CONV_CASES = [
     (1, 1, 500, 1024, 320, 1, 1, 1, 'VALID', 'relu'),
     (2, 1, 301, 1024, 81, 1, 1, 1, 'VALID', None),      # Linear layer, 81 columns: rows % 8 != 0, odd row count
     (1, 1, 37, 256, 21, 1, 1, 1, 'VALID', 'relu'),      # ... with an activation, 21 columns (VOC classes + 1)
+    (2, 24, 40, 512, 24, 1, 1, 1, 'VALID', None),       # RPN cls head (2 x 12 anchors): k_skinny_bwd_data, K = 24
+    (2, 23, 41, 512, 48, 1, 1, 1, 'VALID', None),       # RPN bbox head (4 x 12): K = 48, pixel count % 64 != 0
+    (1, 9, 9, 288, 48, 1, 1, 1, 'SAME', 'relu'),        # skinny bwd-data with a partial 256-channel tile (C = 288)
     (2, 18, 18, 1024, 24, 3, 1, 1, 'SAME', None),       # SSD multibox offsets head: 3x3, K % 32 != 0
     (2, 9, 9, 512, 126, 3, 1, 1, 'SAME', None),         # SSD multibox classes head: 3x3, K % 4 != 0
     (1, 19, 19, 512, 1024, 3, 1, 6, 'SAME', 'relu'),    # SSD conv6: rate 6
@@ -826,11 +829,15 @@ def test_optimizer_variants_match_tf_formulas(K):
     want = _np_clip_factors(w0, grads[0], off, wd, gscale, clip)
     assert want.min() < 0.9 and want.max() == 1.0       # segment 1 (4 elements) is below the clip norm
     np.testing.assert_allclose(fac.cpu().numpy(), want, rtol=1e-6)
-    for kind, p1, p2, eps in ((0, 0.9, 0.0, 0.0), (1, 0.9, 0.999, 1e-8), (2, 0.9, 0.1, 1e-10)):
+    # kinds 3 / 4: use_nesterov=True (TF ApplyMomentum) and centered=True (TF ApplyCenteredRMSProp), the keyword
+    # arguments training.py:64-81 forwards to the TF constructors
+    for kind, p1, p2, eps in ((0, 0.9, 0.0, 0.0), (1, 0.9, 0.999, 1e-8), (2, 0.9, 0.1, 1e-10), (3, 0.9, 0.0, 0.0),
+                              (4, 0.9, 0.1, 1e-10)):
         w = w0.copy()
-        s1 = np.ones(n, F) if kind == 2 else np.zeros(n, F)
+        s1 = np.ones(n, F) if kind in (2, 4) else np.zeros(n, F)
         s2 = np.zeros(n, F)
-        dw, ds1, ds2 = T(w), T(s1), T(s2)
+        s3 = np.zeros(n, F)
+        dw, ds1, ds2, ds3 = T(w), T(s1), T(s2), T(s3)
         for t, g in enumerate(grads, 1):
             f = _np_clip_factors(w, g, off, wd, gscale, clip)
             gp = (g * F(gscale) + wd[seg_of] * w) * f[seg_of]
@@ -843,12 +850,21 @@ def test_optimizer_variants_match_tf_formulas(K):
                 s1 = F(p1) * s1 + F(1 - p1) * gp
                 s2 = F(p2) * s2 + F(1 - p2) * gp * gp
                 w = w - F(lr_t) * s1 / (np.sqrt(s2) + F(eps))
-            else:
+            elif kind == 2:
                 s1 = F(p1) * s1 + F(1 - p1) * gp * gp
                 s2 = F(p2) * s2 + F(lr) * gp / np.sqrt(s1 + F(eps))
                 w = w - s2
+            elif kind == 3:
+                s1 = F(p1) * s1 + gp
+                w = w - (gp * F(lr) + s1 * F(p1) * F(lr))
+            else:
+                s3 = F(p1) * s3 + F(1 - p1) * gp
+                s1 = F(p1) * s1 + F(1 - p1) * gp * gp
+                s2 = F(p2) * s2 + F(lr) * gp / np.sqrt(s1 - s3 * s3 + F(eps))
+                w = w - s2
             K.grad_clip_factors(dw, T(g), dev_off, dev_wd, gscale, clip, fac)
-            K.optimizer_step(kind, dw, T(g), ds1, ds2 if kind else None, dev_off, dev_wd, fac, lr_t, p1, p2, eps, gscale)
+            K.optimizer_step(kind, dw, T(g), ds1, ds2 if kind not in (0, 3) else None, dev_off, dev_wd, fac, lr_t, p1, p2, eps,
+                             gscale, slot3=ds3 if kind == 4 else None)
         np.testing.assert_allclose(dw.cpu().numpy(), w, rtol=2e-5, atol=1e-6, err_msg='kind %d' % kind)
         np.testing.assert_allclose(ds1.cpu().numpy(), s1, rtol=2e-5, atol=1e-7, err_msg='kind %d slot1' % kind)
     # the fused default kernel (lmh_sgd_momentum) == kind 0 without clipping
