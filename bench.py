@@ -371,6 +371,18 @@ def main():
             if rank == 0 and prof:
                 res['roofline'] = roofline_of(prof, nprof, dtype, dt, steps)
         if world > 1:
+            # data-parallel sanity: after the same number of identical updates every replica must hold the SAME bits
+            # (seeded init + broadcast, ring all-reduce hands every rank the same sums, one update kernel)
+            torch.cuda.synchronize()
+            flat = model.store.flat
+            chk = torch.stack([flat.view(torch.int32).to(torch.int64).sum(), flat.double().abs().sum().view(torch.int64)])
+            if dist.get_backend() != 'nccl':
+                chk = chk.cpu()          # gloo gathers host tensors
+            allc = [torch.zeros_like(chk) for _ in range(world)]
+            dist.all_gather(allc, chk)
+            same = all(bool(torch.equal(c, allc[0])) for c in allc)
+            res['replicas_identical'] = same
+            assert same, 'data-parallel replicas diverged: parameter checksums %r' % [c.tolist() for c in allc]
             dist.barrier()
         return res
 
@@ -473,7 +485,8 @@ def main():
                      'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
                      'streams': 'issue (high priority), proposal/RCNN (high priority), weight-gradient x2' +
                                 (', gradient-bucket, RCCL internal' if world > 1 else ''),
-                     'buckets': getattr(T.ACTIVE_BUCKETS, 'describe', lambda: None)()},
+                     'buckets': getattr(T.ACTIVE_BUCKETS, 'describe', lambda: None)(),
+                     'replicas_identical_after_timed_steps': head.get('replicas_identical')},
         }
         if head.get('phases'):
             out['phases_ms'] = head['phases']

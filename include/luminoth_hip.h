@@ -172,6 +172,19 @@ void lmh_stream_destroy(lmh_stream_t stream);
  * (base_network.py:84-89) folded into per-channel scale / shift for the convolution epilogues, refreshed once a step. */
 int lmh_bn_refresh(const float* gamma, const float* beta, const float* mean, const float* rstd, int64_t n,
                    float* scale, float* shift, lmh_stream_t stream);
+/* BatchNorm in TRAINING mode — `train_batch_norm: True` (base_network.py:82-93, truncated_base_network.py:56-95:
+ * slim.batch_norm(is_training=True), epsilon 1e-5, decay 0.997; update ops: train.py:87-88).  z (rows, K) is the RAW
+ * convolution output.  fwd: mean / rstd (K) of the batch are written (kept for the backward), y = act(z * gamma * rstd +
+ * beta - mean * gamma * rstd (+ residual)); with update_moving the moving statistics are advanced in place (variance with
+ * Bessel's correction, like tf.nn.fused_batch_norm).  bwd: g = gradient of the pre-activation sum; dgamma / dbeta (K) are
+ * WRITTEN, dz = gradient of the raw convolution output (then lmh_conv2d_bwd_data / _bwd_weight with no BatchNorm scale). */
+size_t lmh_bn_train_workspace_bytes(int64_t rows, int K);
+int lmh_bn_train_fwd(const float* z, int64_t rows, int K, const float* gamma, const float* beta, float eps, float decay,
+                     float* moving_mean, float* moving_var, int update_moving, const float* residual, int act, float* y,
+                     float* mean, float* rstd, void* ws, size_t ws_bytes, lmh_stream_t stream);
+int lmh_bn_train_bwd(const float* g, const float* z, const float* mean, const float* rstd, const float* gamma,
+                     int64_t rows, int K, float* dgamma, float* dbeta, float* dz, void* ws, size_t ws_bytes,
+                     lmh_stream_t stream);
 /* total_loss bookkeeping of fasterrcnn.py:203-259 on the device: out[1] = no_reg = sum of the n (<= 8) weighted loss
  * scalars in order, out[2] = regularization = reg_a + reg_b (NULL = 0), out[0] = total = no_reg + regularization. */
 int lmh_loss_sums(const float* const* terms, int n, const float* reg_a, const float* reg_b, float* out,

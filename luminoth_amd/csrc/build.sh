@@ -7,7 +7,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-result"
 OBJS=""
 pids=""
-for f in api plan proposals detect targets roi loss optim elementwise ssd tail halfstore conv; do
+for f in api plan proposals detect targets roi loss optim elementwise bnorm ssd tail halfstore conv; do
   stale=0
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ]; then stale=1; fi
   for h in *.h ../../include/luminoth_hip.h; do

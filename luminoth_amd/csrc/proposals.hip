@@ -250,8 +250,13 @@ k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts,
         const float iy1 = fmaxf(y1, c.y), ix1 = fmaxf(x1, c.x);
         const float iy2 = fminf(y2, c.w), ix2 = fminf(x2, c.z);
         const float inter = fmaxf(iy2 - iy1, 0.f) * fmaxf(ix2 - ix1, 0.f);
-        const float iou = inter / ((area_r + area_c) - inter);
-        if (iou > thr) word |= (1ull << j);
+        const float uni = (area_r + area_c) - inter;      // > 0: both areas are, and inter <= min(area)
+        // TF decides on fl(inter / uni) > thr.  The correctly rounded division is ~a third of this loop's vector-ALU work
+        // (72 M pairs per image at 12 000 candidates), and it only matters within a few ulp of the threshold: pairs clearly
+        // on one side are decided by a product, the rest (practically none) take the division — same decisions, bit for bit.
+        const float p = thr * uni;
+        if (inter > p * 1.000001f) word |= (1ull << j);
+        else if (inter >= p * 0.999999f && inter / uni > thr) word |= (1ull << j);
       }
     }
   }

@@ -105,6 +105,35 @@ def bn_refresh(gamma, beta, mean, rstd, scale, shift):
                                      _stream()), 'lmh_bn_refresh')
 
 
+def bn_train_fwd(z, gamma, beta, moving_mean, moving_var, residual=None, act=None, eps=1e-5, decay=0.997,
+                 update_moving=True):
+    """BatchNorm with the statistics of the batch over the RAW convolution output z (N,H,W,K) -> (y, mean, rstd); the
+    moving statistics are advanced in place (lmh_bn_train_fwd)."""
+    lib = _lib.load()
+    Kc = z.shape[-1]
+    rows = z.numel() // Kc
+    y = torch.empty_like(z)
+    mean = torch.empty((Kc,), dtype=torch.float32, device=z.device)
+    rstd = torch.empty((Kc,), dtype=torch.float32, device=z.device)
+    ws = _workspace(lib.lmh_bn_train_workspace_bytes(rows, Kc), z.device, 'bn_train')
+    check(lib.lmh_bn_train_fwd(_p(_f32(z)), rows, Kc, _p(gamma), _p(beta), float(eps), float(decay), _p(moving_mean),
+                               _p(moving_var), int(bool(update_moving)), _p(residual), ACT[act], _p(y), _p(mean), _p(rstd),
+                               _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_bn_train_fwd')
+    return y, mean, rstd
+
+
+def bn_train_bwd(g, z, mean, rstd, gamma, dgamma, dbeta):
+    """-> dz (gradient of the raw convolution output); dgamma / dbeta (K,) are written."""
+    lib = _lib.load()
+    Kc = z.shape[-1]
+    rows = z.numel() // Kc
+    dz = torch.empty_like(z)
+    ws = _workspace(lib.lmh_bn_train_workspace_bytes(rows, Kc), z.device, 'bn_train')
+    check(lib.lmh_bn_train_bwd(_p(_f32(g)), _p(z), _p(mean), _p(rstd), _p(gamma), rows, Kc, _p(dgamma), _p(dbeta), _p(dz),
+                               _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_bn_train_bwd')
+    return dz
+
+
 def loss_sums(terms, reg_a=None, reg_b=None, out=None):
     """-> out (3,) = [total, no_reg, regularization]: no_reg = ((t0 + t1) + t2) + ..., regularization = reg_a + reg_b
     (fasterrcnn.py:203-259) in ONE single-thread launch.  `terms`: 0-d / 1-element device tensors."""

@@ -22,6 +22,7 @@ FUSE_ACT = os.environ.get('LUMINOTH_AMD_FUSE_ACT', '0') == '1'
 # streaming pass.  The bit mask is 2 KB per tile and is requested before the accumulator transpose.
 FUSE_MASK = os.environ.get('LUMINOTH_AMD_FUSE_MASK', '1') == '1'
 BN_EPS = 1e-5  # slim resnet_arg_scope batch_norm_epsilon (truncated_base_network.py:69-73)
+BN_DECAY = 0.997  # slim resnet_arg_scope batch_norm_decay (its default; the reference does not override it)
 # Half-STORAGE trunk (BASELINE configs[4], csrc/conv_hs.h): layers with `storage` 'f16' / 'bf16' keep their activations,
 # activation gradients and working weight copies as 16-bit tensors.  Activation gradients carry a static loss scale (f16
 # has 5 exponent bits: gradients of 1e-7 would flush); the weight-gradient kernels divide it out of their fp32 sums.
@@ -97,6 +98,9 @@ class ConvLayer(object):
         self.norm = norm          # 'bn' | 'bias' | None
         self.wd, self.init = wd, init
         self.trainable = True
+        # `train_batch_norm: True` while training (base_network.py:82-93): normalise with the statistics of the batch and
+        # advance the moving averages (set per call by the base network; csrc/bnorm.hip)
+        self.bn_train = False
         self.compute = None       # MFMA operand arithmetic: None = fp32; 'f16' / 'bf16' = mixed precision (conv_half.h)
         self.compute_wgrad = 'same'   # arithmetic of the weight-gradient GEMM alone ('same' = self.compute)
         self.storage = None       # 'f16' / 'bf16': half tensors in HBM (then compute is the same type)
@@ -129,6 +133,9 @@ class ConvLayer(object):
         if self.norm == 'bn':
             self.bn = bn_table.views(self.scope)
             self.scale, self.shift = self.bn['scale'], self.bn['shift']
+            self.bn_table = bn_table
+            self.bn_vars = tuple(store['%s/BatchNorm/%s' % (self.scope, n)]
+                                 for n in ('gamma', 'beta', 'moving_mean', 'moving_variance'))
         elif self.norm == 'bias':
             self.shift = store[self.b_name]
             self.gb = store.grads.get(self.b_name)
@@ -154,6 +161,8 @@ class ConvLayer(object):
         """want_bits: also return the activation bit mask of y (None when the layer has no activation or a channel
         count that is not a multiple of 32) -> (y, bits).  out: tensor the result is written to (a buffer at a fixed
         address: the frozen trunk prefix computed one step ahead)."""
+        if self.bn_train and self.norm == 'bn':
+            return self._forward_bn_train(x, residual, in_sub, want_bits, keep_v, out)
         d = self.desc(x.shape)
         bits = None
         if want_bits and FUSE_MASK and K.act_bits_ok(self.cout, self.act):
@@ -184,6 +193,54 @@ class ConvLayer(object):
         if ACT_TAP is not None:
             ACT_TAP[self.scope] = y
         return (y, bits) if want_bits else y
+
+    # ---- BatchNorm in training mode (train_batch_norm: True; csrc/bnorm.hip) -------------------------------------------
+    def _desc_raw(self, x_shape):
+        """The convolution alone: no activation (BatchNorm sits between it and the activation)."""
+        key = tuple(x_shape) + ('raw',)
+        d = self._desc.get(key)
+        if d is None:
+            d = self._desc[key] = K.conv_desc(x_shape, (self.k, self.k, self.cin, self.cout), self.stride, self.rate,
+                                              self.padding, None, None)
+        return d
+
+    def _forward_bn_train(self, x, residual, in_sub, want_bits, keep_v, out):
+        if self.storage is not None or x.dtype != torch.float32 or self.compute not in (None, 'f32', 'fp32', 'float32'):
+            raise NotImplementedError('%s: train_batch_norm is implemented for fp32 tensors and arithmetic' % self.scope)
+        d0 = self._desc_raw(x.shape)
+        z = K.conv2d_fwd(d0, x, self.w, None, None, None, in_sub, keep_v=(want_bits or keep_v) and self.trainable)
+        gamma, beta, mm, mv = self.bn_vars
+        y, mean, rstd = K.bn_train_fwd(z, gamma, beta, mm, mv, residual, self.act, eps=BN_EPS, decay=BN_DECAY)
+        if out is not None:
+            y = K.copy_(out, y)
+        self.bn_table.stats_moved = True        # the folded scale / shift of the inference path are stale now
+        y._lmh_bn = (z, mean, rstd)
+        bits = None
+        if want_bits and FUSE_MASK and K.act_bits_ok(self.cout, self.act):
+            bits = K.act_bits(y, self.act)
+        if ACT_TAP is not None:
+            ACT_TAP[self.scope] = y
+        return (y, bits) if want_bits else y
+
+    def _backward_bn_train(self, x, y, dy, need_dx, addend, dy_is_g, mask_bits):
+        z, mean, rstd = y._lmh_bn
+        d0 = self._desc_raw(x.shape)
+        g = dy if (dy_is_g or not self.act) else K.act_bwd(dy, y, self.act, want_g=True)
+        gamma = self.bn_vars[0]
+        if self.trainable:
+            dgamma, dbeta = self.bn['ggamma'], self.bn['gbeta']
+            SideStream.layers_left -= 1
+        else:
+            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        dz = K.bn_train_bwd(g, z, mean, rstd, gamma, dgamma, dbeta)
+        # from here on a convolution without normalisation: dz is the gradient of its raw output
+        if self.trainable:
+            key = self.w_name if (K.TAILS.active and self.cout % 4 == 0 and self.cout <= 4096) else None
+            K.conv2d_bwd_weight(d0, x, dz, out=self.gw, colsum=None, defer=key)
+        dx = None
+        if need_dx:
+            dx = K.conv2d_bwd_data(d0, dz, self.w, kscale=None, addend=addend, xbits=mask_bits)
+        return dx, g
 
     def _weight_grads(self, d, x, g, yact, colsum):
         if self.compute_wgrad != 'same':
@@ -221,6 +278,8 @@ class ConvLayer(object):
         dy_is_g: the incoming gradient already is g (the producer applied act'(y) in its epilogue).
         mask_bits: activation bit mask of x (written by the forward kernel of the layer that produced x): the
         returned dx is then dx * act'(x), i.e. THAT layer's g (applied in the bwd_data epilogue)."""
+        if getattr(y, '_lmh_bn', None) is not None:
+            return self._backward_bn_train(x, y, dy, need_dx, addend, dy_is_g, mask_bits)
         d = self.desc(x.shape)
         boundary = self.storage is not None and self.hs_in_f32 and x.dtype == torch.float32
         if boundary:
@@ -348,6 +407,7 @@ class BNTable(object):
 
     def __init__(self):
         self.layers = []   # (scope, K, trainable)
+        self.stats_moved = False     # a training-mode BatchNorm advanced the moving statistics (ConvLayer._forward_bn_train)
 
     def add(self, scope, k, trainable):
         self.layers.append((scope, k, trainable))
@@ -407,6 +467,9 @@ class BNTable(object):
         self.refresh(force=True)
 
     def refresh(self, force=False):
+        if self.stats_moved:
+            self.stats_moved = False
+            return self.reload_statistics()
         for grp in self.groups:
             if grp['trainable'] or force:
                 # scale = gamma * rstd; shift = beta - mean * scale: one launch of the library per group

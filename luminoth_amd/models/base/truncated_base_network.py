@@ -174,10 +174,20 @@ class TruncatedBaseNetwork(BaseNetwork):
         self._anchor = torch.zeros(1, device=store.flat.device, requires_grad=True)
 
     # ---- forward ------------------------------------------------------------------
+    def set_bn_mode(self, is_training):
+        """base_network.py:82-93 / truncated_base_network.py:61-76: with `train_batch_norm: True` every BatchNorm of the
+        network (frozen blocks included — slim hands `is_training` to all of them) uses the statistics of the batch while
+        training and advances its moving averages; otherwise the frozen-statistics path.  Statistics are per process:
+        under data parallelism every replica normalises with its own batch, like the reference's per-worker graphs.
+        -> whether the training-mode path is on."""
+        on = bool(is_training and self._config.get('train_batch_norm'))
+        if on and not self.resnet_v1_type:
+            raise NotImplementedError('train_batch_norm: only the resnet_v1 networks have BatchNorm layers')
+        for layer in self._creation_order_layers() + (self.tail.all_layers() if self.tail else []):
+            layer.bn_train = on and layer.norm == 'bn'
+        return on
+
     def _run(self, trunk, x, is_training):
-        if is_training and self._config.get('train_batch_norm'):
-            raise NotImplementedError('train_batch_norm: True (BatchNorm in training mode) is not implemented; '
-                                      'the reference default is False (base_config.yml:147)')
         start = trunk.first_trainable()
         needs_grad = torch.is_grad_enabled() and (start < len(trunk.nodes) or x.requires_grad)
         if not needs_grad:
@@ -197,6 +207,7 @@ class TruncatedBaseNetwork(BaseNetwork):
 
     def __call__(self, inputs, is_training=False):
         """inputs (B,H,W,3) fp32 RGB 0..255 -> feature map (B,fh,fw,C)."""
+        self.set_bn_mode(is_training)
         self.bn_table.refresh()
         if self._hs_layers:
             L.prepare_half_weights(self._hs_layers + self.extra_hs_layers, self.storage_dtype)   # weights may have changed
@@ -209,4 +220,5 @@ class TruncatedBaseNetwork(BaseNetwork):
     def _build_tail(self, inputs, is_training=False):
         if not self._use_tail or self.tail is None:
             return inputs
+        self.set_bn_mode(is_training)
         return self._run(self.tail, inputs, is_training)

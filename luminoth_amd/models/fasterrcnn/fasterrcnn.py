@@ -355,7 +355,9 @@ class FasterRCNN(object):
             S['seeds'][p].copy_(self._image_seeds(B))
         self._step += 1
         # ---- the next step's inputs into slot 1 - p (its prefix / anchor targets are computed inside this step)
-        produce = (next_image is not None and next_gt is not None and PREFETCH_PREFIX and torch.is_tensor(next_image))
+        bn_train = self.base_network.set_bn_mode(True)
+        produce = (next_image is not None and next_gt is not None and PREFETCH_PREFIX and torch.is_tensor(next_image)
+                   and not bn_train)
         if produce:
             nimg = next_image if next_image.dim() == 4 else next_image.unsqueeze(0)
             ngt, ncnt = self._pack_gt(next_gt, nimg.shape[0])
@@ -368,7 +370,9 @@ class FasterRCNN(object):
             S['seeds'][q].copy_(self._image_seeds(B))       # self._step already counts this step: the NEXT step's seeds
             S['pf'] = dict(slot=q, image=next_image, image_v=next_image._version, gt=next_gt, step=self._step)
         variant = (p, bool(have_pf), bool(produce))
-        plannable = P.ENABLED and self._rcnn._dropout_keep_prob in (None, 1, 1.0)
+        # host-drawn dropout seeds and the in-place moving averages of training-mode BatchNorm are per-step state a
+        # recorded plan would freeze / the look-ahead would advance early: those configurations run every step eagerly
+        plannable = P.ENABLED and self._rcnn._dropout_keep_prob in (None, 1, 1.0) and not bn_train
         plan = S['plans'].get(variant) if plannable else None
         if plan is not None:
             self._phase_collect(S, p)
@@ -413,7 +417,8 @@ class FasterRCNN(object):
         bn.bn_table.refresh()
         if bn._hs_layers:
             L.prepare_half_weights(bn._hs_layers + bn.extra_hs_layers, bn.storage_dtype)
-        wl = self._winograd_layers() if WINO_BATCH else []
+        # (training-mode BatchNorm: the backward weights are NOT pre-scaled by a frozen BatchNorm scale: transformed per call)
+        wl = self._winograd_layers() if (WINO_BATCH and not self.base_network._config.get('train_batch_norm')) else []
         wino_bwd_side = None
         if wl:
             L.prepare_winograd_weights(wl, backward=False)

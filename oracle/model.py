@@ -45,8 +45,12 @@ class OracleFasterRCNN(object):
     def __init__(self, variables, arch='resnet_v1_50', num_classes=80, scope='fasterrcnn',
                  base_scope='truncated_base_network', anchors=None, rpn=None, rcnn=None, weight_decay=5e-4,
                  l2_rpn=5e-4, l2_rcnn=5e-4, fine_tune_from='block2', seed=None, dtype=torch.float32, compute=None,
-                 storage=None):
+                 storage=None, train_bn=False):
         self.dtype = dtype
+        # `train_batch_norm: True` (base_network.py:82-93): every BatchNorm normalises with the statistics of the tensor it
+        # sees (the reference is batch-1: one image) and reports the moving-average update slim would apply (bn_updates)
+        self.train_bn = bool(train_bn)
+        self.bn_updates = {}
         # 'f16' / 'bf16': the ResNet blocks keep 16-bit tensors in memory (oracle/torch_ops.py HalfStorageConvFn restates
         # luminoth_amd/csrc/conv_hs.h); implies the same `compute`
         self.storage = storage if storage in ('f16', 'bf16') else None
@@ -109,9 +113,27 @@ class OracleFasterRCNN(object):
         v = self.v
         q = self.compute if x.shape[-1] % 32 == 0 else None          # conv1 (3 channels) runs the fp32 stem kernel
         y = ot.conv2d_nhwc(x, v[scope + '/weights'], stride, rate, padding, quant=q)
+        if self.train_bn:
+            # slim.batch_norm(is_training=True): biased batch variance normalises; tf.nn.fused_batch_norm hands the
+            # UNBIASED one to the moving average (decay 0.997: resnet_arg_scope's default)
+            mean = y.mean(dim=(0, 1, 2))
+            var = ((y - mean) ** 2).mean(dim=(0, 1, 2))
+            n = float(y.numel() // y.shape[-1])
+            self.bn_updates[scope] = (mean.detach().clone(), (var * (n / max(n - 1.0, 1.0))).detach().clone())
+            y = (y - mean) * torch.rsqrt(var + 1e-5) * v[scope + '/BatchNorm/gamma'] + v[scope + '/BatchNorm/beta']
+            return self._activate(y, act, scope)
         y = ot.frozen_batch_norm(y, v[scope + '/BatchNorm/gamma'], v[scope + '/BatchNorm/beta'],
                                  v[scope + '/BatchNorm/moving_mean'], v[scope + '/BatchNorm/moving_variance'])
         return self._activate(y, act, scope)
+
+    def moving_statistics_after_step(self, decay=0.997):
+        """What the UPDATE_OPS of the step (train.py:87-88) leave in the moving statistics: v -= (v - batch) * (1 - decay)."""
+        out = {}
+        for scope, (mean, var) in self.bn_updates.items():
+            mm, mv = self.v[scope + '/BatchNorm/moving_mean'], self.v[scope + '/BatchNorm/moving_variance']
+            out[scope + '/BatchNorm/moving_mean'] = mm - (mm - mean) * (1.0 - decay)
+            out[scope + '/BatchNorm/moving_variance'] = mv - (mv - var) * (1.0 - decay)
+        return out
 
     def _bottleneck(self, x, scope, depth, stride, rate):
         p = scope + '/bottleneck_v1'
