@@ -103,7 +103,7 @@ def build(wl, device, dtype='f32', half_storage=True):
             # f16 / bf16: 16-bit activations, activation gradients and working weights in HBM for the ResNet trunk
             # (csrc/conv_hs.h); --fp32-storage keeps the round-2 path (fp32 tensors, operands rounded
             # on their way into LDS)
-            if half_storage and dtype in ('f16', 'bf16') and wl['arch'].startswith('resnet_v1') and wl['arch'] != 'resnet_v1_101':
+            if half_storage and dtype in ('f16', 'bf16') and wl['arch'].startswith('resnet_v1'):
                 bn['storage_dtype'] = dtype
         cfg = get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': wl['classes']},
                                     'base_network': bn}, 'train': {'seed': 0, 'debug': False}})

@@ -183,8 +183,15 @@ int lmh_bn_train_fwd(const float* z, int64_t rows, int K, const float* gamma, co
                      float* moving_mean, float* moving_var, int update_moving, const float* residual, int act, float* y,
                      float* mean, float* rstd, void* ws, size_t ws_bytes, lmh_stream_t stream);
 int lmh_bn_train_bwd(const float* g, const float* z, const float* mean, const float* rstd, const float* gamma,
-                     int64_t rows, int K, float* dgamma, float* dbeta, float* dz, void* ws, size_t ws_bytes,
-                     lmh_stream_t stream);
+                     int64_t rows, int K, const float* addend, int frozen_statistics, float* dgamma, float* dbeta,
+                     float* dz, void* ws, size_t ws_bytes, lmh_stream_t stream);
+/* ... `addend` (rows, K; may be NULL) is added to dz (a second consumer's gradient of the same tensor);
+ * frozen_statistics != 0: mean / rstd are constants (the moving statistics): dz = gamma * rstd * g, dgamma / dbeta as
+ * above — the backward of a stand-alone inference-mode BatchNorm with trainable gamma / beta; dz may be NULL (parameter
+ * gradients only).  lmh_bn_apply: that layer's forward, y = act(z * scale + shift (+ residual)) — the `preact` BatchNorm
+ * of slim's resnet_v2 units (base_network.py:94-101), which does not follow a convolution. */
+int lmh_bn_apply(const float* z, int64_t rows, int K, const float* scale, const float* shift, const float* residual,
+                 int act, float* y, lmh_stream_t stream);
 /* total_loss bookkeeping of fasterrcnn.py:203-259 on the device: out[1] = no_reg = sum of the n (<= 8) weighted loss
  * scalars in order, out[2] = regularization = reg_a + reg_b (NULL = 0), out[0] = total = no_reg + regularization. */
 int lmh_loss_sums(const float* const* terms, int n, const float* reg_a, const float* reg_b, float* out,

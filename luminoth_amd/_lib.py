@@ -145,7 +145,8 @@ SIGNATURES = {
     'lmh_bn_refresh': (c_i, [c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f]),
     'lmh_bn_train_workspace_bytes': (c_sz, [c_i64, c_i]),
     'lmh_bn_train_fwd': (c_i, [c_f, c_i64, c_i, c_f, c_f, c_fl, c_fl, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_sz, c_f]),
-    'lmh_bn_train_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_bn_train_bwd': (c_i, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i, c_f, c_i, c_f, c_f, c_f, c_f, c_sz, c_f]),
+    'lmh_bn_apply': (c_i, [c_f, c_i64, c_i, c_f, c_f, c_f, c_i, c_f, c_f]),
     'lmh_loss_sums': (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_f, c_f, c_f, c_f]),
     'lmh_conv2d_hs_supported': (c_i, [P(ConvDesc)]),
     'lmh_conv2d_fwd_hs': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f]),

@@ -97,12 +97,19 @@ k_bn_finish_bwd(const float* __restrict__ part, int nb, int K, const float* __re
 __global__ void __launch_bounds__(256)
 k_bn_apply_bwd(const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ mean,
                const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ dgamma,
-               const float* __restrict__ dbeta, int64_t rows, int64_t n, int K, float* __restrict__ dz) {
+               const float* __restrict__ dbeta, const float* __restrict__ addend, int frozen, int64_t rows, int64_t n,
+               int K, float* __restrict__ dz) {
   const float inv_n = 1.f / (float)rows;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % K);
-    const float xhat = (z[i] - mean[c]) * rstd[c];
-    dz[i] = gamma[c] * rstd[c] * (g[i] - dbeta[c] * inv_n - xhat * dgamma[c] * inv_n);
+    float v;
+    if (frozen) {       // statistics are constants (inference-mode BatchNorm with trainable gamma / beta)
+      v = gamma[c] * rstd[c] * g[i];
+    } else {
+      const float xhat = (z[i] - mean[c]) * rstd[c];
+      v = gamma[c] * rstd[c] * (g[i] - dbeta[c] * inv_n - xhat * dgamma[c] * inv_n);
+    }
+    dz[i] = addend ? v + addend[i] : v;
   }
 }
 
@@ -148,9 +155,9 @@ extern "C" int lmh_bn_train_fwd(const float* z, int64_t rows, int K, const float
 }
 
 extern "C" int lmh_bn_train_bwd(const float* g, const float* z, const float* mean, const float* rstd, const float* gamma,
-                                int64_t rows, int K, float* dgamma, float* dbeta, float* dz, void* ws, size_t ws_bytes,
-                                lmh_stream_t stream) {
-  LMH_CHECK_ARG(g && z && mean && rstd && gamma && dgamma && dbeta && dz && rows > 0 && K > 0 && K <= BNT_MAX_K);
+                                int64_t rows, int K, const float* addend, int frozen_statistics, float* dgamma,
+                                float* dbeta, float* dz, void* ws, size_t ws_bytes, lmh_stream_t stream) {
+  LMH_CHECK_ARG(g && z && mean && rstd && gamma && dgamma && dbeta && rows > 0 && K > 0 && K <= BNT_MAX_K);
   if (!ws || ws_bytes < lmh_bn_train_workspace_bytes(rows, K)) {
     lmh_set_error("lmh_bn_train_bwd: workspace too small");
     return LMH_ERR_WORKSPACE;
@@ -163,8 +170,21 @@ extern "C" int lmh_bn_train_bwd(const float* g, const float* z, const float* mea
   const int eb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   lmh_launch(k_bn_partial<2>, dim3(nb), dim3(256), 0, st, z, g, mean, rows, K, rpb, part);
   lmh_launch(k_bn_finish_bwd, dim3((K + 255) / 256), dim3(256), 0, st, (const float*)part, nb, K, rstd, dgamma, dbeta);
-  lmh_launch(k_bn_apply_bwd, dim3(eb), dim3(256), 0, st, g, z, mean, rstd, gamma, (const float*)dgamma, (const float*)dbeta,
-             rows, n, K, dz);
+  if (dz)       // (NULL: only the parameter gradients are wanted — nothing below needs the data gradient)
+    lmh_launch(k_bn_apply_bwd, dim3(eb), dim3(256), 0, st, g, z, mean, rstd, gamma, (const float*)dgamma,
+               (const float*)dbeta, addend, frozen_statistics, rows, n, K, dz);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+// y = act(z * scale[c] + shift[c] (+ residual)): a BatchNorm with frozen statistics that does NOT follow a convolution
+// (the `preact` of slim's resnet_v2 units, base_network.py:94-101) — convolutions fold the same expression into their epilogue.
+extern "C" int lmh_bn_apply(const float* z, int64_t rows, int K, const float* scale, const float* shift,
+                            const float* residual, int act, float* y, lmh_stream_t stream) {
+  LMH_CHECK_ARG(z && scale && shift && y && rows > 0 && K > 0 && act >= 0 && act <= 2);
+  const int64_t n = rows * K;
+  const int eb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  lmh_launch(k_bn_apply_fwd, dim3(eb), dim3(256), 0, (hipStream_t)stream, z, scale, shift, residual, act, n, K, y);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

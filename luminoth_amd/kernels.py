@@ -122,16 +122,27 @@ def bn_train_fwd(z, gamma, beta, moving_mean, moving_var, residual=None, act=Non
     return y, mean, rstd
 
 
-def bn_train_bwd(g, z, mean, rstd, gamma, dgamma, dbeta):
-    """-> dz (gradient of the raw convolution output); dgamma / dbeta (K,) are written."""
+def bn_train_bwd(g, z, mean, rstd, gamma, dgamma, dbeta, addend=None, frozen=False, need_dz=True):
+    """-> dz (gradient of the BatchNorm input; + addend); dgamma / dbeta (K,) are written.  frozen: mean / rstd are the
+    moving statistics (constants): dz = gamma * rstd * g."""
     lib = _lib.load()
     Kc = z.shape[-1]
     rows = z.numel() // Kc
-    dz = torch.empty_like(z)
+    dz = torch.empty_like(z) if need_dz else None
     ws = _workspace(lib.lmh_bn_train_workspace_bytes(rows, Kc), z.device, 'bn_train')
-    check(lib.lmh_bn_train_bwd(_p(_f32(g)), _p(z), _p(mean), _p(rstd), _p(gamma), rows, Kc, _p(dgamma), _p(dbeta), _p(dz),
-                               _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_bn_train_bwd')
+    check(lib.lmh_bn_train_bwd(_p(_f32(g)), _p(z), _p(mean), _p(rstd), _p(gamma), rows, Kc, _p(addend), int(bool(frozen)),
+                               _p(dgamma), _p(dbeta), _p(dz), _p(ws), ctypes.c_size_t(ws.numel()), _stream()),
+          'lmh_bn_train_bwd')
     return dz
+
+
+def bn_apply(z, scale, shift, residual=None, act=None):
+    """y = act(z * scale + shift (+ residual)): a frozen-statistics BatchNorm that does not follow a convolution."""
+    Kc = z.shape[-1]
+    y = torch.empty_like(z)
+    check(_lib.load().lmh_bn_apply(_p(_f32(z)), z.numel() // Kc, Kc, _p(scale), _p(shift), _p(residual), ACT[act], _p(y),
+                                   _stream()), 'lmh_bn_apply')
+    return y
 
 
 def loss_sums(terms, reg_a=None, reg_b=None, out=None):

@@ -17,7 +17,7 @@ VALID_ARCHITECTURES = set([
     'resnet_v2_50', 'resnet_v2_101', 'resnet_v2_152',
     'vgg_16', 'truncated_vgg_16',
 ])
-_IMPLEMENTED = {'resnet_v1_50', 'resnet_v1_101', 'resnet_v1_152', 'vgg_16', 'truncated_vgg_16'}
+_IMPLEMENTED = set(VALID_ARCHITECTURES)
 
 
 def he_normal(shape, gen):
@@ -63,6 +63,10 @@ class BaseNetwork(object):
     @property
     def resnet_v1_type(self):
         return self._architecture.startswith('resnet_v1')
+
+    @property
+    def resnet_v2_type(self):
+        return self._architecture.startswith('resnet_v2')
 
     def _weight_decay(self):
         return float((self._config.get('arg_scope') or {}).get('weight_decay', 0.0) or 0.0)

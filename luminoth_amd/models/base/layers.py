@@ -407,21 +407,26 @@ class BNTable(object):
 
     def __init__(self):
         self.layers = []   # (scope, K, trainable)
+        self.prefix = {}   # scope -> variable-name prefix ('<scope>/BatchNorm' behind a convolution; '<scope>' for a stand-alone layer)
         self.stats_moved = False     # a training-mode BatchNorm advanced the moving statistics (ConvLayer._forward_bn_train)
 
-    def add(self, scope, k, trainable):
+    def add(self, scope, k, trainable, prefix=None):
         self.layers.append((scope, k, trainable))
+        self.prefix[scope] = prefix or (scope + '/BatchNorm')
+
+    def var(self, scope, kind):
+        return '%s/%s' % (self.prefix[scope], kind)
 
     def register(self, store, ones, zeros):
         # grouped registration keeps each kind contiguous inside the flat buffers
         for scope, k, tr in self.layers:
-            store.add('%s/BatchNorm/gamma' % scope, (k,), ones, trainable=tr)
+            store.add(self.var(scope, 'gamma'), (k,), ones, trainable=tr)
         for scope, k, tr in self.layers:
-            store.add('%s/BatchNorm/beta' % scope, (k,), zeros, trainable=tr)
+            store.add(self.var(scope, 'beta'), (k,), zeros, trainable=tr)
         for scope, k, tr in self.layers:
-            store.add('%s/BatchNorm/moving_mean' % scope, (k,), zeros, trainable=False)
+            store.add(self.var(scope, 'moving_mean'), (k,), zeros, trainable=False)
         for scope, k, tr in self.layers:
-            store.add('%s/BatchNorm/moving_variance' % scope, (k,), ones, trainable=False)
+            store.add(self.var(scope, 'moving_variance'), (k,), ones, trainable=False)
 
     def bind(self, store):
         self.store = store
@@ -435,14 +440,14 @@ class BNTable(object):
             total = sum(k for _, k in ls)
 
             def region(kind):
-                first = '%s/BatchNorm/%s' % (ls[0][0], kind)
+                first = self.var(ls[0][0], kind)
                 is_tr, o, _ = store.offsets[first]
                 buf = store.flat if is_tr else store.frozen
                 return buf[o:o + total], (store.grad[o:o + total] if is_tr else None)
             gamma, ggamma = region('gamma')
             beta, gbeta = region('beta')
-            mean = torch.cat([store['%s/BatchNorm/moving_mean' % s].reshape(-1) for s, _ in ls])
-            var = torch.cat([store['%s/BatchNorm/moving_variance' % s].reshape(-1) for s, _ in ls])
+            mean = torch.cat([store[self.var(s, 'moving_mean')].reshape(-1) for s, _ in ls])
+            var = torch.cat([store[self.var(s, 'moving_variance')].reshape(-1) for s, _ in ls])
             rstd = torch.rsqrt(var + BN_EPS)
             scale = torch.empty(total, dtype=torch.float32, device=dev)
             shift = torch.empty(total, dtype=torch.float32, device=dev)
@@ -461,8 +466,8 @@ class BNTable(object):
         """Call after loading a checkpoint: moving statistics changed."""
         for grp in self.groups:
             ls = [(s, k) for s, k, t in self.layers if t == grp['trainable']]
-            var = torch.cat([self.store['%s/BatchNorm/moving_variance' % s].reshape(-1) for s, _ in ls])
-            grp['mean'].copy_(torch.cat([self.store['%s/BatchNorm/moving_mean' % s].reshape(-1) for s, _ in ls]))
+            var = torch.cat([self.store[self.var(s, 'moving_variance')].reshape(-1) for s, _ in ls])
+            grp['mean'].copy_(torch.cat([self.store[self.var(s, 'moving_mean')].reshape(-1) for s, _ in ls]))
             grp['rstd'].copy_(torch.rsqrt(var + BN_EPS))
         self.refresh(force=True)
 
@@ -604,6 +609,127 @@ class BottleneckNode(object):
         return dx
 
 
+class PreactLayer(object):
+    """A BatchNorm + ReLU that does not follow a convolution: `slim.batch_norm(inputs, activation_fn=tf.nn.relu,
+    scope='preact')` at the head of every slim resnet_v2 bottleneck (base_network.py:94-101 builds resnet_v2 through
+    tf.contrib.slim.nets.resnet_v2).  Variables `<scope>/{beta,gamma,moving_mean,moving_variance}` (no `BatchNorm`
+    level).  Inference: y = relu(x * scale + shift) with the folded moving statistics (lmh_bn_apply); training: the
+    statistics of the batch (lmh_bn_train_fwd / _bwd) — the reference hands `is_training` to every resnet_v2 BatchNorm."""
+    norm, act, k, stride, rate, padding = 'bn', 'relu', 0, 1, 1, 'SAME'
+    storage = compute = None
+    w_name = b_name = None
+    wd = 0.0
+
+    def __init__(self, scope, channels):
+        self.scope, self.cin, self.cout = scope, channels, channels
+        self.trainable = True
+        self.bn_train = False
+
+    def var_names(self):
+        return ['%s/beta' % self.scope, '%s/gamma' % self.scope]
+
+    def bind(self, store, bn_table):
+        self.store, self.bn_table = store, bn_table
+        self.bn = bn_table.views(self.scope)
+        self.bn_vars = tuple(store['%s/%s' % (self.scope, n)] for n in ('gamma', 'beta', 'moving_mean', 'moving_variance'))
+
+    def forward(self, x, want_bits=False):
+        if x.dtype != torch.float32:
+            raise NotImplementedError('%s: fp32 tensors only' % self.scope)
+        if self.bn_train:
+            gamma, beta, mm, mv = self.bn_vars
+            y, mean, rstd = K.bn_train_fwd(x, gamma, beta, mm, mv, None, 'relu', eps=BN_EPS, decay=BN_DECAY)
+            y._lmh_bn = (x, mean, rstd)
+            self.bn_table.stats_moved = True
+        else:
+            y = K.bn_apply(x, self.bn['scale'], self.bn['shift'], None, 'relu')
+        bits = K.act_bits(y, 'relu') if (want_bits and FUSE_MASK and K.act_bits_ok(self.cout, 'relu')) else None
+        if ACT_TAP is not None:
+            ACT_TAP[self.scope] = y
+        return (y, bits) if want_bits else y
+
+    def backward(self, x, y, g, need_dx, addend=None):
+        """g: gradient of the pre-activation (already masked by relu'(y)).  -> dx (+ addend) or None."""
+        if not (need_dx or self.trainable):
+            return None
+        gamma = self.bn_vars[0]
+        if self.trainable:
+            dgamma, dbeta = self.bn['ggamma'], self.bn['gbeta']
+        else:
+            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        kept = getattr(y, '_lmh_bn', None)
+        if kept is not None:
+            return K.bn_train_bwd(g, kept[0], kept[1], kept[2], gamma, dgamma, dbeta, addend=addend, need_dz=need_dx)
+        return K.bn_train_bwd(g, x, self.bn['mean'], self.bn['rstd'], gamma, dgamma, dbeta, addend=addend, frozen=True,
+                              need_dz=need_dx)
+
+
+class PreactBottleneckNode(object):
+    """slim resnet_v2.bottleneck: preact = relu(BN(x)); shortcut = subsample(x) | conv1x1(preact) + bias;
+    residual = conv1x1(preact) [BN, relu] -> conv3x3 conv2d_same(stride, rate) [BN, relu] -> conv1x1 + bias;
+    output = shortcut + residual (no activation: the next unit's preact applies it)."""
+    out_act = None
+
+    def __init__(self, scope, cin, depth, depth_bottleneck, stride, rate, wd, init):
+        p = scope + '/bottleneck_v2'
+        self.stride = stride
+        self.preact = PreactLayer(p + '/preact', cin)
+        self.shortcut = None
+        if depth != cin:
+            self.shortcut = ConvLayer(p + '/shortcut', cin, depth, 1, stride=stride, act=None, norm='bias', wd=wd, init=init)
+        self.conv1 = ConvLayer(p + '/conv1', cin, depth_bottleneck, 1, act='relu', wd=wd, init=init)
+        self.conv2 = ConvLayer(p + '/conv2', depth_bottleneck, depth_bottleneck, 3, stride=stride, rate=rate,
+                               padding='SAME' if stride == 1 else 'SAME_EXPLICIT', act='relu', wd=wd, init=init)
+        self.conv3 = ConvLayer(p + '/conv3', depth_bottleneck, depth, 1, act=None, norm='bias', wd=wd, init=init)
+        # TF creation order inside a unit: preact, shortcut, conv1, conv2, conv3
+        self.layers = [self.preact] + ([self.shortcut] if self.shortcut else []) + [self.conv1, self.conv2, self.conv3]
+
+    def out_hw(self, h, w):
+        return -(-h // self.stride), -(-w // self.stride)
+
+    @staticmethod
+    def out_bits(saved):
+        return None
+
+    def forward(self, x, save, out=None):
+        geom = None
+        pre, pbits = self.preact.forward(x, want_bits=True) if save else (self.preact.forward(x), None)
+        if self.shortcut is not None:
+            sc = self.shortcut.forward(pre)
+        elif self.stride > 1:
+            sc, geom = K.maxpool_fwd(x, 1, self.stride, 'VALID')   # resnet_utils.subsample(inputs)
+        else:
+            sc = x
+        if not save:
+            a = self.conv1.forward(pre)
+            b = self.conv2.forward(a)
+            return self.conv3.forward(b, residual=sc, out=out), None
+        a, ba = self.conv1.forward(pre, want_bits=True)
+        b, bb = self.conv2.forward(a, want_bits=True)
+        y = self.conv3.forward(b, residual=sc, out=out)
+        return y, (x, pre, pbits, sc, a, b, y, geom, ba, bb)
+
+    def backward(self, saved, dy, need_dx, dy_is_g=False, mask_bits=None):
+        x, pre, pbits, sc, a, b, y, geom, ba, bb = saved
+        d_b, _ = self.conv3.backward(b, y, dy, dy_is_g=True, mask_bits=bb)          # no activation on the sum: g = dy
+        d_a, _ = self.conv2.backward(a, b, d_b, dy_is_g=bb is not None, mask_bits=ba)
+        need_pre = need_dx or self.preact.trainable
+        d_pre_sc = None
+        if self.shortcut is not None:
+            d_pre_sc, _ = self.shortcut.backward(pre, sc, dy, need_dx=need_pre, dy_is_g=True)
+        g_pre, _ = self.conv1.backward(pre, a, d_a, need_dx=need_pre, addend=d_pre_sc, dy_is_g=ba is not None,
+                                       mask_bits=pbits if need_pre else None)
+        if not need_pre:
+            return None
+        if pbits is None:                          # channel count not a multiple of 32: the ReLU gradient as a pass
+            g_pre = K.act_bwd(g_pre, pre, 'relu', want_g=True)
+        d_x_sc = None                               # the shortcut's share of the gradient of x (identity / subsample)
+        if need_dx and self.shortcut is None:
+            d_x_sc = K.maxpool_bwd(x, sc, dy, 1, self.stride, geom) if self.stride > 1 else dy
+        dx = self.preact.backward(x, pre, g_pre, need_dx, addend=d_x_sc)
+        return K.apply_act_bits(dx, mask_bits) if (dx is not None and mask_bits is not None) else dx
+
+
 class Trunk(object):
     """Ordered nodes; nodes before `first_trainable` run forward-only."""
 
@@ -649,7 +775,7 @@ class Trunk(object):
         hook = BACKWARD_HOOK        # data-parallel gradient buckets (utils/training.py); None on one GPU
         if hook is not None:
             hook(nodes, len(nodes))
-        SideStream.layers_left = sum(1 for n in nodes for l in n.layers if l.trainable)
+        SideStream.layers_left = sum(1 for n in nodes for l in n.layers if l.trainable and isinstance(l, ConvLayer))
         for j in range(len(nodes) - 1, -1, -1):
             need_dx = (j > 0) or need_dx_first
             # node j-1's activation gradient is folded into node j's data gradient (bit mask in the bwd_data epilogue)

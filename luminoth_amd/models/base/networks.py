@@ -10,12 +10,15 @@ party, not in /root/reference — structure per SURVEY.md §8a-A2):
   atrous rate of block4 (stack_blocks_dense).
 slim vgg_16: 3x3 SAME conv + bias + ReLU, 2x2/2 VALID max-pools.
 """
-from .layers import BottleneckNode, ConvLayer, ConvNode, MaxPoolNode
+from .layers import BottleneckNode, ConvLayer, ConvNode, MaxPoolNode, PreactBottleneckNode, PreactLayer
 
 RESNET_UNITS = {
     'resnet_v1_50': (3, 4, 6, 3),
     'resnet_v1_101': (3, 4, 23, 3),
     'resnet_v1_152': (3, 8, 36, 3),
+    'resnet_v2_50': (3, 4, 6, 3),
+    'resnet_v2_101': (3, 4, 23, 3),
+    'resnet_v2_152': (3, 8, 36, 3),
 }
 _RGB_MEANS = (123.68, 116.78, 103.94)  # base_network.py:14-16
 
@@ -47,6 +50,39 @@ def resnet_v1_nodes(arch, scope, wd, init, output_stride=16, in_sub=None, up_to_
             cin = base_depth * 4
         endpoints['block%d' % (bi + 1)] = len(nodes) - 1
     return nodes, endpoints
+
+
+def resnet_v2_nodes(arch, scope, wd, init, bias_init, output_stride=16, in_sub=None, up_to_block=4):
+    """slim resnet_v2 (pre-activation): conv1 7x7/2 conv2d_same with a BIAS and neither BatchNorm nor activation
+    (arg_scope activation_fn=None, normalizer_fn=None) -> 3x3/2 SAME max-pool -> blocks of pre-activation bottlenecks (the
+    stride-2 unit is the last of a block; output_stride as in v1) -> `postnorm` BatchNorm + ReLU (after block4 only: not
+    on the path of the `block3` endpoint, returned as a layer to REGISTER so that its variables exist).
+    Returns (nodes, endpoints, unused_layers)."""
+    units = RESNET_UNITS[arch]
+    p = '%s/%s' % (scope, arch)
+    nodes, endpoints = [], {}
+    conv1 = ConvLayer(p + '/conv1', 3, 64, 7, stride=2, padding='SAME_EXPLICIT', act=None, norm='bias', wd=wd, init=init)
+    conv1.bias_init = bias_init
+    nodes.append(ConvNode(conv1, in_sub=in_sub))
+    nodes.append(MaxPoolNode(3, 2, 'SAME'))
+    current_stride, rate, cin = 4, 1, 64
+    for bi, (base_depth, n_units) in enumerate(zip((64, 128, 256, 512), units)):
+        if bi + 1 > up_to_block:
+            break
+        block_stride = 2 if bi < 3 else 1
+        for u in range(n_units):
+            unit_stride = block_stride if u == n_units - 1 else 1
+            if output_stride is not None and current_stride == output_stride:
+                stride, unit_rate = 1, rate
+                rate *= unit_stride
+            else:
+                stride, unit_rate = unit_stride, 1
+                current_stride *= unit_stride
+            nodes.append(PreactBottleneckNode('%s/block%d/unit_%d' % (p, bi + 1, u + 1), cin, base_depth * 4,
+                                              base_depth, stride, unit_rate, wd, init))
+            cin = base_depth * 4
+        endpoints['block%d' % (bi + 1)] = len(nodes) - 1
+    return nodes, endpoints, [PreactLayer(p + '/postnorm', cin)]
 
 
 def resnet_v1_tail_nodes(arch, scope, wd, init):

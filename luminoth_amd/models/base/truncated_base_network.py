@@ -64,6 +64,22 @@ class TruncatedBaseNetwork(BaseNetwork):
                 self.tail = L.Trunk(networks.resnet_v1_tail_nodes(arch, name, wd, he_normal))
             self.feat_channels = self.trunk.nodes[-1].conv3.cout
             self.tail_channels = 2048 if (self.tail is not None and self._use_tail) else self.feat_channels
+        elif self.resnet_v2_type:
+            # base_network.py:94-101: slim resnet_v2 (pre-activation bottlenecks); no pooled-ROI tail (the reference only
+            # builds one for resnet_v1_101, truncated_base_network.py:58)
+            nodes, endpoints, unused = networks.resnet_v2_nodes(arch, name, wd, he_normal, zeros,
+                                                                output_stride=config.get('output_stride'))
+            if self._endpoint not in endpoints:
+                raise ValueError('"{}" is an invalid value of endpoint for this architecture.'.format(
+                    '%s/%s/%s' % (name, arch, self._endpoint)))
+            cut = endpoints[self._endpoint] + 1
+            self._all_nodes = nodes
+            self.trunk = L.Trunk(nodes[:cut])
+            self._unused_nodes = nodes[cut:]
+            self._unused_layers = unused
+            self.tail = None
+            self.feat_channels = self.trunk.nodes[-1].conv3.cout
+            self.tail_channels = self.feat_channels
         elif self.vgg_type or self.truncated_vgg_type:
             nodes, endpoints = networks.vgg16_nodes(name, arch, wd, he_normal, zeros, in_sub=None)
             if self._endpoint not in endpoints:
@@ -104,9 +120,11 @@ class TruncatedBaseNetwork(BaseNetwork):
             if K_COMPUTE[self.compute_dtype] != K_COMPUTE[self.storage_dtype]:
                 raise ValueError('storage_dtype "{}" needs the same compute_dtype (got "{}")'.format(
                     self.storage_dtype, self.compute_dtype))
-            if not self.resnet_v1_type or (self.tail is not None and self._use_tail):
-                raise NotImplementedError('storage_dtype: implemented for the resnet_v1 trunks without the block4 tail '
-                                          '(BASELINE configs[4] is ResNet-50)')
+            if not self.resnet_v1_type:
+                raise NotImplementedError('storage_dtype: implemented for the resnet_v1 trunks (BASELINE configs[4] is '
+                                          'ResNet-50; VGG / SSD / resnet_v2 keep fp32 tensors)')
+            # ResNet-101 (round 4): the TRUNK keeps 16-bit tensors; the block4 tail runs on the fp32 ROI crops of the fp32
+            # feature map with the same 16-bit MFMA operands but fp32 tensors (conv_half.h) — its layers keep storage None
             nodes = self.trunk.nodes
             if not (isinstance(nodes[1], L.MaxPoolNode) and all(isinstance(n, L.BottleneckNode) for n in nodes[2:])):
                 raise NotImplementedError('storage_dtype: unexpected trunk structure')
@@ -147,6 +165,10 @@ class TruncatedBaseNetwork(BaseNetwork):
         self._trainable_names = tr
         tail_layers = {l.scope: l for l in (self.tail.all_layers() if self.tail else [])}
         for layer in self._creation_order_layers():
+            if isinstance(layer, L.PreactLayer):         # resnet_v2 `preact` / `postnorm`: a BatchNorm without a convolution
+                layer.trainable = ('%s/gamma' % layer.scope) in tr
+                self.bn_table.add(layer.scope, layer.cout, layer.trainable, prefix=layer.scope)
+                continue
             layer.trainable = layer.w_name in tr
             store.add(layer.w_name, (layer.k, layer.k, layer.cin, layer.cout), layer.init or he_normal,
                       trainable=layer.trainable, wd=layer.wd)
@@ -180,9 +202,10 @@ class TruncatedBaseNetwork(BaseNetwork):
         training and advances its moving averages; otherwise the frozen-statistics path.  Statistics are per process:
         under data parallelism every replica normalises with its own batch, like the reference's per-worker graphs.
         -> whether the training-mode path is on."""
-        on = bool(is_training and self._config.get('train_batch_norm'))
-        if on and not self.resnet_v1_type:
-            raise NotImplementedError('train_batch_norm: only the resnet_v1 networks have BatchNorm layers')
+        # resnet_v2: base_network.py:94-101 hands `is_training` itself to slim (not gated by train_batch_norm)
+        on = bool(is_training and (self._config.get('train_batch_norm') or self.resnet_v2_type))
+        if on and not self.resnet_type:
+            raise NotImplementedError('train_batch_norm: only the resnet networks have BatchNorm layers')
         for layer in self._creation_order_layers() + (self.tail.all_layers() if self.tail else []):
             layer.bn_train = on and layer.norm == 'bn'
         return on

@@ -418,7 +418,7 @@ class FasterRCNN(object):
         if bn._hs_layers:
             L.prepare_half_weights(bn._hs_layers + bn.extra_hs_layers, bn.storage_dtype)
         # (training-mode BatchNorm: the backward weights are NOT pre-scaled by a frozen BatchNorm scale: transformed per call)
-        wl = self._winograd_layers() if (WINO_BATCH and not self.base_network._config.get('train_batch_norm')) else []
+        wl = self._winograd_layers() if (WINO_BATCH and not any(l.bn_train for l in self.base_network.trunk.all_layers())) else []
         wino_bwd_side = None
         if wl:
             L.prepare_winograd_weights(wl, backward=False)

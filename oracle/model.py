@@ -26,7 +26,8 @@ from . import frcnn as of
 from . import rng
 from . import torch_ops as ot
 
-RESNET_UNITS = {'resnet_v1_50': (3, 4, 6, 3), 'resnet_v1_101': (3, 4, 23, 3), 'resnet_v1_152': (3, 8, 36, 3)}
+RESNET_UNITS = {'resnet_v1_50': (3, 4, 6, 3), 'resnet_v1_101': (3, 4, 23, 3), 'resnet_v1_152': (3, 8, 36, 3),
+                'resnet_v2_50': (3, 4, 6, 3), 'resnet_v2_101': (3, 4, 23, 3), 'resnet_v2_152': (3, 8, 36, 3)}
 MEANS = torch.tensor([123.68, 116.78, 103.94])   # models/base/base_network.py:14-16
 
 
@@ -130,9 +131,10 @@ class OracleFasterRCNN(object):
         """What the UPDATE_OPS of the step (train.py:87-88) leave in the moving statistics: v -= (v - batch) * (1 - decay)."""
         out = {}
         for scope, (mean, var) in self.bn_updates.items():
-            mm, mv = self.v[scope + '/BatchNorm/moving_mean'], self.v[scope + '/BatchNorm/moving_variance']
-            out[scope + '/BatchNorm/moving_mean'] = mm - (mm - mean) * (1.0 - decay)
-            out[scope + '/BatchNorm/moving_variance'] = mv - (mv - var) * (1.0 - decay)
+            pre = scope if (scope + '/moving_mean') in self.v else scope + '/BatchNorm'      # resnet_v2 keys are prefixes
+            mm, mv = self.v[pre + '/moving_mean'], self.v[pre + '/moving_variance']
+            out[pre + '/moving_mean'] = mm - (mm - mean) * (1.0 - decay)
+            out[pre + '/moving_variance'] = mv - (mv - var) * (1.0 - decay)
         return out
 
     def _bottleneck(self, x, scope, depth, stride, rate):
@@ -146,6 +148,36 @@ class OracleFasterRCNN(object):
                           padding='SAME' if stride == 1 else 'SAME_EXPLICIT')
         r = self._conv_bn(r, p + '/conv3', act=None)
         return self._activate(sc + r, 'relu', p + '/conv3')
+
+    # ---- slim resnet_v2 (pre-activation; base_network.py:94-101) ----------------------------------------------------
+    def _batch_norm(self, y, prefix):
+        """BatchNorm over variables `<prefix>/{gamma,beta,moving_mean,moving_variance}`: the statistics of the batch when
+        `train_bn` (the reference hands is_training to every resnet_v2 BatchNorm), else the moving ones."""
+        v = self.v
+        if self.train_bn:
+            mean = y.mean(dim=(0, 1, 2))
+            var = ((y - mean) ** 2).mean(dim=(0, 1, 2))
+            n = float(y.numel() // y.shape[-1])
+            self.bn_updates[prefix] = (mean.detach().clone(), (var * (n / max(n - 1.0, 1.0))).detach().clone())
+            return (y - mean) * torch.rsqrt(var + 1e-5) * v[prefix + '/gamma'] + v[prefix + '/beta']
+        return ot.frozen_batch_norm(y, v[prefix + '/gamma'], v[prefix + '/beta'], v[prefix + '/moving_mean'],
+                                    v[prefix + '/moving_variance'])
+
+    def _conv_bias(self, x, scope, stride=1, rate=1, padding='SAME'):
+        return ot.conv2d_nhwc(x, self.v[scope + '/weights'], stride, rate, padding) + self.v[scope + '/biases']
+
+    def _bottleneck_v2(self, x, scope, depth, stride, rate):
+        p = scope + '/bottleneck_v2'
+        pre = self._activate(self._batch_norm(x, p + '/preact'), 'relu', p + '/preact')
+        if x.shape[-1] == depth:
+            sc = x if stride == 1 else x[:, ::stride, ::stride, :]      # resnet_utils.subsample(inputs)
+        else:
+            sc = self._conv_bias(pre, p + '/shortcut', stride=stride)
+        r = ot.conv2d_nhwc(pre, self.v[p + '/conv1/weights'], 1, 1, 'SAME')
+        r = self._activate(self._batch_norm(r, p + '/conv1/BatchNorm'), 'relu', p + '/conv1')
+        r = ot.conv2d_nhwc(r, self.v[p + '/conv2/weights'], stride, rate, 'SAME' if stride == 1 else 'SAME_EXPLICIT')
+        r = self._activate(self._batch_norm(r, p + '/conv2/BatchNorm'), 'relu', p + '/conv2')
+        return sc + self._conv_bias(r, p + '/conv3')
 
     def vgg_backbone(self, image):
         """slim vgg_16 up to conv5/conv5_3 (truncated_base_network.py:8-16): 3x3 SAME conv + bias + ReLU,
@@ -166,7 +198,11 @@ class OracleFasterRCNN(object):
         if self.arch == 'vgg_16':
             return self.vgg_backbone(image)
         x = image - MEANS.to(self.dtype)
-        x = self._conv_bn(x, self.base + '/conv1', stride=2, padding='SAME_EXPLICIT')
+        v2 = self.arch.startswith('resnet_v2')
+        if v2:       # root: conv2d_same with a bias, no BatchNorm, no activation
+            x = self._conv_bias(x, self.base + '/conv1', stride=2, padding='SAME_EXPLICIT')
+        else:
+            x = self._conv_bn(x, self.base + '/conv1', stride=2, padding='SAME_EXPLICIT')
         x = ot.max_pool_nhwc(x, 3, 2, 'SAME')
         if self.storage:
             x = ot._q(x, self.storage)          # the pool writes the first 16-bit tensor of the trunk
@@ -186,6 +222,8 @@ class OracleFasterRCNN(object):
                 if self.storage:
                     top = bi + 1 == last_block and u == n - 1          # the feature map is handed on as fp32
                     x = self._bottleneck_hs(x, '%s/block%d/unit_%d' % (self.base, bi + 1, u + 1), depth, s, r, out_f32=top)
+                elif v2:
+                    x = self._bottleneck_v2(x, '%s/block%d/unit_%d' % (self.base, bi + 1, u + 1), depth, s, r)
                 else:
                     x = self._bottleneck(x, '%s/block%d/unit_%d' % (self.base, bi + 1, u + 1), depth, s, r)
         return x

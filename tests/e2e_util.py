@@ -43,7 +43,9 @@ def condition_like_pretrained(model, arch):
     1e-4 comparison would measure the conditioning of the synthetic weights, not the kernels.  ResNet: conv1's frozen
     BatchNorm variance = pixel variance x fan-in gain; VGG (no BN): conv1_1 weights / pixel std."""
     sd = model.state_dict()
-    if arch.startswith('resnet'):
+    if arch.startswith('resnet_v2'):     # the root convolution has no BatchNorm: scale its weights by the pixel std instead
+        sd['truncated_base_network/%s/conv1/weights' % arch].mul_(1.0 / 73.6)
+    elif arch.startswith('resnet'):
         sd['truncated_base_network/%s/conv1/BatchNorm/moving_variance' % arch].fill_(73.6 ** 2 * 2)
         if arch != 'resnet_v1_50':      # 33 residual adds: keep the deep trunk O(1) (bench.py does the same)
             for k in sd:
@@ -99,7 +101,7 @@ def run_step_with_tap(model, images, gts, fused=False):
 
 def compare_step_with_oracle(model, images, gts, num_classes, arch='resnet_v1_50', oracle_kwargs=None,
                              check_grads=True, min_checked=100, out_tol=1e-4, loss_tol=1e-4, grad_tight=2e-4,
-                             grad_max=1e-3, stats=None, fused=False):
+                             grad_max=1e-3, stats=None, fused=False, grad_floor_rel=0.0):
     """out_tol / loss_tol / grad_tight / grad_max: the fp32 bounds by default; the mixed-precision tests pass theirs
     (stated in tests/test_gpu_half.py).  stats (dict, optional): filled with the errors actually observed."""
     B, H, W = images.shape[0], images.shape[1], images.shape[2]
@@ -179,12 +181,16 @@ def compare_step_with_oracle(model, images, gts, num_classes, arch='resnet_v1_50
     total.backward()
     grads = model.store.grads
     checked, worst = 0, (0.0, None)
+    # grad_floor_rel: tensors whose exact gradient is ZERO (a bias in front of a training-mode BatchNorm: adding a
+    # per-channel constant changes nothing downstream) hold nothing but rounding residue on both sides; their scale is
+    # floored at this fraction of the largest gradient in the network instead of at the residue itself
+    floor = grad_floor_rel * max([float(oracle.v[n].grad.abs().max()) for n in names if oracle.v[n].grad is not None] or [0.0])
     for n in names:
         g_ref = oracle.v[n].grad
         if g_ref is None:
             continue
         g = grads[n].cpu().numpy().reshape(g_ref.shape)
-        scale = max(1e-6, float(g_ref.abs().max()))
+        scale = max(1e-6, floor, float(g_ref.abs().max()))
         err = np.abs(g - g_ref.numpy())
         tight = err <= grad_tight * scale + 10 * grad_tight * np.abs(g_ref.numpy())
         if stats is not None:

@@ -114,9 +114,13 @@ def test_storage_dtype_key_selects_the_half_storage_layers():
         TruncatedBaseNetwork(C.Config({'architecture': 'resnet_v1_50', 'storage_dtype': 'f16', 'compute_dtype': 'bf16'}))
     with pytest.raises(NotImplementedError):      # VGG trunks / the R101 tail keep fp32 tensors
         TruncatedBaseNetwork(C.Config({'architecture': 'vgg_16', 'storage_dtype': 'f16'}))
-    with pytest.raises(NotImplementedError):
-        TruncatedBaseNetwork(C.get_config({'model': {'type': 'fasterrcnn', 'base_network': {
-            'storage_dtype': 'f16'}}}).model.base_network)
+    with pytest.raises(NotImplementedError):      # resnet_v2's stand-alone BatchNorm layers are fp32 only
+        TruncatedBaseNetwork(C.Config({'architecture': 'resnet_v2_50', 'storage_dtype': 'f16'}))
+    # round 4: ResNet-101 — the 33-unit trunk keeps 16-bit tensors, the block4 tail on the fp32 ROI crops keeps fp32 tensors
+    r101 = TruncatedBaseNetwork(C.get_config({'model': {'type': 'fasterrcnn', 'base_network': {
+        'architecture': 'resnet_v1_101', 'storage_dtype': 'f16'}}}).model.base_network)
+    assert len(r101._hs_layers) == 3 * 3 + 4 * 3 + 23 * 3 + 3 and r101.tail is not None
+    assert all(l.storage is None and l.compute == 'f16' for l in r101.tail.all_layers())
 
 
 def test_oracle_half_storage_layer_rounds_where_the_kernels_round():
