@@ -44,6 +44,7 @@ RPN_BWD_SIDE = os.environ.get('LUMINOTH_AMD_RPN_BWD_SIDE', 'auto')
 # where the next batch's frozen prefix runs: 'middle' = main stream while it waits for the RCNN branch (rounds 2-3);
 # 'side' / 'aux' = at the START of the step on the weight-gradient / proposal stream, under the trunk forward
 PREFIX_AT = os.environ.get('LUMINOTH_AMD_PREFIX_AT', 'middle')
+PREFIX_SPLIT = os.environ.get('LUMINOTH_AMD_PREFIX_SPLIT', '0') != '0'      # stem of the next batch right behind the RPN heads
 WINO_BATCH = os.environ.get('LUMINOTH_AMD_WINO_BATCH', '1') != '0'      # transformed Winograd weights of the whole step in two launches
 
 
@@ -457,6 +458,17 @@ class FasterRCNN(object):
         self._mark('trunk_fwd_done')
         rpn_pred, rpn_ctx = rpn.heads_fwd(feat)
         self._mark('rpn_heads_done')
+        # Experiment (LUMINOTH_AMD_PREFIX_SPLIT=1, off): the next batch's stem (conv1 + max-pool) HERE, while only the small
+        # kernels of the proposal chain are in flight — its 62 KB of LDS per block do not fit beside the 96-131 KB blocks
+        # of the RPN weight gradient / ROI pooling that fill every CU a moment later, and a kernel that arrives then
+        # waits until those grids are fully dispatched (the stem starts ~200 us after the kernel in front of it).
+        # Measured: fp32 7.01 -> 6.99 ms (noise), f16 4.20 -> 4.30 ms (the stem then delays the RPN backward and slows the
+        # proposal chain, which bounds the f16 step) — rejected
+        split_prefix = (produce and start > 2 and PREFIX_AT == 'middle' and PREFIX_SPLIT)
+        stem_out = None
+        if split_prefix:
+            stem_out, _ = self._sub_trunk(0, 2).forward(S['images'][1 - p], save_from=None)
+            self._mark('next_stem_done')
         # Host enqueue order matters while the host is not far ahead of the GPU (eager steps): the proposal chain is
         # ONE C call (cheap to enqueue, long to run), so it goes first; then the RPN branch of the main stream; the
         # RCNN part of the aux stream last (it cannot start before the NMS finishes anyway).
@@ -507,7 +519,10 @@ class FasterRCNN(object):
         # ---- the main stream has nothing left but to wait for the RCNN branch: the slot for the frozen trunk prefix of
         # the NEXT step's images (conv1 + fixed blocks: nothing this step's update writes)
         if produce and start > 0 and not (PREFIX_AT in ('side', 'aux') and SideStream.enabled):
-            self._sub_trunk(0, start).forward(S['images'][1 - p], save_from=None, out=S['prefix'][1 - p])
+            if split_prefix:
+                self._sub_trunk(2, start).forward(stem_out, save_from=None, out=S['prefix'][1 - p])
+            else:
+                self._sub_trunk(0, start).forward(S['images'][1 - p], save_from=None, out=S['prefix'][1 - p])
             self._mark('next_prefix_done')
         # ---- join (the wait captures the aux stream as of NOW: what is queued there below does not delay the trunk backward)
         K.stream_wait(main, aux)
