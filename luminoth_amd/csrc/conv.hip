@@ -233,9 +233,10 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
     LMH_CHECK_LAUNCH();
     return LMH_OK;
   }
-  if (!fast && !d->compute && d->R == 1 && d->S == 1 && d->stride == 1 && d->K <= 128 && (d->C & 3) == 0 &&
+  if (!fast && d->R == 1 && d->S == 1 && d->stride == 1 && d->K <= 128 && (d->C & 3) == 0 &&
       !in_sub && M <= 4096 && (size_t)d->C * 8 <= 64 * 1024) {
-    // skinny Linear / 1x1 head (e.g. the 81-wide RCNN classifier): vector-ALU kernel out of LDS (conv_generic.h)
+    // skinny Linear / 1x1 head (e.g. the 81-wide RCNN classifier): vector-ALU kernel out of LDS (conv_generic.h); shapes
+    // off the MFMA fast paths run fp32 whatever `compute` says (like the predicated kernels they replace)
     prof_begin(st);
     lmh_launch(k_skinny_fwd, dim3((unsigned)((M + 1) / 2)), dim3(256), (unsigned)((size_t)d->C * 8), st, x, w, scale, shift,
                residual, y, (int)M, d->C, d->K, d->act);
@@ -325,7 +326,7 @@ static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const
     LMH_CHECK_LAUNCH();
     return LMH_OK;
   }
-  if (!fast && !d->compute && !yact && d->R == 1 && d->S == 1 && d->stride == 1 && d->K <= 64 && (d->K & 3) == 0 &&
+  if (!fast && !yact && d->R == 1 && d->S == 1 && d->stride == 1 && d->K <= 64 && (d->K & 3) == 0 &&
       (d->C & 3) == 0) {
     // skinny 1x1 head (24 / 48 output channels of the RPN): vector-ALU kernel out of LDS, addend + bit mask fused
     static bool attr = false;

@@ -323,8 +323,11 @@ class FasterRCNN(object):
                  prefix=None, start=start)
         if 0 < start:
             ph, pw = L.Trunk(bn.trunk.nodes[:start]).out_hw(H, W)
-            last = bn.trunk.nodes[start - 1]
-            ch = last.conv3.cout if hasattr(last, 'conv3') else last.layer.cout
+            ch = None
+            for node in bn.trunk.nodes[start - 1::-1]:          # channels of the prefix output: the last convolution in it
+                if hasattr(node, 'conv3') or hasattr(node, 'layer'):
+                    ch = node.conv3.cout if hasattr(node, 'conv3') else node.layer.cout
+                    break
             pdt = torch.float32
             if bn.storage_dtype in ('f16', 'bf16') and start > 1:
                 pdt = K.half_type(bn.storage_dtype)[1]
@@ -434,7 +437,7 @@ class FasterRCNN(object):
             early = SideStream.get(self.device) if PREFIX_AT == 'side' else aux
             K.stream_wait(early, main)
             with torch.cuda.stream(early):
-                self._sub_trunk(0, start).forward(S['images'][1 - p], save_from=None, out=S['prefix'][1 - p])
+                self._prefix_forward(0, start, S['images'][1 - p], S['prefix'][1 - p])
                 self._mark('early:next_prefix_done')
         from luminoth_amd.utils import training as _tr
         # the aux stream is idle once the RCNN branch is done: weight-gradient tails of the trunk backward are finished
@@ -448,7 +451,7 @@ class FasterRCNN(object):
             if have_pf:
                 x0 = S['prefix'][p]
             else:
-                x0, _ = self._sub_trunk(0, start).forward(image, save_from=None, out=S['prefix'][p])
+                x0 = self._prefix_forward(0, start, image, S['prefix'][p])
         saved = None
         if start < len(nodes):
             feat, saved = self._sub_trunk(start, len(nodes)).forward(x0, save_from=0)
@@ -520,9 +523,9 @@ class FasterRCNN(object):
         # the NEXT step's images (conv1 + fixed blocks: nothing this step's update writes)
         if produce and start > 0 and not (PREFIX_AT in ('side', 'aux') and SideStream.enabled):
             if split_prefix:
-                self._sub_trunk(2, start).forward(stem_out, save_from=None, out=S['prefix'][1 - p])
+                self._prefix_forward(2, start, stem_out, S['prefix'][1 - p])
             else:
-                self._sub_trunk(0, start).forward(S['images'][1 - p], save_from=None, out=S['prefix'][1 - p])
+                self._prefix_forward(0, start, S['images'][1 - p], S['prefix'][1 - p])
             self._mark('next_prefix_done')
         # ---- join (the wait captures the aux stream as of NOW: what is queued there below does not delay the trunk backward)
         K.stream_wait(main, aux)
@@ -563,6 +566,16 @@ class FasterRCNN(object):
         pred = {'rpn_prediction': rpn_pred, 'classification_prediction': cp, 'rpn_loss_dict': rpn_losses,
                 'rcnn_loss_dict': rcnn_losses, '_batch': {'B': B, 'unbatched': False}}
         return total_loss, pred, losses
+
+    def _prefix_forward(self, lo, hi, x, out):
+        """Nodes [lo, hi) of the trunk forward-only into the fixed-address buffer `out`: written by the last node itself
+        when it is a convolution, copied there when it is a pooling node (VGG: the frozen prefix ends in pool2)."""
+        sub = self._sub_trunk(lo, hi)
+        if isinstance(sub.nodes[-1], L.MaxPoolNode):
+            y, _ = sub.forward(x, save_from=None)
+            return K.copy_(out, y)
+        y, _ = sub.forward(x, save_from=None, out=out)
+        return y
 
     def _sub_trunk(self, lo, hi):
         c = getattr(self, '_sub_trunks', None)
