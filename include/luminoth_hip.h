@@ -43,7 +43,7 @@ typedef void* lmh_stream_t; /* hipStream_t */
 
 /* Tuning options (process global; defaults are the measured best on MI355X).  Names: bd_parity_small, half_pf,
  * x3_tile_slots, x3_pf, x3_pf_fwd, x3_pf_gb, x3_pf_bd, x3_pf_bw, bd_slots, bw_slots, wgrad_glds, wg_slots, wino_m,
- * hs_slab_cap, roi_cs, roi_mean_cs (csrc/api.hip documents each).  Unknown name: LMH_ERR_INVALID. */
+ * hs_slab_cap, nms_stage_mult, roi_cs, roi_mean_cs (csrc/api.hip documents each).  Unknown name: LMH_ERR_INVALID. */
 int lmh_set_option(const char* name, int value);
 int lmh_get_option(const char* name, int* value);
 

@@ -221,6 +221,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own libamdhip64; loaded before this library, the dynamic linker binds ours to the same
+    # runtime instance.  The other order puts two HIP runtimes into the process and ours sees no device ("no ROCm-capable
+    # device is detected" at the first launch) — met when build() and smoke() ran in one process.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise LuminothHipError(
             'libluminoth_hip.so not found at %s — run `python -c "import __graft_entry__ as g; '

@@ -374,7 +374,11 @@ static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const
 // smallest one (>= 16 stages per block) that fills the 512 resident-block slots to >= 90 %.
 static void bwd_weight_plan(const lmh_conv_desc* d, int* bm, int* bn, int* splits, int* kt_per_split) {
   const int64_t t128 = (int64_t)d->R * d->S * ((d->C + 127) / 128) * ((d->K + 127) / 128);
-  if (t128 >= 128 && d->C >= 128 && d->K >= 128) { *bm = 128; *bn = 128; }
+  // the 36 stacked reduction GEMMs of a Winograd weight gradient (dilation 0: conv_winograd.h) are not split, so 128x128
+  // tiles only pay once two of them per CU exist (block3 256x256: 144 tiles, 70.0 us at 128x128 against 57.5 at 64x64;
+  // RPN 1024x512: 1152 tiles, 254 against 242 — scripts/sweep_wino_tiles.py)
+  const int64_t need128 = d->dilation == 0 ? 2048 : 128;
+  if (t128 >= need128 && d->C >= 128 && d->K >= 128) { *bm = 128; *bn = 128; }
   else { *bm = 64; *bn = 64; }
   // half-precision operands: the kernel is bound by its staging path, 128x128 tiles halve the bytes per FLOP
   if (d->compute && d->C >= 128 && d->K >= 128) { *bm = 128; *bn = 128; }

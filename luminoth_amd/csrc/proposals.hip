@@ -7,6 +7,7 @@
 // bit-mask tiles (one u64 word per lane) and a wave-serial greedy reduce.
 #include <stdlib.h>
 #include "lmh_common.h"
+int lmh_opt(const char* name);   // api.hip: the lmh_set_option registry
 
 // ----------------------------------------------------------------------------
 // 1. decode + clip + validity + sort key   (one thread per anchor)
@@ -215,15 +216,17 @@ k_gather_topk(const uint64_t* __restrict__ keys, const float4* __restrict__ boxe
 //    suppressed iff IoU > thr (strict), never when either area <= 0.
 //    Phase 1: 64x64 suppression bit tiles (upper triangle); phase 2: greedy reduce, one block per image.
 //
-//    Two STAGES (round 4).  Rounds 1-3 built the whole K x K mask first: 72 M IoUs per image at 12 000 candidates, 137 us of
-//    vector-ALU work on the whole chip — but the scan stops after max_out keeps, on anchor-like boxes after ~5 000
-//    candidates (scripts/bench_nms.py), and never looks at the rest.  Stage A = mask + reduce over the first
-//    R1 = 3 max_out (rounded up to a super-chunk) candidates only: 19 M IoUs.  Stage B = the rest of the mask and of the
-//    scan; both of its launches return at once when stage A ended with `done` (the common case), and do exactly the
-//    remaining work of the one-stage version otherwise.  Same decisions, bit for bit.  (A version with one pair of
-//    launches per 1024-candidate super-chunk — only the rows actually kept x the columns actually reached — did 10x
-//    fewer IoUs still, but its 24 small dependent launches each queued behind the resident MFMA grids of the other
-//    streams: the proposal chain got 0.67 ms LONGER inside the step; deleted.)
+//    Optional two STAGES (round 4; lmh_set_option("nms_stage_mult", m), default 0 = one stage).  The scan stops after
+//    max_out keeps and never looks at the rest of the K x K mask (72 M IoUs per image at 12 000 candidates, ~120 us of
+//    vector-ALU work on the whole chip).  Stage A = mask + scan of the first m x max_out candidates, stage B = the rest;
+//    both launches of B return at once when A ended with `done`.  Same decisions, bit for bit.  On anchor-like boxes
+//    (scripts/bench_nms.py: 2000 keeps inside the first 5 000 candidates) m = 3 takes the pair from 254 to 183 us alone;
+//    inside the train step of a randomly initialised network the scan needs MORE than 6 000 candidates, both stages run,
+//    and the step is 0.05-0.07 ms SLOWER (fp32 6.95 -> 7.00-7.02 ms, f16 4.21 -> 4.23, A/B on one box,
+//    scripts/r4_exp5.sh) — hence off by default; a trained RPN (sharper scores) is the case it is kept for.
+//    (A finer version, one pair of launches per 1024-candidate super-chunk computing only the kept rows x the columns
+//    reached — 10x fewer IoUs — put 24 small dependent launches on the proposal stream, each queued behind the resident
+//    MFMA grids of the other streams: the chain got 0.67 ms LONGER inside the step; deleted.)
 // ----------------------------------------------------------------------------
 struct nms_state { int32_t total, done; };
 
@@ -434,7 +437,8 @@ int lmh_nms_impl(const float* boxes, const int32_t* counts, int B, int K, float 
   const float4* b4 = reinterpret_cast<const float4*>(boxes);
   // stage A: the first R1 candidates (whole super-chunks); stage B: the rest, skipped on the device when A was enough
   const int nsc_all = (W + NMS_SC_WORDS - 1) / NMS_SC_WORDS;
-  int sc1 = (3 * max_out + 64 * NMS_SC_WORDS - 1) / (64 * NMS_SC_WORDS);
+  const int mult = lmh_opt("nms_stage_mult");        // stage A covers mult x max_out candidates; 0: one stage (rounds 1-3)
+  int sc1 = mult > 0 ? (mult * max_out + 64 * NMS_SC_WORDS - 1) / (64 * NMS_SC_WORDS) : nsc_all;
   if (sc1 < 1) sc1 = 1;
   if (sc1 > nsc_all) sc1 = nsc_all;
   const int W1 = sc1 * NMS_SC_WORDS < W ? sc1 * NMS_SC_WORDS : W;
