@@ -1,0 +1,21 @@
+R=$GRAFT_REPO_ROOT
+cd $R
+python -m pytest tests/test_gpu_kernels.py tests/test_gpu_ref_tf_golden.py -x -q -m gpu -k "proposal or sort or nms" 2>&1 | tail -n 3
+B="python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-other-configs --no-roofline --phases 20"
+B5="python bench.py --workload frcnn_r50_coco --dtype f16 --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --phases 20"
+for v in $1; do
+  for rep in 1 2; do
+  env $v $B > /tmp/o.json 2>/dev/null
+  python - /tmp/o.json "$v" <<'P'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); p=d['phases_ms']
+print('f32', sys.argv[2], '%.3f ms' % d['ms_per_step'], 'proposals %.3f' % (p['aux:proposals_done']-p['rpn_heads_done']), 'rcnn %.3f' % (p['aux:rcnn_bwd_done']-p['aux:proposals_done']), 'join %.3f' % p['joined'], 'prefix %.3f' % p['next_prefix_done'])
+P
+  env $v $B5 > /tmp/o.json 2>/dev/null
+  python - /tmp/o.json "$v" <<'P'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); p=d['phases_ms']
+print('f16', sys.argv[2], '%.3f ms' % d['ms_per_step'], 'proposals %.3f' % (p['aux:proposals_done']-p['rpn_heads_done']), 'rcnn %.3f' % (p['aux:rcnn_bwd_done']-p['aux:proposals_done']), 'join %.3f' % p['joined'], 'prefix %.3f' % p['next_prefix_done'])
+P
+  done
+done
