@@ -305,6 +305,8 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
   // continues from `state` and returns at once when stage A finished the scan
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
   __shared__ __attribute__((aligned(16))) unsigned long long rem[NMS_SC_WORDS];
+  __shared__ unsigned long long s_keptm[NMS_SC_WORDS];   // kept mask of chunk c of the current super-chunk, once published
+  __shared__ int s_ready, s_folded[NMS_SC_WORDS];          // chunks published so far (-1: stop) / word j holds every earlier chunk's rows
   __shared__ int s_tot[NMS_SC_WORDS];          // running total AFTER chunk c of the current super-chunk (one slot per chunk:
                                                // no slot is rewritten before every wave has read it and passed a barrier)
   __shared__ int32_t s_kidx[NMS_LDS_KEEP];     // LDS mirror of the kept indices (one global latency less in (2))
@@ -346,30 +348,39 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
     if (tid < NMS_SC_WORDS) rem[tid] = 0ull;
     __syncthreads();
     const int nkept = total;
-    for (int i0 = tid; i0 < nkept * NMS_SC_WORDS; i0 += 4 * NMS_RED_THREADS) {
-      uint64_t v[4];
-      int wj[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * NMS_RED_THREADS;
-        wj[u] = i & (NMS_SC_WORDS - 1);
-        v[u] = 0ull;
-        if (i < nkept * NMS_SC_WORDS && wj[u] < nw) {
-          const int kr = lds_keep ? s_kidx[i / NMS_SC_WORDS] : kidx[i / NMS_SC_WORDS];
-          v[u] = mb[(size_t)kr * W + w0 + wj[u]];
+    {
+      // thread = (word wj of the super-chunk, 64 kept rows per pass): its loads are independent of each other (8 in flight),
+      // the OR stays in a register; lanes l, l+16, l+32, l+48 hold the same word and are folded before ONE atomic per wave
+      // and word (round 3: 4 loads per iteration, an LDS atomic per non-zero word: 6 us per super-chunk at 2000 kept rows)
+      const int wj = tid & (NMS_SC_WORDS - 1);
+      uint64_t accw = 0ull;
+      if (wj < nw) {
+#pragma unroll 8
+        for (int r = tid >> 4; r < nkept; r += NMS_RED_THREADS / NMS_SC_WORDS) {
+          const int kr = lds_keep ? s_kidx[r] : kidx[r];
+          accw |= mb[(size_t)kr * W + w0 + wj];
         }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (v[u]) atomicOr(&rem[wj[u]], (unsigned long long)v[u]);
+      uint32_t lo = (uint32_t)accw, hi = (uint32_t)(accw >> 32);
+      lo |= __shfl_xor(lo, 16); hi |= __shfl_xor(hi, 16);
+      lo |= __shfl_xor(lo, 32); hi |= __shfl_xor(hi, 32);
+      accw = ((uint64_t)hi << 32) | lo;
+      if (lane < NMS_SC_WORDS && accw) atomicOr(&rem[lane], (unsigned long long)accw);
     }
     __syncthreads();
-    // (3) the chunks of this super-chunk, resolved back to back by ONE wave out of LDS — no block barrier per chunk (round 3:
-    //     16 barriers of a 1024-thread block per super-chunk were most of what was left of this kernel)
-    bool done = false;
+    // (3) the 16 chunks of this super-chunk.  Wave 0 resolves them in order; wave j (1..15) owns word j: as soon as the kept
+    //     mask of chunk c < j is published it folds the kept rows' word j into rem[j], so that wave 0 finds rem[c + 1]
+    //     complete one LDS hand-shake after it published chunk c (round 3: the kept lanes of wave 0 themselves walked
+    //     the later words, up to 15 dependent LDS reads + atomics per chunk: 0.7 us per chunk).  All 16 waves of the block
+    //     are resident, so the spin-waits cannot deadlock; `s_ready` = chunks published, -1 = stop.
+    if (tid == 0) s_ready = 0;
+    if (tid < NMS_SC_WORDS) s_folded[tid] = 0;
+    __syncthreads();
     if (wave == 0) {
       int tot = total;
       for (int c = 0; c < nw; ++c) {
+        if (c > 0)
+          while (*reinterpret_cast<volatile int*>(&s_folded[c]) == 0) __builtin_amdgcn_s_sleep(1);
         const int rl = c * 64 + lane;                       // this lane's row inside the super-chunk
         const uint64_t diag = sdT[c * NMS_RED_THREADS + rl];
         const int nin = min(64, cnt - (w0 + c) * 64);
@@ -393,23 +404,40 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
         const int room = max_out - tot;
         if (__popcll(kept) > room)                      // the scan stops at max_out: keep the first `room` of them
           kept = __ballot(((kept >> lane) & 1ull) && __popcll(kept & below) < room);
+        if (lane == 0) {                                // publish: the folding waves pick the kept rows of this chunk up
+          s_keptm[c] = kept;
+          __threadfence_block();
+          *reinterpret_cast<volatile int*>(&s_ready) = c + 1;
+        }
         if ((kept >> lane) & 1ull) {
           const int slot = tot + __popcll(kept & below);
           kidx[slot] = (w0 + c) * 64 + lane;              // kept indices, in order
           if (lds_keep) s_kidx[slot] = (w0 + c) * 64 + lane;
-          for (int j = c + 1; j < nw; ++j) {              // suppress later candidates of this super-chunk
-            const uint64_t v = sdT[j * NMS_RED_THREADS + rl];
-            if (v) atomicOr(&rem[j], (unsigned long long)v);
-          }
         }
         tot += __popcll(kept);
         if (tot >= max_out) break;
       }
-      if (lane == 0) s_tot[0] = tot;
+      if (lane == 0) {
+        s_tot[0] = tot;
+        __threadfence_block();
+        *reinterpret_cast<volatile int*>(&s_ready) = -1;   // release whoever still waits (early stop at max_out)
+      }
+    } else if (wave < nw) {
+      const int j = wave;                                  // this wave's word
+      for (int c = 0; c < j; ++c) {
+        const uint64_t v = sdT[j * NMS_RED_THREADS + c * 64 + lane];     // row (c, lane)'s word j: fetched before the wait
+        int rdy;
+        while ((rdy = *reinterpret_cast<volatile int*>(&s_ready)) >= 0 && rdy <= c) __builtin_amdgcn_s_sleep(1);
+        if (rdy < 0) break;          // wave 0 is done with this super-chunk (max_out reached, or its end): rem[] is dead
+        const uint64_t k = *reinterpret_cast<volatile unsigned long long*>(&s_keptm[c]);
+        if (((k >> lane) & 1ull) && v) atomicOr(&rem[j], (unsigned long long)v);
+      }
+      __threadfence_block();         // this wave's LDS atomics are done before the flag is
+      if (lane == 0) *reinterpret_cast<volatile int*>(&s_folded[j]) = 1;
     }
     __syncthreads();
     total = s_tot[0];
-    done = total >= max_out;
+    const bool done = total >= max_out;
     if (done) break;
     // the kept indices written above are read back (kidx) by the next super-chunk's gather: same block, global memory
     __threadfence_block();
