@@ -140,7 +140,7 @@ def test_resnet_v2_matches_oracle(fused):
 def test_free_running_agreement_at_benchmark_shape():
     """the step comparison is teacher-forced stage by stage.  Here the oracle runs FREE on its own
     upstream outputs at the benchmark shape; reported (printed) and bounded: the proposal lists and the sampled ROI sets
-    must coincide almost everywhere (near-ties of scores at the last bit may reorder a few), every loss within 1e-3."""
+    must coincide almost everywhere (near-ties of scores at the last bit may reorder a few), every loss within 1e-4."""
     from luminoth_amd.models import get_model
     import bench
     cfg = make_config()
@@ -157,11 +157,12 @@ def test_free_running_agreement_at_benchmark_shape():
     note('free_running@2x1024x1024/sampled_roi_set_mismatch', 1.0 - min(rep['roi_set']), 0.05)
     assert min(rep['same_set']) >= 0.98 and min(rep['roi_set']) >= 0.95
     for k, (got, ref) in rep['losses'].items():
-        # RPN losses see no discrete decision of the free run (anchor targets depend on gt only): the fp32 bound 1e-4.
-        # RCNN losses are means over the SAMPLED ROI set: a proposal pair within an ulp of the NMS threshold, or two
-        # scores equal to the last bit, swaps a few of the 256 ROIs of an image (roi_set above: the count), and each
-        # swapped ROI moves the mean by up to |loss_i| / 256 — bounded at 1e-3, the observed value is recorded
-        tol = 1e-4 if k.startswith('rpn') else 1e-3
+        # north_star's 1e-4 on every loss of the free run (round 3 allowed 1e-3).  RPN losses see no discrete decision of
+        # the free run (anchor targets depend on gt only: observed 6e-8); RCNN losses are means over the SAMPLED ROI set —
+        # a proposal pair within an ulp of the NMS threshold, or two scores equal to the last bit, swaps a few of the 256
+        # ROIs of an image (observed: 3 % of the sampled set, 1.7 % of the proposal set) and each swapped ROI moves the
+        # mean by |loss_i - loss_j| / 256: observed 2.1e-5 (profiles/r04_parity_observed.json)
+        tol = 1e-4
         note('free_running@2x1024x1024/loss:' + k, abs(got - ref) / max(1.0, abs(ref)), tol)
         assert abs(got - ref) <= tol * max(1.0, abs(ref)), (k, got, ref)
 
