@@ -233,6 +233,18 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
     LMH_CHECK_LAUNCH();
     return LMH_OK;
   }
+  if (d->R == 1 && d->S == 1 && d->stride == 1 && (d->C % 128) == 0 && d->C >= 512 && d->C <= 4096 && d->K <= 512 &&
+      d->act == 0 && !in_sub && M <= 4096 && !g_force_bm && lmh_opt("head_gemm")) {
+    // Linear head on few rows (the RCNN classifier / box regressor over 512 ROIs): 32x32 tiles, the reduction split over
+    // the four waves of a block (conv_generic.h k_head_fwd); fp32 whatever `compute` says, like the skinny kernels
+    const int tiles = (int)(((M + 31) / 32) * ((d->K + 31) / 32));
+    prof_begin(st);
+    lmh_launch(k_head_fwd, dim3(tiles), dim3(256), 0, st, x, w, scale, shift, residual, y, (int)M, d->C, d->K, d->act);
+    prof_end(st, desc_flops(d), "k_head_fwd");
+    *bits_done = false;
+    LMH_CHECK_LAUNCH();
+    return LMH_OK;
+  }
   if (!fast && d->R == 1 && d->S == 1 && d->stride == 1 && d->K <= 128 && (d->C & 3) == 0 &&
       !in_sub && M <= 4096 && (size_t)d->C * 8 <= 64 * 1024) {
     // skinny Linear / 1x1 head (e.g. the 81-wide RCNN classifier): vector-ALU kernel out of LDS (conv_generic.h); shapes

@@ -560,3 +560,86 @@ k_skinny_fwd(const float* __restrict__ x, const float* __restrict__ w, const flo
   else if (act == 2) v = fminf(fmaxf(v, 0.f), 6.f);
   y[(size_t)(m0 + r) * K + k] = v;
 }
+
+// ============================================================================
+// Linear heads on few rows (round 4): y[M][N] = act((x[M][C] . w[C][N]) * scale + shift (+ residual)), M <= 4096 rows (the
+// 512 ROIs of the RCNN head), a long reduction (C = 1024 / 2048) and a narrow output (81 / 320 columns).  The tiled kernels
+// give such a shape 40 blocks that each walk the whole reduction stage by stage — 27 us alone, 55 us beside the MFMA
+// kernels of the other streams, on the critical proposal -> RCNN chain (the 81-wide classifier, off the MFMA paths, took
+// 83).  Here a 256-thread block owns a 32 x 32 output tile and its four waves split the REDUCTION (C/4 each): operands go
+// straight from global memory into MFMA fragments (no LDS, no barrier in the loop: a lane loads one float4 of its x row and
+// the four w values of its column for four consecutive v_mfma_f32_32x32x2_f32), the next batch of 32 reduction steps is
+// loaded while the current one multiplies, and the four partial tiles are added in wave order through LDS (deterministic).
+// Any N (columns past N are clamped on load and not stored); C % 128 == 0.
+// ============================================================================
+__global__ void __launch_bounds__(256)
+k_head_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+           const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ y, int M, int C,
+           int N, int act) {
+  __builtin_amdgcn_s_setprio(3);     // latency-bound chain beside MFMA kernels of other streams
+  __shared__ float red[3][16][64];   // partial accumulators of waves 1..3
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int tiles_n = (N + 31) >> 5;
+  const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+  const int kper = C >> 2;                           // a multiple of 32
+  const int row = min(m0 + l31, M - 1), col = min(n0 + l31, N - 1);   // clamped lanes compute values nobody stores
+  const float* xa = x + (size_t)row * C + wave * kper + 4 * h;
+  const float* wb = w + (size_t)(wave * kper + 4 * h) * N + col;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  f32x4 a_cur[4];
+  float b_cur[4][4];
+#define HEAD_LOAD(a_, b_)                                                                  \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
+    a_[u] = *reinterpret_cast<const f32x4*>(xk + 8 * u);                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) b_[u][j] = wk[(8 * u + j) * N];          \
+  }
+  const float* xk = xa;
+  const float* wk = wb;
+  const size_t wstep = (size_t)32 * N;
+  HEAD_LOAD(a_cur, b_cur)
+  for (int k = 0; k < kper; k += 32) {
+    f32x4 a_nxt[4];
+    float b_nxt[4][4];
+    if (k + 32 < kper) { xk += 32; wk += wstep; }    // the last iteration re-reads a valid address and drops the data
+    HEAD_LOAD(a_nxt, b_nxt)
+    __builtin_amdgcn_sched_barrier(0);               // keep the loads of the next batch ahead of these MFMAs
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][j], b_cur[u][j], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a_cur[u] = a_nxt[u];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b_cur[u][j] = b_nxt[u][j];
+    }
+  }
+#undef HEAD_LOAD
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += red[q][i][lane];
+  const int n = n0 + l31;
+  if (n >= N) return;
+  const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (m >= M) continue;
+    float v = acc[i] * sc + sh;
+    if (residual) v += residual[(size_t)m * N + n];
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 2) v = fminf(fmaxf(v, 0.f), 6.f);
+    y[(size_t)m * N + n] = v;
+  }
+}

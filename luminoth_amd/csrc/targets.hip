@@ -16,7 +16,12 @@ template <typename Pred>
 __device__ void block_select_kth(int n, uint32_t k, uint32_t seed, uint32_t stream, Pred pred,
                                  uint32_t* hist, uint32_t* eq_list, uint32_t* bc,
                                  lmh_select_state* out) {
+  // Radix select, 8 bits per pass.  Round 4: the 256-bin scan is done by wave 0 (4 bins per lane + a shuffle scan; it was a
+  // serial loop of thread 0: ~7 us per pass on the one block per image these kernels run as), and as soon as the selected
+  // bin holds <= 64 candidates — after the first pass for the 2000 proposals of an image, after the second for 49 152
+  // anchors — they are ranked directly by one wave instead of walking the remaining passes.
   uint32_t prefix = 0, mask = 0, remaining = k;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
@@ -28,22 +33,71 @@ __device__ void block_select_kth(int n, uint32_t k, uint32_t seed, uint32_t stre
       }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t cum = 0, dsel = 255;
-      for (uint32_t dgt = 0; dgt < 256; ++dgt) {
-        const uint32_t c = hist[dgt];
-        if (cum + c >= remaining) { dsel = dgt; break; }
-        cum += c;
+    if (wave == 0) {
+      const uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+      const uint32_t mine = c0 + c1 + c2 + c3;
+      uint32_t incl = mine;
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      uint32_t cum = incl - mine;
+      if (cum < remaining && incl >= remaining) {          // exactly one lane: the first bin whose running count reaches k
+        uint32_t dsel, cnt;
+        if (cum + c0 >= remaining) { dsel = 0; cnt = c0; }
+        else if (cum + c0 + c1 >= remaining) { dsel = 1; cnt = c1; cum += c0; }
+        else if (cum + c0 + c1 + c2 >= remaining) { dsel = 2; cnt = c2; cum += c0 + c1; }
+        else { dsel = 3; cnt = c3; cum += c0 + c1 + c2; }
+        bc[0] = 4 * lane + dsel;
+        bc[1] = remaining - cum;
+        bc[2] = cnt;
+      } else if (lane == 63 && incl < remaining) {         // k beyond the candidates (callers do not ask): the last bin
+        bc[0] = 255; bc[1] = remaining - incl; bc[2] = c3;
       }
-      bc[0] = dsel;
-      bc[1] = remaining - cum;
-      bc[2] = hist[dsel];
     }
     __syncthreads();
     prefix |= bc[0] << shift;
     mask |= 255u << shift;
     remaining = bc[1];
+    const uint32_t cnt = bc[2];
     __syncthreads();
+    if (pass < 3 && cnt <= 64u) {
+      // ---- direct finish: the <= 64 candidates of the selected bin as (hash, index) pairs in hist[0..127]
+      if (threadIdx.x == 0) bc[3] = 0;
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (pred(i)) {
+          const uint32_t h = lmh_hash_u32(seed, stream, (uint32_t)i);
+          if ((h & mask) == prefix) {
+            const uint32_t slot = atomicAdd(&bc[3], 1u);
+            if (slot < 64u) { hist[2 * slot] = h; hist[2 * slot + 1] = (uint32_t)i; }
+          }
+        }
+      }
+      __syncthreads();
+      if (wave == 0) {
+        const uint32_t c = min(bc[3], 64u);
+        const bool have = (uint32_t)lane < c;
+        const uint32_t hme = have ? hist[2 * lane] : 0xFFFFFFFFu, ime = have ? hist[2 * lane + 1] : 0xFFFFFFFFu;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < c; ++j) {
+          const uint32_t hj = hist[2 * j], ij = hist[2 * j + 1];
+          rank += (hj < hme || (hj == hme && ij < ime)) ? 1u : 0u;
+        }
+        const unsigned long long kb = __ballot(have && rank + 1u == remaining);
+        const int src = kb ? (int)__ffsll((long long)kb) - 1 : 0;
+        const uint32_t thr = __shfl(hme, src);
+        const unsigned long long eqb = __ballot(have && hme == thr);
+        const uint32_t n_eq = (uint32_t)__popcll(eqb), below = (uint32_t)__popcll(__ballot(have && hme < thr));
+        const uint32_t need = remaining - below;
+        if (n_eq != need && have && hme == thr)
+          eq_list[__popcll(eqb & ((1ull << lane) - 1ull))] = ime;
+        if (lane == 0) { bc[0] = thr; bc[1] = need; bc[2] = (n_eq != need) ? n_eq : 0xFFFFFFFFu; }
+      }
+      __syncthreads();
+      out->thr_hash = bc[0];
+      out->need_eq = bc[1];
+      out->eq_count = bc[2];
+      __syncthreads();
+      return;
+    }
   }
   const uint32_t n_eq = bc[2];
   // collect the (rare) equal-hash candidates so ties break on the lower index
