@@ -157,7 +157,11 @@ extern "C" int lmh_rpn_loss(const float* cls_score, const float* bbox_pred, cons
 // ---------------------------------------------------------------------------
 // RCNN loss: rows (B,R); a wave per row, lanes over classes.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(LOSS_THREADS)
+// 512 threads, not LOSS_THREADS: the batched loads below cost registers, and a 16-wave block that needs ~64 VGPRs per lane
+// waited up to 200 us for a CU with that much room beside the convolution blocks of the other streams (fp32 step); eight
+// waves place at once.
+#define RCNN_LOSS_THREADS 512
+__global__ void __launch_bounds__(RCNN_LOSS_THREADS)
 k_rcnn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_offsets,
             const float* __restrict__ labels, const float* __restrict__ targets, int B, int R, int C,
             float sigma2, float* __restrict__ per_image) {
@@ -299,7 +303,7 @@ extern "C" int lmh_rcnn_loss(const float* cls_score, const float* bbox_offsets, 
   LMH_CHECK_ARG(cls_score && bbox_offsets && labels && targets && losses && per_image);
   LMH_CHECK_ARG(B > 0 && R > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
-  lmh_launch(k_rcnn_loss, dim3(B), dim3(LOSS_THREADS), 0, st, cls_score, bbox_offsets, labels,
+  lmh_launch(k_rcnn_loss, dim3(B), dim3(RCNN_LOSS_THREADS), 0, st, cls_score, bbox_offsets, labels,
                      targets, B, R, C, sigma * sigma, per_image);
   if (d_cls_score || d_bbox_offsets)
     lmh_launch(k_rcnn_loss_grad, dim3((unsigned)(((int64_t)B * R + 3) / 4)), dim3(256), 0, st, cls_score,
