@@ -518,6 +518,32 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize('M,C,N', [(512, 1024, 81), (512, 1024, 320), (37, 2048, 81), (1000, 512, 1), (4096, 4096, 33),
+                                   (33, 1024, 512)])
+def test_linear_head_kernel(K, M, C, N):
+    """k_head_fwd (split-reduction MFMA kernel of the RCNN heads, rcnn.py:221-228): ragged row / column counts, one column,
+    the largest routed shape; against float64, and bit-identical to itself with the option that routes it off — the tiled
+    kernels — within fp32 round-off; integer data: exact, whatever the summation order."""
+    rs = np.random.RandomState(M + C + N)
+    x = rs.randn(1, 1, M, C).astype(F)
+    w = (rs.randn(1, 1, C, N) * np.sqrt(1.0 / C)).astype(F)
+    b = rs.randn(N).astype(F)
+    d = K.conv_desc(x.shape, w.shape, 1, 1, 'VALID', None)
+    y = K.conv2d_fwd(d, T(x), T(w), None, T(b)).cpu().numpy().reshape(M, N)
+    ref = x.reshape(M, C).astype(np.float64) @ w.reshape(C, N).astype(np.float64) + b
+    np.testing.assert_allclose(y, ref, rtol=1e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+    K.set_option('head_gemm', 0)
+    try:
+        y0 = K.conv2d_fwd(d, T(x), T(w), None, T(b)).cpu().numpy().reshape(M, N)
+    finally:
+        K.set_option('head_gemm', 1)
+    np.testing.assert_allclose(y, y0, rtol=1e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+    xi = rs.randint(-8, 9, size=x.shape).astype(F)
+    wi = rs.randint(-8, 9, size=w.shape).astype(F)
+    yi = K.conv2d_fwd(d, T(xi), T(wi)).cpu().numpy().reshape(M, N)
+    np.testing.assert_array_equal(yi, xi.reshape(M, C) @ wi.reshape(C, N))
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_fwd_bwd(K, case, monkeypatch):
     monkeypatch.setattr(K, 'WINOGRAD', False)      # the direct kernels are under test here (bit-identity checks)
