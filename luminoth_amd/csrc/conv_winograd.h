@@ -388,7 +388,10 @@ k_wino4_weight_batch(wino_weight_batch b) {
   else wino4_weight_fwd_body(b.w[j], b.C[j], b.K[j], b.u[j], idx);
 }
 
-// input: V[6a+b][tile][c] = (B^T d B)[a][b], d = the 6x6 patch at (4i-1, 4j-1), zero outside the image
+// input: V[6a+b][tile][c] = (B^T d B)[a][b], d = the 6x6 patch at (4i-1, 4j-1), zero outside the image.
+// All 36 loads are unconditional (out-of-image positions read the zero page) and issued before the first use: with the
+// `ok ? load : 0` form the compiler put every column's six loads behind a branch and a full s_waitcnt — seven serial
+// round trips of memory latency per thread in a kernel that has one wave per SIMD to hide them (round 4; ISA check).
 __global__ void __launch_bounds__(256)
 k_wino4_input(const float* __restrict__ x, int N, int H, int W, int C, float* __restrict__ V) {
   const int C2 = C >> 1, th = (H + 3) >> 2, tw = (W + 3) >> 2;
@@ -397,18 +400,25 @@ k_wino4_input(const float* __restrict__ x, int N, int H, int W, int C, float* __
   if (idx >= (int64_t)T * C2) return;
   const int c2 = (int)(idx % C2), tile = (int)(idx / C2);
   const int j = tile % tw, t1 = tile / tw, i = t1 % th, n = t1 / th;
+  f32x2 d[6][6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const int h = 4 * i - 1 + a;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const int ww = 4 * j - 1 + b;
+      const bool ok = (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W;
+      const float* p = ok ? x + ((size_t)(n * H + h) * W + ww) * C + 2 * c2 : lmh_zero_page;
+      d[a][b] = *reinterpret_cast<const f32x2*>(p);
+    }
+  }
   f32x2 t[6][6];
 #pragma unroll
   for (int b = 0; b < 6; ++b) {            // column b of the patch -> column b of B^T d
-    const int ww = 4 * j - 1 + b;
-    f32x2 d[6], u[6];
+    f32x2 col[6], u[6];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const int h = 4 * i - 1 + a;
-      const bool ok = (unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W;
-      d[a] = ok ? *reinterpret_cast<const f32x2*>(x + ((size_t)(n * H + h) * W + ww) * C + 2 * c2) : f32x2{0.f, 0.f};
-    }
-    w4_bt(d, u);
+    for (int a = 0; a < 6; ++a) col[a] = d[a][b];
+    w4_bt(col, u);
 #pragma unroll
     for (int a = 0; a < 6; ++a) t[a][b] = u[a];
   }
@@ -423,7 +433,12 @@ k_wino4_input(const float* __restrict__ x, int N, int H, int W, int C, float* __
   }
 }
 
-// output: y = act( (A^T m A) * scale + shift + extra ), 4x4 pixels per tile (+ activation bit masks, see k_conv_fwd)
+// output: y = act( (A^T m A) * scale + shift + extra ), 4x4 pixels per tile (+ activation bit masks, see k_conv_fwd).
+// EXTRA / BITS_IN: the residual (forward) or addend (backward data) rows and the input-mask words of the 16 pixels are
+// requested together with the 36 planes, before anything is used (pixels outside the image read the zero page): as
+// conditional loads inside the pixel loop each of them was a load + s_waitcnt vmcnt(0) of its own — up to 32 serial
+// round trips per thread in the backward-data direction (round 4; ISA check).
+template <bool EXTRA, bool BITS_IN>
 __global__ void __launch_bounds__(256)
 k_wino4_output(const float* __restrict__ Mo, int N, int H, int W, int K, const float* __restrict__ scale,
                const float* __restrict__ shift, const float* __restrict__ extra, float act_lo, float act_hi,
@@ -436,13 +451,31 @@ k_wino4_output(const float* __restrict__ Mo, int N, int H, int W, int K, const f
   const int j = tile % tw, t1 = tile / tw, i = t1 % th, n = t1 / th;
   const size_t plane = (size_t)T * K;
   const float* src = Mo + (size_t)tile * K + 2 * k2;
+  f32x2 m[6][6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) m[a][b] = *reinterpret_cast<const f32x2*>(src + (size_t)(6 * a + b) * plane);
+  f32x2 ex[EXTRA ? 4 : 1][EXTRA ? 4 : 1];
+  uint32_t bw[BITS_IN ? 4 : 1][BITS_IN ? 4 : 1];
+  if (EXTRA || BITS_IN) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bool in = 4 * i + a < H && 4 * j + b < W;
+        const size_t off = ((size_t)(n * H + 4 * i + a) * W + 4 * j + b) * K + 2 * k2;
+        if (EXTRA) ex[a][b] = *reinterpret_cast<const f32x2*>(in ? extra + off : lmh_zero_page);
+        if (BITS_IN) bw[a][b] = *(in ? bits_in + (off >> 5) : reinterpret_cast<const uint32_t*>(lmh_zero_page));
+      }
+  }
   f32x2 t[4][6];
 #pragma unroll
   for (int b = 0; b < 6; ++b) {
-    f32x2 m[6], u[4];
+    f32x2 col[6], u[4];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x2*>(src + (size_t)(6 * a + b) * plane);
-    w4_at(m, u);
+    for (int a = 0; a < 6; ++a) col[a] = m[a][b];
+    w4_at(col, u);
 #pragma unroll
     for (int a = 0; a < 4; ++a) t[a][b] = u[a];
   }
@@ -458,12 +491,12 @@ k_wino4_output(const float* __restrict__ Mo, int N, int H, int W, int K, const f
       if (4 * i + a >= H || 4 * j + b >= W) continue;     // uniform over the 16 lanes of a mask word (same tile)
       const size_t off = ((size_t)(n * H + 4 * i + a) * W + 4 * j + b) * K + 2 * k2;
       f32x2 v = o4[b] * sc + sh;
-      if (extra) v += *reinterpret_cast<const f32x2*>(extra + off);
+      if (EXTRA) v += ex[a][b];
       v.x = fminf(fmaxf(v.x, act_lo), act_hi);
       v.y = fminf(fmaxf(v.y, act_lo), act_hi);
       const size_t word = off >> 5;
-      if (bits_in) {
-        const unsigned two = bits_in[word] >> (2 * (k2 & 15));
+      if (BITS_IN) {
+        const unsigned two = bw[a][b] >> (2 * (k2 & 15));
         v.x = (two & 1u) ? v.x : 0.f;
         v.y = (two & 2u) ? v.y : 0.f;
       }
@@ -481,7 +514,8 @@ k_wino4_output(const float* __restrict__ Mo, int N, int H, int W, int K, const f
   }
 }
 
-// weight gradient: dM[6a+b][tile][k] = (A dY A^T)[a][b] of the 4x4 gradient tile (zero outside the image)
+// weight gradient: dM[6a+b][tile][k] = (A dY A^T)[a][b] of the 4x4 gradient tile (zero outside the image); loads
+// unconditional and up front, like k_wino4_input
 __global__ void __launch_bounds__(256)
 k_wino4_dy(const float* __restrict__ g, int N, int H, int W, int K, float* __restrict__ dM) {
   const int K2 = K >> 1, th = (H + 3) >> 2, tw = (W + 3) >> 2;
@@ -490,17 +524,22 @@ k_wino4_dy(const float* __restrict__ g, int N, int H, int W, int K, float* __res
   if (idx >= (int64_t)T * K2) return;
   const int k2 = (int)(idx % K2), tile = (int)(idx / K2);
   const int j = tile % tw, t1 = tile / tw, i = t1 % th, n = t1 / th;
+  f32x2 yv[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const bool ok = 4 * i + a < H && 4 * j + b < W;
+      const float* p = ok ? g + ((size_t)(n * H + 4 * i + a) * W + 4 * j + b) * K + 2 * k2 : lmh_zero_page;
+      yv[a][b] = *reinterpret_cast<const f32x2*>(p);
+    }
   f32x2 t[6][4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    f32x2 yv[4], u[6];
+    f32x2 col[4], u[6];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const bool ok = 4 * i + a < H && 4 * j + b < W;
-      yv[a] = ok ? *reinterpret_cast<const f32x2*>(g + ((size_t)(n * H + 4 * i + a) * W + 4 * j + b) * K + 2 * k2)
-                 : f32x2{0.f, 0.f};
-    }
-    w4_a(yv, u);
+    for (int a = 0; a < 4; ++a) col[a] = yv[a][b];
+    w4_a(col, u);
 #pragma unroll
     for (int a = 0; a < 6; ++a) t[a][b] = u[a];
   }
@@ -614,8 +653,14 @@ static int wino_run(const lmh_conv_desc* d, int mo, const float* in, int Cg, int
   else prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd<%d, %d, true>", bm, bn);
   if (mo == 4) {
     const int64_t n = (int64_t)T * (Kg / 2);
-    lmh_launch(k_wino4_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,
-                       d->H, d->W, Kg, scale, shift, extra, act_lo, act_hi, out, bits_out, bits_in);
+#define LAUNCH_WO(EX_, BI_)                                                                              \
+    lmh_launch((k_wino4_output<EX_, BI_>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, \
+               d->N, d->H, d->W, Kg, scale, shift, extra, act_lo, act_hi, out, bits_out, bits_in)
+    if (extra && bits_in) LAUNCH_WO(true, true);
+    else if (extra) LAUNCH_WO(true, false);
+    else if (bits_in) LAUNCH_WO(false, true);
+    else LAUNCH_WO(false, false);
+#undef LAUNCH_WO
   } else {
     const int64_t n = (int64_t)T * (Kg / 4);
     lmh_launch(k_wino_output, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)Mo, d->N,
