@@ -763,7 +763,7 @@ k_conv_stem7x7s2(lmh_conv_desc d, const float* __restrict__ x, const float* __re
     prow[q] = e / STEM_ROWF;
     pcol[q] = e - prow[q] * STEM_ROWF;
   }
-  float pre[STEM_NLD];
+  float pre[STEM_NLD], psub[STEM_NLD];
 #define STEM_FETCH(t_)                                                                       \
   do {                                                                                       \
     const int tw_ = (t_) % tiles_w, tq_ = (t_) / tiles_w;                                    \
@@ -774,14 +774,19 @@ k_conv_stem7x7s2(lmh_conv_desc d, const float* __restrict__ x, const float* __re
       const int ih = ih0 + prow[q], iwc = iw0 * 3 + pcol[q];                                 \
       const bool ok = e < STEM_PATCH && (unsigned)ih < (unsigned)d.H && iwc >= 0 && iwc < d.W * 3; \
       const int ch = pcol[q] % 3;                                                            \
-      pre[q] = ok ? x[((size_t)n_ * d.H + ih) * d.W * 3 + iwc] - sub[ch] : 0.f;              \
+      /* unconditional load (the zero page when outside the image), used unconditionally: as `ok ? x[..] : 0` every   \
+         one of the STEM_NLD loads sat behind a branch and a full s_waitcnt, i.e. the "prefetch" of the next patch was   \
+         ten serial round trips BEFORE the MFMAs of this tile instead of one under them (round 4; ISA check) */         \
+      const float* xp_ = ok ? x + ((size_t)n_ * d.H + ih) * d.W * 3 + iwc : lmh_zero_page;   \
+      pre[q] = *xp_;                                  /* first use: STEM_COMMIT, after the MFMAs */ \
+      psub[q] = ok ? sub[ch] : 0.f;                                                          \
     }                                                                                        \
   } while (0)
 #define STEM_COMMIT(buf_)                                                                    \
   do {                                                                                       \
     _Pragma("unroll") for (int q = 0; q < STEM_NLD; ++q) {                                   \
       const int e = tid + 256 * q;                                                           \
-      if (e < STEM_PATCH) Ps[buf_][e] = pre[q];                                              \
+      if (e < STEM_PATCH) Ps[buf_][e] = pre[q] - psub[q];                                    \
     }                                                                                        \
   } while (0)
   // this wave's 32 pixels: rows 2*wave, 2*wave+1 of the 8 x 16 tile
