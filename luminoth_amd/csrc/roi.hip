@@ -13,6 +13,7 @@ int lmh_opt(const char* name);   // api.hip: the lmh_set_option registry
 #include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __attribute__((aligned(16))) const float roi_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // target of unconditional loads
 
 struct roi_geom {
   float y1n, x1n, hs, ws;  // normalised top-left * (dim-1), per-sample scale
@@ -249,35 +250,67 @@ k_roi_pool_bwd_slab(const float* __restrict__ dout, const uint8_t* __restrict__ 
   const int nroi = min(roi_count[b], R);
   const int pairs = nroi * cells;
   const int cc = threadIdx.x % CS;
-  for (int pair = threadIdx.x / CS; pair < pairs; pair += 1024 / CS) {
-    const size_t gp = (size_t)b * R * cells + pair;
-    const size_t o = gp * C + c0 + cc;
-    const float go = MEAN ? dout[((size_t)b * R + pair / cells) * C + c0 + cc] / (float)cells : dout[o];
-    const int q = argmax[o] & 3;
-    const roi_sample_rec s = table[gp * 4 + q];
-    if (s.top < 0 || go == 0.f) continue;
-    const float dtop = (1.f - s.ylerp) * go;
-    const float dbot = s.ylerp * go;
-    roi_fx_add(&slab[(s.top * FW + s.left) * CS + cc], (1.f - s.xlerp) * dtop);
-    roi_fx_add(&slab[(s.top * FW + s.right) * CS + cc], s.xlerp * dtop);
-    roi_fx_add(&slab[(s.bot * FW + s.left) * CS + cc], (1.f - s.xlerp) * dbot);
-    roi_fx_add(&slab[(s.bot * FW + s.right) * CS + cc], s.xlerp * dbot);
+  // FOUR (roi-cell, channel) pairs per trip: a pair costs two DEPENDENT global reads (arg-max byte -> sample record) and a
+  // thread walks ~49 of them; one at a time that was ~100 serial round trips of memory latency per thread — most of the
+  // kernel (135 us alone, 240-290 us beside the convolution streams).  Here the four gradient / arg-max reads go out
+  // together (clamped index past the end), then the four record reads, then the LDS atomics (round 4).
+  constexpr int STEP = 1024 / CS;
+  for (int pair0 = threadIdx.x / CS; pair0 < pairs; pair0 += 4 * STEP) {
+    float go[4];
+    int q[4];
+    size_t gp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pair = min(pair0 + u * STEP, pairs - 1);
+      gp[u] = (size_t)b * R * cells + pair;
+      const size_t o = gp[u] * C + c0 + cc;
+      go[u] = MEAN ? dout[((size_t)b * R + pair / cells) * C + c0 + cc] : dout[o];
+      q[u] = argmax[o];
+    }
+    roi_sample_rec s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = table[gp[u] * 4 + (q[u] & 3)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float g = MEAN ? go[u] / (float)cells : go[u];
+      if (pair0 + u * STEP >= pairs || s[u].top < 0 || g == 0.f) continue;
+      const float dtop = (1.f - s[u].ylerp) * g;
+      const float dbot = s[u].ylerp * g;
+      roi_fx_add(&slab[(s[u].top * FW + s[u].left) * CS + cc], (1.f - s[u].xlerp) * dtop);
+      roi_fx_add(&slab[(s[u].top * FW + s[u].right) * CS + cc], s[u].xlerp * dtop);
+      roi_fx_add(&slab[(s[u].bot * FW + s[u].left) * CS + cc], (1.f - s[u].xlerp) * dbot);
+      roi_fx_add(&slab[(s[u].bot * FW + s[u].right) * CS + cc], s[u].xlerp * dbot);
+    }
   }
   __syncthreads();
   float* fb = dfeat + (size_t)b * npix * C + c0;
-  for (int i = threadIdx.x; i < npix * CS / 4; i += 1024) {
-    const int pix = i / (CS / 4), part = i - pix * (CS / 4);
-    const unsigned long long* p4 = slab + (size_t)pix * CS + 4 * part;
-    float4 v;
-    v.x = (float)((double)(long long)p4[0] * ROI_FX_INV);
-    v.y = (float)((double)(long long)p4[1] * ROI_FX_INV);
-    v.z = (float)((double)(long long)p4[2] * ROI_FX_INV);
-    v.w = (float)((double)(long long)p4[3] * ROI_FX_INV);
-    if (addend) {       // the other branch's gradient of the same feature map (RPN): the sum leaves in this one store
-      const float4 a = *reinterpret_cast<const float4*>(addend + (size_t)b * npix * C + c0 + (size_t)pix * C + 4 * part);
-      v.x = a.x + v.x; v.y = a.y + v.y; v.z = a.z + v.z; v.w = a.w + v.w;
+  const float* ab = addend ? addend + (size_t)b * npix * C + c0 : nullptr;
+  const int nvec = npix * CS / 4;
+  for (int i0 = threadIdx.x; i0 < nvec; i0 += 4 * 1024) {      // four rows per trip, their addend reads issued together
+    f32x4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 1024;
+      const int pix = i / (CS / 4), part = i - pix * (CS / 4);
+      const float* ap = (ab && i < nvec) ? ab + (size_t)pix * C + 4 * part : roi_zero_page;
+      a[u] = *reinterpret_cast<const f32x4*>(ap);
     }
-    *reinterpret_cast<float4*>(fb + (size_t)pix * C + 4 * part) = v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 1024;
+      if (i >= nvec) break;
+      const int pix = i / (CS / 4), part = i - pix * (CS / 4);
+      const unsigned long long* p4 = slab + (size_t)pix * CS + 4 * part;
+      float4 v;
+      v.x = (float)((double)(long long)p4[0] * ROI_FX_INV);
+      v.y = (float)((double)(long long)p4[1] * ROI_FX_INV);
+      v.z = (float)((double)(long long)p4[2] * ROI_FX_INV);
+      v.w = (float)((double)(long long)p4[3] * ROI_FX_INV);
+      if (addend) {       // the other branch's gradient of the same feature map (RPN): the sum leaves in this one store
+        v.x = a[u].x + v.x; v.y = a[u].y + v.y; v.z = a[u].z + v.z; v.w = a[u].w + v.w;
+      }
+      *reinterpret_cast<float4*>(fb + (size_t)pix * C + 4 * part) = v;
+    }
   }
 }
 
