@@ -233,7 +233,7 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
     LMH_CHECK_LAUNCH();
     return LMH_OK;
   }
-  if (d->R == 1 && d->S == 1 && d->stride == 1 && (d->C % 256) == 0 && d->C >= 512 && d->C <= 4096 && d->K <= 512 &&
+  if (d->R == 1 && d->S == 1 && d->stride == 1 && (d->C % 128) == 0 && d->C >= 512 && d->C <= 4096 && d->K <= 512 &&
       d->act == 0 && !in_sub && M <= 4096 && ((M + 63) / 64) * ((d->K + 63) / 64) < 128 && !g_force_bm &&
       lmh_opt("head_gemm")) {      // (fewer than 128 tiles of 64 x 64: the tiled kernels would leave half the chip empty)
     // Linear head on few rows (the RCNN classifier / box regressor over 512 ROIs): 32x32 tiles, the reduction split over

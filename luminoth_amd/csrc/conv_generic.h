@@ -489,18 +489,7 @@ k_skinny_bwd_data(const float* __restrict__ dy, const float* __restrict__ w, con
   f32x4 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // the addend rows and mask words of this thread's 16 outputs, requested BEFORE the multiply loop (clamped addresses, the
-  // stores below are what is predicated): inside the store loop each was a conditional load + s_waitcnt of its own, 32
-  // serial round trips per thread — most of the kernel (round 4; ISA check)
-  const int cq = min(c0 + 4 * c4, C - 4), words = C >> 5;
-  f32x4 ad[16];
-  uint32_t mw[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int p = min(m0 + 16 * pg + i, M - 1);
-    ad[i] = addend ? *reinterpret_cast<const f32x4*>(addend + (size_t)p * C + cq) : f32x4{0.f, 0.f, 0.f, 0.f};
-    mw[i] = xbits ? xbits[(size_t)p * words + (cq >> 5)] : 0xFFFFFFFFu;
-  }
+
   for (int k4 = 0; k4 < K4; ++k4) {
     f32x4 wv[4];
 #pragma unroll
@@ -520,17 +509,32 @@ k_skinny_bwd_data(const float* __restrict__ dy, const float* __restrict__ w, con
   }
   const int c = c0 + 4 * c4;
   if (c >= C) return;
+  const int words = C >> 5;
+  // the addend rows and mask words of eight outputs at a time, requested together (clamped row, the store is what is
+  // predicated): inside the store loop each was a conditional load + s_waitcnt of its own, 32 serial round trips of memory
+  // latency per thread — most of the kernel (round 4; ISA check).  Eight, not sixteen, and here, not above the multiply
+  // loop: that variant needed 218 VGPRs and such a block waits for a CU with room inside the step.
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int p = m0 + 16 * pg + i;
-    if (p >= M) break;
-    f32x4 v = acc[i];
-    const size_t o = (size_t)p * C + c;
-    if (addend) { v.x += ad[i].x; v.y += ad[i].y; v.z += ad[i].z; v.w += ad[i].w; }
-    const uint32_t mb = mw[i] >> (c & 31);
-    v.x = (mb & 1u) ? v.x : 0.f; v.y = (mb & 2u) ? v.y : 0.f;
-    v.z = (mb & 4u) ? v.z : 0.f; v.w = (mb & 8u) ? v.w : 0.f;
-    *reinterpret_cast<f32x4*>(dx + o) = v;
+  for (int i0 = 0; i0 < 16; i0 += 8) {
+    f32x4 ad[8];
+    uint32_t mw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = min(m0 + 16 * pg + i0 + i, M - 1);
+      ad[i] = addend ? *reinterpret_cast<const f32x4*>(addend + (size_t)p * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      mw[i] = xbits ? xbits[(size_t)p * words + (c >> 5)] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = m0 + 16 * pg + i0 + i;
+      if (p >= M) break;
+      f32x4 v = acc[i0 + i];
+      if (addend) { v.x += ad[i].x; v.y += ad[i].y; v.z += ad[i].z; v.w += ad[i].w; }
+      const uint32_t mb = mw[i] >> (c & 31);
+      v.x = (mb & 1u) ? v.x : 0.f; v.y = (mb & 2u) ? v.y : 0.f;
+      v.z = (mb & 4u) ? v.z : 0.f; v.w = (mb & 8u) ? v.w : 0.f;
+      *reinterpret_cast<f32x4*>(dx + (size_t)p * C + c) = v;
+    }
   }
 }
 
@@ -574,9 +578,10 @@ k_skinny_fwd(const float* __restrict__ x, const float* __restrict__ w, const flo
 // kernels of the other streams, on the critical proposal -> RCNN chain (the 81-wide classifier, off the MFMA paths, took
 // 83).  Here a 256-thread block owns a 32 x 32 output tile and its four waves split the REDUCTION (C/4 each): operands go
 // straight from global memory into MFMA fragments (no LDS, no barrier in the loop: a lane loads one float4 of its x row and
-// the four w values of its column for four consecutive v_mfma_f32_32x32x2_f32), the next batch of 64 reduction steps is
-// loaded while the current one multiplies (four rounds of memory latency at C = 1024), and the four partial tiles are added in wave order through LDS (deterministic).
-// Any N (columns past N are clamped on load and not stored); C % 256 == 0.
+// the four w values of its column for four consecutive v_mfma_f32_32x32x2_f32), the next batch of 32 reduction steps is
+// loaded while the current one multiplies (90 VGPRs; batches of 64 halve the rounds of memory latency but need 202, and
+// inside the step the kernel then took 49 instead of 31 us: a block that size waits for a CU with room), and the four partial tiles are added in wave order through LDS (deterministic).
+// Any N (columns past N are clamped on load and not stored); C % 128 == 0.
 // ============================================================================
 __global__ void __launch_bounds__(256)
 k_head_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
@@ -588,37 +593,37 @@ k_head_fwd(const float* __restrict__ x, const float* __restrict__ w, const float
   const int l31 = lane & 31, h = lane >> 5;
   const int tiles_n = (N + 31) >> 5;
   const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
-  const int kper = C >> 2;                           // a multiple of 64
+  const int kper = C >> 2;                           // a multiple of 32
   const int row = min(m0 + l31, M - 1), col = min(n0 + l31, N - 1);   // clamped lanes compute values nobody stores
   const float* xa = x + (size_t)row * C + wave * kper + 4 * h;
   const float* wb = w + (size_t)(wave * kper + 4 * h) * N + col;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  f32x4 a_cur[8];
-  float b_cur[8][4];
+  f32x4 a_cur[4];
+  float b_cur[4][4];
 #define HEAD_LOAD(a_, b_)                                                                  \
-  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                          \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
     a_[u] = *reinterpret_cast<const f32x4*>(xk + 8 * u);                                   \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) b_[u][j] = wk[(8 * u + j) * N];          \
   }
   const float* xk = xa;
   const float* wk = wb;
-  const size_t wstep = (size_t)64 * N;
+  const size_t wstep = (size_t)32 * N;
   HEAD_LOAD(a_cur, b_cur)
-  for (int k = 0; k < kper; k += 64) {
-    f32x4 a_nxt[8];
-    float b_nxt[8][4];
-    if (k + 64 < kper) { xk += 64; wk += wstep; }    // the last iteration re-reads a valid address and drops the data
+  for (int k = 0; k < kper; k += 32) {
+    f32x4 a_nxt[4];
+    float b_nxt[4][4];
+    if (k + 32 < kper) { xk += 32; wk += wstep; }    // the last iteration re-reads a valid address and drops the data
     HEAD_LOAD(a_nxt, b_nxt)
     __builtin_amdgcn_sched_barrier(0);               // keep the loads of the next batch ahead of these MFMAs
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][j], b_cur[u][j], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4; ++u) {
       a_cur[u] = a_nxt[u];
 #pragma unroll
       for (int j = 0; j < 4; ++j) b_cur[u][j] = b_nxt[u][j];
