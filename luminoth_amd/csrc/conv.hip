@@ -736,6 +736,7 @@ extern "C" int lmh_conv2d_fwd_hs(const lmh_conv_desc* d, const void* x, const vo
   LMH_CHECK_ARG(x && w_fwd && y);
   if (!hs_ok(d)) { lmh_set_error("lmh_conv2d_fwd_hs: needs compute f16 / bf16, C %% 64 == 0, K %% 64 == 0"); return LMH_ERR_UNSUPPORTED; }
   LMH_CHECK_ARG(act_bits == nullptr || d->act != 0);
+  LMH_CHECK_ARG((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0);      // read as float4 by the epilogue
   g_prof_pending_bytes = hs_bytes(d);
   hs_epilogue e = {scale, shift, residual, nullptr, act_bits, y, y_is_f32, 1.f};
   return hs_launch<false>(d, x, w_fwd, e, (hipStream_t)stream);

@@ -285,32 +285,43 @@ k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict
 #undef FWD_STORE
 #undef FWD_SETUP_RS
 
-  // ---- epilogue through LDS: float4 rows.  The residual rows of the first chunk are requested BEFORE the
-  // accumulator transpose so their (L2 / HBM) latency runs under it; each later chunk issues all of its loads
-  // together (the old row-by-row loop exposed that latency four times per tile).
+  // ---- epilogue through LDS: float4 rows.  EVERY load of the epilogue — the residual rows of all chunks, scale and
+  // shift — is requested BEFORE the accumulator transpose, so that one round of (L2 / HBM) latency runs under it and
+  // nothing but stores follows the first store.  Round 4 (ISA check): loads and stores count on the same vmcnt and may
+  // retire out of order with respect to each other, so with both kinds in flight the compiler can only wait for
+  // vmcnt(0): the second residual chunk requested after the first chunk's stores, and the scale / shift vectors
+  // requested after the barrier, each cost a full store + load round trip per tile (three exposed trips in all).
   constexpr int CT = BN / 4, RSTEP = 256 / CT;
   constexpr int NR = BM / RSTEP, NRC = NR < 8 ? NR : 8, NCH = NR / NRC;
   const int c4 = tid % CT, r0 = tid / CT;
   const int col = n0 + 4 * c4;
   const bool col_ok = col < K;
-  f32x4 ex[NRC];
-#define FWD_EPI_ISSUE(ch_)                                                                       \
-  _Pragma("unroll") for (int i = 0; i < NRC; ++i) {                                              \
-    const int row = m0 + r0 + ((ch_) * NRC + i) * RSTEP;                                         \
-    ex[i] = (residual && col_ok && row < M) ? *reinterpret_cast<const f32x4*>(residual + (size_t)row * K + col) \
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};                         \
-  }
-  FWD_EPI_ISSUE(0)
-  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
-  __syncthreads();
+  f32x4 ex[NCH][NRC];
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
   if (col_ok) {
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (scale) sc = *reinterpret_cast<const f32x4*>(scale + col);
     if (shift) sh = *reinterpret_cast<const f32x4*>(shift + col);
+  }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int i = 0; i < NRC; ++i) {
+      const int row = m0 + r0 + (ch * NRC + i) * RSTEP;
+      ex[ch][i] = (residual && col_ok && row < M) ? *reinterpret_cast<const f32x4*>(residual + (size_t)row * K + col)
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+  // every requested row is awaited HERE, in front of the first store: a wait the compiler places later, at the join
+  // behind the first (conditional) row, would be a vmcnt(0) that also waits for that row's stores
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int i = 0; i < NRC; ++i) asm volatile("" ::"v"(ex[ch][i]));
+  if (col_ok) {
     const float act_lo = d.act ? 0.f : -INFINITY, act_hi = (d.act == 2) ? 6.f : INFINITY;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      if (ch > 0) { FWD_EPI_ISSUE(ch) }
 #pragma unroll
       for (int i = 0; i < NRC; ++i) {
         const int r = r0 + (ch * NRC + i) * RSTEP;
@@ -319,7 +330,7 @@ k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict
           f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
           if (scale) v *= sc;
           v += sh;
-          v += ex[i];
+          v += ex[ch][i];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
           *reinterpret_cast<f32x4*>(y + (size_t)row * K + col) = v;
@@ -336,7 +347,6 @@ k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict
       }
     }
   }
-#undef FWD_EPI_ISSUE
 }
 
 // ============================================================================
@@ -513,47 +523,52 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
 #undef BD_SETUP_RS
 #undef BD_TAP
 
-  // epilogue: same chunked prefetch of the addend / mask rows as the forward kernel
+  // epilogue: every addend row and mask word of the tile is requested before the accumulator transpose and nothing but
+  // stores follows the first store (see the forward kernel: loads and stores in flight together force vmcnt(0) waits)
   constexpr int CT = BN / 4, RSTEP = 256 / CT;
   constexpr int NR = BM / RSTEP, NRC = NR < 8 ? NR : 8, NCH = NR / NRC;
   const int c4 = tid % CT, r0 = tid / CT;
   const int col = n0 + 4 * c4;
   const bool col_ok = col < C;
-  f32x4 ex[NRC];
-  uint32_t xw[NRC];
+  f32x4 ex[NCH][NRC];
+  uint32_t xw[NCH][NRC];
   auto out_row = [&](int p) {      // GEMM row -> pixel index of dx / addend / mask words
     if (!par) return p;
     int n_, h_, w_;
     pixel(p, n_, h_, w_);
     return (n_ * d.H + h_) * d.W + w_;
   };
-#define BD_EPI_ISSUE(ch_)                                                                        \
-  _Pragma("unroll") for (int i = 0; i < NRC; ++i) {                                              \
-    const int prow_ = m0 + r0 + ((ch_) * NRC + i) * RSTEP;                                       \
-    const bool ok = col_ok && prow_ < M;                                                         \
-    const int row = ok ? out_row(prow_) : 0;                                                     \
-    ex[i] = (addend && ok) ? *reinterpret_cast<const f32x4*>(addend + (size_t)row * C + col) : f32x4{0.f, 0.f, 0.f, 0.f}; \
-    if (xbits) xw[i] = ok ? xbits[(size_t)row * (C >> 5) + (col >> 5)] : 0u;                     \
-  }
-  BD_EPI_ISSUE(0)
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int i = 0; i < NRC; ++i) {
+      const int prow_ = m0 + r0 + (ch * NRC + i) * RSTEP;
+      const bool ok = col_ok && prow_ < M;
+      const int row = ok ? out_row(prow_) : 0;
+      ex[ch][i] = (addend && ok) ? *reinterpret_cast<const f32x4*>(addend + (size_t)row * C + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xw[ch][i] = (xbits && ok) ? xbits[(size_t)row * (C >> 5) + (col >> 5)] : 0u;
+    }
   acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
   __syncthreads();
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)          // all loads awaited in front of the first store (forward kernel)
+#pragma unroll
+    for (int i = 0; i < NRC; ++i) asm volatile("" ::"v"(ex[ch][i]), "v"(xw[ch][i]));
   if (col_ok) {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      if (ch > 0) { BD_EPI_ISSUE(ch) }
 #pragma unroll
       for (int i = 0; i < NRC; ++i) {
         const int r = r0 + (ch * NRC + i) * RSTEP;
         if (m0 + r < M) {
           const int row = out_row(m0 + r);
           f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
-          v += ex[i];
+          v += ex[ch][i];
           // x is the (post-activation) output of the layer below: emitting dx * act'(x) hands that layer its
           // pre-activation gradient directly — no separate lmh_act_bwd pass over dx (2 KB of mask words per tile,
           // requested before the accumulator transpose: their latency runs under it)
           if (xbits) {
-            const unsigned nib = xw[i] >> (4 * (c4 & 7));
+            const unsigned nib = xw[ch][i] >> (4 * (c4 & 7));
             v.x = (nib & 1u) ? v.x : 0.f;
             v.y = (nib & 2u) ? v.y : 0.f;
             v.z = (nib & 4u) ? v.z : 0.f;
@@ -564,7 +579,6 @@ k_conv_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __re
       }
     }
   }
-#undef BD_EPI_ISSUE
 }
 
 // ============================================================================

@@ -138,6 +138,18 @@ k_conv_fwd_gen(lmh_conv_desc d, const float* __restrict__ x, const float* __rest
     const float sh = shift ? shift[col] : 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      // the 16 residual values of this accumulator tile are requested together (clamped row) and awaited, with scale and
+      // shift, in front of its first store: a load behind a store can only be awaited with vmcnt(0), i.e. together with
+      // that store — it was one store round trip per ELEMENT (round 4; tools/isa_mixed_vm_waits.py)
+      float rs[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = min(m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase, M - 1);
+        rs[i] = residual ? residual[(size_t)row * K + col] : 0.f;
+      }
+      asm volatile("" ::"v"(sc), "v"(sh));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(rs[i]));
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase;
@@ -145,7 +157,7 @@ k_conv_fwd_gen(lmh_conv_desc d, const float* __restrict__ x, const float* __rest
           float v = acc[tm][tn][i];
           if (scale) v = v * sc;
           v = v + sh;
-          if (residual) v += residual[(size_t)row * K + col];
+          v += rs[i];
           y[(size_t)row * K + col] = apply_act(v, d.act);
         }
       }
@@ -271,16 +283,21 @@ k_conv_bwd_data_gen(lmh_conv_desc d, const float* __restrict__ dy, const float* 
     const int col = n0 + wn * (BN / 2) + tn * 32 + col_l;
     if (col >= C) continue;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm) {
+      float rs[16];                    // addend values of the tile: requested together, awaited in front of the first store
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = min(m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase, M - 1);
+        rs[i] = addend ? addend[(size_t)row * C + col] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(rs[i]));
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = m0 + wm * (BM / 2) + tm * 32 + (i & 3) + 8 * (i >> 2) + rbase;
-        if (row < M) {
-          float v = acc[tm][tn][i];
-          if (addend) v += addend[(size_t)row * C + col];
-          dx[(size_t)row * C + col] = v;
-        }
+        if (row < M) dx[(size_t)row * C + col] = acc[tm][tn][i] + rs[i];
       }
+    }
   }
 }
 
@@ -600,6 +617,7 @@ k_head_fwd(const float* __restrict__ x, const float* __restrict__ w, const float
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const float sc = scale ? scale[col] : 1.f, sh = shift ? shift[col] : 0.f;      // used by wave 0's epilogue (col = its n, clamped)
   f32x4 a_cur[4];
   float b_cur[4][4];
 #define HEAD_LOAD(a_, b_)                                                                  \
@@ -642,13 +660,23 @@ k_head_fwd(const float* __restrict__ x, const float* __restrict__ w, const float
     for (int i = 0; i < 16; ++i) acc[i] += red[q][i][lane];
   const int n = n0 + l31;
   if (n >= N) return;
-  const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+  // (scale / shift were requested before the reduction loop; the residual rows all at once and in front of the first store:
+  // a load behind a store can only be awaited with vmcnt(0), i.e. together with that store)
+  float rs[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int m = min(m0 + (i & 3) + 8 * (i >> 2) + 4 * h, M - 1);
+    rs[i] = residual ? residual[(size_t)m * N + n] : 0.f;
+  }
+  asm volatile("" ::"v"(sc), "v"(sh));       // every load awaited here, unconditionally: a wait the compiler places inside a
+#pragma unroll                               // conditional row block is a vmcnt(0) that also waits for the previous row's store
+  for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(rs[i]));
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
     if (m >= M) continue;
     float v = acc[i] * sc + sh;
-    if (residual) v += residual[(size_t)m * N + n];
+    v += rs[i];
     if (act == 1) v = fmaxf(v, 0.f);
     else if (act == 2) v = fminf(fmaxf(v, 0.f), 6.f);
     y[(size_t)m * N + n] = v;

@@ -211,22 +211,45 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
   }
 #undef HS_ISSUE
   __syncthreads();      // the epilogue tile overlays the ring
-  // ---- epilogue through LDS: a thread owns 8 consecutive output channels of a row (one 16-byte half store)
-  constexpr int CT = BN / 8, RSTEP = 256 / CT;
+  // ---- epilogue through LDS: a thread owns 8 consecutive output channels of a row (one 16-byte half store).
+  // Every load of the epilogue (scale / shift, the residual or addend rows, the input-mask words) is requested BEFORE the
+  // accumulator transpose and awaited once, in front of the first store.  Round 4 (ISA check): with the loads inside the
+  // row loop each row was load -> wait -> store, and since loads and stores count on the same vmcnt and retire out of
+  // order with respect to each other the wait was a vmcnt(0) that also waited for the previous row's store — four to
+  // eight serial memory round trips per tile in every backward launch (mask words) and every residual forward launch.
+  constexpr int CT = BN / 8, RSTEP = 256 / CT, NRW = BM / RSTEP;
   const int c8 = tid % CT, r0 = tid / CT;
   const int col = n0 + 8 * c8;
+  const bool col_ok = col < NC;
+  const int words = NC >> 5, wcol = col >> 5, bsh = 8 * (c8 & 3);
+  f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+  if (!BWD && col_ok) {
+    if (e.scale) { sc0 = *reinterpret_cast<const f32x4*>(e.scale + col); sc1 = *reinterpret_cast<const f32x4*>(e.scale + col + 4); }
+    if (e.shift) { sh0 = *reinterpret_cast<const f32x4*>(e.shift + col); sh1 = *reinterpret_cast<const f32x4*>(e.shift + col + 4); }
+  }
+  V8 x8[NRW];
+  uint32_t mw[NRW];
+#pragma unroll
+  for (int i = 0; i < NRW; ++i) {
+    const int row = m0 + r0 + i * RSTEP;
+    const bool ok = col_ok && row < M;
+    const size_t o = ok ? (size_t)row * NC + col : 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x8[i][q] = (HTT)0.f;
+    if (e.extra && ok) x8[i] = *reinterpret_cast<const V8*>(reinterpret_cast<const HTT*>(e.extra) + o);
+    mw[i] = (BWD && e.bits_in && ok) ? e.bits_in[(size_t)row * words + wcol] : 0xFFFFFFFFu;
+  }
   acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
   __syncthreads();
-  if (col < NC) {
-    float sc[8], sh[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      sc[i] = (!BWD && e.scale) ? e.scale[col + i] : 1.f;
-      sh[i] = (!BWD && e.shift) ? e.shift[col + i] : 0.f;
-    }
+  for (int i = 0; i < NRW; ++i) asm volatile("" ::"v"(x8[i]), "v"(mw[i]));      // loads awaited in front of the first store
+  if (col_ok) {
+    const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+    const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
     const float act_lo = (!BWD && d.act) ? 0.f : -INFINITY, act_hi = (!BWD && d.act == 2) ? 6.f : INFINITY;
-    const int words = NC >> 5, wcol = col >> 5, bsh = 8 * (c8 & 3);
-    for (int r = r0; r < BM; r += RSTEP) {
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+      const int r = r0 + i * RSTEP;
       const int row = m0 + r;
       if (row >= M) break;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 8 * c8]);
@@ -235,25 +258,24 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
       const size_t o = (size_t)row * NC + col;
       if (BWD) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= e.mul;
+        for (int q = 0; q < 8; ++q) v[q] *= e.mul;
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
+        for (int q = 0; q < 8; ++q) v[q] = fmaf(v[q], sc[q], sh[q]);
       }
       if (e.extra) {
-        const V8 x8 = *reinterpret_cast<const V8*>(reinterpret_cast<const HTT*>(e.extra) + o);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += (float)x8[i];
+        for (int q = 0; q < 8; ++q) v[q] += (float)x8[i][q];
       }
       if (BWD) {
         if (e.bits_in) {
-          const uint32_t m = e.bits_in[(size_t)row * words + wcol] >> bsh;
+          const uint32_t m = mw[i] >> bsh;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = ((m >> i) & 1u) ? v[i] : 0.f;
+          for (int q = 0; q < 8; ++q) v[q] = ((m >> q) & 1u) ? v[q] : 0.f;
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fminf(fmaxf(v[i], act_lo), act_hi);
+        for (int q = 0; q < 8; ++q) v[q] = fminf(fmaxf(v[q], act_lo), act_hi);
       }
       if (e.out_f32) {
         float* yo = reinterpret_cast<float*>(e.out) + o;
@@ -264,17 +286,17 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
         // f16 has 5 exponent bits: a value beyond +-65504 would round to inf and poison the fp32 master weights through
         // the weight gradient; it is stored as the largest finite f16 instead (bf16 has fp32's range)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) h[i] = (HTT)(DT == 1 ? fminf(fmaxf(v[i], -65504.f), 65504.f) : v[i]);
+        for (int q = 0; q < 8; ++q) h[q] = (HTT)(DT == 1 ? fminf(fmaxf(v[q], -65504.f), 65504.f) : v[q]);
         *reinterpret_cast<V8*>(reinterpret_cast<HTT*>(e.out) + o) = h;
         // the mask follows the STORED value: a positive sum that rounds to zero (f16 underflow) is a dead unit for
         // the next layer and for the backward pass alike
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+        for (int q = 0; q < 8; ++q) v[q] = (float)h[q];
       }
       if (!BWD && e.bits_out) {   // 4 adjacent lanes hold the 32 channels of one mask word (same row: active together)
         uint32_t m = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) m |= ((v[i] > 0.f && v[i] < act_hi) ? 1u : 0u) << i;
+        for (int q = 0; q < 8; ++q) m |= ((v[q] > 0.f && v[q] < act_hi) ? 1u : 0u) << q;
         m <<= bsh;
         m |= __shfl_xor(m, 1);
         m |= __shfl_xor(m, 2);

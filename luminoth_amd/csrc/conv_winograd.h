@@ -456,6 +456,9 @@ k_wino4_output(const float* __restrict__ Mo, int N, int H, int W, int K, const f
   for (int a = 0; a < 6; ++a)
 #pragma unroll
     for (int b = 0; b < 6; ++b) m[a][b] = *reinterpret_cast<const f32x2*>(src + (size_t)(6 * a + b) * plane);
+  f32x2 sc = {1.f, 1.f}, sh = {0.f, 0.f};
+  if (scale) sc = *reinterpret_cast<const f32x2*>(scale + 2 * k2);
+  if (shift) sh = *reinterpret_cast<const f32x2*>(shift + 2 * k2);
   f32x2 ex[EXTRA ? 4 : 1][EXTRA ? 4 : 1];
   uint32_t bw[BITS_IN ? 4 : 1][BITS_IN ? 4 : 1];
   if (EXTRA || BITS_IN) {
@@ -479,9 +482,23 @@ k_wino4_output(const float* __restrict__ Mo, int N, int H, int W, int K, const f
 #pragma unroll
     for (int a = 0; a < 4; ++a) t[a][b] = u[a];
   }
-  f32x2 sc = {1.f, 1.f}, sh = {0.f, 0.f};
-  if (scale) sc = *reinterpret_cast<const f32x2*>(scale + 2 * k2);
-  if (shift) sh = *reinterpret_cast<const f32x2*>(shift + 2 * k2);
+  // everything loaded above is awaited HERE, unconditionally and in front of the first store: loads and stores count on
+  // the same vmcnt, so a wait the compiler places inside a conditional pixel block below (it must assume the loads still
+  // pending on the path that skipped the previous block) is a vmcnt(0) that also waits for the previous pixel's store —
+  // fifteen serial store round trips per thread (round 4; ISA check, tools/isa_mixed_vm_waits.py)
+  asm volatile("" ::"v"(sc), "v"(sh));
+  if (EXTRA) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(ex[a][b]));
+  }
+  if (BITS_IN) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(bw[a][b]));
+  }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     f32x2 o4[4];

@@ -230,6 +230,11 @@ k_gather_topk(const uint64_t* __restrict__ keys, const float4* __restrict__ boxe
 // ----------------------------------------------------------------------------
 struct nms_state { int32_t total, done; };
 
+// v_max_f32 / v_min_f32 as they are: fmaxf / fminf on a value that comes out of LDS compile to a canonicalising
+// v_max_f32 x, x, x in front of the operation (four extra instructions per pair in k_nms_mask's loop; ISA check)
+__device__ __forceinline__ float nms_vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float nms_vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 __global__ void __launch_bounds__(64)
 k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts, int K, int W,
            float thr, int cb0, const nms_state* __restrict__ state, uint64_t* __restrict__ mask) {
@@ -248,36 +253,45 @@ k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts,
     float4 v = (c < cnt) ? bb[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 nrm = make_float4(fminf(v.x, v.z), fminf(v.y, v.w), fmaxf(v.x, v.z), fmaxf(v.y, v.w));
     cbox[lane] = nrm;
-    carea[lane] = (c < cnt) ? (nrm.w - nrm.y) * (nrm.z - nrm.x) : 0.f;
+    // a column that can never be suppressed (past the list, or area <= 0) carries a NaN area: its union, and with it
+    // every comparison below, is then false whatever the threshold — no test of its own inside the loop
+    const float a = (nrm.w - nrm.y) * (nrm.z - nrm.x);
+    carea[lane] = (c < cnt && a > 0.f) ? a : __builtin_nanf("");
   }
   __syncthreads();
   const int r = rb * 64 + lane;
-  uint64_t word = 0;
+  uint32_t wlo = 0, whi = 0;
   if (r < cnt) {
     const float4 v = bb[r];
     const float x1 = fminf(v.x, v.z), y1 = fminf(v.y, v.w), x2 = fmaxf(v.x, v.z), y2 = fmaxf(v.y, v.w);
     const float area_r = (y2 - y1) * (x2 - x1);
     if (area_r > 0.f) {
-      // diagonal tiles carry both triangles (IoU is symmetric; self excluded): lane i of k_nms_reduce then reads
-      // "who suppresses me" (bits j < i) and "whom I suppress" (bits j > i) from the same word
+      // TF decides on fl(inter / uni) > thr.  The correctly rounded division is most of the vector-ALU work of a pair
+      // (72 M pairs per image at 12 000 candidates) and only matters within a few ulp of the threshold: pairs clearly on
+      // one side are decided by a product, and the division sits behind a branch that is taken only when some lane of the
+      // wave is that close — practically never.  (Round 3 wrote it as `if (sure) .. else if (close && division)`, which
+      // compiled to the division for every lane that was not `sure`, i.e. in every iteration; ISA check, round 4.)
+      // Same decisions, bit for bit.  Diagonal tiles carry both triangles (IoU is symmetric): lane i of the scan reads
+      // "who suppresses me" (bits j < i) and "whom I suppress" (bits j > i) from the same word; the self pair is cleared
+      // after the loop.
+#pragma unroll 16
       for (int j = 0; j < 64; ++j) {
-        const float area_c = carea[j];
-        if (!(area_c > 0.f) || (cb == rb && j == lane)) continue;
         const float4 c = cbox[j];
-        const float iy1 = fmaxf(y1, c.y), ix1 = fmaxf(x1, c.x);
-        const float iy2 = fminf(y2, c.w), ix2 = fminf(x2, c.z);
+        const float area_c = carea[j];
+        const float iy1 = nms_vmax(y1, c.y), ix1 = nms_vmax(x1, c.x);
+        const float iy2 = nms_vmin(y2, c.w), ix2 = nms_vmin(x2, c.z);
         const float inter = fmaxf(iy2 - iy1, 0.f) * fmaxf(ix2 - ix1, 0.f);
-        const float uni = (area_r + area_c) - inter;      // > 0: both areas are, and inter <= min(area)
-        // TF decides on fl(inter / uni) > thr.  The correctly rounded division is ~a third of this loop's vector-ALU work
-        // (72 M pairs per image at 12 000 candidates), and it only matters within a few ulp of the threshold: pairs clearly
-        // on one side are decided by a product, the rest (practically none) take the division — same decisions, bit for bit.
+        const float uni = (area_r + area_c) - inter;      // > 0 for a real column: both areas are, and inter <= min(area)
         const float p = thr * uni;
-        if (inter > p * 1.000001f) word |= (1ull << j);
-        else if (inter >= p * 0.999999f && inter / uni > thr) word |= (1ull << j);
+        bool bit = inter > p * 1.000001f;
+        if (__builtin_expect(!bit && inter >= p * 0.999999f, 0)) bit = inter / uni > thr;
+        const uint32_t m = bit ? (1u << (j & 31)) : 0u;
+        if (j < 32) wlo |= m; else whi |= m;
       }
+      if (cb == rb) { if (lane < 32) wlo &= ~(1u << lane); else whi &= ~(1u << (lane - 32)); }
     }
   }
-  if (r < K) mask[((size_t)b * K + r) * W + cb] = word;
+  if (r < K) mask[((size_t)b * K + r) * W + cb] = ((uint64_t)whi << 32) | wlo;
 }
 
 //    Phase 2: greedy reduce, one 1024-thread block per image, in SUPER-CHUNKS of 16 mask words (1024 candidates).
@@ -450,9 +464,273 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ coun
   }
 }
 
+//    Round 4: the same scan as a PIPELINE over the super-chunks (k_nms_reduce_p; `nms_pipe` = 0 selects the kernel above).
+//    What bounded k_nms_reduce at the train-step size (12 super-chunks, all of them scanned when the RPN is untrained:
+//    215 us on an idle chip) was not the greedy chain but, per super-chunk, three global round trips issued one after
+//    the other by ONE block — the 1024 row reads (a lane per row: 64 different cache lines per wave instruction), the
+//    gather of every kept row's 16 words (<= 2000 rows, 31 dependent-free loads per thread in batches of 8), and only
+//    then the 16 chunk hand-shakes.  Here
+//      (a) the rows of super-chunk s + 1 are requested right before super-chunk s is resolved and stay in registers until
+//          it is (8 lanes per row: a wave instruction reads 8 whole 128-byte rows);
+//      (b) the words of super-chunk s + 1 in the rows kept BEFORE super-chunk s — known when s starts, and almost all of
+//          the gather — are OR-ed by eleven waves that have no part in resolving s, into a second bitmap (remN);
+//          what is left for the critical path is the gather over the rows kept IN s (a few hundred at most: one round trip);
+//      (c) wave 0 folds the kept rows' word c + 1 into rem[c + 1] itself (LDS atomics of one wave run in order with its
+//          later read: no hand-shake between a chunk and the next); four waves fold the words from c + 2 on and publish
+//          `word j complete up to chunk j - 2`, which wave 0 finds set when it gets there.
+//    Same decisions, bit for bit (tests/test_gpu_kernels.py, the reference fixtures of tests/test_gpu_ref_tf_golden.py).
+// OR of a 64-bit value over the lanes of a wave into one LDS word: one ds_or_b64 per lane that has something to add (the
+// LDS unit serialises the lanes of a same-address atomic itself, a handful of cycles for the ~10 kept rows of a chunk).
+// The offset is an opaque zero in a vector register: with a provably wave-uniform address the compiler's atomic optimizer
+// replaces the instruction by a scalar loop over all 64 lanes (v_readlane + s_or per lane: ISA check), several times slower.
+__device__ __forceinline__ void nms_wave_or(unsigned long long* dst, uint64_t v) {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  if (v) atomicOr(dst + z, (unsigned long long)v);
+}
+
+#define NMS_SDT_STRIDE (NMS_RED_THREADS + 1)    // u64 per word plane: the (row, word-pair) writes of (1b) hit 16 bank pairs
+#define NMS_FOLD_WAVES 4
+
+template <bool WIDE>   // WIDE: W even, so a row's word pairs are 16-byte aligned and read as one dwordx4
+__device__ __forceinline__ void nms_load2(const uint64_t* __restrict__ rowp, int pair, int last, uint64_t& a, uint64_t& b) {
+  // words 2 pair, 2 pair + 1 of the 16-word window at rowp; indices past `last` (the last word of the window that exists)
+  // are clamped: their values are discarded by the caller
+  if (WIDE) {
+    const int pc = min(pair, last >> 1);
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(rowp + 2 * pc);
+    a = v.x; b = v.y;
+  } else {
+    a = rowp[min(2 * pair, last)];
+    b = rowp[min(2 * pair + 1, last)];
+  }
+}
+
+// OR of words [wbase, wbase + nwin) over the keep-list rows [lo, hi): thread `t` of `nt` (a multiple of 8) takes word pair
+// t & 7 of every (nt / 8)-th row, eight independent 16-byte loads in flight; lanes with the same pair are folded and lanes
+// 0..7 of each wave add the result to dst[0..15] (LDS atomics).  Clamped row indices repeat a row: harmless under OR.
+template <bool WIDE>
+__device__ __forceinline__ void nms_gather_or(const uint64_t* __restrict__ mb, int W, int wbase, int nwin,
+                                              const int32_t* __restrict__ kl, int lo, int hi, int t, int nt,
+                                              unsigned long long* dst) {
+  if (lo >= hi) return;                          // block-uniform
+  const int p = t & 7, stride = nt >> 3, lane = threadIdx.x & 63;
+  uint64_t a0 = 0ull, a1 = 0ull;
+  for (int base = lo + (t >> 3); base < hi; base += 8 * stride) {
+    uint64_t x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kr = kl[min(base + u * stride, hi - 1)];
+      nms_load2<WIDE>(mb + (size_t)kr * W + wbase, p, nwin - 1, x[u], y[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a0 |= x[u]; a1 |= y[u]; }
+  }
+  if (2 * p >= nwin) a0 = 0ull;
+  if (2 * p + 1 >= nwin) a1 = 0ull;
+  uint32_t v0 = (uint32_t)a0, v1 = (uint32_t)(a0 >> 32), v2 = (uint32_t)a1, v3 = (uint32_t)(a1 >> 32);
+#pragma unroll
+  for (int m = 8; m < 64; m <<= 1) {
+    v0 |= __shfl_xor(v0, m); v1 |= __shfl_xor(v1, m); v2 |= __shfl_xor(v2, m); v3 |= __shfl_xor(v3, m);
+  }
+  if (lane < 8) {
+    a0 = ((uint64_t)v1 << 32) | v0;
+    a1 = ((uint64_t)v3 << 32) | v2;
+    if (a0) atomicOr(&dst[2 * p], (unsigned long long)a0);
+    if (a1) atomicOr(&dst[2 * p + 1], (unsigned long long)a1);
+  }
+}
+
+// LDS flags of the scan's hand-shakes: relaxed atomics on the __shared__ objects themselves compile to ds_read / ds_write
+// (a `volatile` access through a cast pointer becomes a FLAT load with a vmcnt(0) wait, which would also wait for the
+// row prefetch in flight); a wave's LDS operations execute in order, so a flag written after the data is seen after it
+__device__ __forceinline__ int nms_lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned long long nms_lds_ld(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void nms_lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void nms_lds_st(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(NMS_RED_THREADS)
+k_nms_reduce_p(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts, int K, int W,
+               int max_out, int sc_begin, int sc_end, nms_state* __restrict__ state, int32_t* __restrict__ keep_idx,
+               int32_t* __restrict__ keep_count) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ __attribute__((aligned(16))) unsigned long long rem[NMS_SC_WORDS];    // removed-bits of the current super-chunk
+  __shared__ __attribute__((aligned(16))) unsigned long long remN[NMS_SC_WORDS];   // ... of the next one, from the rows kept before this one
+  __shared__ unsigned long long s_keptm[NMS_SC_WORDS];
+  __shared__ int s_ready, s_folded[NMS_SC_WORDS], s_tot;
+  __shared__ int32_t s_kidx[NMS_LDS_KEEP];
+  __shared__ __attribute__((aligned(16))) unsigned long long sdT[NMS_SC_WORDS * NMS_SDT_STRIDE];   // [word][row]
+  const bool lds_keep = max_out <= NMS_LDS_KEEP;
+  const int b = blockIdx.x;
+  if (sc_begin > 0 && state[b].done) return;
+  const int cnt = min(counts[b], K);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t* mb = mask + (size_t)b * K * W;
+  int32_t* kidx = keep_idx + (size_t)b * max_out;
+  int total = 0;
+  if (sc_begin == 0) {
+    for (int i = tid; i < max_out; i += NMS_RED_THREADS) kidx[i] = -1;
+  } else {
+    total = state[b].total;
+    if (lds_keep)
+      for (int i = tid; i < total; i += NMS_RED_THREADS) s_kidx[i] = kidx[i];
+  }
+  if (tid < NMS_SC_WORDS) remN[tid] = 0ull;
+  const int nchunks = (cnt + 63) / 64;
+  const int nsc_all = (nchunks + NMS_SC_WORDS - 1) / NMS_SC_WORDS;
+  const int nsc = min(sc_end, nsc_all);
+  // (1) row loads: instruction i of a wave covers rows 64 wave + 8 i .. + 7 of the super-chunk, 8 lanes (word pairs) per row
+  const int lrow = lane >> 3, lp = lane & 7;
+  uint64_t d0[8], d1[8];
+#define NMS_LOAD_ROWS(sc_)                                                                          \
+  do {                                                                                              \
+    const int w0_ = (sc_) * NMS_SC_WORDS, nw_ = min(NMS_SC_WORDS, nchunks - w0_);                   \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                 \
+      const int row_ = min((sc_) * 64 * NMS_SC_WORDS + wave * 64 + 8 * i + lrow, cnt - 1);          \
+      nms_load2<WIDE>(mb + (size_t)row_ * W + w0_, lp, nw_ - 1, d0[i], d1[i]);                      \
+    }                                                                                               \
+  } while (0)
+  if (sc_begin < nsc) NMS_LOAD_ROWS(sc_begin);
+  int pre_hi = 0;            // keep-list rows [0, pre_hi) are already folded into remN for the super-chunk about to start
+  for (int sc = sc_begin; sc < nsc; ++sc) {
+    const int r0 = sc * 64 * NMS_SC_WORDS, w0 = sc * NMS_SC_WORDS;
+    const int nw = min(NMS_SC_WORDS, nchunks - w0);
+    // (1b) rows -> LDS, word-major; words that do not exist (past the list, below the diagonal block) as zeros
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = wave * 64 + 8 * i + lrow, row = r0 + rl;
+      const bool ok0 = row < cnt && 2 * lp < nw && (w0 + 2 * lp) >= (row >> 6);
+      const bool ok1 = row < cnt && 2 * lp + 1 < nw && (w0 + 2 * lp + 1) >= (row >> 6);
+      sdT[(2 * lp) * NMS_SDT_STRIDE + rl] = ok0 ? d0[i] : 0ull;
+      sdT[(2 * lp + 1) * NMS_SDT_STRIDE + rl] = ok1 ? d1[i] : 0ull;
+    }
+    if (tid < NMS_SC_WORDS) { rem[tid] = remN[tid]; remN[tid] = 0ull; s_folded[tid] = 0; }
+    if (tid == 0) s_ready = 0;
+    __syncthreads();
+    // (2) what the look-ahead of the previous round could not know: the rows kept since then
+    if (lds_keep) nms_gather_or<WIDE>(mb, W, w0, nw, s_kidx, pre_hi, total, tid, NMS_RED_THREADS, rem);
+    else nms_gather_or<WIDE>(mb, W, w0, nw, kidx, pre_hi, total, tid, NMS_RED_THREADS, rem);
+    const bool more = sc + 1 < nsc;
+    if (more) NMS_LOAD_ROWS(sc + 1);          // (a) in flight while this super-chunk is resolved
+    __syncthreads();
+    // (3) the 16 chunks
+    if (wave == 0) {
+      int tot = total;
+      uint64_t diag = sdT[lane];                                                  // chunk 0: word 0 of row (0, lane)
+      uint64_t nxt = nw > 1 ? sdT[NMS_SDT_STRIDE + lane] : 0ull;                  // ... and its word 1
+      for (int c = 0; c < nw; ++c) {
+        uint64_t diag_n = 0ull, nxt_n = 0ull;          // the next chunk's operands do not depend on this chunk's outcome
+        if (c + 1 < nw) diag_n = sdT[(c + 1) * NMS_SDT_STRIDE + (c + 1) * 64 + lane];
+        if (c + 2 < nw) nxt_n = sdT[(c + 2) * NMS_SDT_STRIDE + (c + 1) * 64 + lane];
+        if (c >= 2)                                    // chunks 0 .. c-2 folded into word c by its owner; c-1 by this wave
+          while (nms_lds_ld(&s_folded[c]) == 0) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");                 // rem[c] is read after the flag, not before
+        const int nin = min(64, cnt - (w0 + c) * 64);
+        uint64_t alive_v = ~nms_lds_ld(&rem[c]);
+        if (nin < 64) alive_v &= ((1ull << nin) - 1ull);
+        const uint64_t below = (1ull << lane) - 1ull;
+        const bool me_alive = (alive_v >> lane) & 1ull;
+        uint64_t kept = __ballot(me_alive);            // greedy keep inside the chunk as a parallel fixed point (above)
+        for (int it = 0; it < 64; ++it) {
+          const uint64_t next = __ballot(me_alive && (diag & below & kept) == 0ull);
+          if (next == kept) break;
+          kept = next;
+        }
+        const int room = max_out - tot;
+        if (__popcll(kept) > room)
+          kept = __ballot(((kept >> lane) & 1ull) && __popcll(kept & below) < room);
+        const bool mine = (kept >> lane) & 1ull;
+        if (c + 1 < nw) nms_wave_or(&rem[c + 1], mine ? nxt : 0ull);      // in order with this wave's next read of it
+        if (lane == 0) {
+          nms_lds_st(&s_keptm[c], (unsigned long long)kept);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          nms_lds_st(&s_ready, c + 1);
+        }
+        if (mine) {
+          const int slot = tot + __popcll(kept & below);
+          kidx[slot] = (w0 + c) * 64 + lane;
+          if (lds_keep) s_kidx[slot] = (w0 + c) * 64 + lane;
+        }
+        tot += __popcll(kept);
+        if (tot >= max_out) break;
+        diag = diag_n; nxt = nxt_n;
+      }
+      if (!lds_keep) __threadfence();     // the gathers of the next rounds read the keep list from global memory
+      if (lane == 0) {
+        s_tot = tot;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        nms_lds_st(&s_ready, -1);
+      }
+    } else if (wave <= NMS_FOLD_WAVES) {
+      // wave f owns words 1 + f, 1 + f + 4, ...: after chunk c is published it folds the kept rows' owned words >= c + 2,
+      // the one wave 0 needs first (c + 2) first, and then says so
+      for (int c = 0; c + 2 < nw; ++c) {
+        int jf = 1 + wave;
+        while (jf < c + 2) jf += NMS_FOLD_WAVES;
+        uint64_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = jf + NMS_FOLD_WAVES * k;
+          v[k] = j < nw ? sdT[j * NMS_SDT_STRIDE + c * 64 + lane] : 0ull;
+        }
+        int rdy;
+        while ((rdy = nms_lds_ld(&s_ready)) >= 0 && rdy <= c) __builtin_amdgcn_s_sleep(1);
+        if (rdy < 0) break;
+        asm volatile("" ::: "memory");
+        const uint64_t k = nms_lds_ld(&s_keptm[c]);
+        const bool mine = (k >> lane) & 1ull;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = jf + NMS_FOLD_WAVES * q;
+          if (j < nw) nms_wave_or(&rem[j], mine ? v[q] : 0ull);
+        }
+        if (jf == c + 2) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) nms_lds_st(&s_folded[jf], 1);
+        }
+      }
+    } else if (more) {
+      // (b) look-ahead: the next super-chunk's words in every row kept before this one
+      const int w0n = w0 + NMS_SC_WORDS;
+      const int nwn = min(NMS_SC_WORDS, nchunks - w0n), pt = tid - 64 * (NMS_FOLD_WAVES + 1);
+      constexpr int NP = NMS_RED_THREADS - 64 * (NMS_FOLD_WAVES + 1);
+      if (lds_keep) nms_gather_or<WIDE>(mb, W, w0n, nwn, s_kidx, 0, total, pt, NP, remN);
+      else nms_gather_or<WIDE>(mb, W, w0n, nwn, kidx, 0, total, pt, NP, remN);
+    }
+    pre_hi = total;
+    __syncthreads();
+    total = s_tot;
+    if (total >= max_out) break;
+  }
+#undef NMS_LOAD_ROWS
+  if (tid == 0) {
+    keep_count[b] = total;
+    state[b].total = total;
+    state[b].done = (total >= max_out || nsc >= nsc_all) ? 1 : 0;
+  }
+}
+
 extern "C" size_t lmh_nms_workspace_bytes(int B, int K) {
   const size_t W = (size_t)(K + 63) / 64;
   return lmh_align_up((size_t)B * K * W * sizeof(uint64_t), 256) + lmh_align_up(sizeof(nms_state) * (size_t)B, 256);
+}
+
+static void nms_reduce_launch(int B, hipStream_t st, const uint64_t* mask, const int32_t* counts, int K, int W, int max_out,
+                              int sc_begin, int sc_end, nms_state* state, int32_t* keep_idx, int32_t* keep_count) {
+  if (!lmh_opt("nms_pipe"))
+    lmh_launch(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts, K, W, max_out, sc_begin, sc_end, state,
+               keep_idx, keep_count);
+  else if (W & 1)
+    lmh_launch(k_nms_reduce_p<false>, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts, K, W, max_out, sc_begin, sc_end,
+               state, keep_idx, keep_count);
+  else
+    lmh_launch(k_nms_reduce_p<true>, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts, K, W, max_out, sc_begin, sc_end,
+               state, keep_idx, keep_count);
 }
 
 int lmh_nms_impl(const float* boxes, const int32_t* counts, int B, int K, float thr, int max_out,
@@ -471,12 +749,10 @@ int lmh_nms_impl(const float* boxes, const int32_t* counts, int B, int K, float 
   if (sc1 > nsc_all) sc1 = nsc_all;
   const int W1 = sc1 * NMS_SC_WORDS < W ? sc1 * NMS_SC_WORDS : W;
   lmh_launch(k_nms_mask, dim3(W1, W1, B), dim3(64), 0, st, b4, counts, K, W, thr, 0, (const nms_state*)nullptr, mask);
-  lmh_launch(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), 0, st, (const uint64_t*)mask, counts, K, W, max_out, 0, sc1,
-             state, keep_idx, keep_count);
+  nms_reduce_launch(B, st, (const uint64_t*)mask, counts, K, W, max_out, 0, sc1, state, keep_idx, keep_count);
   if (W1 < W) {
     lmh_launch(k_nms_mask, dim3(W - W1, W, B), dim3(64), 0, st, b4, counts, K, W, thr, W1, (const nms_state*)state, mask);
-    lmh_launch(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), 0, st, (const uint64_t*)mask, counts, K, W, max_out, sc1,
-               nsc_all, state, keep_idx, keep_count);
+    nms_reduce_launch(B, st, (const uint64_t*)mask, counts, K, W, max_out, sc1, nsc_all, state, keep_idx, keep_count);
   }
   LMH_CHECK_LAUNCH();
   return LMH_OK;

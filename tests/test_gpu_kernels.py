@@ -94,6 +94,40 @@ def test_nms_full_size_super_chunks(K):
             assert (keep[b, kc[b]:] == -1).all()
 
 
+@pytest.mark.parametrize('pipe,stage_mult', [(1, 0), (0, 0), (1, 2), (1, 1)])
+def test_nms_scan_variants_agree(K, pipe, stage_mult):
+    """The pipelined scan (k_nms_reduce_p: row prefetch, look-ahead gather, wave 0 folding the next word itself), the
+    round-3 scan and the two-stage split (stage B continues from the saved state: the first gather of the pipelined
+    kernel then covers the whole keep list) give the oracle's keep list bit for bit: even and odd row lengths (the
+    16-byte and the 8-byte loads), ragged counts, a count that ends inside the first chunk of a super-chunk, max_out
+    reached inside a chunk, keep lists inside and beyond the LDS mirror."""
+    rs = np.random.RandomState(11)
+    old = K.get_option('nms_pipe'), K.get_option('nms_stage_mult')
+    K.set_option('nms_pipe', pipe)
+    K.set_option('nms_stage_mult', stage_mult)
+    try:
+        for Kn, counts, cases in ((12000, [12000, 1025, 7000], ((0.7, 2000), (0.5, 2500))),
+                                  (4160, [4160, 4097, 1], ((0.7, 700), (0.3, 4160)))):       # W = 188 / 65
+            B = len(counts)
+            boxes = np.zeros((B, Kn, 4), F)
+            for b in range(B):
+                base = rand_boxes(rs, 300 + 900 * b, 1000, 30, 300)
+                boxes[b] = (base[rs.randint(0, base.shape[0], size=Kn)] + rs.randint(-10, 11, size=(Kn, 4))).astype(F)
+            cnt = np.array(counts, np.int32)
+            for thr, max_out in cases:
+                keep, kc = K.nms(T(boxes), T(cnt), thr, max_out)
+                keep, kc = keep.cpu().numpy(), kc.cpu().numpy()
+                for b in range(B):
+                    scores = np.arange(cnt[b], 0, -1).astype(F)
+                    ref = tfops.non_max_suppression(boxes[b, :cnt[b]][:, [1, 0, 3, 2]], scores, max_out, thr)
+                    assert kc[b] == ref.shape[0], (Kn, thr, max_out, b, kc[b], ref.shape[0])
+                    np.testing.assert_array_equal(keep[b, :kc[b]], ref)
+                    assert (keep[b, kc[b]:] == -1).all()
+    finally:
+        K.set_option('nms_pipe', old[0])
+        K.set_option('nms_stage_mult', old[1])
+
+
 # ---------------------------------------------------------- RPN proposal ----
 def _proposal_case(K, feat, A, stride, im, pre, post, thr, zero_wh, seed, **kw):
     rs = np.random.RandomState(seed)
