@@ -30,7 +30,6 @@ static lmh_option g_options[] = {
     {"wino_m", 4},            // Winograd output tile: 4 = F(4x4,3x3) (round 3 default), 2 = F(2x2,3x3)
     {"hs_slab_cap", 2},       // half-storage weight gradient: split-K slabs stay within this multiple of the operand bytes (0: no cap)
     {"nms_stage_mult", 0},    // > 0: NMS in two stages, A = this many x max_out candidates (mask + scan), the rest only if needed; 0: one stage
-    {"nms_pipe", 1},          // NMS scan: 1 = pipelined over the super-chunks (k_nms_reduce_p), 0 = round-3 kernel
     {"head_gemm", 1},         // Linear heads on <= 4096 rows: the split-reduction 32x32 kernel (conv_generic.h k_head_fwd); 0: the tiled / skinny kernels
     {"roi_cs", 0},            // ROI backward slab width (0: automatic, 4: force the 4-channel slab)
     {"roi_mean_cs", -1},      // fused ROI pool+mean (-1: automatic, 0: report unsupported, 4: force 4 channels)

@@ -763,8 +763,25 @@ k_conv_stem7x7s2(lmh_conv_desc d, const float* __restrict__ x, const float* __re
   __shared__ __attribute__((aligned(16))) float Sc[64], Sh[64];                     // BN scale / shift (epilogue)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  for (int i = tid; i < STEM_KP * 64; i += 256) Ws[i] = (i < 147 * 64) ? w[i] : 0.f;
-  if (tid < 64) { Sc[tid] = scale ? scale[tid] : 1.f; Sh[tid] = shift ? shift[tid] : 0.f; }
+  {
+    // the weight matrix goes to LDS with ALL of a thread's loads in flight together (ten float4 + scale / shift).  The
+    // loop it replaces (`Ws[i] = i < 147 * 64 ? w[i] : 0`, one float per trip) compiled to load -> s_waitcnt vmcnt(0) ->
+    // ds_write: forty serial L2 round trips per thread before the first tile, a fifth of the kernel (round 4; ISA check).
+    constexpr int NV = STEM_KP * 64 / 4, NW = 147 * 64 / 4, NQ = (NV + 255) / 256;      // float4 slots: 2560 / 2352 real / 10 per thread
+    f32x4 wv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + 256 * q;
+      wv[q] = *reinterpret_cast<const f32x4*>(w + 4 * min(i, NW - 1));
+    }
+    const float sc_ = (scale && tid < 64) ? scale[tid] : 1.f, sh_ = (shift && tid < 64) ? shift[tid] : 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + 256 * q;
+      if (i < NV) *reinterpret_cast<f32x4*>(&Ws[4 * i]) = (i < NW) ? wv[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 64) { Sc[tid] = sc_; Sh[tid] = sh_; }
+  }
   const float act_lo = d.act ? 0.f : -INFINITY, act_hi = (d.act == 2) ? 6.f : INFINITY;   // branch-free activation
   for (int i = tid; i < 2 * (STEM_PATCH + 64 * 3 + 32); i += 256) (&Ps[0][0])[i] = 0.f;
   const float sub[3] = {in_sub ? in_sub[0] : 0.f, in_sub ? in_sub[1] : 0.f, in_sub ? in_sub[2] : 0.f};

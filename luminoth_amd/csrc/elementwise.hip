@@ -2,6 +2,8 @@
 // sums, BatchNorm parameter gradients, max pooling.
 #include "lmh_common.h"
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: loads stay loads
+
 // ============================================================================
 // elementwise helpers
 // ============================================================================
@@ -76,6 +78,16 @@ k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act, in
 __device__ __forceinline__ float colsum_partial(const float* __restrict__ partial, int nb, int K, int c, int g) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int b = g;
+  // sixteen rows requested together, added in the order of the loop below (same four chains, same sums): with four loads
+  // per trip a thread walked its 64 rows of a 512-row plane as 16 serial round trips of memory latency (round 4)
+  for (; b + 120 < nb; b += 128) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = partial[(size_t)(b + 8 * q) * K + c];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s0 += v[4 * q]; s1 += v[4 * q + 1]; s2 += v[4 * q + 2]; s3 += v[4 * q + 3]; }
+  }
   for (; b + 24 < nb; b += 32) {
     s0 += partial[(size_t)b * K + c];
     s1 += partial[(size_t)(b + 8) * K + c];
@@ -320,6 +332,44 @@ k_maxpool_fwd(const float* __restrict__ x, int N, int H, int W, int C, int ks, i
   }
 }
 
+// 3 x 3 window (every pooling layer of ResNet / VGG16 here): the nine taps are requested together — clamped address,
+// -inf where the tap lies outside the image — instead of load -> wait -> max one tap at a time (nine serial round trips
+// of memory latency per output with the runtime-sized loops above; round 4).  max is exact: same values.
+__global__ void __launch_bounds__(256)
+k_maxpool3_fwd(const float* __restrict__ x, int N, int H, int W, int C, int stride, int pt, int pl, int OH, int OW,
+               float* __restrict__ y) {
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)N * OH * OW * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    int64_t t = i / C4;
+    const int ow = (int)(t % OW); t /= OW;
+    const int oh = (int)(t % OH);
+    const int n = (int)(t / OH);
+    f32x4 v[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int ih = min(max(oh * stride - pt + r, 0), H - 1), iw = min(max(ow * stride - pl + q, 0), W - 1);
+        v[3 * r + q] = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + ih) * W + iw) * C + 4 * c4);
+      }
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int ih = oh * stride - pt + r, iw = ow * stride - pl + q;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          const f32x4 u = v[3 * r + q];
+          m.x = fmaxf(m.x, u.x); m.y = fmaxf(m.y, u.y); m.z = fmaxf(m.z, u.z); m.w = fmaxf(m.w, u.w);
+        }
+      }
+    *reinterpret_cast<f32x4*>(y + (size_t)i * 4) = m;
+  }
+}
+
 // dx must be zeroed by the caller; gradient goes to the first max in (r,s) scan order.
 __global__ void __launch_bounds__(256)
 k_maxpool_bwd(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy, int N,
@@ -353,8 +403,12 @@ extern "C" int lmh_maxpool_fwd(const float* x, int N, int H, int W, int C, int k
   LMH_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && ksize > 0 && stride > 0);
   const int64_t total = (int64_t)N * OH * OW * (C / 4);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  lmh_launch(k_maxpool_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ksize,
-                     stride, pad_top, pad_left, OH, OW, y);
+  if (ksize == 3)
+    lmh_launch(k_maxpool3_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, stride, pad_top, pad_left,
+               OH, OW, y);
+  else
+    lmh_launch(k_maxpool_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C, ksize,
+               stride, pad_top, pad_left, OH, OW, y);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

@@ -166,6 +166,36 @@ k_maxpool_fwd_hs(const void* __restrict__ xv, int N, int H, int W, int C, int ks
     float m[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    if (ks == 3) {
+      // the nine taps requested together (clamped address; a tap outside the image is skipped below) instead of load ->
+      // wait -> max one tap at a time: nine serial round trips of memory latency per output (round 4).  max is exact.
+      f32x4 fa[IN_F32 ? 9 : 1], fb[IN_F32 ? 9 : 1];
+      V8 hv[IN_F32 ? 1 : 9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int ih = min(max(oh * stride - pt + q / 3, 0), H - 1), iw = min(max(ow * stride - pl + q % 3, 0), W - 1);
+        const size_t o = ((size_t)(n * H + ih) * W + iw) * C + 8 * c8;
+        if (IN_F32) {
+          const float* px = reinterpret_cast<const float*>(xv) + o;
+          fa[q] = *reinterpret_cast<const f32x4*>(px);
+          fb[q] = *reinterpret_cast<const f32x4*>(px + 4);
+        } else {
+          hv[q] = *reinterpret_cast<const V8*>(reinterpret_cast<const T*>(xv) + o);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int ih = oh * stride - pt + q / 3, iw = ow * stride - pl + q % 3;
+        if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
+        if (IN_F32) {
+          m[0] = fmaxf(m[0], fa[q].x); m[1] = fmaxf(m[1], fa[q].y); m[2] = fmaxf(m[2], fa[q].z); m[3] = fmaxf(m[3], fa[q].w);
+          m[4] = fmaxf(m[4], fb[q].x); m[5] = fmaxf(m[5], fb[q].y); m[6] = fmaxf(m[6], fb[q].z); m[7] = fmaxf(m[7], fb[q].w);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)hv[q][e]);
+        }
+      }
+    } else
     for (int r = 0; r < ks; ++r) {
       const int ih = oh * stride - pt + r;
       if ((unsigned)ih >= (unsigned)H) continue;

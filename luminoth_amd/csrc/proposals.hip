@@ -68,6 +68,78 @@ __device__ __forceinline__ void cmp_swap(uint64_t& a, uint64_t& b, bool asc) {
   if ((a > b) == asc) { uint64_t t = a; a = b; b = t; }
 }
 
+// LDS phases of the sort (round 4).  Rounds 1-3 ran one compare-exchange pass per barrier — 78 barriers for a 4096-key
+// chunk, each pass two LDS reads + two writes per pair — and filled LDS with a load -> wait -> ds_write loop (8 serial
+// round trips per thread).  Now
+//   * a chunk is loaded with all of a thread's (<= 8) global reads in flight together;
+//   * up to THREE consecutive passes of a merge step (strides j, j/2, j/4) run on registers: a thread owns the 8 keys
+//     that differ in exactly those three index bits (the scheme of k_sort_global_multi, inside LDS): 30 barriers for
+//     the local sort, 4 for a merge tail;
+//   * key i sits at slot i + i / 32: with 8-byte keys and power-of-two strides the plain layout puts a wave's accesses
+//     on a few banks (8 consecutive keys per thread at the smallest strides: 8-way), the skew spreads them.
+#define SORT_SLOT(i_) ((i_) + ((i_) >> 5))
+#define SORT_LDS_KEYS(chunk_) ((chunk_) + ((chunk_) >> 5) + 1)
+
+template <int NT>
+__device__ __forceinline__ void sort_chunk_load(uint64_t* s, const uint64_t* __restrict__ src, int chunk) {
+  uint64_t v[SORT_CHUNK / NT];
+#pragma unroll
+  for (int u = 0; u < SORT_CHUNK / NT; ++u) {
+    const int i = threadIdx.x + u * NT;
+    v[u] = src[min(i, chunk - 1)];
+  }
+#pragma unroll
+  for (int u = 0; u < SORT_CHUNK / NT; ++u) {
+    const int i = threadIdx.x + u * NT;
+    if (i < chunk) s[SORT_SLOT(i)] = v[u];
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void sort_chunk_store(const uint64_t* s, uint64_t* __restrict__ dst, int chunk) {
+#pragma unroll
+  for (int u = 0; u < SORT_CHUNK / NT; ++u) {
+    const int i = threadIdx.x + u * NT;
+    if (i < chunk) dst[i] = s[SORT_SLOT(i)];
+  }
+}
+
+// S passes (strides j, j / 2, ..., j >> (S - 1)) of merge step k over the chunk in LDS; ascending where bit k of the
+// GLOBAL index (gbase + index in the chunk) is clear.  Ends with a barrier.
+template <int S>
+__device__ __forceinline__ void sort_lds_passes(uint64_t* s, int chunk, int gbase, int k, int j) {
+  constexpr int E = 1 << S;
+  const int jl = j >> (S - 1);
+  for (int g = threadIdx.x; g < chunk / E; g += blockDim.x) {
+    const int low = g & (jl - 1);
+    const int base = ((g - low) << S) | low;             // index with the S stride bits clear
+    const bool asc = (((gbase + base) & k) == 0);          // bit k lies above every stride of the step
+    uint64_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = s[SORT_SLOT(base + e * jl)];
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      const int bit = 1 << (S - 1 - q);
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (!(e & bit)) cmp_swap(v[e], v[e | bit], asc);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[SORT_SLOT(base + e * jl)] = v[e];
+  }
+  __syncthreads();
+}
+
+// every pass of merge step k with stride <= j0 (j0 < chunk), three at a time
+__device__ __forceinline__ void sort_lds_step(uint64_t* s, int chunk, int gbase, int k, int j0) {
+  int j = j0;
+  while (j > 0) {
+    if (j >= 4) { sort_lds_passes<3>(s, chunk, gbase, k, j); j >>= 3; }
+    else if (j == 2) { sort_lds_passes<2>(s, chunk, gbase, k, j); j = 0; }
+    else { sort_lds_passes<1>(s, chunk, gbase, k, j); j = 0; }
+  }
+}
+
 // Sort (full network up to k = min(n_pad, SORT_CHUNK)) each chunk in LDS.
 __global__ void __launch_bounds__(SORT_THREADS)
 k_sort_local(uint64_t* __restrict__ keys, int n_pad, int chunk) {
@@ -75,20 +147,11 @@ k_sort_local(uint64_t* __restrict__ keys, int n_pad, int chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
   const size_t base = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * chunk;
-  for (int i = threadIdx.x; i < chunk; i += blockDim.x) s[i] = keys[base + i];
+  sort_chunk_load<SORT_THREADS>(s, keys + base, chunk);
   __syncthreads();
   const int gbase = blockIdx.x * chunk;
-  for (int k = 2; k <= chunk; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < chunk / 2; t += blockDim.x) {
-        const int i = 2 * t - (t & (j - 1));  // index with bit j clear
-        const bool asc = (((gbase + i) & k) == 0);
-        cmp_swap(s[i], s[i + j], asc);
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = threadIdx.x; i < chunk; i += blockDim.x) keys[base + i] = s[i];
+  for (int k = 2; k <= chunk; k <<= 1) sort_lds_step(s, chunk, gbase, k, k >> 1);
+  sort_chunk_store<SORT_THREADS>(s, keys + base, chunk);
 }
 
 // One global compare-exchange pass (stride j >= chunk) of merge step k.
@@ -141,23 +204,16 @@ k_sort_merge_local(uint64_t* __restrict__ keys, int n_pad, int chunk, int k) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
   const size_t base = (size_t)blockIdx.y * n_pad + (size_t)blockIdx.x * chunk;
-  for (int i = threadIdx.x; i < chunk; i += blockDim.x) s[i] = keys[base + i];
+  sort_chunk_load<SORT_THREADS>(s, keys + base, chunk);
   __syncthreads();
-  const bool asc = (((blockIdx.x * chunk) & k) == 0);
-  for (int j = chunk >> 1; j > 0; j >>= 1) {
-    for (int t = threadIdx.x; t < chunk / 2; t += blockDim.x) {
-      const int i = 2 * t - (t & (j - 1));
-      cmp_swap(s[i], s[i + j], asc);
-    }
-    __syncthreads();
-  }
-  for (int i = threadIdx.x; i < chunk; i += blockDim.x) keys[base + i] = s[i];
+  sort_lds_step(s, chunk, blockIdx.x * chunk, k, chunk >> 1);       // k > chunk: one direction for the whole chunk
+  sort_chunk_store<SORT_THREADS>(s, keys + base, chunk);
 }
 
 int lmh_sort_u64_impl(uint64_t* keys, int B, int n_pad, hipStream_t st) {
   if (n_pad <= 1) return LMH_OK;
   const int chunk = n_pad < SORT_CHUNK ? n_pad : SORT_CHUNK;
-  const size_t lds = (size_t)chunk * sizeof(uint64_t);
+  const size_t lds = (size_t)SORT_LDS_KEYS(chunk) * sizeof(uint64_t);
   dim3 gl(n_pad / chunk, B);
   lmh_launch(k_sort_local, gl, dim3(SORT_THREADS), lds, st, keys, n_pad, chunk);
   for (int k = chunk * 2; k <= n_pad; k <<= 1) {
@@ -298,173 +354,17 @@ k_nms_mask(const float4* __restrict__ boxes, const int32_t* __restrict__ counts,
 //    The greedy scan is a dependent chain over the candidates; what round 1 paid for was not that chain but a global
 //    round trip per 64-candidate chunk: after every chunk the kept rows were OR-ed into ALL remaining words of the
 //    removed-bitmap (188 words at 12 000 candidates) although the scan stops after max_out (2000) keeps — 377 us, the
-//    longest kernel of the proposal chain the main stream waits for.  Here
-//      (1) thread t owns row r0 + t of the current super-chunk and holds that row's 16 diagonal-block words in
-//          REGISTERS (one 128-byte read per row, issued before anything depends on it);
-//      (2) the removed-words of the super-chunk start as the OR of those 16 words over every row kept so far
-//          (<= max_out rows x 128 contiguous bytes: one fully parallel gather per super-chunk, not per chunk);
-//      (3) the 16 chunks are then resolved back to back without touching global memory by ONE wave that reads the rows'
-//          words out of LDS (stored word-major: lane-consecutive, conflict-free); kept lanes OR their later words into the
-//          LDS bitmap with ds_or_b64.  No block barrier inside a super-chunk (round 2 had one per chunk).
-//    Global round trips: 2 per 1024 candidates instead of 1 per 64.
+//    longest kernel of the proposal chain the main stream waits for.  Rounds 2-3 (k_nms_reduce, deleted in round 4; git
+//    history): (1) thread t owns row r0 + t of the current super-chunk and reads that row's 16 diagonal-block words;
+//    (2) the removed-words of the super-chunk start as the OR of those 16 words over every row kept so far (one parallel
+//    gather per super-chunk, not per chunk); (3) the 16 chunks are resolved back to back without touching global memory by
+//    ONE wave that reads the rows' words out of LDS (word-major), the greedy keep inside a chunk being a parallel fixed
+//    point on the symmetric diagonal word (2-4 ballots instead of a 64-step serial scan).
 #define NMS_RED_THREADS 1024
 #define NMS_SC_WORDS 16
 #define NMS_LDS_KEEP 2048
 #define NMS_MAX_K (64 * 65535)  // grid.y of k_nms_mask; the mask itself is K*K/8 bytes of the caller's workspace
-__global__ void __launch_bounds__(NMS_RED_THREADS)
-k_nms_reduce(const uint64_t* __restrict__ mask, const int32_t* __restrict__ counts, int K, int W,
-             int max_out, int sc_begin, int sc_end, nms_state* __restrict__ state, int32_t* __restrict__ keep_idx,
-             int32_t* __restrict__ keep_count) {
-  // super-chunks sc_begin .. min(sc_end, end of the list) - 1; stage A (sc_begin == 0) starts the keep list, stage B
-  // continues from `state` and returns at once when stage A finished the scan
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain beside MFMA kernels of other streams: win the issue arbitration
-  __shared__ __attribute__((aligned(16))) unsigned long long rem[NMS_SC_WORDS];
-  __shared__ unsigned long long s_keptm[NMS_SC_WORDS];   // kept mask of chunk c of the current super-chunk, once published
-  __shared__ int s_ready, s_folded[NMS_SC_WORDS];          // chunks published so far (-1: stop) / word j holds every earlier chunk's rows
-  __shared__ int s_tot[NMS_SC_WORDS];          // running total AFTER chunk c of the current super-chunk (one slot per chunk:
-                                               // no slot is rewritten before every wave has read it and passed a barrier)
-  __shared__ int32_t s_kidx[NMS_LDS_KEEP];     // LDS mirror of the kept indices (one global latency less in (2))
-  __shared__ unsigned long long sdT[NMS_SC_WORDS * NMS_RED_THREADS];   // [word][row] of the current super-chunk: 128 KB
-  const bool lds_keep = max_out <= NMS_LDS_KEEP;
-  const int b = blockIdx.x;
-  if (sc_begin > 0 && state[b].done) return;
-  const int cnt = min(counts[b], K);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t* mb = mask + (size_t)b * K * W;
-  int32_t* kidx = keep_idx + (size_t)b * max_out;
-  int total = 0;                               // block-uniform copy of the running total
-  if (sc_begin == 0) {
-    for (int i = tid; i < max_out; i += NMS_RED_THREADS) kidx[i] = -1;
-  } else {
-    total = state[b].total;
-    if (lds_keep)
-      for (int i = tid; i < total; i += NMS_RED_THREADS) s_kidx[i] = kidx[i];
-    __syncthreads();
-  }
-  const int nchunks = (cnt + 63) / 64;                       // mask words >= nchunks were never written
-  const int nsc_all = (nchunks + NMS_SC_WORDS - 1) / NMS_SC_WORDS;
-  const int nsc = min(sc_end, nsc_all);
-  for (int sc = sc_begin; sc < nsc; ++sc) {
-    const int r0 = sc * 64 * NMS_SC_WORDS, w0 = sc * NMS_SC_WORDS;
-    const int nw = min(NMS_SC_WORDS, nchunks - w0);          // words of this super-chunk
-    // (1) this thread's row: words w0 .. w0+nw-1; the mask holds only the upper triangle (word >= row / 64)
-    const int row = r0 + tid;
-    uint64_t d[NMS_SC_WORDS];
-#pragma unroll
-    for (int j = 0; j < NMS_SC_WORDS; ++j) {
-      const bool ok = row < cnt && j < nw && (w0 + j) >= (row >> 6);
-      d[j] = ok ? mb[(size_t)row * W + w0 + j] : 0ull;
-    }
-    // (1b) ... and leaves them in LDS word-major (lane-consecutive: conflict-free) for the wave that resolves the chunks
-#pragma unroll
-    for (int j = 0; j < NMS_SC_WORDS; ++j) sdT[j * NMS_RED_THREADS + tid] = d[j];
-    // (2) removed-words of this super-chunk from every row kept so far (rows < r0: all their words here are valid)
-    if (tid < NMS_SC_WORDS) rem[tid] = 0ull;
-    __syncthreads();
-    const int nkept = total;
-    {
-      // thread = (word wj of the super-chunk, 64 kept rows per pass): its loads are independent of each other (8 in flight),
-      // the OR stays in a register; lanes l, l+16, l+32, l+48 hold the same word and are folded before ONE atomic per wave
-      // and word (round 3: 4 loads per iteration, an LDS atomic per non-zero word: 6 us per super-chunk at 2000 kept rows)
-      const int wj = tid & (NMS_SC_WORDS - 1);
-      uint64_t accw = 0ull;
-      if (wj < nw) {
-#pragma unroll 8
-        for (int r = tid >> 4; r < nkept; r += NMS_RED_THREADS / NMS_SC_WORDS) {
-          const int kr = lds_keep ? s_kidx[r] : kidx[r];
-          accw |= mb[(size_t)kr * W + w0 + wj];
-        }
-      }
-      uint32_t lo = (uint32_t)accw, hi = (uint32_t)(accw >> 32);
-      lo |= __shfl_xor(lo, 16); hi |= __shfl_xor(hi, 16);
-      lo |= __shfl_xor(lo, 32); hi |= __shfl_xor(hi, 32);
-      accw = ((uint64_t)hi << 32) | lo;
-      if (lane < NMS_SC_WORDS && accw) atomicOr(&rem[lane], (unsigned long long)accw);
-    }
-    __syncthreads();
-    // (3) the 16 chunks of this super-chunk.  Wave 0 resolves them in order; wave j (1..15) owns word j: as soon as the kept
-    //     mask of chunk c < j is published it folds the kept rows' word j into rem[j], so that wave 0 finds rem[c + 1]
-    //     complete one LDS hand-shake after it published chunk c (round 3: the kept lanes of wave 0 themselves walked
-    //     the later words, up to 15 dependent LDS reads + atomics per chunk: 0.7 us per chunk).  All 16 waves of the block
-    //     are resident, so the spin-waits cannot deadlock; `s_ready` = chunks published, -1 = stop.
-    if (tid == 0) s_ready = 0;
-    if (tid < NMS_SC_WORDS) s_folded[tid] = 0;
-    __syncthreads();
-    if (wave == 0) {
-      int tot = total;
-      for (int c = 0; c < nw; ++c) {
-        if (c > 0)
-          while (*reinterpret_cast<volatile int*>(&s_folded[c]) == 0) __builtin_amdgcn_s_sleep(1);
-        const int rl = c * 64 + lane;                       // this lane's row inside the super-chunk
-        const uint64_t diag = sdT[c * NMS_RED_THREADS + rl];
-        const int nin = min(64, cnt - (w0 + c) * 64);
-        uint64_t alive_v = ~(*reinterpret_cast<volatile unsigned long long*>(&rem[c]));
-        if (nin < 64) alive_v &= ((1ull << nin) - 1ull);
-        // Greedy NMS inside the chunk as a parallel fixed point instead of a 64-step serial scan (a dependent chain
-        // of ~200 cycles per kept box on one wave: 2000 keeps = the whole 360 us of round 1's kernel).  Candidate i is
-        // kept  <=>  it is alive and no KEPT candidate j < i suppresses it.  With the symmetric diagonal word (bit j of
-        // lane i = IoU(i, j) > thr) that is local to lane i once the kept set K is known:
-        //     K_0 = alive;   K_{t+1} = { i alive : (diag_i & below_i & K_t) == 0 }
-        // Bits only depend on lower bits, so K_t is exact on the first t levels of the suppression chains and the
-        // iteration reaches the greedy answer in (longest chain + 1) ballots — typically 2-4, never more than 64.
-        const uint64_t below = (1ull << lane) - 1ull;
-        const bool me_alive = (alive_v >> lane) & 1ull;
-        uint64_t kept = __ballot(me_alive);
-        for (int it = 0; it < 64; ++it) {
-          const uint64_t next = __ballot(me_alive && (diag & below & kept) == 0ull);
-          if (next == kept) break;
-          kept = next;
-        }
-        const int room = max_out - tot;
-        if (__popcll(kept) > room)                      // the scan stops at max_out: keep the first `room` of them
-          kept = __ballot(((kept >> lane) & 1ull) && __popcll(kept & below) < room);
-        if (lane == 0) {                                // publish: the folding waves pick the kept rows of this chunk up
-          s_keptm[c] = kept;
-          __threadfence_block();
-          *reinterpret_cast<volatile int*>(&s_ready) = c + 1;
-        }
-        if ((kept >> lane) & 1ull) {
-          const int slot = tot + __popcll(kept & below);
-          kidx[slot] = (w0 + c) * 64 + lane;              // kept indices, in order
-          if (lds_keep) s_kidx[slot] = (w0 + c) * 64 + lane;
-        }
-        tot += __popcll(kept);
-        if (tot >= max_out) break;
-      }
-      if (lane == 0) {
-        s_tot[0] = tot;
-        __threadfence_block();
-        *reinterpret_cast<volatile int*>(&s_ready) = -1;   // release whoever still waits (early stop at max_out)
-      }
-    } else if (wave < nw) {
-      const int j = wave;                                  // this wave's word
-      for (int c = 0; c < j; ++c) {
-        const uint64_t v = sdT[j * NMS_RED_THREADS + c * 64 + lane];     // row (c, lane)'s word j: fetched before the wait
-        int rdy;
-        while ((rdy = *reinterpret_cast<volatile int*>(&s_ready)) >= 0 && rdy <= c) __builtin_amdgcn_s_sleep(1);
-        if (rdy < 0) break;          // wave 0 is done with this super-chunk (max_out reached, or its end): rem[] is dead
-        const uint64_t k = *reinterpret_cast<volatile unsigned long long*>(&s_keptm[c]);
-        if (((k >> lane) & 1ull) && v) atomicOr(&rem[j], (unsigned long long)v);
-      }
-      __threadfence_block();         // this wave's LDS atomics are done before the flag is
-      if (lane == 0) *reinterpret_cast<volatile int*>(&s_folded[j]) = 1;
-    }
-    __syncthreads();
-    total = s_tot[0];
-    const bool done = total >= max_out;
-    if (done) break;
-    // the kept indices written above are read back (kidx) by the next super-chunk's gather: same block, global memory
-    __threadfence_block();
-    __syncthreads();
-  }
-  if (tid == 0) {
-    keep_count[b] = total;
-    state[b].total = total;
-    state[b].done = (total >= max_out || nsc >= nsc_all) ? 1 : 0;
-  }
-}
-
-//    Round 4: the same scan as a PIPELINE over the super-chunks (k_nms_reduce_p; `nms_pipe` = 0 selects the kernel above).
+//    Round 4: the same scan as a PIPELINE over the super-chunks (k_nms_reduce_p).
 //    What bounded k_nms_reduce at the train-step size (12 super-chunks, all of them scanned when the RPN is untrained:
 //    215 us on an idle chip) was not the greedy chain but, per super-chunk, three global round trips issued one after
 //    the other by ONE block — the 1024 row reads (a lane per row: 64 different cache lines per wave instruction), the
@@ -722,10 +622,7 @@ extern "C" size_t lmh_nms_workspace_bytes(int B, int K) {
 
 static void nms_reduce_launch(int B, hipStream_t st, const uint64_t* mask, const int32_t* counts, int K, int W, int max_out,
                               int sc_begin, int sc_end, nms_state* state, int32_t* keep_idx, int32_t* keep_count) {
-  if (!lmh_opt("nms_pipe"))
-    lmh_launch(k_nms_reduce, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts, K, W, max_out, sc_begin, sc_end, state,
-               keep_idx, keep_count);
-  else if (W & 1)
+  if (W & 1)
     lmh_launch(k_nms_reduce_p<false>, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts, K, W, max_out, sc_begin, sc_end,
                state, keep_idx, keep_count);
   else

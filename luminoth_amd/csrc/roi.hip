@@ -396,10 +396,25 @@ k_roi_pool_mean_fwd(const float* __restrict__ feat, const float4* __restrict__ r
   const int b = blockIdx.y, c0 = roi_slab_of_block(blockIdx.x, gridDim.x) * CS;
   const int npix = FH * FW;
   const float* fb = feat + (size_t)b * npix * C + c0;
-  for (int i = threadIdx.x; i < npix * CS / 4; i += 1024) {
-    const int pix = i / (CS / 4), part = i - pix * (CS / 4);
-    *reinterpret_cast<float4*>(fslab + (size_t)pix * CS + 4 * part) =
-        *reinterpret_cast<const float4*>(fb + (size_t)pix * C + 4 * part);
+  {
+    // the slab goes from global memory straight into LDS (global_load_lds_dwordx4: a wave instruction fills 1 KB = PPI
+    // pixels x CS channels, lane-linear, which IS the [pixel][CS] layout), every instruction of a wave issued back to
+    // back and awaited once.  The register-staged loop it replaces was load -> wait -> ds_write per float4: eight
+    // serial round trips of memory latency per thread before the first ROI (round 4; ISA check).
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    constexpr int LPP = CS / 4, PPI = 64 / LPP;          // lanes per pixel, pixels per wave instruction
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nins = npix / PPI;
+    const float* src = fb + (size_t)(lane / LPP) * C + 4 * (lane % LPP);
+    for (int k = wave; k < nins; k += 16)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src + (size_t)k * PPI * C), (lds_ptr)(fslab + (size_t)k * PPI * CS), 16, 0, 0);
+    for (int i = nins * PPI * LPP + threadIdx.x; i < npix * LPP; i += 1024) {      // pixels past the last whole instruction
+      const int pix = i / LPP, part = i - pix * LPP;
+      *reinterpret_cast<float4*>(fslab + (size_t)pix * CS + 4 * part) =
+          *reinterpret_cast<const float4*>(fb + (size_t)pix * C + 4 * part);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
   const int nroi = min(roi_count[b], R);

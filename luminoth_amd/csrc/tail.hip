@@ -44,28 +44,54 @@ k_tail_reduce(tail_args a, float* __restrict__ partial) {
   const int c4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
   const bool bn = t.dgamma != nullptr;
   if (rsub < rstep) {
+    // FOUR rows per trip, and four slabs per round of a trip: sixteen float4 loads in flight, every load of a trip in
+    // front of its first store.  The loop this replaces took one row per trip — slab loads four at a time, then w, then
+    // the store, and the next trip's loads behind that store (loads and stores share vmcnt: a vmcnt(0) round trip per
+    // row) — and ran at 2.5 TB/s.  Same additions in the same order: slab 0, 1, 2, ... per element, rows in order.
+    constexpr int RB = 4, SPB = 4;
     for (int cc = c4; cc < K4; cc += tpr) {
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
       if (t.scale) sc = *reinterpret_cast<const float4*>(t.scale + 4 * cc);
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int64_t r = r0 + rsub; r < r1; r += rstep) {
-        const size_t o = (size_t)r * K + 4 * cc;
-        float4 d;
+      for (int64_t rb = r0 + rsub; rb < r1; rb += (int64_t)RB * rstep) {
+        size_t o[RB];
+        float4 d[RB], wv[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) o[u] = (size_t)min(rb + (int64_t)u * rstep, r1 - 1) * K + 4 * cc;   // clamped: result unused
         if (t.splits > 0) {                        // deterministic: slab 0, 1, 2, ... in order
-          d = *reinterpret_cast<const float4*>(t.slabs + o);
-          for (int sp = 1; sp < t.splits; ++sp) {
-            const float4 e = *reinterpret_cast<const float4*>(t.slabs + (size_t)sp * t.n + o);
-            d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+#pragma unroll
+          for (int u = 0; u < RB; ++u) d[u] = *reinterpret_cast<const float4*>(t.slabs + o[u]);
+          for (int sp = 1; sp < t.splits; sp += SPB) {
+            float4 e[SPB][RB];
+#pragma unroll
+            for (int q = 0; q < SPB; ++q)
+#pragma unroll
+              for (int u = 0; u < RB; ++u)
+                e[q][u] = *reinterpret_cast<const float4*>(t.slabs + (size_t)min(sp + q, t.splits - 1) * t.n + o[u]);
+            __builtin_amdgcn_sched_barrier(0);     // all sixteen requested before the first is added (the scheduler sinks loads to their use)
+#pragma unroll
+            for (int q = 0; q < SPB; ++q) {
+              if (sp + q >= t.splits) break;
+#pragma unroll
+              for (int u = 0; u < RB; ++u) { d[u].x += e[q][u].x; d[u].y += e[q][u].y; d[u].z += e[q][u].z; d[u].w += e[q][u].w; }
+            }
           }
         } else {
-          d = *reinterpret_cast<const float4*>(t.dw + o);
+#pragma unroll
+          for (int u = 0; u < RB; ++u) d[u] = *reinterpret_cast<const float4*>(t.dw + o[u]);
         }
-        if (bn) {
-          const float4 wv = *reinterpret_cast<const float4*>(t.w + o);
-          s.x += wv.x * d.x; s.y += wv.y * d.y; s.z += wv.z * d.z; s.w += wv.w * d.w;
+#pragma unroll
+        for (int u = 0; u < RB; ++u) wv[u] = bn ? *reinterpret_cast<const float4*>(t.w + o[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < RB; ++u) asm volatile("" ::"v"(d[u].x), "v"(d[u].y), "v"(d[u].z), "v"(d[u].w), "v"(wv[u].x), "v"(wv[u].y), "v"(wv[u].z), "v"(wv[u].w));
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          if (rb + (int64_t)u * rstep >= r1) break;
+          float4 dd = d[u];
+          if (bn) { s.x += wv[u].x * dd.x; s.y += wv[u].y * dd.y; s.z += wv[u].z * dd.z; s.w += wv[u].w * dd.w; }
+          if (t.scale) { dd.x *= sc.x; dd.y *= sc.y; dd.z *= sc.z; dd.w *= sc.w; }
+          if (t.splits > 0 || t.scale) *reinterpret_cast<float4*>(t.dw + o[u]) = dd;
         }
-        if (t.scale) { d.x *= sc.x; d.y *= sc.y; d.z *= sc.z; d.w *= sc.w; }
-        if (t.splits > 0 || t.scale) *reinterpret_cast<float4*>(t.dw + o) = d;
       }
       if (bn) *reinterpret_cast<float4*>(&scol[rsub * K + 4 * cc]) = s;
     }
@@ -84,6 +110,16 @@ k_tail_reduce(tail_args a, float* __restrict__ partial) {
 __device__ __forceinline__ float tail_colsum(const float* __restrict__ p, int nb, int K, int c, int g) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four independent chains: the loads of a round are in flight together
   int b = g;
+  // sixteen rows requested together, added in the order of the loop below (same four chains, same sums): with four loads
+  // per trip a thread walked its 64 rows of a 512-row plane as 16 serial round trips of memory latency (round 4)
+  for (; b + 120 < nb; b += 128) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = p[(size_t)(b + 8 * q) * K + c];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s0 += v[4 * q]; s1 += v[4 * q + 1]; s2 += v[4 * q + 2]; s3 += v[4 * q + 3]; }
+  }
   for (; b + 24 < nb; b += 32) {
     s0 += p[(size_t)b * K + c];
     s1 += p[(size_t)(b + 8) * K + c];

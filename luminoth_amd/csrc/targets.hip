@@ -334,10 +334,18 @@ k_rpn_target_subsample(lmh_rpn_target_desc d, int N, const int32_t* __restrict__
   const uint32_t seed = seeds[b];
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
   uint32_t cf = 0, cb = 0;
-  for (int i = threadIdx.x; i < N; i += RT_SUB_THREADS) {
-    const float l = lab[i];
-    sl[i] = (int8_t)(int)l;
-    cf += (l == 1.f);
+  for (int i0 = threadIdx.x; i0 < N; i0 += 8 * RT_SUB_THREADS) {      // eight label reads in flight per trip (clamped index)
+    float l[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) l[u] = lab[min(i0 + u * RT_SUB_THREADS, N - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * RT_SUB_THREADS;
+      if (i < N) {
+        sl[i] = (int8_t)(int)l[u];
+        cf += (l[u] == 1.f);
+      }
+    }
   }
   __syncthreads();
   for (int o = 32; o > 0; o >>= 1) cf += __shfl_down(cf, o);

@@ -5,6 +5,7 @@ cd $R
 mkdir -p gpurun_out
 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_ref_tf_golden.py tests/test_gpu_hs.py tests/test_gpu_plan.py -x -q -m gpu 2>&1 | tail -n 15
 python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "matches_oracle" 2>&1 | tail -n 6
+# (the nms_pipe option existed only at that commit: 0 selected the round-3 scan kernel, deleted afterwards)
 for p in 1 0; do LMH_OPT_NMS_PIPE=$p python scripts/bench_nms.py 2>&1 | tail -n 1 | sed "s/^/nms_pipe=$p /"; done
 B="python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-other-configs --no-roofline --phases 20"
 B5="python bench.py --workload frcnn_r50_coco --dtype f16 --steps 60 --warmup 15 --no-cpu-baseline --no-roofline --phases 20"

@@ -94,16 +94,15 @@ def test_nms_full_size_super_chunks(K):
             assert (keep[b, kc[b]:] == -1).all()
 
 
-@pytest.mark.parametrize('pipe,stage_mult', [(1, 0), (0, 0), (1, 2), (1, 1)])
-def test_nms_scan_variants_agree(K, pipe, stage_mult):
-    """The pipelined scan (k_nms_reduce_p: row prefetch, look-ahead gather, wave 0 folding the next word itself), the
-    round-3 scan and the two-stage split (stage B continues from the saved state: the first gather of the pipelined
+@pytest.mark.parametrize('stage_mult', [0, 2, 1])
+def test_nms_scan_variants_agree(K, stage_mult):
+    """The pipelined scan (k_nms_reduce_p: row prefetch, look-ahead gather, wave 0 folding the next word itself) and its
+    two-stage split (stage B continues from the saved state: the first gather of the pipelined
     kernel then covers the whole keep list) give the oracle's keep list bit for bit: even and odd row lengths (the
     16-byte and the 8-byte loads), ragged counts, a count that ends inside the first chunk of a super-chunk, max_out
     reached inside a chunk, keep lists inside and beyond the LDS mirror."""
     rs = np.random.RandomState(11)
-    old = K.get_option('nms_pipe'), K.get_option('nms_stage_mult')
-    K.set_option('nms_pipe', pipe)
+    old = K.get_option('nms_stage_mult')
     K.set_option('nms_stage_mult', stage_mult)
     try:
         for Kn, counts, cases in ((12000, [12000, 1025, 7000], ((0.7, 2000), (0.5, 2500))),
@@ -124,8 +123,7 @@ def test_nms_scan_variants_agree(K, pipe, stage_mult):
                     np.testing.assert_array_equal(keep[b, :kc[b]], ref)
                     assert (keep[b, kc[b]:] == -1).all()
     finally:
-        K.set_option('nms_pipe', old[0])
-        K.set_option('nms_stage_mult', old[1])
+        K.set_option('nms_stage_mult', old)
 
 
 # ---------------------------------------------------------- RPN proposal ----
