@@ -382,7 +382,11 @@ def main():
             dist.all_gather(allc, chk)
             same = all(bool(torch.equal(c, allc[0])) for c in allc)
             res['replicas_identical'] = same
-            assert same, 'data-parallel replicas diverged: parameter checksums %r' % [c.tolist() for c in allc]
+            if not same and rank == 0:
+                # reported on the line (`dist.replicas_identical_after_timed_steps`: false) instead of raised: a diverged
+                # replica set makes the number suspect, but a traceback here would leave the scaling record empty
+                sys.stderr.write('bench.py: WARNING data-parallel replicas diverged: parameter checksums %r\n'
+                                 % [c.tolist() for c in allc])
             dist.barrier()
         return res
 

@@ -46,19 +46,32 @@ __device__ __forceinline__ void hs_mma_stage(const typename HT<DT>::T* __restric
                                              int a_off, int b_off, int lane) {
   typedef typename HT<DT>::V8 V8;
   const int l31 = lane & 31, hi = lane >> 5, swz = (l31 >> 1) & 7;      // (tile offsets are multiples of 32 rows)
+  // The fragments of k-step s + 1 are read while the MFMAs of k-step s issue (two register sets, regions pinned with
+  // sched_barrier).  Round 3 read each k-step's fragments right in front of its MFMAs: the compiler put an
+  // s_waitcnt lgkmcnt(0) before every MFMA pair, i.e. a wave paid the LDS latency (~100+ cycles) for every 64 cycles of
+  // matrix work and only the other block of the CU could fill it (ISA check, round 4).
+  V8 a[2][TM], b[2][TN];
+#define HS_FRAG(set_, s_)                                                                                       \
+  do {                                                                                                          \
+    const int ch_ = ((2 * (s_) + hi) ^ swz) * 8;                                                                \
+    _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                              \
+      a[set_][t] = *reinterpret_cast<const V8*>(&As[(a_off + t * 32 + l31) * HS_BK + ch_]);                     \
+    _Pragma("unroll") for (int t = 0; t < TN; ++t)                                                              \
+      b[set_][t] = *reinterpret_cast<const V8*>(&Bs[(b_off + t * 32 + l31) * HS_BK + ch_]);                     \
+  } while (0)
+  HS_FRAG(0, 0);
 #pragma unroll
   for (int s = 0; s < HS_BK / 16; ++s) {
-    const int ch = ((2 * s + hi) ^ swz) * 8;
-    V8 a[TM], b[TN];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const V8*>(&As[(a_off + t * 32 + l31) * HS_BK + ch]);
-#pragma unroll
-    for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const V8*>(&Bs[(b_off + t * 32 + l31) * HS_BK + ch]);
+    const int cur = s & 1;
+    if (s + 1 < HS_BK / 16) HS_FRAG(cur ^ 1, s + 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[tm], b[tn], acc[tm][tn]);
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[cur][tm], b[cur][tn], acc[tm][tn]);
+    __builtin_amdgcn_sched_barrier(0);
   }
+#undef HS_FRAG
 }
 
 template <int BM, int BN, int NBUF>
@@ -323,6 +336,18 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
 
 template <int BM> __device__ __forceinline__ int hsw_swz(int row) { return BM == 64 ? 4 * ((row >> 1) & 1) : 4 * (row & 3); }
 
+// MFMA with the accumulator in VECTOR registers (gfx950 takes either file).  The column-sum accumulators of k_wgrad_hs_tr are
+// only touched in the blocks of one tile column; through the builtin the compiler gave them VGPR homes and copied all 32 of
+// them to AGPRs and back around the two MFMAs of EVERY k-step (64 v_accvgpr moves + the MFMA result latency): those
+// blocks ran ~3x longer per stage than the others, and a launch ends with its slowest blocks (ISA check, round 4).
+// Inline asm is outside the compiler's hazard tracking: s_nop 1 covers a vector write of an operand right in front, the
+// caller waits out the write-back before it reads the accumulator.
+template <int DT>
+__device__ __forceinline__ void hs_mfma_vgpr(f32x16& c, typename HT<DT>::V8 a, typename HT<DT>::V8 b) {
+  if (DT == 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
 typedef short hs_s16x4 __attribute__((ext_vector_type(4)));
 typedef short hs_s16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ hs_s16x4 hs_tr_read(const void* p) {      // 16-bit elements as raw bits: one builtin for f16 and bf16
@@ -412,7 +437,10 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   // per-channel sums of g: blocks of ONE tile column (tap 0, first channel tile), waves wm == 0, on the matrix pipe
-  const bool do_col = colpart != nullptr && bx == 0 && wm == 0;
+  // (wave-uniform, and told so: as a per-lane condition the branch around the column-sum MFMAs was an exec-mask region whose
+  // accumulators lived in VGPRs and were copied to AGPRs and back — 64 v_accvgpr moves plus the MFMA result latency —
+  // in EVERY k-step of the blocks that carry the sums, i.e. of the blocks every launch ends with; ISA check, round 4)
+  const bool do_col = __builtin_amdgcn_readfirstlane((int)(colpart != nullptr && bx == 0 && wm == 0)) != 0;
   f32x16 cacc[TN];
 #pragma unroll
   for (int t = 0; t < TN; ++t)
@@ -440,45 +468,50 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
     if (t + D < n_st) HSW_ISSUE(cur == 0 ? NBUF - 1 : cur - 1);
     const char* As = reinterpret_cast<const char*>(ring + cur * STAGE);
     const char* Bs = As + A_SZ * 2;
+    // fragments of k-step s + 1 are read (transposing LDS reads) while the MFMAs of k-step s issue: two register sets,
+    // regions pinned with sched_barrier (round 4; before, every MFMA pair sat behind an s_waitcnt lgkmcnt(0))
+    hs_s16x8 ar[2][TM], br[2][TN];
+#define HSW_FRAG(set_, s_)                                                                                      \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                             \
+      const int row = 16 * (s_) + 4 * h + frow;                                                                 \
+      _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {                                                       \
+        const int c = wm * (BM / 2) + tm * 32 + fch;                                                            \
+        const hs_s16x4 v = hs_tr_read(As + row * (BM * 2) + (((c >> 3) ^ hsw_swz<BM>(row)) << 4) + ((c & 7) << 1)); \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) ar[set_][tm][4 * h + e] = v[e];                            \
+      }                                                                                                         \
+      _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) {                                                       \
+        const int c = wn * (BN / 2) + tn * 32 + fch;                                                            \
+        const hs_s16x4 v = hs_tr_read(Bs + row * (BN * 2) + (((c >> 3) ^ hsw_swz<BN>(row)) << 4) + ((c & 7) << 1)); \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) br[set_][tn][4 * h + e] = v[e];                            \
+      }                                                                                                         \
+    }
+    HSW_FRAG(0, 0)
 #pragma unroll
     for (int s = 0; s < HSW_BK / 16; ++s) {
-      hs_s16x8 ar[TM], br[TN];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = 16 * s + 4 * h + frow;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const int c = wm * (BM / 2) + tm * 32 + fch;
-          const hs_s16x4 v = hs_tr_read(As + row * (BM * 2) + (((c >> 3) ^ hsw_swz<BM>(row)) << 4) + ((c & 7) << 1));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ar[tm][4 * h + e] = v[e];
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const int c = wn * (BN / 2) + tn * 32 + fch;
-          const hs_s16x4 v = hs_tr_read(Bs + row * (BN * 2) + (((c >> 3) ^ hsw_swz<BN>(row)) << 4) + ((c & 7) << 1));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) br[tn][4 * h + e] = v[e];
-        }
-      }
+      const int fc = s & 1;
+      if (s + 1 < HSW_BK / 16) { HSW_FRAG(fc ^ 1, s + 1) }
+      __builtin_amdgcn_sched_barrier(0);
       V8 a[TM], b[TN];
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) a[tm] = __builtin_bit_cast(V8, ar[tm]);
+      for (int tm = 0; tm < TM; ++tm) a[tm] = __builtin_bit_cast(V8, ar[fc][tm]);
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b[tn] = __builtin_bit_cast(V8, br[tn]);
+      for (int tn = 0; tn < TN; ++tn) b[tn] = __builtin_bit_cast(V8, br[fc][tn]);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[tm], b[tn], acc[tm][tn]);
       if (do_col) {
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) cacc[tn] = HT<DT>::mfma(ones, b[tn], cacc[tn]);
+        for (int tn = 0; tn < TN; ++tn) hs_mfma_vgpr<DT>(cacc[tn], ones, b[tn]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+#undef HSW_FRAG
     cur = (cur + 1 == NBUF) ? 0 : cur + 1;
   }
 #undef HSW_ISSUE
   const int l31 = lane & 31, rbase = 4 * (lane >> 5);
+  if (do_col) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last column-sum MFMA (inline asm: no hazard tracking) has written back
   if (do_col && lane < 32) {          // every row of cacc holds the column sums; row 0 = register 0 of lanes 0..31
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
