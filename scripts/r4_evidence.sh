@@ -20,6 +20,7 @@ $B --workload frcnn_r101 --dtype f16 --steps 30 --warmup 8 > $O/r04_bench_frcnn_
 $B --workload frcnn_r50_coco > $O/r04_bench_frcnn_r50_coco_f32.json 2>/dev/null
 $B --workload frcnn_r50_coco --dtype f16 > $O/r04_bench_frcnn_r50_coco_f16.json 2>/dev/null
 $B --workload frcnn_r50_coco --dtype bf16 > $O/r04_bench_frcnn_r50_coco_bf16.json 2>/dev/null
+LUMINOTH_AMD_RPN_BWD_SIDE=1 $B --workload frcnn_r50_coco --dtype f16 --no-roofline > $O/r04_bench_frcnn_r50_coco_f16_rpn_bwd_side.json 2>/dev/null
 $B --workload frcnn_r50_coco --dtype f16 --batch 8 --steps 30 --warmup 8 > $O/r04_bench_frcnn_r50_coco_f16_batch8.json 2>/dev/null
 $B --workload frcnn_r50 --batch 8 --steps 30 --warmup 8 --no-other-configs > $O/r04_bench_frcnn_r50_f32_batch8.json 2>/dev/null
 $B --alt --no-other-configs > $O/r04_bench_with_alt.json 2>/dev/null
