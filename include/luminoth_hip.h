@@ -488,6 +488,13 @@ int lmh_rcnn_loss(const float* cls_score, const float* bbox_offsets, const float
                   const float* targets, int B, int R, int C, float sigma, float w_cls, float w_reg,
                   float* losses, float* per_image, float* d_cls_score, float* d_bbox_offsets,
                   lmh_stream_t stream);
+/* The gradient half of lmh_rcnn_loss alone (models/fasterrcnn/rcnn.py:255-411 under TF autodiff, train.py:80): d(w_cls*cls +
+ * w_reg*reg) / d(cls_score, bbox_offsets).  It counts its two normalisers (#labelled, #positive rows per image) from
+ * `labels` itself, so the train step can issue it where the loss sits and the sums (lmh_rcnn_loss with NULL gradient
+ * pointers: reported values only) anywhere behind the RCNN backward.  Same bits as lmh_rcnn_loss's gradients. */
+int lmh_rcnn_loss_grad(const float* cls_score, const float* bbox_offsets, const float* labels,
+                       const float* targets, int B, int R, int C, float sigma, float w_cls, float w_reg,
+                       float* d_cls_score, float* d_bbox_offsets, lmh_stream_t stream);
 /* tf.nn.softmax over the last axis (rcnn.py:206, ssd.py:109). */
 int lmh_softmax(const float* x, int64_t rows, int C, float* y, lmh_stream_t stream);
 

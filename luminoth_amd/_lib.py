@@ -181,6 +181,7 @@ SIGNATURES = {
     'lmh_spatial_mean_bwd': (c_i, [c_f, c_i64, c_i, c_i, c_f, c_f]),
     'lmh_rpn_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
     'lmh_rcnn_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_rcnn_loss_grad': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_fl, c_f, c_f, c_f]),
     'lmh_softmax': (c_i, [c_f, c_i64, c_i, c_f, c_f]),
     'lmh_l2norm_scale_fwd': (c_i, [c_f, c_f, c_i64, c_i, c_fl, c_f, c_f]),
     'lmh_l2norm_scale_bwd_workspace_bytes': (c_sz, [c_i64, c_i]),

@@ -157,10 +157,12 @@ extern "C" int lmh_rpn_loss(const float* cls_score, const float* bbox_pred, cons
 // ---------------------------------------------------------------------------
 // RCNN loss: rows (B,R); a wave per row, lanes over classes.
 // ---------------------------------------------------------------------------
-// 512 threads, not LOSS_THREADS: the batched loads below cost registers, and a 16-wave block that needs ~64 VGPRs per lane
-// waited up to 200 us for a CU with that much room beside the convolution blocks of the other streams (fp32 step); eight
-// waves place at once.
-#define RCNN_LOSS_THREADS 512
+// 256 threads and four rows per trip (81 VGPRs, one wave per SIMD): such a block fits beside two resident MFMA blocks
+// (188-208 VGPRs x 2 waves per SIMD) on any CU.  Rounds 3-4 history: 1024 threads waited up to 200 us for a CU with room
+// beside the convolution blocks of the other streams; 512 threads x 129 VGPRs (eight rows per trip) still needed a CU with
+// only ONE resident MFMA block: 31 us alone, 97-185 us inside the step (profiles/r04_bench_summary.md).
+#define RCNN_LOSS_THREADS 256
+#define RCNN_LOSS_ROWS 4      // rows of a wave per trip (all their loads in flight together)
 __global__ void __launch_bounds__(RCNN_LOSS_THREADS)
 k_rcnn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_offsets,
             const float* __restrict__ labels, const float* __restrict__ targets, int B, int R, int C,
@@ -172,19 +174,19 @@ k_rcnn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_
   const int C1 = C + 1;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (C1 <= 128) {
-    // The rows a wave owns, EIGHT at a time with every load of the eight issued together: two rounds of memory latency per
+    // The rows a wave owns, RCNN_LOSS_ROWS at a time with every load of the batch issued together: two rounds of memory latency per
     // chunk (labels, then scores + the few values only lane 0 consumes, fetched by lanes 0..8) instead of three dependent
     // rounds per row — the kernel is one block per image on the critical proposal -> RCNN chain (56-71 us inside the step
     // before).  Same arithmetic in the same order as the row-by-row loop below: bit-identical sums.
-    for (int r0 = wave; r0 < R; r0 += 8 * nw) {
-      float l[8], s0[8], s1[8], ex[8];
+    for (int r0 = wave; r0 < R; r0 += RCNN_LOSS_ROWS * nw) {
+      float l[RCNN_LOSS_ROWS], s0[RCNN_LOSS_ROWS], s1[RCNN_LOSS_ROWS], ex[RCNN_LOSS_ROWS];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < RCNN_LOSS_ROWS; ++q) {
         const int r = r0 + q * nw;
         l[q] = (r < R) ? labels[(size_t)b * R + r] : -1.f;
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < RCNN_LOSS_ROWS; ++q) {
         const size_t row = (size_t)b * R + r0 + q * nw;
         const bool on = l[q] >= 0.f;
         const float* s = cls_score + row * C1;
@@ -197,7 +199,7 @@ k_rcnn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_
         ex[q] = e;
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < RCNN_LOSS_ROWS; ++q) {
         if (!(l[q] >= 0.f)) continue;              // wave-uniform
         float m = fmaxf(s0[q], s1[q]);
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -257,16 +259,25 @@ k_rcnn_loss(const float* __restrict__ cls_score, const float* __restrict__ bbox_
 __global__ void __launch_bounds__(256)
 k_rcnn_loss_grad(const float* __restrict__ cls_score, const float* __restrict__ bbox_offsets,
                  const float* __restrict__ labels, const float* __restrict__ targets, int B, int R, int C,
-                 float sigma2, float w_cls, float w_reg, const float* __restrict__ per_image,
-                 float* __restrict__ d_cls, float* __restrict__ d_off) {
+                 float sigma2, float w_cls, float w_reg, float* __restrict__ d_cls, float* __restrict__ d_off) {
   __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= (int64_t)B * R) return;
   const int b = (int)(row / R);
   const int C1 = C + 1;
-  const float gc = w_cls / (per_image[b * 4 + 2] * (float)B);
-  const float gr = w_reg / (per_image[b * 4 + 3] * (float)B);
+  // the two normalisers — #labelled and #positive rows of this image — counted by the wave itself from the image's R
+  // labels (1 KB out of L2): the gradients then do not wait for the one-block-per-image sum kernel, which only feeds the
+  // REPORTED loss values and can run anywhere behind (round 4).  Counts are integers: the same floats k_rcnn_loss sums.
+  int n_lab = 0, n_pos = 0;
+  for (int r = lane; r < R; r += 64) {
+    const float lr = labels[(size_t)b * R + r];
+    n_lab += (lr >= 0.f);
+    n_pos += (lr > 0.f);
+  }
+  for (int o = 32; o > 0; o >>= 1) { n_lab += __shfl_xor(n_lab, o); n_pos += __shfl_xor(n_pos, o); }
+  const float gc = w_cls / ((float)n_lab * (float)B);
+  const float gr = w_reg / ((float)n_pos * (float)B);
   const float l = labels[row];
   if (d_cls) {
     const float* s = cls_score + row * C1;
@@ -296,6 +307,13 @@ k_rcnn_loss_grad(const float* __restrict__ cls_score, const float* __restrict__ 
   }
 }
 
+static void rcnn_loss_grad_launch(const float* cls_score, const float* bbox_offsets, const float* labels,
+                                  const float* targets, int B, int R, int C, float sigma, float w_cls, float w_reg,
+                                  float* d_cls_score, float* d_bbox_offsets, hipStream_t st) {
+  lmh_launch(k_rcnn_loss_grad, dim3((unsigned)(((int64_t)B * R + 3) / 4)), dim3(256), 0, st, cls_score, bbox_offsets,
+             labels, targets, B, R, C, sigma * sigma, w_cls, w_reg, d_cls_score, d_bbox_offsets);
+}
+
 extern "C" int lmh_rcnn_loss(const float* cls_score, const float* bbox_offsets, const float* labels,
                              const float* targets, int B, int R, int C, float sigma, float w_cls,
                              float w_reg, float* losses, float* per_image, float* d_cls_score,
@@ -303,13 +321,24 @@ extern "C" int lmh_rcnn_loss(const float* cls_score, const float* bbox_offsets, 
   LMH_CHECK_ARG(cls_score && bbox_offsets && labels && targets && losses && per_image);
   LMH_CHECK_ARG(B > 0 && R > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
+  // gradients first: what follows them on the stream (the RCNN backward) does not need the sums
+  if (d_cls_score || d_bbox_offsets)
+    rcnn_loss_grad_launch(cls_score, bbox_offsets, labels, targets, B, R, C, sigma, w_cls, w_reg, d_cls_score,
+                          d_bbox_offsets, st);
   lmh_launch(k_rcnn_loss, dim3(B), dim3(RCNN_LOSS_THREADS), 0, st, cls_score, bbox_offsets, labels,
                      targets, B, R, C, sigma * sigma, per_image);
-  if (d_cls_score || d_bbox_offsets)
-    lmh_launch(k_rcnn_loss_grad, dim3((unsigned)(((int64_t)B * R + 3) / 4)), dim3(256), 0, st, cls_score,
-                       bbox_offsets, labels, targets, B, R, C, sigma * sigma, w_cls, w_reg, per_image, d_cls_score,
-                       d_bbox_offsets);
   lmh_launch(k_loss_mean, dim3(1), dim3(64), 0, st, per_image, B, w_cls, w_reg, losses);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+extern "C" int lmh_rcnn_loss_grad(const float* cls_score, const float* bbox_offsets, const float* labels,
+                                  const float* targets, int B, int R, int C, float sigma, float w_cls, float w_reg,
+                                  float* d_cls_score, float* d_bbox_offsets, lmh_stream_t stream) {
+  LMH_CHECK_ARG(cls_score && bbox_offsets && labels && targets && (d_cls_score || d_bbox_offsets));
+  LMH_CHECK_ARG(B > 0 && R > 0 && C > 0);
+  rcnn_loss_grad_launch(cls_score, bbox_offsets, labels, targets, B, R, C, sigma, w_cls, w_reg, d_cls_score,
+                        d_bbox_offsets, (hipStream_t)stream);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

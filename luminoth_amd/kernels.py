@@ -1098,6 +1098,19 @@ def rcnn_loss(cls_score, bbox_offsets, labels, targets, num_classes, sigma=1.0, 
     return losses, per_image, d_cls, d_off
 
 
+def rcnn_loss_grad(cls_score, bbox_offsets, labels, targets, num_classes, sigma=1.0, w_cls=1.0, w_reg=1.0):
+    """The gradients of rcnn_loss alone (lmh_rcnn_loss_grad): the fused train step issues them where the loss sits and the
+    reported sums (rcnn_loss(..., want_grad=False)) behind the RCNN backward."""
+    lib = _lib.load()
+    B, R = labels.shape
+    d_cls = torch.empty_like(cls_score)
+    d_off = torch.empty_like(bbox_offsets)
+    check(lib.lmh_rcnn_loss_grad(_p(cls_score), _p(bbox_offsets), _p(labels), _p(targets), B, R, int(num_classes),
+                                 float(sigma), float(w_cls), float(w_reg), _p(d_cls), _p(d_off), _stream()),
+          'lmh_rcnn_loss_grad')
+    return d_cls, d_off
+
+
 def softmax(x):
     lib = _lib.load()
     C = x.shape[-1]

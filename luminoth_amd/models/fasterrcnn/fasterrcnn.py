@@ -44,6 +44,8 @@ RPN_BWD_SIDE = os.environ.get('LUMINOTH_AMD_RPN_BWD_SIDE', 'auto')
 # where the next batch's frozen prefix runs: 'middle' = main stream while it waits for the RCNN branch (rounds 2-3);
 # 'side' / 'aux' = at the START of the step on the weight-gradient / proposal stream, under the trunk forward
 PREFIX_AT = os.environ.get('LUMINOTH_AMD_PREFIX_AT', 'middle')
+# the RCNN loss VALUES (one block per image, reported only) behind the join instead of in front of the RCNN backward
+RCNN_LOSS_LATE = os.environ.get('LUMINOTH_AMD_RCNN_LOSS_LATE', '1') != '0'
 PREFIX_SPLIT = os.environ.get('LUMINOTH_AMD_PREFIX_SPLIT', '0') != '0'      # stem of the next batch right behind the RPN heads
 WINO_BATCH = os.environ.get('LUMINOTH_AMD_WINO_BATCH', '1') != '0'      # transformed Winograd weights of the whole step in two launches
 
@@ -514,7 +516,11 @@ class FasterRCNN(object):
         with torch.cuda.stream(aux):
             self._mark('aux:rcnn_enqueue')
             cp, rcnn_ctx = rcnn.train_fwd(feat, rcnn_tgt, im_shape, bn)
-            rcnn_losses, rcnn_g = rcnn.loss_and_grads(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
+            if RCNN_LOSS_LATE:
+                # gradients only (one grid-wide launch); the reported sums — a one-block-per-image kernel — behind the join
+                rcnn_losses, rcnn_g = None, rcnn.loss_grads(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
+            else:
+                rcnn_losses, rcnn_g = rcnn.loss_and_grads(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
             self._mark('aux:rcnn_loss_done')
             d_feat = rcnn.train_bwd(rcnn_ctx, rcnn_g[0], rcnn_g[1], addend=d_feat_rpn,
                                     before_pool_bwd=lambda: K.stream_wait(aux, rpn_bwd_stream))
@@ -532,6 +538,8 @@ class FasterRCNN(object):
         self._mark('joined')
         with torch.cuda.stream(aux):
             # the loss scalars are only reported: built on the stream that has nothing else to do
+            if rcnn_losses is None:
+                rcnn_losses = rcnn.loss_values(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
             reg = K.l2_reg_loss(self.store.flat, self.store.seg_offset, self.store.seg_wd)
             sums = K.loss_sums([rpn_losses['rpn_cls_loss'], rpn_losses['rpn_reg_loss'],
                                 rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']], reg, self._frozen_reg_tensor())

@@ -229,6 +229,22 @@ class RCNN(object):
                                               want_grad=True)
         return {'rcnn_cls_loss': losses[0], 'rcnn_reg_loss': losses[1]}, (d_cls, d_off)
 
+    def loss_grads(self, prediction_dict, w_cls=1.0, w_reg=1.0):
+        """The gradient half of loss_and_grads alone: one grid-wide launch that counts its own normalisers, so the RCNN
+        backward queued behind it does not wait for the one-block-per-image sum kernel (loss_values, reported only)."""
+        cs, bo = prediction_dict['rcnn']['cls_score'], prediction_dict['rcnn']['bbox_offsets']
+        return K.rcnn_loss_grad(cs.detach().contiguous(), bo.detach().contiguous(), prediction_dict['target']['cls'],
+                                prediction_dict['target']['bbox_offsets'], self._num_classes, float(self._l1_sigma),
+                                float(w_cls), float(w_reg))
+
+    def loss_values(self, prediction_dict, w_cls=1.0, w_reg=1.0):
+        """The reported half: rcnn.py:255-411 without gradients."""
+        cs, bo = prediction_dict['rcnn']['cls_score'], prediction_dict['rcnn']['bbox_offsets']
+        losses = K.rcnn_loss(cs.detach().contiguous(), bo.detach().contiguous(), prediction_dict['target']['cls'],
+                             prediction_dict['target']['bbox_offsets'], self._num_classes, float(self._l1_sigma),
+                             float(w_cls), float(w_reg), want_grad=False)[0]
+        return {'rcnn_cls_loss': losses[0], 'rcnn_reg_loss': losses[1]}
+
     def loss(self, prediction_dict, w_cls=1.0, w_reg=1.0):
         """rcnn.py:255-411; batch mean over images; weights per fasterrcnn.py:194-201."""
         losses = A.RcnnLossFn.apply(prediction_dict['rcnn']['cls_score'], prediction_dict['rcnn']['bbox_offsets'],

@@ -515,6 +515,11 @@ def test_rcnn_loss(K):
     np.testing.assert_allclose(float(losses.sum()), float(tot), rtol=1e-5)
     np.testing.assert_allclose(dc.cpu().numpy(), st.grad.numpy(), rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(do.cpu().numpy(), ot_.grad.numpy(), rtol=1e-4, atol=1e-8)
+    # the gradient half alone (it counts its own normalisers) and the value half alone give the same bits
+    dc2, do2 = K.rcnn_loss_grad(T(score), T(off), T(labels), T(tg), C, sigma=1.0)
+    assert torch.equal(dc2, dc) and torch.equal(do2, do)
+    losses2, per2, _, _ = K.rcnn_loss(T(score), T(off), T(labels), T(tg), C, sigma=1.0, want_grad=False)
+    assert torch.equal(losses2, losses) and torch.equal(per2, per)
     y = K.softmax(T(score)).cpu().numpy()
     np.testing.assert_allclose(y, tfops.softmax(score), rtol=1e-5, atol=1e-7)
 
