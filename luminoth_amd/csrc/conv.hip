@@ -196,7 +196,7 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
   int bm, bn;
   pick_tile(M, d->K, &bm, &bn);
   hipStream_t st = (hipStream_t)stream;
-  if (stem_fast(d) && residual == nullptr && !g_force_bm) {   // ResNet conv1: dedicated persistent kernel
+  if (stem_fast(d) && residual == nullptr && !g_force_bm && ((uintptr_t)w & 15) == 0) {   // ResNet conv1: dedicated persistent kernel (reads w as float4)
     const int tiles_h = (d->OH + STEM_TH - 1) / STEM_TH, tiles_w = (d->OW + STEM_TW - 1) / STEM_TW;
     const int ntiles = d->N * tiles_h * tiles_w;
     const int grid1 = ntiles < 512 ? ntiles : 512;   // 2 resident blocks per CU (61 KB LDS each)

@@ -622,7 +622,7 @@ extern "C" size_t lmh_nms_workspace_bytes(int B, int K) {
 
 static void nms_reduce_launch(int B, hipStream_t st, const uint64_t* mask, const int32_t* counts, int K, int W, int max_out,
                               int sc_begin, int sc_end, nms_state* state, int32_t* keep_idx, int32_t* keep_count) {
-  if (W & 1)
+  if ((W & 1) || ((uintptr_t)mask & 15))      // odd row length or a mask that is not 16-byte aligned: 8-byte loads
     lmh_launch(k_nms_reduce_p<false>, dim3(B), dim3(NMS_RED_THREADS), 0, st, mask, counts, K, W, max_out, sc_begin, sc_end,
                state, keep_idx, keep_count);
   else
