@@ -259,3 +259,68 @@ def test_get_config_requires_model_type():
     with pytest.raises(KeyError):
         get_config({'train': {'seed': 0}})
     assert get_config({'model': {'type': 'ssd'}}).model.type == 'ssd'
+
+
+def test_lds_sort_pass_grouping_sorts():
+    """Host twin of the LDS phases of the u64 sort (csrc/proposals.hip: sort_lds_passes / sort_lds_step, round 4): up to
+    three compare-exchange passes of a bitonic merge step run on the 2^S keys a thread owns (the keys that differ in exactly
+    the S stride bits), the remainder of a step as a group of two or one.  The index arithmetic — group g -> base with the
+    stride bits cleared, direction from bit k of the GLOBAL index, stride-j0 >= chunk passes done globally — is restated
+    here and must sort; the device kernels are pinned against np.sort in tests/test_gpu_kernels.py::test_sort_u64."""
+    import numpy as np
+
+    def passes(s, chunk, gbase, k, j, S):
+        E, jl = 1 << S, j >> (S - 1)
+        for g in range(chunk // E):
+            low = g & (jl - 1)
+            base = ((g - low) << S) | low
+            asc = ((gbase + base) & k) == 0
+            idx = [base + e * jl for e in range(E)]
+            v = [s[i] for i in idx]
+            for q in range(S):
+                bit = 1 << (S - 1 - q)
+                for e in range(E):
+                    if not (e & bit) and (v[e] > v[e | bit]) == asc:
+                        v[e], v[e | bit] = v[e | bit], v[e]
+            for i, x in zip(idx, v):
+                s[i] = x
+
+    def step(s, chunk, gbase, k, j0):
+        j = j0
+        while j > 0:
+            if j >= 4:
+                passes(s, chunk, gbase, k, j, 3)
+                j >>= 3
+            elif j == 2:
+                passes(s, chunk, gbase, k, j, 2)
+                j = 0
+            else:
+                passes(s, chunk, gbase, k, j, 1)
+                j = 0
+
+    rs = np.random.RandomState(5)
+    for n, chunk in ((2, 2), (8, 8), (64, 64), (256, 64), (1024, 128), (2048, 2048), (4096, 512)):
+        keys = [int(x) for x in rs.randint(0, 1000, size=n)]
+        ref = sorted(keys)
+        for c0 in range(0, n, chunk):                       # k_sort_local
+            s = keys[c0:c0 + chunk]
+            k = 2
+            while k <= chunk:
+                step(s, chunk, c0, k, k >> 1)
+                k <<= 1
+            keys[c0:c0 + chunk] = s
+        k = chunk * 2
+        while k <= n:                                       # global passes + k_sort_merge_local
+            j = k >> 1
+            while j >= chunk:
+                for t in range(n // 2):
+                    i = 2 * t - (t & (j - 1))
+                    if (keys[i] > keys[i + j]) == ((i & k) == 0):
+                        keys[i], keys[i + j] = keys[i + j], keys[i]
+                j >>= 1
+            for c0 in range(0, n, chunk):
+                s = keys[c0:c0 + chunk]
+                step(s, chunk, c0, k, chunk >> 1)
+                keys[c0:c0 + chunk] = s
+            k <<= 1
+        assert keys == ref, (n, chunk)
