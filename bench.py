@@ -15,14 +15,22 @@ Weak scaling: per-GPU batch fixed, gradients all-reduced over RCCL (bucketed, ov
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
   roofline     — the convolution MFMA kernel class with the LARGEST time per step (over forward, backward-data and
-                 backward-weight classes alike): FLOPs the launch executes / mean launch duration vs the dense MFMA
-                 peak of the compute dtype.  Durations are HIP events recorded by the C library on the launch stream
-                 directly around that kernel, in profiling steps run right after the timed region with the
-                 weight-gradient / proposal side streams SERIALISED onto one stream (un-overlapped timing; the timed
-                 region itself uses the production multi-stream schedule).  `whole_step` = algorithmic conv FLOPs of
-                 the step / timed step time.
+                 backward-weight classes alike): FLOPs (or, for a kernel whose HBM time exceeds its MFMA time, algorithmic
+                 bytes) of one launch / its mean launch duration vs the peak.  The launch duration comes from profiling
+                 steps run right after the timed region with the weight-gradient / proposal side streams SERIALISED onto
+                 one stream (un-overlapped timing; the timed region itself uses the production multi-stream schedule),
+                 measured twice: (1) HIP events recorded by the C library on the launch stream directly around the kernel
+                 (`frac_raw_event_interval`), (2) at N = 1, the same steps in a child process under
+                 `rocprofv3 --kernel-trace --stats` ON THIS BOX IN THIS RUN (`frac_rocprofv3`, kernel begin / end
+                 timestamps).  `frac` = (2) when the profiler ran, else (1); `frac_source` says which.  Nothing on the line
+                 is read from a committed profile except `traffic` (PMC bytes need separate `--pmc` passes:
+                 scripts/r5_evidence.sh -> profiles/r05_pmc.json, `traffic_source`).
+                 `whole_step` = algorithmic conv FLOPs of the step / timed step time.
   cpu_baseline — the CPU oracle (oracle/, kind "port": the TF reference cannot run here) timed on this host's
                  cores on a bounded sample: 1 warm-up + median of 5 steps, and a 1-thread step beside it.
+  dist         — N > 1: which exchange mode produced `value` (`mode`), the modes that failed before it (`fallbacks`: the
+                 ladder bucketed all-reduce + launch plan -> one all-reduce + launch plan -> one all-reduce, eager
+                 launches), replica bit-identity after the timed steps, the collective timeout.
 """
 import argparse
 import json
@@ -174,28 +182,88 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def rocprof_avg_ms(kernel):
-    """Average duration (ms) of `kernel` in the newest committed rocprofv3 kernel trace of the serialised profiling steps
-    (profiles/*_bench_roofline_steps_kernel_stats.csv: `rocprofv3 --kernel-trace --stats -- python bench.py`, reduced by
-    scripts/make_profile_summary.py) — printed beside the live HIP-event figure so that the two can be compared on the
-    line itself.  (None, None) if absent."""
+def _short_kernel_name(name):
+    name = name.replace('void ', '')
+    i = name.find('(')
+    return (name[:i] if i > 0 else name).replace(' ', '')
+
+
+def reduce_kernel_trace(path, nprof):
+    """rocprofv3 kernel_trace.csv -> {kernel: {'avg_ms', 'calls_per_step'}, '_step_ms': ...} over the dispatches of the LAST
+    `nprof` steps.  A step ends with its optimizer launch (k_sgd_momentum / k_optimizer): model construction, weight
+    upload and the settling steps in front are excluded.  None if the trace holds fewer than nprof + 1 optimizer launches."""
     import csv
+    rows = []
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            rows.append((int(row['Start_Timestamp']), int(row['End_Timestamp']), _short_kernel_name(row['Kernel_Name'])))
+    rows.sort()
+    ends = [i for i, row in enumerate(rows) if 'k_sgd_momentum' in row[2] or 'k_optimizer' in row[2]]
+    if len(ends) < nprof + 1:
+        return None
+    win = rows[ends[-nprof - 1] + 1:ends[-1] + 1]
+    agg = {}
+    for s0, e0, n in win:
+        a = agg.setdefault(n, [0, 0])
+        a[0] += e0 - s0
+        a[1] += 1
+    out = {n: {'avg_ms': t / float(c) * 1e-6, 'calls_per_step': c / float(nprof)} for n, (t, c) in agg.items()}
+    out['_step_ms'] = (win[-1][1] - rows[ends[-nprof - 1]][1]) / float(nprof) * 1e-6
+    return out
+
+
+def rocprof_child(workload, dtype, batch=None, fp32_storage=False, nprof=3, keep_dir=None, timeout=360):
+    """The rocprofv3 figure of the roofline, measured LIVE on this box: runs
+        rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --roofline-child --workload W --dtype D
+    as a child process (the same serialised profiling steps the HIP-event leg times: 2 settling + `nprof` recorded steps on
+    one stream), reads its kernel trace and returns {kernel: {'avg_ms', 'calls_per_step'}} over the dispatches of the LAST
+    `nprof` steps (optimizer launch to optimizer launch), plus '_step_ms' and '_cmd'.  None (with the reason on stderr) if
+    rocprofv3 is missing, fails or times out: the line then says `frac_source: hip_events`.
+    `keep_dir`: copy the raw kernel trace / stats CSVs there (scripts/r5_evidence.sh turns them into profiles/r05_*)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_bench_roofline_steps_kernel_stats.csv')))
-    want = kernel.replace(' ', '')
-    for f in files[::-1]:
-        try:
-            for row in csv.DictReader(open(f)):
-                name = (row.get('Name') or row.get('name') or row.get('kernel') or '').replace(' ', '')
-                if name.startswith('void'):
-                    name = name[4:]
-                if name.split('(')[0] == want:
-                    avg = row.get('AverageNs') or row.get('avg_ns') or row.get('Average')
-                    if avg:
-                        return float(avg) * 1e-6, os.path.relpath(f, ROOT)
-        except Exception:
-            continue
-    return None, None
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        sys.stderr.write('bench.py: rocprofv3 not found; roofline from HIP events only\n')
+        return None
+    tmp = tempfile.mkdtemp(prefix='lmh_rocprof_', dir='/tmp')
+    child = [sys.executable, os.path.abspath(__file__), '--roofline-child', '--workload', workload, '--dtype', dtype,
+             '--roofline-steps', str(nprof)]
+    if batch:
+        child += ['--batch', str(batch)]
+    if fp32_storage:
+        child += ['--fp32-storage']
+    cmd = [exe, '--kernel-trace', '--stats', '--output-format', 'csv', '-d', tmp, '-o', 'rp', '--'] + child
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0:
+            sys.stderr.write('bench.py: rocprofv3 child rc %d: %s\n' % (r.returncode, r.stderr[-600:]))
+            return None
+        traces = glob.glob(os.path.join(tmp, '**', '*kernel_trace.csv'), recursive=True)
+        if not traces:
+            sys.stderr.write('bench.py: rocprofv3 child wrote no kernel trace\n')
+            return None
+        out = reduce_kernel_trace(traces[0], nprof)
+        if out is None:
+            sys.stderr.write('bench.py: rocprofv3 child trace holds fewer than %d optimizer launches\n' % (nprof + 1))
+            return None
+        out['_cmd'] = 'rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ' + ' '.join(child[2:])
+        if keep_dir:
+            os.makedirs(keep_dir, exist_ok=True)
+            for f in glob.glob(os.path.join(tmp, '**', '*.csv'), recursive=True):
+                if f.endswith('kernel_trace.csv') or f.endswith('kernel_stats.csv'):
+                    shutil.copy(f, os.path.join(keep_dir, os.path.basename(f)))
+        return out
+    except Exception as e:          # a profiler problem must never cost the bench line
+        sys.stderr.write('bench.py: rocprofv3 child failed: %r\n' % (e,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def free_port():
@@ -239,6 +307,20 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--no-rocprof', action='store_true',
+                    help='do not run the rocprofv3 child processes; `roofline.frac` then comes from the HIP-event intervals')
+    ap.add_argument('--rocprof-keep', default=None, metavar='DIR',
+                    help='keep the raw kernel trace / stats CSVs of the rocprofv3 children under DIR/<workload>_<dtype>/')
+    ap.add_argument('--roofline-child', action='store_true',
+                    help='(internal) only the serialised roofline profiling steps of --workload / --dtype: the command the '
+                         'parent process runs under rocprofv3')
+    ap.add_argument('--roofline-steps', type=int, default=3, help='serialised profiling steps of the roofline leg')
+    ap.add_argument('--collective-timeout', type=int, default=int(os.environ.get('LUMINOTH_AMD_COLLECTIVE_TIMEOUT', '180')),
+                    help='seconds after which a collective that does not complete aborts the rank (N > 1): a hang becomes '
+                         'a non-zero exit code instead of an empty record')
+    ap.add_argument('--inject-bucket-failure', action='store_true',
+                    help='(test hook) the bucketed gradient exchange raises on its first early bucket: exercises the '
+                         'fall-back ladder bucketed+plan -> one all-reduce+plan -> one all-reduce, eager launches')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -251,9 +333,12 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or run `python bench.py '
                          '--gpus N` and let it spawn them)' % (args.gpus, world))
-    if world > 1:
+    if world > 1 or 'WORLD_SIZE' in os.environ:
         # main, aux, weight-gradient side stream, the bucket stream and RCCL's own: more streams than the 4
-        # hardware queues HIP creates by default (read at runtime initialisation, i.e. before the first cuda call)
+        # hardware queues HIP creates by default (read at runtime initialisation, i.e. before the first cuda call).
+        # Every process started by a launcher (torch.distributed.run sets WORLD_SIZE, also for ONE rank) gets the same
+        # mapping, so the N = 1 point of a scaling run and its N > 1 points differ in the exchange only; the plain
+        # `python bench.py` headline keeps HIP's default (A/B of the two at N = 1: DESIGN.md 8).
         os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -267,10 +352,14 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        import datetime
+        tmo = datetime.timedelta(seconds=max(30, args.collective_timeout))
+        # the watchdog of the NCCL (= RCCL) backend tears the process down when a collective exceeds `tmo`
+        os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
+            dist.init_process_group('nccl', device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     from luminoth_amd import kernels as K
     from luminoth_amd import plan as P
@@ -289,6 +378,38 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    class StepFailure(RuntimeError):
+        """The timed block of one exchange mode failed on some rank (agreed on by all ranks)."""
+
+    if world > 1:
+        # last resort: a hang that no collective timeout sees (a stream waiting for an event that never fires) still ends
+        # the process with a traceback and a non-zero exit code instead of leaving the scaling record empty
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get('LUMINOTH_AMD_BENCH_WATCHDOG', '1500')), exit=True)
+
+    if args.inject_bucket_failure:
+        _orig_launch = T.GradientBuckets._launch
+
+        def _failing_launch(self, lo, hi):
+            raise RuntimeError('injected failure of the bucketed gradient exchange (--inject-bucket-failure)')
+        T.GradientBuckets._launch = _failing_launch
+
+    if args.roofline_child:
+        # what the parent runs under rocprofv3: the serialised profiling steps only (same calls as the HIP-event leg)
+        wl = dict(WORKLOADS[args.workload])
+        if args.batch:
+            wl['batch'] = args.batch
+        cfg, model = build(wl, device, args.dtype, half_storage=not args.fp32_storage)
+        opt = T.get_optimizer(cfg.train, model)
+        images, gts = inputs(wl, 100 + rank, device)
+        serialise(True)
+        for _ in range(2 + args.roofline_steps):
+            T.train_step(model, opt, images, gts)
+        torch.cuda.synchronize()
+        print(json.dumps({'roofline_child': 'ok', 'workload': args.workload, 'dtype': args.dtype,
+                          'steps': args.roofline_steps}))
+        return
 
     def run_workload(name, dtype, steps, warmup, batch=None, want_roofline=True, phases_n=0, keep_sd=False):
         """Build the workload's model, run `warmup` untimed + `steps` timed train steps (barrier + synchronize on both
@@ -315,23 +436,41 @@ def main():
             return T.train_step(model, opt, cur[0], cur[1], next_image=nxt[0], next_gt=nxt[1])
 
         serialise(args.serial)
-        for _ in range(warmup):
-            step_fn()
-        sync()
-        # per-step times: one HIP event per step boundary on the issuing stream (the MEDIAN step time is
-        # reported beside the block mean; the events cost ~2 us of host time each and no GPU time)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-        t0 = time.perf_counter()
-        marks[0].record()
-        for i in range(steps):
-            total, _ = step_fn()
-            marks[i + 1].record()
-        sync()
-        dt = time.perf_counter() - t0
+        failure = None
+        try:
+            for _ in range(warmup):
+                step_fn()
+            sync()
+            # per-step times: one HIP event per step boundary on the issuing stream (the MEDIAN step time is
+            # reported beside the block mean; the events cost ~2 us of host time each and no GPU time)
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            t0 = time.perf_counter()
+            marks[0].record()
+            for i in range(steps):
+                total, _ = step_fn()
+                marks[i + 1].record()
+            sync()
+            dt = time.perf_counter() - t0
+        except Exception as e:      # N > 1: the ladder in main() retries with a simpler exchange; N = 1: re-raised below
+            if world == 1:
+                raise
+            import traceback
+            failure = '%s: %s' % (type(e).__name__, e)
+            sys.stderr.write('bench.py: rank %d: timed block failed:\n%s' % (rank, traceback.format_exc()))
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t[0])
+            # every rank learns whether ANY rank failed (a deterministic failure hits all ranks at the same call, so this
+            # collective pairs up; a one-sided failure ends in the collective timeout and a non-zero exit code)
+            flag = torch.tensor([1.0 if failure else 0.0, dt if not failure else 0.0], dtype=torch.float64)
+            flag = flag.to(device) if dist.get_backend() == 'nccl' else flag
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if float(flag[0]) > 0:
+                K.TAILS.abort()
+                T.install_buckets(None)
+                del model, opt
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                raise StepFailure(failure or 'another rank failed')
+            dt = float(flag[1])
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         loss_val = float(total.detach())
         assert np.isfinite(loss_val), 'train step diverged (loss %r)' % loss_val
@@ -357,7 +496,7 @@ def main():
                 step_fn()
             res['phases'] = {k: round(v, 3) for k, v in sorted(model.phase_times().items(), key=lambda kv: kv[1])}
 
-        nprof = min(steps, 3)
+        nprof = max(1, min(steps, args.roofline_steps))
         if want_roofline:
             # every rank takes the profiling steps (they contain the gradient all-reduce); rank 0 records
             serialise(True)
@@ -370,8 +509,14 @@ def main():
             prof = K._Profile.stop() if rank == 0 else None
             serialise(args.serial)
             if rank == 0 and prof:
-                res['roofline'] = roofline_of(prof, nprof, dtype, dt, steps,
-                                              rocprof_ok=(name == 'frcnn_r50' and dtype == 'f32' and not batch))
+                # ... and the SAME steps once more in a child process under rocprofv3 (kernel begin / end timestamps of this
+                # very box and run: what `frac` is computed from; N = 1 only, like the CPU baseline)
+                rp = None
+                if world == 1 and not args.no_rocprof:
+                    rp = rocprof_child(name, dtype, batch=batch, fp32_storage=args.fp32_storage, nprof=nprof,
+                                       keep_dir=os.path.join(args.rocprof_keep, '%s_%s' % (name, dtype))
+                                       if args.rocprof_keep else None)
+                res['roofline'] = roofline_of(prof, nprof, dtype, dt, steps, rp)
         if world > 1:
             # data-parallel sanity: after the same number of identical updates every replica must hold the SAME bits
             # (seeded init + broadcast, ring all-reduce hands every rank the same sums, one update kernel)
@@ -392,7 +537,7 @@ def main():
             dist.barrier()
         return res
 
-    def roofline_of(prof, nprof, dtype, dt, steps, rocprof_ok=False):
+    def roofline_of(prof, nprof, dtype, dt, steps, rp=None):
         peak = PEAK_TFLOPS[dtype]
         name = max(prof, key=lambda k: prof[k]['ms'])          # the dominant kernel class, whichever pass it is in
         step_flops = sum(v['direct_flops'] for v in prof.values()) / nprof
@@ -400,13 +545,18 @@ def main():
         r = prof[name]
         fl = r['flops'] / r['launches']
         by = r['bytes'] / r['launches']
-        ms = r['ms'] / r['launches']
+        ms_ev = r['ms'] / r['launches']
         ms_raw = r['ms_raw'] / r['launches']
-        achieved = fl / (ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(name)
-        # the committed kernel trace is the one of the DEFAULT line (frcnn_r50, fp32, default batch): the same kernel name on
-        # another workload runs other layer shapes, so no rocprofv3 figure is quoted there
-        rp_ms, rp_src = rocprof_avg_ms(name) if rocprof_ok else (None, None)
+        rk = (rp or {}).get(name.replace(' ', ''))
+        rp_ms = rk['avg_ms'] if rk else None
+        # `frac` is computed from the rocprofv3 kernel duration of THIS run (child process above) whenever the profiler ran;
+        # the HIP-event figures stay beside it, labelled.  Without the profiler (N > 1, --no-rocprof, profiler failure) it is
+        # the RAW event interval — dispatch latency included, a lower bound — never the calibrated one.
+        ms = rp_ms if rp_ms else ms_raw
+        src = ('rocprofv3 --kernel-trace, child process of this run: average duration of the kernel over the dispatches of '
+               '%d serialised steps' % nprof) if rp_ms else 'hip_events: raw interval of an event pair around the kernel (lower bound)'
+        achieved = fl / (ms * 1e-3) / 1e12
         # which roofline bounds this kernel: the larger of its two ideal times (fp32 convolutions are always
         # matrix-bound; with f16 / bf16 operands the tensors in HBM become the limit on the thin layers)
         t_mfma, t_hbm = fl / (peak * 1e12), by / (PEAK_HBM_GBS * 1e9)
@@ -417,11 +567,16 @@ def main():
             unit, pk, per_launch = 'TFLOP/s', peak, fl / 1e12
             bound = {'bound': 'mfma'}
         bound.update({'achieved': per_launch / (ms * 1e-3), 'peak': pk, 'unit': unit, 'frac': per_launch / (ms * 1e-3) / pk,
-                      # the same figure from the event interval as measured (no calibration: a lower bound) and from the
-                      # committed rocprofv3 summary of this command (kernel begin / end timestamps)
-                      'frac_raw_event_interval': per_launch / (ms_raw * 1e-3) / pk,
+                      'frac_source': src,
                       'frac_rocprofv3': (per_launch / (rp_ms * 1e-3) / pk) if rp_ms else None,
-                      'rocprofv3_avg_ms': rp_ms, 'rocprofv3_source': rp_src})
+                      'frac_raw_event_interval': per_launch / (ms_raw * 1e-3) / pk,
+                      'frac_event_interval_minus_empty_pair': per_launch / (ms_ev * 1e-3) / pk,
+                      'rocprofv3': None if not rp else {
+                          'cmd': rp['_cmd'], 'avg_ms': rp_ms, 'calls_per_step': rk['calls_per_step'] if rk else None,
+                          'step_ms_under_profiler': rp['_step_ms'],
+                          'top_kernels': {k: {'avg_us': round(v['avg_ms'] * 1e3, 2), 'calls_per_step': v['calls_per_step']}
+                                          for k, v in sorted(((k, v) for k, v in rp.items() if not k.startswith('_')),
+                                                             key=lambda kv: -kv[1]['avg_ms'] * kv[1]['calls_per_step'])[:8]}}})
         return dict(bound, **{
             'kernel': name, 'traffic': traffic, 'algorithmic_bytes_per_launch': by,
             'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes)',
@@ -429,10 +584,11 @@ def main():
             'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
             'ms_per_launch_raw_event_interval': ms_raw,
             'event_pair_overhead_ms': K._Profile.overhead_ms,
-            'ms_per_step': r['ms'] / nprof,
-            'timing': 'HIP events around the kernel on its launch stream, %d serialised profiling steps; `frac` = minus the '
-                      'interval of an event pair around an EMPTY kernel (dispatch latency, calibrated in this process), '
-                      '`frac_raw_event_interval` = as measured, `frac_rocprofv3` = from the committed kernel trace' % nprof,
+            'ms_per_step': ms * r['launches'] / nprof,
+            'timing': '%d serialised profiling steps (every stream of the step on one); `frac` / `ms_per_launch` from '
+                      '`frac_source`; `frac_raw_event_interval` = HIP events around the kernel on its launch stream, as '
+                      'measured; `frac_event_interval_minus_empty_pair` = the same minus the interval of an event pair around '
+                      'an EMPTY kernel (dispatch latency, calibrated in this process)' % nprof,
             # conv_flops = the ALGORITHMIC count of SURVEY.md 8(d) (direct convolution); executed_flops = what the
             # launched kernels actually multiply (Winograd F(4x4,3x3) layers do 4x fewer): the second is the honest
             # measure of how busy the matrix pipe is, the first of how fast the step's defined work gets done
@@ -450,9 +606,39 @@ def main():
                                      'ms_per_step': v['ms'] / nprof}
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}})
 
-    head = run_workload(args.workload, args.dtype, args.steps, args.warmup, batch=args.batch,
-                        want_roofline=not args.no_roofline, phases_n=args.phases,
-                        keep_sd=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+    # ---- N > 1: first contact with RCCL has a safety net.  The exchange modes, most overlapped first; a mode whose timed
+    # block raises on any rank, or leaves the replicas with different bits, is reported under `dist.fallbacks` and the next
+    # one produces the number (`dist.mode` says which did).  N = 1 has one mode and no collective.
+    ladder = [{}]
+    if world > 1:
+        ladder += [{'LUMINOTH_AMD_BUCKETED_ALLREDUCE': '0'},
+                   {'LUMINOTH_AMD_BUCKETED_ALLREDUCE': '0', 'LUMINOTH_AMD_PLAN': '0'}]
+    fallbacks, head = [], None
+    for li, env in enumerate(ladder):
+        os.environ.update(env)
+        P.ENABLED = os.environ.get('LUMINOTH_AMD_PLAN', '1') != '0'
+        mode = {'bucketed_allreduce_under_backward': world > 1 and os.environ.get('LUMINOTH_AMD_BUCKETED_ALLREDUCE', '1') != '0',
+                'launch_plan': P.ENABLED}
+        try:
+            head = run_workload(args.workload, args.dtype, args.steps, args.warmup, batch=args.batch,
+                                want_roofline=not args.no_roofline, phases_n=args.phases,
+                                keep_sd=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+        except StepFailure as e:
+            fallbacks.append(dict(mode, error=str(e)))
+            head = None
+            continue
+        if world > 1 and head.get('replicas_identical') is False and li + 1 < len(ladder):
+            fallbacks.append(dict(mode, error='replicas diverged after the timed steps'))
+            T.install_buckets(None)
+            head = None
+            torch.cuda.empty_cache()
+            continue
+        head['mode'] = mode
+        break
+    if head is None:
+        if rank == 0:
+            sys.stderr.write('bench.py: every exchange mode failed: %r\n' % (fallbacks,))
+        raise SystemExit(3)
     wl, dt, model = head['wl'], head['dt'], head['model']
     plan_on = head['launch_plan']['enabled']
     schedule = ('three streams; ' + ('recorded launch plan replayed with one host call per step (%d kernel launches per step, '
@@ -494,7 +680,10 @@ def main():
                      'streams': 'issue (high priority), proposal/RCNN (high priority), weight-gradient x2' +
                                 (', gradient-bucket, RCCL internal' if world > 1 else ''),
                      'buckets': getattr(T.ACTIVE_BUCKETS, 'describe', lambda: None)(),
-                     'replicas_identical_after_timed_steps': head.get('replicas_identical')},
+                     'replicas_identical_after_timed_steps': head.get('replicas_identical'),
+                     # which exchange mode produced `value`, and the modes that failed before it (first-contact ladder)
+                     'mode': head['mode'], 'fallbacks': fallbacks,
+                     'collective_timeout_s': args.collective_timeout if world > 1 else None},
         }
         if head.get('phases'):
             out['phases_ms'] = head['phases']
@@ -506,8 +695,12 @@ def main():
         # geometry, 15 + 60 steps (~0.4 s of GPU time), with its own roofline leg.  Every rank runs it (it contains the
         # gradient exchange); reported BESIDE `value`, never as it.
         torch.cuda.empty_cache()
-        o = run_workload('frcnn_r50_coco', 'f16', 60, 15, want_roofline=not args.no_roofline)
-        if rank == 0:
+        try:
+            o = run_workload('frcnn_r50_coco', 'f16', 60, 15, want_roofline=not args.no_roofline)
+        except StepFailure as e:
+            o = None
+            other['frcnn_r50_coco_f16'] = {'error': str(e)}
+        if rank == 0 and o is not None:
             owl = o['wl']
             other['frcnn_r50_coco_f16'] = {
                 'config': 'BASELINE configs[4] (frcnn_r50_coco): fasterrcnn resnet_v1_50, %dx%d (HxW) synthetic, batch %d/GPU, '

@@ -268,6 +268,11 @@ class FasterRCNN(object):
         recorded launch plan with one host call (luminoth_amd/plan.py).  Returns (total_loss, prediction_dict);
         gradients are complete in `self.store.grad` when the caller's stream reaches this point.
 
+        ALIASING: a replayed step returns the tensors of the recorded one — `total_loss`, the loss scalars and every entry
+        of `prediction_dict` are the SAME device buffers each time a plan of that parity runs, rewritten two steps later.
+        Read (or `.clone()`) what you want to keep before calling the step after next; `luminoth_amd.train.run` fetches
+        the loss right away.  Eager steps (plans off, shapes not yet recorded) return fresh tensors.
+
         The process-global tail queue is guarded: if anything raises mid-step (an argument check of a kernel, an
         out-of-memory) it is left inactive and empty, not silently swallowing the tails of whatever backward runs next."""
         try:
@@ -292,23 +297,40 @@ class FasterRCNN(object):
         return wl
 
     # ---- per-shape state of the fused step: buffers at fixed addresses + the recorded plans -------------------------
+    @staticmethod
+    def _gt_bucket(G):
+        """Capacity of the fixed gt buffers for G boxes per image: 8, 16, 32, ... — the number of gt boxes varies from batch
+        to batch with real data, and `gt_count` carries the real counts (the kernels never read a padded row), so it is
+        not part of what identifies a shape."""
+        g = 8
+        while g < G:
+            g *= 2
+        return g
+
     def _state_for(self, B, H, W, G):
         """What one step hands to the next and what the caller hands to a step lives at FIXED addresses, double-buffered
         by step parity p (step n uses slot n % 2 as "current" and fills slot 1 - p for step n + 1): images, gt boxes,
         seeds, the frozen trunk prefix computed one step ahead and the anchor targets computed one step ahead.  A
-        recorded step can therefore be replayed: the addresses it reads and writes mean the same thing every time."""
+        recorded step can therefore be replayed: the addresses it reads and writes mean the same thing every time.
+        One state per (batch, image size, gt capacity bucket); the 4 most recently USED are kept."""
         main = torch.cuda.current_stream(self.device)
         from luminoth_amd.utils import training as _tr
-        key = (B, H, W, G, main.cuda_stream, K.OPTION_VERSION, id(_tr.ACTIVE_BUCKETS), L.SideStream.enabled,
-               getattr(self, '_phase_left', 0) > 0)
+        G = self._gt_bucket(G)
+        # the gradient buckets by GENERATION, not id(): a plan holds closures bound to the buckets object it was recorded
+        # with, and CPython may hand a new object the id of a dead one
+        key = (B, H, W, G, main.cuda_stream, K.OPTION_VERSION, getattr(_tr.ACTIVE_BUCKETS, 'generation', None),
+               L.SideStream.enabled, getattr(self, '_phase_left', 0) > 0)
         states = getattr(self, '_step_state', None)
         if states is None:
             states = self._step_state = {}
         S = states.get(key)
         if S is not None:
+            states[key] = states.pop(key)          # most recently used last
             return S
-        if len(states) >= 4:          # a data loader with many shapes: keep the plans of the most recent ones only
-            states.pop(next(iter(states)))
+        if len(states) >= 4:          # a data loader with many shapes: keep the plans of the most recently used ones only
+            old = states.pop(next(iter(states)))
+            for pl in old['plans'].values():
+                pl.destroy()
         dev = self.device
         bn = self.base_network
         fh, fw = bn.feature_hw(H, W)
@@ -345,40 +367,40 @@ class FasterRCNN(object):
             image = image.unsqueeze(0)
         B, H, W, _ = image.shape
         gt, gt_count = self._pack_gt(gt_boxes, B)
-        G = gt.shape[1]
-        S = self._state_for(B, H, W, G)
+        S = self._state_for(B, H, W, gt.shape[1])
         p = S['n'] & 1
         S['n'] += 1
         main = torch.cuda.current_stream(self.device)
         # ---- this step's inputs: already in slot p if the previous step was told about them, else copied there now
         pf, S['pf'] = S['pf'], None
         have_pf = (pf is not None and pf['slot'] == p and pf['image'] is image_src and pf['image_v'] == image_src._version
-                   and pf['gt'] is gt_boxes and pf['step'] == self._step)
+                   and pf['gt'] is gt_boxes and pf['gt_v'] == self._gt_versions(gt_boxes) and pf['step'] == self._step)
         if not have_pf:
-            S['images'][p].copy_(image, non_blocking=True)
-            S['gt'][p].copy_(gt)
-            S['cnt'][p].copy_(gt_count)
-            S['seeds'][p].copy_(self._image_seeds(B))
+            self._fill_slot(S, p, image, gt, gt_count, B)
         self._step += 1
-        # ---- the next step's inputs into slot 1 - p (its prefix / anchor targets are computed inside this step)
+        # ---- the next step's inputs into the slot that step will read (its prefix / anchor targets are computed inside
+        # this step).  Same shape: the other parity of this state.  Another shape (real data: the image size changes from
+        # batch to batch): the current slot of THAT shape's state — the look-ahead happens either way; only a step whose
+        # next batch has its own shape can be replayed from a plan (a plan bakes in the addresses it writes)
         bn_train = self.base_network.set_bn_mode(True)
         produce = (next_image is not None and next_gt is not None and PREFETCH_PREFIX and torch.is_tensor(next_image)
                    and not bn_train)
+        NS, q = S, 1 - p
         if produce:
             nimg = next_image if next_image.dim() == 4 else next_image.unsqueeze(0)
             ngt, ncnt = self._pack_gt(next_gt, nimg.shape[0])
-            produce = tuple(nimg.shape) == (B, H, W, 3) and ngt.shape[1] == G
+            nB, nH, nW = (int(v) for v in nimg.shape[:3])
+            if (nB, nH, nW, self._gt_bucket(ngt.shape[1])) != S['key'][:4]:
+                NS = self._state_for(nB, nH, nW, ngt.shape[1])
+                q = NS['n'] & 1
         if produce:
-            q = 1 - p
-            S['images'][q].copy_(nimg, non_blocking=True)
-            S['gt'][q].copy_(ngt)
-            S['cnt'][q].copy_(ncnt)
-            S['seeds'][q].copy_(self._image_seeds(B))       # self._step already counts this step: the NEXT step's seeds
-            S['pf'] = dict(slot=q, image=next_image, image_v=next_image._version, gt=next_gt, step=self._step)
+            self._fill_slot(NS, q, nimg, ngt, ncnt, NS['key'][0])    # self._step already counts this step: the NEXT step's seeds
+            NS['pf'] = dict(slot=q, image=next_image, image_v=next_image._version, gt=next_gt,
+                            gt_v=self._gt_versions(next_gt), step=self._step)
         variant = (p, bool(have_pf), bool(produce))
         # host-drawn dropout seeds and the in-place moving averages of training-mode BatchNorm are per-step state a
         # recorded plan would freeze / the look-ahead would advance early: those configurations run every step eagerly
-        plannable = P.ENABLED and self._rcnn._dropout_keep_prob in (None, 1, 1.0) and not bn_train
+        plannable = (P.ENABLED and self._rcnn._dropout_keep_prob in (None, 1, 1.0) and not bn_train and NS is S)
         plan = S['plans'].get(variant) if plannable else None
         if plan is not None:
             self._phase_collect(S, p)
@@ -388,19 +410,51 @@ class FasterRCNN(object):
             return out[0], out[1]
         seen = S['seen'].get(variant, 0)
         S['seen'][variant] = seen + 1
-        if plannable and seen >= P.WARM_STEPS:
+        if plannable and seen >= P.WARM_STEPS and self._plan_budget_left():
             plan = P.StepPlan()
             with plan:
-                out = self._step_body(S, p, have_pf, produce, B, H, W)
+                out = self._step_body(S, p, have_pf, produce, B, H, W, NS, q)
                 plan.result = out
                 plan.keep.append(out)
             S['plans'][variant] = plan
         else:
-            out = self._step_body(S, p, have_pf, produce, B, H, W)
+            out = self._step_body(S, p, have_pf, produce, B, H, W, NS, q)
         self._last_losses = out[2]
         return out[0], out[1]
 
-    def _step_body(self, S, p, have_pf, produce, B, H, W):
+    @staticmethod
+    def _gt_versions(gt):
+        """In-place modification counters of the tensors of a gt argument (a loader that refills its buffers between
+        announcing a batch and passing it must not be served the copy taken earlier); None where nothing can be versioned
+        (numpy arrays, lists of arrays: the identity check is all there is, as for the reference's feed dicts)."""
+        if torch.is_tensor(gt):
+            return gt._version
+        if isinstance(gt, (tuple, list)):
+            return tuple(g._version if torch.is_tensor(g) else None for g in gt)
+        return None
+
+    def _fill_slot(self, S, slot, image, gt, gt_count, B):
+        """The caller's batch into the fixed-address buffers of `slot` (gt rows beyond this batch's Gmax are zeroed: the
+        buffers have the bucket's capacity)."""
+        S['images'][slot].copy_(image, non_blocking=True)
+        G = gt.shape[1]
+        buf = S['gt'][slot]
+        buf[:, :G].copy_(gt)
+        if G < buf.shape[1]:
+            buf[:, G:].zero_()
+        S['cnt'][slot].copy_(gt_count)
+        S['seeds'][slot].copy_(self._image_seeds(B))
+
+    # every tensor whose address entered a recorded launch stays alive with the plan: all activations of a step (~3 GB at
+    # config 2).  LUMINOTH_AMD_PLAN_MAX_GB bounds what the plans of one model may pin; past it new variants run eagerly.
+    PLAN_MAX_BYTES = int(float(os.environ.get('LUMINOTH_AMD_PLAN_MAX_GB', '64')) * (1 << 30))
+
+    def _plan_budget_left(self):
+        from luminoth_amd import plan as P
+        pinned = sum(P.pinned_bytes(pl) for S in self._step_state.values() for pl in S['plans'].values())
+        return pinned < self.PLAN_MAX_BYTES
+
+    def _step_body(self, S, p, have_pf, produce, B, H, W, NS=None, q=None):
         """The device work of one train step on three HIP streams, from / into the fixed-address buffers of `S`:
 
             main : trunk fwd -> RPN convs -> RPN targets -> RPN loss -> RPN backward -> [next batch: frozen prefix] -> trunk backward -> tails
@@ -411,6 +465,8 @@ class FasterRCNN(object):
         Everything here launches through luminoth_amd.kernels (recordable by a launch plan); cross-stream order is
         made with K.stream_wait only.  -> (total_loss, prediction_dict, losses dict)."""
         image, gt, gt_count, seeds = S['images'][p], S['gt'][p], S['cnt'][p], S['seeds'][p]
+        if NS is None:
+            NS, q = S, 1 - p
         im_shape = (H, W)
         main = torch.cuda.current_stream(self.device)
         aux = self._aux_stream()
@@ -439,7 +495,7 @@ class FasterRCNN(object):
             early = SideStream.get(self.device) if PREFIX_AT == 'side' else aux
             K.stream_wait(early, main)
             with torch.cuda.stream(early):
-                self._prefix_forward(0, start, S['images'][1 - p], S['prefix'][1 - p])
+                self._prefix_forward(0, start, NS['images'][q], NS['prefix'][q])
                 self._mark('early:next_prefix_done')
         from luminoth_amd.utils import training as _tr
         # the aux stream is idle once the RCNN branch is done: weight-gradient tails of the trunk backward are finished
@@ -472,7 +528,7 @@ class FasterRCNN(object):
         split_prefix = (produce and start > 2 and PREFIX_AT == 'middle' and PREFIX_SPLIT)
         stem_out = None
         if split_prefix:
-            stem_out, _ = self._sub_trunk(0, 2).forward(S['images'][1 - p], save_from=None)
+            stem_out, _ = self._sub_trunk(0, 2).forward(NS['images'][q], save_from=None)
             self._mark('next_stem_done')
         # Host enqueue order matters while the host is not far ahead of the GPU (eager steps): the proposal chain is
         # ONE C call (cheap to enqueue, long to run), so it goes first; then the RPN branch of the main stream; the
@@ -529,9 +585,9 @@ class FasterRCNN(object):
         # the NEXT step's images (conv1 + fixed blocks: nothing this step's update writes)
         if produce and start > 0 and not (PREFIX_AT in ('side', 'aux') and SideStream.enabled):
             if split_prefix:
-                self._prefix_forward(2, start, stem_out, S['prefix'][1 - p])
+                self._prefix_forward(2, start, stem_out, NS['prefix'][q])
             else:
-                self._prefix_forward(0, start, S['images'][1 - p], S['prefix'][1 - p])
+                self._prefix_forward(0, start, NS['images'][q], NS['prefix'][q])
             self._mark('next_prefix_done')
         # ---- join (the wait captures the aux stream as of NOW: what is queued there below does not delay the trunk backward)
         K.stream_wait(main, aux)
@@ -545,9 +601,9 @@ class FasterRCNN(object):
                                 rcnn_losses['rcnn_cls_loss'], rcnn_losses['rcnn_reg_loss']], reg, self._frozen_reg_tensor())
             # ... and the anchor targets of the NEXT batch (they depend on its gt boxes and this model's seeds only)
             if produce:
-                q = 1 - p
-                rpn.targets({}, self._anchor_ref_i32, (fh, fw), self._anchor_stride, S['gt'][q], S['cnt'][q], S['seeds'][q],
-                            im_shape, out=S['tgt'][q])
+                nH, nW = NS['key'][1], NS['key'][2]          # the next batch may have its own image size
+                rpn.targets({}, self._anchor_ref_i32, bn.feature_hw(nH, nW), self._anchor_stride, NS['gt'][q], NS['cnt'][q],
+                            NS['seeds'][q], (nH, nW), out=NS['tgt'][q])
                 self._mark('aux:next_targets_done')
         total_loss, no_reg_loss, regularization_loss = sums[0], sums[1], sums[2]
         # ---- trunk backward.  Data parallel: the head gradients (RPN on main / side, RCNN joined from aux) are complete

@@ -107,6 +107,28 @@ class StepPlan(object):
             pass
 
 
+def pinned_bytes(plan):
+    """Bytes of device memory `plan` keeps alive (distinct storages among the tensors it holds; cached on the plan)."""
+    n = getattr(plan, '_pinned', None)
+    if n is None:
+        import torch
+        seen, n = set(), 0
+        stack = list(plan.keep)
+        while stack:
+            o = stack.pop()
+            if torch.is_tensor(o):
+                st = o.untyped_storage()
+                if st.data_ptr() not in seen:
+                    seen.add(st.data_ptr())
+                    n += st.nbytes()
+            elif isinstance(o, dict):
+                stack.extend(o.values())
+            elif isinstance(o, (list, tuple)):
+                stack.extend(o)
+        plan._pinned = n
+    return n
+
+
 def recording():
     return _ACTIVE is not None
 

@@ -8,6 +8,7 @@ The optimizer is ONE fused kernel over the flat parameter buffer
 all-reduced with one collective before the update (replaces the reference's
 asynchronous parameter-server exchange, train.py:46,282-326).
 """
+import itertools
 import os
 
 import torch
@@ -65,8 +66,12 @@ class GradientBuckets(object):
     which then is the single all-reduce of the whole buffer.  Every element is reduced exactly once per step
     (tested on one GPU with a stand-in reduce that doubles the range: tests/test_gpu_model.py)."""
 
+    _generations = itertools.count(1)
+
     def __init__(self, store, reduce_fn=None, bucket_bytes=None):
         self.store = store
+        # identifies THIS object in the keys of recorded launch plans (whose cut callbacks are bound to it): never reused
+        self.generation = next(GradientBuckets._generations)
         self.reduce_fn = reduce_fn or self._all_reduce
         if bucket_bytes is None:
             mb = os.environ.get('LUMINOTH_AMD_BUCKET_MB')

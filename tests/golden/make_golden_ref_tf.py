@@ -16,6 +16,18 @@ Reference code executed (loaded BY PATH from /root/reference/luminoth, never cop
     models/ssd/target.py:35-200               SSDTarget._build                                             (S4)
     models/ssd/proposal.py:41-171             SSDProposal._build                                           (S5)
     models/ssd/ssd.py:197-300                 SSD.loss                                                     (S6)
+    models/fasterrcnn/rpn.py:23-217           RPN.__init__ / _instantiate_layers / _build                  (A4)
+    models/fasterrcnn/rcnn.py:41-250          RCNN.__init__ / _instantiate_layers / _build                 (A13)
+    models/ssd/ssd.py:21-195                  SSD.__init__ / _build (multibox heads, anchors, targets,      (S2)
+                                              hard-negative filter, proposals) over GIVEN feature maps
+    utils/vars.py:1-130                       get_initializer / get_activation_function / summaries
+
+The three head `_build`s run on numpy `snt.Conv2D` / `snt.Linear` (tf_numpy_shim.py) whose variables are a fixed
+function of the module NAME (`seeded_variable`), so the replaying tests rebuild the same weights; what they pin is the
+reference's composition: which output channel is which anchor / class / coordinate after its reshapes and concats
+(`(N,2)` / `(N,4)`, `(R,C+1)` / `(R,4C)`, the flatten order in front of the FC stack, the order of the six multibox
+heads and of their anchors).  `SSDFeatureExtractor` (slim VGG: third party, absent) is replaced by a stand-in that returns
+the fixture's feature maps; `base_network._build_tail` by the identity (the ResNet-50 / VGG case: no tail).
 
 `tf.random_shuffle` (rpn_target.py:206,243; rcnn_target.py:172,223) is handed the permutation "descending
 (hash(seed, stream, index), index)" of the shared counter RNG (oracle/rng.py == csrc/lmh_common.h lmh_hash_u32): the
@@ -62,7 +74,8 @@ def load_reference():
             sys.modules[name] = tf._Inert(name)
         sys.modules[name].__path__ = []
     mods = {}
-    for rel in ('utils/bbox_transform_tf.py', 'utils/bbox_transform.py', 'utils/bbox_overlap.py', 'utils/losses.py',
+    for rel in ('utils/vars.py', 'models/ssd/utils.py',
+                'utils/bbox_transform_tf.py', 'utils/bbox_transform.py', 'utils/bbox_overlap.py', 'utils/losses.py',
                 'models/fasterrcnn/rpn_target.py', 'models/fasterrcnn/rpn_proposal.py',
                 'models/fasterrcnn/rcnn_target.py', 'models/fasterrcnn/rcnn_proposal.py',
                 'models/fasterrcnn/roi_pool.py', 'models/fasterrcnn/rpn.py', 'models/fasterrcnn/rcnn.py',
@@ -420,6 +433,124 @@ def gen_ssd(m, out):
         print('ssd_proposal %-10s -> %3d detections' % (name, r['objects'].shape[0]))
 
 
+# ------------------------------------------------------------------------------------------ head layouts ----
+INIT = {'type': 'random_normal_initializer', 'mean': 0.0, 'stddev': 0.01}
+
+
+def gen_heads(m, out):
+    """RPN._build, RCNN._build and SSD._build executed as they are (VERDICT r4 next #6)."""
+    # ---- RPN (rpn.py:96-217): 3x3 conv + relu6, 1x1 cls / bbox convs, reshape to (N,2) / (N,4), softmax, proposals, targets
+    rs = np.random.RandomState(1000)
+    fh, fw, cin, stride = 6, 8, 16, 16
+    H, W = fh * stride, fw * stride
+    ref_i32, anchors = anchor_grid(64, [0.5, 1, 2], [0.25, 0.5, 1, 2], fh, fw, stride)
+    feat = rs.randn(1, fh, fw, cin).astype(F)
+    gt = np.concatenate([rand_boxes(rs, 3, W, H, 16, 64), rs.randint(0, 5, size=(3, 1))], 1).astype(F)
+    prop_cfg = dict(pre_nms_top_n=12000, post_nms_top_n=2000, apply_nms=True, nms_threshold=0.7, min_size=0,
+                    filter_outside_anchors=False, clip_after_nms=False, min_prob_threshold=0.0)
+    tgt_cfg = dict(allowed_border=0, clobber_positives=False, foreground_threshold=0.7,
+                   background_threshold_high=0.3, foreground_fraction=0.5, minibatch_size=256)
+    cfg = ED(num_channels=24, kernel_shape=[3, 3], rpn_initializer=INIT, cls_initializer=INIT, bbox_initializer=INIT,
+             l2_regularization_scale=0.0005, l1_sigma=3.0, activation_function='relu6', proposals=prop_cfg, target=tgt_cfg)
+    seed = orng.image_seed(7, 0, 0)
+    inside = np.where((anchors[:, 0] >= 0) & (anchors[:, 1] >= 0) & (anchors[:, 2] < W) & (anchors[:, 3] < H))[0]
+    tf.set_random_shuffle(shuffle_by_counter_rng(
+        seed, {'subsample_positive': orng.STREAM_RPN_FG, 'subsample_negative': orng.STREAM_RPN_BG}, inside))
+    rpn = m['rpn'].RPN(ref_i32.shape[0], cfg, debug=False, seed=None)
+    r = rpn(feat, np.array([H, W], np.int32), anchors, gt_boxes=gt, is_training=True)
+    k = 'heads/rpn/'
+    out[k + 'feat'], out[k + 'gt'], out[k + 'ref_i32'] = feat, gt, ref_i32
+    out[k + 'geom'] = np.array([fh, fw, stride, H, W, cfg.num_channels], np.int32)
+    out[k + 'seed'] = np.array([seed], np.uint32)
+    for key in ('rpn_cls_score', 'rpn_cls_prob', 'rpn_bbox_pred', 'proposals', 'scores', 'rpn_cls_target', 'rpn_bbox_target'):
+        out[k + key] = r[key]
+    assert r['rpn_cls_score'].shape == (fh * fw * 12, 2) and r['rpn_bbox_pred'].shape == (fh * fw * 12, 4)
+    print('heads/rpn: N=%d proposals=%d fg=%d' % (anchors.shape[0], r['proposals'].shape[0], (r['rpn_cls_target'] == 1).sum()))
+
+    # ---- RCNN (rcnn.py:112-250), the two configurations of the sample configs: spatial mean and no FC stack (ResNet),
+    # flattened 7x7xC features through two FC layers (VGG)
+    class NoTail(object):          # truncated_base_network.py:56-63 returns its input unless the architecture is resnet_v1_101
+        @staticmethod
+        def _build_tail(inputs, is_training=False):
+            return inputs
+    C = 5
+    for name, use_mean, sizes, cf in (('mean', True, [], 12), ('flatten_fc', False, [32, 24], 6)):
+        rs = np.random.RandomState(1100 + len(name))
+        fh, fw = 10, 12
+        H, W = fh * 16, fw * 16
+        feat = rs.randn(1, fh, fw, cf).astype(F)
+        G, P = 4, 90
+        gt = np.concatenate([rand_boxes(rs, G, W, H, 24, 96), rs.randint(0, C, size=(G, 1))], 1).astype(F)
+        jit = gt[rs.randint(0, G, size=P // 3), :4] + rs.randint(-8, 9, size=(P // 3, 4))
+        props = np.concatenate([jit, rand_boxes(rs, P - P // 3, W, H, 12, 120)], 0).astype(F)[rs.permutation(P)]
+        t_cfg = dict(foreground_fraction=0.25, minibatch_size=32, foreground_threshold=0.5,
+                     background_threshold_high=0.5, background_threshold_low=0.0)
+        p_cfg = dict(class_max_detections=100, class_nms_threshold=0.5, total_max_detections=300, min_prob_threshold=0.5)
+        cfg = ED(layer_sizes=sizes, activation_function='relu', dropout_keep_prob=1.0, use_mean=use_mean,
+                 target_normalization_variances=[0.1, 0.2], rcnn_initializer=INIT, cls_initializer=INIT,
+                 bbox_initializer=INIT, l2_regularization_scale=0.0005, l1_sigma=1.0,
+                 roi=dict(pooling_mode='crop', pooled_width=7, pooled_height=7, padding='VALID'), target=t_cfg,
+                 proposals=p_cfg)
+        seed = orng.image_seed(8, 1, 0)
+        tf.set_random_shuffle(shuffle_by_counter_rng(
+            seed, {'disable_some_fgs': orng.STREAM_RCNN_FG, 'disable_some_bgs': orng.STREAM_RCNN_BG}))
+        rcnn = m['rcnn'].RCNN(C, cfg, debug=False, seed=None)
+        r = rcnn(feat, props, np.array([H, W], np.int32), NoTail(), gt_boxes=gt, is_training=True)
+        k = 'heads/rcnn_%s/' % name
+        out[k + 'feat'], out[k + 'gt'], out[k + 'proposals'] = feat, gt, props
+        out[k + 'geom'] = np.array([H, W, C, int(use_mean)] + sizes, np.int32)
+        out[k + 'seed'] = np.array([seed], np.uint32)
+        out[k + 'target_cls'], out[k + 'target_bbox'] = r['target']['cls'], r['target']['bbox_offsets']
+        out[k + 'cls_score'], out[k + 'cls_prob'] = r['rcnn']['cls_score'], r['rcnn']['cls_prob']
+        out[k + 'bbox_offsets'] = r['rcnn']['bbox_offsets']
+        n = r['target']['cls'].shape[0]
+        assert r['rcnn']['cls_score'].shape == (n, C + 1) and r['rcnn']['bbox_offsets'].shape == (n, 4 * C)
+        print('heads/rcnn_%-10s rois=%d fg=%d' % (name, n, (r['target']['cls'] > 0).sum()))
+
+    # ---- SSD (ssd/ssd.py:37-195) over given feature maps: six multibox head pairs, reshape + concat, anchors, targets with
+    # the hard-negative filter (training) / proposals (inference)
+    import collections
+    C = 4
+    shapes = [(5, 5, 8), (3, 3, 12), (2, 2, 8), (2, 2, 6), (1, 1, 6), (1, 1, 4)]
+    app = [4, 6, 6, 6, 4, 4]
+    names = ['vgg_16/conv4/conv4_3', 'vgg_16/fc7', 'conv6_2', 'conv7_2', 'conv8_2', 'conv9_2']
+    rs = np.random.RandomState(1200)
+    fmaps = collections.OrderedDict((n, tf.Tensor((rs.randn(1, h, w, c) * 1.5).astype(F))) for n, (h, w, c) in zip(names, shapes))
+    ssd_mod = m['ssd_ssd']
+    ssd_mod.SSDFeatureExtractor = lambda cfg, parent_name=None: (lambda image, is_training=False: fmaps)
+    gt = np.concatenate([rand_boxes(rs, 3, 96, 96, 20, 70), rs.randint(0, C, size=(3, 1))], 1).astype(F)
+    for mode in ('train', 'predict'):
+        tf.reset_losses()
+        cfg = ED(model=dict(network=dict(num_classes=C),
+                            anchors=dict(max_scale=0.88, min_scale=0.1, ratios=[1, 0.5, 2, 0.333, 3], anchors_per_point=app),
+                            loss=dict(localization_loss_weight=1.0), base_network={}, variances=[0.1, 0.2],
+                            target=dict(hard_negative_ratio=3.0, foreground_threshold=0.5, background_threshold_high=0.2),
+                            proposals=dict(class_nms_threshold=0.45, class_max_detections=100, total_max_detections=100,
+                                           min_prob_threshold=0.3, filter_outside_anchors=False)),
+                 train=dict(debug=False, seed=None),
+                 dataset=dict(image_preprocessing=dict(fixed_height=96, fixed_width=96)))
+        ssd = ssd_mod.SSD(cfg)
+        image = tf.Tensor(np.zeros((96, 96, 3), F))
+        if mode == 'train':
+            r = ssd(image, gt_boxes=gt, is_training=True)
+        else:
+            r = ssd(image, is_training=False)
+        k = 'heads/ssd_%s/' % mode
+        out[k + 'cls_pred'], out[k + 'loc_pred'] = r['cls_pred'], r['loc_pred']
+        if mode == 'train':
+            out[k + 'target_cls'], out[k + 'target_bbox'] = r['target']['cls'], r['target']['bbox_offsets']
+            out[k + 'target_anchors'] = r['target']['anchors']
+        else:
+            cp = r['classification_prediction']
+            out[k + 'objects'], out[k + 'labels'], out[k + 'probs'] = cp['objects'], cp['labels'], cp['probs']
+        print('heads/ssd_%-8s rows=%d' % (mode, r['cls_pred'].shape[0]))
+    for n, fm in fmaps.items():
+        out['heads/ssd/fmap/' + n.replace('/', '.')] = np.asarray(fm)
+    out['heads/ssd/gt'] = gt
+    out['heads/ssd/geom'] = np.array([96, 96, C] + app, np.int32)
+    tf.reset_losses()
+
+
 def main():
     m = load_reference()
     out = {}
@@ -431,6 +562,7 @@ def main():
     gen_roi_pool(m, out)
     gen_losses(m, out)
     gen_ssd(m, out)
+    gen_heads(m, out)
     for k, v in out.items():
         v = np.asarray(v)
         assert v.dtype != np.float64 or k.endswith('/cfg'), (k, v.dtype)     # nothing silently promoted

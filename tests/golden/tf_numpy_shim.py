@@ -20,7 +20,13 @@ What is restated here and what is not:
   * `random_shuffle` is a hook (`set_random_shuffle`): TF's Philox stream is not reproducible, any permutation is a
     valid outcome, so the fixture generator installs the permutation that corresponds to the shared counter RNG
     (`oracle/rng.py` == `lmh_hash_u32`) and the reference's own subsample code runs on it unmodified;
-  * `summary`, `name_scope`, `variable_scope`, `control_dependencies`, `logging` are inert.
+  * `summary`, `name_scope`, `variable_scope`, `control_dependencies`, `logging` are inert;
+  * `snt.Conv2D` / `snt.Linear` (round 5: the reference's head `_build`s — rpn.py:148-172, rcnn.py:185-239,
+    ssd/ssd.py:73-109 — are executed too) are direct numpy convolutions / matrix products in float32 with Sonnet's
+    variable layout (`w`: HWIO / (in, out), `b`: (out,)), SAME = TF's padding rule; their variables come from
+    `seeded_variable(module name, 'w' | 'b', shape)` — a fixed function of the NAME, so the generator and the tests
+    that replay a fixture rebuild the same weights without storing them (initializers / regularizers are accepted
+    and ignored: the layouts are what is pinned, not the init distribution).
 
 `install()` puts `tensorflow`, `sonnet` and `easydict` stand-ins into `sys.modules`.
 """
@@ -276,6 +282,7 @@ def _red(f):
 
 
 reduce_max = _red(np.max)
+reduce_prod = _red(np.prod)
 reduce_min = _red(np.min)
 reduce_sum = _red(np.sum)
 reduce_any = _red(np.any)
@@ -442,6 +449,22 @@ class _Inert(types.ModuleType):
 summary = _Inert('tensorflow.summary')
 logging = _Inert('tensorflow.logging')
 contrib = _Inert('tensorflow.contrib')
+
+
+def _flatten(x, *a, **k):
+    x = _t(x)
+    return x.reshape(x.shape[0], -1)
+
+
+contrib.layers = _Inert('tensorflow.contrib.layers')
+contrib.layers.flatten = _flatten          # tf.contrib.layers.flatten (rcnn.py:192): (N, ...) -> (N, prod(...)), row-major
+
+
+def _initializer(*a, **k):
+    return None       # variables come from `seeded_variable`; see the module docstring
+
+
+truncated_normal_initializer = random_normal_initializer = zeros_initializer = _initializer
 train = _Inert('tensorflow.train')
 flags = _Inert('tensorflow.flags')
 app = _Inert('tensorflow.app')
@@ -501,6 +524,11 @@ class _NN(object):
     @staticmethod
     def relu6(x, name=None):
         return np.minimum(np.maximum(_t(x), 0), 6)
+
+    @staticmethod
+    def zero_fraction(value, name=None):
+        v = _t(value)
+        return np.float32((v == 0).mean()) if v.size else np.float32(0)
 
 
 nn = _NN()
@@ -568,6 +596,107 @@ class AbstractModule(object):
         return self._build(*args, **kwargs)
 
 
+def seeded_variable(module_name, var, shape):
+    """The variable `var` ('w' / 'b') of the Sonnet module called `module_name`: float32 values that are a fixed
+    function of the name and the shape (legacy numpy RandomState seeded with a CRC of the name: the same on every numpy
+    version) — O(1) outputs for O(1) inputs (w ~ N(0, 1 / fan_in)), non-zero biases so that a mis-ordered channel shows."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(('%s/%s' % (module_name, var)).encode()) & 0x7FFFFFFF)
+    shape = tuple(int(v) for v in shape)
+    if var == 'w':
+        fan_in = int(np.prod(shape[:-1]))
+        return (rs.randn(*shape) / np.sqrt(fan_in)).astype(np.float32)
+    return (rs.randn(*shape) * 0.25).astype(np.float32)
+
+
+class _Shape(tuple):
+    def as_list(self):
+        return list(self)
+
+
+class Tensor(np.ndarray):
+    """An array that also answers the two static-shape calls the reference makes on graph tensors
+    (`set_shape`, ssd.py:63; `.shape.as_list()`, ssd.py:122).  Any op on it returns a plain array."""
+
+    def __new__(cls, a):
+        return np.asarray(a).view(cls)
+
+    def __array_finalize__(self, obj):
+        pass
+
+    def __array_wrap__(self, out, context=None, return_scalar=False):
+        return np.asarray(out)
+
+    @property
+    def shape(self):
+        return _Shape(np.asarray(self).shape)
+
+    def set_shape(self, shape):
+        assert list(shape) == list(np.asarray(self).shape), (shape, np.asarray(self).shape)
+
+
+def _conv2d_nhwc(x, w, padding):
+    """Stride-1 NHWC x HWIO convolution in float32; SAME pads (k - 1) // 2 before and the rest after (TF's rule)."""
+    x, w = np.asarray(x), np.asarray(w)
+    assert x.dtype == np.float32 and w.dtype == np.float32 and x.ndim == 4
+    kh, kw, cin, cout = w.shape
+    assert x.shape[3] == cin
+    if padding.upper() == 'SAME':
+        pt, pl = (kh - 1) // 2, (kw - 1) // 2
+        x = np.pad(x, ((0, 0), (pt, kh - 1 - pt), (pl, kw - 1 - pl), (0, 0)))
+    else:
+        assert padding.upper() == 'VALID'
+    n, h, ww_, _ = x.shape
+    oh, ow = h - kh + 1, ww_ - kw + 1
+    y = np.zeros((n, oh, ow, cout), np.float32)
+    for r in builtins.range(kh):
+        for c in builtins.range(kw):
+            y += (x[:, r:r + oh, c:c + ow, :].reshape(-1, cin) @ w[r, c]).reshape(n, oh, ow, cout)
+    return y
+
+
+class Conv2D(AbstractModule):
+    """snt.Conv2D(output_channels, kernel_shape, stride=1, rate=1, padding='SAME', use_bias=True, ...): NHWC input,
+    variables `w` (kh, kw, in, out) and `b` (out,)."""
+
+    def __init__(self, output_channels, kernel_shape, stride=1, rate=1, padding='SAME', use_bias=True,
+                 initializers=None, partitioners=None, regularizers=None, mask=None, data_format='NHWC',
+                 custom_getter=None, name='conv_2d'):
+        super(Conv2D, self).__init__(name=name)
+        assert stride in (1, (1, 1), [1, 1]) and rate in (1, (1, 1), [1, 1]) and data_format == 'NHWC'
+        ks = kernel_shape if isinstance(kernel_shape, (list, tuple)) else [kernel_shape, kernel_shape]
+        self._kh, self._kw, self._cout = int(ks[0]), int(ks[1]), int(output_channels)
+        self._padding, self._use_bias = padding, use_bias
+
+    def _build(self, inputs):
+        x = np.asarray(_t(inputs))
+        self._w = seeded_variable(self.module_name, 'w', (self._kh, self._kw, x.shape[3], self._cout))
+        y = _conv2d_nhwc(x, self._w, self._padding)
+        if self._use_bias:
+            self._b = seeded_variable(self.module_name, 'b', (self._cout,))
+            y = y + self._b
+        return y
+
+
+class Linear(AbstractModule):
+    """snt.Linear(output_size, use_bias=True, ...): (N, in) @ w (in, out) + b (out,)."""
+
+    def __init__(self, output_size, use_bias=True, initializers=None, partitioners=None, regularizers=None,
+                 custom_getter=None, name='linear'):
+        super(Linear, self).__init__(name=name)
+        self._out, self._use_bias = int(output_size), use_bias
+
+    def _build(self, inputs):
+        x = np.asarray(_t(inputs))
+        assert x.ndim == 2 and x.dtype == np.float32
+        self._w = seeded_variable(self.module_name, 'w', (x.shape[1], self._out))
+        y = x @ self._w
+        if self._use_bias:
+            self._b = seeded_variable(self.module_name, 'b', (self._out,))
+            y = y + self._b
+        return y
+
+
 class EasyDict(dict):
     """easydict.EasyDict: attribute access, recursive for nested dicts."""
 
@@ -601,9 +730,11 @@ def install():
     sys.modules['tensorflow'] = me
     snt = _Inert('sonnet')
     snt.AbstractModule = AbstractModule
+    snt.Conv2D, snt.Linear = Conv2D, Linear
     sys.modules['sonnet'] = snt
     for sub in ('sonnet.python', 'sonnet.python.modules', 'sonnet.python.modules.conv'):
         sys.modules[sub] = _Inert(sub)
+    sys.modules['sonnet.python.modules.conv'].Conv2D = Conv2D
     ed = types.ModuleType('easydict')
     ed.EasyDict = EasyDict
     sys.modules['easydict'] = ed

@@ -494,6 +494,32 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d['roofline'] is not None and d['roofline']['whole_step']['executed_flops'] > 0
 
 
+def test_bench_two_ranks_fallback_ladder():
+    """first-contact safety of `bench.py --gpus N`.  The bucketed exchange is made to raise on its first
+    early bucket (both ranks, inside the step being recorded into a launch plan); the timed block is re-run with ONE
+    all-reduce after the backward, the line says which mode produced the number and what failed before it, and the
+    replicas end bit-identical."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LUMINOTH_AMD_DIST_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'LUMINOTH_AMD_BUCKETED_ALLREDUCE', 'LUMINOTH_AMD_PLAN'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '4',
+                          '--no-cpu-baseline', '--no-other-configs', '--no-roofline', '--inject-bucket-failure'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['dist']['world_size'] == 2
+    assert len(d['dist']['fallbacks']) == 1 and 'injected failure' in d['dist']['fallbacks'][0]['error']
+    assert d['dist']['fallbacks'][0]['bucketed_allreduce_under_backward'] is True
+    assert d['dist']['mode'] == {'bucketed_allreduce_under_backward': False, 'launch_plan': True}
+    assert d['dist']['buckets'] is None
+    assert d['dist']['replicas_identical_after_timed_steps'] is True
+    assert d['dist']['GPU_MAX_HW_QUEUES'] == '8' and d['dist']['collective_timeout_s'] == 180
+    assert np.isfinite(d['config']['final_total_loss']) and d['value'] > 0
+
+
 def test_bench_two_ranks_over_rccl():
     """the same two-rank run over RCCL (backend `nccl`) whenever the box has two GPUs — the driver's
     8-GPU node exercises the real collective layer (communication stream, RCCL's own stream, the launch-plan cuts)

@@ -107,6 +107,57 @@ def test_unannounced_batch_falls_back_to_its_own_prefix(setup):
         model._step_state = {}
 
 
+def test_variable_shapes_keep_lookahead_and_replay(setup):
+    """real data hands the step a new image size and a new number of gt boxes almost every batch.
+    The gt count is not part of a shape's identity (fixed buffers have a bucketed capacity, `gt_count` carries the real
+    counts), a next batch of ANOTHER image size still gets its frozen prefix and anchor targets computed one step ahead
+    (into that shape's own state), a shape that comes back replays its plan, and all of it leaves the same bits as plain
+    eager steps without any look-ahead."""
+    from luminoth_amd import plan as P
+    from luminoth_amd.utils import training as T
+    cfg, model, _ = setup
+    dev = model.device
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    shapes = [(256, 320, 3), (256, 320, 5), (320, 256, 2), (256, 320, 4), (256, 320, 6), (256, 320, 3), (256, 320, 7),
+              (320, 256, 5), (256, 320, 2), (256, 320, 4), (256, 320, 3), (256, 320, 5)]
+    data = []
+    for i, (h, w, g) in enumerate(shapes):
+        im, gts = synth(2, h, w, g, 80, 40 + i)
+        gts[1] = gts[1][:max(1, g - 1)]                     # ragged counts inside a batch as well
+        data.append((im.to(dev), gts))
+
+    def run(plan_on, lookahead):
+        P.ENABLED = plan_on
+        model.load_state_dict(sd0)
+        model._step_state, model._step = {}, 0
+        model.store.mom.zero_()
+        opt = T.get_optimizer(cfg.train, model)
+        for i, (im, gts) in enumerate(data):
+            if lookahead and i + 1 < len(data):
+                T.train_step(model, opt, im, gts, next_image=data[i + 1][0], next_gt=data[i + 1][1])
+            else:
+                T.train_step(model, opt, im, gts)
+        torch.cuda.synchronize()
+        return model.store.flat.clone()
+
+    try:
+        want = run(False, False)
+        got = run(True, True)
+        states = model._step_state
+        assert len(states) == 2, list(states)                                   # two image sizes, ONE gt bucket each
+        assert all(k[3] == 8 for k in states)
+        served = sum(n for S in states.values() for v, n in S['seen'].items() if v[1])
+        replays = sum(pl.replays for S in states.values() for pl in S['plans'].values())
+        # every batch but the first was announced: its prefix / targets were waiting in its slot, also across the size change
+        assert served + replays >= len(data) - 1 and served >= 3, (served, replays)
+        assert replays >= 1, [(v, pl.replays) for S in states.values() for v, pl in S['plans'].items()]
+        assert bool(torch.isfinite(want).all()) and torch.equal(got, want)
+    finally:
+        P.ENABLED = True
+        model.load_state_dict(sd0)
+        model._step_state = {}
+
+
 def test_gradient_buckets_under_replay(setup):
     """The data-parallel exchange is host work between two parts of a plan (plan.host_call): with a stand-in reduce that
     doubles its range, replayed steps must leave exactly 2 x the plain gradient — every element handed over once per

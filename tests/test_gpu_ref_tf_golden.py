@@ -180,3 +180,161 @@ def test_ssd_loss_kernel_matches_reference_graph(G, K, name):
     np.testing.assert_allclose(losses[0] + G[k + 'reg'], G[k + 'total_loss'], rtol=1e-5)
     np.testing.assert_allclose(losses[1], G[k + 'cls_loss'], rtol=1e-5)
     np.testing.assert_allclose(losses[2], G[k + 'bbox_loss'], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------ A4 / A13 / S2: head layouts through the product modules (round 5) ----
+def _seeded(name, var, shape):
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    from tf_numpy_shim import seeded_variable
+    return seeded_variable(name, var, shape)
+
+
+def _load_seeded(store, names):
+    """store variable `<scope>/<module>/<w|b>` <- seeded_variable(<module>, <w|b>, shape): what the generator's numpy
+    Sonnet layers used."""
+    for full in names:
+        mod, var = full.split('/')[-2], full.split('/')[-1]
+        t = store.params[full]
+        t.copy_(torch.from_numpy(_seeded(mod, var, tuple(t.shape))).to(t.device))
+
+
+def test_rpn_module_layout_matches_reference_build(G):
+    """The product's RPN module (luminoth_amd/models/fasterrcnn/rpn.py: HIP convolutions + reshape) on the fixture the
+    reference's own RPN._build (rpn.py:96-217) produced: `(N,2)` / `(N,4)` orderings, anchor targets, proposals."""
+    from luminoth_amd.models.fasterrcnn.rpn import RPN
+    from luminoth_amd.params import ParamStore
+    from luminoth_amd.utils.config import get_config
+    k = 'heads/rpn/'
+    feat = G[k + 'feat']
+    fh, fw, stride, H, W, ch = (int(v) for v in G[k + 'geom'])
+    cfg = get_config({'model': {'type': 'fasterrcnn', 'rpn': {'num_channels': ch}}}).model.rpn
+    A = G[k + 'ref_i32'].shape[0]
+    rpn = RPN(A, cfg, feat.shape[3], seed=None)
+    store = ParamStore()
+    rpn.register(store)
+    store.build(torch.device('cuda:0'), seed=0)
+    rpn.bind(store)
+    _load_seeded(store, list(store.params))
+    gt, cnt = pack_gt(G[k + 'gt'])
+    pred = rpn(T(feat), (H, W), T(G[k + 'ref_i32']), stride, gt_boxes=gt, gt_count=cnt,
+               seeds=T(G[k + 'seed'].view(np.int32)), is_training=True)
+    check_close('ref_tf_golden/heads/rpn/rpn_cls_score', pred['rpn_cls_score'][0].detach().cpu().numpy(), G[k + 'rpn_cls_score'],
+                rtol=1e-5, atol=1e-5)
+    check_close('ref_tf_golden/heads/rpn/rpn_bbox_pred', pred['rpn_bbox_pred'][0].detach().cpu().numpy(), G[k + 'rpn_bbox_pred'],
+                rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pred['rpn_cls_prob'][0].cpu().numpy(), G[k + 'rpn_cls_prob'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(pred['rpn_cls_target'][0].cpu().numpy(), G[k + 'rpn_cls_target'])
+    np.testing.assert_allclose(pred['rpn_bbox_target'][0].cpu().numpy(), G[k + 'rpn_bbox_target'], rtol=1e-5, atol=1e-6)
+    # proposals of free-running scores (1e-6 apart from the reference's): same boxes up to rare rank flips of near-ties
+    n = int(pred['num_proposals'][0])
+    want = G[k + 'proposals']
+    assert abs(n - want.shape[0]) <= 2
+    got = pred['proposals'][0, :n].cpu().numpy()
+    m = min(n, want.shape[0])
+    same = (np.abs(got[:m] - want[:m]).max(axis=1) <= 1e-3).mean()
+    assert same >= 0.98, same
+
+
+@pytest.mark.parametrize('case', ['mean', 'flatten_fc'])
+def test_rcnn_module_layout_matches_reference_build(G, case):
+    """The product's RCNN module on the fixture of the reference's RCNN._build (rcnn.py:112-250): training-batch
+    compaction order, fused crop pooling, spatial mean / HWC flatten, FC stack, `(R,C+1)` / `(R,4C)`."""
+    from luminoth_amd.models.fasterrcnn.rcnn import RCNN
+    from luminoth_amd.params import ParamStore
+    from luminoth_amd.utils.config import get_config
+    k = 'heads/rcnn_%s/' % case
+    feat, props = G[k + 'feat'], G[k + 'proposals']
+    geom = [int(v) for v in G[k + 'geom']]
+    H, W, C, use_mean, sizes = geom[0], geom[1], geom[2], bool(geom[3]), geom[4:]
+    cfg = get_config({'model': {'type': 'fasterrcnn', 'network': {'num_classes': C},
+                                'rcnn': {'layer_sizes': sizes, 'use_mean': use_mean, 'dropout_keep_prob': 1.0,
+                                         'target': {'minibatch_size': 32}}}}).model.rcnn
+    rcnn = RCNN(C, cfg, feat.shape[3], seed=None)
+    store = ParamStore()
+    rcnn.register(store)
+    store.build(torch.device('cuda:0'), seed=0)
+    rcnn.bind(store)
+    _load_seeded(store, list(store.params))
+
+    class NoTail(object):
+        has_tail = False
+
+        @staticmethod
+        def _build_tail(x, is_training=False):
+            return x
+    gt, cnt = pack_gt(G[k + 'gt'])
+    pred = rcnn(T(feat), T(props[None]), T(np.array([props.shape[0]], np.int32)), (H, W), NoTail(), gt_boxes=gt,
+                gt_count=cnt, seeds=T(G[k + 'seed'].view(np.int32)), is_training=True)
+    n = G[k + 'target_cls'].shape[0]
+    np.testing.assert_array_equal(pred['target']['cls'][0, :n].cpu().numpy(), G[k + 'target_cls'])
+    np.testing.assert_allclose(pred['target']['bbox_offsets'][0, :n].cpu().numpy(), G[k + 'target_bbox'], rtol=1e-5, atol=1e-6)
+    check_close('ref_tf_golden/heads/rcnn_%s/cls_score' % case, pred['rcnn']['cls_score'][0, :n].detach().cpu().numpy(),
+                G[k + 'cls_score'], rtol=1e-5, atol=1e-5)
+    check_close('ref_tf_golden/heads/rcnn_%s/bbox_offsets' % case, pred['rcnn']['bbox_offsets'][0, :n].detach().cpu().numpy(),
+                G[k + 'bbox_offsets'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pred['rcnn']['cls_prob'][0, :n].cpu().numpy(), G[k + 'cls_prob'], rtol=1e-5, atol=1e-6)
+
+
+def test_ssd_module_layout_matches_reference_build(G):
+    """The product's SSD module (multibox heads, reshape / concat, anchors, SSDTarget kernel, SSDProposal kernel) on the
+    fixture of the reference's SSD._build (ssd/ssd.py:37-195) over the same given feature maps."""
+    import collections
+    from luminoth_amd.models.base.layers import ConvLayer
+    from luminoth_amd.models.ssd import ssd as ssd_mod
+    from luminoth_amd.models.ssd.feature_extractor import sonnet_default
+    from luminoth_amd.params import ParamStore
+    from luminoth_amd.utils.config import get_config
+    geom = [int(v) for v in G['heads/ssd/geom']]
+    H, W, C, app = geom[0], geom[1], geom[2], geom[3:]
+    names = ['vgg_16/conv4/conv4_3', 'vgg_16/fc7', 'conv6_2', 'conv7_2', 'conv8_2', 'conv9_2']
+    maps = collections.OrderedDict((n, T(G['heads/ssd/fmap/' + n.replace('/', '.')])) for n in names)
+    cfg = get_config({'model': {'type': 'ssd', 'network': {'num_classes': C},
+                                'proposals': {'min_prob_threshold': 0.3}},
+                      'dataset': {'image_preprocessing': {'fixed_height': H, 'fixed_width': W}}})
+    # the module around GIVEN feature maps: everything of SSD.__init__ except the (slim VGG) feature extractor
+    m = object.__new__(ssd_mod.SSD)
+    m._config, m._name, m._num_classes, m._debug, m._seed = cfg.model, 'ssd', C, False, None
+    m._anchor_max_scale, m._anchor_min_scale = cfg.model.anchors.max_scale, cfg.model.anchors.min_scale
+    m._anchor_ratios = np.array(cfg.model.anchors.ratios)
+    m._anchors_per_point, m._variances = app, list(cfg.model.variances)
+    m.device = torch.device('cuda:0')
+    m.feature_extractor = lambda image, is_training=False: maps
+    m.heads, m.store = [], ParamStore()
+    zeros = lambda shape, gen: torch.zeros(shape)
+    for i, fm in enumerate(maps.values()):
+        pair = []
+        for kind, cout in (('offsets', app[i] * 4), ('classes', app[i] * (C + 1))):
+            l = ConvLayer('ssd/MultiBox_%d_%s_conv' % (i, kind), fm.shape[3], cout, 3, act=None, norm='bias', wd=0.0,
+                          init=sonnet_default, weight_name='w', bias_name='b')
+            m.store.add(l.w_name, (3, 3, l.cin, l.cout), l.init, trainable=True, wd=0.0)
+            m.store.add(l.b_name, (l.cout,), zeros, trainable=True)
+            pair.append(l)
+        m.heads.append(tuple(pair))
+    m.store.build(m.device, seed=0)
+    for off, cls in m.heads:
+        off.bind(m.store, None)
+        cls.bind(m.store, None)
+    _load_seeded(m.store, list(m.store.params))
+    m._anchor = torch.zeros(1, device=m.device, requires_grad=True)
+    m._anchors_cache, m._frozen_reg = {}, None
+    image = torch.zeros((H, W, 3))
+    # inference call: un-batched results truncated to the reference's shapes
+    pd = m(image, is_training=False)
+    check_close('ref_tf_golden/heads/ssd/cls_pred', pd['cls_pred'].cpu().numpy(), G['heads/ssd_predict/cls_pred'], rtol=1e-5, atol=1e-5)
+    check_close('ref_tf_golden/heads/ssd/loc_pred', pd['loc_pred'].cpu().numpy(), G['heads/ssd_predict/loc_pred'], rtol=1e-5, atol=1e-5)
+    cp = pd['classification_prediction']
+    want = G['heads/ssd_predict/objects']
+    assert abs(cp['objects'].shape[0] - want.shape[0]) <= 1
+    n = min(cp['objects'].shape[0], want.shape[0])
+    same = (np.abs(cp['objects'][:n].cpu().numpy() - want[:n]).max(axis=1) <= 1e-3) & \
+        (cp['labels'][:n].cpu().numpy() == G['heads/ssd_predict/labels'][:n])
+    assert same.mean() >= 0.97, same.mean()
+    # training call: targets + the hard-negative filter (kept as -1 rows by the product; compacted here like ssd.py:146-161)
+    pd = m(image[None], gt_boxes=[G['heads/ssd/gt']], is_training=True)
+    lab = pd['target']['cls'][0].cpu().numpy()
+    keep = lab >= 0
+    np.testing.assert_array_equal(lab[keep], G['heads/ssd_train/target_cls'])
+    np.testing.assert_array_equal(pd['target']['anchors'].cpu().numpy()[keep], G['heads/ssd_train/target_anchors'])
+    np.testing.assert_allclose(pd['target']['bbox_offsets'][0].cpu().numpy()[keep], G['heads/ssd_train/target_bbox'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pd['cls_pred'][0].detach().cpu().numpy()[keep], G['heads/ssd_train/cls_pred'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pd['loc_pred'][0].detach().cpu().numpy()[keep], G['heads/ssd_train/loc_pred'], rtol=1e-5, atol=1e-5)

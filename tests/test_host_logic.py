@@ -324,3 +324,32 @@ def test_lds_sort_pass_grouping_sorts():
                 keys[c0:c0 + chunk] = s
             k <<= 1
         assert keys == ref, (n, chunk)
+
+
+def test_bench_kernel_trace_reduction(tmp_path):
+    """bench.py's rocprofv3 leg: `roofline.frac` comes from the kernel trace of a child run; the reduction keeps the
+    dispatches of the LAST n steps only (optimizer launch to optimizer launch) and averages per kernel name."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = ['"Kind","Agent_Id","Queue_Id","Kernel_Name","Start_Timestamp","End_Timestamp"']
+    t = 1000
+    # model build noise, then 5 steps: conv of 50 us in the first two (settling), 40 / 42 / 44 us in the last three
+    rows.append('"KERNEL_DISPATCH",1,1,"__amd_rocclr_copyBuffer",%d,%d' % (t, t + 500)); t += 1000
+    for dur in (50000, 50000, 40000, 42000, 44000):
+        for _ in range(2):
+            rows.append('"KERNEL_DISPATCH",1,1,"void k_conv_fwd<128, 128, false>(lmh_conv_desc, float const*)",%d,%d' % (t, t + dur))
+            t += dur + 1000
+        rows.append('"KERNEL_DISPATCH",1,1,"k_sgd_momentum(float*, float const*)",%d,%d' % (t, t + 10000)); t += 11000
+    f = tmp_path / 'rp_kernel_trace.csv'
+    f.write_text('\n'.join(rows) + '\n')
+    out = bench.reduce_kernel_trace(str(f), 3)
+    k = out['k_conv_fwd<128,128,false>']
+    assert abs(k['avg_ms'] - 0.042) < 1e-9 and k['calls_per_step'] == 2.0
+    assert out['k_sgd_momentum']['calls_per_step'] == 1.0
+    assert '__amd_rocclr_copyBuffer' not in out
+    assert abs(out['_step_ms'] - (2 * 42000 + 2 * 1000 + 11000) * 1e-6) < 1e-9
+    assert bench.reduce_kernel_trace(str(f), 5) is None          # needs n + 1 optimizer launches

@@ -41,7 +41,7 @@ def test_fixture_is_fresh_when_reference_present():
                 "ns = runpy.run_path(%r)\n"
                 "m = ns['load_reference'](); out = {}\n"
                 "for f in ('gen_box_utils','gen_rpn_target','gen_rcnn_target','gen_rpn_proposal','gen_rcnn_proposal',"
-                "'gen_roi_pool','gen_losses','gen_ssd'): ns[f](m, out)\n"
+                "'gen_roi_pool','gen_losses','gen_ssd','gen_heads'): ns[f](m, out)\n"
                 "np.savez(%r, **{k: np.asarray(v) for k, v in out.items()})\n") % (gen, os.path.join(d, 'x.npz'))
         subprocess.check_call([sys.executable, '-c', code], stdout=subprocess.DEVNULL)
         new, old = np.load(os.path.join(d, 'x.npz')), np.load(GOLD)
@@ -199,3 +199,105 @@ def test_ssd_loss_matches_reference_graph(G, name):
     np.testing.assert_allclose(final + G[k + 'reg'], G[k + 'total_loss'], rtol=1e-6)      # + regularisation collection
     if name == 'no_positives':
         assert float(final) == 0.0                                                         # ssd.py:262-270
+
+
+# ------------------------------------------------------------------------- A4 / A13 / S2: head layouts (round 5) ----
+def _seeded(name, var, shape):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    from tf_numpy_shim import seeded_variable
+    return seeded_variable(name, var, shape)
+
+
+def test_rpn_head_layout_matches_reference_build(G):
+    """rpn.py:148-172 executed by the generator (numpy Sonnet Conv2D): the oracle's `rpn_head` puts the same anchor /
+    class / coordinate in the same place of `(N,2)` / `(N,4)`; values 1e-5 (two float32 convolution orders)."""
+    import torch
+    from oracle.model import OracleFasterRCNN
+    k = 'heads/rpn/'
+    feat = G[k + 'feat']
+    fh, fw, stride, H, W, ch = (int(v) for v in G[k + 'geom'])
+    cin, A = feat.shape[3], G[k + 'ref_i32'].shape[0]
+    p = 'fasterrcnn/rpn'
+    sd = {p + '/conv/w': _seeded('conv', 'w', (3, 3, cin, ch)), p + '/conv/b': _seeded('conv', 'b', (ch,)),
+          p + '/cls_conv/w': _seeded('cls_conv', 'w', (1, 1, ch, 2 * A)), p + '/cls_conv/b': _seeded('cls_conv', 'b', (2 * A,)),
+          p + '/bbox_conv/w': _seeded('bbox_conv', 'w', (1, 1, ch, 4 * A)), p + '/bbox_conv/b': _seeded('bbox_conv', 'b', (4 * A,))}
+    o = OracleFasterRCNN(sd, num_classes=5)
+    cls, box = o.rpn_head(torch.from_numpy(feat))
+    np.testing.assert_allclose(cls.numpy(), G[k + 'rpn_cls_score'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(box.numpy(), G[k + 'rpn_bbox_pred'], rtol=1e-5, atol=1e-5)
+    # a layout error is O(1): swapping the two columns or two anchors must fail this comparison by a wide margin
+    assert np.abs(G[k + 'rpn_cls_score'][:, 0] - G[k + 'rpn_cls_score'][:, 1]).mean() > 0.1
+    # ... and the rest of _build on those scores: anchor targets (bit-exact) and the proposals of its own softmax
+    anchors = obx.generate_anchors(obx.generate_anchors_reference(64, np.array([0.5, 1, 2]), np.array([0.25, 0.5, 1, 2])),
+                                   fh, fw, stride)
+    labels, targets, _ = of.rpn_target(anchors, G[k + 'gt'], (H, W), seed=int(G[k + 'seed'][0]))
+    np.testing.assert_array_equal(labels, G[k + 'rpn_cls_target'])
+    np.testing.assert_allclose(targets, G[k + 'rpn_bbox_target'], rtol=1e-6, atol=1e-6)
+    r = of.rpn_proposal(G[k + 'rpn_cls_prob'], G[k + 'rpn_bbox_pred'], anchors, (H, W), pre_nms_top_n=12000,
+                        post_nms_top_n=2000, nms_threshold=0.7)
+    np.testing.assert_allclose(r['proposals'], G[k + 'proposals'], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('case', ['mean', 'flatten_fc'])
+def test_rcnn_head_layout_matches_reference_build(G, case):
+    """rcnn.py:149-239 executed by the generator: targets + training-batch compaction (order of the kept proposals),
+    crop pooling, spatial mean OR row-major flatten of (7,7,C), the FC stack, `(R,C+1)` / `(R,4C)`."""
+    import torch
+    from oracle import torch_ops as ot
+    k = 'heads/rcnn_%s/' % case
+    feat, props, gt = G[k + 'feat'], G[k + 'proposals'], G[k + 'gt']
+    geom = [int(v) for v in G[k + 'geom']]
+    H, W, C, use_mean, sizes = geom[0], geom[1], geom[2], bool(geom[3]), geom[4:]
+    lab, tg = of.rcnn_target(props, gt, seed=int(G[k + 'seed'][0]), minibatch_size=32)
+    keep = lab >= 0
+    np.testing.assert_array_equal(lab[keep], G[k + 'target_cls'])
+    np.testing.assert_allclose(tg[keep], G[k + 'target_bbox'], rtol=1e-6, atol=1e-6)
+    rois = torch.from_numpy(props[keep])
+    pooled = ot.roi_pool(torch.from_numpy(feat), rois, torch.zeros(rois.shape[0], dtype=torch.long), (H, W))
+    net = pooled.mean(dim=(1, 2)) if use_mean else pooled.reshape(pooled.shape[0], -1)
+    for i, size in enumerate(sizes):
+        net = torch.relu(net @ torch.from_numpy(_seeded('fc_%d' % i, 'w', (net.shape[1], size))) +
+                         torch.from_numpy(_seeded('fc_%d' % i, 'b', (size,))))
+    cls = net @ torch.from_numpy(_seeded('fc_classifier', 'w', (net.shape[1], C + 1))) + \
+        torch.from_numpy(_seeded('fc_classifier', 'b', (C + 1,)))
+    box = net @ torch.from_numpy(_seeded('fc_bbox', 'w', (net.shape[1], 4 * C))) + torch.from_numpy(_seeded('fc_bbox', 'b', (4 * C,)))
+    np.testing.assert_allclose(cls.numpy(), G[k + 'cls_score'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(box.numpy(), G[k + 'bbox_offsets'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(torch.softmax(cls, 1).numpy(), G[k + 'cls_prob'], rtol=1e-5, atol=1e-6)
+
+
+def _ssd_head_variables(G, scope='ssd'):
+    geom = [int(v) for v in G['heads/ssd/geom']]
+    C, app = geom[2], geom[3:]
+    names = ['vgg_16/conv4/conv4_3', 'vgg_16/fc7', 'conv6_2', 'conv7_2', 'conv8_2', 'conv9_2']
+    maps = [G['heads/ssd/fmap/' + n.replace('/', '.')] for n in names]
+    sd = {}
+    for i, (fm, a) in enumerate(zip(maps, app)):
+        for kind, cout in (('offsets', a * 4), ('classes', a * (C + 1))):
+            n = 'MultiBox_%d_%s_conv' % (i, kind)
+            sd['%s/%s/w' % (scope, n)] = _seeded(n, 'w', (3, 3, fm.shape[3], cout))
+            sd['%s/%s/b' % (scope, n)] = _seeded(n, 'b', (cout,))
+    return sd, maps, C, app, geom[:2]
+
+
+def test_ssd_head_layout_matches_reference_build(G):
+    """ssd/ssd.py:73-195 executed by the generator over given feature maps: six multibox head pairs, `[-1,4]` /
+    `[-1,C+1]` reshapes, concat order, anchors in the same order, targets + hard-negative filter, proposals."""
+    import torch
+    from oracle.ssd_model import OracleSSD
+    sd, maps, C, app, (H, W) = _ssd_head_variables(G)
+    o = OracleSSD(sd, num_classes=C, anchors_per_point=app)
+    loc, cls = o.heads([torch.from_numpy(m) for m in maps])
+    np.testing.assert_allclose(cls.numpy(), G['heads/ssd_predict/cls_pred'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(loc.numpy(), G['heads/ssd_predict/loc_pred'], rtol=1e-5, atol=1e-5)
+    anchors = ossd.all_anchors([(m.shape[1], m.shape[2]) for m in maps], (H, W, 3), anchors_per_point=app)
+    probs = torch.softmax(cls, 1).numpy()
+    labels, targets = ossd.ssd_target(probs, anchors, G['heads/ssd/gt'], variances=(0.1, 0.2), hard_negative_ratio=3.0,
+                                      foreground_threshold=0.5, background_threshold_high=0.2)
+    keep = labels >= 0
+    np.testing.assert_array_equal(labels[keep], G['heads/ssd_train/target_cls'])
+    np.testing.assert_array_equal(anchors[keep], G['heads/ssd_train/target_anchors'])
+    np.testing.assert_allclose(targets[keep], G['heads/ssd_train/target_bbox'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(cls.numpy()[keep], G['heads/ssd_train/cls_pred'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(loc.numpy()[keep], G['heads/ssd_train/loc_pred'], rtol=1e-5, atol=1e-5)
