@@ -46,6 +46,9 @@ RPN_BWD_SIDE = os.environ.get('LUMINOTH_AMD_RPN_BWD_SIDE', 'auto')
 PREFIX_AT = os.environ.get('LUMINOTH_AMD_PREFIX_AT', 'middle')
 # the RCNN loss VALUES (one block per image, reported only) behind the join instead of in front of the RCNN backward
 RCNN_LOSS_LATE = os.environ.get('LUMINOTH_AMD_RCNN_LOSS_LATE', '1') != '0'
+# the RPN backward BEHIND the join instead of beside the proposal chain / the next batch's prefix (round 5): its data gradient
+# takes the RCNN branch's gradient of the feature map as `addend` (instead of the ROI-pooling backward taking the RPN's)
+RPN_BWD_LATE = os.environ.get('LUMINOTH_AMD_RPN_BWD_LATE', '0') != '0'
 PREFIX_SPLIT = os.environ.get('LUMINOTH_AMD_PREFIX_SPLIT', '0') != '0'      # stem of the next batch right behind the RPN heads
 WINO_BATCH = os.environ.get('LUMINOTH_AMD_WINO_BATCH', '1') != '0'      # transformed Winograd weights of the whole step in two launches
 
@@ -552,7 +555,13 @@ class FasterRCNN(object):
         if wino_bwd_side is not None:
             K.stream_wait(main, wino_bwd_side)      # transformed backward weights (enqueued before the forward pass: long done)
         rpn_bwd_stream = main
-        if SideStream.enabled and (RPN_BWD_SIDE == '1' or (RPN_BWD_SIDE == 'auto' and not bn._hs_layers)):
+        # late: nothing MFMA-bound runs beside the proposal chain and the prefix; the RPN data gradients follow the join
+        # (not when the RPN convolution is a half-storage layer with fp32 tensors on both sides: no addend there)
+        rpn_late = RPN_BWD_LATE and not (rpn._rpn.storage is not None and rpn._rpn.hs_in_f32)
+        d_feat_rpn = None
+        if rpn_late:
+            pass
+        elif SideStream.enabled and (RPN_BWD_SIDE == '1' or (RPN_BWD_SIDE == 'auto' and not bn._hs_layers)):
             # the RPN backward (MFMA-bound) on the weight-gradient stream, which is idle until the trunk backward starts:
             # it then runs beside the next batch's prefix (HBM-bound) on the main stream and the proposal chain
             # (latency-bound) on the aux stream instead of in front of the prefix
@@ -579,7 +588,7 @@ class FasterRCNN(object):
                 rcnn_losses, rcnn_g = rcnn.loss_and_grads(cp, self._rcnn_cls_loss_weight, self._rcnn_reg_loss_weight)
             self._mark('aux:rcnn_loss_done')
             d_feat = rcnn.train_bwd(rcnn_ctx, rcnn_g[0], rcnn_g[1], addend=d_feat_rpn,
-                                    before_pool_bwd=lambda: K.stream_wait(aux, rpn_bwd_stream))
+                                    before_pool_bwd=None if rpn_late else (lambda: K.stream_wait(aux, rpn_bwd_stream)))
             self._mark('aux:rcnn_bwd_done')
         # ---- the main stream has nothing left but to wait for the RCNN branch: the slot for the frozen trunk prefix of
         # the NEXT step's images (conv1 + fixed blocks: nothing this step's update writes)
@@ -592,6 +601,10 @@ class FasterRCNN(object):
         # ---- join (the wait captures the aux stream as of NOW: what is queued there below does not delay the trunk backward)
         K.stream_wait(main, aux)
         self._mark('joined')
+        if rpn_late:
+            SideStream.layers_left = 0          # weight gradients on the side stream, beside the start of the trunk backward
+            d_feat = rpn.heads_bwd(rpn_ctx, rpn_g[0], rpn_g[1], addend=d_feat)
+            self._mark('rpn_bwd_done')
         with torch.cuda.stream(aux):
             # the loss scalars are only reported: built on the stream that has nothing else to do
             if rcnn_losses is None:

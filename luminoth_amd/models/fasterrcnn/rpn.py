@@ -68,7 +68,7 @@ class RPN(object):
         pred = {'rpn_cls_score': cls.reshape(B, -1, 2), 'rpn_bbox_pred': bbox.reshape(B, -1, 4)}
         return pred, (feat, rf, bits, cls, bbox)
 
-    def heads_bwd(self, ctx, d_cls, d_bbox):
+    def heads_bwd(self, ctx, d_cls, d_bbox, addend=None):
         """Gradient of the feature map through the three convolutions (their parameter gradients go to the flat
         buffer).  The two 1x1 heads read the same tensor: the second one's data gradient takes the first one's as its
         `addend` and applies the activation bit mask of the 3x3 convolution's output in the same epilogue, so what
@@ -76,7 +76,8 @@ class RPN(object):
         feat, rf, bits, cls, bbox = ctx
         d1, _ = self._rpn_cls.backward(rf, cls, d_cls.view_as(cls), need_dx=True)
         g, _ = self._rpn_bbox.backward(rf, bbox, d_bbox.view_as(bbox), need_dx=True, addend=d1, mask_bits=bits)
-        d_feat, _ = self._rpn.backward(feat, rf, g, need_dx=True, dy_is_g=bits is not None)
+        # `addend`: the gradient another consumer of the feature map left (the RCNN branch), added in this store
+        d_feat, _ = self._rpn.backward(feat, rf, g, need_dx=True, dy_is_g=bits is not None, addend=addend)
         return d_feat
 
     def targets(self, pred, anchor_ref_i32, feat_hw, stride, gt_boxes, gt_count, seeds, im_shape, out=None):

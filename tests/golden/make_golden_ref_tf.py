@@ -474,7 +474,7 @@ def gen_heads(m, out):
         def _build_tail(inputs, is_training=False):
             return inputs
     C = 5
-    for name, use_mean, sizes, cf in (('mean', True, [], 12), ('flatten_fc', False, [32, 24], 6)):
+    for name, use_mean, sizes, cf in (('mean', True, [], 12), ('flatten_fc', False, [32, 24], 8)):
         rs = np.random.RandomState(1100 + len(name))
         fh, fw = 10, 12
         H, W = fh * 16, fw * 16

@@ -2,7 +2,7 @@
 (tests/golden/make_golden_ref_tf.py; the oracle replays the same file in tests/test_ref_tf_golden.py).  Nothing here
 goes through oracle/: the expected values are the reference's own outputs.  Labels, indices, keep lists, IoUs:
 bit-exact.  fp32 values that pass through expf / logf on the device: 1e-5 relative; box coordinates: north_star's 1e-4
-(absolute, in pixels) — the largest errors observed are written to profiles/r04_parity_observed.json (parity_log.py)."""
+(absolute, in pixels) — the largest errors observed are written to profiles/r05_parity_observed.json (parity_log.py)."""
 import os
 import sys
 
