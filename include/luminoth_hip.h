@@ -124,6 +124,9 @@ int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* d
 int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op);
 /* Diagnostics: force the block tile (bm,bn in {64,128}) and the bwd-weight split count; 0 = automatic. */
 void lmh_conv2d_force_config(int bm, int bn, int splits);
+/* Diagnostics (round 5): start the co-resident blocks of the fp32 forward / backward-data kernels `units` x ~1 us apart
+ * (block slot (blockIdx >> 8) % resident-blocks-per-CU), 0 = together.  Same results; synchronises the device. */
+int lmh_conv_set_stagger(int units);
 /* Diagnostics: 1x1 weight-gradient kernel variant: 0 automatic, -1 register-staged kernel only, 2..4 LDS ring depth
  * of the direct-to-LDS GEMM kernel (conv_wgrad1x1.h). */
 void lmh_conv2d_force_wgrad_variant(int v);
@@ -167,6 +170,8 @@ int lmh_plan_run(void* plan, int first, int last);
 /* A stream restricted to the compute units {i : i % period < keep} (hipExtStreamCreateWithCUMask) — the
  * backward-overlap experiment of DESIGN.md §4; NULL on failure. */
 lmh_stream_t lmh_stream_create_cu_mask(int period, int keep);
+/* ... those with lo <= c % period < hi (complementary ranges partition the chip between two streams). */
+lmh_stream_t lmh_stream_create_cu_range(int period, int lo, int hi);
 void lmh_stream_destroy(lmh_stream_t stream);
 /* scale = gamma * rstd, shift = beta - mean * scale over n channels: the frozen-statistics BatchNorm of every layer
  * (base_network.py:84-89) folded into per-channel scale / shift for the convolution epilogues, refreshed once a step. */

@@ -111,6 +111,7 @@ SIGNATURES = {
     'lmh_conv2d_bwd_weight': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_kernel_id': (c_i, [P(ConvDesc), c_i]),
     'lmh_conv2d_force_config': (None, [c_i, c_i, c_i]),
+    'lmh_conv_set_stagger': (c_i, [c_i]),
     'lmh_conv2d_force_wgrad_variant': (None, [c_i]),
     'lmh_conv2d_bwd_weight_fuses_colsum': (c_i, [P(ConvDesc)]),
     'lmh_conv2d_profile_next': (c_i, [c_f, c_f]),
@@ -141,6 +142,7 @@ SIGNATURES = {
     'lmh_plan_kernel_count': (c_i, [c_f, c_i, c_i]),
     'lmh_plan_run': (c_i, [c_f, c_i, c_i]),
     'lmh_stream_create_cu_mask': (ctypes.c_void_p, [c_i, c_i]),
+    'lmh_stream_create_cu_range': (ctypes.c_void_p, [c_i, c_i, c_i]),
     'lmh_stream_destroy': (None, [c_f]),
     'lmh_bn_refresh': (c_i, [c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f]),
     'lmh_bn_train_workspace_bytes': (c_sz, [c_i64, c_i]),

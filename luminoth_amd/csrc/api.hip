@@ -32,6 +32,7 @@ static lmh_option g_options[] = {
     {"nms_stage_mult", 0},    // > 0: NMS in two stages, A = this many x max_out candidates (mask + scan), the rest only if needed; 0: one stage
     {"head_gemm", 1},         // Linear heads on <= 4096 rows: the split-reduction 32x32 kernel (conv_generic.h k_head_fwd); 0: the tiled / skinny kernels
     {"roi_cs", 0},            // ROI backward slab width (0: automatic, 4: force the 4-channel slab)
+    {"conv_pp", 1},           // 1x1 forward with >= 2 tiles of 128 x 128 per compute unit: the persistent pipelined kernel (conv_pp.h)
     {"roi_mean_cs", -1},      // fused ROI pool+mean (-1: automatic, 0: report unsupported, 4: force 4 channels)
 };
 extern "C" int lmh_set_option(const char* name, int value) {

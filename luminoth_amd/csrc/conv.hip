@@ -34,6 +34,7 @@
 __device__ __attribute__((aligned(64))) float lmh_zero_page[16];  // zero-initialised: padding source
 
 #include "conv_fast.h"
+#include "conv_pp.h"
 #include "conv_wgrad1x1.h"
 #include "conv_half.h"
 
@@ -95,6 +96,11 @@ static inline double desc_bytes(const lmh_conv_desc* d) {
 }
 
 // Tuning override (diagnostics only: scripts/bench_conv.py sweeps tile shapes / split counts with it).
+// (experiment, conv_common.h) units of ~1 us by which co-resident blocks of the fast forward / backward-data kernels are staggered
+extern "C" int lmh_conv_set_stagger(int units) {
+  LMH_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stagger), &units, sizeof(int)));
+  return LMH_OK;
+}
 static int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
 extern "C" void lmh_conv2d_force_config(int bm, int bn, int splits) {
   g_force_bm = bm; g_force_bn = bn; g_force_splits = splits;
@@ -257,6 +263,38 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
     *bits_done = false;
     LMH_CHECK_LAUNCH();
     return LMH_OK;
+  }
+  if (fast && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->OH == d->H &&
+      d->OW == d->W && !in_sub && d->C >= 128 && !g_force_bm && lmh_opt("conv_pp")) {
+    // persistent software-pipelined kernel (conv_pp.h): one block per compute unit walks >= 2 tiles of 128 x 128; taken when
+    // the tiles divide evenly enough over the chip (the tiled kernel keeps the layers with fewer than two tiles per CU)
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+        ncu = 256;
+    }
+    const int tiles_m = (int)((M + 127) / 128), tiles_n = (d->K + 127) / 128;
+    const int64_t ntiles = (int64_t)tiles_m * tiles_n;
+    const int nsub = (int)((ntiles + ncu - 1) / ncu);
+    // (measured, scripts/r5_epilogue_decomp.py: 4- and 8-stage tiles gain 6-15 %; at 16 stages per tile the epilogue is a
+    // small share and two independent blocks per CU are as good: those layers stay with the tiled kernel)
+    if (nsub >= 2 && ntiles * 10 >= (int64_t)nsub * ncu * 9 && (d->K % 128) == 0 && d->C <= 256 && (d->C >= 160 || d->C == 128) &&
+        (M + 128) * (int64_t)d->K * 4 < ((int64_t)1 << 31) && (act_bits == nullptr || (d->K % 32) == 0)) {
+      const int nblk = (int)((ntiles + nsub - 1) / nsub);
+      prof_begin(st);
+#define LAUNCH_PP(CC4_, BITS_)                                                                                    \
+      lmh_launch((k_conv1x1_pp<CC4_, BITS_>), dim3(nblk), dim3(512), 0, st, (int)M, d->C, d->K, d->act, x, w, scale, \
+                 shift, residual, y, act_bits, (int)ntiles, tiles_n, nsub)
+      if (d->C == 128) { if (act_bits) LAUNCH_PP(true, true); else LAUNCH_PP(true, false); }
+      else { if (act_bits) LAUNCH_PP(false, true); else LAUNCH_PP(false, false); }
+#undef LAUNCH_PP
+      prof_end(st, desc_flops(d), "k_conv1x1_pp");
+      *bits_done = true;
+      LMH_CHECK_LAUNCH();
+      return LMH_OK;
+    }
   }
 #define LAUNCH_FWD(BM_, BN_)                                                                              \
   do {                                                                                                    \

@@ -278,9 +278,9 @@ extern "C" int lmh_plan_run(void* plan, int first, int last) {
 // A HIP stream whose kernels may only occupy a subset of the compute units: of every XCD's CUs c = 0..31 those with
 // c % period < keep.  Used for the backward-overlap experiment (weight-gradient stream on a fraction of the chip
 // beside the data-gradient stream); returns NULL on failure.  Destroy with lmh_stream_destroy.
-extern "C" lmh_stream_t lmh_stream_create_cu_mask(int period, int keep) {
-  if (period < 1 || keep < 1 || keep > period) {
-    lmh_set_error("lmh_stream_create_cu_mask: need 1 <= keep <= period");
+static lmh_stream_t stream_with_cu_range(int period, int lo, int hi) {
+  if (period < 1 || lo < 0 || hi <= lo || hi > period) {
+    lmh_set_error("lmh_stream_create_cu_mask: need 0 <= lo < hi <= period");
     return nullptr;
   }
   int dev = 0, ncu = 0;
@@ -293,10 +293,12 @@ extern "C" lmh_stream_t lmh_stream_create_cu_mask(int period, int keep) {
   std::vector<uint32_t> mask(words, 0u);
   // Measured on MI355X (scripts/probe_cu_mask.py): mask bit i is CU (i / 8) of XCD (i % 8) — a mask that leaves an XCD
   // without any CU is ignored by the runtime (patterns with a power-of-two stride ran at full speed), so the subset is
-  // chosen on the per-XCD index and every XCD keeps keep / period of its CUs.
+  // chosen on the per-XCD index and every XCD keeps (hi - lo) / period of its CUs.
   const int xcds = 8;
-  for (int i = 0; i < ncu; ++i)
-    if ((i / xcds) % period < keep) mask[i >> 5] |= 1u << (i & 31);
+  for (int i = 0; i < ncu; ++i) {
+    const int c = (i / xcds) % period;
+    if (c >= lo && c < hi) mask[i >> 5] |= 1u << (i & 31);
+  }
   hipStream_t st = nullptr;
   if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()) != hipSuccess) {
     lmh_set_error("hipExtStreamCreateWithCUMask failed");
@@ -304,6 +306,10 @@ extern "C" lmh_stream_t lmh_stream_create_cu_mask(int period, int keep) {
   }
   return (lmh_stream_t)st;
 }
+extern "C" lmh_stream_t lmh_stream_create_cu_mask(int period, int keep) { return stream_with_cu_range(period, 0, keep); }
+// ... those with lo <= c % period < hi: two streams with complementary ranges PARTITION the chip (round 5: the proposal /
+// RCNN chain on CUs of its own while the convolution streams run on the rest)
+extern "C" lmh_stream_t lmh_stream_create_cu_range(int period, int lo, int hi) { return stream_with_cu_range(period, lo, hi); }
 extern "C" void lmh_stream_destroy(lmh_stream_t stream) {
   if (stream) (void)hipStreamDestroy((hipStream_t)stream);
 }

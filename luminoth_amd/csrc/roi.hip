@@ -387,40 +387,58 @@ extern "C" int lmh_roi_pool_bwd(const float* dout, const uint8_t* argmax, const 
 // k_spatial_mean_fwd uses.  HBM traffic: the feature map once (33.5 MB) + arg-max bytes (12.8 MB) + the means (2 MB),
 // instead of ~485 MB of corner gathers that depend on L2 hit rates — which is what made the gather kernel 3x slower
 // whenever the convolution streams were thrashing the L2 next to it.
+// CS = 8 / 4: 1024 threads, the slab of a 64 x 64 map is 128 / 64 KB — a block then needs (half) a compute unit to itself and,
+// beside the convolution streams of the train step, WAITS for one to drain (round 4: 116 us alone, 141 us in the fp32 step,
+// 396 us in the f16 step whose GEMM blocks hold 2 x 64 KB per CU).  CS = 2 / 1 (round 5): 32 / 16 KB slabs in blocks of
+// 256 * CS threads that fit beside resident GEMM blocks; the slab is then filled with 4-byte pieces (a pixel's CS channels).
 template <int CS>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(CS >= 4 ? 1024 : 256 * CS)
 k_roi_pool_mean_fwd(const float* __restrict__ feat, const float4* __restrict__ rois,
                     const int32_t* __restrict__ roi_count, int R, int FH, int FW, int C, float im_h, float im_w,
                     int ph, int pw, float* __restrict__ mean, uint8_t* __restrict__ argmax) {
   extern __shared__ __attribute__((aligned(16))) float fslab[];      // [npix][CS]
+  constexpr int NT = CS >= 4 ? 1024 : 256 * CS;
+  __builtin_amdgcn_s_setprio(3);
   const int b = blockIdx.y, c0 = roi_slab_of_block(blockIdx.x, gridDim.x) * CS;
   const int npix = FH * FW;
   const float* fb = feat + (size_t)b * npix * C + c0;
-  {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  if (CS >= 4) {
     // the slab goes from global memory straight into LDS (global_load_lds_dwordx4: a wave instruction fills 1 KB = PPI
     // pixels x CS channels, lane-linear, which IS the [pixel][CS] layout), every instruction of a wave issued back to
     // back and awaited once.  The register-staged loop it replaces was load -> wait -> ds_write per float4: eight
     // serial round trips of memory latency per thread before the first ROI (round 4; ISA check).
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* glb_ptr;
-    constexpr int LPP = CS / 4, PPI = 64 / LPP;          // lanes per pixel, pixels per wave instruction
+    constexpr int LPP = CS >= 4 ? CS / 4 : 1, PPI = 64 / LPP;          // lanes per pixel, pixels per wave instruction
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nins = npix / PPI;
     const float* src = fb + (size_t)(lane / LPP) * C + 4 * (lane % LPP);
-    for (int k = wave; k < nins; k += 16)
+    for (int k = wave; k < nins; k += NT / 64)
       __builtin_amdgcn_global_load_lds((glb_ptr)(src + (size_t)k * PPI * C), (lds_ptr)(fslab + (size_t)k * PPI * CS), 16, 0, 0);
-    for (int i = nins * PPI * LPP + threadIdx.x; i < npix * LPP; i += 1024) {      // pixels past the last whole instruction
+    for (int i = nins * PPI * LPP + threadIdx.x; i < npix * LPP; i += NT) {      // pixels past the last whole instruction
       const int pix = i / LPP, part = i - pix * LPP;
       *reinterpret_cast<float4*>(fslab + (size_t)pix * CS + 4 * part) =
           *reinterpret_cast<const float4*>(fb + (size_t)pix * C + 4 * part);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    // dword pieces: a wave instruction fills 256 B = 64 / CS pixels x CS channels, lane-linear = the [pixel][CS] layout
+    constexpr int PPI = 64 / CS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nins = npix / PPI;
+    const float* src = fb + (size_t)(lane / CS) * C + (lane % CS);
+    for (int k = wave; k < nins; k += NT / 64)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(src + (size_t)k * PPI * C), (lds_ptr)(fslab + (size_t)k * PPI * CS), 4, 0, 0);
+    for (int i = nins * PPI * CS + threadIdx.x; i < npix * CS; i += NT) {
+      const int pix = i / CS, part = i - pix * CS;
+      fslab[(size_t)pix * CS + part] = fb[(size_t)pix * C + part];
+    }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int nroi = min(roi_count[b], R);
   const int cells = ph * pw, ch = 2 * ph, cw = 2 * pw;
   const int cc = threadIdx.x % CS;
-  for (int r = threadIdx.x / CS; r < R; r += 1024 / CS) {
+  for (int r = threadIdx.x / CS; r < R; r += NT / CS) {
     const int rr = b * R + r;
     uint8_t* am = argmax + (size_t)rr * cells * C + c0 + cc;
     if (r >= nroi) {                                   // dead ROI: zeros, like k_roi_pool_fwd
@@ -455,8 +473,9 @@ k_roi_pool_mean_fwd(const float* __restrict__ feat, const float4* __restrict__ r
 
 static int roi_mean_fwd_width(int FH, int FW, int C) {
   const size_t npix = (size_t)FH * FW, lds_cap = 160 * 1024;
-  const int force = lmh_opt("roi_mean_cs");   // 0: report "unsupported" (lmh_set_option)
+  const int force = lmh_opt("roi_mean_cs");   // 0: report "unsupported"; 1, 2, 4: force that slab width (lmh_set_option)
   if (force == 0) return 0;
+  if ((force == 1 || force == 2) && (C % force) == 0 && npix * force * sizeof(float) <= lds_cap) return force;
   if (force != 4 && (C % 8) == 0 && npix * 8 * sizeof(float) <= lds_cap) return 8;
   if ((C % 4) == 0 && npix * 4 * sizeof(float) <= lds_cap) return 4;
   return 0;
@@ -480,25 +499,22 @@ extern "C" int lmh_roi_pool_mean_fwd(const float* feat, const float* rois, const
   }
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)FH * FW * cs * sizeof(float);
-  if (cs == 8) {
-    static bool attr = false;
-    if (!attr) {
-      LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_mean_fwd<8>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr = true;
-    }
-    lmh_launch((k_roi_pool_mean_fwd<8>), dim3(C / 8, B), dim3(1024), lds, st, feat,
-                       reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, mean, argmax);
-  } else {
-    static bool attr = false;
-    if (!attr) {
-      LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_mean_fwd<4>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr = true;
-    }
-    lmh_launch((k_roi_pool_mean_fwd<4>), dim3(C / 4, B), dim3(1024), lds, st, feat,
-                       reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, mean, argmax);
-  }
+#define ROI_MEAN_LAUNCH(CS_)                                                                                         \
+  do {                                                                                                               \
+    static bool attr = false;                                                                                        \
+    if (!attr) {                                                                                                     \
+      LMH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_roi_pool_mean_fwd<CS_>),                    \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
+      attr = true;                                                                                                   \
+    }                                                                                                                \
+    lmh_launch((k_roi_pool_mean_fwd<CS_>), dim3(C / CS_, B), dim3(CS_ >= 4 ? 1024 : 256 * CS_), lds, st, feat,        \
+               reinterpret_cast<const float4*>(rois), roi_count, R, FH, FW, C, im_h, im_w, ph, pw, mean, argmax);    \
+  } while (0)
+  if (cs == 8) ROI_MEAN_LAUNCH(8);
+  else if (cs == 4) ROI_MEAN_LAUNCH(4);
+  else if (cs == 2) ROI_MEAN_LAUNCH(2);
+  else ROI_MEAN_LAUNCH(1);
+#undef ROI_MEAN_LAUNCH
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

@@ -74,6 +74,17 @@ def stream_wait(waiter, signaler):
           'lmh_stream_wait_stream')
 
 
+def cu_range_stream(spec, device):
+    """'period:lo:hi' (or 'period:keep' = 'period:0:keep') -> a torch stream whose kernels only occupy, of every XCD's
+    compute units c = 0..31, those with lo <= c % period < hi (hipExtStreamCreateWithCUMask; experiments only)."""
+    v = [int(x) for x in spec.split(':')]
+    period, lo, hi = (v[0], 0, v[1]) if len(v) == 2 else v
+    h = _lib.load().lmh_stream_create_cu_range(period, lo, hi)
+    if not h:
+        raise _lib.LuminothHipError('lmh_stream_create_cu_range(%d, %d, %d) failed' % (period, lo, hi))
+    return torch.cuda.ExternalStream(h, device=device)
+
+
 def event_record(event, stream):
     """hipEventRecord of a library event (lmh_event_create handle) on a torch stream — recordable in a launch plan."""
     check(_lib.load().lmh_event_record(ctypes.c_void_p(event), ctypes.c_void_p(stream.cuda_stream)), 'lmh_event_record')

@@ -64,12 +64,8 @@ class SideStream(object):
         st = cls._streams.get(key)
         if st is None:
             if cls.cu_mask:
-                # experiment: the weight-gradient stream confined to keep / period of the compute units
-                period, keep = (int(v) for v in cls.cu_mask.split(':'))
-                h = K._lib.load().lmh_stream_create_cu_mask(period, keep)
-                if not h:
-                    raise K._lib.LuminothHipError('lmh_stream_create_cu_mask(%d, %d) failed' % (period, keep))
-                st = torch.cuda.ExternalStream(h, device=device)
+                # experiment: the weight-gradient stream confined to a subset of the compute units
+                st = K.cu_range_stream(cls.cu_mask, device)
             else:
                 st = torch.cuda.Stream(device=device)
             cls._streams[key] = st

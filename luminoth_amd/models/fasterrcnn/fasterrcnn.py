@@ -397,7 +397,8 @@ class FasterRCNN(object):
                 NS = self._state_for(nB, nH, nW, ngt.shape[1])
                 q = NS['n'] & 1
         if produce:
-            self._fill_slot(NS, q, nimg, ngt, ncnt, NS['key'][0])    # self._step already counts this step: the NEXT step's seeds
+            # (self._step already counts this step: these are the NEXT step's seeds)
+            self._fill_slot(NS, q, nimg, ngt, ncnt, NS['key'][0])
             NS['pf'] = dict(slot=q, image=next_image, image_v=next_image._version, gt=next_gt,
                             gt_v=self._gt_versions(next_gt), step=self._step)
         variant = (p, bool(have_pf), bool(produce))
@@ -764,7 +765,9 @@ class FasterRCNN(object):
         key = str(self.device)
         st = FasterRCNN._AUX_STREAMS.get(key)
         if st is None:
-            st = FasterRCNN._AUX_STREAMS[key] = torch.cuda.Stream(device=self.device, priority=-1)
+            spec = os.environ.get('LUMINOTH_AMD_AUX_CU_MASK', '')       # experiment: the chain on compute units of its own
+            st = K.cu_range_stream(spec, self.device) if spec else torch.cuda.Stream(device=self.device, priority=-1)
+            FasterRCNN._AUX_STREAMS[key] = st
         return st
 
     # --------------------------------------------------------------- variables --

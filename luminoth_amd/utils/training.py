@@ -367,7 +367,8 @@ def issue_from_high_priority_stream(device):
     left (measured on one MI355X box: 8.35 -> 8.28 ms/step).  LUMINOTH_AMD_MAIN_PRIORITY=0 keeps the default stream."""
     if os.environ.get('LUMINOTH_AMD_MAIN_PRIORITY', '1') == '0' or not torch.cuda.is_available():
         return None
-    st = torch.cuda.Stream(device=device, priority=-1)
+    spec = os.environ.get('LUMINOTH_AMD_MAIN_CU_MASK', '')       # experiment: 'period:lo:hi' (kernels.cu_range_stream)
+    st = K.cu_range_stream(spec, device) if spec else torch.cuda.Stream(device=device, priority=-1)
     st.wait_stream(torch.cuda.current_stream(device))
     torch.cuda.set_stream(st)
     return st

@@ -36,3 +36,8 @@ t = timeit(lambda: K.roi_pool_mean_fwd(feat, roist, cnt, (1024, 1024)), 10)
 print('roi_pool_mean_fwd (fused): %.1f us' % (t * 1e3))
 t = timeit(lambda: K.roi_pool_mean_bwd(dy, am2, roist, cnt, (B, FH, FW, C), (1024, 1024)), 10)
 print('roi_pool_mean_bwd (fused): %.1f us' % (t * 1e3))
+for cs in (8, 4, 2, 1):
+    K.set_option('roi_mean_cs', -1 if cs == 8 else cs)
+    t = timeit(lambda: K.roi_pool_mean_fwd(feat, roist, cnt, (1024, 1024)), 10)
+    print('roi_pool_mean_fwd slab of %d channels: %.1f us' % (cs, t * 1e3))
+K.set_option('roi_mean_cs', -1)

@@ -447,6 +447,15 @@ def test_roi_pool_mean_fused_equals_pool_then_mean(K, shape):
     mean, am2 = K.roi_pool_mean_fwd(T(feat), T(rois), T(cnt), im)
     assert torch.equal(mean, ref_mean)
     assert torch.equal(am, am2)
+    # every slab width of the forward kernel (8 / 4 channels: one block per (half a) compute unit; 2 / 1: 256 * CS threads
+    # and <= 32 KB, round 5) is the same arithmetic per (ROI, channel)
+    for cs in (4, 2, 1):
+        K.set_option('roi_mean_cs', cs)
+        try:
+            m_cs, am_cs = K.roi_pool_mean_fwd(T(feat), T(rois), T(cnt), im)
+        finally:
+            K.set_option('roi_mean_cs', -1)
+        assert torch.equal(m_cs, ref_mean) and torch.equal(am_cs, am), cs
     dy = T(rs.randn(B * R, C).astype(F))
     ref_d = K.roi_pool_bwd(K.spatial_mean_bwd(dy, tuple(out.shape)), am, T(rois), T(cnt), (B, FH, FW, C), im)
     d = K.roi_pool_mean_bwd(dy, am2, T(rois), T(cnt), (B, FH, FW, C), im)
@@ -579,6 +588,63 @@ def test_linear_head_kernel(K, M, C, N):
     wi = rs.randint(-8, 9, size=w.shape).astype(F)
     yi = K.conv2d_fwd(d, T(xi), T(wi)).cpu().numpy().reshape(M, N)
     np.testing.assert_array_equal(yi, xi.reshape(M, C) @ wi.reshape(C, N))
+
+
+PP_CASES = [
+    # N, H, W, C, K, residual, scale/shift, act, act_bits, which kernel takes it
+    (2, 64, 64, 256, 1024, True, True, 'relu', True, 'pp'),      # block3 expand of the benchmark step: 512 tiles, 2 per block
+    (2, 128, 128, 128, 512, True, True, 'relu', True, 'pp'),     # block2 expand: 1024 tiles, 4 per block, 4 stages per tile
+    (2, 63, 65, 128, 1024, True, True, 'relu6', True, 'pp'),     # ragged rows: the last row tile has 126 rows
+    (2, 64, 64, 256, 1024, False, False, None, False, 'pp'),     # no residual, no BatchNorm, no activation, no mask
+    (1, 128, 96, 160, 640, True, False, 'relu', True, 'pp'),     # 5 stages per tile; 480 tiles over 240 blocks
+    (2, 63, 65, 128, 1000, True, True, 'relu6', False, 'tiled'),  # K % 128 != 0: the tiled kernel keeps it
+    (2, 64, 64, 512, 1024, True, True, 'relu', True, 'tiled'),   # 16 stages per tile: the tiled kernel keeps it
+]
+
+
+@pytest.mark.parametrize('case', PP_CASES)
+def test_conv1x1_pp_equals_tiled_kernel(K, case):
+    """k_conv1x1_pp (csrc/conv_pp.h: one block per compute unit, tiles software-pipelined, epilogue straight from the
+    accumulator registers) == k_conv_fwd (one block per tile, epilogue through LDS), bit for bit: output AND activation
+    bit mask; and both within the fp32 contract of the torch-CPU reference."""
+    import ctypes
+    N, H, W, C, Kc, use_res, use_bn, act, want_bits, taker = case
+    rs = np.random.RandomState(PP_CASES.index(case) + 900)
+    x = T(rs.randn(N, H, W, C).astype(F))
+    w = T((rs.randn(1, 1, C, Kc) * np.sqrt(2.0 / C)).astype(F))
+    scale = T((1 + 0.1 * rs.randn(Kc)).astype(F)) if use_bn else None
+    shift = T((0.1 * rs.randn(Kc)).astype(F)) if use_bn else None
+    res = T(rs.randn(N, H, W, Kc).astype(F)) if use_res else None
+    d = K.conv_desc(x.shape, w.shape, 1, 1, 'SAME', act)
+    lib = K._lib.load()
+    out = {}
+    for pp in (1, 0):
+        K.set_option('conv_pp', pp)
+        try:
+            bits = K.new_act_bits(N * H * W, Kc, x.device).fill_(-1) if want_bits else None
+            fl = ctypes.c_double(0.0)
+            e0, e1 = lib.lmh_event_create(), lib.lmh_event_create()
+            lib.lmh_conv2d_profile_next(e0, e1)
+            y = K.conv2d_fwd(d, x, w, scale, shift, res, act_bits=bits)
+            name = lib.lmh_conv2d_profile_last(ctypes.byref(fl)).decode()
+            torch.cuda.synchronize()
+            lib.lmh_event_destroy(e0)
+            lib.lmh_event_destroy(e1)
+            out[pp] = (y, bits, name)
+        finally:
+            K.set_option('conv_pp', 1)
+    assert out[1][2] == ('k_conv1x1_pp' if taker == 'pp' else out[0][2]) and out[0][2].startswith('k_conv_fwd<'), (out[1][2], out[0][2])
+    assert torch.equal(out[1][0], out[0][0])
+    if want_bits:
+        assert torch.equal(out[1][1], out[0][1])
+    yt = ot.conv2d_nhwc(x.cpu(), w.cpu(), 1, 1, 'SAME')
+    if use_bn:
+        yt = yt * scale.cpu() + shift.cpu()
+    if use_res:
+        yt = yt + res.cpu()
+    if act:
+        yt = torch.clamp(yt, 0, 6) if act == 'relu6' else torch.relu(yt)
+    np.testing.assert_allclose(out[1][0].cpu().numpy(), yt.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(yt.abs().max())))
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
