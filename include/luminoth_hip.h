@@ -124,8 +124,9 @@ int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* d
 int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op);
 /* Diagnostics: force the block tile (bm,bn in {64,128}) and the bwd-weight split count; 0 = automatic. */
 void lmh_conv2d_force_config(int bm, int bn, int splits);
-/* Diagnostics (round 5): start the co-resident blocks of the fp32 forward / backward-data kernels `units` x ~1 us apart
- * (block slot (blockIdx >> 8) % resident-blocks-per-CU), 0 = together.  Same results; synchronises the device. */
+/* Probes (round 5; only in a library built with LMH_PROBES=1, otherwise LMH_ERR_UNSUPPORTED for units != 0): low 8 bits =
+ * start the co-resident blocks of the fp32 forward / backward-data kernels `units` x ~1 us apart (block slot
+ * (blockIdx >> 8) % resident-blocks-per-CU); bits 8..10 = timing decomposition of the forward kernel (wrong results). */
 int lmh_conv_set_stagger(int units);
 /* Diagnostics: 1x1 weight-gradient kernel variant: 0 automatic, -1 register-staged kernel only, 2..4 LDS ring depth
  * of the direct-to-LDS GEMM kernel (conv_wgrad1x1.h). */

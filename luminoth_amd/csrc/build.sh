@@ -4,7 +4,8 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-result"
+if [ -n "$LMH_PROBES" ]; then PROBES="-DLMH_PROBES"; fi   # timing probes in the convolution kernels (scripts/r5_*sweep*, r5_epilogue_decomp)
+FLAGS="--offload-arch=gfx950 $PROBES -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-result"
 OBJS=""
 pids=""
 for f in api plan proposals detect targets roi loss optim elementwise bnorm ssd tail halfstore conv; do

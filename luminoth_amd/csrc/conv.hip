@@ -98,8 +98,14 @@ static inline double desc_bytes(const lmh_conv_desc* d) {
 // Tuning override (diagnostics only: scripts/bench_conv.py sweeps tile shapes / split counts with it).
 // (experiment, conv_common.h) units of ~1 us by which co-resident blocks of the fast forward / backward-data kernels are staggered
 extern "C" int lmh_conv_set_stagger(int units) {
+#ifdef LMH_PROBES
   LMH_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stagger), &units, sizeof(int)));
   return LMH_OK;
+#else
+  if (units == 0) return LMH_OK;
+  lmh_set_error("lmh_conv_set_stagger: probes are not compiled in (LMH_PROBES=1 bash build.sh)");
+  return LMH_ERR_UNSUPPORTED;
+#endif
 }
 static int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
 extern "C" void lmh_conv2d_force_config(int bm, int bn, int splits) {

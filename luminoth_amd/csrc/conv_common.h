@@ -22,13 +22,15 @@ __device__ __forceinline__ unsigned lmh_div(unsigned n, lmh_fastdiv f) { return 
 #define BK 32
 #define LDK (BK + 4)  // row stride (floats) of K-contiguous LDS tiles: 9*m mod 16 slots, conflict-free b128
 
-// EXPERIMENT (round 5): start-time stagger of co-resident blocks.  On an idle chip blocks b, b + 256, b + 512, ... of a grid
-// share a CU (scripts/probes/lds_base_probe.hip); block slot s = (b >> 8) % NRES sleeps s * units x ~1 us (2048 cycles)
-// before its first load, so that the epilogue of one resident block (HBM stores, matrix pipe idle) falls under the main
-// loop of its neighbours instead of under their epilogues.  Set from the host (lmh_conv_set_stagger); 0 = off.
+// PROBES (round 5; compiled only with -DLMH_PROBES: `LMH_PROBES=1 bash build.sh`, not part of the product build).
+// Start-time stagger of co-resident blocks: on an idle chip blocks b, b + 256, b + 512, ... of a grid share a CU
+// (scripts/probes/lds_base_probe.hip); block slot s = (b >> 8) % NRES sleeps s * units x ~1 us (2048 cycles) before its
+// first load.  Bits 8..10 of the same word are a timing decomposition (results are WRONG with them): 256 = no residual /
+// addend read, 512 = no output stores, 1024 = no main loop.  Set with lmh_conv_set_stagger; 0 = off.
+// (profiles/r05_tile_stagger_sweep.log, profiles/r05_epilogue_decomp.log.)
+#ifdef LMH_PROBES
 __device__ int g_conv_stagger = 0;
-// bits 8..10 (timing decomposition only — results are WRONG with them): 256 = no residual / addend read, 512 = no output
-// stores, 1024 = no main loop
+__device__ __forceinline__ int conv_probe_bits() { return g_conv_stagger; }
 __device__ __forceinline__ void conv_stagger(int nres) {
   const int units = g_conv_stagger & 255;
   if (units > 0) {
@@ -36,6 +38,10 @@ __device__ __forceinline__ void conv_stagger(int nres) {
     for (int i = 0; i < slot * units; ++i) __builtin_amdgcn_s_sleep(32);
   }
 }
+#else
+__device__ __forceinline__ int conv_probe_bits() { return 0; }
+__device__ __forceinline__ void conv_stagger(int) {}
+#endif
 
 // bijective XCD remap: hardware places block b on XCD b % 8
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -205,7 +205,7 @@ k_conv_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict
     y += (size_t)g * M * K;
   }
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int dbg = g_conv_stagger;
+  const int dbg = conv_probe_bits();
   if (dbg & 256) residual = nullptr;
   const int CC = C / BK, KT = (dbg & 1024) ? 0 : d.R * d.S * CC;
 

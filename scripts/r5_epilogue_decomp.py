@@ -1,4 +1,4 @@
-"""Round 5 probe: what does the epilogue of the dominant 1x1 forward class cost?  Times k_conv_fwd on the two expand layers
+"""(needs the probe build: `LMH_PROBES=1 bash luminoth_amd/csrc/build.sh` after touching conv.hip)  Round 5 probe: what does the epilogue of the dominant 1x1 forward class cost?  Times k_conv_fwd on the two expand layers
 with (a) everything, (b) no residual read, (c) no output stores, (d) neither, (e) no main loop (prologue + epilogue only),
 (f) no main loop and no epilogue traffic (launch + index math).  40 launches back to back on one stream, 4 rotating tensor
 sets (past the Infinity Cache).  The variants with bits set compute WRONG results: timing only."""

@@ -1,4 +1,4 @@
-"""Round 5 probe: do SMALLER tiles (more tiles than resident-block slots) with start-time stagger of the co-resident blocks
+"""(needs the probe build: `LMH_PROBES=1 bash luminoth_amd/csrc/build.sh` after touching conv.hip)  Round 5 probe: do SMALLER tiles (more tiles than resident-block slots) with start-time stagger of the co-resident blocks
 beat one lock-step wave of 128x128 tiles on the 1x1 layers of block2 / block3?  (a 512-tile launch is 2 blocks
 per CU that do prologue / main loop / epilogue at the same time; the round-4 stagger probe gained 8 % only where a CU ran
 >= 4 tiles.)  One layer at a time, 40 launches back to back on one stream (kernels of a stream run one after the other),
