@@ -201,7 +201,8 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
                              uint32_t* act_bits, bool* bits_done, lmh_stream_t stream) {
   int rc = 0;
   LMH_CHECK_ARG(x && w && y);
-  g_prof_pending_bytes = desc_bytes(d);
+  // (the residual / addend is an operand tensor like the others: read once)
+  g_prof_pending_bytes = desc_bytes(d) + (residual ? 4.0 * d->N * d->OH * d->OW * (double)d->K : 0.0);
   const int64_t M = (int64_t)d->N * d->OH * d->OW;
   const bool fast = fwd_fast(d);
   LMH_CHECK_ARG((d->C % BK) != 0 || in_sub == nullptr);
@@ -349,7 +350,7 @@ static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const
                                   const float* addend, const float* yact, const uint32_t* xbits, bool* bits_done,
                                   float* dx, lmh_stream_t stream) {
   LMH_CHECK_ARG(dy && w && dx);
-  g_prof_pending_bytes = desc_bytes(d);
+  g_prof_pending_bytes = desc_bytes(d) + (addend ? 4.0 * d->N * d->H * d->W * (double)d->C : 0.0);
   LMH_CHECK_ARG(yact == nullptr || (bwd_data_fast(d) && d->act != 0));   // fused act'(y) only on the fast path
   const int64_t M = (int64_t)d->N * d->H * d->W;
   const bool fast = bwd_data_fast(d);
@@ -781,7 +782,7 @@ extern "C" int lmh_conv2d_fwd_hs(const lmh_conv_desc* d, const void* x, const vo
   if (!hs_ok(d)) { lmh_set_error("lmh_conv2d_fwd_hs: needs compute f16 / bf16, C %% 64 == 0, K %% 64 == 0"); return LMH_ERR_UNSUPPORTED; }
   LMH_CHECK_ARG(act_bits == nullptr || d->act != 0);
   LMH_CHECK_ARG((((uintptr_t)scale | (uintptr_t)shift) & 15) == 0);      // read as float4 by the epilogue
-  g_prof_pending_bytes = hs_bytes(d);
+  g_prof_pending_bytes = hs_bytes(d) + (residual ? 2.0 * d->N * d->OH * d->OW * (double)d->K : 0.0) + (y_is_f32 ? 2.0 * d->N * d->OH * d->OW * (double)d->K : 0.0);
   hs_epilogue e = {scale, shift, residual, nullptr, act_bits, y, y_is_f32, 1.f};
   return hs_launch<false>(d, x, w_fwd, e, (hipStream_t)stream);
 }
@@ -792,7 +793,7 @@ extern "C" int lmh_conv2d_bwd_data_hs(const lmh_conv_desc* d, const void* g, con
   if (rc) return rc;
   LMH_CHECK_ARG(g && w_bwd && dx);
   if (!hs_ok(d)) { lmh_set_error("lmh_conv2d_bwd_data_hs: needs compute f16 / bf16, C %% 64 == 0, K %% 64 == 0"); return LMH_ERR_UNSUPPORTED; }
-  g_prof_pending_bytes = hs_bytes(d);
+  g_prof_pending_bytes = hs_bytes(d) + (addend ? 2.0 * d->N * d->H * d->W * (double)d->C : 0.0) + (dx_is_f32 ? 2.0 * d->N * d->H * d->W * (double)d->C : 0.0);
   hs_epilogue e = {nullptr, nullptr, addend, xbits, nullptr, dx, dx_is_f32, mul};
   return hs_launch<true>(d, g, w_bwd, e, (hipStream_t)stream);
 }

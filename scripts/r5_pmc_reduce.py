@@ -1,6 +1,8 @@
 """profiles/r05_pmc_<tag>.json from three rocprofv3 --pmc passes over `python bench.py --roofline-child ...` (the serialised
 roofline steps): per kernel of the LAST `nsteps` steps
   * matrix-pipe busy fraction = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs)   [pass 1]
+    (GRBM_GUI_ACTIVE spans the dispatch, not just the kernel's waves: a 10 us kernel shows ~6 us of it around its duration,
+    so the fraction UNDER-states short kernels; kernels under counter collection also run 5-25 % longer)
   * HBM bytes per launch = 2 x FETCH_SIZE (gfx950: /opt/skills/guides/MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes [2, 3]
 usage: python scripts/r5_pmc_reduce.py <dir_mfma> <dir_fetch> <dir_write> <out.json> [nsteps]
 Also writes `<out>_traffic.json` in the layout bench.py's `traffic` reader expects ({'kernels': {name: {...}}})."""
@@ -58,7 +60,6 @@ def main():
             k['launches'] = len(m['GRBM_GUI_ACTIVE'])
             if dur.get(n):
                 k['avg_us_under_counters'] = sum(dur[n]) / len(dur[n]) / 1e3
-                k['clock_ghz'] = k['gui_active_cycles_per_launch'] / (sum(dur[n]) / len(dur[n]))
         f, w = vf.get(n, {}).get('FETCH_SIZE'), vw.get(n, {}).get('WRITE_SIZE')
         if f:
             k['fetch_bytes_per_launch'] = 2.0 * 1024.0 * sum(f) / len(f)
@@ -76,10 +77,9 @@ def main():
     json.dump(doc, open(out, 'w'), indent=1, sort_keys=True)
     top = sorted(kernels.items(), key=lambda kv: -(kv[1].get('avg_us_under_counters', 0) * kv[1].get('launches', 0)))[:10]
     for n, k in top:
-        print('%-44s x%-4d %7.1f us  mfma busy %s  clock %s GHz  fetch %s MB  write %s MB' % (
+        print('%-44s x%-4d %7.1f us  mfma busy %s  fetch %s MB  write %s MB' % (
             n[:44], k.get('launches', 0), k.get('avg_us_under_counters', 0),
             '%.2f' % k['mfma_busy_frac'] if k.get('mfma_busy_frac') is not None else '-',
-            '%.2f' % k['clock_ghz'] if k.get('clock_ghz') else '-',
             '%.1f' % (k['fetch_bytes_per_launch'] / 1e6) if 'fetch_bytes_per_launch' in k else '-',
             '%.1f' % (k['write_bytes_per_launch'] / 1e6) if 'write_bytes_per_launch' in k else '-'))
 
