@@ -297,7 +297,7 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
       if (d->C == 128) { if (act_bits) LAUNCH_PP(true, true); else LAUNCH_PP(true, false); }
       else { if (act_bits) LAUNCH_PP(false, true); else LAUNCH_PP(false, false); }
 #undef LAUNCH_PP
-      prof_end(st, desc_flops(d), "k_conv1x1_pp");
+      prof_end(st, desc_flops(d), "k_conv1x1_pp<%s, %s>", d->C == 128 ? "true" : "false", act_bits ? "true" : "false");   // as rocprofv3 prints it
       *bits_done = true;
       LMH_CHECK_LAUNCH();
       return LMH_OK;
