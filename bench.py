@@ -212,7 +212,7 @@ def reduce_kernel_trace(path, nprof):
     return out
 
 
-def rocprof_child(workload, dtype, batch=None, fp32_storage=False, nprof=3, keep_dir=None, timeout=360):
+def rocprof_child(workload, dtype, batch=None, fp32_storage=False, nprof=3, keep_dir=None, timeout=150):
     """The rocprofv3 figure of the roofline, measured LIVE on this box: runs
         rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --roofline-child --workload W --dtype D
     as a child process (the same serialised profiling steps the HIP-event leg times: 2 settling + `nprof` recorded steps on

@@ -547,6 +547,13 @@ int lmh_ssd_loss(const float* cls_pred, const float* loc_pred, const float* labe
 int lmh_sgd_momentum(float* w, const float* g, float* v, int64_t n, const int64_t* seg_offset,
                      const float* seg_wd, int nseg, float lr, float momentum, float gscale,
                      lmh_stream_t stream);
+/* The same update over the range [lo, hi) of the flat buffer (lo % 4 == 0; hi % 4 == 0 or hi == n) with the learning rate read
+ * from device memory (`lr_dev`, one float): recordable in a launch plan, issued per gradient range under the backward pass
+ * (replaces one slice of MomentumOptimizer.apply_gradients, luminoth/train.py:79-91).  `early` only selects the kernel NAME
+ * (k_sgd_early_range / k_sgd_momentum_range: trace tools find the end of a step by the latter). */
+int lmh_sgd_momentum_range(float* w, const float* g, float* v, int64_t n, int64_t lo, int64_t hi,
+                           const int64_t* seg_offset, const float* seg_wd, int nseg, const float* lr_dev,
+                           float momentum, float gscale, int early, lmh_stream_t stream);
 /* Deferred weight-gradient tails.  While lmh_tail_defer(1) is in effect on the calling thread, lmh_conv2d_bwd_weight and
  * lmh_act_bwd launch their main kernel only: the split-K slabs stay in the caller's `ws`, the per-channel partial sums
  * of g stay in theirs, and lmh_tail_last_plan reports where (slabs NULL / splits 0: `dw` already holds the raw

@@ -192,6 +192,7 @@ SIGNATURES = {
     'lmh_ssd_target': (c_i, [P(SsdTargetDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_ssd_loss': (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_fl, c_f, c_f, c_f, c_f, c_f]),
     'lmh_sgd_momentum': (c_i, [c_f, c_f, c_f, c_i64, c_f, c_f, c_i, c_fl, c_fl, c_fl, c_f]),
+    'lmh_sgd_momentum_range': (c_i, [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_f, c_f, c_i, c_f, c_fl, c_fl, c_i, c_f]),
     'lmh_tail_defer': (None, [c_i]),
     'lmh_tail_last_plan': (None, [P(ctypes.c_void_p), P(c_i), P(ctypes.c_void_p), P(c_i)]),
     'lmh_wgrad_tail_batch_workspace_bytes': (c_sz, [P(WgradTail), c_i]),

@@ -73,6 +73,82 @@ extern "C" int lmh_sgd_momentum(float* w, const float* g, float* v, int64_t n, c
   return LMH_OK;
 }
 
+// The same update over the float4-aligned range [lo, hi) of the flat buffer, with the learning rate read from DEVICE memory:
+// a launch that can sit inside a recorded launch plan (a by-value rate would be frozen into it) and run as soon as the
+// gradients of a range are final — behind the early tail batches, under the rest of the backward pass.
+__device__ __forceinline__ void sgd_momentum_range_body(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, int64_t lo, int64_t hi,
+                     const int64_t* __restrict__ seg_offset, const float* __restrict__ seg_wd, int nseg,
+                     const float* __restrict__ lr_ptr, float momentum, float gscale) {
+  __shared__ int64_t s_off[OPT_MAX_SEG + 1];
+  __shared__ float s_wd[OPT_MAX_SEG];
+  for (int i = threadIdx.x; i <= nseg; i += 256) s_off[i] = seg_offset[i];
+  for (int i = threadIdx.x; i < nseg; i += 256) s_wd[i] = seg_wd[i];
+  __syncthreads();
+  const float lr = *lr_ptr;
+  const int64_t lo4 = lo >> 2, hi4 = hi >> 2, stride = (int64_t)gridDim.x * 256;
+  int64_t i4 = lo4 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < (hi & 3)) {   // scalar tail (only when hi is the end of the buffer)
+    const int64_t i = 4 * hi4 + threadIdx.x;
+    const float wdt = s_wd[seg_find(s_off, nseg, i)];
+    const float wi = w[i];
+    const float vi = momentum * v[i] + (g[i] * gscale + wdt * wi);
+    v[i] = vi;
+    w[i] = wi - lr * vi;
+  }
+  if (i4 >= hi4) return;
+  int seg = seg_find(s_off, nseg, 4 * i4);
+  for (; i4 < hi4; i4 += stride) {
+    float wd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      while (s_off[seg + 1] <= 4 * i4 + e) ++seg;
+      wd[e] = s_wd[seg];
+    }
+    float4 wi = reinterpret_cast<const float4*>(w)[i4];
+    const float4 gi = reinterpret_cast<const float4*>(g)[i4];
+    float4 vi = reinterpret_cast<const float4*>(v)[i4];
+    vi.x = momentum * vi.x + (gi.x * gscale + wd[0] * wi.x);
+    vi.y = momentum * vi.y + (gi.y * gscale + wd[1] * wi.y);
+    vi.z = momentum * vi.z + (gi.z * gscale + wd[2] * wi.z);
+    vi.w = momentum * vi.w + (gi.w * gscale + wd[3] * wi.w);
+    wi.x -= lr * vi.x; wi.y -= lr * vi.y; wi.z -= lr * vi.z; wi.w -= lr * vi.w;
+    reinterpret_cast<float4*>(v)[i4] = vi;
+    reinterpret_cast<float4*>(w)[i4] = wi;
+  }
+}
+
+// two names for the trace tools: a step ENDS with k_sgd_momentum / k_sgd_momentum_range (scripts/make_profile_summary.py,
+// bench.py reduce_kernel_trace); the updates issued under the backward pass are k_sgd_early_range
+__global__ void __launch_bounds__(256)
+k_sgd_momentum_range(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, int64_t lo, int64_t hi,
+                     const int64_t* __restrict__ seg_offset, const float* __restrict__ seg_wd, int nseg,
+                     const float* __restrict__ lr_ptr, float momentum, float gscale) {
+  sgd_momentum_range_body(w, g, v, lo, hi, seg_offset, seg_wd, nseg, lr_ptr, momentum, gscale);
+}
+__global__ void __launch_bounds__(256)
+k_sgd_early_range(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, int64_t lo, int64_t hi,
+                  const int64_t* __restrict__ seg_offset, const float* __restrict__ seg_wd, int nseg,
+                  const float* __restrict__ lr_ptr, float momentum, float gscale) {
+  sgd_momentum_range_body(w, g, v, lo, hi, seg_offset, seg_wd, nseg, lr_ptr, momentum, gscale);
+}
+
+extern "C" int lmh_sgd_momentum_range(float* w, const float* g, float* v, int64_t n, int64_t lo, int64_t hi,
+                                      const int64_t* seg_offset, const float* seg_wd, int nseg, const float* lr_dev,
+                                      float momentum, float gscale, int early, lmh_stream_t stream) {
+  LMH_CHECK_ARG(w && g && v && seg_offset && seg_wd && lr_dev && n > 0 && nseg > 0 && nseg <= OPT_MAX_SEG);
+  LMH_CHECK_ARG(lo >= 0 && lo < hi && hi <= n && (lo & 3) == 0 && ((hi & 3) == 0 || hi == n));
+  const int64_t n4 = (hi - lo) >> 2;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 + 1 : 2048);
+  if (early)
+    lmh_launch(k_sgd_early_range, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, v, lo, hi, seg_offset, seg_wd,
+               nseg, lr_dev, momentum, gscale);
+  else
+    lmh_launch(k_sgd_momentum_range, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, g, v, lo, hi, seg_offset, seg_wd,
+               nseg, lr_dev, momentum, gscale);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
 __global__ void __launch_bounds__(256)
 k_l2_reg(const float* __restrict__ w, int64_t n, const int64_t* __restrict__ seg_offset,
          const float* __restrict__ seg_wd, int nseg, float* __restrict__ out) {

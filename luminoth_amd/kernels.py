@@ -1137,6 +1137,14 @@ def sgd_momentum(w, g, v, seg_offset, seg_wd, lr, momentum, gscale=1.0):
                                float(lr), float(momentum), float(gscale), _stream()), 'lmh_sgd_momentum')
 
 
+def sgd_momentum_range(w, g, v, seg_offset, seg_wd, lo, hi, lr_dev, momentum, gscale=1.0, early=False):
+    """The momentum update over [lo, hi) of the flat buffer; `lr_dev`: one-float device tensor (recordable in a launch plan)."""
+    lib = _lib.load()
+    check(lib.lmh_sgd_momentum_range(_p(w), _p(g), _p(v), w.numel(), int(lo), int(hi), _p(seg_offset), _p(seg_wd),
+                                     seg_wd.numel(), _p(lr_dev), float(momentum), float(gscale), int(bool(early)), _stream()),
+          'lmh_sgd_momentum_range')
+
+
 def grad_clip_factors(w, g, seg_offset, seg_wd, gscale, clip_norm, out):
     """out[s] = clip / max(||g*gscale + wd*w||_2 over segment s, clip)  (tf.clip_by_norm per variable)."""
     lib = _lib.load()

@@ -215,6 +215,74 @@ class GradientBuckets(object):
         self._armed = None
 
 
+class EarlyUpdates(GradientBuckets):
+    """ONE GPU, opt-in: the same walk over finished gradient ranges, but instead of all-reducing a range it is UPDATED right
+    away (the 48 us optimizer launch at the end of the step, with the main stream idle, shrinks to the
+    ranges the backward finishes last — and the backward pays for it: see MomentumOptimizer.__init__).  A range [lo, hi) is complete once the trunk backward has enqueued its nodes: the
+    update is a recordable launch (`lmh_sgd_momentum_range`, learning rate read from device memory) on the bucket stream,
+    behind every stream that produced those gradients and behind the weight-gradient tails of those layers (which read the
+    weights: dgamma of a frozen BatchNorm) — and behind the proposal stream, whose reported L2 term reads ALL weights.
+    Nothing reads the weights of a finished node again in the step (the Winograd-transformed copies, the BatchNorm scale
+    table and the 16-bit working copies were made at the start of the step).  Same arithmetic per element as the one
+    launch over the whole buffer: bit-identical weights (tests/test_gpu_plan.py)."""
+
+    def __init__(self, store, optimizer, bucket_bytes=None):
+        if bucket_bytes is None:
+            bucket_bytes = int(os.environ.get('LUMINOTH_AMD_EARLY_UPDATE_MB', '8')) << 20
+        super(EarlyUpdates, self).__init__(store, reduce_fn=lambda t: None, bucket_bytes=bucket_bytes)
+        self.opt = optimizer
+
+    def _launch(self, lo, hi):
+        from luminoth_amd.models.base.layers import SideStream
+        from luminoth_amd.models.fasterrcnn.fasterrcnn import FasterRCNN
+        st = self.store
+        grad = st.grad
+        cur = torch.cuda.current_stream(grad.device)
+        # the proposal / RCNN stream is idle during the trunk backward, and a FOURTH stream would alias one of the three onto
+        # the same hardware queue (HIP creates 4: measured 10.9 instead of 6.6 ms per step with a stream of its own here).
+        # Its earlier work of the step (the reported L2 term reads ALL weights) is in front of the update by stream order.
+        comm = FasterRCNN._AUX_STREAMS.get(str(grad.device))
+        if comm is None:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=grad.device)
+            comm = self._comm
+        self._comm = comm
+        K.stream_wait(comm, cur)
+        for s_ in SideStream._streams.values():
+            if s_ is not comm:
+                K.stream_wait(comm, s_)
+        hi4 = hi if hi == int(grad.numel()) else hi // 4 * 4
+        lo4 = (lo + 3) // 4 * 4
+        if hi4 <= lo4:
+            return
+        from luminoth_amd import plan as P
+        with K.launch_on(comm):
+            K.TAILS.flush()
+            K.sgd_momentum_range(st.flat, grad, st.mom, st.seg_offset, st.seg_wd, lo4, hi4, self.opt.lr_dev,
+                                 self.opt.momentum, 1.0, early=True)
+        # host bookkeeping of what the final update may skip: under a recorded plan it has to happen at every replay too
+        P.host_call(lambda: self._done.append((lo4, hi4)))
+
+    def finish(self):
+        """-> the ranges no early update covered, after ordering the calling stream behind the bucket stream."""
+        grad = self.store.grad
+        numel = int(grad.numel())
+        todo, pos = [], 0
+        for lo, hi in sorted(self._done):
+            if lo < pos or hi > numel or lo >= hi:
+                raise RuntimeError('EarlyUpdates: ranges %r overlap or leave [0, %d)' % (sorted(self._done), numel))
+            if lo > pos:
+                todo.append((pos, lo))
+            pos = hi
+        if pos < numel:
+            todo.append((pos, numel))
+        if self._comm is not None and self._done:
+            K.stream_wait(torch.cuda.current_stream(grad.device), self._comm)
+        self._done = []
+        self._armed = None
+        return todo
+
+
 ACTIVE_BUCKETS = None          # the GradientBuckets of the optimizer in use (None: single GPU)
 
 
@@ -242,12 +310,23 @@ class MomentumOptimizer(object):
         self.buckets = None
         self._slot2 = None
         self._factors = None
+        self.early = None
+        self.lr_dev, self._lr_dev_value = None, None
         if dist.is_available() and dist.is_initialized() and \
                 (dist.get_world_size() > 1 or os.environ.get('LUMINOTH_AMD_FORCE_BUCKETS') == '1'):
             if os.environ.get('LUMINOTH_AMD_BUCKETED_ALLREDUCE', '1') != '0' and \
                     (self.store.grad.is_cuda or os.environ.get('LUMINOTH_AMD_FORCE_BUCKETS') == '1'):
                 self.buckets = GradientBuckets(self.store)
                 install_buckets(self.buckets)
+        elif (type(self) is MomentumOptimizer and not self.use_nesterov and self.clip_norm is None and
+              self.store.grad.is_cuda and hasattr(model, '_step_body') and
+              os.environ.get('LUMINOTH_AMD_EARLY_UPDATE', '0') != '0'):
+            # one GPU, plain momentum SGD: finished gradient ranges are updated under the rest of the backward pass.  OPT-IN
+            # (LUMINOTH_AMD_EARLY_UPDATE=1): measured on the benchmark step the end of the step gets 0.043 ms shorter and the
+            # backward 0.066 ms longer (the HBM-bound update competes with it): 6.547 -> 6.570 ms, profiles/r05_schedule_ab.md
+            self.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.store.grad.device)
+            self.early = EarlyUpdates(self.store, self)
+            install_buckets(self.early)
 
     def reduce_gradients(self):
         """Sum the flat gradient buffer over the data-parallel replicas; returns the factor that turns the sum
@@ -280,7 +359,23 @@ class MomentumOptimizer(object):
             K.optimizer_step(3 if self.use_nesterov else 0, st.flat, st.grad, st.mom, None, st.seg_offset, st.seg_wd,
                              factors, lr, self.momentum, 0.0, 0.0, gscale)
 
+    def prepare_step(self):
+        """Before the step's launches: the learning rate of THIS step in device memory (early updates read it from there;
+        written only when it changes)."""
+        if self.early is not None:
+            lr = get_learning_rate(self.cfg, self.global_step)
+            if lr != self._lr_dev_value:
+                self.lr_dev.fill_(lr)
+                self._lr_dev_value = lr
+
     def step(self):
+        if self.early is not None:
+            self.prepare_step()          # (a caller that did not go through train_step: nothing was updated early then)
+            st = self.store
+            for lo, hi in self.early.finish():
+                K.sgd_momentum_range(st.flat, st.grad, st.mom, st.seg_offset, st.seg_wd, lo, hi, self.lr_dev, self.momentum, 1.0)
+            self.global_step += 1
+            return
         gscale = self.reduce_gradients()
         lr = get_learning_rate(self.cfg, self.global_step)
         self._update(lr, gscale, self._clip_factors(gscale))
@@ -385,6 +480,8 @@ def train_step(model, optimizer, image, gt_boxes, next_image=None, next_gt=None)
     """One step of train.py:66-91: forward, loss, backward, (all-reduce), update.  `next_image` / `next_gt` (optional): the
     batch of the FOLLOWING step, if the caller already has it — the model computes that batch's frozen trunk prefix and
     anchor targets ahead of time in otherwise idle slots of this step (same arithmetic; see FasterRCNN.train_step)."""
+    if hasattr(optimizer, 'prepare_step'):
+        optimizer.prepare_step()
     if FUSED_STEP and hasattr(model, 'train_step'):
         if next_image is not None and getattr(model, 'accepts_next_image', False):
             total, pred = model.train_step(image, gt_boxes, next_image=next_image, next_gt=next_gt)
