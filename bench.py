@@ -266,6 +266,38 @@ def rocprof_child(workload, dtype, batch=None, fp32_storage=False, nprof=3, keep
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+class StepFailure(RuntimeError):
+    """The timed block of one exchange mode failed on some rank (agreed on by all ranks)."""
+
+
+# N > 1: the exchange modes, most overlapped first (environment each one adds on top of the previous)
+LADDER = [{}, {'LUMINOTH_AMD_BUCKETED_ALLREDUCE': '0'}, {'LUMINOTH_AMD_BUCKETED_ALLREDUCE': '0', 'LUMINOTH_AMD_PLAN': '0'}]
+
+
+def run_ladder(world, attempt, environ=None):
+    """First-contact safety net of the multi-GPU run.  `attempt(mode)` runs the timed block in exchange mode `mode`
+    ({'bucketed_allreduce_under_backward', 'launch_plan'}) and returns its result dict, or raises StepFailure.  A mode that
+    raises, or that leaves the replicas with different bits (`replicas_identical` False) while a simpler mode is left, is
+    recorded and the next one runs.  -> (result, mode, fallbacks); result None when every mode failed.  N = 1: one mode."""
+    environ = os.environ if environ is None else environ
+    ladder = LADDER if world > 1 else LADDER[:1]
+    fallbacks = []
+    for li, env in enumerate(ladder):
+        environ.update(env)
+        mode = {'bucketed_allreduce_under_backward': world > 1 and environ.get('LUMINOTH_AMD_BUCKETED_ALLREDUCE', '1') != '0',
+                'launch_plan': environ.get('LUMINOTH_AMD_PLAN', '1') != '0'}
+        try:
+            res = attempt(mode)
+        except StepFailure as e:
+            fallbacks.append(dict(mode, error=str(e)))
+            continue
+        if world > 1 and res.get('replicas_identical') is False and li + 1 < len(ladder):
+            fallbacks.append(dict(mode, error='replicas diverged after the timed steps'))
+            continue
+        return res, mode, fallbacks
+    return None, None, fallbacks
+
+
 def free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -378,9 +410,6 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-
-    class StepFailure(RuntimeError):
-        """The timed block of one exchange mode failed on some rank (agreed on by all ranks)."""
 
     if world > 1:
         # last resort: a hang that no collective timeout sees (a stream waiting for an event that never fires) still ends
@@ -606,39 +635,28 @@ def main():
                                      'ms_per_step': v['ms'] / nprof}
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}})
 
-    # ---- N > 1: first contact with RCCL has a safety net.  The exchange modes, most overlapped first; a mode whose timed
-    # block raises on any rank, or leaves the replicas with different bits, is reported under `dist.fallbacks` and the next
-    # one produces the number (`dist.mode` says which did).  N = 1 has one mode and no collective.
-    ladder = [{}]
-    if world > 1:
-        ladder += [{'LUMINOTH_AMD_BUCKETED_ALLREDUCE': '0'},
-                   {'LUMINOTH_AMD_BUCKETED_ALLREDUCE': '0', 'LUMINOTH_AMD_PLAN': '0'}]
-    fallbacks, head = [], None
-    for li, env in enumerate(ladder):
-        os.environ.update(env)
-        P.ENABLED = os.environ.get('LUMINOTH_AMD_PLAN', '1') != '0'
-        mode = {'bucketed_allreduce_under_backward': world > 1 and os.environ.get('LUMINOTH_AMD_BUCKETED_ALLREDUCE', '1') != '0',
-                'launch_plan': P.ENABLED}
+    # ---- N > 1: first contact with RCCL has a safety net (run_ladder): a mode whose timed block raises on any rank, or leaves
+    # the replicas with different bits, is reported under `dist.fallbacks` and the next one produces the number (`dist.mode`
+    # says which did).  N = 1 has one mode and no collective.
+    def attempt(mode):
+        P.ENABLED = mode['launch_plan']
         try:
-            head = run_workload(args.workload, args.dtype, args.steps, args.warmup, batch=args.batch,
-                                want_roofline=not args.no_roofline, phases_n=args.phases,
-                                keep_sd=(rank == 0 and world == 1 and not args.no_cpu_baseline))
-        except StepFailure as e:
-            fallbacks.append(dict(mode, error=str(e)))
-            head = None
-            continue
-        if world > 1 and head.get('replicas_identical') is False and li + 1 < len(ladder):
-            fallbacks.append(dict(mode, error='replicas diverged after the timed steps'))
+            res = run_workload(args.workload, args.dtype, args.steps, args.warmup, batch=args.batch,
+                               want_roofline=not args.no_roofline, phases_n=args.phases,
+                               keep_sd=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+        except StepFailure:
+            raise
+        if world > 1 and res.get('replicas_identical') is False:
             T.install_buckets(None)
-            head = None
             torch.cuda.empty_cache()
-            continue
-        head['mode'] = mode
-        break
+        return res
+
+    head, mode, fallbacks = run_ladder(world, attempt)
     if head is None:
         if rank == 0:
             sys.stderr.write('bench.py: every exchange mode failed: %r\n' % (fallbacks,))
         raise SystemExit(3)
+    head['mode'] = mode
     wl, dt, model = head['wl'], head['dt'], head['model']
     plan_on = head['launch_plan']['enabled']
     schedule = ('three streams; ' + ('recorded launch plan replayed with one host call per step (%d kernel launches per step, '

@@ -210,7 +210,10 @@ class LuminothHipError(RuntimeError):
 
 
 def build(force=False):
-    """Compile csrc/*.hip for gfx950 into csrc/libluminoth_hip.so (in-tree)."""
+    """Compile csrc/*.hip for gfx950 into csrc/libluminoth_hip.so (in-tree).  build.sh recompiles an object when its source,
+    any header of csrc/ or the C-ABI header is newer, and prints which translation units it compiled and which it reused;
+    `force` (or LUMINOTH_AMD_REBUILD=1) removes every object first."""
+    force = force or os.environ.get('LUMINOTH_AMD_REBUILD') == '1'
     script = os.path.join(_HERE, 'csrc', 'build.sh')
     if force:
         for f in os.listdir(os.path.join(_HERE, 'csrc')):

@@ -353,3 +353,51 @@ def test_bench_kernel_trace_reduction(tmp_path):
     assert '__amd_rocclr_copyBuffer' not in out
     assert abs(out['_step_ms'] - (2 * 42000 + 2 * 1000 + 11000) * 1e-6) < 1e-9
     assert bench.reduce_kernel_trace(str(f), 5) is None          # needs n + 1 optimizer launches
+
+
+def test_bench_exchange_ladder():
+    """bench.py --gpus N: the fall-back ladder bucketed + plan -> one all-reduce + plan -> one all-reduce, eager (first contact
+    with an 8-GPU node must not end in an empty record).  Pure host logic: exercised here with stand-in attempts."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    B, NB = {'bucketed_allreduce_under_backward': True, 'launch_plan': True}, {'bucketed_allreduce_under_backward': False, 'launch_plan': True}
+    E_ = {'bucketed_allreduce_under_backward': False, 'launch_plan': False}
+
+    def scripted(outcomes):
+        seen = []
+
+        def attempt(mode):
+            seen.append(dict(mode))
+            o = outcomes[len(seen) - 1]
+            if isinstance(o, Exception):
+                raise o
+            return dict(o)
+        return attempt, seen
+
+    # the bucketed exchange raises: ONE fall-back, the second mode produces the result
+    a, seen = scripted([bench.StepFailure('boom'), {'dt': 1.0, 'replicas_identical': True}])
+    res, mode, fb = bench.run_ladder(8, a, environ={})
+    assert res['dt'] == 1.0 and mode == NB and seen == [B, NB]
+    assert fb == [dict(B, error='boom')]
+    # diverged replicas in the first two modes: eager launches with one all-reduce produce the number
+    a, seen = scripted([{'replicas_identical': False}, {'replicas_identical': False}, {'dt': 2.0, 'replicas_identical': True}])
+    res, mode, fb = bench.run_ladder(2, a, environ={})
+    assert res['dt'] == 2.0 and mode == E_ and [f['error'] for f in fb] == ['replicas diverged after the timed steps'] * 2
+    # the LAST mode is reported even when it diverged (the line then says so), and a ladder that only raises returns None
+    a, _ = scripted([bench.StepFailure('a'), bench.StepFailure('b'), {'dt': 3.0, 'replicas_identical': False}])
+    res, mode, fb = bench.run_ladder(4, a, environ={})
+    assert res['replicas_identical'] is False and mode == E_ and len(fb) == 2
+    a, _ = scripted([bench.StepFailure('a'), bench.StepFailure('b'), bench.StepFailure('c')])
+    assert bench.run_ladder(4, a, environ={})[0] is None
+    # one GPU: one mode, no bucketed exchange, the user's environment decides about the plan
+    a, seen = scripted([{'dt': 4.0}])
+    res, mode, fb = bench.run_ladder(1, a, environ={'LUMINOTH_AMD_PLAN': '0'})
+    assert mode == {'bucketed_allreduce_under_backward': False, 'launch_plan': False} and fb == [] and len(seen) == 1
+    # a pre-set environment is respected by the first mode
+    a, seen = scripted([{'dt': 5.0, 'replicas_identical': True}])
+    res, mode, fb = bench.run_ladder(8, a, environ={'LUMINOTH_AMD_BUCKETED_ALLREDUCE': '0'})
+    assert mode == NB
