@@ -228,7 +228,11 @@ def rocprof_child(workload, dtype, batch=None, fp32_storage=False, nprof=3, keep
     if not os.path.exists(exe):
         sys.stderr.write('bench.py: rocprofv3 not found; roofline from HIP events only\n')
         return None
-    tmp = tempfile.mkdtemp(prefix='lmh_rocprof_', dir='/tmp')
+    try:
+        tmp = tempfile.mkdtemp(prefix='lmh_rocprof_', dir='/tmp' if os.access('/tmp', os.W_OK) else None)
+    except Exception as e:
+        sys.stderr.write('bench.py: no scratch directory for the rocprofv3 child (%r); roofline from HIP events only\n' % (e,))
+        return None
     child = [sys.executable, os.path.abspath(__file__), '--roofline-child', '--workload', workload, '--dtype', dtype,
              '--roofline-steps', str(nprof)]
     if batch:
@@ -240,7 +244,7 @@ def rocprof_child(workload, dtype, batch=None, fp32_storage=False, nprof=3, keep
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     try:
-        r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run(cmd, cwd=tmp, env=dict(env, TMPDIR='/tmp' if os.access('/tmp', os.W_OK) else tmp), capture_output=True, text=True, timeout=timeout)
         if r.returncode != 0:
             sys.stderr.write('bench.py: rocprofv3 child rc %d: %s\n' % (r.returncode, r.stderr[-600:]))
             return None
