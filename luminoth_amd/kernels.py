@@ -6,6 +6,7 @@ that merely own the memory.  Nothing in this file computes with torch ops, and
 nothing falls back to the CPU: tensors must live on a ROCm device.
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -19,20 +20,27 @@ ACT = {None: 0, 'none': 0, 'relu': 1, 'relu6': 2}
 # While a launch plan is being recorded (luminoth_amd/plan.py) every tensor whose address enters a launch is appended
 # here and kept alive by the plan: a recorded pointer must stay valid — and must never be handed to another tensor —
 # for as long as the plan is replayed.
-_PLAN_KEEP = None
+# per THREAD, like the C recorder (csrc/plan.hip g_rec): tensors whose addresses enter launches of the plan this thread records
+class _PlanTLS(threading.local):
+    keep = None
+
+
+_TLS = _PlanTLS()
 
 
 def plan_keep(*tensors):
     """Tensors whose data_ptr() goes into a launch without passing through _p (descriptor arrays)."""
-    if _PLAN_KEEP is not None:
-        _PLAN_KEEP.extend(t for t in tensors if t is not None)
+    keep = _TLS.keep
+    if keep is not None:
+        keep.extend(t for t in tensors if t is not None)
 
 
 def _p(t):
     if t is None:
         return None
-    if _PLAN_KEEP is not None:
-        _PLAN_KEEP.append(t)
+    keep = _TLS.keep
+    if keep is not None:
+        keep.append(t)
     if not t.is_cuda:
         raise _lib.LuminothHipError('luminoth_amd kernels need ROCm device tensors (got %s); '
                                     'there is no CPU fallback' % t.device)
@@ -296,7 +304,7 @@ class TailQueue(object):
             t.colpart, t.colrows = e.get('colpart', 0) or 0, e.get('colrows', 0)
             cs = e.get('colsum')
             t.colsum = cs.data_ptr() if cs is not None else 0
-            if _PLAN_KEEP is not None:
+            if _TLS.keep is not None:
                 plan_keep(dw, cs, e.get('_ws'), e.get('_cws'), *(bn.values() if bn is not None else ()))
         ws = _workspace(lib.lmh_wgrad_tail_batch_workspace_bytes(arr, n), dev, 'tails')
         check(lib.lmh_wgrad_tail_batch(arr, n, _p(ws), ctypes.c_size_t(ws.numel()), _stream()), 'lmh_wgrad_tail_batch')

@@ -698,7 +698,7 @@ class FasterRCNN(object):
             return
         from luminoth_amd import plan as P
         if P.recording():
-            ev = P._ACTIVE.new_event()
+            ev = P.active().new_event()
         else:
             ev = _lib.load().lmh_event_create()
         K.event_record(ev, torch.cuda.current_stream(self.device))

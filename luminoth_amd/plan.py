@@ -9,7 +9,7 @@ recorded sequence from C — the same kernels with the same arguments on the sam
 
 What makes a recorded step replayable is a property of the HOST code around it, kept here and in
 `FasterRCNN._planned_step`:
-  * every tensor whose address entered a recorded launch is kept alive by the plan (`kernels._PLAN_KEEP`), so an address
+  * every tensor whose address entered a recorded launch is kept alive by the plan (`kernels._TLS.keep`), so an address
     never goes back to the allocator and never means another tensor;
   * per-step inputs (images, gt boxes, seeds) and what one step hands to the next (the frozen trunk prefix and the
     anchor targets computed one step ahead) live in buffers at fixed addresses, double-buffered by step parity;
@@ -30,7 +30,18 @@ ENABLED = os.environ.get('LUMINOTH_AMD_PLAN', '1') != '0'
 # eager steps of one shape / variant before it is recorded: allocations, workspaces and lazily built constants settle
 WARM_STEPS = int(os.environ.get('LUMINOTH_AMD_PLAN_WARM', '1'))
 
-_ACTIVE = None      # the StepPlan being recorded on this thread
+import threading
+
+
+class _TLS(threading.local):
+    active = None      # the StepPlan being recorded on THIS thread (the C recorder, csrc/plan.hip g_rec, is thread-local too)
+
+
+_tls = _TLS()
+
+
+def active():
+    return _tls.active
 
 
 class StepPlan(object):
@@ -46,19 +57,17 @@ class StepPlan(object):
 
     # ---- recording ----------------------------------------------------------------------------------
     def __enter__(self):
-        global _ACTIVE
-        if _ACTIVE is not None:
+        if _tls.active is not None:
             raise RuntimeError('a launch plan is already being recorded')
         _lib.check(_lib.load().lmh_plan_begin(), 'lmh_plan_begin')
-        _ACTIVE = self
-        K._PLAN_KEEP = self.keep
+        _tls.active = self
+        K._TLS.keep = self.keep
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        global _ACTIVE
         lib = _lib.load()
-        _ACTIVE = None
-        K._PLAN_KEEP = None
+        _tls.active = None
+        K._TLS.keep = None
         if exc_type is not None:
             lib.lmh_plan_abort()
             self.destroy()
@@ -130,18 +139,18 @@ def pinned_bytes(plan):
 
 
 def recording():
-    return _ACTIVE is not None
+    return _tls.active is not None
 
 
 def host_call(fn):
     """Run `fn()` now; while a plan is being recorded also register it to run at this very position of every replay
     (host work that launches through something else than this library: a collective)."""
-    if _ACTIVE is not None:
-        _ACTIVE.cuts.append((_lib.load().lmh_plan_position(), fn))
+    if _tls.active is not None:
+        _tls.active.cuts.append((_lib.load().lmh_plan_position(), fn))
     return fn()
 
 
 def keep(*objs):
     """Objects the plan being recorded must keep alive."""
-    if _ACTIVE is not None:
-        _ACTIVE.keep.extend(objs)
+    if _tls.active is not None:
+        _tls.active.keep.extend(objs)
