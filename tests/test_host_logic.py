@@ -401,3 +401,32 @@ def test_bench_exchange_ladder():
     a, seen = scripted([{'dt': 5.0, 'replicas_identical': True}])
     res, mode, fb = bench.run_ladder(8, a, environ={'LUMINOTH_AMD_BUCKETED_ALLREDUCE': '0'})
     assert mode == NB
+
+
+def test_step_state_helpers():
+    """Host pieces of the per-shape step state (round 5): the gt CAPACITY of a state's fixed buffers (the gt count of a
+    batch no longer creates states), the in-place version fingerprint of a gt argument (a loader that refills its buffers is not
+    served a stale copy), and the bytes a recorded plan pins (distinct storages, nested containers)."""
+    import numpy as np
+    import torch
+    from luminoth_amd import plan as P
+    from luminoth_amd.models.fasterrcnn.fasterrcnn import FasterRCNN
+    assert [FasterRCNN._gt_bucket(g) for g in (0, 1, 8, 9, 16, 17, 100)] == [8, 8, 8, 16, 16, 32, 128]
+    t = torch.zeros(3, 5)
+    v0 = FasterRCNN._gt_versions(t)
+    t.add_(1.0)
+    assert FasterRCNN._gt_versions(t) != v0
+    pair = (torch.zeros(2, 4, 5), torch.zeros(2, dtype=torch.int32))
+    f0 = FasterRCNN._gt_versions(pair)
+    pair[1].fill_(3)
+    f1 = FasterRCNN._gt_versions(pair)
+    assert f0 != f1 and f0[0] == f1[0]
+    assert FasterRCNN._gt_versions([np.zeros((2, 5), np.float32)]) == (None,) and FasterRCNN._gt_versions(None) is None
+
+    class FakePlan(object):
+        pass
+    base = torch.zeros(1000)
+    pl = FakePlan()
+    pl.keep = [base, base[10:20], {'a': torch.zeros(8, dtype=torch.float64), 'b': (base[:5], [torch.zeros(3)])}, 7, None]
+    assert P.pinned_bytes(pl) == 4000 + 64 + 12          # views share their storage; counted once
+    assert P.pinned_bytes(pl) == pl._pinned
