@@ -23,6 +23,10 @@ static lmh_option g_options[] = {
     {"x3_tile_slots", 256},   // bf16x3 fwd / bwd_data tile by pick_tile(slots); 0: half_tile
     {"x3_pf", -1},            // bf16x3 pipeline for every pass (-1: per-pass values below)
     {"x3_pf_fwd", 0}, {"x3_pf_gb", 0}, {"x3_pf_bd", 0}, {"x3_pf_bw", 0},
+    {"x3_pipe", 0},           // ... their schedule: 0 = phase by phase, two blocks per CU (default: 5.59 ms per step against 6.60 — the
+                              // pipelined blocks need a whole CU and shut the other streams' kernels out); 1 = software-pipelined
+    {"x3_stagger", 0},        // phase-by-phase schedule: the block in a CU's second LDS slot starts this many x 64 cycles late
+    {"x3_new", 1},            // bf16x3: the software-pipelined kernels of round 6 (conv_x3.h); 0: the round-2 kernels (conv_half.h)
     {"bd_slots", 256},        // resident-block slots the backward-data tile choice fills
     {"bw_slots", 512},        // ... the split-K weight gradient
     {"wgrad_glds", 1},        // 1x1 weight gradient: operands straight into LDS (conv_wgrad1x1.h)

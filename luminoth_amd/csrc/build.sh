@@ -4,16 +4,18 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-if [ -n "$LMH_PROBES" ]; then PROBES="-DLMH_PROBES"; fi   # timing probes in the convolution kernels (scripts/r5_*sweep*, r5_epilogue_decomp)
+if [ "${LMH_PROBES:-0}" != 0 ]; then PROBES="-DLMH_PROBES"; fi   # timing probes in the convolution kernels (scripts/r5_*sweep*, r5_epilogue_decomp)
 FLAGS="--offload-arch=gfx950 $PROBES -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-result"
 OBJS=""
 pids=""
 # objects built with other flags (e.g. a probe build) are stale whatever their age
 if [ "$(cat .build_flags 2>/dev/null)" != "$FLAGS" ]; then rm -f *.o; echo "$FLAGS" > .build_flags; fi
-for f in api plan proposals detect targets roi loss optim elementwise bnorm ssd tail halfstore conv; do
+for f in api plan proposals detect targets roi loss optim elementwise bnorm ssd tail halfstore conv conv_x3; do
   stale=0
   if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ]; then stale=1; fi
   for h in *.h ../../include/luminoth_hip.h; do
+    # (conv_x3.h holds the kernels of conv_x3.hip alone: no other translation unit includes it)
+    if [ "$h" = conv_x3.h ] && [ "$f" != conv_x3 ]; then continue; fi
     if [ "$h" -nt "$f.o" ]; then stale=1; fi
   done
   if [ $stale = 1 ]; then

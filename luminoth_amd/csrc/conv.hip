@@ -37,6 +37,7 @@ __device__ __attribute__((aligned(64))) float lmh_zero_page[16];  // zero-initia
 #include "conv_pp.h"
 #include "conv_wgrad1x1.h"
 #include "conv_half.h"
+#include "conv_x3_api.h"
 
 // ============================================================================
 // host dispatch
@@ -160,6 +161,8 @@ static float half_gscale(const lmh_conv_desc* d) { return d->compute == 1 ? 1024
 // 0 for every pass against 7.29 (forward 3), 7.46 (stacked Winograd GEMMs 3), 7.60 (forward + stacked 1).
 // LMH_X3_PF forces one value for all passes.
 #define x3_tile_pick lmh_opt("x3_tile_slots")   // tile of the bf16x3 fwd / bwd_data kernels by pick_tile(slots); 0: half_tile
+// schedule of the round-6 bf16x3 kernels (conv_x3.h): 1 = software-pipelined (needs an even stage count), 0 = phase by phase
+static int x3_pipe(int stages) { return (lmh_opt("x3_pipe") && (stages & 1) == 0) ? 1 : 0; }
 static int x3_pf(const char* pass) { const int a = lmh_opt("x3_pf"); return a >= 0 ? a : lmh_opt(pass); }
 #define x3_pf_fwd x3_pf("x3_pf_fwd")
 #define x3_pf_gb x3_pf("x3_pf_gb")     // stacked Winograd GEMMs (forward kernel)
@@ -223,6 +226,13 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
   const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
   if (d->compute && fast && in_sub == nullptr) {          // f16 / bf16 operands, fp32 accumulate (conv_half.h)
     if (d->compute == 3 && x3_tile_pick) pick_tile(M, d->K, &bm, &bn, x3_tile_pick); else half_tile(M, d->K, &bm, &bn);
+    if (d->compute == 3 && lmh_opt("x3_new") ) {      // round-6 bf16x3 kernel, bit mask fused (conv_x3.h)
+      prof_begin(st);
+      rc = lmh_x3_fwd_launch(d, x, w, scale, shift, residual, y, act_bits, 0, bm, bn, x3_pipe(d->R * d->S * (d->C / BK)), st);
+      prof_end(st, desc_flops(d), "k_x3_fwd<%d, %d, false>", bm, bn);
+      *bits_done = true;
+      return rc;
+    }
     const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn));
 #define LAUNCH_FWD_H(DT_, BM_, BN_)                                                                       \
     do { if (half_pf == 4) lmh_launch((k_conv_fwd_h<DT_, BM_, BN_, 4>), dim3(grid), dim3(512), 0, st, *d, x, w, scale, shift, residual, y, 1); \
@@ -361,6 +371,13 @@ static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const
   hipStream_t st = (hipStream_t)stream;
   if (d->compute && fast && !yact) {
     if (d->compute == 3 && x3_tile_pick) pick_tile(M, d->C, &bm, &bn, x3_tile_pick); else half_tile(M, d->C, &bm, &bn);   // (no parity classes here)
+    if (d->compute == 3 && lmh_opt("x3_new") ) {      // round-6 bf16x3 kernel, input mask fused (conv_x3.h)
+      prof_begin(st);
+      const int rc3 = lmh_x3_bwd_data_launch(d, dy, w, kscale, addend, xbits, dx, bm, bn, x3_pipe(d->R * d->S * (d->K / BK)), st);
+      prof_end(st, desc_flops(d), "k_x3_bwd_data<%d, %d>", bm, bn);
+      *bits_done = true;
+      return rc3;
+    }
     const int gridh = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
     const float gs = half_gscale(d);
 #define LAUNCH_BD_H(DT_, BM_, BN_)                                                                        \
@@ -624,6 +641,20 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
   const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
   if (d->compute == 3 && fast && gb && !yact && !colsum) {      // Winograd weight gradient, 16 stacked GEMMs in bf16x3
     const int nblk = (int)(grid.x * grid.y * grid.z);
+    if (lmh_opt("x3_new")) {
+      prof_begin(st);
+      const int rc3 = lmh_x3_bwd_weight_launch(d, x, dy, out, kps, (int)grid.x, (int)grid.y, (int)grid.z, nullptr, true, bm, bn, x3_pipe(2), st);
+      prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, true>", bm, bn);
+      if (rc3) return rc3;
+      if (splits > 1) {
+        const int64_t n = (int64_t)d->R * d->S * d->C * d->K;
+        const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
+        lmh_launch(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
+                   splits, dw, (const float*)nullptr, (float*)nullptr, d->K, nb_slab, 0);
+      }
+      LMH_CHECK_LAUNCH();
+      return LMH_OK;
+    }
 #define LAUNCH_BW_G(BM_, BN_)                                                                              \
     lmh_launch((k_conv_bwd_weight_h<3, BM_, BN_, 0, true>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
                        dvh, 1.f, (int)grid.x, (int)grid.y, (int)grid.z, (float*)nullptr)
@@ -669,13 +700,18 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
          else lmh_launch((k_conv_bwd_weight_h<3, BM_, BN_, 2>), dim3(nblk), dim3(256), 0, st, *d, x, dy, out, kps, dvw, \
                        dvh, gs, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h); } while (0)
     prof_begin(st);
-    if (bm == 128 && bn == 128) LAUNCH_BW_HT(128, 128);
+    if (d->compute == 3 && lmh_opt("x3_new")) {
+      const int rc3 = lmh_x3_bwd_weight_launch(d, x, dy, out, kps, (int)grid.x, (int)grid.y, (int)grid.z, cpart_h, false, bm, bn, x3_pipe(2), st);
+      if (rc3) return rc3;
+    }
+    else if (bm == 128 && bn == 128) LAUNCH_BW_HT(128, 128);
     else if (bm == 128) LAUNCH_BW_HT(128, 64);
     else if (bn == 128) LAUNCH_BW_HT(64, 128);
     else LAUNCH_BW_HT(64, 64);
 #undef LAUNCH_BW_HT
 #undef LAUNCH_BW_H
-    prof_end(st, desc_flops(d), "k_conv_bwd_weight_h<%d, %d, %d>", d->compute, bm, bn);
+    if (d->compute == 3 && lmh_opt("x3_new")) prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, false>", bm, bn);
+    else prof_end(st, desc_flops(d), "k_conv_bwd_weight_h<%d, %d, %d>", d->compute, bm, bn);
     if (g_lmh_defer_tail) {
       g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;
       g_lmh_last_plan.splits = splits > 1 ? splits : 0;

@@ -649,7 +649,9 @@ static int wino_run(const lmh_conv_desc* d, int mo, const float* in, int Cg, int
   const bool x3 = d->compute == 3;        // bf16x3: the stacked GEMMs on the bf16 matrix pipe (conv_half.h), transforms unchanged
 #define LAUNCH_WG(BM_, BN_)                                                                           \
   do {                                                                                                \
-    if (x3 && x3_pf_gb == 3)                                                                          \
+    if (x3 && lmh_opt("x3_new"))                                                                      \
+      (void)lmh_x3_fwd_launch(&g, (const float*)V, U, nullptr, nullptr, nullptr, Mo, nullptr, P2, BM_, BN_, x3_pipe(Cg / BK), st); \
+    else if (x3 && x3_pf_gb == 3)                                                                     \
       lmh_launch((k_conv_fwd_h<3, BM_, BN_, 3, true>), dim3(grid), dim3(512), 0, st, g, (const float*)V, U, \
                          (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, Mo, P2);  \
     else if (x3)                                                                                      \
@@ -666,7 +668,8 @@ static int wino_run(const lmh_conv_desc* d, int mo, const float* in, int Cg, int
   else if (bm == 128) LAUNCH_WG(128, 64);
   else LAUNCH_WG(64, 64);
 #undef LAUNCH_WG
-  if (x3) prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd_h<3, %d, %d, GB>", bm, bn);
+  if (x3 && lmh_opt("x3_new")) prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_x3_fwd<%d, %d, true>", bm, bn);
+  else if (x3) prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd_h<3, %d, %d, GB>", bm, bn);
   else prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd<%d, %d, true>", bm, bn);
   if (mo == 4) {
     const int64_t n = (int64_t)T * (Kg / 2);

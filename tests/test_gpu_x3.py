@@ -166,8 +166,8 @@ def test_bf16x3_inside_winograd_matches_native_winograd(K, shape, monkeypatch):
     K._Profile.start()
     x3 = _run_all(K, case, 'bf16x3', x, w, scale, shift, res, gy, addend=False)
     names = set(K._Profile.stop())
-    assert any(n.startswith('k_conv_fwd_h<3') and 'GB' in n for n in names), names
-    assert any(n.startswith('k_conv_bwd_weight_h<3') and 'GB' in n for n in names), names
+    assert any(n.startswith('k_x3_fwd<') and n.endswith('true>') for n in names), names            # stacked (GB) launches
+    assert any(n.startswith('k_x3_bwd_weight<') and n.endswith('true>') for n in names), names
     # F(2x2,3x3): 3e-6 of the output scale; F(4x4,3x3) (round 3 default): the output transform amplifies the GEMMs' own
     # fp32 rounding (the two GEMM schemes round differently) by its coefficients, up to 8 x 8: 4e-5
     amp = 3e-6 if K.get_option('wino_m') == 2 else 4e-5
@@ -194,3 +194,46 @@ def test_bf16x3_weight_gradient_emits_the_channel_sums(K, case, monkeypatch):
     np.testing.assert_array_equal(dw, dw_plain)
     want = gy.reshape(-1, Kc).astype(np.float64).sum(0)
     np.testing.assert_allclose(cs.cpu().numpy(), want, rtol=1e-5, atol=1e-5 * np.abs(gy).sum(axis=(0, 1, 2)).max())
+
+
+@pytest.mark.parametrize('pipe', [1, 0], ids=['pipelined', 'phase-by-phase'])
+@pytest.mark.parametrize('case', CASES + [(2, 64, 64, 256, 1024, 1, 1, 1, 'SAME'), (2, 64, 64, 512, 256, 1, 1, 1, 'SAME')])
+def test_pipelined_bf16x3_kernels_equal_the_round2_kernels(K, case, pipe, monkeypatch):
+    """csrc/conv_x3.h (round 6: one software-pipelined instruction stream per wave, fused activation bit masks) forms every
+    sum in the order of the round-2 kernels k_conv_*_h<3, ...>: forward (+ residual, activation, bit mask), backward data
+    (+ kscale, addend, input mask) and weight gradient (split-K included) are BIT-identical on random data; the per-channel
+    sums of g come off the matrix pipe in another order (compared with the float64 sums)."""
+    monkeypatch.setattr(K, 'WINOGRAD', False)
+    N, H, W, C, Kc, R, stride, dil, padding = case
+    rs = np.random.RandomState(300 + len(str(case)))
+    x = rs.randn(N, H, W, C).astype(F)
+    w = (rs.randn(R, R, C, Kc) * np.sqrt(2.0 / (R * R * C))).astype(F)
+    scale = (1 + 0.1 * rs.randn(Kc)).astype(F)
+    shift = (0.1 * rs.randn(Kc)).astype(F)
+    d = K.conv_desc(x.shape, w.shape, stride, dil, padding, 'relu', 'bf16x3')
+    res = rs.randn(N, d.OH, d.OW, Kc).astype(F)
+    gy = rs.randn(N, d.OH, d.OW, Kc).astype(F)
+    xbits_src = rs.randn(N, H, W, C).astype(F)
+    out = {}
+    for new in (0, 1):
+        K.set_option('x3_new', new)
+        K.set_option('x3_pipe', pipe)
+        try:
+            bits = K.new_act_bits(N * d.OH * d.OW, Kc, 'cuda:0') if Kc % 32 == 0 else None
+            y = K.conv2d_fwd(d, T(x), T(w), T(scale), T(shift), T(res), act_bits=bits)
+            xb = K.act_bits(T(xbits_src), 'relu') if C % 32 == 0 else None
+            dx = K.conv2d_bwd_data(d, T(gy), T(w), T(scale), addend=T(x), xbits=xb)
+            cs = torch.zeros((Kc,), device='cuda:0')
+            fused = K.conv_fused_colsum_ok(d)
+            dw = K.conv2d_bwd_weight(d, T(x), T(gy), colsum=cs if fused else None)
+            out[new] = (y.cpu().numpy(), None if bits is None else bits.cpu().numpy(), dx.cpu().numpy(), dw.cpu().numpy(),
+                        cs.cpu().numpy() if fused else None)
+        finally:
+            K.set_option('x3_new', 1)
+            K.set_option('x3_pipe', 0)
+    for name, a, b in zip(('y', 'act_bits', 'dx', 'dw'), out[1][:4], out[0][:4]):
+        if a is not None:
+            np.testing.assert_array_equal(a, b, err_msg=name)
+    if out[1][4] is not None:
+        want = gy.reshape(-1, Kc).astype(np.float64).sum(0)
+        np.testing.assert_allclose(out[1][4], want, rtol=1e-5, atol=1e-5 * np.abs(gy).sum(axis=(0, 1, 2)).max())
