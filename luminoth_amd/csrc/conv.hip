@@ -564,6 +564,10 @@ extern "C" size_t lmh_conv2d_bwd_weight_workspace_bytes(const lmh_conv_desc* d) 
 
 static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float* dy, const float* yact,
                              float* dw, float* colsum, void* ws, size_t ws_bytes, hipStream_t stream, bool gb);
+// stacked (gb) launches on behalf of the Winograd weight gradient: with `want` set a split reduction is NOT reduced here —
+// the slabs and their count are reported and the caller's next kernel (k_wino4_dw) adds them on load
+struct lmh_gb_slabs { bool want; const float* slabs; int splits; };
+static thread_local lmh_gb_slabs g_gb_slabs = {false, nullptr, 0};
 
 extern "C" int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* dy, const float* yact,
                                      float* dw, float* colsum, void* ws, size_t ws_bytes,
@@ -646,7 +650,10 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
       const int rc3 = lmh_x3_bwd_weight_launch(d, x, dy, out, kps, (int)grid.x, (int)grid.y, (int)grid.z, nullptr, true, bm, bn, x3_pipe(2), st);
       prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, true>", bm, bn);
       if (rc3) return rc3;
-      if (splits > 1) {
+      if (splits > 1 && g_gb_slabs.want) {
+        g_gb_slabs.slabs = reinterpret_cast<const float*>(ws);
+        g_gb_slabs.splits = splits;
+      } else if (splits > 1) {
         const int64_t n = (int64_t)d->R * d->S * d->C * d->K;
         const int nb_slab = (int)((n / 4 + 255) / 256 + 1);
         lmh_launch(k_splitk_reduce, dim3(nb_slab), dim3(256), 0, st, reinterpret_cast<const float*>(ws), n,
@@ -755,6 +762,9 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     g_lmh_last_plan.splits = splits > 1 ? splits : 0;
     g_lmh_last_plan.colpart = cpart;                 // [splits][K] partial sums of g (fused dbeta / dbias), or NULL
     g_lmh_last_plan.colrows = cpart ? splits : 0;
+  } else if (gb && splits > 1 && g_gb_slabs.want) {
+    g_gb_slabs.slabs = reinterpret_cast<const float*>(ws);
+    g_gb_slabs.splits = splits;
   } else if (splits > 1 || colsum) {
     const int64_t n = splits > 1 ? (int64_t)d->R * d->S * d->C * d->K : 0;
     const int nb_slab = n > 0 ? (int)((n / 4 + 255) / 256 + 1) : 0;

@@ -7,6 +7,7 @@
 // Workspace layout (floats): U [16][Cg][Kg] | V [16][T][Cg] | Mo [16][T][Kg], T = N*ceil(H/2)*ceil(W/2) tiles,
 // (Cg, Kg) = (C, K) forward, (K, C) backward data; odd H / W use ceil(H/2) x ceil(W/2) tiles.  Included by conv.hip (needs lmh_zero_page in the same TU).
 #pragma once
+#include "colsum_common.h"
 
 // ---- weights: U[t][cg][kg], t = 4*a + b -----------------------------------------------------------------------
 // forward: thread = (c, k4): float4 loads along k.
@@ -571,9 +572,18 @@ k_wino4_dy(const float* __restrict__ g, int N, int H, int W, int K, float* __res
   }
 }
 
-// dw[r][s][c][k] = (G^T dU G)[r][s];  thread = (c, k2)
+// dw[r][s][c][k] = (G^T dU G)[r][s];  thread = (c, k2).  Round 6: two launches of the weight gradient ride along —
+//   * dU may arrive as `splits` split-K slabs (stride slab_n floats): they are added on load in slab order, the order of
+//     k_splitk_reduce (bit-identical), instead of in a launch of their own;
+//   * blocks past nb_dw add up the tiles' pixel sums (plane (1,1) of dM: cs_rows, cs_nb rows of K) into cs_out — the
+//     per-channel sums of dy (dbeta / dbias), k_colsum_finish's code (colsum_common.h).
 __global__ void __launch_bounds__(256)
-k_wino4_dw(const float* __restrict__ dU, int C, int K, float* __restrict__ dw) {
+k_wino4_dw(const float* __restrict__ dU, int C, int K, float* __restrict__ dw, int splits, size_t slab_n,
+           const float* __restrict__ cs_rows, int cs_nb, float* __restrict__ cs_out, int nb_dw) {
+  if ((int)blockIdx.x >= nb_dw) {
+    colsum_finish_block(cs_rows, cs_nb, K, cs_out, (int)blockIdx.x - nb_dw);
+    return;
+  }
   const int K2 = K >> 1;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= C * K2) return;
@@ -586,6 +596,10 @@ k_wino4_dw(const float* __restrict__ dU, int C, int K, float* __restrict__ dw) {
     f32x2 u[6], v[3];
 #pragma unroll
     for (int a = 0; a < 6; ++a) u[a] = *reinterpret_cast<const f32x2*>(src + (size_t)(6 * a + b) * plane);
+    for (int sp = 1; sp < splits; ++sp) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) u[a] += *reinterpret_cast<const f32x2*>(src + (size_t)sp * slab_n + (size_t)(6 * a + b) * plane);
+    }
     w4_gt(u, v);
 #pragma unroll
     for (int r = 0; r < 3; ++r) t[r][b] = v[r];
@@ -882,16 +896,23 @@ extern "C" int lmh_conv2d_bwd_weight_winograd(const lmh_conv_desc* d, const floa
     const int64_t m = (int64_t)T * (d->K / 4);
     lmh_launch(k_wino_dy, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dy, d->N, d->H, d->W, d->K, dM);
   }
-  if (colsum) {      // plane (1,1) = index (mo+2)*1 + 1: the tiles' pixel sums
-    rc = lmh_colsum_rows_impl(dM + (size_t)(mo + 3) * T * d->K, T, d->K, colsum, st);
+  const float* cs_rows = dM + (size_t)(mo + 3) * T * d->K;      // plane (1,1) = index (mo+2)*1 + 1: the tiles' pixel sums
+  if (colsum && mo != 4) {
+    rc = lmh_colsum_rows_impl(cs_rows, T, d->K, colsum, st);
     if (rc) return rc;
   }
   const lmh_conv_desc g = wino_gemm_desc(d, T, mo);
+  g_gb_slabs.want = (mo == 4);            // F(4x4): a split reduction stays in its slabs; k_wino4_dw adds them on load
+  g_gb_slabs.splits = 0;
   rc = bwd_weight_launch(&g, Vin, dM, nullptr, dU, nullptr, ws2, ws_bytes - planes, st, true);   // gb: never deferred
+  g_gb_slabs.want = false;
   if (rc) return rc;
   if (mo == 4) {
     const int n = d->C * (d->K / 2);
-    lmh_launch(k_wino4_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);
+    const int nb_dw = (n + 255) / 256, nb_cs = colsum ? (d->K + 31) / 32 : 0;
+    const bool slabs = g_gb_slabs.splits > 1;
+    lmh_launch(k_wino4_dw, dim3(nb_dw + nb_cs), dim3(256), 0, st, slabs ? g_gb_slabs.slabs : (const float*)dU, d->C, d->K, dw,
+               slabs ? g_gb_slabs.splits : 1, (size_t)P2 * d->C * d->K, cs_rows, T, colsum, nb_dw);
   } else {
     const int n = d->C * (d->K / 4);
     lmh_launch(k_wino_dw, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)dU, d->C, d->K, dw);

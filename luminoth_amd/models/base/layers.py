@@ -371,7 +371,9 @@ def release_half_weights(layers):
 def winograd_candidates(layers):
     """The layers whose 3x3 convolution the kernels route through Winograd whatever the spatial size (stride 1, SAME,
     fp32, channel counts the transforms cover, above the routing threshold)."""
-    return [l for l in layers if l.k == 3 and l.stride == 1 and l.rate == 1 and l.padding == 'SAME' and l.compute is None and
+    def arithmetic_ok(l):      # fp32, or bf16x3 with the transformed-domain GEMMs on the bf16 pipe (kernels._use_winograd)
+        return l.compute in (None, 'f32', 'fp32', 'float32') or (K.COMPUTE.get(l.compute) == 3 and K.X3_WINOGRAD_MODE == '3')
+    return [l for l in layers if l.k == 3 and l.stride == 1 and l.rate == 1 and l.padding == 'SAME' and arithmetic_ok(l) and
             l.cin % 32 == 0 and l.cout % 32 == 0 and K.WINOGRAD and l.cin * l.cout >= K.WINOGRAD_MIN_CK]
 
 
