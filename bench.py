@@ -13,6 +13,15 @@ RPN minibatch 256, RCNN minibatch 256, fp32, random-init weights.  The other BAS
 `--workload {frcnn_vgg16, ssd300_b32, frcnn_r101, frcnn_r50_coco}` and print the same contract line.
 Weak scaling: per-GPU batch fixed, gradients all-reduced over RCCL (bucketed, overlapped with the backward).
 
+Arithmetic of the headline (round 6).  `value` is measured with the trunk / RPN convolutions in bf16x3:
+every fp32 operand split EXACTLY into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32
+accumulation (csrc/conv_x3.h) — fp32 arithmetic on the bf16 matrix pipe: bit-identical to the native fp32-MFMA kernels on
+representable data, the same error against float64, and every parity test of the fp32 contract passes under the SAME bounds
+(tests/test_gpu_model.py[bf16x3], tests/test_gpu_ref_tf_golden.py[bf16x3], tests/test_gpu_x3.py).  The line says so in
+`dtype` ("f32 (bf16x3 exact split)"), prices `roofline.frac` against 2500 / 6 = 417 TFLOP/s of fp32-equivalent work and
+carries the SAME step on the native fp32 MFMA, measured in the same process, beside it (`native_fp32_mfma`).
+`--dtype f32` makes the native path the headline again.
+
 Prints ONE JSON line (rank 0) with the driver's contract plus
   roofline     — the convolution MFMA kernel class with the LARGEST time per step (over forward, backward-data and
                  backward-weight classes alike): FLOPs (or, for a kernel whose HBM time exceeds its MFMA time, algorithmic
@@ -26,6 +35,10 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
                  is read from a committed profile except `traffic` (PMC bytes need separate `--pmc` passes:
                  scripts/r5_evidence.sh -> profiles/r05_pmc.json, `traffic_source`).
                  `whole_step` = algorithmic conv FLOPs of the step / timed step time.
+  roofline.step — the whole step as tracked numbers: kernel launches per step (the replayed launch plan), HBM bytes per
+                 step by the memory-side counters (the newest committed PMC summary of this workload / dtype:
+                 profiles/*_pmc_traffic.json `step`, scripts/pmc_reduce.py) against the algorithmic bytes of SURVEY.md 8(d)
+                 (tools/flops.py: resnet_frcnn_step_bytes), and their ratio.
   cpu_baseline — the CPU oracle (oracle/, kind "port": the TF reference cannot run here) timed on this host's
                  cores on a bounded sample: 1 warm-up + median of 5 steps, and a 1-thread step beside it.
   dist         — N > 1: which exchange mode produced `value` (`mode`), the modes that failed before it (`fallbacks`: the
@@ -51,6 +64,7 @@ if ROOT not in sys.path:
 # bf16x3: fp32 arithmetic as six bf16 MFMA products per fp32 product (conv_half.h): 2500 / 6 fp32-equivalent TFLOP/s
 PEAK_TFLOPS = {'f32': 157.3, 'f16': 2500.0, 'bf16': 2500.0, 'bf16x3': 2500.0 / 6}
 PEAK_HBM_GBS = 8000.0
+DTYPE_LABEL = {'f32': 'f32', 'f16': 'f16', 'bf16': 'bf16', 'bf16x3': 'f32 (bf16x3 exact split)'}
 
 WORKLOADS = {
     # name: model type, architecture, per-GPU batch, H, W, classes, gt boxes/image, BASELINE.json configs[] index
@@ -182,6 +196,31 @@ def pmc_traffic(kernel):
     return None, None
 
 
+def pmc_step_traffic(workload, dtype):
+    """HBM bytes per STEP by the memory-side counters, from the newest committed PMC summary taken on this workload and
+    dtype (profiles/*_pmc_traffic.json: `workload`, `dtype`, `step.hbm_bytes`; scripts/pmc_reduce.py).  (None, None) if
+    there is none."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))[::-1]:
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get('workload') == workload and d.get('dtype') == dtype and (d.get('step') or {}).get('hbm_bytes'):
+            return d['step'], os.path.relpath(f, ROOT)
+    return None, None
+
+
+def algorithmic_step_bytes(wl, dtype, model):
+    """SURVEY.md 8(d)'s compulsory HBM bytes of one train step (tools/flops.py); ResNet Faster R-CNN workloads only."""
+    if wl['model'] != 'fasterrcnn' or not wl['arch'].startswith('resnet_v1'):
+        return None
+    from tools import flops
+    half = getattr(getattr(model, 'base_network', None), 'storage_dtype', None) in ('f16', 'bf16')
+    return flops.resnet_frcnn_step_bytes(wl['arch'], wl['H'], wl['W'], wl['batch'], int(model.store.flat.numel()),
+                                         2 if half else 4)['step']
+
+
 def _short_kernel_name(name):
     name = name.replace('void ', '')
     i = name.find('(')
@@ -198,7 +237,16 @@ def reduce_kernel_trace(path, nprof):
         for row in csv.DictReader(f):
             rows.append((int(row['Start_Timestamp']), int(row['End_Timestamp']), _short_kernel_name(row['Kernel_Name'])))
     rows.sort()
-    ends = [i for i, row in enumerate(rows) if 'k_sgd_momentum' in row[2] or 'k_optimizer' in row[2]]
+    is_opt = lambda n: 'k_sgd_momentum' in n or 'k_optimizer' in n or 'k_sgd_early' in n      # noqa: E731
+    # a step ends with its LAST optimizer launch: with per-range updates under the backward (LUMINOTH_AMD_EARLY_UPDATE=1)
+    # a step issues several; an optimizer launch followed (before the next step's kernels) by another one is not an end
+    ends = []
+    for i, row in enumerate(rows):
+        if is_opt(row[2]) and 'early' not in row[2]:
+            if ends and all(is_opt(r[2]) for r in rows[ends[-1] + 1:i]):
+                ends[-1] = i
+            else:
+                ends.append(i)
     if len(ends) < nprof + 1:
         return None
     win = rows[ends[-nprof - 1] + 1:ends[-1] + 1]
@@ -321,8 +369,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=15)
     ap.add_argument('--workload', default='frcnn_r50', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the workload\'s)')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16', 'bf16x3'],
-                    help='convolution compute dtype (f32 = the parity dtype of north_star)')
+    ap.add_argument('--dtype', default='auto', choices=['auto', 'f32', 'f16', 'bf16', 'bf16x3'],
+                    help='convolution arithmetic.  auto (default) = bf16x3 for the Faster R-CNN workloads (fp32 arithmetic as an '
+                         'exact three-way bf16 split, the headline since round 6) and f32 for SSD; f32 = the native fp32 MFMA')
+    ap.add_argument('--no-native', action='store_true',
+                    help='with bf16x3: do not re-run the step on the native fp32 MFMA for `native_fp32_mfma`')
     ap.add_argument('--fp32-storage', action='store_true',
                     help='with --dtype f16 / bf16: keep fp32 tensors in HBM (round-2 path) instead of the half-storage trunk')
     ap.add_argument('--serial', action='store_true',
@@ -333,10 +384,6 @@ def main():
                          'of the three streams ("phases" in the JSON line; Faster R-CNN workloads)')
     ap.add_argument('--no-lookahead', action='store_true',
                     help='do not tell the step which batch comes next (no cross-step prefetch of the frozen trunk prefix)')
-    ap.add_argument('--alt', action='store_true',
-                    help='also re-run the step with bf16x3 convolutions and report it as `alt_arithmetic` (opt-in since '
-                         'round 3: its gain did not reproduce on the driver\'s box)')
-    ap.add_argument('--no-alt', action='store_true', help='(accepted for compatibility; the alt run is opt-in now)')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the BASELINE configs[4] leg (f16 half-storage step at 800x1333) the default run adds as '
                          '`other_configs.frcnn_r50_coco_f16`')
@@ -358,6 +405,8 @@ def main():
                     help='(test hook) the bucketed gradient exchange raises on its first early bucket: exercises the '
                          'fall-back ladder bucketed+plan -> one all-reduce+plan -> one all-reduce, eager launches')
     args = ap.parse_args()
+    if args.dtype == 'auto':
+        args.dtype = 'f32' if WORKLOADS[args.workload]['model'] == 'ssd' else 'bf16x3'
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # launched plainly with --gpus N: become N ranks (one process per GPU over RCCL)
@@ -549,7 +598,19 @@ def main():
                     rp = rocprof_child(name, dtype, batch=batch, fp32_storage=args.fp32_storage, nprof=nprof,
                                        keep_dir=os.path.join(args.rocprof_keep, '%s_%s' % (name, dtype))
                                        if args.rocprof_keep else None)
-                res['roofline'] = roofline_of(prof, nprof, dtype, dt, steps, rp)
+                # the step as tracked numbers: launches from the replayed plan, counter bytes from the
+                # newest committed PMC summary of this workload / dtype, algorithmic bytes from tools/flops.py
+                pst, psrc = pmc_step_traffic(name, dtype)
+                alg = algorithmic_step_bytes(wl, dtype, model) if (batch is None or batch == WORKLOADS[name]['batch']) else None
+                step_block = {
+                    'launches': res['launch_plan']['kernel_launches_per_step'] or None,
+                    'hbm_bytes_counter': pst['hbm_bytes'] if pst else None,
+                    'hbm_bytes_counter_source': (psrc + ': sum over the kernels of one serialised step of 2 x FETCH_SIZE + '
+                                                 'WRITE_SIZE (separate --pmc passes, gfx950 correction)') if pst else None,
+                    'launches_in_counter_profile': pst.get('launches') if pst else None,
+                    'hbm_bytes_algorithmic': alg,
+                    'ratio': (pst['hbm_bytes'] / alg) if (pst and alg) else None}
+                res['roofline'] = roofline_of(prof, nprof, dtype, dt, steps, rp, step_block)
         if world > 1:
             # data-parallel sanity: after the same number of identical updates every replica must hold the SAME bits
             # (seeded init + broadcast, ring all-reduce hands every rank the same sums, one update kernel)
@@ -570,7 +631,7 @@ def main():
             dist.barrier()
         return res
 
-    def roofline_of(prof, nprof, dtype, dt, steps, rp=None):
+    def roofline_of(prof, nprof, dtype, dt, steps, rp=None, step_block=None):
         peak = PEAK_TFLOPS[dtype]
         name = max(prof, key=lambda k: prof[k]['ms'])          # the dominant kernel class, whichever pass it is in
         step_flops = sum(v['direct_flops'] for v in prof.values()) / nprof
@@ -612,6 +673,7 @@ def main():
                                                              key=lambda kv: -kv[1]['avg_ms'] * kv[1]['calls_per_step'])[:8]}}})
         return dict(bound, **{
             'kernel': name, 'traffic': traffic, 'algorithmic_bytes_per_launch': by,
+            'step': step_block,
             'traffic_unit': 'HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE PMC passes)',
             'traffic_source': traffic_src,
             'launches_per_step': r['launches'] / nprof, 'flops_per_launch': fl, 'ms_per_launch': ms,
@@ -682,7 +744,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'ms_per_step_median': head['ms_per_step_median'], 'ms_per_step_min': head['ms_per_step_min'],
             'ms_per_step_max': head['ms_per_step_max'], 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_LABEL[args.dtype], 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[%d] (%s): %s %s, %dx%d (HxW) synthetic, batch %d/GPU, %d classes, '
                                    '%d gt/image, fwd+loss+bwd+optimizer update%s'
                                    % (wl['cfg'], args.workload, wl['model'], wl['arch'], wl['H'], wl['W'], wl['batch'],
@@ -712,7 +774,28 @@ def main():
     sd0 = head['sd0']
     del head, model
     other = {}
-    if args.workload == 'frcnn_r50' and args.dtype == 'f32' and not args.serial and not args.no_other_configs:
+    native = None
+    if args.dtype == 'bf16x3' and not args.no_native and not args.serial:
+        # the SAME step on the native fp32 MFMA (v_mfma_f32_32x32x2_f32), same process, same inputs: reported beside `value`
+        # (every rank runs it: it contains the gradient exchange)
+        torch.cuda.empty_cache()
+        try:
+            native = run_workload(args.workload, 'f32', args.steps, args.warmup, batch=args.batch, want_roofline=False)
+        except StepFailure as e:
+            native = {'error': str(e)}
+        if rank == 0:
+            if 'error' in native:
+                out['native_fp32_mfma'] = native
+            else:
+                out['native_fp32_mfma'] = {
+                    'dtype': 'f32', 'value': gb * args.steps / native['dt'], 'unit': 'images/sec',
+                    'ms_per_step': native['ms_per_step'], 'ms_per_step_median': native['ms_per_step_median'],
+                    'steps': args.steps, 'warmup': args.warmup, 'final_total_loss': native['loss'],
+                    'launch_plan': native['launch_plan'],
+                    'note': 'same workload, schedule, tensors, inputs and tolerances with every convolution on '
+                            'v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s peak): the arithmetic of rounds 1-5\'s headline'}
+        native = None
+    if args.workload == 'frcnn_r50' and args.dtype in ('f32', 'bf16x3') and not args.serial and not args.no_other_configs:
         # BASELINE configs[4] ("fp16 MFMA path, 1333x800 COCO shapes") on the same record: the half-storage trunk at its own
         # geometry, 15 + 60 steps (~0.4 s of GPU time), with its own roofline leg.  Every rank runs it (it contains the
         # gradient exchange); reported BESIDE `value`, never as it.
@@ -736,19 +819,6 @@ def main():
     if rank == 0:
         if other:
             out['other_configs'] = other
-        if args.dtype == 'f32' and world == 1 and args.alt and wl['model'] != 'ssd' and not args.serial:
-            # the same step with the convolutions in bf16x3 (fp32 arithmetic on the bf16 matrix pipe),
-            # measured in this process right after the headline run: reported BESIDE `value`, never as it
-            a = run_workload(args.workload, 'bf16x3', args.steps, args.warmup, batch=args.batch, want_roofline=False)
-            out['alt_arithmetic'] = {
-                'dtype': 'bf16x3', 'value': gb * args.steps / a['dt'], 'unit': 'images/sec',
-                'ms_per_step': a['ms_per_step'], 'steps': args.steps, 'warmup': args.warmup,
-                'final_total_loss': a['loss'],
-                'note': 'same workload, schedule, tensors and tolerances; every fp32 convolution operand split exactly into '
-                        'three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate (bit-exact with the '
-                        'native kernels on integer data, same error against float64: tests/test_gpu_x3.py).  Not the headline: '
-                        '`value` above is the native fp32-MFMA path.'}
-            del a
         if not args.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
             cb = cpu_baseline(wl, sd0, args.cpu_steps)
             if cb is not None:

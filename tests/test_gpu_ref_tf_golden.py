@@ -198,7 +198,8 @@ def _load_seeded(store, names):
         t.copy_(torch.from_numpy(_seeded(mod, var, tuple(t.shape))).to(t.device))
 
 
-def test_rpn_module_layout_matches_reference_build(G):
+@pytest.mark.parametrize('compute', [None, 'bf16x3'], ids=['f32', 'bf16x3'])
+def test_rpn_module_layout_matches_reference_build(G, compute):
     """The product's RPN module (luminoth_amd/models/fasterrcnn/rpn.py: HIP convolutions + reshape) on the fixture the
     reference's own RPN._build (rpn.py:96-217) produced: `(N,2)` / `(N,4)` orderings, anchor targets, proposals."""
     from luminoth_amd.models.fasterrcnn.rpn import RPN
@@ -210,6 +211,9 @@ def test_rpn_module_layout_matches_reference_build(G):
     cfg = get_config({'model': {'type': 'fasterrcnn', 'rpn': {'num_channels': ch}}}).model.rpn
     A = G[k + 'ref_i32'].shape[0]
     rpn = RPN(A, cfg, feat.shape[3], seed=None)
+    # the 3x3 convolution in the arithmetic under test (bf16x3 = fp32 arithmetic on the bf16 matrix pipe: the SAME bounds
+    # against the reference's outputs; FasterRCNN.__init__ sets this from model.base_network.compute_dtype)
+    rpn._rpn.compute = compute
     store = ParamStore()
     rpn.register(store)
     store.build(torch.device('cuda:0'), seed=0)

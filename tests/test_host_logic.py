@@ -353,6 +353,57 @@ def test_bench_kernel_trace_reduction(tmp_path):
     assert '__amd_rocclr_copyBuffer' not in out
     assert abs(out['_step_ms'] - (2 * 42000 + 2 * 1000 + 11000) * 1e-6) < 1e-9
     assert bench.reduce_kernel_trace(str(f), 5) is None          # needs n + 1 optimizer launches
+    # per-range updates (LUMINOTH_AMD_EARLY_UPDATE=1): early range updates under the backward and SEVERAL
+    # consecutive optimizer launches at the end of a step are ONE step end
+    rows, t = [rows[0]], 1000
+    for dur in (50000, 50000, 40000, 42000, 44000):
+        rows.append('"KERNEL_DISPATCH",1,1,"void k_conv_fwd<128, 128, false>(lmh_conv_desc, float const*)",%d,%d' % (t, t + dur)); t += dur + 1000
+        rows.append('"KERNEL_DISPATCH",1,1,"k_sgd_early_range(float*)",%d,%d' % (t, t + 3000)); t += 4000
+        rows.append('"KERNEL_DISPATCH",1,1,"void k_conv_fwd<128, 128, false>(lmh_conv_desc, float const*)",%d,%d' % (t, t + dur)); t += dur + 1000
+        for _ in range(3):
+            rows.append('"KERNEL_DISPATCH",1,1,"k_sgd_momentum_range(float*)",%d,%d' % (t, t + 3000)); t += 4000
+    f.write_text('\n'.join(rows) + '\n')
+    out = bench.reduce_kernel_trace(str(f), 3)
+    assert out['k_conv_fwd<128,128,false>']['calls_per_step'] == 2.0 and abs(out['k_conv_fwd<128,128,false>']['avg_ms'] - 0.042) < 1e-9
+    assert out['k_sgd_momentum_range']['calls_per_step'] == 3.0 and out['k_sgd_early_range']['calls_per_step'] == 1.0
+
+
+def test_bench_step_block_sources(tmp_path, monkeypatch):
+    """`roofline.step`: counter bytes per step come from the newest committed PMC summary of the SAME
+    workload and dtype, algorithmic bytes from tools/flops.py (~4.7 GB for ResNet-50 at 2 x 1024^2)."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    (tmp_path / 'profiles').mkdir()
+    json.dump({'workload': 'frcnn_r50', 'dtype': 'f32', 'step': {'hbm_bytes': 1.0e10, 'launches': 250}, 'kernels': {}},
+              open(tmp_path / 'profiles' / 'r01_a_pmc_traffic.json', 'w'))
+    json.dump({'workload': 'frcnn_r50', 'dtype': 'bf16x3', 'step': {'hbm_bytes': 9.0e9, 'launches': 226}, 'kernels': {}},
+              open(tmp_path / 'profiles' / 'r02_b_pmc_traffic.json', 'w'))
+    json.dump({'kernels': {}}, open(tmp_path / 'profiles' / 'r03_c_pmc_traffic.json', 'w'))       # an old-layout file: skipped
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    st, src = bench.pmc_step_traffic('frcnn_r50', 'bf16x3')
+    assert st['hbm_bytes'] == 9.0e9 and src.endswith('r02_b_pmc_traffic.json')
+    assert bench.pmc_step_traffic('frcnn_r50', 'f32')[0]['launches'] == 250
+    assert bench.pmc_step_traffic('frcnn_r50_coco', 'f16') == (None, None)
+
+    class _M(object):
+        class base_network(object):
+            storage_dtype = None
+
+        class store(object):
+            class flat(object):
+                @staticmethod
+                def numel():
+                    return 13500000
+    b = bench.algorithmic_step_bytes(bench.WORKLOADS['frcnn_r50'], 'f32', _M)
+    assert 4.3e9 < b < 5.1e9, b
+    _M.base_network.storage_dtype = 'f16'
+    assert bench.algorithmic_step_bytes(bench.WORKLOADS['frcnn_r50_coco'], 'f16', _M) < 0.6 * b
+    assert bench.algorithmic_step_bytes(bench.WORKLOADS['ssd300_b32'], 'f32', _M) is None
 
 
 def test_bench_exchange_ladder():

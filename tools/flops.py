@@ -68,6 +68,46 @@ def vgg_frcnn(H, W):
     return dict(trunk=trunk, rpn=rpn, feature_hw=(fh, fw))
 
 
+def trunk_elems(nodes, h, w, frozen_nodes=0):
+    """Activation elements the trunk WRITES per image: every convolution / pooling output (a bottleneck: shortcut, conv1,
+    conv2, conv3).  -> (all, those of the first `frozen_nodes` nodes, output (h, w))."""
+    total = frozen = 0
+    for i, n in enumerate(nodes):
+        e = 0
+        if hasattr(n, 'conv1'):
+            _, hw1 = conv_macs(n.conv1, h, w)
+            _, hw2 = conv_macs(n.conv2, *hw1)
+            e += hw1[0] * hw1[1] * n.conv1.cout + hw2[0] * hw2[1] * (n.conv2.cout + n.conv3.cout)
+            if n.shortcut is not None:
+                e += hw2[0] * hw2[1] * n.shortcut.cout
+        elif n.layers:
+            _, hw1 = conv_macs(n.layers[0], h, w)
+            e += hw1[0] * hw1[1] * n.layers[0].cout
+        else:                                           # pooling node
+            oh, ow = n.out_hw(h, w)
+            e += oh * ow * getattr(n, 'channels', 64)
+        h, w = n.out_hw(h, w)
+        total += e
+        if i < frozen_nodes:
+            frozen += e
+    return total, frozen, (h, w)
+
+
+def resnet_frcnn_step_bytes(arch, H, W, batch, trainable_params, act_bytes=4):
+    """ALGORITHMIC (compulsory) HBM bytes of one Faster R-CNN train step, SURVEY.md §8(d)'s rule: every backbone / RPN
+    activation written once in the forward pass and read once in the backward pass, the same again for the activation
+    gradients of the trainable part, the input image read once, and the optimizer's 20 B per trainable parameter (read w, g,
+    v; write w, v).  act_bytes = 2 for the half-storage trunk.  Post-processing stages are < 1 % and not counted.
+    (§8(d) quotes 157 M elements and ~2.2 GB per image for ResNet-50 at 1024^2; asserted in check().)"""
+    nodes, endpoints = networks.resnet_v1_nodes(arch, 'truncated_base_network', 0.0, None, up_to_block=3)
+    n_frozen = endpoints['block1'] + 1
+    elems, frozen, (fh, fw) = trunk_elems(nodes, H, W, n_frozen)
+    rpn = fh * fw * (512 + 12 * 6)
+    per_image = (2 * (elems + rpn) + 2 * (elems - frozen + rpn)) * act_bytes + H * W * 3 * 4
+    return dict(elements_per_image=elems + rpn, frozen_elements=frozen, per_image=per_image,
+                optimizer=20 * trainable_params, step=batch * per_image + 20 * trainable_params)
+
+
 G = 1e9
 EXPECT = {      # SURVEY.md §8d, GMAC
     'r50_1024': dict(trunk=60.05, frozen=13.80, rpn=19.48, fc=0.105, fwd=79.63),
@@ -95,6 +135,12 @@ def check(tab=None, rel=5e-3):
     r50 = tab['r50_1024']
     assert abs(2 * r50['train'] / G - 422.6) < 1.0, 2 * r50['train'] / G           # GFLOP per image per train step
     assert abs(2 * tab['r101_1024']['train'] / G - 2013) < 8, 2 * tab['r101_1024']['train'] / G
+    b = resnet_frcnn_step_bytes('resnet_v1_50', 1024, 1024, 2, 13.5e6)
+    # §8(d): 157 M activation elements, ~2.2 GB per image, 270 MB of optimizer traffic -> ~4.7 GB per step at batch 2
+    # (the count here includes the projection shortcuts and the stem's pooling output, 193 M elements: the survey's 157 M
+    # leaves them out; its rounded per-image and per-step figures hold within 6 %)
+    assert 150 < b['elements_per_image'] / 1e6 < 200, b['elements_per_image']
+    assert abs(b['per_image'] / G - 2.2) < 0.2 and abs(b['step'] / G - 4.7) < 0.4, b
     return tab
 
 
