@@ -14,8 +14,9 @@
  *    returns 0 or a negative lmh_status, message via lmh_last_error()
  *    (thread local).
  *  - State: the data path keeps none — every result is a function of the
- *    arguments of the call.  What IS process- or thread-global is confined to
- *    four documented entry points: tuning options (lmh_set_option: which
+ *    arguments of the call.  What IS thread-global (nothing is process-global
+ *    but the option DEFAULTS) is confined to four documented entry points, all
+ *    per calling thread: tuning options (lmh_set_option: which
  *    kernel variant / tile runs — equal results up to fp32 summation order,
  *    EXCEPT `wino_m`, which selects Winograd F(2x2,3x3) or F(4x4,3x3) and
  *    with it the rounding of every Winograd layer: ~1e-6 vs ~2e-5 of the
@@ -41,10 +42,16 @@ extern "C" {
 
 typedef void* lmh_stream_t; /* hipStream_t */
 
-/* Tuning options (process global; defaults are the measured best on MI355X).  Names: bd_parity_small, half_pf,
- * x3_tile_slots, x3_pf, x3_pf_fwd, x3_pf_gb, x3_pf_bd, x3_pf_bw, bd_slots, bw_slots, wgrad_glds, wg_slots, wino_m,
- * hs_slab_cap, nms_stage_mult, roi_cs, roi_mean_cs (csrc/api.hip documents each).  Unknown name: LMH_ERR_INVALID. */
+/* Tuning options (defaults are the measured best on MI355X).  Names: bd_parity_small, half_pf, x3_tile_slots, x3_pf,
+ * x3_pf_fwd, x3_pf_gb, x3_pf_bd, x3_pf_bw, x3_new, x3_pipe, x3_stagger, bd_slots, bw_slots, wgrad_glds, wg_slots, wino_m,
+ * hs_slab_cap, nms_stage_mult, head_gemm, conv_pp, roi_cs, roi_mean_cs (csrc/api.hip documents each).  Unknown name:
+ * LMH_ERR_INVALID.
+ * Re-entrancy (round 6): lmh_set_option sets the value for the CALLING THREAD only — two threads that drive two models
+ * with different options do not see each other's settings; lmh_set_default_option sets the process default, which is what
+ * a thread sees for every option it has not set itself (the host forwards LMH_OPT_<NAME> variables through it when it
+ * loads the library); lmh_get_option returns what the calling thread's launches will use. */
 int lmh_set_option(const char* name, int value);
+int lmh_set_default_option(const char* name, int value);
 int lmh_get_option(const char* name, int* value);
 
 enum lmh_status {
@@ -122,7 +129,7 @@ int lmh_conv2d_bwd_weight(const lmh_conv_desc* d, const float* x, const float* d
  * Returns BM*1000 + BN (+1000000 for the generic C%32 != 0 forward gather).  Used by
  * bench.py to attribute per-kernel time / algorithmic FLOPs (roofline). */
 int lmh_conv2d_kernel_id(const lmh_conv_desc* d, int op);
-/* Diagnostics: force the block tile (bm,bn in {64,128}) and the bwd-weight split count; 0 = automatic. */
+/* Diagnostics: force the block tile (bm,bn in {64,128}) and the bwd-weight split count; 0 = automatic.  Per calling thread. */
 void lmh_conv2d_force_config(int bm, int bn, int splits);
 /* Probes (round 5; only in a library built with LMH_PROBES=1, otherwise LMH_ERR_UNSUPPORTED for units != 0): low 8 bits =
  * start the co-resident blocks of the fp32 forward / backward-data kernels `units` x ~1 us apart (block slot

@@ -92,6 +92,7 @@ SIGNATURES = {
     'lmh_last_error': (ctypes.c_char_p, []),
     'lmh_device_count': (c_i, []),
     'lmh_set_option': (c_i, [ctypes.c_char_p, c_i]),
+    'lmh_set_default_option': (c_i, [ctypes.c_char_p, c_i]),
     'lmh_get_option': (c_i, [ctypes.c_char_p, P(c_i)]),
     'lmh_conv2d_fwd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     'lmh_conv2d_bwd_data': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
@@ -236,6 +237,17 @@ def load():
         raise LuminothHipError(
             'libluminoth_hip.so not found at %s — run `python -c "import __graft_entry__ as g; '
             'g.build()"` (there is no CPU fallback on the product path)' % LIB_PATH)
+    # a library built with LMH_PROBES=1 (timing probes in the convolution kernels; lmh_conv_set_stagger's decomposition
+    # bits give deliberately wrong results) must not be picked up silently by a later product run
+    flags_file = os.path.join(os.path.dirname(LIB_PATH), '.build_flags')
+    try:
+        probe_build = '-DLMH_PROBES' in open(flags_file).read()
+    except OSError:
+        probe_build = False
+    if probe_build and os.environ.get('LMH_PROBES', '0') in ('', '0'):
+        import warnings
+        warnings.warn('libluminoth_hip.so was built with LMH_PROBES=1 (timing probes); rebuilding the product library')
+        build(force=True)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
@@ -245,7 +257,7 @@ def load():
     # the C library reads no environment variable; sweeps / ablations set LMH_<OPTION>=<int> and it is forwarded here
     for key, val in os.environ.items():
         if key.startswith('LMH_OPT_'):
-            rc = lib.lmh_set_option(key[len('LMH_OPT_'):].lower().encode(), int(val))
+            rc = lib.lmh_set_default_option(key[len('LMH_OPT_'):].lower().encode(), int(val))    # process default: every thread
             if rc != 0:
                 raise LuminothHipError('unknown tuning option %s' % key)
     return lib

@@ -13,20 +13,24 @@ void lmh_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// ---- tuning options: the ONLY process-global knobs of the library (none changes a result; they select among kernel
-// variants that the parity tests hold equal).  No environment variable is read anywhere in this library: the host
-// (luminoth_amd/_lib.py) forwards LMH_OPT_<NAME>=<int> variables through lmh_set_option at load time for sweeps / ablations.
+// ---- tuning options (none changes a result beyond fp32 summation order, except `wino_m`: luminoth_hip.h).  Round 6
+// (the ABI is specified re-entrant): an option has a PROCESS DEFAULT (lmh_set_default_option: what the
+// host forwards from LMH_OPT_<NAME>=<int> at load time, and what a thread sees until it sets the option itself) and a
+// PER-THREAD value (lmh_set_option: the calling thread only) — two threads driving two models with different options do
+// not see each other's settings.  No environment variable is read anywhere in this library.
+#include <atomic>
 struct lmh_option { const char* name; int value; };
-static lmh_option g_options[] = {
+static const lmh_option g_option_defaults[] = {
     {"bd_parity_small", 1},   // stride-2 3x3 backward data: 64x64 tiles when the parity classes are unbalanced
     {"half_pf", 1},           // f16/bf16 kernels: 1, 2 register sets; 3, 4 warp-specialised 512-thread blocks
     {"x3_tile_slots", 256},   // bf16x3 fwd / bwd_data tile by pick_tile(slots); 0: half_tile
-    {"x3_pf", -1},            // bf16x3 pipeline for every pass (-1: per-pass values below)
+    {"x3_pf", -1},            // round-2 bf16x3 kernels (x3_new = 0): pipeline for every pass (-1: per-pass values below)
     {"x3_pf_fwd", 0}, {"x3_pf_gb", 0}, {"x3_pf_bd", 0}, {"x3_pf_bw", 0},
-    {"x3_pipe", 0},           // ... their schedule: 0 = phase by phase, two blocks per CU (default: 5.59 ms per step against 6.60 — the
-                              // pipelined blocks need a whole CU and shut the other streams' kernels out); 1 = software-pipelined
-    {"x3_stagger", 0},        // phase-by-phase schedule: the block in a CU's second LDS slot starts this many x 64 cycles late
-    {"x3_new", 1},            // bf16x3: the software-pipelined kernels of round 6 (conv_x3.h); 0: the round-2 kernels (conv_half.h)
+    {"x3_pipe", 0},           // round-6 bf16x3 kernels (conv_x3.h): 0 = phase by phase, two blocks per CU (default: 5.59 ms per step
+                              // against 6.60 — the pipelined blocks need a whole CU and shut the other streams' kernels out);
+                              // 1 = software-pipelined, one block per CU
+    {"x3_stagger", 0},        // phase-by-phase schedule: the block in a CU's second LDS slot starts this many x 64 cycles late (no effect measured)
+    {"x3_new", 1},            // bf16x3: the kernels of round 6 (conv_x3.h: fused mask epilogues); 0: the round-2 kernels (conv_half.h)
     {"bd_slots", 256},        // resident-block slots the backward-data tile choice fills
     {"bw_slots", 512},        // ... the split-K weight gradient
     {"wgrad_glds", 1},        // 1x1 weight gradient: operands straight into LDS (conv_wgrad1x1.h)
@@ -39,24 +43,54 @@ static lmh_option g_options[] = {
     {"conv_pp", 1},           // 1x1 forward with >= 2 tiles of 128 x 128 per compute unit: the persistent pipelined kernel (conv_pp.h)
     {"roi_mean_cs", -1},      // fused ROI pool+mean (-1: automatic, 0: report unsupported, 4: force 4 channels)
 };
-extern "C" int lmh_set_option(const char* name, int value) {
-  if (!name) return LMH_ERR_INVALID;
-  for (auto& o : g_options)
-    if (!strcmp(o.name, name)) { o.value = value; return LMH_OK; }
-  lmh_set_error("lmh_set_option: unknown option '%s'", name);
-  return LMH_ERR_INVALID;
+enum { LMH_NOPT = sizeof(g_option_defaults) / sizeof(g_option_defaults[0]) };
+static std::atomic<int> g_option_process[LMH_NOPT];          // process defaults (initialised below on first use)
+static std::atomic<int> g_option_init{0};
+struct lmh_thread_options { bool set[LMH_NOPT]; int value[LMH_NOPT]; };
+static thread_local lmh_thread_options g_option_thread = {};
+static void lmh_options_init() {
+  if (g_option_init.load(std::memory_order_acquire) == 2) return;
+  int expect = 0;
+  if (g_option_init.compare_exchange_strong(expect, 1)) {
+    for (int i = 0; i < LMH_NOPT; ++i) g_option_process[i].store(g_option_defaults[i].value, std::memory_order_relaxed);
+    g_option_init.store(2, std::memory_order_release);
+  } else {
+    while (g_option_init.load(std::memory_order_acquire) != 2) {}
+  }
 }
-extern "C" int lmh_get_option(const char* name, int* value) {
-  if (!name || !value) return LMH_ERR_INVALID;
-  for (auto& o : g_options)
-    if (!strcmp(o.name, name)) { *value = o.value; return LMH_OK; }
-  lmh_set_error("lmh_get_option: unknown option '%s'", name);
-  return LMH_ERR_INVALID;
+static int lmh_option_index(const char* name) {
+  for (int i = 0; i < LMH_NOPT; ++i)
+    if (!strcmp(g_option_defaults[i].name, name)) return i;
+  return -1;
+}
+extern "C" int lmh_set_option(const char* name, int value) {          // the calling thread only
+  if (!name) return LMH_ERR_INVALID;
+  const int i = lmh_option_index(name);
+  if (i < 0) { lmh_set_error("lmh_set_option: unknown option '%s'", name); return LMH_ERR_INVALID; }
+  g_option_thread.set[i] = true;
+  g_option_thread.value[i] = value;
+  return LMH_OK;
+}
+extern "C" int lmh_set_default_option(const char* name, int value) {  // every thread that has not set the option itself
+  if (!name) return LMH_ERR_INVALID;
+  const int i = lmh_option_index(name);
+  if (i < 0) { lmh_set_error("lmh_set_default_option: unknown option '%s'", name); return LMH_ERR_INVALID; }
+  lmh_options_init();
+  g_option_process[i].store(value, std::memory_order_relaxed);
+  return LMH_OK;
 }
 int lmh_opt(const char* name) {   // internal reader (a dozen strcmp per convolution launch: nanoseconds)
-  for (auto& o : g_options)
-    if (!strcmp(o.name, name)) return o.value;
-  return 0;
+  const int i = lmh_option_index(name);
+  if (i < 0) return 0;
+  if (g_option_thread.set[i]) return g_option_thread.value[i];
+  lmh_options_init();
+  return g_option_process[i].load(std::memory_order_relaxed);
+}
+extern "C" int lmh_get_option(const char* name, int* value) {         // what the calling thread's launches see
+  if (!name || !value) return LMH_ERR_INVALID;
+  if (lmh_option_index(name) < 0) { lmh_set_error("lmh_get_option: unknown option '%s'", name); return LMH_ERR_INVALID; }
+  *value = lmh_opt(name);
+  return LMH_OK;
 }
 
 extern "C" int lmh_version(void) { return 101; }

@@ -28,6 +28,7 @@
 // predicated kernels in conv_generic.h.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <atomic>
 #include "conv_common.h"
 #include "conv_generic.h"
 
@@ -108,7 +109,7 @@ extern "C" int lmh_conv_set_stagger(int units) {
   return LMH_ERR_UNSUPPORTED;
 #endif
 }
-static int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
+static thread_local int g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;      // (per thread, like the options)
 extern "C" void lmh_conv2d_force_config(int bm, int bn, int splits) {
   g_force_bm = bm; g_force_bn = bn; g_force_splits = splits;
 }
@@ -285,12 +286,15 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
       d->OW == d->W && !in_sub && d->C >= 128 && !g_force_bm && lmh_opt("conv_pp")) {
     // persistent software-pipelined kernel (conv_pp.h): one block per compute unit walks >= 2 tiles of 128 x 128; taken when
     // the tiles divide evenly enough over the chip (the tiled kernel keeps the layers with fewer than two tiles per CU)
-    static int ncu = 0;
+    // compute units of the CURRENT device (cached per device id; a stream created with a CU mask sees fewer: the balance
+    // heuristic below then over-estimates and the kernel is merely slower than the tiled one, never wrong)
+    static std::atomic<int> ncu_dev[16];
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    ncu = ncu_dev[dev].load(std::memory_order_relaxed);
     if (!ncu) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-        ncu = 256;
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+      ncu_dev[dev].store(ncu, std::memory_order_relaxed);
     }
     const int tiles_m = (int)((M + 127) / 128), tiles_n = (d->K + 127) / 128;
     const int64_t ntiles = (int64_t)tiles_m * tiles_n;
@@ -480,7 +484,7 @@ static void bwd_weight_plan(const lmh_conv_desc* d, int* bm, int* bn, int* split
 
 // ---- 1x1 / stride-1 weight gradient through the direct-to-LDS GEMM kernel (conv_wgrad1x1.h) -------------------
 // variant: 0 automatic, -1 never (the register-staged k_conv_bwd_weight), 2..4 = forced LDS ring depth
-static int g_wg_variant = 0;
+static thread_local int g_wg_variant = 0;
 extern "C" void lmh_conv2d_force_wgrad_variant(int v) { g_wg_variant = v; }
 static bool wgrad_1x1_ok(const lmh_conv_desc* d) {
   const int on = lmh_opt("wgrad_glds");

@@ -458,7 +458,8 @@ def winograd_transform_weights(d, w, kscale, backward, out):
 
 
 def set_option(name, value):
-    """Process-global tuning option of the C library (include/luminoth_hip.h: lmh_set_option)."""
+    """Tuning option of the C library for the CALLING THREAD (include/luminoth_hip.h: lmh_set_option; the process default
+    other threads see is lmh_set_default_option, which _lib.load() uses for LMH_OPT_* variables)."""
     global OPTION_VERSION
     check(_lib.load().lmh_set_option(name.encode(), int(value)), 'lmh_set_option')
     OPTION_VERSION += 1

@@ -110,6 +110,10 @@ class FasterRCNN(object):
         self._anchor_ref_i32 = torch.tensor(truncate_reference(self._anchor_reference), dtype=torch.int32,
                                             device=self.device)
         self._step = 0
+        # launch-plan bookkeeping of the fused step, readable by the driver (a loader whose shapes thrash the four
+        # kept states or keep the steps eager is a silent performance cliff otherwise)
+        import collections
+        self.plan_stats = collections.Counter()
         self._frozen_reg = None
 
     # ------------------------------------------------------------------ inputs --
@@ -288,6 +292,9 @@ class FasterRCNN(object):
         except BaseException:
             K.TAILS.abort()
             self._step_state = {}
+            from luminoth_amd.utils import training as T_
+            if getattr(T_, 'ACTIVE_BUCKETS', None) is not None:      # gradient buckets / early range updates of this step
+                T_.ACTIVE_BUCKETS.abort()
             raise
         finally:
             L.release_winograd_weights(self._winograd_layers())
@@ -310,6 +317,16 @@ class FasterRCNN(object):
             g *= 2
         return g
 
+    def _gt_capacity(self, G):
+        """The capacity a batch with G boxes per image is given: its bucket, but never less than the largest bucket this model
+        has seen.  With real data the box count varies from batch to batch; keyed by each batch's own bucket,
+        two batches of one image size landed in different states (8 vs 16 boxes), every switch ran eagerly and past four
+        states recorded plans were destroyed.  The capacity only grows — at most four times up to 100 boxes — after which
+        every batch of an image size maps to ONE state; `gt_count` carries the real counts and no kernel reads a padded row."""
+        cap = max(self._gt_bucket(G), getattr(self, '_gt_cap_seen', 8))
+        self._gt_cap_seen = cap
+        return cap
+
     def _state_for(self, B, H, W, G):
         """What one step hands to the next and what the caller hands to a step lives at FIXED addresses, double-buffered
         by step parity p (step n uses slot n % 2 as "current" and fills slot 1 - p for step n + 1): images, gt boxes,
@@ -318,7 +335,7 @@ class FasterRCNN(object):
         One state per (batch, image size, gt capacity bucket); the 4 most recently USED are kept."""
         main = torch.cuda.current_stream(self.device)
         from luminoth_amd.utils import training as _tr
-        G = self._gt_bucket(G)
+        G = self._gt_capacity(G)
         # the gradient buckets by GENERATION, not id(): a plan holds closures bound to the buckets object it was recorded
         # with, and CPython may hand a new object the id of a dead one
         key = (B, H, W, G, main.cuda_stream, K.OPTION_VERSION, getattr(_tr.ACTIVE_BUCKETS, 'generation', None),
@@ -332,6 +349,8 @@ class FasterRCNN(object):
             return S
         if len(states) >= 4:          # a data loader with many shapes: keep the plans of the most recently used ones only
             old = states.pop(next(iter(states)))
+            self.plan_stats['evicted_states'] += 1
+            self.plan_stats['destroyed_plans'] += len(old['plans'])
             for pl in old['plans'].values():
                 pl.destroy()
         dev = self.device
@@ -393,7 +412,7 @@ class FasterRCNN(object):
             nimg = next_image if next_image.dim() == 4 else next_image.unsqueeze(0)
             ngt, ncnt = self._pack_gt(next_gt, nimg.shape[0])
             nB, nH, nW = (int(v) for v in nimg.shape[:3])
-            if (nB, nH, nW, self._gt_bucket(ngt.shape[1])) != S['key'][:4]:
+            if (nB, nH, nW, self._gt_capacity(ngt.shape[1])) != S['key'][:4]:
                 NS = self._state_for(nB, nH, nW, ngt.shape[1])
                 q = NS['n'] & 1
         if produce:
@@ -406,6 +425,9 @@ class FasterRCNN(object):
         # recorded plan would freeze / the look-ahead would advance early: those configurations run every step eagerly
         plannable = (P.ENABLED and self._rcnn._dropout_keep_prob in (None, 1, 1.0) and not bn_train and NS is S)
         plan = S['plans'].get(variant) if plannable else None
+        self.plan_stats['replayed_steps' if plan is not None else 'eager_steps'] += 1
+        if plan is None and P.ENABLED and NS is not S:
+            self.plan_stats['eager_because_next_batch_has_another_shape'] += 1
         if plan is not None:
             self._phase_collect(S, p)
             out = plan.run()

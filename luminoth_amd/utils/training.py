@@ -89,6 +89,13 @@ class GradientBuckets(object):
         self._done = []          # [lo, hi) ranges already handed to reduce_fn this step
         self._comm = None
 
+    def abort(self):
+        """A step raised after some ranges were handed out: forget them.  The next step starts with no range
+        marked done, no pending work handles and no armed plan; what the failed step half-did to the gradient buffer (or,
+        with EarlyUpdates, to the weights of the ranges it had already updated) is the caller's to judge — the step's
+        exception propagates."""
+        self._done, self._works, self._armed = [], [], None
+
     @staticmethod
     def _all_reduce(t):
         return dist.all_reduce(t, async_op=True)

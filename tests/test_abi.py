@@ -73,3 +73,53 @@ def test_tuning_options_registry_and_no_getenv_in_the_library():
     for f in glob.glob(os.path.join(ROOT, 'luminoth_amd', 'csrc', '*.hip')) + \
             glob.glob(os.path.join(ROOT, 'luminoth_amd', 'csrc', '*.h')):
         assert 'getenv' not in open(f).read(), f
+
+
+def test_tuning_options_are_per_thread():
+    """VERDICT r5 next #7 ("no global state, re-entrant"): lmh_set_option is per calling thread.  Two threads
+    set different `wino_m` at the same time; each keeps seeing its own value and gets the result that depends on it
+    (lmh_winograd_u_bytes: 16 planes for F(2x2,3x3), 36 for F(4x4,3x3)) while the other is active; a third thread that sets
+    nothing sees the process default, which lmh_set_default_option moves for it alone."""
+    import threading
+    from luminoth_amd import _lib
+    lib = _lib.load()
+    C, K = 64, 96
+    barrier = threading.Barrier(2)
+    seen, errors = {}, []
+
+    def worker(m):
+        try:
+            v = ctypes.c_int(0)
+            assert lib.lmh_set_option(b'wino_m', m) == 0
+            barrier.wait(timeout=30)                     # both threads have set their value
+            for _ in range(200):
+                assert lib.lmh_get_option(b'wino_m', ctypes.byref(v)) == 0 and v.value == m
+                assert lib.lmh_winograd_u_bytes(C, K) == (m + 2) * (m + 2) * C * K * 4
+            barrier.wait(timeout=30)
+            seen[m] = v.value
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+            barrier.abort()
+
+    ts = [threading.Thread(target=worker, args=(m,)) for m in (2, 4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors and seen == {2: 2, 4: 4}, (errors, seen)
+    # this thread never set wino_m: it sees the process default, before and after the two threads above
+    v = ctypes.c_int(0)
+    assert lib.lmh_get_option(b'wino_m', ctypes.byref(v)) == 0 and v.value == 4
+    res = {}
+
+    def fresh():
+        w = ctypes.c_int(0)
+        lib.lmh_get_option(b'bw_slots', ctypes.byref(w))
+        res['v'] = w.value
+    assert lib.lmh_set_default_option(b'bw_slots', 384) == 0
+    try:
+        t = threading.Thread(target=fresh)
+        t.start()
+        t.join()
+        assert res['v'] == 384
+    finally:
+        assert lib.lmh_set_default_option(b'bw_slots', 512) == 0
+    assert lib.lmh_set_default_option(b'no_such_option', 1) != 0

@@ -152,10 +152,26 @@ def test_variable_shapes_keep_lookahead_and_replay(setup):
         assert served + replays >= len(data) - 1 and served >= 3, (served, replays)
         assert replays >= 1, [(v, pl.replays) for S in states.values() for v, pl in S['plans'].items()]
         assert bool(torch.isfinite(want).all()) and torch.equal(got, want)
+        # the gt capacity of a model only GROWS.  A batch with 12 boxes moves the 256 x 320 batches to a capacity-16
+        # state; a following batch with 3 boxes stays there (keyed by its own bucket it would bounce back to the capacity-8
+        # state and every switch would run eagerly), and the counters show what was replayed / run eagerly / evicted
+        model.plan_stats.clear()
+        opt = T.get_optimizer(cfg.train, model)
+        for g in (12, 3, 5, 12, 2, 4):
+            im, gts = synth(2, 256, 320, g, 80, 70 + g)
+            T.train_step(model, opt, im.to(dev), gts)
+        torch.cuda.synchronize()
+        caps = sorted(k[3] for k in model._step_state if k[1:3] == (256, 320))
+        assert caps == [8, 16] and model._gt_cap_seen == 16, caps
+        S16 = [S for k, S in model._step_state.items() if k[1:3] == (256, 320) and k[3] == 16][0]
+        assert S16['n'] == 6                                    # all six steps, whatever their own box count
+        assert model.plan_stats['replayed_steps'] + model.plan_stats['eager_steps'] == 6
+        assert model.plan_stats['replayed_steps'] >= 2 and model.plan_stats['evicted_states'] == 0, dict(model.plan_stats)
     finally:
         P.ENABLED = True
         model.load_state_dict(sd0)
         model._step_state = {}
+        model._gt_cap_seen = 8
 
 
 @pytest.mark.parametrize('decay', [False, True], ids=['constant_lr', 'exponential_decay'])
