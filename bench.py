@@ -717,6 +717,23 @@ def main():
             torch.cuda.empty_cache()
         return res
 
+    # ---- N > 1: what the collective costs on THIS node, before the first step: the all-reduce of the
+    # real flat gradient and of one 12 MB bucket, 5 repetitions each; the bucket size of the exchange follows from the
+    # measured latency / bandwidth (LUMINOTH_AMD_BUCKET_MB still overrides)
+    probe = None
+    if world > 1:
+        try:
+            _cfg, _m = build(dict(WORKLOADS[args.workload]), device, args.dtype, half_storage=not args.fp32_storage)
+            numel = int(_m.store.flat.numel())
+            del _cfg, _m
+            torch.cuda.empty_cache()
+            probe = T.allreduce_probe(numel, device)
+            if probe and not os.environ.get('LUMINOTH_AMD_BUCKET_MB'):
+                T.PROBED_BUCKET_BYTES = probe['bucket_bytes_from_probe']
+        except Exception as e:      # the probe must never cost the run
+            probe = {'error': '%s: %s' % (type(e).__name__, e)}
+            sys.stderr.write('bench.py: all-reduce probe failed: %r\n' % (e,))
+
     head, mode, fallbacks = run_ladder(world, attempt)
     if head is None:
         if rank == 0:
@@ -764,6 +781,9 @@ def main():
                      'streams': 'issue (high priority), proposal/RCNN (high priority), weight-gradient x2' +
                                 (', gradient-bucket, RCCL internal' if world > 1 else ''),
                      'buckets': getattr(T.ACTIVE_BUCKETS, 'describe', lambda: None)(),
+                     # the collective as measured on this node before the first step: bytes, ms, GB/s per rank, the ranks the
+                     # collective itself saw (all-reduce of ones), and the bucket size derived from it
+                     'allreduce_probe': probe,
                      'replicas_identical_after_timed_steps': head.get('replicas_identical'),
                      # which exchange mode produced `value`, and the modes that failed before it (first-contact ladder)
                      'mode': head['mode'], 'fallbacks': fallbacks,
@@ -825,7 +845,16 @@ def main():
                 out['cpu_baseline'] = cb
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
+        # Two models, their launch plans (HIP events, recorded kernel arguments), side streams and the process group are
+        # torn down by the interpreter in no particular order at exit; with two ranks on one GPU that ended in a SIGABRT
+        # of rank 0 AFTER the line was printed about one run in three (round 6) — and a non-zero exit code makes the
+        # launcher report the whole run as failed.  The record is complete at this point: leave without the teardown.
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':

@@ -75,13 +75,17 @@ class GradientBuckets(object):
         self.reduce_fn = reduce_fn or self._all_reduce
         if bucket_bytes is None:
             mb = os.environ.get('LUMINOTH_AMD_BUCKET_MB')
-            if mb is None:
-                # a ring all-reduce over N ranks pays 2 (N - 1) hop latencies per collective whatever its size, so the
-                # bucket that amortises them grows with the ring: 6 MB at 2 ranks, 12 MB at 4, 24 MB at 8 (xGMI is
-                # point to point: ~100 GB/s per link in each direction; 2 (N-1) x ~10 us against 2 (N-1)/N x bytes / BW)
+            if mb is not None:
+                bucket_bytes = int(mb) << 20
+            elif PROBED_BUCKET_BYTES:
+                # measured on this node before the first step (allreduce_probe): what the collective actually costs
+                bucket_bytes = int(PROBED_BUCKET_BYTES)
+            else:
+                # no measurement: a ring all-reduce over N ranks pays 2 (N - 1) hop latencies per collective whatever its
+                # size, so the bucket that amortises them grows with the ring: 6 MB at 2 ranks, 12 MB at 4, 24 MB at 8
+                # (a GUESS — xGMI ~100 GB/s per link and direction, ~10 us per hop)
                 world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-                mb = min(24, max(6, 3 * world))
-            bucket_bytes = int(mb) << 20
+                bucket_bytes = int(min(24, max(6, 3 * world))) << 20
         self.bucket_bytes = int(bucket_bytes)
         self._armed = None
         self._plans = {}
@@ -288,6 +292,76 @@ class EarlyUpdates(GradientBuckets):
         self._done = []
         self._armed = None
         return todo
+
+
+# ---- the collective, measured: before the first multi-rank step the driver times the all-reduce of
+# the real flat gradient and of one 12 MB bucket; the line reports what RCCL delivered and how many ranks it saw, and the
+# bucket size follows from the measured latency / bandwidth instead of the constants above.
+PROBED_BUCKET_BYTES = None
+
+
+def bucket_bytes_from_probe(t_small_s, small_bytes, t_large_s, large_bytes, lo=4 << 20, hi=64 << 20, share=0.25):
+    """Cost model of ONE all-reduce from two measurements, t(bytes) = alpha + bytes / beta (alpha: what a collective costs
+    whatever its size — launch, ring hops —, beta: sustained bytes per second), and the bucket it implies: the smallest
+    size whose fixed cost is at most `share` of its transfer time, alpha <= share * bytes / beta, rounded up to 1 MB and
+    clamped to [lo, hi].  -> (bucket_bytes, alpha_s, beta_Bps).  Degenerate measurements (the larger message not slower)
+    fall back to beta = large_bytes / t_large and alpha = the small message's whole time."""
+    if large_bytes > small_bytes and t_large_s > t_small_s > 0:
+        beta = (large_bytes - small_bytes) / (t_large_s - t_small_s)
+        alpha = max(0.0, t_small_s - small_bytes / beta)
+    else:
+        beta = large_bytes / max(t_large_s, 1e-9)
+        alpha = max(t_small_s, 0.0)
+    want = alpha * beta / share
+    mb = 1 << 20
+    bucket = int(min(hi, max(lo, (int(want) + mb - 1) // mb * mb)))
+    return bucket, alpha, beta
+
+
+def allreduce_probe(flat_numel, device, reps=5, bucket_mb=12):
+    """Times dist.all_reduce (sum, fp32) of a tensor as large as the model's flat gradient and of one `bucket_mb` MB bucket:
+    one untimed round, then the median of `reps`; plus an all-reduce of ones — `ranks_seen` comes from the collective's own
+    result.  Every rank calls this at the same point.  -> dict for the bench line (`dist.allreduce_probe`); None when
+    torch.distributed is not initialised or has one rank."""
+    import time
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return None
+    world = dist.get_world_size()
+    on_gpu = dist.get_backend() == 'nccl'
+    dev = device if on_gpu else torch.device('cpu')
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(ones)
+    out = {'ranks_seen': int(round(float(ones[0]))), 'world_size': world, 'backend': dist.get_backend(), 'reps': reps,
+           'messages': []}
+    times = {}
+    for label, nbytes in (('flat_gradient', int(flat_numel) * 4), ('bucket', int(bucket_mb) << 20)):
+        t = torch.ones(max(1, nbytes // 4), dtype=torch.float32, device=dev)
+        dist.all_reduce(t)                      # connection set-up, buffer registration
+        samples = []
+        for _ in range(reps):
+            t.fill_(1.0)
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            dist.all_reduce(t)
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+            samples.append(time.perf_counter() - t0)
+        med = sorted(samples)[len(samples) // 2]
+        times[label] = (med, t.numel() * 4)
+        # a ring moves 2 (N - 1) / N x bytes through every rank: the usual "bus bandwidth" of an all-reduce
+        out['messages'].append({'what': label, 'bytes': t.numel() * 4, 'ms': med * 1e3, 'ms_min': min(samples) * 1e3,
+                                'GB/s_per_rank': t.numel() * 4 / med / 1e9,
+                                'bus_GB/s': 2.0 * (world - 1) / world * t.numel() * 4 / med / 1e9,
+                                'correct': bool(abs(float(t[0]) - world) < 1e-3)})
+        del t
+    (ts, bs), (tl, bl) = sorted(times.values(), key=lambda v: v[1])
+    bucket, alpha, beta = bucket_bytes_from_probe(ts, bs, tl, bl)
+    out.update({'alpha_us': alpha * 1e6, 'beta_GB/s': beta / 1e9, 'bucket_bytes_from_probe': bucket,
+                'model': 't(bytes) = alpha + bytes / beta from the two messages; bucket = smallest size with alpha <= 25 % of '
+                         'its transfer time, 1 MB steps, clamped to [4, 64] MB'})
+    return out
 
 
 ACTIVE_BUCKETS = None          # the GradientBuckets of the optimizer in use (None: single GPU)

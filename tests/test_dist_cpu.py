@@ -267,3 +267,60 @@ def test_train_driver_world2_gloo(tmp_path):
     assert (s0, s1) == (3, 3) and len(seen0) == len(seen1) == 3
     assert not set(seen0) & set(seen1)                       # disjoint shards
     assert any(f.startswith('model.ckpt-3') for f in files0) and 'checkpoint' in files0
+
+
+def _probe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from luminoth_amd.utils import training
+    p = training.allreduce_probe(300000, torch.device('cpu'), reps=3, bucket_mb=1)
+    # the bucket size the exchange of this process would use now
+    training.PROBED_BUCKET_BYTES = p['bucket_bytes_from_probe']
+    m = _Model()
+    m.store = _Store(1000, rank)
+    b = training.GradientBuckets(m.store, reduce_fn=lambda t: None)
+    q.put((rank, p, b.bucket_bytes))
+    dist.destroy_process_group()
+
+
+def test_allreduce_probe_world2():
+    """before the first multi-rank step bench.py times the all-reduce of the flat gradient and of one
+    bucket and derives the bucket size of the exchange from what it measured; `ranks_seen` is the collective's own result.
+    World size 2 over gloo (the code path of the RCCL run, host tensors)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_probe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, pr, bucket in res:
+        assert pr['ranks_seen'] == 2 and pr['world_size'] == 2 and pr['backend'] == 'gloo'
+        whats = {m['what']: m for m in pr['messages']}
+        assert whats['flat_gradient']['bytes'] == 1200000 and whats['bucket']['bytes'] == 1 << 20
+        assert all(m['correct'] and m['ms'] > 0 and m['GB/s_per_rank'] > 0 for m in pr['messages'])
+        assert (4 << 20) <= pr['bucket_bytes_from_probe'] <= (64 << 20) and pr['bucket_bytes_from_probe'] % (1 << 20) == 0
+        assert bucket == pr['bucket_bytes_from_probe']          # GradientBuckets takes the measured size
+
+
+def test_bucket_size_from_measured_allreduce_cost():
+    """t(bytes) = alpha + bytes / beta from two timings; the bucket is the smallest size whose fixed cost is <= 25 % of its
+    transfer time (1 MB steps, [4, 64] MB)."""
+    from luminoth_amd.utils.training import bucket_bytes_from_probe
+    mb = 1 << 20
+    # 100 GB/s and 40 us per collective: alpha * beta / 0.25 = 16 MB
+    t = lambda n: 40e-6 + n / 100e9      # noqa: E731
+    b, alpha, beta = bucket_bytes_from_probe(t(12 * mb), 12 * mb, t(54 * mb), 54 * mb)
+    assert abs(alpha - 40e-6) < 1e-9 and abs(beta - 100e9) / 100e9 < 1e-9 and b == 16 * mb
+    # a fast fabric with a cheap collective: clamped to 4 MB; a slow start-up: clamped to 64 MB
+    t2 = lambda n: 2e-6 + n / 300e9      # noqa: E731
+    assert bucket_bytes_from_probe(t2(12 * mb), 12 * mb, t2(54 * mb), 54 * mb)[0] == 4 * mb
+    t3 = lambda n: 1e-3 + n / 100e9      # noqa: E731
+    assert bucket_bytes_from_probe(t3(12 * mb), 12 * mb, t3(54 * mb), 54 * mb)[0] == 64 * mb
+    # degenerate timings (the larger message measured faster): still a valid size
+    b4, a4, be4 = bucket_bytes_from_probe(1e-3, 12 * mb, 0.9e-3, 54 * mb)
+    assert 4 * mb <= b4 <= 64 * mb and be4 > 0 and a4 >= 0

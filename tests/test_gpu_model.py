@@ -557,7 +557,13 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
     assert d['dist']['world_size'] == 2 and d['dist']['backend'] == 'gloo'
     assert d['dist']['replicas_identical_after_timed_steps'] is True
-    assert d['dist']['buckets']['bucket_mb'] == 6.0 and len(d['dist']['buckets']['early_ranges_mb'][0]) >= 3
+    # the collective was measured before the first step (all-reduce of the flat gradient and of one 12 MB bucket) and the
+    # bucket size of the exchange follows from it
+    pr = d['dist']['allreduce_probe']
+    assert pr['ranks_seen'] == 2 and {m['what'] for m in pr['messages']} == {'flat_gradient', 'bucket'}
+    assert all(m['correct'] and m['ms'] > 0 for m in pr['messages'])
+    assert d['dist']['buckets']['bucket_mb'] == pr['bucket_bytes_from_probe'] / float(1 << 20)
+    assert len(d['dist']['buckets']['early_ranges_mb'][0]) >= 2
     assert d['config']['launch_plan']['enabled'] and d['config']['launch_plan']['kernel_launches_per_step'] > 150
     assert np.isfinite(d['config']['final_total_loss']) and d['value'] > 0
     assert d['roofline'] is not None and d['roofline']['whole_step']['executed_flops'] > 0
