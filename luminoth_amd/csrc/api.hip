@@ -23,7 +23,9 @@ struct lmh_option { const char* name; int value; };
 static const lmh_option g_option_defaults[] = {
     {"bd_parity_small", 1},   // stride-2 3x3 backward data: 64x64 tiles when the parity classes are unbalanced
     {"half_pf", 1},           // f16/bf16 kernels: 1, 2 register sets; 3, 4 warp-specialised 512-thread blocks
-    {"x3_tile_slots", 256},   // bf16x3 fwd / bwd_data tile by pick_tile(slots); 0: half_tile
+    {"x3_tile_slots", 512},   // bf16x3 fwd / bwd_data tile by pick_tile(slots): 512 = two resident blocks per CU (round 6: 5.47 ms per
+                              // step against 5.54 with 256, 5.51 with 1024); 0: half_tile
+    {"x3_bw_slots", 256},     // bf16x3 weight gradient: resident-block slots its split count fills (bw_slots for the native kernels)
     {"x3_pf", -1},            // round-2 bf16x3 kernels (x3_new = 0): pipeline for every pass (-1: per-pass values below)
     {"x3_pf_fwd", 0}, {"x3_pf_gb", 0}, {"x3_pf_bd", 0}, {"x3_pf_bw", 0},
     {"x3_pipe", 0},           // round-6 bf16x3 kernels (conv_x3.h): 0 = phase by phase, two blocks per CU (default: 5.59 ms per step

@@ -468,7 +468,9 @@ static void bwd_weight_plan(const lmh_conv_desc* d, int* bm, int* bn, int* split
   int max_split = KT / 16 > 0 ? KT / 16 : 1;
   if (d->compute) max_split = KT / 8 > 0 ? KT / 8 : 1;
   if (max_split > (d->compute ? 128 : 64)) max_split = d->compute ? 128 : 64;
-  const int bw_slots = lmh_opt("bw_slots");
+  // bf16x3 (conv_x3.h, two 61 KB blocks per CU): filling 256 slots — half the splits, half the slab traffic — measured 5.38 ms per
+  // step against 5.54 with 512 (round 6, one box; 128: 5.77, 192: 5.47, 384: 5.48)
+  const int bw_slots = d->compute == 3 ? lmh_opt("x3_bw_slots") : lmh_opt("bw_slots");
   int want = 1;
   double best_eff = -1.0;
   for (int s = 1; s <= max_split; ++s) {
