@@ -273,7 +273,9 @@ class OracleFasterRCNN(object):
         to values produced elsewhere (identical-input comparisons)."""
         ov = overrides or {}
         H, W = image.shape[0], image.shape[1]
-        feat = self.backbone(image[None])
+        # 'feat': the trunk's output given (fixtures of the reference's top-level composition over a slim stand-in,
+        # tests/golden/make_golden_ref_tf.py gen_toplevel: the composition around the trunk is what is compared)
+        feat = torch.as_tensor(ov['feat']).to(self.dtype) if 'feat' in ov else self.backbone(image[None])
         fh, fw = feat.shape[1], feat.shape[2]
         cls_score, bbox_pred = self.rpn_head(feat)
         anchors = bx.generate_anchors(self.anchor_ref, fh, fw, self.stride)
@@ -302,6 +304,61 @@ class OracleFasterRCNN(object):
                                     torch.tensor(np.asarray(roi_targets)).to(self.dtype), self.C, 1.0)
         out['rcnn_cls_loss'], out['rcnn_reg_loss'] = c_cls, c_reg
         return out
+
+    # ---- which variables exist, in TensorFlow's creation order (slim resnet_v1: third party, restated; pinned against the
+    # reference's own variable lists by tests/test_ref_tf_golden.py::test_toplevel_* over tests/golden/slim_standin.py) ----
+    def resnet_variable_order(self, trainable_only=True):
+        """conv1, then block1..4 / unit_i / bottleneck_v1 / [shortcut (unit_1 only),] conv1, conv2, conv3; per convolution
+        `weights`, `BatchNorm/beta`, `BatchNorm/gamma` (+ moving_mean, moving_variance: not trainable)."""
+        kinds = ['weights', 'BatchNorm/beta', 'BatchNorm/gamma'] + ([] if trainable_only else
+                                                                    ['BatchNorm/moving_mean', 'BatchNorm/moving_variance'])
+        convs = ['conv1']
+        for b, units in enumerate(RESNET_UNITS[self.arch]):
+            for u in range(units):
+                p = 'block%d/unit_%d/bottleneck_v1/' % (b + 1, u + 1)
+                convs += ([p + 'shortcut'] if u == 0 else []) + [p + 'conv1', p + 'conv2', p + 'conv3']
+        return ['%s/%s/%s' % (self.base, c, k) for c in convs for k in kinds]
+
+    def head_variable_order(self):
+        """Sonnet creation order inside FasterRCNN._build: RPN (conv, cls_conv, bbox_conv: rpn.py:67-90), then RCNN (the FC
+        stack, fc_classifier, fc_bbox: rcnn.py:70-98); `w` before `b`."""
+        mods = ['rpn/conv', 'rpn/cls_conv', 'rpn/bbox_conv']
+        mods += sorted({k.split('/')[2] for k in self.v if k.startswith(self.scope + '/rcnn/fc_') and
+                        k.split('/')[2] not in ('fc_classifier', 'fc_bbox')}, key=lambda m: int(m.split('_')[1]))
+        mods = [m if m.startswith('rpn/') else 'rcnn/' + m for m in mods] + ['rcnn/fc_classifier', 'rcnn/fc_bbox']
+        return ['%s/%s/%s' % (self.scope, m, v) for m in mods for v in ('w', 'b')]
+
+    def trainable_names_in_reference_order(self, endpoint='block3', use_tail=True, freeze_tail=False, base_trainable=True):
+        """FasterRCNN.get_trainable_vars (fasterrcnn.py:337-358): the module's own variables, then — when
+        `base_network.trainable` — BaseNetwork.get_trainable_vars (base_network.py:211-241: everything from the first
+        variable whose name contains `fine_tune_from`) cut by TruncatedBaseNetwork.get_trainable_vars
+        (truncated_base_network.py:96-144: up to the LAST variable whose name contains the endpoint; for resnet_v1_101 with
+        a trainable tail, plus everything from the first `block4` variable on).  ResNet architectures."""
+        names = self.head_variable_order()
+        if not base_trainable:
+            return names
+        allv = self.resnet_variable_order()
+        if self.fine_tune_from is not None:
+            first = next((i for i, n in enumerate(allv) if self.fine_tune_from in n), None)
+            if first is None:
+                raise ValueError('"%s" is an invalid value of fine_tune_from for this architecture.' % self.fine_tune_from)
+            allv = allv[first:]
+        last = None
+        for i, n in enumerate(allv):
+            if endpoint in n:
+                last = i
+        out = allv[:last + 1] if last is not None else []
+        if use_tail and not freeze_tail and self.arch == 'resnet_v1_101':
+            first4 = next((i for i, n in enumerate(allv) if 'block4' in n), None)
+            if first4 is None:
+                raise ValueError('"block4" not present in the trainable vars retrieved from base network.')
+            out = out + allv[first4:]
+        return names + out
+
+    def regularized_names(self):
+        """The variables whose L2 term enters `regularization_loss`: every slim convolution `weights` (weight_decay arg_scope,
+        frozen and unused blocks included) and every Sonnet layer `w` of the heads (rpn.py:54-56, rcnn.py:60-62)."""
+        return [k for k in self.v if k.endswith('/weights') or k.endswith('/w')]
 
     # ---- trainable set (base_network.py:211-241, truncated_base_network.py:97-144) ---
     def trainable_names(self):

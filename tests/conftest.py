@@ -32,7 +32,7 @@ def lib():
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """Write what the parity checks observed (tests/parity_log.py) to profiles/r05_parity_observed.json — on a GPU box
+    """Write what the parity checks observed (tests/parity_log.py) to profiles/r06_parity_observed.json — on a GPU box
     only, merged over the file's previous content."""
     import json
     try:
@@ -42,7 +42,7 @@ def pytest_sessionfinish(session, exitstatus):
         return
     if not OBSERVED or not torch.cuda.is_available():
         return
-    path = os.path.join(ROOT, 'profiles', 'r05_parity_observed.json')
+    path = os.path.join(ROOT, 'profiles', 'r06_parity_observed.json')
     old = {}
     if os.path.exists(path):
         try:
@@ -60,5 +60,5 @@ def pytest_sessionfinish(session, exitstatus):
     out = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out, exist_ok=True)
     if os.path.isdir(out):          # gpurun merges gpurun_out/ back into the build container
-        with open(os.path.join(out, 'r05_parity_observed.json'), 'w') as f:
+        with open(os.path.join(out, 'r06_parity_observed.json'), 'w') as f:
             json.dump(doc, f, indent=1, sort_keys=True)

@@ -63,7 +63,7 @@ def _stat(stats, name, got, ref):
 
 
 def _log_stats(model, images, arch, fused, oracle_kwargs, stats):
-    """The errors this comparison observed -> tests/parity_log.py (profiles/r05_parity_observed.json)."""
+    """The errors this comparison observed -> tests/parity_log.py (profiles/r06_parity_observed.json)."""
     from parity_log import note
     bn = model.base_network
     tag = 'e2e/%s/%dx%dx%d/%s%s%s' % (arch, images.shape[0], images.shape[1], images.shape[2],

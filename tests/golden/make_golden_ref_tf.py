@@ -21,6 +21,11 @@ Reference code executed (loaded BY PATH from /root/reference/luminoth, never cop
     models/ssd/ssd.py:21-195                  SSD.__init__ / _build (multibox heads, anchors, targets,      (S2)
                                               hard-negative filter, proposals) over GIVEN feature maps
     utils/vars.py:1-130                       get_initializer / get_activation_function / summaries
+    models/fasterrcnn/fasterrcnn.py:22-358    FasterRCNN.__init__ / _build / loss / _generate_anchors /             (A16)
+                                              get_trainable_vars / get_base_network_checkpoint_vars
+    models/base/base_network.py:39-259        BaseNetwork (arg_scope, network, _build, preprocess, variable lists)   (A1, A2 names)
+    models/base/truncated_base_network.py:28-169  TruncatedBaseNetwork (_build, _build_tail, get_trainable_vars)
+    utils/anchors.py:4-52                     generate_anchors_reference                                            (A3)
 
 The three head `_build`s run on numpy `snt.Conv2D` / `snt.Linear` (tf_numpy_shim.py) whose variables are a fixed
 function of the module NAME (`seeded_variable`), so the replaying tests rebuild the same weights; what they pin is the
@@ -551,6 +556,134 @@ def gen_heads(m, out):
     tf.reset_losses()
 
 
+TOPLEVEL_CFG = {            # overrides of the reference's own models/fasterrcnn/base_config.yml (small shapes; replayed by the tests)
+    'train': {'seed': 7, 'debug': False},
+    'model': {'network': {'num_classes': 5},
+              'anchors': {'base_size': 64},
+              'base_network': {'architecture': 'resnet_v1_50'},
+              'rpn': {'num_channels': 24},
+              'rcnn': {'target': {'minibatch_size': 32}}}}
+
+
+def _merge(dst, src):
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _merge(dst[k], v)
+        else:
+            dst[k] = v
+    return dst
+
+
+def load_toplevel():
+    """The reference's top-level modules (fasterrcnn.py, base_network.py, truncated_base_network.py, utils/anchors.py) by path,
+    on the shim + the slim stand-in."""
+    import slim_standin
+    slim_standin.install()
+    for name in ('luminoth.utils.checkpoint_downloader', 'luminoth.models.base.truncated_vgg'):
+        sys.modules[name] = tf._Inert(name)
+    mods = {}
+    for rel in ('utils/anchors.py', 'models/base/base_network.py', 'models/base/truncated_base_network.py',
+                'models/fasterrcnn/fasterrcnn.py'):
+        name = 'luminoth.' + rel[:-3].replace('/', '.')
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        if rel.endswith('truncated_base_network.py'):
+            sys.modules['luminoth.models.base'].BaseNetwork = mods['base_network'].BaseNetwork
+        if rel.endswith('fasterrcnn.py'):
+            sys.modules['luminoth.models.base'].TruncatedBaseNetwork = mods['truncated_base_network'].TruncatedBaseNetwork
+        spec.loader.exec_module(mod)
+        mods[rel[:-3].split('/')[-1]] = mod
+    return mods, slim_standin
+
+
+def toplevel_config(over=None):
+    import copy
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(REF, 'models/fasterrcnn/base_config.yml')))
+    _merge(cfg, copy.deepcopy(TOPLEVEL_CFG))
+    if over:
+        _merge(cfg, over)
+    return ED(cfg)
+
+
+def gen_toplevel(m, out):
+    """the reference's TOP-LEVEL composition executed as it is — FasterRCNN.__init__ / _build / loss /
+    get_trainable_vars (fasterrcnn.py:22-259,337-358) and BaseNetwork._get_base_network_vars / get_trainable_vars /
+    get_base_network_checkpoint_vars + TruncatedBaseNetwork.get_trainable_vars (base_network.py:196-259,
+    truncated_base_network.py:96-144) — over a slim stand-in that creates the real variables (names, order, shapes,
+    collections, weight decay: tests/golden/slim_standin.py) and returns the fixture's feature map.  Pinned: the int32 anchor
+    grid the composition itself forms, stop_gradient'ed proposals into the RCNN, loss weights and what enters total_loss
+    (the loss dict), WHICH variables train per `fine_tune_from`, which are regularised, and the checkpoint name map."""
+    import json
+    tl, slim_standin = load_toplevel()
+    k = 'toplevel/'
+    rs = np.random.RandomState(2000)
+    fh, fw, stride = 6, 8, 16
+    H, W = fh * stride, fw * stride
+    feat = (rs.randn(1, fh, fw, 1024) * 0.5).astype(F)
+    gt = np.concatenate([rand_boxes(rs, 3, W, H, 16, 64), rs.randint(0, 5, size=(3, 1))], 1).astype(F)
+    image = tf.Tensor((rs.rand(H, W, 3) * 255).astype(F))
+    cfg = toplevel_config()
+    seed = orng.image_seed(cfg.train.seed, 0, 0)
+
+    def build(cfg_):
+        tf.reset_variables()
+        tf.reset_losses()
+        tf.track_regularizers(True)
+        slim_standin.set_feature_map(feat)
+        model = tl['fasterrcnn'].FasterRCNN(cfg_)
+        ref = np.trunc(model._anchor_reference).astype(np.int32)
+        anchors = obx.generate_anchors(model._anchor_reference, fh, fw, stride).astype(np.int32)
+        inside = np.where((anchors[:, 0] >= 0) & (anchors[:, 1] >= 0) & (anchors[:, 2] < W) & (anchors[:, 3] < H))[0]
+        rpn_hook = shuffle_by_counter_rng(seed, {'subsample_positive': orng.STREAM_RPN_FG,
+                                                 'subsample_negative': orng.STREAM_RPN_BG}, inside)
+        rcnn_hook = shuffle_by_counter_rng(seed, {'disable_some_fgs': orng.STREAM_RCNN_FG,
+                                                  'disable_some_bgs': orng.STREAM_RCNN_BG})
+        tf.set_random_shuffle(lambda v, s, caller: (rpn_hook if caller.startswith('subsample') else rcnn_hook)(v, s, caller))
+        pred = model(image, gt_boxes=gt, is_training=True)
+        return model, pred, ref, anchors
+
+    model, pred, ref_i32, anchors = build(cfg)
+    losses = model.loss(pred, return_all=True)
+    rp, cp = pred['rpn_prediction'], pred['classification_prediction']
+    out[k + 'cfg'] = np.array(json.dumps(TOPLEVEL_CFG, sort_keys=True))
+    out[k + 'feat'], out[k + 'gt'], out[k + 'ref_i32'] = feat, gt, ref_i32
+    out[k + 'geom'] = np.array([fh, fw, stride, H, W], np.int32)
+    out[k + 'seed'] = np.array([seed], np.uint32)
+    for key in ('rpn_cls_score', 'rpn_bbox_pred', 'proposals', 'rpn_cls_target', 'rpn_bbox_target'):
+        out[k + key] = rp[key]
+    out[k + 'rcnn_target_cls'], out[k + 'rcnn_target_bbox'] = cp['target']['cls'], cp['target']['bbox_offsets']
+    out[k + 'rcnn_cls_score'], out[k + 'rcnn_bbox_offsets'] = cp['rcnn']['cls_score'], cp['rcnn']['bbox_offsets']
+    for name, v in losses.items():
+        out[k + 'loss/' + name] = np.float32(v)
+    assert set(losses) == {'total_loss', 'no_reg_loss', 'regularization_loss', 'rpn_cls_loss', 'rpn_reg_loss',
+                           'rcnn_cls_loss', 'rcnn_reg_loss'}
+    strip = lambda vs: np.array([v.name[:-2] for v in vs])          # noqa: E731  ('<name>:0' -> '<name>')
+    out[k + 'names/all_variables'] = np.array([v.op.name for v in tf._variables])
+    out[k + 'names/all_shapes'] = np.array([list(v.shape) + [0] * (4 - len(v.shape)) for v in tf._variables], np.int32)
+    out[k + 'names/all_trainable'] = np.array([tf.GraphKeys.TRAINABLE_VARIABLES in v.collections for v in tf._variables])
+    out[k + 'names/regularized'] = np.array(tf.regularized_names())
+    ck = model.get_base_network_checkpoint_vars()
+    out[k + 'names/checkpoint_keys'] = np.array(list(ck))
+    out[k + 'names/checkpoint_vars'] = np.array([v.op.name for v in ck.values()])
+    out[k + 'names/trainable/block2'] = strip(model.get_trainable_vars())
+    n_all, n_reg, n_tr = len(tf._variables), len(tf.regularized_names()), len(model.get_trainable_vars())
+    # the other fine_tune_from settings of the config surface, and ResNet-101 (whose block4 tail trains: use_tail, not
+    # freeze_tail — truncated_base_network.py:127-142): names only
+    for tag, over in (('none', {'model': {'base_network': {'fine_tune_from': None}}}),
+                      ('block3_unit_2', {'model': {'base_network': {'fine_tune_from': 'block3/unit_2'}}}),
+                      ('not_trainable', {'model': {'base_network': {'trainable': False}}}),
+                      ('resnet_v1_101', {'model': {'base_network': {'architecture': 'resnet_v1_101'}}})):
+        m2, _, _, _ = build(toplevel_config(over))
+        out[k + 'names/trainable/' + tag] = strip(m2.get_trainable_vars())
+    tf.track_regularizers(False)
+    tf.reset_variables()
+    tf.reset_losses()
+    print('toplevel: %d variables, %d regularised, %d trainable (fine_tune_from block2); total_loss %.6f = no_reg %.6f + reg %.6f'
+          % (n_all, n_reg, n_tr, float(losses['total_loss']), float(losses['no_reg_loss']), float(losses['regularization_loss'])))
+
+
 def main():
     m = load_reference()
     out = {}
@@ -563,6 +696,7 @@ def main():
     gen_losses(m, out)
     gen_ssd(m, out)
     gen_heads(m, out)
+    gen_toplevel(m, out)
     for k, v in out.items():
         v = np.asarray(v)
         assert v.dtype != np.float64 or k.endswith('/cfg'), (k, v.dtype)     # nothing silently promoted

@@ -28,7 +28,21 @@ What is restated here and what is not:
     that replay a fixture rebuild the same weights without storing them (initializers / regularizers are accepted
     and ignored: the layouts are what is pinned, not the init distribution).
 
-`install()` puts `tensorflow`, `sonnet` and `easydict` stand-ins into `sys.modules`.
+  * round 6 (the reference's TOP-LEVEL composition is executed too: fasterrcnn.py:22-259,337-358 and
+    models/base/{base_network,truncated_base_network}.py): variable scopes are real (`variable_scope` pushes names; a Sonnet
+    module takes its scope where it is CONSTRUCTED and enters it when called), variables are objects with TensorFlow names
+    (`Variable`: `.name` = '<scope>/<var>:0', `.op.name`, collections) kept in creation order, so
+    `snt.get_variables_in_module`, `tf.get_collection(MODEL_VARIABLES, scope)`, `module.variable_scope.name` and the
+    reference's own `get_trainable_vars` / `get_base_network_checkpoint_vars` run unmodified; `l2_regularizer` is real and,
+    while `track_regularizers(True)` is in effect, a layer built with `regularizers={'w': fn}` adds fn(w) to the
+    regularization losses and its variable name to `regularized_names()` (off by default: the round-5 fixtures were made
+    with inert regularizers and stay byte-identical);
+  * `expand_dims` returns a `Tensor` view that applies TensorFlow's rule for `ndarray + tensor`: the ndarray is converted
+    to the TENSOR's dtype (float -> int truncates toward zero) — fasterrcnn.py:299-302 adds the float64 anchor reference to
+    an int32 grid that way, which is what makes `all_anchors` int32.
+
+`install()` puts `tensorflow`, `sonnet` and `easydict` stand-ins into `sys.modules`; the slim stand-in of the top-level
+fixtures lives in tests/golden/slim_standin.py.
 """
 import builtins
 import collections
@@ -133,7 +147,7 @@ def squeeze(x, axis=None, name=None):
 
 
 def expand_dims(x, axis, name=None):
-    return np.expand_dims(_t(x), axis)
+    return Tensor(np.expand_dims(_t(x), axis))      # (a graph tensor: `ndarray + tensor` converts the ndarray, see Tensor)
 
 
 def transpose(x, perm=None, name=None):
@@ -433,7 +447,129 @@ def _scope(*a, **k):
     yield None
 
 
-name_scope = variable_scope = control_dependencies = _scope
+name_scope = control_dependencies = _scope
+
+
+class GraphKeys(object):
+    GLOBAL_VARIABLES = 'variables'
+    TRAINABLE_VARIABLES = 'trainable_variables'
+    MODEL_VARIABLES = 'model_variables'
+    REGULARIZATION_LOSSES = 'regularization_losses'
+
+
+_VS = ['']            # stack of ABSOLUTE variable-scope names ('' = the root)
+_variables = []       # every Variable, in creation order (TensorFlow's order of `tf.trainable_variables()`)
+_var_by_name = {}
+_scope_names = set()
+_track_reg = [False]
+_reg_names = []
+
+
+class _Op(object):
+    def __init__(self, name):
+        self.name = name
+
+
+class Variable(object):
+    """A model variable: `.name` ('<scope>/<var>:0'), `.op.name`, `.value` (numpy, float32), `.collections`."""
+
+    def __init__(self, full_name, value, collections):
+        self.name = full_name + ':0'
+        self.op = _Op(full_name)
+        self.value = value
+        self.collections = set(collections)
+        self.shape = _Shape(np.shape(value))
+
+    def __repr__(self):
+        return '<Variable %s %s>' % (self.name, tuple(self.shape))
+
+
+class _VarScope(object):
+    def __init__(self, name):
+        self.name = name
+        self.original_name_scope = name + '/'
+
+
+@contextlib.contextmanager
+def variable_scope(name_or_scope=None, default_name=None, values=None, reuse=None, **k):
+    """Relative names nest under the current scope; a _VarScope object re-enters its absolute name."""
+    if isinstance(name_or_scope, _VarScope):
+        full = name_or_scope.name
+    else:
+        nm = name_or_scope if name_or_scope is not None else default_name
+        full = (_VS[-1] + '/' + nm) if _VS[-1] else nm
+    _VS.append(full)
+    try:
+        yield _VarScope(full)
+    finally:
+        _VS.pop()
+
+
+def get_variable_scope():
+    return _VarScope(_VS[-1])
+
+
+def reset_variables():
+    """Forget every variable, scope name and regularised-variable name (between fixture generators)."""
+    del _variables[:]
+    del _reg_names[:]
+    _var_by_name.clear()
+    _scope_names.clear()
+    del _VS[1:]
+
+
+def track_regularizers(on):
+    _track_reg[0] = bool(on)
+
+
+def regularized_names():
+    return list(_reg_names)
+
+
+def create_variable(name, make_value, trainable=True, model_variable=False, regularizer=None):
+    """The variable `name` of the CURRENT scope: created on first use (creation order is kept), returned again afterwards
+    (`reuse`).  make_value: () -> float32 array.  With track_regularizers(True), `regularizer(value)` joins the
+    regularization losses when the variable is created (TF: once per variable)."""
+    full = (_VS[-1] + '/' + name) if _VS[-1] else name
+    v = _var_by_name.get(full)
+    if v is not None:
+        return v
+    cols = [GraphKeys.GLOBAL_VARIABLES]
+    if trainable:
+        cols.append(GraphKeys.TRAINABLE_VARIABLES)
+    if model_variable:
+        cols.append(GraphKeys.MODEL_VARIABLES)
+    v = Variable(full, np.asarray(make_value(), np.float32), cols)
+    _variables.append(v)
+    _var_by_name[full] = v
+    if regularizer is not None and _track_reg[0]:
+        add_regularization_loss(regularizer(v.value))
+        _reg_names.append(full)
+    return v
+
+
+def get_collection(key, scope=None):
+    return [v for v in _variables if key in v.collections and (scope is None or v.name.startswith(scope))]
+
+
+def trainable_variables():
+    return get_collection(GraphKeys.TRAINABLE_VARIABLES)
+
+
+def get_variables_in_module(module, collection=GraphKeys.TRAINABLE_VARIABLES):
+    """snt.get_variables_in_module: the variables under the module's scope, creation order, as a TUPLE."""
+    prefix = module.variable_scope.name + '/'
+    return tuple(v for v in _variables if collection in v.collections and v.name.startswith(prefix))
+
+
+def l2_regularizer(scale, scope=None):
+    """tf.contrib.layers.l2_regularizer: scale * tf.nn.l2_loss(w) = scale * sum(w^2) / 2, float32."""
+    sc = np.float32(scale)
+
+    def reg(w):
+        w = np.asarray(w, np.float32)
+        return np.float32(sc * np.float32(np.sum(np.square(w), dtype=np.float32) / np.float32(2)))
+    return reg
 
 
 class _Inert(types.ModuleType):
@@ -458,6 +594,7 @@ def _flatten(x, *a, **k):
 
 contrib.layers = _Inert('tensorflow.contrib.layers')
 contrib.layers.flatten = _flatten          # tf.contrib.layers.flatten (rcnn.py:192): (N, ...) -> (N, prod(...)), row-major
+contrib.layers.l2_regularizer = l2_regularizer
 
 
 def _initializer(*a, **k):
@@ -583,17 +720,38 @@ def add_regularization_loss(value):
 
 # ------------------------------------------------------------------------------------------------ sonnet ----
 class AbstractModule(object):
-    """snt.AbstractModule: `module(*args)` calls `_build(*args)`."""
+    """snt.AbstractModule: `module(*args)` calls `_build(*args)` inside the module's variable scope, which is fixed where
+    the module is CONSTRUCTED: '<scope at construction>/<name>', made unique with a numeric suffix like Sonnet does."""
 
     def __init__(self, _sentinel=None, custom_getter=None, name=None):
         self._module_name = name
+        base = (_VS[-1] + '/' + name) if _VS[-1] else name
+        full, i = base, 0
+        while full in _scope_names:
+            i += 1
+            full = '%s_%d' % (base, i)
+        _scope_names.add(full)
+        self._scope_name = full
 
     @property
     def module_name(self):
         return self._module_name
 
+    @property
+    def variable_scope(self):
+        return _VarScope(self._scope_name)
+
+    @contextlib.contextmanager
+    def _enter_variable_scope(self, reuse=None):
+        _VS.append(self._scope_name)
+        try:
+            yield _VarScope(self._scope_name)
+        finally:
+            _VS.pop()
+
     def __call__(self, *args, **kwargs):
-        return self._build(*args, **kwargs)
+        with self._enter_variable_scope():
+            return self._build(*args, **kwargs)
 
 
 def seeded_variable(module_name, var, shape):
@@ -627,12 +785,31 @@ class Tensor(np.ndarray):
     def __array_wrap__(self, out, context=None, return_scalar=False):
         return np.asarray(out)
 
+    # `ndarray <op> tensor`: python tries the reflected method of the SUBCLASS operand first.  TensorFlow converts the
+    # ndarray to the tensor's dtype (ops.convert_to_tensor(value, dtype=tensor.dtype)): float -> int truncates toward zero.
+    def _coerce(self, other):
+        me = np.asarray(self)
+        if isinstance(other, np.ndarray) and not isinstance(other, Tensor) and other.dtype != me.dtype:
+            if np.issubdtype(me.dtype, np.integer) and np.issubdtype(other.dtype, np.floating):
+                other = np.trunc(other)
+            other = other.astype(me.dtype)
+        return me, np.asarray(other)
+
+    def __radd__(self, other):
+        me, o = self._coerce(other)
+        return o + me
+
+    def __add__(self, other):
+        me, o = self._coerce(other)
+        return me + o
+
     @property
     def shape(self):
         return _Shape(np.asarray(self).shape)
 
     def set_shape(self, shape):
-        assert list(shape) == list(np.asarray(self).shape), (shape, np.asarray(self).shape)
+        have = list(np.asarray(self).shape)
+        assert len(shape) == len(have) and all(a is None or a == b for a, b in zip(shape, have)), (shape, have)
 
 
 def _conv2d_nhwc(x, w, padding):
@@ -667,13 +844,17 @@ class Conv2D(AbstractModule):
         ks = kernel_shape if isinstance(kernel_shape, (list, tuple)) else [kernel_shape, kernel_shape]
         self._kh, self._kw, self._cout = int(ks[0]), int(ks[1]), int(output_channels)
         self._padding, self._use_bias = padding, use_bias
+        self._regularizers = regularizers or {}
 
     def _build(self, inputs):
         x = np.asarray(_t(inputs))
-        self._w = seeded_variable(self.module_name, 'w', (self._kh, self._kw, x.shape[3], self._cout))
+        shape = (self._kh, self._kw, x.shape[3], self._cout)
+        self._w = create_variable('w', lambda: seeded_variable(self.module_name, 'w', shape),
+                                  regularizer=self._regularizers.get('w')).value
         y = _conv2d_nhwc(x, self._w, self._padding)
         if self._use_bias:
-            self._b = seeded_variable(self.module_name, 'b', (self._cout,))
+            self._b = create_variable('b', lambda: seeded_variable(self.module_name, 'b', (self._cout,)),
+                                      regularizer=self._regularizers.get('b')).value
             y = y + self._b
         return y
 
@@ -685,14 +866,17 @@ class Linear(AbstractModule):
                  custom_getter=None, name='linear'):
         super(Linear, self).__init__(name=name)
         self._out, self._use_bias = int(output_size), use_bias
+        self._regularizers = regularizers or {}
 
     def _build(self, inputs):
         x = np.asarray(_t(inputs))
         assert x.ndim == 2 and x.dtype == np.float32
-        self._w = seeded_variable(self.module_name, 'w', (x.shape[1], self._out))
+        self._w = create_variable('w', lambda: seeded_variable(self.module_name, 'w', (x.shape[1], self._out)),
+                                  regularizer=self._regularizers.get('w')).value
         y = x @ self._w
         if self._use_bias:
-            self._b = seeded_variable(self.module_name, 'b', (self._out,))
+            self._b = create_variable('b', lambda: seeded_variable(self.module_name, 'b', (self._out,)),
+                                      regularizer=self._regularizers.get('b')).value
             y = y + self._b
         return y
 
@@ -731,6 +915,7 @@ def install():
     snt = _Inert('sonnet')
     snt.AbstractModule = AbstractModule
     snt.Conv2D, snt.Linear = Conv2D, Linear
+    snt.get_variables_in_module = get_variables_in_module
     sys.modules['sonnet'] = snt
     for sub in ('sonnet.python', 'sonnet.python.modules', 'sonnet.python.modules.conv'):
         sys.modules[sub] = _Inert(sub)

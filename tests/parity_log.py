@@ -1,6 +1,6 @@
 """What the GPU parity tests actually OBSERVED, not only whether they passed: every tolerance check
 that goes through `check_close` / `note` leaves its largest error here, and tests/conftest.py writes the collection to
-profiles/r05_parity_observed.json at the end of a `-m gpu` session (merged over what earlier sessions wrote, so a run of
+profiles/r06_parity_observed.json at the end of a `-m gpu` session (merged over what earlier sessions wrote, so a run of
 a single test file does not erase the rest)."""
 import numpy as np
 

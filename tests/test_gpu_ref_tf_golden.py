@@ -2,7 +2,7 @@
 (tests/golden/make_golden_ref_tf.py; the oracle replays the same file in tests/test_ref_tf_golden.py).  Nothing here
 goes through oracle/: the expected values are the reference's own outputs.  Labels, indices, keep lists, IoUs:
 bit-exact.  fp32 values that pass through expf / logf on the device: 1e-5 relative; box coordinates: north_star's 1e-4
-(absolute, in pixels) — the largest errors observed are written to profiles/r05_parity_observed.json (parity_log.py)."""
+(absolute, in pixels) — the largest errors observed are written to profiles/r06_parity_observed.json (parity_log.py)."""
 import os
 import sys
 
@@ -342,3 +342,77 @@ def test_ssd_module_layout_matches_reference_build(G):
     np.testing.assert_allclose(pd['target']['bbox_offsets'][0].cpu().numpy()[keep], G['heads/ssd_train/target_bbox'], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(pd['cls_pred'][0].detach().cpu().numpy()[keep], G['heads/ssd_train/cls_pred'], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(pd['loc_pred'][0].detach().cpu().numpy()[keep], G['heads/ssd_train/loc_pred'], rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------- the reference's TOP-LEVEL composition (round 6) ----
+class _GivenTrunk(object):
+    """The product's base network with its forward replaced by a given feature map (the fixture's): everything else —
+    the tail, variable bookkeeping, feature geometry — is the real object's."""
+
+    def __init__(self, real, fmap):
+        self.__dict__['_real'], self.__dict__['_fmap'] = real, fmap
+
+    def __call__(self, image, is_training=False):
+        return self._fmap
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+
+@pytest.mark.parametrize('compute', [None, 'bf16x3'], ids=['f32', 'bf16x3'])
+def test_toplevel_composition_matches_reference_build(G, compute):
+    """VERDICT r5 next #6.  FasterRCNN.__init__ / _build / loss (fasterrcnn.py:22-259) were executed by the reference over a
+    slim stand-in that returns the fixture's feature map; the product's FasterRCNN — same config overrides, the same
+    variables by name, its trunk replaced by the same feature map — must give the reference's RPN outputs, anchor targets,
+    proposals (stop_gradient'ed into the RCNN), sampled ROIs, RCNN outputs and EVERY entry of the loss dict, the L2 term over
+    all 58 regularised variables included (frozen conv1 / block1 and the unused block4 too)."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+    import slim_standin
+    from luminoth_amd.models import get_model
+    from luminoth_amd.utils.config import get_config
+    k = 'toplevel/'
+    cfg = json.loads(str(G[k + 'cfg']))
+    cfg['model']['type'] = 'fasterrcnn'
+    if compute:
+        cfg['model']['base_network']['compute_dtype'] = compute
+    model = get_model('fasterrcnn')(get_config(cfg), device='cuda:0')
+    names_, shapes = [str(n) for n in G[k + 'names/all_variables']], G[k + 'names/all_shapes']
+    sd = {n: torch.from_numpy(slim_standin.variable_value(n, shapes[i])) for i, n in enumerate(names_)}
+    assert sorted(sd) == sorted(model.state_dict())
+    model.load_state_dict(sd)
+    fh, fw, stride, H, W = (int(v) for v in G[k + 'geom'])
+    np.testing.assert_array_equal(model._anchor_ref_i32.cpu().numpy(), G[k + 'ref_i32'])
+    assert model._anchor_stride == stride
+    model.base_network = _GivenTrunk(model.base_network, T(G[k + 'feat']))
+    model._step = 0
+    assert int(model._image_seeds(1)[0].cpu().numpy().view(np.uint32)) == int(G[k + 'seed'][0])
+    pred = model(torch.zeros((H, W, 3)), G[k + 'gt'], is_training=True)
+    losses = model.loss(pred, return_all=True)
+    torch.cuda.synchronize()
+    rp, cp = pred['rpn_prediction'], pred['classification_prediction']
+    check_close('ref_tf_golden/toplevel/rpn_cls_score', rp['rpn_cls_score'][0].detach().cpu().numpy(), G[k + 'rpn_cls_score'],
+                rtol=1e-5, atol=2e-5)
+    check_close('ref_tf_golden/toplevel/rpn_bbox_pred', rp['rpn_bbox_pred'][0].detach().cpu().numpy(), G[k + 'rpn_bbox_pred'],
+                rtol=1e-5, atol=2e-5)
+    np.testing.assert_array_equal(rp['rpn_cls_target'][0].cpu().numpy(), G[k + 'rpn_cls_target'])
+    np.testing.assert_allclose(rp['rpn_bbox_target'][0].cpu().numpy(), G[k + 'rpn_bbox_target'], rtol=1e-5, atol=1e-6)
+    n = int(rp['num_proposals'][0])
+    assert n == G[k + 'proposals'].shape[0]
+    np.testing.assert_allclose(rp['proposals'][0, :n].cpu().numpy(), G[k + 'proposals'], rtol=0, atol=1e-3)
+    m = int(cp['num_proposals'][0])
+    assert m == G[k + 'rcnn_target_cls'].shape[0]
+    np.testing.assert_array_equal(cp['target']['cls'][0, :m].cpu().numpy(), G[k + 'rcnn_target_cls'])
+    np.testing.assert_allclose(cp['target']['bbox_offsets'][0, :m].cpu().numpy(), G[k + 'rcnn_target_bbox'], rtol=1e-5, atol=1e-5)
+    check_close('ref_tf_golden/toplevel/rcnn_cls_score', cp['rcnn']['cls_score'][0, :m].detach().cpu().numpy(),
+                G[k + 'rcnn_cls_score'], rtol=1e-5, atol=2e-5)
+    check_close('ref_tf_golden/toplevel/rcnn_bbox_offsets', cp['rcnn']['bbox_offsets'][0, :m].detach().cpu().numpy(),
+                G[k + 'rcnn_bbox_offsets'], rtol=1e-5, atol=2e-5)
+    assert set(losses) == {'total_loss', 'no_reg_loss', 'regularization_loss', 'rpn_cls_loss', 'rpn_reg_loss',
+                           'rcnn_cls_loss', 'rcnn_reg_loss'}
+    from parity_log import note
+    for name_, v in losses.items():
+        ref = float(G[k + 'loss/' + name_])
+        err = abs(float(v) - ref) / max(1.0, abs(ref))
+        note('ref_tf_golden/toplevel[%s]/loss:%s' % (compute or 'f32', name_), err, 2e-6)
+        assert err <= 2e-6, (name_, float(v), ref)

@@ -146,3 +146,72 @@ def test_losses_collection():
     assert tf.losses.get_total_loss() == np.float32(1.75)
     tf.reset_losses()
     assert tf.losses.get_total_loss() == 0
+
+
+def test_variable_scopes_modules_and_collections():
+    """Round 6 (the reference's top-level composition is executed): a Sonnet module takes its variable scope where it is
+    CONSTRUCTED and enters it when called; variables keep TensorFlow names and creation order; collections answer
+    snt.get_variables_in_module / tf.get_collection; same-named modules are made unique."""
+    tf.reset_variables()
+    tf.reset_losses()
+    try:
+        class Outer(tf.AbstractModule):
+            def __init__(self):
+                super(Outer, self).__init__(name='outer')
+                self.side = tf.Linear(3, name='side')                 # constructed OUTSIDE _build: scope 'side', not 'outer/side'
+
+            def _build(self, x):
+                a = tf.Linear(4, name='fc')(x)                        # 'outer/fc'
+                b = tf.Linear(4, name='fc')(x)                        # 'outer/fc_1'
+                with tf.variable_scope('extra'):
+                    tf.create_variable('stat', lambda: np.zeros(2, np.float32), trainable=False, model_variable=True)
+                return a + b + self.side(x)[:, :1]
+        m = Outer()
+        m(np.ones((2, 5), np.float32))
+        names = [v.name for v in tf._variables]
+        assert names == ['outer/fc/w:0', 'outer/fc/b:0', 'outer/fc_1/w:0', 'outer/fc_1/b:0', 'outer/extra/stat:0',
+                         'side/w:0', 'side/b:0']
+        assert m.variable_scope.name == 'outer' and m.side.variable_scope.name == 'side'
+        assert [v.op.name for v in tf.get_variables_in_module(m)] == ['outer/fc/w', 'outer/fc/b', 'outer/fc_1/w', 'outer/fc_1/b']
+        assert [v.name for v in tf.get_variables_in_module(m, tf.GraphKeys.MODEL_VARIABLES)] == ['outer/extra/stat:0']
+        assert [v.name for v in tf.get_collection(tf.GraphKeys.MODEL_VARIABLES, scope='outer')] == ['outer/extra/stat:0']
+        # (every module is connected ONCE in the fixtures: Sonnet's template machinery that re-uses the sub-modules of a second
+        # connection is not restated)
+        m.side(np.ones((2, 5), np.float32))                          # ... a layer called again re-uses its variables
+        assert len(tf._variables) == 7
+    finally:
+        tf.reset_variables()
+
+
+def test_regularizers_are_tracked_only_on_request():
+    tf.reset_variables()
+    tf.reset_losses()
+    try:
+        reg = tf.l2_regularizer(0.5)
+        w = np.arange(6, dtype=np.float32).reshape(2, 3)
+        assert reg(w) == np.float32(0.5 * (w ** 2).sum() / 2) and reg(w).dtype == np.float32
+        tf.Linear(3, regularizers={'w': reg}, name='quiet')(np.ones((1, 2), np.float32))
+        assert tf.regularized_names() == [] and tf.losses.get_regularization_loss() == 0       # round-5 behaviour by default
+        tf.track_regularizers(True)
+        lin = tf.Linear(3, regularizers={'w': reg}, name='loud')
+        lin(np.ones((1, 2), np.float32))
+        lin(np.ones((1, 2), np.float32))                                                      # once per VARIABLE, not per call
+        assert tf.regularized_names() == ['loud/w']
+        assert tf.losses.get_regularization_loss() == reg(lin._w)
+    finally:
+        tf.track_regularizers(False)
+        tf.reset_variables()
+        tf.reset_losses()
+
+
+def test_ndarray_plus_tensor_takes_the_tensors_dtype():
+    """fasterrcnn.py:299-302 adds the float64 numpy anchor reference to an int32 graph tensor: TensorFlow converts the
+    ndarray to the TENSOR's dtype (truncation toward zero), which is why `all_anchors` is int32 (SURVEY.md appendix B.1,
+    pinned by fasterrcnn_test.py:285-295)."""
+    shifts = tf.expand_dims(np.array([[0, 0, 0, 0], [16, 0, 16, 0]], np.int32), axis=1)        # (2, 1, 4) graph tensor
+    ref = np.array([[-22.627417, -11.3137085, 22.627417, 11.3137085]], np.float64)
+    out = np.expand_dims(ref, axis=0) + shifts
+    assert out.dtype == np.int32 and out.tolist() == [[[-22, -11, 22, 11]], [[-6, -11, 38, 11]]]
+    assert (shifts + np.expand_dims(ref, axis=0)).dtype == np.int32
+    same = tf.expand_dims(np.ones(3, np.float32), 0) + np.ones(3, np.float32)                 # equal dtypes: plain addition
+    assert same.dtype == np.float32 and same.tolist() == [[2.0, 2.0, 2.0]]
