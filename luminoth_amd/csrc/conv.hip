@@ -229,8 +229,9 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
     if (d->compute == 3 && x3_tile_pick) pick_tile(M, d->K, &bm, &bn, x3_tile_pick); else half_tile(M, d->K, &bm, &bn);
     if (d->compute == 3 && lmh_opt("x3_new") ) {      // round-6 bf16x3 kernel, bit mask fused (conv_x3.h)
       prof_begin(st);
-      rc = lmh_x3_fwd_launch(d, x, w, scale, shift, residual, y, act_bits, 0, bm, bn, x3_pipe(d->R * d->S * (d->C / BK)), st);
-      prof_end(st, desc_flops(d), "k_x3_fwd<%d, %d, false>", bm, bn);
+      const int pipe = x3_pipe(d->R * d->S * (d->C / BK));
+      rc = lmh_x3_fwd_launch(d, x, w, scale, shift, residual, y, act_bits, 0, bm, bn, pipe, st);
+      prof_end(st, desc_flops(d), "k_x3_fwd<%d, %d, false, %d>", bm, bn, pipe);   // as rocprofv3 prints it
       *bits_done = true;
       return rc;
     }
@@ -377,8 +378,9 @@ static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const
     if (d->compute == 3 && x3_tile_pick) pick_tile(M, d->C, &bm, &bn, x3_tile_pick); else half_tile(M, d->C, &bm, &bn);   // (no parity classes here)
     if (d->compute == 3 && lmh_opt("x3_new") ) {      // round-6 bf16x3 kernel, input mask fused (conv_x3.h)
       prof_begin(st);
-      const int rc3 = lmh_x3_bwd_data_launch(d, dy, w, kscale, addend, xbits, dx, bm, bn, x3_pipe(d->R * d->S * (d->K / BK)), st);
-      prof_end(st, desc_flops(d), "k_x3_bwd_data<%d, %d>", bm, bn);
+      const int pipe = x3_pipe(d->R * d->S * (d->K / BK));
+      const int rc3 = lmh_x3_bwd_data_launch(d, dy, w, kscale, addend, xbits, dx, bm, bn, pipe, st);
+      prof_end(st, desc_flops(d), "k_x3_bwd_data<%d, %d, %d>", bm, bn, pipe);
       *bits_done = true;
       return rc3;
     }
@@ -654,7 +656,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     if (lmh_opt("x3_new")) {
       prof_begin(st);
       const int rc3 = lmh_x3_bwd_weight_launch(d, x, dy, out, kps, (int)grid.x, (int)grid.y, (int)grid.z, nullptr, true, bm, bn, x3_pipe(2), st);
-      prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, true>", bm, bn);
+      prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, true, %d>", bm, bn, x3_pipe(2));
       if (rc3) return rc3;
       if (splits > 1 && g_gb_slabs.want) {
         g_gb_slabs.slabs = reinterpret_cast<const float*>(ws);
@@ -723,7 +725,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     else LAUNCH_BW_HT(64, 64);
 #undef LAUNCH_BW_HT
 #undef LAUNCH_BW_H
-    if (d->compute == 3 && lmh_opt("x3_new")) prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, false>", bm, bn);
+    if (d->compute == 3 && lmh_opt("x3_new")) prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, false, %d>", bm, bn, x3_pipe(2));
     else prof_end(st, desc_flops(d), "k_conv_bwd_weight_h<%d, %d, %d>", d->compute, bm, bn);
     if (g_lmh_defer_tail) {
       g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;

@@ -682,7 +682,7 @@ static int wino_run(const lmh_conv_desc* d, int mo, const float* in, int Cg, int
   else if (bm == 128) LAUNCH_WG(128, 64);
   else LAUNCH_WG(64, 64);
 #undef LAUNCH_WG
-  if (x3 && lmh_opt("x3_new")) prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_x3_fwd<%d, %d, true>", bm, bn);
+  if (x3 && lmh_opt("x3_new")) prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_x3_fwd<%d, %d, true, %d>", bm, bn, x3_pipe(Cg / BK));
   else if (x3) prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd_h<3, %d, %d, GB>", bm, bn);
   else prof_end(st, (double)P2 * 2.0 * T * (double)Cg * Kg, "k_conv_fwd<%d, %d, true>", bm, bn);
   if (mo == 4) {

@@ -15,6 +15,7 @@ from luminoth_amd import autograd as A
 from luminoth_amd.models.base.base_network import BaseNetwork, zeros
 from luminoth_amd.models.base.layers import ConvLayer
 from luminoth_amd.models.base.networks import VGG16_CFG
+from luminoth_amd.utils.vars import truncated_standard_normal
 
 VALID_SSD_ARCHITECTURES = set(['truncated_vgg_16'])
 
@@ -38,7 +39,7 @@ def xavier_uniform(shape, gen):
 def sonnet_default(shape, gen):
     """Sonnet Conv2D default w initializer: truncated normal, stddev 1/sqrt(fan_in)."""
     fan_in = shape[0] * shape[1] * shape[2]
-    return torch.randn(shape, generator=gen).clamp_(-2, 2) / math.sqrt(fan_in)
+    return truncated_standard_normal(shape, gen) / math.sqrt(fan_in)
 
 
 class SSDFeatureExtractor(BaseNetwork):

@@ -13,6 +13,17 @@ VALID_INITIALIZERS = {
 }
 
 
+def truncated_standard_normal(shape, gen):
+    """tf.truncated_normal (vars.py:4-5; Sonnet's default Conv2D / Linear initializer): values further than two standard
+    deviations from the mean are DROPPED AND RE-DRAWN, not clamped (a clamp would put 4.6 % of the mass on the bounds)."""
+    t = torch.randn(shape, generator=gen)
+    bad = t.abs() > 2
+    while bool(bad.any()):
+        t[bad] = torch.randn(int(bad.sum()), generator=gen)
+        bad = t.abs() > 2
+    return t
+
+
 def get_initializer(cfg, seed=None):
     """cfg: {'type': ..., **kwargs}.  Returns fn(shape, generator) -> cpu fp32 tensor.
     Unknown types raise ValueError (vars.py:66-71)."""
@@ -28,12 +39,13 @@ def get_initializer(cfg, seed=None):
             rf *= s
         return shape[-2] * rf, shape[-1] * rf
 
+    truncated = truncated_standard_normal
+
     def init(shape, gen):
         if kind == 'random_normal_initializer':
             return torch.randn(shape, generator=gen) * cfg.get('stddev', 1.0) + cfg.get('mean', 0.0)
         if kind == 'truncated_normal_initializer':
-            t = torch.randn(shape, generator=gen).clamp_(-2, 2)
-            return t * cfg.get('stddev', 1.0) + cfg.get('mean', 0.0)
+            return truncated(shape, gen) * cfg.get('stddev', 1.0) + cfg.get('mean', 0.0)
         if kind in ('variance_scaling_initializer', 'xavier_initializer'):
             fan_in, fan_out = fans(shape)
             mode = cfg.get('mode', 'FAN_AVG' if kind == 'xavier_initializer' else 'FAN_IN')
@@ -42,7 +54,7 @@ def get_initializer(cfg, seed=None):
             if cfg.get('uniform', kind == 'xavier_initializer'):
                 lim = math.sqrt(3.0 * factor / n)
                 return (torch.rand(shape, generator=gen) * 2 - 1) * lim
-            return torch.randn(shape, generator=gen).clamp_(-2, 2) * math.sqrt(1.3 * factor / n)
+            return truncated(shape, gen) * math.sqrt(1.3 * factor / n)
         if kind == 'constant_initializer':
             return torch.full(shape, float(cfg.get('value', 0.0)))
         return torch.zeros(shape)

@@ -61,7 +61,7 @@ out.write('Step (optimizer launch to optimizer launch, under the profiler): **%.
           'of kernel durations %.2f ms/step (streams overlap; durations of kernels that share the GPU include the '
           'slow-down from sharing).\n\n' % (wall / 1e6, len(win) / float(timed), total / timed / 1e6))
 out.write('| kernel | calls/step | us/step | avg us | % |\n|---|---|---|---|---|\n')
-for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:36]:
+for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):       # every kernel of the step: the launch inventory
     nm = n if len(n) <= 70 else n[:67] + '...'
     out.write('| `%s` | %.1f | %.1f | %.1f | %.2f |\n' % (nm, c / float(timed), t / timed / 1e3, t / c / 1e3, 100.0 * t / total))
 tl = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'timeline.py'), os.path.join(src, trace), '--skip', str(skip_last)],

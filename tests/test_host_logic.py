@@ -58,6 +58,11 @@ def test_initializers_and_activations():
     assert float(u.abs().max()) <= np.sqrt(3.0 / ((1024 + 81) / 2)) + 1e-6
     with pytest.raises(ValueError):
         get_initializer({'type': 'nope'})
+    # tf.truncated_normal re-draws what falls outside two standard deviations (vars.py:4-5): no mass ON the bounds, and the
+    # standard deviation of the truncated law (0.8796 sigma), not that of a clamped one (0.9543 sigma)
+    t = get_initializer({'type': 'truncated_normal_initializer', 'mean': 0., 'stddev': 0.5})((512, 512), g)
+    assert float(t.abs().max()) < 1.0 and int((t.abs() == 1.0).sum()) == 0
+    assert abs(float(t.std()) / 0.5 - 0.8796) < 5e-3
     assert get_activation_function('relu6') == 'relu6' and get_activation_function(None) is None
     with pytest.raises(ValueError):
         get_activation_function('swish')
