@@ -806,6 +806,8 @@ static int hs_launch(const lmh_conv_desc* d, const void* A, const void* B, const
   const int64_t M = BWD ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->OH * d->OW;
   const int NC = BWD ? d->C : d->K;
   int bm, bn;
+  // (round 6: a six-deep ring — 144 KB, five stages in flight, one block per CU — for the launches of about one tile per CU was
+  // built, bit-identical, and LOST inside the step: forward 0.85 -> 0.99 ms of the f16 step, profiles/r06_ab.md; removed)
   // 128 x 64 once it still gives every CU a block (fewer, longer tiles: the RPN 3x3 backward 161 -> 141 us, block3
   // 256->1024 forward 16.2 -> 14.5 us), else 64 x 64; 128 x 128 (one block per CU) never won (scripts/bench_conv_hs.py --sweep)
   if (g_force_bm && g_force_bn) { bm = g_force_bm; bn = g_force_bn; }
@@ -857,6 +859,12 @@ extern "C" int lmh_conv2d_bwd_data_hs(const lmh_conv_desc* d, const void* g, con
 static bool wgrad_hs_plan(const lmh_conv_desc* d, int* bm, int* bn, int* splits, int* kt_per_split) {
   if (!((d->compute == 1 || d->compute == 2) && (d->C % 64) == 0 && (d->K % 64) == 0)) return false;
   *bm = *bn = (d->C >= 128 && d->K >= 128) ? 128 : 64;
+  const bool gather = d->R * d->S > 1 || d->stride > 1;
+  // round 6: the split-K slabs are splits x |dW| fp32 bytes written here and read again by the tail; for a
+  // fixed number of blocks that is blocks x tile area, so 64 x 64 tiles carry a quarter of the slab bytes of 128 x 128 ones
+  // (and twice the operand traffic, which L2 absorbs).  hs_wg_tile: 0 = the rule above, 64 / 128 = that tile for the 1x1 layers
+  const int wt = lmh_opt("hs_wg_tile");
+  if (!gather && (wt == 64 || (wt == 128 && d->C >= 128 && d->K >= 128))) *bm = *bn = wt;
   if (g_force_bm && g_force_bn) *bm = *bn = (g_force_bm >= 128 && g_force_bn >= 128) ? 128 : 64;
   const int64_t tiles = (int64_t)d->R * d->S * ((d->C + *bm - 1) / *bm) * ((d->K + *bn - 1) / *bn);
   const int64_t P = (int64_t)d->N * d->OH * d->OW;
@@ -864,7 +872,6 @@ static bool wgrad_hs_plan(const lmh_conv_desc* d, int* bm, int* bn, int* splits,
   // 1x1: fill the resident-block slots once.  Gathered (3x3) layers re-read x once per tap and g once per tap and channel
   // tile, mostly out of the Infinity Cache: they run best cut into ~2000 short blocks (measured, scripts/bench_conv_hs.py:
   // RPN 3x3 1024->512 386 us unsplit, 250 us with 8 splits; block3 3x3 51 -> 42 us)
-  const bool gather = d->R * d->S > 1 || d->stride > 1;
   const int slots = gather ? 2048 : ((*bm == 128) ? 256 : 512);
   int want = (int)((slots + tiles - 1) / tiles);
   const int max_split = KT / 4 > 0 ? (KT / 4 < 64 ? KT / 4 : 64) : 1;

@@ -279,7 +279,7 @@ k_gather_topk(const uint64_t* __restrict__ keys, const float4* __restrict__ boxe
 //    (scripts/bench_nms.py: 2000 keeps inside the first 5 000 candidates) m = 3 takes the pair from 254 to 183 us alone;
 //    inside the train step of a randomly initialised network the scan needs MORE than 6 000 candidates, both stages run,
 //    and the step is 0.05-0.07 ms SLOWER (fp32 6.95 -> 7.00-7.02 ms, f16 4.21 -> 4.23, A/B on one box,
-//    scripts/r4_exp5.sh) — hence off by default; a trained RPN (sharper scores) is the case it is kept for.
+//    scripts/ab.sh "" "LMH_OPT_NMS_STAGE_MULT=2") — hence off by default; a trained RPN (sharper scores) is the case it is kept for.
 //    (A finer version, one pair of launches per 1024-candidate super-chunk computing only the kept rows x the columns
 //    reached — 10x fewer IoUs — put 24 small dependent launches on the proposal stream, each queued behind the resident
 //    MFMA grids of the other streams: the chain got 0.67 ms LONGER inside the step; deleted.)

@@ -6,10 +6,10 @@
 R=$GRAFT_REPO_ROOT; TAG=$1; ARGS="$2"
 O=$R/gpurun_out/r6_trace_$TAG; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o t -- python $R/bench.py $ARGS --steps 30 --warmup 10 --no-cpu-baseline --no-other-configs --no-rocprof > $O/profiled_line.json 2> $O/prof.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o t -- python $R/bench.py $ARGS --steps 30 --warmup 10 --no-cpu-baseline --no-other-configs --no-native --no-rocprof > $O/profiled_line.json 2> $O/prof.err
 cd $R
 D=$(dirname $(find $O/prof -name '*kernel_trace.csv' | head -n 1))
-python scripts/make_profile_summary.py $D ${TAG}_bench "python bench.py $ARGS --steps 30 --warmup 10 --no-rocprof (production steps: three streams, launch-plan replay)" 30 4 > $O/summary.txt 2>&1
+python scripts/make_profile_summary.py $D ${TAG}_bench "python bench.py $ARGS --steps 30 --warmup 10 --no-native --no-rocprof (production steps: three streams, launch-plan replay)" 30 4 > $O/summary.txt 2>&1
 python scripts/make_profile_summary.py $D ${TAG}_serial "python bench.py $ARGS (the 3 serialised roofline steps at the end of the same run)" 3 0 > $O/summary_serial.txt 2>&1
 cp profiles/${TAG}_bench_summary.md profiles/${TAG}_bench_kernel_stats.csv profiles/${TAG}_serial_summary.md profiles/${TAG}_serial_kernel_stats.csv $O/ 2>/dev/null
 rm -rf $O/prof

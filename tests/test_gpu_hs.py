@@ -185,6 +185,35 @@ def test_hs_convolution_kernels(K, case, storage):
     assert torch.equal(dw2, dw)
 
 
+@pytest.mark.parametrize('storage', ['f16', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 50, 84, 512, 256), (2, 17, 23, 128, 64)])
+def test_hs_small_wgrad_tile_option(K, case, storage):
+    """hs_wg_tile = 64: 64 x 64 tiles for the 1x1 weight gradient (a quarter of the split-K slab bytes for the same block
+    count; another split count, so the fp32 summation order differs: 1e-5 of the scale)."""
+    N, H, W, C, Kc = case
+    tdt = TORCH_DT[storage]
+    rs = np.random.RandomState(77)
+    x = T(rs.randn(N, H, W, C).astype(F)).to(tdt)
+    g = T((rs.randn(N, H, W, Kc) * 0.05).astype(F)).to(tdt)
+    d = K.conv_desc(x.shape, (1, 1, C, Kc), 1, 1, 'SAME', 'relu', storage)
+
+    def run():
+        cs = torch.zeros((Kc,), device=dev())
+        dw = K.conv2d_bwd_weight_hs(d, x, g, 1.0 / 256, colsum=cs)
+        torch.cuda.synchronize()
+        return dw.clone(), cs.clone()
+    old = K.get_option('hs_wg_tile')
+    try:
+        K.set_option('hs_wg_tile', 0)
+        dw0, cs0 = run()
+        K.set_option('hs_wg_tile', 64)
+        dw2, cs2 = run()
+        assert float((dw2 - dw0).abs().max()) <= 1e-5 * float(dw0.abs().max())
+        assert float((cs2 - cs0).abs().max()) <= 1e-5 * float(cs0.abs().max())
+    finally:
+        K.set_option('hs_wg_tile', old)
+
+
 def test_hs_entry_points_refuse_what_they_do_not_take(K):
     from luminoth_amd._lib import LuminothHipError
     d = K.conv_desc((1, 8, 8, 32, ), (1, 1, 32, 64), 1, 1, 'SAME', None, 'f16')       # C % 64 != 0
