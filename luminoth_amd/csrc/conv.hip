@@ -163,7 +163,13 @@ static float half_gscale(const lmh_conv_desc* d) { return d->compute == 1 ? 1024
 // LMH_X3_PF forces one value for all passes.
 #define x3_tile_pick lmh_opt("x3_tile_slots")   // tile of the bf16x3 fwd / bwd_data kernels by pick_tile(slots); 0: half_tile
 // schedule of the round-6 bf16x3 kernels (conv_x3.h): 1 = software-pipelined (needs an even stage count), 0 = phase by phase
-static int x3_pipe(int stages) { return (lmh_opt("x3_pipe") && (stages & 1) == 0) ? 1 : 0; }
+// x3_pipe: 0 = phase by phase; 1 = the software-pipelined variant wherever the stage count is even; N >= 2 = only for
+// reductions of at least N stages (the RPN 3x3 convolution's transformed-domain GEMMs have 32)
+static int x3_pipe(int stages) {
+  const int o = lmh_opt("x3_pipe");
+  if (o <= 0 || (stages & 1) != 0) return 0;
+  return (o == 1 || stages >= o) ? 1 : 0;
+}
 static int x3_pf(const char* pass) { const int a = lmh_opt("x3_pf"); return a >= 0 ? a : lmh_opt(pass); }
 #define x3_pf_fwd x3_pf("x3_pf_fwd")
 #define x3_pf_gb x3_pf("x3_pf_gb")     // stacked Winograd GEMMs (forward kernel)

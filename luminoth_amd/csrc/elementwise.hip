@@ -4,6 +4,80 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: loads stay loads
 
+// ---------------------------------------------------------------------------
+// Activations beyond the two the convolution epilogues fuse (1 relu, 2 relu6).  The reference takes ANY tf.nn.<name> as
+// `activation_function` of the RPN convolution and the RCNN fully connected layers (luminoth/utils/vars.py:80-88,
+// rpn.py:57-59, rcnn.py:73-74); these are the smooth / leaky ones of tf.nn in TF 1.x, applied in place behind the
+// convolution (lmh_act_fwd) and differentiated FROM THE OUTPUT y, like TF's own EluGrad / SeluGrad / SigmoidGrad /
+// TanhGrad (SoftplusGrad / SoftsignGrad take the input there; the expressions in y below are the same functions):
+//   3 elu        z > 0 ? z : e^z - 1                         f' = y > 0 ? 1 : y + 1
+//   4 selu       s * (z > 0 ? z : a (e^z - 1))               f' = y > 0 ? s : y + s a        (s 1.0507009873554805, a 1.6732632423543772)
+//   5 softplus   log(1 + e^z)                                f' = 1 - e^-y
+//   6 softsign   z / (1 + |z|)                               f' = (1 - |y|)^2
+//   7 sigmoid    1 / (1 + e^-z)                              f' = y (1 - y)
+//   8 tanh                                                   f' = 1 - y^2
+//   9 leaky_relu max(0.2 z, z)   (tf.nn.leaky_relu default)  f' = y > 0 ? 1 : 0.2
+// ---------------------------------------------------------------------------
+#define LMH_SELU_S 1.0507009873554805f
+#define LMH_SELU_A 1.6732632423543772f
+__device__ __forceinline__ float lmh_act_apply(float z, int act) {
+  switch (act) {
+    case 1: return fmaxf(z, 0.f);
+    case 2: return fminf(fmaxf(z, 0.f), 6.f);
+    case 3: return z > 0.f ? z : expm1f(z);
+    case 4: return z > 0.f ? LMH_SELU_S * z : (LMH_SELU_S * LMH_SELU_A) * expm1f(z);
+    case 5: return z > 15.f ? z : log1pf(expf(z));          // log1p(e^z) = z to fp32 beyond z = 15
+    case 6: return z / (1.f + fabsf(z));
+    case 7: return 1.f / (1.f + expf(-z));
+    case 8: return tanhf(z);
+    case 9: return fmaxf(0.2f * z, z);
+    default: return z;
+  }
+}
+// dy * f'(.) from the output y.  relu / relu6 stay a SELECT (the bits of dy pass unchanged; a product would turn an inf
+// gradient under a dead unit into NaN)
+__device__ __forceinline__ float lmh_act_grad(float dy, float y, int act, float hi) {
+  switch (act) {
+    case 0: return dy;
+    case 1: case 2: return (y > 0.f && y < hi) ? dy : 0.f;
+    case 3: return y > 0.f ? dy : dy * (y + 1.f);
+    case 4: return dy * (y > 0.f ? LMH_SELU_S : y + LMH_SELU_S * LMH_SELU_A);
+    case 5: return dy * -expm1f(-y);
+    case 6: { const float t = 1.f - fabsf(y); return dy * (t * t); }
+    case 7: return dy * (y * (1.f - y));
+    case 8: return dy * (1.f - y * y);
+    case 9: return y > 0.f ? dy : 0.2f * dy;
+    default: return dy;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_act_fwd(float* __restrict__ y, int act, int64_t n) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(y + 4 * i);
+    v[0] = lmh_act_apply(v[0], act); v[1] = lmh_act_apply(v[1], act);
+    v[2] = lmh_act_apply(v[2], act); v[3] = lmh_act_apply(v[3], act);
+    *reinterpret_cast<f32x4*>(y + 4 * i) = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    y[i] = lmh_act_apply(y[i], act);
+  }
+}
+
+extern "C" int lmh_act_fwd(float* y, int act, int64_t n, lmh_stream_t stream) {
+  LMH_CHECK_ARG(y && n > 0 && act >= 0 && act <= LMH_ACT_MAX);
+  LMH_CHECK_ARG((((uintptr_t)y) & 15) == 0);
+  if (act == 0) return LMH_OK;
+  const int64_t n4 = (n + 3) >> 2;
+  const int nb = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  lmh_launch(k_act_fwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, y, act, n);
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
 // ============================================================================
 // elementwise helpers
 // ============================================================================
@@ -36,10 +110,10 @@ k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act, in
           float4 d4 = *reinterpret_cast<const float4*>(dy + o);
           if (act) {
             const float4 y4 = *reinterpret_cast<const float4*>(y + o);
-            d4.x = (y4.x > 0.f && y4.x < hi) ? d4.x : 0.f;
-            d4.y = (y4.y > 0.f && y4.y < hi) ? d4.y : 0.f;
-            d4.z = (y4.z > 0.f && y4.z < hi) ? d4.z : 0.f;
-            d4.w = (y4.w > 0.f && y4.w < hi) ? d4.w : 0.f;
+            d4.x = lmh_act_grad(d4.x, y4.x, act, hi);
+            d4.y = lmh_act_grad(d4.y, y4.y, act, hi);
+            d4.z = lmh_act_grad(d4.z, y4.z, act, hi);
+            d4.w = lmh_act_grad(d4.w, y4.w, act, hi);
           }
           if (g) *reinterpret_cast<float4*>(g + o) = d4;
           s.x += d4.x; s.y += d4.y; s.z += d4.z; s.w += d4.w;
@@ -61,7 +135,7 @@ k_act_bwd(const float* __restrict__ dy, const float* __restrict__ y, int act, in
       for (int64_t r = r0; r < r1; ++r) {
         const size_t o = (size_t)r * K + c;
         float d = dy[o];
-        if (act) { const float yv = y[o]; d = (yv > 0.f && yv < hi) ? d : 0.f; }
+        if (act) d = lmh_act_grad(d, y[o], act, hi);
         if (g) g[o] = d;
         sacc += d;
       }
@@ -107,7 +181,7 @@ extern "C" size_t lmh_act_bwd_workspace_bytes(int64_t rows, int K) {
 extern "C" int lmh_act_bwd(const float* dy, const float* y, int act, int64_t rows, int K, float* g,
                            float* colsum, void* ws, size_t ws_bytes, lmh_stream_t stream) {
   LMH_CHECK_ARG(dy && rows > 0 && K > 0 && K <= ACT_MAX_K);
-  LMH_CHECK_ARG(act == 0 || y != nullptr);
+  LMH_CHECK_ARG(act >= 0 && act <= LMH_ACT_MAX && (act == 0 || y != nullptr));
   LMH_CHECK_ARG(g || colsum);
   int rpb;
   const int nb = act_bwd_blocks(rows, K, &rpb);

@@ -14,7 +14,11 @@ import torch
 from . import _lib
 from ._lib import (ConvDesc, RpnProposalDesc, RpnTargetDesc, RcnnTargetDesc, RcnnProposalDesc, SsdTargetDesc, check)
 
-ACT = {None: 0, 'none': 0, 'relu': 1, 'relu6': 2}
+ACT = {None: 0, 'none': 0, 'relu': 1, 'relu6': 2,
+       # not fused into a convolution epilogue: applied in place behind it (act_fwd_) and differentiated from the output
+       # (act_bwd); include/luminoth_hip.h lmh_act_fwd, luminoth/utils/vars.py:80-88
+       'elu': 3, 'selu': 4, 'softplus': 5, 'softsign': 6, 'sigmoid': 7, 'tanh': 8, 'leaky_relu': 9}
+FUSED_ACTS = (None, 'none', 'relu', 'relu6')      # what a convolution descriptor (and an activation bit mask) can carry
 
 
 # While a launch plan is being recorded (luminoth_amd/plan.py) every tensor whose address enters a launch is appended
@@ -476,7 +480,7 @@ def get_option(name):
 
 def act_bits_ok(channels, act):
     """A layer output can carry an activation bit mask (one bit per element, 32 channels per word)."""
-    return bool(act) and channels % 32 == 0
+    return bool(act) and act in FUSED_ACTS and channels % 32 == 0
 
 
 def new_act_bits(rows, channels, device):
@@ -659,6 +663,13 @@ def conv2d_bwd_weight(d, x, dy, out=None, yact=None, colsum=None, defer=None):
         if defer is not None:
             lib.lmh_tail_defer(0)
     return dw
+
+
+def act_fwd_(y, act):
+    """y <- act(y) in place for the activations no convolution epilogue fuses (ACT codes 3..9); relu / relu6 work too."""
+    assert y.dtype == torch.float32
+    check(_lib.load().lmh_act_fwd(_p(y), ACT[act], y.numel(), _stream()), 'lmh_act_fwd')
+    return y
 
 
 def act_bwd(dy, y, act, want_g=True, colsum=None, defer=None):

@@ -142,16 +142,25 @@ class ConvLayer(object):
         d = self._desc.get(key)
         if d is None:
             d = K.conv_desc(x_shape, (self.k, self.k, self.cin, self.cout), self.stride, self.rate,
-                            self.padding, self.act, compute)
+                            self.padding, self._desc_act(), compute)
             if d.compute == 3 and K.X3_WINOGRAD_MODE == '1':
                 # bf16x3 is fp32 arithmetic: layers the Winograd F(2x2,3x3) path takes may run it natively (fp32 GEMMs on
                 # 2.25x fewer FLOPs) instead of with bf16x3 GEMMs (mode '3', the default) — DESIGN.md §3.4
                 d0 = K.conv_desc(x_shape, (self.k, self.k, self.cin, self.cout), self.stride, self.rate,
-                                 self.padding, self.act, None)
+                                 self.padding, self._desc_act(), None)
                 if K._use_winograd(d0):
                     d = d0
             self._desc[key] = d
         return d
+
+    def _generic_act(self):
+        """An activation the convolution epilogues do not fuse (tf.nn.elu, selu, softplus, softsign, sigmoid, tanh,
+        leaky_relu: luminoth/utils/vars.py:80-88): the descriptor then says 'none', the activation is applied in place
+        behind the convolution and the backward takes g = dy * act'(y) from the output in one pass (no bit mask)."""
+        return self.act if self.act not in K.FUSED_ACTS else None
+
+    def _desc_act(self):
+        return self.act if self.act in K.FUSED_ACTS else None
 
     def forward(self, x, residual=None, in_sub=None, want_bits=False, keep_v=False, out=None):
         """want_bits: also return the activation bit mask of y (None when the layer has no activation or a channel
@@ -173,6 +182,8 @@ class ConvLayer(object):
             x = xh
         if x.dtype != torch.float32:            # half-storage layer
             assert self.storage is not None and in_sub is None, (self.scope, x.dtype)
+            if self._generic_act():
+                raise NotImplementedError('%s: activation %r with 16-bit storage (relu / relu6 only)' % (self.scope, self.act))
             if not self._wh_ready:
                 prepare_half_weights([self], self.storage)
             y = K.conv2d_fwd_hs(d, x, self.wh[0], self.scale, self.shift, residual, out_f32=self.hs_out_f32, act_bits=bits,
@@ -186,6 +197,8 @@ class ConvLayer(object):
         y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub, out=out, act_bits=bits,
                          keep_v=(want_bits or keep_v) and self.trainable,
                          wino_u=self._wino_u[0] if self._wino_ready[0] else None)
+        if self._generic_act():
+            K.act_fwd_(y, self.act)
         if ACT_TAP is not None:
             ACT_TAP[self.scope] = y
         return (y, bits) if want_bits else y
@@ -206,7 +219,9 @@ class ConvLayer(object):
         d0 = self._desc_raw(x.shape)
         z = K.conv2d_fwd(d0, x, self.w, None, None, None, in_sub, keep_v=(want_bits or keep_v) and self.trainable)
         gamma, beta, mm, mv = self.bn_vars
-        y, mean, rstd = K.bn_train_fwd(z, gamma, beta, mm, mv, residual, self.act, eps=BN_EPS, decay=BN_DECAY)
+        y, mean, rstd = K.bn_train_fwd(z, gamma, beta, mm, mv, residual, self._desc_act(), eps=BN_EPS, decay=BN_DECAY)
+        if self._generic_act():
+            K.act_fwd_(y, self.act)
         if out is not None:
             y = K.copy_(out, y)
         self.bn_table.stats_moved = True        # the folded scale / shift of the inference path are stale now
@@ -312,7 +327,7 @@ class ConvLayer(object):
             g = dy
             if colsum is not None and not colsum_in_wgrad:
                 K.act_bwd(dy, None, None, want_g=False, colsum=colsum, defer=dkey)
-        elif self.act and act_fused and not want_g:
+        elif self.act and act_fused and not want_g and not self._generic_act():
             g, yact = dy, y                               # fused: kernels mask on load
         else:
             g = K.act_bwd(dy, y, self.act, want_g=True, colsum=None if colsum_in_wgrad else colsum, defer=dkey)

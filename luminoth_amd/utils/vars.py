@@ -61,12 +61,18 @@ def get_initializer(cfg, seed=None):
     return init
 
 
-VALID_ACTIVATIONS = {'relu': 'relu', 'relu6': 'relu6', None: None, '': None, 'none': None}
+# tf.nn.<name> -> the activation id of luminoth_amd.kernels.ACT.  relu / relu6 ride in the convolution epilogues; the
+# others run as an in-place pass behind the convolution (csrc/elementwise.hip: lmh_act_fwd / lmh_act_bwd).  What tf.nn
+# holds that is NOT here either is not an activation (conv2d, dropout, ...), changes the channel count (crelu) or needs
+# the pre-activation for its gradient (swish, TF >= 1.7).
+VALID_ACTIVATIONS = {'relu': 'relu', 'relu6': 'relu6', 'elu': 'elu', 'selu': 'selu', 'softplus': 'softplus',
+                     'softsign': 'softsign', 'sigmoid': 'sigmoid', 'tanh': 'tanh', 'leaky_relu': 'leaky_relu',
+                     None: None, '': None, 'none': None}
 
 
 def get_activation_function(name):
-    """vars.py:80-88: unknown names raise ValueError.  Returns the epilogue id
-    string understood by the conv kernel ('relu' | 'relu6' | None)."""
+    """vars.py:80-88: `getattr(tf.nn, name)`, unknown names raise ValueError; a false value is the identity.  Returns the
+    activation id string the layers understand."""
     if name not in VALID_ACTIVATIONS and not (isinstance(name, str) and name.lower() in VALID_ACTIVATIONS):
         raise ValueError('Invalid activation function "{}"'.format(name))
     return VALID_ACTIVATIONS.get(name, VALID_ACTIVATIONS.get(str(name).lower()))

@@ -39,6 +39,24 @@ def _act(x, name):
         return torch.relu(x)
     if name == 'relu6':
         return torch.clamp(x, 0, 6)
+    # the other activations of tf.nn that luminoth/utils/vars.py:80-88 hands through (getattr(tf.nn, name)); TF 1.x
+    # definitions: nn_ops.py / nn_impl.py (leaky_relu: alpha 0.2; selu: scale 1.0507009873554805, alpha 1.6732632423543772)
+    if name == 'elu':
+        return torch.nn.functional.elu(x)
+    if name == 'selu':
+        return torch.nn.functional.selu(x)
+    if name == 'softplus':
+        return torch.nn.functional.softplus(x)
+    if name == 'softsign':
+        return torch.nn.functional.softsign(x)
+    if name == 'sigmoid':
+        return torch.sigmoid(x)
+    if name == 'tanh':
+        return torch.tanh(x)
+    if name == 'leaky_relu':
+        return torch.nn.functional.leaky_relu(x, 0.2)
+    if name:
+        raise ValueError('Invalid activation function "{}"'.format(name))
     return x
 
 
@@ -78,7 +96,7 @@ class OracleFasterRCNN(object):
     def _activate(self, z, act, scope):
         """Activation of layer `scope`; with `self.masks` the branch is the one the kernels took."""
         yk = None if self.masks is None else self.masks.get(scope)
-        if yk is None or not act:
+        if yk is None or act not in ('relu', 'relu6'):      # smooth / leaky activations: no branch to pin
             return _act(z, act)
         yk = torch.as_tensor(yk).reshape(z.shape)
         if act == 'relu':
@@ -241,7 +259,7 @@ class OracleFasterRCNN(object):
     def rpn_head(self, feat):
         v, p = self.v, self.scope + '/rpn'
         f = self._activate(ot.conv2d_nhwc(feat, v[p + '/conv/w'], padding='SAME', bias=v[p + '/conv/b'],
-                                          quant=self.compute), 'relu6',
+                                          quant=self.compute), self.rpn_cfg.get('activation_function', 'relu6'),
                            p + '/conv')
         cls = ot.conv2d_nhwc(f, v[p + '/cls_conv/w'], padding='VALID', bias=v[p + '/cls_conv/b'])
         box = ot.conv2d_nhwc(f, v[p + '/bbox_conv/w'], padding='VALID', bias=v[p + '/bbox_conv/b'])

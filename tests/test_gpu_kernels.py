@@ -1096,3 +1096,37 @@ def test_deferred_weight_gradient_tails_equal_immediate_path(K, shape, monkeypat
     for i, name in enumerate(('dw (BN-scaled)', 'dbeta', 'dgamma', 'dw2', 'dbias2')):
         sc = max(1.0, float(np.abs(a[i]).max()))
         np.testing.assert_allclose(b[i], a[i], rtol=1e-5, atol=1e-5 * sc, err_msg=name)
+
+
+@pytest.mark.parametrize('act', ['elu', 'selu', 'softplus', 'softsign', 'sigmoid', 'tanh', 'leaky_relu', 'relu', 'relu6'])
+def test_activation_pass_matches_torch(K, act):
+    """lmh_act_fwd (in place) / lmh_act_bwd for every activation id: values and the derivative-from-the-output against
+    torch in float64 (TF 1.x definitions: leaky_relu alpha 0.2, selu's two constants), 2e-6 of the scale; ragged sizes,
+    the per-channel sums of g included."""
+    import torch.nn.functional as TF
+    f = {'elu': TF.elu, 'selu': TF.selu, 'softplus': TF.softplus, 'softsign': TF.softsign, 'sigmoid': torch.sigmoid,
+         'tanh': torch.tanh, 'leaky_relu': lambda t: TF.leaky_relu(t, 0.2), 'relu': torch.relu,
+         'relu6': lambda t: torch.clamp(t, 0, 6)}[act]
+    rs = np.random.RandomState(3)
+    for rows, C in ((257, 36), (64, 128), (5, 3)):
+        z = (rs.randn(rows, C) * 4).astype(F)
+        z[0, :3] = (-30.0, 30.0, 0.0)
+        zt = torch.tensor(z, dtype=torch.float64, requires_grad=True)
+        ref = f(zt)
+        dy = rs.randn(rows, C).astype(F)
+        ref.backward(torch.tensor(dy, dtype=torch.float64))
+        y = K.act_fwd_(T(z.copy()), act)
+        np.testing.assert_allclose(y.cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-6)
+        cs = torch.zeros(C, device=y.device)
+        g = K.act_bwd(T(dy), y, act, want_g=True, colsum=cs)
+        gref = zt.grad.numpy()
+        if act in ('relu', 'relu6', 'leaky_relu', 'elu', 'selu'):       # kinks: compare away from them
+            ok = np.abs(z) > 1e-3
+            if act == 'relu6':
+                ok &= np.abs(z - 6) > 1e-3
+        else:
+            ok = np.ones_like(z, bool)
+        np.testing.assert_allclose(g.cpu().numpy()[ok], gref[ok], rtol=2e-5, atol=2e-6)
+        if ok.all():
+            np.testing.assert_allclose(cs.cpu().numpy(), gref.sum(0), rtol=1e-4, atol=1e-4)
+

@@ -535,6 +535,21 @@ def test_non_default_config_surface_trains(monkeypatch):
     assert model._rcnn._dropout_calls == 4                               # after pooling + after fc_0, two steps
 
 
+@pytest.mark.parametrize('fused', [False, True], ids=['module_api', 'train_step'])
+@pytest.mark.parametrize('act', ['elu', 'selu', 'softplus', 'softsign', 'sigmoid', 'tanh', 'leaky_relu', 'relu'])
+def test_rpn_activation_function_of_tf_nn(act, fused):
+    """`model.rpn.activation_function` is any tf.nn.<name> in the reference (luminoth/utils/vars.py:80-88 -> rpn.py:57-59;
+    the default is relu6).  The activations no convolution epilogue fuses run as an in-place pass behind the RPN
+    convolution and are differentiated from their output (csrc/elementwise.hip): whole step against the oracle under the
+    fp32 bounds, through both paths."""
+    from luminoth_amd.models import get_model
+    cfg = make_config(**{'model.rpn.activation_function': act})
+    model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_50')
+    assert model._rpn._rpn.act == act
+    images, gts = synth(2, 256, 320, 3, 80, 5)
+    compare_step_with_oracle(model, images, gts, 80, fused=fused, oracle_kwargs={'rpn': {'activation_function': act}})
+
+
 def test_bench_two_ranks_on_one_gpu_over_gloo():
     """`bench.py --gpus 2` end to end on THIS box every round — the self-spawn through
     torch.distributed.run, rank-sharded synthetic inputs and seeds, the bucketed gradient exchange under the trunk

@@ -64,6 +64,7 @@ def test_initializers_and_activations():
     assert float(t.abs().max()) < 1.0 and int((t.abs() == 1.0).sum()) == 0
     assert abs(float(t.std()) / 0.5 - 0.8796) < 5e-3
     assert get_activation_function('relu6') == 'relu6' and get_activation_function(None) is None
+    assert get_activation_function('elu') == 'elu' and get_activation_function('leaky_relu') == 'leaky_relu'      # any tf.nn activation
     with pytest.raises(ValueError):
         get_activation_function('swish')
 
