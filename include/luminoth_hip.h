@@ -217,12 +217,13 @@ float lmh_event_elapsed_ms(void* e0, void* e1);
 float lmh_event_pair_overhead_ms(int reps, lmh_stream_t stream);
 /* Activations that no convolution epilogue fuses (luminoth/utils/vars.py:80-88 hands any tf.nn.<name> to the RPN
  * convolution and the RCNN fully connected layers, rpn.py:57-59, rcnn.py:73-74): codes 3 elu, 4 selu, 5 softplus,
- * 6 softsign, 7 sigmoid, 8 tanh, 9 leaky_relu (alpha 0.2) besides 0 none, 1 relu, 2 relu6.  lmh_act_fwd applies one in
- * place over n floats (y 16-byte aligned); the convolution descriptors take codes 0..2 only. */
+ * 6 softsign, 7 sigmoid, 8 tanh, 9 leaky_relu (alpha 0.2) besides 0 none, 1 relu, 2 relu6.  lmh_act_fwd: y <- act(z) over
+ * n floats (both 16-byte aligned; y may be z); the convolution descriptors take codes 0..2 only. */
 #define LMH_ACT_MAX 9
-int lmh_act_fwd(float* y, int act, int64_t n, lmh_stream_t stream);
-/* g = dy * act'(y), the derivative expressed in the OUTPUT y (relu / relu6: the select y > 0 [&& y < 6]; codes 3..9: the
- * table in csrc/elementwise.hip) (g may be NULL); colsum[k] = sum_rows g
+int lmh_act_fwd(const float* z, float* y, int act, int64_t n, lmh_stream_t stream);
+/* g = dy * act'(.) with the derivative expressed the way TF's gradient op takes it: in the OUTPUT y for relu / relu6 (the
+ * select y > 0 [&& y < 6]), elu, selu, sigmoid, tanh, leaky_relu — and in the INPUT z for softplus / softsign (5, 6), for
+ * which `y` must be the pre-activation (csrc/elementwise.hip has the table).  g may be NULL; colsum[k] = sum_rows g
  * (may be NULL; written, not accumulated; two-stage deterministic reduction through ws). */
 size_t lmh_act_bwd_workspace_bytes(int64_t rows, int K);
 int lmh_act_bwd(const float* dy, const float* y, int act, int64_t rows, int K,

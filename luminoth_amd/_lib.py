@@ -122,7 +122,7 @@ SIGNATURES = {
     'lmh_event_destroy': (None, [c_f]),
     'lmh_event_elapsed_ms': (ctypes.c_float, [c_f, c_f]),
     'lmh_event_pair_overhead_ms': (ctypes.c_float, [c_i, c_f]),
-    'lmh_act_fwd': (c_i, [c_f, c_i, c_i64, c_f]),
+    'lmh_act_fwd': (c_i, [c_f, c_f, c_i, c_i64, c_f]),
     'lmh_act_bwd_workspace_bytes': (c_sz, [c_i64, c_i]),
     'lmh_act_bwd': (c_i, [c_f, c_f, c_i, c_i64, c_i, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_bn_param_grads_workspace_bytes': (c_sz, [c_i64, c_i]),

@@ -8,12 +8,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: loa
 // Activations beyond the two the convolution epilogues fuse (1 relu, 2 relu6).  The reference takes ANY tf.nn.<name> as
 // `activation_function` of the RPN convolution and the RCNN fully connected layers (luminoth/utils/vars.py:80-88,
 // rpn.py:57-59, rcnn.py:73-74); these are the smooth / leaky ones of tf.nn in TF 1.x, applied in place behind the
-// convolution (lmh_act_fwd) and differentiated FROM THE OUTPUT y, like TF's own EluGrad / SeluGrad / SigmoidGrad /
-// TanhGrad (SoftplusGrad / SoftsignGrad take the input there; the expressions in y below are the same functions):
+// convolution (lmh_act_fwd) and differentiated like TF's own gradient ops: EluGrad / SeluGrad / SigmoidGrad / TanhGrad from
+// the OUTPUT y, SoftplusGrad / SoftsignGrad from the INPUT z (in a saturated softsign 1 - |y| cancels: expressed in y its
+// derivative loses three digits at |z| ~ 1e3, which an RPN convolution on an unnormalised feature map reaches) — so
+// lmh_act_fwd writes those two next to their input instead of over it and lmh_act_bwd takes z as its second operand:
 //   3 elu        z > 0 ? z : e^z - 1                         f' = y > 0 ? 1 : y + 1
 //   4 selu       s * (z > 0 ? z : a (e^z - 1))               f' = y > 0 ? s : y + s a        (s 1.0507009873554805, a 1.6732632423543772)
-//   5 softplus   log(1 + e^z)                                f' = 1 - e^-y
-//   6 softsign   z / (1 + |z|)                               f' = (1 - |y|)^2
+//   5 softplus   log(1 + e^z)                                f' = 1 / (1 + e^-z)            (from z)
+//   6 softsign   z / (1 + |z|)                               f' = 1 / (1 + |z|)^2           (from z)
 //   7 sigmoid    1 / (1 + e^-z)                              f' = y (1 - y)
 //   8 tanh                                                   f' = 1 - y^2
 //   9 leaky_relu max(0.2 z, z)   (tf.nn.leaky_relu default)  f' = y > 0 ? 1 : 0.2
@@ -34,7 +36,8 @@ __device__ __forceinline__ float lmh_act_apply(float z, int act) {
     default: return z;
   }
 }
-// dy * f'(.) from the output y.  relu / relu6 stay a SELECT (the bits of dy pass unchanged; a product would turn an inf
+// dy * f'(.): `y` is the layer OUTPUT, except for softplus / softsign (5, 6) where it is the pre-activation z.
+// relu / relu6 stay a SELECT (the bits of dy pass unchanged; a product would turn an inf
 // gradient under a dead unit into NaN)
 __device__ __forceinline__ float lmh_act_grad(float dy, float y, int act, float hi) {
   switch (act) {
@@ -42,8 +45,8 @@ __device__ __forceinline__ float lmh_act_grad(float dy, float y, int act, float 
     case 1: case 2: return (y > 0.f && y < hi) ? dy : 0.f;
     case 3: return y > 0.f ? dy : dy * (y + 1.f);
     case 4: return dy * (y > 0.f ? LMH_SELU_S : y + LMH_SELU_S * LMH_SELU_A);
-    case 5: return dy * -expm1f(-y);
-    case 6: { const float t = 1.f - fabsf(y); return dy * (t * t); }
+    case 5: return dy / (1.f + expf(-y));
+    case 6: { const float t = 1.f + fabsf(y); return dy / (t * t); }
     case 7: return dy * (y * (1.f - y));
     case 8: return dy * (1.f - y * y);
     case 9: return y > 0.f ? dy : 0.2f * dy;
@@ -52,35 +55,32 @@ __device__ __forceinline__ float lmh_act_grad(float dy, float y, int act, float 
 }
 
 __global__ void __launch_bounds__(256)
-k_act_fwd(float* __restrict__ y, int act, int64_t n) {
+k_act_fwd(const float* __restrict__ z, float* __restrict__ y, int act, int64_t n) {
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(y + 4 * i);
+    f32x4 v = *reinterpret_cast<const f32x4*>(z + 4 * i);
     v[0] = lmh_act_apply(v[0], act); v[1] = lmh_act_apply(v[1], act);
     v[2] = lmh_act_apply(v[2], act); v[3] = lmh_act_apply(v[3], act);
     *reinterpret_cast<f32x4*>(y + 4 * i) = v;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
-    y[i] = lmh_act_apply(y[i], act);
+    y[i] = lmh_act_apply(z[i], act);
   }
 }
 
-extern "C" int lmh_act_fwd(float* y, int act, int64_t n, lmh_stream_t stream) {
-  LMH_CHECK_ARG(y && n > 0 && act >= 0 && act <= LMH_ACT_MAX);
-  LMH_CHECK_ARG((((uintptr_t)y) & 15) == 0);
-  if (act == 0) return LMH_OK;
+extern "C" int lmh_act_fwd(const float* z, float* y, int act, int64_t n, lmh_stream_t stream) {
+  LMH_CHECK_ARG(z && y && n > 0 && act >= 0 && act <= LMH_ACT_MAX);
+  LMH_CHECK_ARG(((((uintptr_t)z) | ((uintptr_t)y)) & 15) == 0);
+  if (act == 0 && z == y) return LMH_OK;
   const int64_t n4 = (n + 3) >> 2;
   const int nb = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-  lmh_launch(k_act_fwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, y, act, n);
+  lmh_launch(k_act_fwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, z, y, act, n);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
 
-// ============================================================================
-// elementwise helpers
-// ============================================================================
 // ---------------------------------------------------------------------------
 // g = dy * act'(y) and per-channel column sums (dbeta / dbias), two stages,
 // deterministic: every block reduces its row slab into LDS and writes ONE

@@ -665,16 +665,21 @@ def conv2d_bwd_weight(d, x, dy, out=None, yact=None, colsum=None, defer=None):
     return dw
 
 
-def act_fwd_(y, act):
-    """y <- act(y) in place for the activations no convolution epilogue fuses (ACT codes 3..9); relu / relu6 work too."""
-    assert y.dtype == torch.float32
-    check(_lib.load().lmh_act_fwd(_p(y), ACT[act], y.numel(), _stream()), 'lmh_act_fwd')
+ACT_GRAD_FROM_INPUT = ('softplus', 'softsign')   # act_bwd takes the PRE-activation for these (TF's SoftplusGrad / SoftsignGrad)
+
+
+def act_fwd(z, act, out=None):
+    """act(z) for any activation id of ACT (the ones no convolution epilogue fuses: codes 3..9); out=z works in place."""
+    assert z.dtype == torch.float32
+    y = torch.empty_like(z) if out is None else out
+    check(_lib.load().lmh_act_fwd(_p(z), _p(y), ACT[act], z.numel(), _stream()), 'lmh_act_fwd')
     return y
 
 
 def act_bwd(dy, y, act, want_g=True, colsum=None, defer=None):
     """g = dy * act'(y); colsum (K,) is WRITTEN with the per-channel sums of g (with `defer` + TAILS.active: its
-    last stage is queued; the partial rows wait in a per-layer workspace)."""
+    last stage is queued; the partial rows wait in a per-layer workspace).  For the activations of ACT_GRAD_FROM_INPUT `y`
+    is the pre-activation."""
     lib = _lib.load()
     K = dy.shape[-1]
     rows = dy.numel() // K

@@ -198,10 +198,29 @@ class ConvLayer(object):
                          keep_v=(want_bits or keep_v) and self.trainable,
                          wino_u=self._wino_u[0] if self._wino_ready[0] else None)
         if self._generic_act():
-            K.act_fwd_(y, self.act)
+            y = self._apply_generic_act(y, out)
         if ACT_TAP is not None:
             ACT_TAP[self.scope] = y
         return (y, bits) if want_bits else y
+
+    def _apply_generic_act(self, z, out=None):
+        """In place, except where the backward needs the pre-activation (softplus, softsign: kept on the result)."""
+        if self.act in K.ACT_GRAD_FROM_INPUT:
+            if out is not None and z.data_ptr() == out.data_ptr():
+                z = z.clone()
+            y = K.act_fwd(z, self.act, out=out)
+            y._lmh_z = z
+            return y
+        return K.act_fwd(z, self.act, out=z)
+
+    def _act_operand(self, y):
+        """What K.act_bwd differentiates in: the output, or the kept pre-activation (softplus / softsign)."""
+        if self.act in K.ACT_GRAD_FROM_INPUT:
+            z = getattr(y, '_lmh_z', None)
+            if z is None:
+                raise RuntimeError('%s: backward of %s needs the tensor its forward returned' % (self.scope, self.act))
+            return z
+        return y
 
     # ---- BatchNorm in training mode (train_batch_norm: True; csrc/bnorm.hip) -------------------------------------------
     def _desc_raw(self, x_shape):
@@ -219,9 +238,9 @@ class ConvLayer(object):
         d0 = self._desc_raw(x.shape)
         z = K.conv2d_fwd(d0, x, self.w, None, None, None, in_sub, keep_v=(want_bits or keep_v) and self.trainable)
         gamma, beta, mm, mv = self.bn_vars
-        y, mean, rstd = K.bn_train_fwd(z, gamma, beta, mm, mv, residual, self._desc_act(), eps=BN_EPS, decay=BN_DECAY)
-        if self._generic_act():
-            K.act_fwd_(y, self.act)
+        if self._generic_act():       # (slim's BatchNorm layers are the backbone's: always relu)
+            raise NotImplementedError('%s: train_batch_norm with activation %r' % (self.scope, self.act))
+        y, mean, rstd = K.bn_train_fwd(z, gamma, beta, mm, mv, residual, self.act, eps=BN_EPS, decay=BN_DECAY)
         if out is not None:
             y = K.copy_(out, y)
         self.bn_table.stats_moved = True        # the folded scale / shift of the inference path are stale now
@@ -330,7 +349,7 @@ class ConvLayer(object):
         elif self.act and act_fused and not want_g and not self._generic_act():
             g, yact = dy, y                               # fused: kernels mask on load
         else:
-            g = K.act_bwd(dy, y, self.act, want_g=True, colsum=None if colsum_in_wgrad else colsum, defer=dkey)
+            g = K.act_bwd(dy, self._act_operand(y), self.act, want_g=True, colsum=None if colsum_in_wgrad else colsum, defer=dkey)
         inline = self.trainable and 0 < SideStream.layers_left <= SideStream.inline_layers
         if self.trainable:
             SideStream.layers_left -= 1

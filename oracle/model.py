@@ -34,6 +34,23 @@ MEANS = torch.tensor([123.68, 116.78, 103.94])   # models/base/base_network.py:1
 VGG16_CFG = (('conv1', 2, 64), ('conv2', 2, 128), ('conv3', 3, 256), ('conv4', 3, 512), ('conv5', 3, 512))
 
 
+class _Softsign(torch.autograd.Function):
+    """tf.nn.softsign with TF's SoftsignGrad, dy / (1 + |x|)^2 (softsign_op.h).  torch.nn.functional.softsign is a composite:
+    autograd differentiates x / (1 + |x|) term by term, 1 / (1 + |x|) - |x| / (1 + |x|)^2, which cancels in fp32 for the
+    |x| ~ 1e3 an RPN convolution on an unnormalised feature map reaches (1e-3 relative on the weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return x / (1 + x.abs())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        t = 1 + x.abs()
+        return g / (t * t)
+
+
 def _act(x, name):
     if name == 'relu':
         return torch.relu(x)
@@ -48,7 +65,7 @@ def _act(x, name):
     if name == 'softplus':
         return torch.nn.functional.softplus(x)
     if name == 'softsign':
-        return torch.nn.functional.softsign(x)
+        return _Softsign.apply(x)
     if name == 'sigmoid':
         return torch.sigmoid(x)
     if name == 'tanh':

@@ -1100,7 +1100,7 @@ def test_deferred_weight_gradient_tails_equal_immediate_path(K, shape, monkeypat
 
 @pytest.mark.parametrize('act', ['elu', 'selu', 'softplus', 'softsign', 'sigmoid', 'tanh', 'leaky_relu', 'relu', 'relu6'])
 def test_activation_pass_matches_torch(K, act):
-    """lmh_act_fwd (in place) / lmh_act_bwd for every activation id: values and the derivative-from-the-output against
+    """lmh_act_fwd / lmh_act_bwd for every activation id: values and the derivative (from the output; from the input for softplus / softsign) against
     torch in float64 (TF 1.x definitions: leaky_relu alpha 0.2, selu's two constants), 2e-6 of the scale; ragged sizes,
     the per-channel sums of g included."""
     import torch.nn.functional as TF
@@ -1115,10 +1115,13 @@ def test_activation_pass_matches_torch(K, act):
         ref = f(zt)
         dy = rs.randn(rows, C).astype(F)
         ref.backward(torch.tensor(dy, dtype=torch.float64))
-        y = K.act_fwd_(T(z.copy()), act)
+        zd = T(z.copy())
+        from_input = act in K.ACT_GRAD_FROM_INPUT          # softplus / softsign: a separate output, z kept for the backward
+        y = K.act_fwd(zd, act, out=None if from_input else zd)
+        assert (y.data_ptr() == zd.data_ptr()) == (not from_input)
         np.testing.assert_allclose(y.cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-6)
         cs = torch.zeros(C, device=y.device)
-        g = K.act_bwd(T(dy), y, act, want_g=True, colsum=cs)
+        g = K.act_bwd(T(dy), zd if from_input else y, act, want_g=True, colsum=cs)
         gref = zt.grad.numpy()
         if act in ('relu', 'relu6', 'leaky_relu', 'elu', 'selu'):       # kinks: compare away from them
             ok = np.abs(z) > 1e-3

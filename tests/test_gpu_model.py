@@ -546,6 +546,13 @@ def test_rpn_activation_function_of_tf_nn(act, fused):
     cfg = make_config(**{'model.rpn.activation_function': act})
     model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_50')
     assert model._rpn._rpn.act == act
+    # pre-activations of O(1): on this unnormalised feature map the default initializer gives pre-activations far above 1, where every one of
+    # these functions is saturated or linear (nothing of the activation would be tested), softsign's peaked derivative
+    # turns the 1e-5-of-scale error of the Winograd forward into 1.5e-3 of the weight gradient, and an unbounded activation
+    # (the reference's default relu6 is bounded) feeds box deltas whose exp() cancels in the decoded corners at 1e-4 px
+    sd = model.state_dict()
+    sd['fasterrcnn/rpn/conv/w'].mul_(0.02)
+    model.load_state_dict(sd)
     images, gts = synth(2, 256, 320, 3, 80, 5)
     compare_step_with_oracle(model, images, gts, 80, fused=fused, oracle_kwargs={'rpn': {'activation_function': act}})
 
