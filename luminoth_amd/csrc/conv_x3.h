@@ -129,7 +129,7 @@ struct x3_smem {
       typedef std::integral_constant<int, 0> S0;                                                    \
       load(S0());                                                                                   \
       advance();                                                                                    \
-      x3_stagger(stagger);                                                                          \
+      x3_stagger(stagger & 255);                                                                    \
       for (int kt_ = 0; kt_ < (KT_); ++kt_) {                                                       \
         store_a(0, S0());                                                                           \
         store_b(0, S0());                                                                           \
@@ -233,6 +233,14 @@ k_x3_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__
   const float* pb = b_ok ? w + (size_t)(4 * kq) * K + n0 + 4 * cq : lmh_zero_page;
   const size_t rowb = b_ok ? (size_t)K : 0, incb = b_ok ? (size_t)BK * K : 0;
 
+  // timing decomposition (probe builds only: LMH_PROBES=1 bash build.sh; scripts/r6_x3_decomp.py): bits 8.. of `stagger`
+  // switch parts of the kernel off — 1 split + LDS writes of B, 2 loads of B, 4 split + writes of A, 8 loads of A, 16 the
+  // MFMA phase, 32 the epilogue's residual loads and stores.  Wrong results; what each part costs inside the launch.
+#ifdef LMH_PROBES
+  const int dbg = stagger >> 8;
+#else
+  constexpr int dbg = 0;
+#endif
   f32x4 ra[2][AJ], rb[2][4];
   f32x16 acc[TM][TN], cdummy[TN];
   zero_acc<TM, TN>(acc);
@@ -241,8 +249,8 @@ k_x3_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__
   auto load = [&](auto S) {
     constexpr int s_ = decltype(S)::value;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) ra[s_][j] = *reinterpret_cast<const f32x4*>(pa[j]);
-    if (B_ALL || b_act) {
+    for (int j = 0; j < AJ; ++j) ra[s_][j] = *reinterpret_cast<const f32x4*>((dbg & 8) ? lmh_zero_page : pa[j]);
+    if ((B_ALL || b_act) && !(dbg & 2)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) rb[s_][i] = *reinterpret_cast<const f32x4*>(pb + i * rowb);
     }
@@ -261,12 +269,13 @@ k_x3_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__
   auto store_a = [&](int buf, auto S) {
     constexpr int s_ = decltype(S)::value;
     x3_t* Ad = As + buf * A_BUF;
+    if (!(dbg & 4))
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) st_kc<3>(Ad, A_SZ, arow + 32 * j, kq, ra[s_][j]);
+      for (int j = 0; j < AJ; ++j) st_kc<3>(Ad, A_SZ, arow + 32 * j, kq, ra[s_][j]);
   };
   auto store_b = [&](int buf, auto S) {
     constexpr int s_ = decltype(S)::value;
-    if (B_ALL || b_act) st_km<3>(Bs + buf * B_BUF, B_SZ, 4 * cq, kq, rb[s_]);
+    if ((B_ALL || b_act) && !(dbg & 1)) st_km<3>(Bs + buf * B_BUF, B_SZ, 4 * cq, kq, rb[s_]);
   };
   auto stage = [&](int buf, auto SL, auto SW) {
     x3_stage<TM, TN, false, 5, AJ * 3, 5, 12>(
@@ -274,6 +283,7 @@ k_x3_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__
         [&]() { load(SL); }, [&]() { store_a(buf ^ 1, SW); }, [&]() { store_b(buf ^ 1, SW); });
   };
   auto mma = [&](int buf) {
+    if (dbg & 16) return;
     x3_stage<TM, TN, false, 0, 0, 0, 0>(As + buf * A_BUF, Bs + buf * B_BUF, A_SZ, B_SZ, acc, cdummy, wm * (BM / 2),
                                         wn * (BN / 2), lane, []() {}, []() {}, []() {});
   };
@@ -296,7 +306,7 @@ k_x3_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__
 #pragma unroll
     for (int i = 0; i < NRC; ++i) {
       const int row = m0 + r0 + (ch * NRC + i) * RSTEP;
-      ex[ch][i] = (residual && col_ok && row < M) ? *reinterpret_cast<const f32x4*>(residual + (size_t)row * K + col)
+      ex[ch][i] = (residual && col_ok && row < M && !(dbg & 32)) ? *reinterpret_cast<const f32x4*>(residual + (size_t)row * K + col)
                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
@@ -313,7 +323,7 @@ k_x3_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__
       for (int i = 0; i < NRC; ++i) {
         const int r = r0 + (ch * NRC + i) * RSTEP;
         const int row = m0 + r;
-        if (row < M) {
+        if (row < M && !(dbg & 32)) {
           f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
           v = v * sc + sh;                 // (k_conv_fwd_h's expression: bit-identical results)
           if (residual) v += ex[ch][i];
