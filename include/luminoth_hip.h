@@ -246,6 +246,28 @@ size_t lmh_conv2d_winograd_workspace_bytes(const lmh_conv_desc* d);
 int lmh_conv2d_winograd_transform_weights(const lmh_conv_desc* d, const float* w, const float* kscale,
                                           int backward, float* u, lmh_stream_t stream);
 /* act_bits / xbits: as for lmh_conv2d_fwd / lmh_conv2d_bwd_data (emitted / applied by the output transform). */
+/* bf16x3 with PRE-SPLIT weights (round 6; csrc/conv_x3.h).  The weights of a layer are split once per step into their three
+ * exact bf16 pieces, laid out in the fragment order of v_mfma_f32_32x32x16_bf16, and the convolution loads them straight
+ * from global memory — instead of every row tile of every launch splitting the same slab of the weight matrix again.
+ * lmh_x3_weights_bytes: bytes of one layer's planes (0 when C or K is not a multiple of 32); `backward`: 0 = the forward
+ * arrangement (GEMM-k = (tap, c), columns = output channels), 1 = the backward-data one (GEMM-k = (tap, k), columns = input
+ * channels).  lmh_x3_split_weights_batch: every job in one launch (w: (rs, C, K) fp32 = HWIO with rs = R * S; out: 16-byte
+ * aligned).  lmh_conv2d_fwd_x3w: lmh_conv2d_fwd for compute bf16x3 with `w3` from a forward split of the layer's w;
+ * bit-identical to it (same pieces, same order of products). */
+typedef struct lmh_x3_weight_job {
+  const float* w;
+  void* out;
+  int32_t rs, C, K;
+} lmh_x3_weight_job;
+size_t lmh_x3_weights_bytes(int rs, int c, int k, int backward);
+int lmh_x3_split_weights_batch(const lmh_x3_weight_job* jobs, int n, int backward, lmh_stream_t stream);
+int lmh_conv2d_fwd_x3w_supported(const lmh_conv_desc* d);
+int lmh_conv2d_fwd_x3w(const lmh_conv_desc* d, const float* x, const void* w3, const float* scale,
+                       const float* shift, const float* residual, float* y, uint32_t* act_bits, lmh_stream_t stream);
+/* lmh_conv2d_bwd_data (no `yact`) with `w3` from a BACKWARD split of the layer's w. */
+int lmh_conv2d_bwd_data_x3w_supported(const lmh_conv_desc* d);
+int lmh_conv2d_bwd_data_x3w(const lmh_conv_desc* d, const float* dy, const void* w3, const float* kscale,
+                            const float* addend, const uint32_t* xbits, float* dx, lmh_stream_t stream);
 /* Transformed weights ahead of the convolution calls: every job of a step in ONE launch (`u` of job i:
  * lmh_winograd_u_bytes(C, K) bytes; forward: G g G^T of w (R,S,C,K); backward: of w[2-r][2-s][c][k] * kscale[k], kscale may
  * be NULL).  Pass the result as `u` to lmh_conv2d_fwd_winograd / lmh_conv2d_bwd_data_winograd (same "wino_m"). */

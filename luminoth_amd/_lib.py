@@ -73,6 +73,11 @@ class WinoWeightJob(ctypes.Structure):
                 ('C', ctypes.c_int32), ('K', ctypes.c_int32)]
 
 
+class X3WeightJob(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p), ('rs', ctypes.c_int32), ('C', ctypes.c_int32),
+                ('K', ctypes.c_int32)]
+
+
 class HalfWeightJob(ctypes.Structure):
     _fields_ = [('w', ctypes.c_void_p), ('kscale', ctypes.c_void_p), ('w_fwd', ctypes.c_void_p), ('w_bwd', ctypes.c_void_p),
                 ('RS', ctypes.c_int32), ('C', ctypes.c_int32), ('K', ctypes.c_int32)]
@@ -104,6 +109,12 @@ SIGNATURES = {
     'lmh_conv2d_winograd_v_bytes': (c_sz, [P(ConvDesc)]),
     'lmh_winograd_u_bytes': (c_sz, [c_i, c_i]),
     'lmh_winograd_transform_weights_batch': (c_i, [P(WinoWeightJob), c_i, c_i, c_f]),
+    'lmh_x3_weights_bytes': (c_sz, [c_i, c_i, c_i, c_i]),
+    'lmh_x3_split_weights_batch': (c_i, [P(X3WeightJob), c_i, c_i, c_f]),
+    'lmh_conv2d_fwd_x3w_supported': (c_i, [P(ConvDesc)]),
+    'lmh_conv2d_fwd_x3w': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    'lmh_conv2d_bwd_data_x3w_supported': (c_i, [P(ConvDesc)]),
+    'lmh_conv2d_bwd_data_x3w': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     'lmh_conv2d_fwd_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_data_winograd': (c_i, [P(ConvDesc), c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_sz, c_f]),
     'lmh_conv2d_bwd_weight_winograd_workspace_bytes': (c_sz, [P(ConvDesc)]),

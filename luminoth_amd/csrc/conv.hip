@@ -39,6 +39,7 @@ __device__ __attribute__((aligned(64))) float lmh_zero_page[16];  // zero-initia
 #include "conv_wgrad1x1.h"
 #include "conv_half.h"
 #include "conv_x3_api.h"
+#define X3W_MAX_JOBS 96
 
 // ============================================================================
 // host dispatch
@@ -206,6 +207,50 @@ extern "C" int lmh_conv2d_fwd(const lmh_conv_desc* d, const float* x, const floa
   return LMH_OK;
 }
 
+// ---- bf16x3 with PRE-SPLIT weights (conv_x3.h, round 6): the weight matrix is split once per step into the MFMA fragment
+// order (lmh_x3_split_weights_batch) and the forward kernel loads its B fragments straight from global memory
+extern "C" size_t lmh_x3_weights_bytes(int rs, int c, int k, int backward) {
+  if (rs <= 0 || c <= 0 || k <= 0 || (c % 32) != 0 || (k % 32) != 0) return 0;
+  return lmh_x3_w3_bytes(rs, c, k, backward ? 0 : 1);
+}
+extern "C" int lmh_x3_split_weights_batch(const lmh_x3_weight_job* jobs, int n, int backward, lmh_stream_t stream) {
+  LMH_CHECK_ARG(jobs && n > 0);
+  const float* w[X3W_MAX_JOBS]; void* out[X3W_MAX_JOBS]; int rs[X3W_MAX_JOBS], c[X3W_MAX_JOBS], k[X3W_MAX_JOBS];
+  for (int j0 = 0; j0 < n; j0 += X3W_MAX_JOBS) {
+    const int m = (n - j0) < X3W_MAX_JOBS ? (n - j0) : X3W_MAX_JOBS;
+    for (int j = 0; j < m; ++j) {
+      const lmh_x3_weight_job& q = jobs[j0 + j];
+      LMH_CHECK_ARG(q.w && q.out && q.rs > 0 && q.C > 0 && q.K > 0 && (((uintptr_t)q.out) & 15) == 0);
+      w[j] = q.w; out[j] = q.out; rs[j] = q.rs; c[j] = q.C; k[j] = q.K;
+    }
+    const int rc = lmh_x3_split_launch(w, out, rs, c, k, m, backward ? 0 : 1, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return LMH_OK;
+}
+static bool x3w_fwd_ok(const lmh_conv_desc* d) {
+  return d->compute == 3 && fwd_fast(d) && (d->K % 32) == 0 && !stem_fast(d);
+}
+extern "C" int lmh_conv2d_fwd_x3w_supported(const lmh_conv_desc* d) { return d && check_desc(d) == LMH_OK && x3w_fwd_ok(d) ? 1 : 0; }
+extern "C" int lmh_conv2d_fwd_x3w(const lmh_conv_desc* d, const float* x, const void* w3, const float* scale,
+                                  const float* shift, const float* residual, float* y, uint32_t* act_bits,
+                                  lmh_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  LMH_CHECK_ARG(x && w3 && y && (((uintptr_t)w3) & 15) == 0);
+  LMH_CHECK_ARG(act_bits == nullptr || (d->act != 0 && (d->K & 31) == 0));
+  if (!x3w_fwd_ok(d)) { lmh_set_error("lmh_conv2d_fwd_x3w: needs compute bf16x3, C %% 32 == 0, K %% 32 == 0"); return LMH_ERR_UNSUPPORTED; }
+  g_prof_pending_bytes = desc_bytes(d) + (residual ? 4.0 * d->N * d->OH * d->OW * (double)d->K : 0.0);
+  const int64_t M = (int64_t)d->N * d->OH * d->OW;
+  int bm, bn;
+  if (x3_tile_pick) pick_tile(M, d->K, &bm, &bn, x3_tile_pick); else half_tile(M, d->K, &bm, &bn);
+  hipStream_t st = (hipStream_t)stream;
+  prof_begin(st);
+  rc = lmh_x3_fwd_ws_launch(d, x, w3, scale, shift, residual, y, act_bits, 0, bm, bn, st);
+  prof_end(st, desc_flops(d), "k_x3_fwd_ws<%d, %d, false>", bm, bn);
+  return rc;
+}
+
 static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float* w, const float* scale,
                              const float* shift, const float* residual, const float* in_sub, float* y,
                              uint32_t* act_bits, bool* bits_done, lmh_stream_t stream) {
@@ -347,6 +392,30 @@ static int conv2d_fwd_launch(const lmh_conv_desc* d, const float* x, const float
   (void)rc;
   LMH_CHECK_LAUNCH();
   return LMH_OK;
+}
+
+static bool x3w_bwd_data_ok(const lmh_conv_desc* d) {
+  return d->compute == 3 && bwd_data_fast(d) && (d->C % 32) == 0 && (d->K % 32) == 0;
+}
+extern "C" int lmh_conv2d_bwd_data_x3w_supported(const lmh_conv_desc* d) { return d && check_desc(d) == LMH_OK && x3w_bwd_data_ok(d) ? 1 : 0; }
+// lmh_conv2d_bwd_data for compute bf16x3 with `w3` from a BACKWARD split of the layer's w (lmh_x3_split_weights_batch);
+// kscale / addend / xbits as there; bit-identical
+extern "C" int lmh_conv2d_bwd_data_x3w(const lmh_conv_desc* d, const float* dy, const void* w3, const float* kscale,
+                                       const float* addend, const uint32_t* xbits, float* dx, lmh_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  LMH_CHECK_ARG(dy && w3 && dx && (((uintptr_t)w3) & 15) == 0);
+  LMH_CHECK_ARG(xbits == nullptr || (d->C & 31) == 0);
+  if (!x3w_bwd_data_ok(d)) { lmh_set_error("lmh_conv2d_bwd_data_x3w: needs compute bf16x3, C %% 32 == 0, K %% 32 == 0"); return LMH_ERR_UNSUPPORTED; }
+  g_prof_pending_bytes = desc_bytes(d) + (addend ? 4.0 * d->N * d->H * d->W * (double)d->C : 0.0);
+  const int64_t M = (int64_t)d->N * d->H * d->W;
+  int bm, bn;
+  if (x3_tile_pick) pick_tile(M, d->C, &bm, &bn, x3_tile_pick); else half_tile(M, d->C, &bm, &bn);
+  hipStream_t st = (hipStream_t)stream;
+  prof_begin(st);
+  rc = lmh_x3_bwd_data_ws_launch(d, dy, w3, kscale, addend, xbits, dx, bm, bn, st);
+  prof_end(st, desc_flops(d), "k_x3_bwd_data_ws<%d, %d>", bm, bn);
+  return rc;
 }
 
 static int conv2d_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const float* w, const float* kscale,

@@ -346,6 +346,268 @@ k_x3_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__
 }
 
 // ============================================================================
+// Round 6, second session: PRE-SPLIT WEIGHTS.  The timing decomposition of k_x3_fwd (scripts/r6_x3_decomp.py, probe build)
+// says the phases of a launch add up instead of overlapping — block3 256->1024: 41 us = 7 (empty launch) + 12 (loads + splits)
+// + 16 (MFMA phases) + 11-15 (epilogue) — and that the staging cost is the SPLIT (VALU + LDS writes), not the loads: without the
+// split of B 35.5 us, without B altogether 31.8.  B is the weight matrix: every one of the 64 row tiles of a launch splits the
+// same 32 x 128 slab again, every stage.  Here the weights are split ONCE per step (k_x3_split_w, all layers in one launch) into
+// the MFMA fragment order, and a wave loads its B fragments straight from global memory (L2-resident: a layer's planes are
+// 1.5 MB) into registers one stage ahead: no LDS traffic, no VALU work and no barrier dependency for B at all.
+//   W3 layout: [stage of 32 GEMM-k][plane 0..2][column group of 32][k-step 0..1][lane 0..63] x 16 bytes (8 bf16):
+//   lane = 32 * (k-half) + (column in the group) — exactly what lane holds as the B operand of v_mfma_f32_32x32x16_bf16 — so one
+//   wave instruction is one contiguous 1 KB.  The pieces are those of split3 (same bits as the in-kernel split: the results
+//   of k_x3_fwd_ws are bit-identical to k_x3_fwd's).
+// ============================================================================
+__host__ __device__ __forceinline__ size_t x3_w3_stage(int ncols) { return (size_t)3 * (ncols >> 5) * 2 * 64; }   // uint4 per stage
+
+// FWD: w is [RS * C][K] (HWIO): GEMM-k = (tap, c), columns = output channels.  BWD (backward data): columns = input
+// channels, GEMM-k = (tap, k): element (kk = tap * K + k, n = c) = w[(tap * C + c) * K + k].
+template <bool FWD>
+__device__ __forceinline__ void x3_split_w_body(const float* __restrict__ w, int RS, int C, int K, uint4* __restrict__ out,
+                                                int64_t idx) {
+  const int N = FWD ? K : C, NG = N >> 5;
+  const int T = FWD ? (RS * C) >> 5 : RS * (K >> 5);
+  if (idx >= (int64_t)T * NG * 128) return;
+  const int lane = (int)(idx & 63), s = (int)((idx >> 6) & 1);
+  const int64_t r = idx >> 7;
+  const int ng = (int)(r % NG), t = (int)(r / NG);
+  const int n = 32 * ng + (lane & 31), k0 = 16 * s + 8 * (lane >> 5);
+  uint32_t h[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v;
+    if (FWD) v = w[(size_t)(32 * t + k0 + e) * K + n];
+    else {
+      const int KC = K >> 5, tap = t / KC, kc = t - tap * KC;
+      v = w[((size_t)tap * C + n) * K + 32 * kc + k0 + e];
+    }
+    split3(v, h[0][e], h[1][e], h[2][e]);
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    uint4 o;
+    o.x = pack_hi(h[p][0], h[p][1]); o.y = pack_hi(h[p][2], h[p][3]);
+    o.z = pack_hi(h[p][4], h[p][5]); o.w = pack_hi(h[p][6], h[p][7]);
+    out[(((size_t)(t * 3 + p) * NG + ng) * 2 + s) * 64 + lane] = o;
+  }
+}
+
+#define X3_SPLIT_MAX 96
+struct x3_split_batch {
+  const float* w[X3_SPLIT_MAX];
+  uint4* out[X3_SPLIT_MAX];
+  int32_t RS[X3_SPLIT_MAX], C[X3_SPLIT_MAX], K[X3_SPLIT_MAX];
+  int32_t first_block[X3_SPLIT_MAX + 1];
+  int32_t n, fwd;
+};
+__global__ void __launch_bounds__(256)
+k_x3_split_w(x3_split_batch b) {
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.first_block[j + 1]) ++j;
+  const int64_t idx = (int64_t)((int)blockIdx.x - b.first_block[j]) * 256 + threadIdx.x;
+  if (b.fwd) x3_split_w_body<true>(b.w[j], b.RS[j], b.C[j], b.K[j], b.out[j], idx);
+  else x3_split_w_body<false>(b.w[j], b.RS[j], b.C[j], b.K[j], b.out[j], idx);
+}
+
+// the MFMA phase of one BK = 32 stage with the B fragments in registers (same order of products as x3_stage).  ONE register
+// set for B: the fragments of k-step s are re-loaded for the NEXT stage right behind the MFMAs that read them (a second
+// set cost 48 more VGPRs at 128 x 128 and spilled); a load then has the rest of this stage and the split phase of the next to land.
+template <int TM, int TN, class ReloadF>
+__device__ __forceinline__ void x3_mma_rb(const x3_t* __restrict__ As, int a_pl, f32x16 (&acc)[TM][TN], int a_off, int lane,
+                                          x3_v8 (&b)[2][3][TN], ReloadF&& reload) {
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first (conv_half.h)
+  const int l31 = lane & 31, kh = 8 * (lane >> 5);
+  x3_v8 a[2][3][TM];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+        a[s][p][t] = *reinterpret_cast<const x3_v8*>(&As[p * a_pl + (a_off + t * 32 + l31) * LDH + s * 16 + kh]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<3>::mfma(a[s][PA[q]][tm], b[s][PB[q]][tn], acc[tm][tn]);
+    __builtin_amdgcn_sched_barrier(0);
+    reload(s);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// forward with pre-split weights: k_x3_fwd's gather, split of A, epilogue; B as above.  Needs K % 32 == 0 besides C % 32 == 0.
+template <int BM, int BN, bool GB>
+__global__ void __launch_bounds__(256, 2)
+k_x3_fwd_ws(lmh_conv_desc d, const float* __restrict__ x, const uint4* __restrict__ w3, const float* __restrict__ scale,
+         const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ y, int gbatch,
+         uint32_t* __restrict__ act_bits, int stagger) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32;
+  constexpr int A_SZ = BM * LDH, A_BUF = 3 * A_SZ;
+  constexpr int LDC = BN + 4;
+  __shared__ __attribute__((aligned(16))) float smem[(3 * BM * LDH / 2) > BM * (BN + 4) ? (3 * BM * LDH / 2) : BM * (BN + 4)];   // A planes, then the fp32 epilogue tile
+  x3_t* const As = reinterpret_cast<x3_t*>(smem);       // [3][BM][LDH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = d.N * d.OH * d.OW, K = d.K, C = d.C;
+  const int tiles_n = (K + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n * (GB ? gbatch : 1));
+  if (GB) {
+    const int gi = tile / (tiles_m * tiles_n);
+    tile -= gi * (tiles_m * tiles_n);
+    x += (size_t)gi * M * C;
+    w3 += (size_t)gi * d.R * d.S * (C / BK) * x3_w3_stage(K);
+    y += (size_t)gi * M * K;
+  }
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int CC = C / BK, KT = d.R * d.S * CC;
+  // ---- A gather state (as k_conv_fwd)
+  const int kq = tid & 7, arow = tid >> 3;
+  int a_n[AJ], a_ih0[AJ], a_iw0[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int p = m0 + arow + 32 * j;
+    if (p < M) {
+      const int ow = p % d.OW, t = p / d.OW;
+      a_n[j] = t / d.OH;
+      a_ih0[j] = (t % d.OH) * d.stride - d.pad_top;
+      a_iw0[j] = ow * d.stride - d.pad_left;
+    } else { a_n[j] = -1; a_ih0[j] = 0; a_iw0[j] = 0; }
+  }
+  const float* pa[AJ];
+  int inca[AJ];
+  auto setup_rs = [&](int rs_) {
+    const int r_ = rs_ / d.S, s_ = rs_ - r_ * d.S;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int ih = a_ih0[j] + r_ * d.dilation, iw = a_iw0[j] + s_ * d.dilation;
+      const bool ok = a_n[j] >= 0 && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+      pa[j] = ok ? x + ((size_t)(a_n[j] * d.H + ih) * d.W + iw) * C + 4 * kq : lmh_zero_page;
+      inca[j] = ok ? BK : 0;
+    }
+  };
+  // ---- B: pre-split fragments straight from global memory (x3_w3_*): this wave's TN column groups of 32
+  const int NG = K >> 5;
+  int bgrp[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int g_ = (n0 + wn * (BN / 2)) / 32 + t;
+    bgrp[t] = g_ < NG ? g_ : 0;                        // (columns past K are never stored)
+  }
+  const size_t w3_stage = x3_w3_stage(K);              // uint4 per stage
+  f32x4 ra[1][AJ];
+  x3_v8 bq[2][3][TN];
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  int rs = 0, cc = 0, ptile = 0;
+  setup_rs(0);
+  auto load = [&](auto S) {
+    constexpr int s_ = decltype(S)::value;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) ra[s_][j] = *reinterpret_cast<const f32x4*>(pa[j]);
+  };
+  auto load_b = [&](int s, int t_) {          // k-step s of stage t_ (past the end: the last stage again, never multiplied)
+    const uint4* base = w3 + (size_t)(t_ < KT ? t_ : KT - 1) * w3_stage;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const uint4 v = base[((size_t)(p * NG + bgrp[t]) * 2 + s) * 64 + lane];
+        bq[s][p][t] = __builtin_bit_cast(x3_v8, v);
+      }
+  };
+  auto advance = [&]() {       // (the tile count is even — host check — so a tile past the last one is never multiplied)
+    if (ptile + 1 < KT) {
+      ++ptile;
+      if (++cc == CC) { cc = 0; ++rs; setup_rs(rs); }
+      else {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) pa[j] += inca[j];
+      }
+    }
+  };
+  auto store_a = [&](int buf, auto S) {
+    constexpr int s_ = decltype(S)::value;
+    x3_t* Ad = As + buf * A_BUF;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) st_kc<3>(Ad, A_SZ, arow + 32 * j, kq, ra[s_][j]);
+  };
+  typedef std::integral_constant<int, 0> S0;
+  load(S0());                        // A tile 0 -> registers
+  advance();
+  load_b(0, 0);
+  load_b(1, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    store_a(0, S0());
+    load(S0());                      // A tile kt + 1 (past the end: a valid tile that is never multiplied)
+    advance();
+    __syncthreads();
+    x3_mma_rb<TM, TN>(As, A_SZ, acc, wm * (BM / 2), lane, bq, [&](int s) { load_b(s, kt + 1); });
+    __syncthreads();
+  }
+
+  // ---- epilogue through LDS (fp32): k_conv_fwd's — every load in front of the first store
+  constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  constexpr int NR = BM / RSTEP, NRC = NR < 8 ? NR : 8, NCH = NR / NRC;
+  const int c4 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 4 * c4;
+  const bool col_ok = col < K;
+  f32x4 ex[NCH][NRC];
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (col_ok) {
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + col);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + col);
+  }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int i = 0; i < NRC; ++i) {
+      const int row = m0 + r0 + (ch * NRC + i) * RSTEP;
+      ex[ch][i] = (residual && col_ok && row < M) ? *reinterpret_cast<const f32x4*>(residual + (size_t)row * K + col)
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int i = 0; i < NRC; ++i) asm volatile("" ::"v"(ex[ch][i]));
+  if (col_ok) {
+    const float act_lo = d.act ? 0.f : -INFINITY, act_hi = (d.act == 2) ? 6.f : INFINITY;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+      for (int i = 0; i < NRC; ++i) {
+        const int r = r0 + (ch * NRC + i) * RSTEP;
+        const int row = m0 + r;
+        if (row < M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]);
+          v = v * sc + sh;                 // (k_conv_fwd_h's expression: bit-identical results)
+          if (residual) v += ex[ch][i];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
+          *reinterpret_cast<f32x4*>(y + (size_t)row * K + col) = v;
+          if (act_bits) {      // 8 adjacent lanes hold the 32 channels of one mask word (same row: all active together)
+            unsigned nib = ((v.x > 0.f && v.x < act_hi) ? 1u : 0u) | ((v.y > 0.f && v.y < act_hi) ? 2u : 0u) |
+                           ((v.z > 0.f && v.z < act_hi) ? 4u : 0u) | ((v.w > 0.f && v.w < act_hi) ? 8u : 0u);
+            nib <<= 4 * (c4 & 7);
+            nib |= __shfl_xor(nib, 1);
+            nib |= __shfl_xor(nib, 2);
+            nib |= __shfl_xor(nib, 4);
+            if ((c4 & 7) == 0) act_bits[(size_t)row * (K >> 5) + (col >> 5)] = nib;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ============================================================================
 // backward data:  dx[p,c] = sum_{r,s,k} dy[opix(p,r,s),k] * kscale[k] * w[r,s,c,k]  (+ addend) (x mask of x)
 //   needs K % 32 == 0, C % 4 == 0.  A: dy gather (K-contiguous).  B: w[rs][c][k] rows (K-contiguous).
 // ============================================================================
@@ -467,6 +729,174 @@ k_x3_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __rest
                                         wn * (BN / 2), lane, []() {}, []() {}, []() {});
   };
   X3_RUN(KT);
+
+  // epilogue (k_conv_bwd_data's): addend rows and mask words requested before the accumulator transpose
+  constexpr int CT = BN / 4, RSTEP = 256 / CT;
+  constexpr int NR = BM / RSTEP, NRC = NR < 8 ? NR : 8, NCH = NR / NRC;
+  const int c4 = tid % CT, r0 = tid / CT;
+  const int col = n0 + 4 * c4;
+  const bool col_ok = col < C;
+  f32x4 ex[NCH][NRC];
+  uint32_t xw[NCH][NRC];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int i = 0; i < NRC; ++i) {
+      const int row = m0 + r0 + (ch * NRC + i) * RSTEP;
+      const bool ok = col_ok && row < M;
+      ex[ch][i] = (addend && ok) ? *reinterpret_cast<const f32x4*>(addend + (size_t)row * C + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xw[ch][i] = (xbits && ok) ? xbits[(size_t)row * (C >> 5) + (col >> 5)] : 0u;
+    }
+  acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
+  __syncthreads();
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int i = 0; i < NRC; ++i) asm volatile("" ::"v"(ex[ch][i]), "v"(xw[ch][i]));
+  if (col_ok) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+      for (int i = 0; i < NRC; ++i) {
+        const int r = r0 + (ch * NRC + i) * RSTEP;
+        const int row = m0 + r;
+        if (row < M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 4 * c4]) * 1.f;
+          if (addend) v += ex[ch][i];
+          if (xbits) {
+            const unsigned nib = xw[ch][i] >> (4 * (c4 & 7));
+            v.x = (nib & 1u) ? v.x : 0.f;
+            v.y = (nib & 2u) ? v.y : 0.f;
+            v.z = (nib & 4u) ? v.z : 0.f;
+            v.w = (nib & 8u) ? v.w : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(dx + (size_t)row * C + col) = v;
+        }
+      }
+    }
+  }
+}
+
+// backward data with pre-split weights (backward arrangement: columns = input channels): k_x3_bwd_data's gather, kscale
+// product and split of dy, epilogue; B fragments as in k_x3_fwd_ws.  Needs C % 32 == 0 besides K % 32 == 0.  Bit-identical.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, 2)
+k_x3_bwd_data_ws(lmh_conv_desc d, const float* __restrict__ dy, const uint4* __restrict__ w3,
+              const float* __restrict__ kscale, const float* __restrict__ addend, const uint32_t* __restrict__ xbits,
+              float* __restrict__ dx, int stagger) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AJ = BM / 32;
+  constexpr int A_SZ = BM * LDH, A_BUF = 3 * A_SZ;
+  constexpr int LDC = BN + 4;
+  __shared__ __attribute__((aligned(16))) float smem[(3 * BM * LDH / 2) > BM * (BN + 4) ? (3 * BM * LDH / 2) : BM * (BN + 4)];
+  x3_t* const As = reinterpret_cast<x3_t*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int M = d.N * d.H * d.W, K = d.K, C = d.C;
+  const int KC = K / BK;
+  const int tiles_n = (C + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int kq = tid & 7, arow = tid >> 3;
+  const int KT = d.R * d.S * KC;
+  int a_n[AJ], a_h[AJ], a_w[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int p = m0 + arow + 32 * j;
+    if (p < M) {
+      const int t = p / d.W;
+      a_w[j] = p - t * d.W + d.pad_left;
+      a_n[j] = t / d.H;
+      a_h[j] = t - a_n[j] * d.H + d.pad_top;
+    } else { a_n[j] = -1; a_h[j] = 0; a_w[j] = 0; }
+  }
+  const float* pa[AJ];
+  int inca[AJ];
+  auto setup_rs = [&](int rs_) {
+    const int r_ = rs_ / d.S, s_ = rs_ - r_ * d.S;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int th = a_h[j] - r_ * d.dilation, tw = a_w[j] - s_ * d.dilation;
+      int oh = th, ow = tw;
+      bool ok = a_n[j] >= 0 && th >= 0 && tw >= 0;
+      if (d.stride > 1) {
+        oh = th / d.stride; ow = tw / d.stride;
+        ok = ok && (oh * d.stride == th) && (ow * d.stride == tw);
+      }
+      ok = ok && oh < d.OH && ow < d.OW;
+      pa[j] = ok ? dy + ((size_t)(a_n[j] * d.OH + oh) * d.OW + ow) * K + 4 * kq : lmh_zero_page;
+      inca[j] = ok ? BK : 0;
+    }
+  };
+  // ---- B: pre-split fragments (columns = input channels) straight from global memory
+  const int NG = C >> 5;
+  int bgrp[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int g_ = (n0 + wn * (BN / 2)) / 32 + t;
+    bgrp[t] = g_ < NG ? g_ : 0;                        // (columns past C are never stored)
+  }
+  const size_t w3_stage = x3_w3_stage(C);
+  const float* pks = kscale ? kscale + 4 * kq : lmh_zero_page;
+  const int incks = kscale ? BK : 0;
+  f32x4 ra[1][AJ], ks[1];
+  x3_v8 bq[2][3][TN];
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  int rs = 0, kc = 0, ptile = 0;
+  setup_rs(0);
+  auto load = [&](auto S) {
+    constexpr int s_ = decltype(S)::value;
+    ks[s_] = *reinterpret_cast<const f32x4*>(pks);
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) ra[s_][j] = *reinterpret_cast<const f32x4*>(pa[j]);
+  };
+  auto load_b = [&](int s, int t_) {
+    const uint4* base = w3 + (size_t)(t_ < KT ? t_ : KT - 1) * w3_stage;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const uint4 v = base[((size_t)(p * NG + bgrp[t]) * 2 + s) * 64 + lane];
+        bq[s][p][t] = __builtin_bit_cast(x3_v8, v);
+      }
+  };
+  auto advance = [&]() {
+    if (ptile + 1 < KT) {       // (even tile count — host check: a tile past the last one is never multiplied)
+      ++ptile;
+      if (++kc == KC) {
+        kc = 0; ++rs;
+        setup_rs(rs);
+        pks -= (KC - 1) * incks;
+      } else {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) pa[j] += inca[j];
+        pks += incks;
+      }
+    }
+  };
+  auto store_a = [&](int buf, auto S) {
+    constexpr int s_ = decltype(S)::value;
+    x3_t* Ad = As + buf * A_BUF;
+    // (k_conv_bwd_data_h multiplies by kscale * gscale with gscale = 1 for bf16x3: the same product)
+    const f32x4 m = kscale ? ks[s_] * 1.f : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) st_kc<3>(Ad, A_SZ, arow + 32 * j, kq, ra[s_][j] * m);
+  };
+  typedef std::integral_constant<int, 0> S0;
+  load(S0());
+  advance();
+  load_b(0, 0);
+  load_b(1, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    store_a(0, S0());
+    load(S0());
+    advance();
+    __syncthreads();
+    x3_mma_rb<TM, TN>(As, A_SZ, acc, wm * (BM / 2), lane, bq, [&](int s) { load_b(s, kt + 1); });
+    __syncthreads();
+  }
+
 
   // epilogue (k_conv_bwd_data's): addend rows and mask words requested before the accumulator transpose
   constexpr int CT = BN / 4, RSTEP = 256 / CT;

@@ -78,3 +78,71 @@ int lmh_x3_bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }
+
+// ---- pre-split weights (conv_x3.h: k_x3_split_w / k_x3_fwd_ws) ---------------------------------------------------------
+size_t lmh_x3_w3_bytes(int rs, int c, int k, int fwd) {
+  const int ncols = fwd ? k : c;
+  const size_t stages = fwd ? (size_t)rs * c / BK : (size_t)rs * (k / BK);
+  return stages * x3_w3_stage(ncols) * sizeof(uint4);
+}
+
+int lmh_x3_split_launch(const float* const* w, void* const* out, const int* rs, const int* c, const int* k, int n, int fwd,
+                        hipStream_t st) {
+  for (int j0 = 0; j0 < n; j0 += X3_SPLIT_MAX) {
+    x3_split_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n = (n - j0) < X3_SPLIT_MAX ? (n - j0) : X3_SPLIT_MAX;
+    b.fwd = fwd;
+    int blocks = 0;
+    for (int j = 0; j < b.n; ++j) {
+      const int i = j0 + j;
+      if ((c[i] % 32) != 0 || (k[i] % 32) != 0) { lmh_set_error("lmh_x3_split_weights: C %% 32 == 0 and K %% 32 == 0 needed"); return LMH_ERR_UNSUPPORTED; }
+      b.w[j] = w[i]; b.out[j] = reinterpret_cast<uint4*>(out[i]);
+      b.RS[j] = rs[i]; b.C[j] = c[i]; b.K[j] = k[i];
+      b.first_block[j] = blocks;
+      const size_t threads = lmh_x3_w3_bytes(rs[i], c[i], k[i], fwd) / sizeof(uint4) / 3;
+      blocks += (int)((threads + 255) / 256);
+    }
+    b.first_block[b.n] = blocks;
+    if (blocks > 0) lmh_launch(k_x3_split_w, dim3(blocks), dim3(256), 0, st, b);
+  }
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+int lmh_x3_fwd_ws_launch(const lmh_conv_desc* d, const float* x, const void* w3, const float* scale, const float* shift,
+                         const float* residual, float* y, uint32_t* act_bits, int gbatch, int bm, int bn, hipStream_t st) {
+  const int64_t M = (int64_t)d->N * d->OH * d->OW;
+  const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn)) * (gbatch > 0 ? gbatch : 1);
+  const uint4* w3p = reinterpret_cast<const uint4*>(w3);
+#define X3_FWS(BM_, BN_)                                                                                              \
+  do {                                                                                                                \
+    if (gbatch > 0) lmh_launch((k_x3_fwd_ws<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, *d, x, w3p, scale, shift, \
+                               residual, y, gbatch, act_bits, 0);                                                      \
+    else lmh_launch((k_x3_fwd_ws<BM_, BN_, false>), dim3(grid), dim3(256), 0, st, *d, x, w3p, scale, shift, residual, \
+                    y, 1, act_bits, 0);                                                                                \
+  } while (0)
+  if (bm == 128 && bn == 128) X3_FWS(128, 128);
+  else if (bm == 128 && bn == 64) X3_FWS(128, 64);
+  else if (bm == 64 && bn == 64) X3_FWS(64, 64);
+  else { lmh_set_error("lmh_x3_fwd_ws_launch: no %d x %d tile", bm, bn); return LMH_ERR_INVALID; }
+#undef X3_FWS
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+
+int lmh_x3_bwd_data_ws_launch(const lmh_conv_desc* d, const float* dy, const void* w3, const float* kscale,
+                              const float* addend, const uint32_t* xbits, float* dx, int bm, int bn, hipStream_t st) {
+  const int64_t M = (int64_t)d->N * d->H * d->W;
+  const int grid = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
+  const uint4* w3p = reinterpret_cast<const uint4*>(w3);
+#define X3_BDS(BM_, BN_) lmh_launch((k_x3_bwd_data_ws<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, dy, w3p, kscale, addend, xbits, dx, 0)
+  if (bm == 128 && bn == 128) X3_BDS(128, 128);
+  else if (bm == 128 && bn == 64) X3_BDS(128, 64);
+  else if (bm == 64 && bn == 64) X3_BDS(64, 64);
+  else { lmh_set_error("lmh_x3_bwd_data_ws_launch: no %d x %d tile", bm, bn); return LMH_ERR_INVALID; }
+#undef X3_BDS
+  LMH_CHECK_LAUNCH();
+  return LMH_OK;
+}
+

@@ -506,6 +506,53 @@ def winograd_weights_batch(jobs, backward):
           'lmh_winograd_transform_weights_batch')
 
 
+def new_x3_weights(rs, C, K, device, backward=False):
+    """Buffer for the pre-split bf16x3 planes of a (rs, C, K) weight tensor (include/luminoth_hip.h lmh_x3_weights_bytes)."""
+    n = _lib.load().lmh_x3_weights_bytes(int(rs), int(C), int(K), int(bool(backward)))
+    if n == 0:
+        raise _lib.LuminothHipError('pre-split bf16x3 weights need C %% 32 == 0 and K %% 32 == 0 (got %d, %d)' % (C, K))
+    return torch.empty((n // 4,), dtype=torch.int32, device=device)
+
+
+def x3_split_weights_batch(jobs, backward=False):
+    """jobs: [(w (..., C, K) fp32 contiguous, rs, out)] -> every layer's three exact bf16 pieces in MFMA fragment order, ONE
+    launch (csrc/conv_x3.h k_x3_split_w).  `out`: new_x3_weights(rs, C, K)."""
+    if not jobs:
+        return
+    arr = (_lib.X3WeightJob * len(jobs))()
+    for i, (w, rs, out) in enumerate(jobs):
+        arr[i].w, arr[i].out = w.data_ptr(), out.data_ptr()
+        arr[i].rs, arr[i].C, arr[i].K = int(rs), w.shape[-2], w.shape[-1]
+        plan_keep(w, out)
+    check(_lib.load().lmh_x3_split_weights_batch(arr, len(jobs), int(bool(backward)), _stream()), 'lmh_x3_split_weights_batch')
+
+
+def conv2d_fwd_x3w_ok(d):
+    return bool(_lib.load().lmh_conv2d_fwd_x3w_supported(ctypes.byref(d)))
+
+
+def conv2d_fwd_x3w(d, x, w3, scale=None, shift=None, residual=None, out=None, act_bits=None):
+    """conv2d_fwd for compute bf16x3 with the layer's PRE-SPLIT weights `w3` (x3_split_weights_batch): bit-identical."""
+    y = out if out is not None else torch.empty((d.N, d.OH, d.OW, d.K), dtype=torch.float32, device=x.device)
+    with _timed(d, 0):
+        check(_lib.load().lmh_conv2d_fwd_x3w(ctypes.byref(d), _p(_f32(x)), _p(w3), _p(scale), _p(shift), _p(residual), _p(y),
+                                             _p(act_bits), _stream()), 'lmh_conv2d_fwd_x3w')
+    return y
+
+
+def conv2d_bwd_data_x3w_ok(d):
+    return bool(_lib.load().lmh_conv2d_bwd_data_x3w_supported(ctypes.byref(d)))
+
+
+def conv2d_bwd_data_x3w(d, dy, w3, kscale=None, addend=None, xbits=None, out=None):
+    """conv2d_bwd_data for compute bf16x3 with the layer's weights pre-split in the BACKWARD arrangement: bit-identical."""
+    dx = out if out is not None else torch.empty((d.N, d.H, d.W, d.C), dtype=torch.float32, device=dy.device)
+    with _timed(d, 1):
+        check(_lib.load().lmh_conv2d_bwd_data_x3w(ctypes.byref(d), _p(_f32(dy)), _p(w3), _p(kscale), _p(addend), _p(xbits),
+                                                  _p(dx), _stream()), 'lmh_conv2d_bwd_data_x3w')
+    return dx
+
+
 def new_winograd_u(C, K, device):
     return torch.empty((_lib.load().lmh_winograd_u_bytes(int(C), int(K)) // 4,), dtype=torch.float32, device=device)
 
