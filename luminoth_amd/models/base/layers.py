@@ -111,6 +111,10 @@ class ConvLayer(object):
         # transformed Winograd weights prepared ahead of the convolution calls (prepare_winograd_weights): [forward, backward]
         self._wino_u = [None, None]
         self._wino_ready = [False, False]
+        # bf16x3: the weights split once per step into their three bf16 pieces in MFMA fragment order (prepare_x3_weights):
+        # [forward arrangement, backward-data arrangement]
+        self._x3w = [None, None]
+        self._x3w_ready = [False, False]
 
     # ---- variable names in TF creation order (drives fine_tune_from) --------
     def var_names(self):
@@ -193,10 +197,14 @@ class ConvLayer(object):
             if ACT_TAP is not None:
                 ACT_TAP[self.scope] = y
             return (y, bits) if want_bits else y
-        # a training forward of a trainable Winograd layer keeps B^T x B for its weight gradient (kernels.py)
-        y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub, out=out, act_bits=bits,
-                         keep_v=(want_bits or keep_v) and self.trainable,
-                         wino_u=self._wino_u[0] if self._wino_ready[0] else None)
+        if self._x3w_ready[0] and in_sub is None and not K._use_winograd(d) and K.conv2d_fwd_x3w_ok(d):
+            # bf16x3 with this step's pre-split weights (bit-identical to the in-kernel split)
+            y = K.conv2d_fwd_x3w(d, x, self._x3w[0], self.scale, self.shift, residual, out=out, act_bits=bits)
+        else:
+            # a training forward of a trainable Winograd layer keeps B^T x B for its weight gradient (kernels.py)
+            y = K.conv2d_fwd(d, x, self.w, self.scale, self.shift, residual, in_sub, out=out, act_bits=bits,
+                             keep_v=(want_bits or keep_v) and self.trainable,
+                             wino_u=self._wino_u[0] if self._wino_ready[0] else None)
         if self._generic_act():
             y = self._apply_generic_act(y, out)
         if ACT_TAP is not None:
@@ -360,6 +368,9 @@ class ConvLayer(object):
                     prepare_half_weights([self], self.storage)
                 return K.conv2d_bwd_data_hs(d, g, self.wh[1], addend=addend, xbits=mask_bits, out_f32=boundary,
                                             mul=1.0 / HS_LOSS_SCALE[self.storage] if boundary else 1.0)
+            if self._x3w_ready[1] and yact is None and not K._use_winograd(d) and K.conv2d_bwd_data_x3w_ok(d):
+                return K.conv2d_bwd_data_x3w(d, g, self._x3w[1], kscale=self.scale if self.norm == 'bn' else None,
+                                             addend=addend, xbits=mask_bits)
             return K.conv2d_bwd_data(d, g, self.w, kscale=self.scale if self.norm == 'bn' else None,
                                      addend=addend, yact=yact, xbits=mask_bits,
                                      wino_u=self._wino_u[1] if self._wino_ready[1] else None)
@@ -425,6 +436,35 @@ def prepare_winograd_weights(layers, backward):
     K.winograd_weights_batch(jobs, backward)
     for l in layers:
         l._wino_ready[b] = True
+
+
+def x3w_candidates(layers):
+    """bf16x3 layers whose weights can be pre-split (C % 32 == 0, K % 32 == 0, fp32 tensors, inference-mode BatchNorm): the
+    1x1 layers and the 3x3 / strided ones that are not routed through Winograd (whose GEMMs multiply transformed weights)."""
+    wino = set(id(l) for l in winograd_candidates(layers))
+    return [l for l in layers if K.COMPUTE.get(l.compute) == 3 and l.storage is None and not l.bn_train and l.k > 0 and
+            l.cin % 32 == 0 and l.cout % 32 == 0 and id(l) not in wino]
+
+
+def prepare_x3_weights(layers, backward):
+    """One launch that splits the weights of every layer in `layers` into the three exact bf16 pieces of bf16x3, laid out in
+    MFMA fragment order (csrc/conv_x3.h k_x3_split_w; forward or backward-data arrangement), on the current stream.  The
+    layers multiply with them until release_x3_weights; the weights must not change in between (the fused train step
+    prepares at its start and releases before the optimizer update)."""
+    jobs = []
+    b = int(bool(backward))
+    for l in layers:
+        if l._x3w[b] is None:
+            l._x3w[b] = K.new_x3_weights(l.k * l.k, l.cin, l.cout, l.w.device, backward=backward)
+        jobs.append((l.w, l.k * l.k, l._x3w[b]))
+    K.x3_split_weights_batch(jobs, backward)
+    for l in layers:
+        l._x3w_ready[b] = True
+
+
+def release_x3_weights(layers):
+    for l in layers:
+        l._x3w_ready = [False, False]
 
 
 def release_winograd_weights(layers):

@@ -51,6 +51,8 @@ RCNN_LOSS_LATE = os.environ.get('LUMINOTH_AMD_RCNN_LOSS_LATE', '1') != '0'
 RPN_BWD_LATE = os.environ.get('LUMINOTH_AMD_RPN_BWD_LATE', '0') != '0'
 PREFIX_SPLIT = os.environ.get('LUMINOTH_AMD_PREFIX_SPLIT', '0') != '0'      # stem of the next batch right behind the RPN heads
 WINO_BATCH = os.environ.get('LUMINOTH_AMD_WINO_BATCH', '1') != '0'      # transformed Winograd weights of the whole step in two launches
+# bf16x3: weights pre-split once per step into MFMA fragment order, B fragments loaded straight from global memory (round 6)
+X3_PRESPLIT = os.environ.get('LUMINOTH_AMD_X3_PRESPLIT', '1') != '0'
 
 
 class FasterRCNN(object):
@@ -298,6 +300,14 @@ class FasterRCNN(object):
             raise
         finally:
             L.release_winograd_weights(self._winograd_layers())
+            L.release_x3_weights(self._x3w_layers())
+
+    def _x3w_layers(self):
+        xl = getattr(self, '_x3w_layer_list', None)
+        if xl is None:
+            layers = self.base_network.trunk.all_layers() + [self._rpn._rpn]
+            xl = self._x3w_layer_list = L.x3w_candidates(layers) if X3_PRESPLIT else []
+        return xl
 
     def _winograd_layers(self):
         wl = getattr(self, '_wino_layers', None)
@@ -507,13 +517,21 @@ class FasterRCNN(object):
             L.prepare_half_weights(bn._hs_layers + bn.extra_hs_layers, bn.storage_dtype)
         # (training-mode BatchNorm: the backward weights are NOT pre-scaled by a frozen BatchNorm scale: transformed per call)
         wl = self._winograd_layers() if (WINO_BATCH and not any(l.bn_train for l in self.base_network.trunk.all_layers())) else []
+        # bf16x3: the weights of the layers that multiply them directly, split once for the whole step (csrc/conv_x3.h)
+        xl = self._x3w_layers() if not any(l.bn_train for l in self.base_network.trunk.all_layers()) else []
         wino_bwd_side = None
         if wl:
             L.prepare_winograd_weights(wl, backward=False)
+        if xl:
+            L.prepare_x3_weights(xl, backward=False)
+        if wl or xl:
             wino_bwd_side = SideStream.get(self.device)
             K.stream_wait(wino_bwd_side, main)
             with K.launch_on(wino_bwd_side):
-                L.prepare_winograd_weights([l for l in wl if l.trainable], backward=True)
+                if wl:
+                    L.prepare_winograd_weights([l for l in wl if l.trainable], backward=True)
+                if [l for l in xl if l.trainable]:
+                    L.prepare_x3_weights([l for l in xl if l.trainable], backward=True)
         K.zero_(self.store.grad)
         start = S['start']
         if produce and start > 0 and PREFIX_AT in ('side', 'aux') and SideStream.enabled:

@@ -237,3 +237,68 @@ def test_pipelined_bf16x3_kernels_equal_the_round2_kernels(K, case, pipe, monkey
     if out[1][4] is not None:
         want = gy.reshape(-1, Kc).astype(np.float64).sum(0)
         np.testing.assert_allclose(out[1][4], want, rtol=1e-5, atol=1e-5 * np.abs(gy).sum(axis=(0, 1, 2)).max())
+
+
+PRESPLIT_CASES = [c for c in CASES if c[3] % 32 == 0 and c[4] % 32 == 0] + [(2, 19, 23, 96, 96, 3, 1, 1, 'SAME'),
+                                                                            (1, 40, 40, 128, 512, 1, 1, 1, 'SAME')]
+
+
+@pytest.mark.parametrize('case', PRESPLIT_CASES)
+def test_presplit_weights_equal_the_in_kernel_split(K, case, monkeypatch):
+    """Round 6: the weights split ONCE into their three bf16 pieces, in MFMA fragment order (k_x3_split_w), and loaded by
+    k_x3_fwd_ws / k_x3_bwd_data_ws straight from global memory — same pieces, same order of products: the SAME BITS as the
+    kernels that split every slab in every block (forward with scale / shift / residual / ReLU and its bit mask; backward
+    data with kscale, addend and the input mask; strided, dilated, ragged and 3x3 cases)."""
+    monkeypatch.setattr(K, 'WINOGRAD', False)
+    N, H, W, C, Kc, R, stride, dil, padding = case
+    rs = np.random.RandomState(11)
+    x = T(rs.randn(N, H, W, C).astype(F))
+    w = T((rs.randn(R, R, C, Kc) * np.sqrt(2.0 / (R * R * C))).astype(F))
+    scale, shift = T((1 + 0.1 * rs.randn(Kc)).astype(F)), T((0.1 * rs.randn(Kc)).astype(F))
+    d = K.conv_desc(x.shape, w.shape, stride, dil, padding, 'relu', 'bf16x3')
+    assert K.conv2d_fwd_x3w_ok(d) and K.conv2d_bwd_data_x3w_ok(d)
+    res = T(rs.randn(N, d.OH, d.OW, Kc).astype(F))
+    gy = T(rs.randn(N, d.OH, d.OW, Kc).astype(F))
+    add = T(rs.randn(N, H, W, C).astype(F))
+    xb = T(rs.randint(-2 ** 31, 2 ** 31 - 1, size=(N * H * W, C // 32)).astype(np.int32))
+    w3f = K.new_x3_weights(R * R, C, Kc, x.device)
+    w3b = K.new_x3_weights(R * R, C, Kc, x.device, backward=True)
+    K.x3_split_weights_batch([(w, R * R, w3f)] * 3)                 # (several jobs in one launch)
+    K.x3_split_weights_batch([(w, R * R, w3b)], backward=True)
+    b0, b1 = K.new_act_bits(N * d.OH * d.OW, Kc, x.device), K.new_act_bits(N * d.OH * d.OW, Kc, x.device)
+    K._Profile.start()
+    y0 = K.conv2d_fwd(d, x, w, scale, shift, res, act_bits=b0)
+    y1 = K.conv2d_fwd_x3w(d, x, w3f, scale, shift, res, act_bits=b1)
+    dx0 = K.conv2d_bwd_data(d, gy, w, kscale=scale, addend=add, xbits=xb)
+    dx1 = K.conv2d_bwd_data_x3w(d, gy, w3b, kscale=scale, addend=add, xbits=xb)
+    names = set(K._Profile.stop())
+    assert any(n.startswith('k_x3_fwd_ws<') for n in names) and any(n.startswith('k_x3_bwd_data_ws<') for n in names), names
+    assert torch.equal(y0, y1) and torch.equal(b0, b1) and torch.equal(dx0, dx1)
+    with pytest.raises(Exception):
+        K.new_x3_weights(1, 48, 64, x.device)                          # C % 32 != 0: not supported, says so
+
+
+def test_presplit_weights_leave_the_train_step_bit_identical(monkeypatch):
+    """The fused step with LUMINOTH_AMD_X3_PRESPLIT on and off: same losses, same gradients, bit for bit (the split
+    launches and the *_ws kernels are part of the recorded launch plan like every other launch)."""
+    from e2e_util import condition_like_pretrained, make_config, synth
+    from luminoth_amd.models import get_model
+    from luminoth_amd.models.fasterrcnn import fasterrcnn as FR
+    images, gts = synth(2, 256, 320, 3, 80, 9)
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(FR, 'X3_PRESPLIT', on)
+        cfg = make_config(**{'model.base_network.compute_dtype': 'bf16x3'})
+        model = condition_like_pretrained(get_model('fasterrcnn')(cfg), 'resnet_v1_50')
+        assert bool(model._x3w_layers()) == on
+        if on:
+            assert len(model._x3w_layers()) >= 30           # the 1x1 layers of the trunk (the 3x3 ones go through Winograd)
+        losses = []
+        for _ in range(3):                                   # eager, recording and replayed steps
+            total, _ = model.train_step(images, gts)
+            losses.append(float(total))
+        torch.cuda.synchronize()
+        out[on] = (losses, model.store.grad.clone())
+    assert out[True][0] == out[False][0]
+    assert torch.equal(out[True][1], out[False][1])
+
