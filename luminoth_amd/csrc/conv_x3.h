@@ -178,7 +178,7 @@ template <int BM, int BN, bool GB, int PIPE>
 __global__ void __launch_bounds__(256, (PIPE && (BM + BN) > 128) ? 1 : 2)
 k_x3_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
          const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ y, int gbatch,
-         uint32_t* __restrict__ act_bits, int stagger) {
+         uint32_t* __restrict__ act_bits, int stagger, lmh_fastdiv dvw, lmh_fastdiv dvh) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH, A_BUF = 3 * A_SZ, B_BUF = 3 * B_SZ;
@@ -207,9 +207,9 @@ k_x3_fwd(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__
   for (int j = 0; j < AJ; ++j) {
     const int p = m0 + arow + 32 * j;
     if (p < M) {
-      const int ow = p % d.OW, t = p / d.OW;
-      a_n[j] = t / d.OH;
-      a_ih0[j] = (t % d.OH) * d.stride - d.pad_top;
+      const int t = (int)lmh_div((unsigned)p, dvw), ow = p - t * d.OW;      // (magic-number division: a plain / and % pair
+      a_n[j] = (int)lmh_div((unsigned)t, dvh);                                //  is ~60 instructions per row in front of the first load)
+      a_ih0[j] = (t - a_n[j] * d.OH) * d.stride - d.pad_top;
       a_iw0[j] = ow * d.stride - d.pad_left;
     } else { a_n[j] = -1; a_ih0[j] = 0; a_iw0[j] = 0; }
   }
@@ -445,7 +445,7 @@ template <int BM, int BN, bool GB>
 __global__ void __launch_bounds__(256, 2)
 k_x3_fwd_ws(lmh_conv_desc d, const float* __restrict__ x, const uint4* __restrict__ w3, const float* __restrict__ scale,
          const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ y, int gbatch,
-         uint32_t* __restrict__ act_bits, int stagger) {
+         uint32_t* __restrict__ act_bits, int stagger, lmh_fastdiv dvw, lmh_fastdiv dvh) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32;
   constexpr int A_SZ = BM * LDH, A_BUF = 3 * A_SZ;
@@ -473,9 +473,9 @@ k_x3_fwd_ws(lmh_conv_desc d, const float* __restrict__ x, const uint4* __restric
   for (int j = 0; j < AJ; ++j) {
     const int p = m0 + arow + 32 * j;
     if (p < M) {
-      const int ow = p % d.OW, t = p / d.OW;
-      a_n[j] = t / d.OH;
-      a_ih0[j] = (t % d.OH) * d.stride - d.pad_top;
+      const int t = (int)lmh_div((unsigned)p, dvw), ow = p - t * d.OW;      // (magic-number division: a plain / and % pair
+      a_n[j] = (int)lmh_div((unsigned)t, dvh);                                //  is ~60 instructions per row in front of the first load)
+      a_ih0[j] = (t - a_n[j] * d.OH) * d.stride - d.pad_top;
       a_iw0[j] = ow * d.stride - d.pad_left;
     } else { a_n[j] = -1; a_ih0[j] = 0; a_iw0[j] = 0; }
   }
@@ -615,7 +615,7 @@ template <int BM, int BN, int PIPE>
 __global__ void __launch_bounds__(256, (PIPE && (BM + BN) > 128) ? 1 : 2)
 k_x3_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __restrict__ w,
               const float* __restrict__ kscale, const float* __restrict__ addend, const uint32_t* __restrict__ xbits,
-              float* __restrict__ dx, int stagger) {
+              float* __restrict__ dx, int stagger, lmh_fastdiv dvw, lmh_fastdiv dvh) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32, BJ = BN / 32;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH, A_BUF = 3 * A_SZ, B_BUF = 3 * B_SZ;
@@ -637,9 +637,9 @@ k_x3_bwd_data(lmh_conv_desc d, const float* __restrict__ dy, const float* __rest
   for (int j = 0; j < AJ; ++j) {
     const int p = m0 + arow + 32 * j;
     if (p < M) {
-      const int t = p / d.W;
+      const int t = (int)lmh_div((unsigned)p, dvw);
       a_w[j] = p - t * d.W + d.pad_left;
-      a_n[j] = t / d.H;
+      a_n[j] = (int)lmh_div((unsigned)t, dvh);
       a_h[j] = t - a_n[j] * d.H + d.pad_top;
     } else { a_n[j] = -1; a_h[j] = 0; a_w[j] = 0; }
   }
@@ -783,7 +783,7 @@ template <int BM, int BN>
 __global__ void __launch_bounds__(256, 2)
 k_x3_bwd_data_ws(lmh_conv_desc d, const float* __restrict__ dy, const uint4* __restrict__ w3,
               const float* __restrict__ kscale, const float* __restrict__ addend, const uint32_t* __restrict__ xbits,
-              float* __restrict__ dx, int stagger) {
+              float* __restrict__ dx, int stagger, lmh_fastdiv dvw, lmh_fastdiv dvh) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AJ = BM / 32;
   constexpr int A_SZ = BM * LDH, A_BUF = 3 * A_SZ;
@@ -804,9 +804,9 @@ k_x3_bwd_data_ws(lmh_conv_desc d, const float* __restrict__ dy, const uint4* __r
   for (int j = 0; j < AJ; ++j) {
     const int p = m0 + arow + 32 * j;
     if (p < M) {
-      const int t = p / d.W;
+      const int t = (int)lmh_div((unsigned)p, dvw);
       a_w[j] = p - t * d.W + d.pad_left;
-      a_n[j] = t / d.H;
+      a_n[j] = (int)lmh_div((unsigned)t, dvh);
       a_h[j] = t - a_n[j] * d.H + d.pad_top;
     } else { a_n[j] = -1; a_h[j] = 0; a_w[j] = 0; }
   }

@@ -11,18 +11,19 @@ int lmh_opt(const char* name);
 int lmh_x3_fwd_launch(const lmh_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
                       const float* residual, float* y, uint32_t* act_bits, int gbatch, int bm, int bn, int pipe, hipStream_t st) {
   const int sg = lmh_opt("x3_stagger");
+  const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
   const int64_t M = (int64_t)d->N * d->OH * d->OW;
   const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn)) * (gbatch > 0 ? gbatch : 1);
 #define X3_FWD(BM_, BN_)                                                                                              \
   do {                                                                                                                \
     if (gbatch > 0 && pipe) lmh_launch((k_x3_fwd<BM_, BN_, true, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, \
-                                       shift, residual, y, gbatch, act_bits, sg);                                         \
+                                       shift, residual, y, gbatch, act_bits, sg, dvw, dvh);                                         \
     else if (gbatch > 0) lmh_launch((k_x3_fwd<BM_, BN_, true, 0>), dim3(grid), dim3(256), 0, st, *d, x, w, scale,    \
-                                    shift, residual, y, gbatch, act_bits, sg);                                            \
+                                    shift, residual, y, gbatch, act_bits, sg, dvw, dvh);                                            \
     else if (pipe) lmh_launch((k_x3_fwd<BM_, BN_, false, 1>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift,  \
-                              residual, y, 1, act_bits, sg);                                                              \
+                              residual, y, 1, act_bits, sg, dvw, dvh);                                                              \
     else lmh_launch((k_x3_fwd<BM_, BN_, false, 0>), dim3(grid), dim3(256), 0, st, *d, x, w, scale, shift, residual,  \
-                    y, 1, act_bits, sg);                                                                                  \
+                    y, 1, act_bits, sg, dvw, dvh);                                                                                  \
   } while (0)
   if (bm == 128 && bn == 128) X3_FWD(128, 128);
   else if (bm == 128 && bn == 64) X3_FWD(128, 64);
@@ -36,12 +37,13 @@ int lmh_x3_fwd_launch(const lmh_conv_desc* d, const float* x, const float* w, co
 int lmh_x3_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const float* w, const float* kscale,
                            const float* addend, const uint32_t* xbits, float* dx, int bm, int bn, int pipe, hipStream_t st) {
   const int sg = lmh_opt("x3_stagger");
+  const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->W), dvh = lmh_make_fastdiv((uint32_t)d->H);
   const int64_t M = (int64_t)d->N * d->H * d->W;
   const int grid = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
 #define X3_BD(BM_, BN_)                                                                                               \
   do {                                                                                                                \
-    if (pipe) lmh_launch((k_x3_bwd_data<BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, addend, xbits, dx, sg); \
-    else lmh_launch((k_x3_bwd_data<BM_, BN_, 0>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, addend, xbits, dx, sg); \
+    if (pipe) lmh_launch((k_x3_bwd_data<BM_, BN_, 1>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, addend, xbits, dx, sg, dvw, dvh); \
+    else lmh_launch((k_x3_bwd_data<BM_, BN_, 0>), dim3(grid), dim3(256), 0, st, *d, dy, w, kscale, addend, xbits, dx, sg, dvw, dvh); \
   } while (0)
   if (bm == 128 && bn == 128) X3_BD(128, 128);
   else if (bm == 128 && bn == 64) X3_BD(128, 64);
@@ -112,15 +114,16 @@ int lmh_x3_split_launch(const float* const* w, void* const* out, const int* rs, 
 
 int lmh_x3_fwd_ws_launch(const lmh_conv_desc* d, const float* x, const void* w3, const float* scale, const float* shift,
                          const float* residual, float* y, uint32_t* act_bits, int gbatch, int bm, int bn, hipStream_t st) {
+  const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
   const int64_t M = (int64_t)d->N * d->OH * d->OW;
   const int grid = (int)(((M + bm - 1) / bm) * ((d->K + bn - 1) / bn)) * (gbatch > 0 ? gbatch : 1);
   const uint4* w3p = reinterpret_cast<const uint4*>(w3);
 #define X3_FWS(BM_, BN_)                                                                                              \
   do {                                                                                                                \
     if (gbatch > 0) lmh_launch((k_x3_fwd_ws<BM_, BN_, true>), dim3(grid), dim3(256), 0, st, *d, x, w3p, scale, shift, \
-                               residual, y, gbatch, act_bits, 0);                                                      \
+                               residual, y, gbatch, act_bits, 0, dvw, dvh);                                                      \
     else lmh_launch((k_x3_fwd_ws<BM_, BN_, false>), dim3(grid), dim3(256), 0, st, *d, x, w3p, scale, shift, residual, \
-                    y, 1, act_bits, 0);                                                                                \
+                    y, 1, act_bits, 0, dvw, dvh);                                                                                \
   } while (0)
   if (bm == 128 && bn == 128) X3_FWS(128, 128);
   else if (bm == 128 && bn == 64) X3_FWS(128, 64);
@@ -133,10 +136,11 @@ int lmh_x3_fwd_ws_launch(const lmh_conv_desc* d, const float* x, const void* w3,
 
 int lmh_x3_bwd_data_ws_launch(const lmh_conv_desc* d, const float* dy, const void* w3, const float* kscale,
                               const float* addend, const uint32_t* xbits, float* dx, int bm, int bn, hipStream_t st) {
+  const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->W), dvh = lmh_make_fastdiv((uint32_t)d->H);
   const int64_t M = (int64_t)d->N * d->H * d->W;
   const int grid = (int)(((M + bm - 1) / bm) * ((d->C + bn - 1) / bn));
   const uint4* w3p = reinterpret_cast<const uint4*>(w3);
-#define X3_BDS(BM_, BN_) lmh_launch((k_x3_bwd_data_ws<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, dy, w3p, kscale, addend, xbits, dx, 0)
+#define X3_BDS(BM_, BN_) lmh_launch((k_x3_bwd_data_ws<BM_, BN_>), dim3(grid), dim3(256), 0, st, *d, dy, w3p, kscale, addend, xbits, dx, 0, dvw, dvh)
   if (bm == 128 && bn == 128) X3_BDS(128, 128);
   else if (bm == 128 && bn == 64) X3_BDS(128, 64);
   else if (bm == 64 && bn == 64) X3_BDS(64, 64);

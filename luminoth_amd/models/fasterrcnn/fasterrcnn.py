@@ -305,7 +305,10 @@ class FasterRCNN(object):
     def _x3w_layers(self):
         xl = getattr(self, '_x3w_layer_list', None)
         if xl is None:
-            layers = self.base_network.trunk.all_layers() + [self._rpn._rpn]
+            bn = self.base_network
+            layers = bn.trunk.all_layers() + [self._rpn._rpn]
+            if getattr(bn, 'tail', None) is not None and getattr(bn, '_use_tail', True):
+                layers = layers + bn.tail.all_layers()          # ResNet-101: block4 on the pooled ROIs
             xl = self._x3w_layer_list = L.x3w_candidates(layers) if X3_PRESPLIT else []
         return xl
 
