@@ -994,6 +994,11 @@ k_x3_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __res
   const float* gb = g + n0 + 4 * cq + (GB ? (size_t)rs * P * K : 0);
   int p0 = kt_begin * BK + 4 * kq;       // first of this thread's 4 pixels in the tile the pointers stand on
   const unsigned p_end = (unsigned)min(P, kt_end * BK);      // pixels of this split: [kt_begin * BK, p_end)
+#ifdef LMH_PROBES      // timing decomposition (scripts/r6_x3_decomp.py): 1 / 2 split + writes of g / x, 4 loads, 16 MFMA phase, 32 slab store
+  const int dbg = stagger >> 8;
+#else
+  constexpr int dbg = 0;
+#endif
   f32x4 ra[2][4], rb[2][4];
   auto load = [&](auto S) {
     constexpr int s_ = decltype(S)::value;
@@ -1004,21 +1009,21 @@ k_x3_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __res
       const unsigned n = lmh_div(t, div_oh), oh = t - n * (unsigned)d.OH;
       const int ih = (int)oh * d.stride + dh0, iw = (int)ow * d.stride + dw0;
       const bool oka = a_ok && p < p_end && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-      const float* pa_ = oka ? xb + ((size_t)((int)n * d.H + ih) * d.W + iw) * C : lmh_zero_page;
+      const float* pa_ = (oka && !(dbg & 4)) ? xb + ((size_t)((int)n * d.H + ih) * d.W + iw) * C : lmh_zero_page;
       if (A_ALL || a_act) ra[s_][i] = *reinterpret_cast<const f32x4*>(pa_);
       const bool okb = b_ok && p < p_end;
-      const float* pb_ = okb ? gb + (size_t)p * K : lmh_zero_page;
+      const float* pb_ = (okb && !(dbg & 4)) ? gb + (size_t)p * K : lmh_zero_page;
       if (B_ALL || b_act) rb[s_][i] = *reinterpret_cast<const f32x4*>(pb_);
     }
   };
   auto advance = [&]() { p0 += BK; };   // past the split's end (p_end): the zero page
   auto store_a = [&](int buf, auto S) {
     constexpr int s_ = decltype(S)::value;
-    if (A_ALL || a_act) st_km<3>(As + buf * A_BUF, A_SZ, 4 * cq, kq, ra[s_]);
+    if ((A_ALL || a_act) && !(dbg & 2)) st_km<3>(As + buf * A_BUF, A_SZ, 4 * cq, kq, ra[s_]);
   };
   auto store_b = [&](int buf, auto S) {
     constexpr int s_ = decltype(S)::value;
-    if (B_ALL || b_act) st_km<3>(Bs + buf * B_BUF, B_SZ, 4 * cq, kq, rb[s_]);
+    if ((B_ALL || b_act) && !(dbg & 1)) st_km<3>(Bs + buf * B_BUF, B_SZ, 4 * cq, kq, rb[s_]);
   };
   f32x16 acc[TM][TN], ccol[TN];
   zero_acc<TM, TN>(acc);
@@ -1054,6 +1059,7 @@ k_x3_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __res
           [&]() { load(SL); }, [&]() { store_a(buf ^ 1, SW); }, [&]() { store_b(buf ^ 1, SW); });
     };
     auto mma = [&](int buf) {
+      if (dbg & 16) return;
       x3_stage<TM, TN, false, 0, 0, 0, 0>(As + buf * A_BUF, Bs + buf * B_BUF, A_SZ, B_SZ, acc, ccol, wm * (BM / 2),
                                           wn * (BN / 2), lane, []() {}, []() {}, []() {});
     };
@@ -1065,7 +1071,7 @@ k_x3_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __res
   constexpr int CT = BN / 4, RSTEP = 256 / CT;
   const int c4 = tid % CT, r0 = tid / CT;
   const int col = n0 + 4 * c4;
-  if (col < K) {
+  if (col < K && !(dbg & 32)) {
 #pragma unroll 4
     for (int rr = r0; rr < BM; rr += RSTEP) {
       const int row = m0 + rr;

@@ -52,3 +52,20 @@ for name, H, C, Kc, res in LAYERS:
         row.append((pname, timeit(lambda: K.conv2d_fwd(d, x, w, sc, sh, r, out=y, act_bits=bits))))
     K.set_option('x3_stagger', 0)
     print('%-26s' % name + '  '.join('%s %.1f' % (p, t) for p, t in row))
+
+
+# ---- weight gradient (k_x3_bwd_weight): 1 split of g, 2 split of x, 4 loads, 16 MFMA phase, 32 slab store
+WPARTS = [('full', 0), ('-g split', 1), ('-x split', 2), ('-both splits', 3), ('-splits -loads', 7), ('-MFMA', 16), ('-slab store', 32),
+          ('-staging -MFMA', 23), ('nothing', 55)]
+print()
+for name, H, C, Kc, res in LAYERS:
+    x = torch.randn(2, H, H, C, device=dev)
+    g = torch.randn(2, H, H, Kc, device=dev)
+    d = K.conv_desc(x.shape, (1, 1, C, Kc), 1, 1, 'SAME', 'relu', 'bf16x3')
+    dw = torch.empty(1, 1, C, Kc, device=dev)
+    row = []
+    for pname, bitsv in WPARTS:
+        K.set_option('x3_stagger', bitsv << 8)
+        row.append((pname, timeit(lambda: K.conv2d_bwd_weight(d, x, g, out=dw))))
+    K.set_option('x3_stagger', 0)
+    print('wgrad %-20s' % name.replace(' (+res)', '') + '  '.join('%s %.1f' % (p, t) for p, t in row))
