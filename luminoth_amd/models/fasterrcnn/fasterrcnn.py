@@ -172,6 +172,15 @@ class FasterRCNN(object):
             seeds = self._image_seeds(B)
             if is_training:
                 self._step += 1
+        # bf16x3: this call's weights pre-split once (csrc/conv_x3.h), forward and backward-data arrangements, for a training
+        # call; whatever an earlier call left is dropped first (the weights may have been updated or loaded since)
+        xl = self._x3w_layers()
+        if xl:
+            L.release_x3_weights(xl)
+            if is_training and gt is not None and not any(l.bn_train for l in self.base_network.trunk.all_layers()):
+                L.prepare_x3_weights(xl, backward=False)
+                if [l for l in xl if l.trainable]:
+                    L.prepare_x3_weights([l for l in xl if l.trainable], backward=True)
         with torch.set_grad_enabled(bool(is_training)):
             conv_feature_map = self.base_network(image, is_training=is_training)
             im_shape = (H, W)
