@@ -177,6 +177,9 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
   zero_acc<TM, TN>(acc);
   int rs = 0, kc = 0;
   setup_tap(0);
+  // timing decomposition (probe builds only; scripts/r6_hs_decomp.py): bits 8.. of the probe word — 1 no residual / addend /
+  // mask reads, 2 no output stores, 4 no main loop, 8 loads from the zero page, 16 no MFMA phase.  Wrong results.
+  const int dbg = conv_probe_bits() >> 8;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   // issue the loads of the stage the pointers stand on into ring slot `buf`, then advance the pointers by one stage
@@ -185,9 +188,9 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
     HTT* As_ = ring + (buf_) * STAGE;                                                                      \
     HTT* Bs_ = As_ + A_SZ;                                                                                 \
     _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                         \
-      __builtin_amdgcn_global_load_lds((glb_ptr)pa[j], (lds_ptr)(As_ + (wave * AJ + j) * 8 * HS_BK), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((glb_ptr)((dbg & 8) ? zero : pa[j]), (lds_ptr)(As_ + (wave * AJ + j) * 8 * HS_BK), 16, 0, 0); \
     _Pragma("unroll") for (int j = 0; j < BJ; ++j)                                                         \
-      __builtin_amdgcn_global_load_lds((glb_ptr)pb[j], (lds_ptr)(Bs_ + (wave * BJ + j) * 8 * HS_BK), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((glb_ptr)((dbg & 8) ? zero : pb[j]), (lds_ptr)(Bs_ + (wave * BJ + j) * 8 * HS_BK), 16, 0, 0); \
     if (++kc == KC) {                                                                                      \
       kc = 0; ++rs;                                                                                        \
       if (rs < RS) setup_tap(rs);                                                                          \
@@ -201,7 +204,7 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
   for (int s = 0; s < D; ++s)
     if (s < KT) HS_ISSUE(s);
   int cur = 0;
-  for (int t = 0; t < KT; ++t) {
+  for (int t = 0; t < ((dbg & 4) ? 0 : KT); ++t) {
     // stage t has landed once at most min(D - 1, KT - 1 - t) younger stages are still in flight
     if (KT - 1 - t >= D - 1) {
       if (D - 1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -219,7 +222,7 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (t + D < KT) HS_ISSUE(cur == 0 ? NBUF - 1 : cur - 1);
     const HTT* As = ring + cur * STAGE;
-    hs_mma_stage<DT, TM, TN>(As, As + A_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
+    if (!(dbg & 16)) hs_mma_stage<DT, TM, TN>(As, As + A_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
     cur = (cur + 1 == NBUF) ? 0 : cur + 1;
   }
 #undef HS_ISSUE
@@ -249,8 +252,8 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
     const size_t o = ok ? (size_t)row * NC + col : 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) x8[i][q] = (HTT)0.f;
-    if (e.extra && ok) x8[i] = *reinterpret_cast<const V8*>(reinterpret_cast<const HTT*>(e.extra) + o);
-    mw[i] = (BWD && e.bits_in && ok) ? e.bits_in[(size_t)row * words + wcol] : 0xFFFFFFFFu;
+    if (e.extra && ok && !(dbg & 1)) x8[i] = *reinterpret_cast<const V8*>(reinterpret_cast<const HTT*>(e.extra) + o);
+    mw[i] = (BWD && e.bits_in && ok && !(dbg & 1)) ? e.bits_in[(size_t)row * words + wcol] : 0xFFFFFFFFu;
   }
   acc_to_lds<BM, BN, TM, TN>(smem, acc, wm, wn, lane);
   __syncthreads();
@@ -264,7 +267,7 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
     for (int i = 0; i < NRW; ++i) {
       const int r = r0 + i * RSTEP;
       const int row = m0 + r;
-      if (row >= M) break;
+      if (row >= M || (dbg & 2)) break;
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 8 * c8]);
       const f32x4 v1 = *reinterpret_cast<const f32x4*>(&smem[r * LDC + 8 * c8 + 4]);
       float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
