@@ -44,7 +44,7 @@ typedef void* lmh_stream_t; /* hipStream_t */
 
 /* Tuning options (defaults are the measured best on MI355X).  Names: bd_parity_small, half_pf, x3_tile_slots, x3_pf,
  * x3_pf_fwd, x3_pf_gb, x3_pf_bd, x3_pf_bw, x3_new, x3_pipe, x3_stagger, x3_bw_slots, bd_slots, bw_slots, wgrad_glds, wg_slots, wino_m,
- * hs_slab_cap, hs_wg_tile, nms_stage_mult, head_gemm, conv_pp, roi_cs, roi_mean_cs (csrc/api.hip documents each).  Unknown name:
+ * hs_slab_cap, hs_wg_tile, hs_bg, nms_stage_mult, head_gemm, conv_pp, roi_cs, roi_mean_cs (csrc/api.hip documents each).  Unknown name:
  * LMH_ERR_INVALID.
  * Re-entrancy (round 6): lmh_set_option sets the value for the CALLING THREAD only — two threads that drive two models
  * with different options do not see each other's settings; lmh_set_default_option sets the process default, which is what
@@ -327,8 +327,13 @@ int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, const void* 
 typedef struct lmh_half_weight_job {
   const float* w;       /* (R*S, C, K) fp32 master weights (HWIO) */
   const float* kscale;  /* K floats folded into w_bwd (frozen-BatchNorm scale), or NULL */
-  void* w_fwd;          /* [K][R*S*C] halfs, or NULL */
-  void* w_bwd;          /* [R*S*C][K] halfs, or NULL */
+  void* w_fwd;          /* K * R*S*C halfs, or NULL: q(w) as B[n = k][q = tap * C + c] */
+  void* w_bwd;          /* R*S*C * K halfs, or NULL: q(w * kscale[k]) as B[n = c][q = tap * K + k] */
+  /* Layout of both copies when C % 64 == 0 and K % 64 == 0 (the shapes lmh_conv2d_hs_supported accepts): the fragment order
+   * of the MFMA's B operand, element (n, q) at
+   *     ((((n / 32) * (Q / 64) + q / 64) * 4 + (q % 64) / 16) * 64 + 32 * ((q % 16) / 8) + n % 32) * 8 + q % 8      (Q = q's range)
+   * — opaque working copies: lmh_conv2d_fwd_hs / lmh_conv2d_bwd_data_hs are their only readers.  Other shapes: row-major
+   * [n][q] for w_fwd, [q-major HWIO] i.e. [R*S*C][K] for w_bwd (rounds 3-5's layout; nothing reads them). */
   int32_t RS, C, K;
 } lmh_half_weight_job;
 int lmh_half_weights_batch(const lmh_half_weight_job* jobs, int n, int dtype, lmh_stream_t stream);
@@ -633,9 +638,11 @@ int lmh_optimizer_step(int kind, float* w, const float* g, float* slot1, float* 
 /* tf.nn.dropout of the RCNN head (models/fasterrcnn/rcnn.py:196,218): y = x * keep / keep_prob, keep a pure function
  * of (seed, element index) — call it again on dy with the same seed for the backward pass. */
 int lmh_dropout(const float* x, int64_t n, float keep_prob, uint32_t seed, float* y, lmh_stream_t stream);
-/* regularization_loss = sum_s wd[s] * sum(w_s^2)/2 (tf l2_regularizer), out (1) zeroed by caller. */
+/* regularization_loss = sum_s wd[s] * sum(w_s^2)/2 (tf l2_regularizer); out (1) is WRITTEN.  Two launches through `ws`
+ * (lmh_l2_reg_workspace_bytes): per-block partial sums, then their sum in block order — the same bits every call. */
+size_t lmh_l2_reg_workspace_bytes(void);
 int lmh_l2_reg_loss(const float* w, int64_t n, const int64_t* seg_offset, const float* seg_wd,
-                    int nseg, float* out, lmh_stream_t stream);
+                    int nseg, float* out, void* ws, size_t ws_bytes, lmh_stream_t stream);
 
 #ifdef __cplusplus
 }

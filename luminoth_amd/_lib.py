@@ -214,7 +214,8 @@ SIGNATURES = {
     'lmh_grad_clip_factors': (c_i, [c_f, c_f, c_i64, c_f, c_f, c_i, c_fl, c_fl, c_f, c_f, c_sz, c_f]),
     'lmh_optimizer_step': (c_i, [c_i, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_f, c_f, c_i, c_fl, c_fl, c_fl, c_fl, c_fl, c_f]),
     'lmh_dropout': (c_i, [c_f, c_i64, c_fl, ctypes.c_uint32, c_f, c_f]),
-    'lmh_l2_reg_loss': (c_i, [c_f, c_i64, c_f, c_f, c_i, c_f, c_f]),
+    'lmh_l2_reg_workspace_bytes': (c_sz, []),
+    'lmh_l2_reg_loss': (c_i, [c_f, c_i64, c_f, c_f, c_i, c_f, c_f, c_sz, c_f]),
 }
 
 

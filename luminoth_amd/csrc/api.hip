@@ -41,6 +41,8 @@ static const lmh_option g_option_defaults[] = {
     {"hs_slab_cap", 2},       // half-storage weight gradient: split-K slabs stay within this multiple of the operand bytes (0: no cap)
     {"hs_wg_tile", 0},        // half-storage 1x1 weight gradient tile: 0 = 128 x 128 when both channel counts reach it, 64 / 128 = forced (64: a quarter
                               // of the split-K slab bytes, f16 step 3.60 -> 3.67 ms: profiles/r06_ab.md)
+    {"hs_bg", 1},             // half-storage forward / backward data: B fragments straight from global memory into registers (conv_hs.h, BG); 0: through
+                              // the LDS ring like A
     {"nms_stage_mult", 0},    // > 0: NMS in two stages, A = this many x max_out candidates (mask + scan), the rest only if needed; 0: one stage
     {"head_gemm", 1},         // Linear heads on <= 4096 rows: the split-reduction 32x32 kernel (conv_generic.h k_head_fwd); 0: the tiled / skinny kernels
     {"roi_cs", 0},            // ROI backward slab width (0: automatic, 4: force the 4-channel slab)

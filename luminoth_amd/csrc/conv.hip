@@ -881,25 +881,46 @@ static int hs_launch(const lmh_conv_desc* d, const void* A, const void* B, const
   const int64_t M = BWD ? (int64_t)d->N * d->H * d->W : (int64_t)d->N * d->OH * d->OW;
   const int NC = BWD ? d->C : d->K;
   int bm, bn;
+  const bool bg = lmh_opt("hs_bg") != 0;
+  const int KT = d->R * d->S * ((BWD ? d->K : d->C) / HS_BK);
   // (round 6: a six-deep ring — 144 KB, five stages in flight, one block per CU — for the launches of about one tile per CU was
   // built, bit-identical, and LOST inside the step: forward 0.85 -> 0.99 ms of the f16 step, profiles/r06_ab.md; removed)
-  // 128 x 64 once it still gives every CU a block (fewer, longer tiles: the RPN 3x3 backward 161 -> 141 us, block3
-  // 256->1024 forward 16.2 -> 14.5 us), else 64 x 64; 128 x 128 (one block per CU) never won (scripts/bench_conv_hs.py --sweep)
+  // B through LDS (hs_bg = 0, rounds 3-5): 128 x 64 once it still gives every CU a block (fewer, longer tiles: the RPN 3x3
+  // backward 161 -> 141 us, block3 256->1024 forward 16.2 -> 14.5 us), else 64 x 64; 128 x 128 (one block per CU) never won.
+  // B straight from global memory (hs_bg = 1): a stage's LDS-DMA traffic is the A rows alone and 64 x 64 blocks (24 KB of LDS,
+  // 88 VGPRs: five per CU) win every trunk layer (scripts/bench_conv_hs.py --sweep, profiles/r06_ab.md); the long reductions
+  // with tiles to spare (RPN 3x3: 144 stages) keep 128 x 64
   if (g_force_bm && g_force_bn) { bm = g_force_bm; bn = g_force_bn; }
+  else if (bg) {
+    if (KT >= 64 && ((M + 127) / 128) * ((NC + 63) / 64) >= 256) { bm = 128; bn = 64; }
+    else { bm = 64; bn = 64; }
+  }
   else if (((M + 127) / 128) * ((NC + 63) / 64) >= 256) { bm = 128; bn = 64; }
   else { bm = 64; bn = 64; }
+  if (bm == 256) bn = 128;
+  if (bm == 64 && bn > 64 && !bg) bn = 64;            // the wide 64-row tiles exist for the register-B kernels only
+  if (bm == 64 && bn > 128) bn = 256;
   const int grid = (int)(((M + bm - 1) / bm) * ((NC + bn - 1) / bn));
-#define LAUNCH_HS(DT_, BM_, BN_)                                                                             \
-  lmh_launch((k_conv_hs<DT_, BM_, BN_, BWD>), dim3(grid), dim3(256), 0, st, *d,                         \
+#define LAUNCH_HS(DT_, BM_, BN_, BG_)                                                                        \
+  lmh_launch((k_conv_hs<DT_, BM_, BN_, BWD, BG_>), dim3(grid), dim3(256), 0, st, *d,                    \
                      reinterpret_cast<const HT<DT_>::T*>(A), reinterpret_cast<const HT<DT_>::T*>(B), e)
-#define LAUNCH_HS_T(BM_, BN_) do { if (d->compute == 1) LAUNCH_HS(1, BM_, BN_); else LAUNCH_HS(2, BM_, BN_); } while (0)
+#define LAUNCH_HS_T(BM_, BN_)                                                                                \
+  do {                                                                                                       \
+    if (d->compute == 1) { if (bg) LAUNCH_HS(1, BM_, BN_, true); else LAUNCH_HS(1, BM_, BN_, false); }       \
+    else { if (bg) LAUNCH_HS(2, BM_, BN_, true); else LAUNCH_HS(2, BM_, BN_, false); }                       \
+  } while (0)
+#define LAUNCH_HS_BG(BM_, BN_) do { if (d->compute == 1) LAUNCH_HS(1, BM_, BN_, true); else LAUNCH_HS(2, BM_, BN_, true); } while (0)
   prof_begin(st);
-  if (bm == 128 && bn == 128) LAUNCH_HS_T(128, 128);
-  else if (bm == 128) LAUNCH_HS_T(128, 64);
-  else LAUNCH_HS_T(64, 64);
+  if (bm == 256) LAUNCH_HS_T(256, 128);
+  else if (bm == 128 && bn == 128) LAUNCH_HS_T(128, 128);
+  else if (bm == 128) { bn = 64; LAUNCH_HS_T(128, 64); }
+  else if (bn == 256) LAUNCH_HS_BG(64, 256);
+  else if (bn == 128) LAUNCH_HS_BG(64, 128);
+  else { bn = 64; LAUNCH_HS_T(64, 64); }
+#undef LAUNCH_HS_BG
 #undef LAUNCH_HS_T
 #undef LAUNCH_HS
-  prof_end(st, desc_flops(d), "k_conv_hs<%d, %d, %d, %s>", d->compute, bm, bm == 128 ? bn : 64, BWD ? "true" : "false");
+  prof_end(st, desc_flops(d), "k_conv_hs<%d, %d, %d, %s, %s>", d->compute, bm, bn, BWD ? "true" : "false", bg ? "true" : "false");
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

@@ -7,9 +7,10 @@
 //
 // Forward and backward-data are ONE kernel: both are gather-GEMMs whose two operands are contiguous along the reduction
 // axis once the weight copy has the right layout — the cast pass of the optimizer step (k_half_weights, halfstore.hip) writes
-//     w_fwd[k][r][s][c] = q(w[r][s][c][k])                  ("OHWI": a row = everything one output channel multiplies)
-//     w_bwd[r][s][c][k] = q(w[r][s][c][k] * bn_scale[k])    (HWIO with the frozen-BatchNorm scale folded in)
-// so neither pass transposes anything:
+//     w_fwd  =  q(w[r][s][c][k])                  as B[n = k][q = (tap, c)]
+//     w_bwd  =  q(w[r][s][c][k] * bn_scale[k])    as B[n = c][q = (tap, k)]   (the frozen-BatchNorm scale folded in)
+// in the FRAGMENT ORDER of the MFMA's B operand ([n / 32][stage q / 64][k-step][lane][8 halfs], halfstore.hip; round 6 —
+// rounds 3-5: row-major [n][q]), so neither pass transposes anything and a wave instruction moves one contiguous 1 KB of B:
 //     forward    y[p][k]  = q( act( sum_{tap,c} x[src(p,tap)][c] * w_fwd[k][tap][c] * scale[k] + shift[k] + res[p][k] ) )
 //     backward   dx[p][c] = q( ( sum_{tap,k} g[dst(p,tap)][k] * w_bwd[tap][c][k] + addend[p][c] ) * act'(x[p][c]) )
 // with act'(x) read from the activation bit mask the forward epilogue of the producing layer wrote (conv_fast.h).
@@ -38,8 +39,9 @@ struct hs_epilogue {
   float mul;                 // accumulator multiplier (backward: 1)
 };
 
-// One stage out of the swizzled LDS image: row R holds its eight 16-byte k-chunks at chunk position c ^ ((R >> 1) & 7), so
-// the 16 rows a lane group of ds_read_b128 touches ({0-3,12-15,20-27} ...) land on 16 different 4-bank groups.
+// One stage out of LDS.  A: the swizzled image — row R holds its eight 16-byte k-chunks at chunk position c ^ ((R >> 1) & 7), so
+// the 16 rows a lane group of ds_read_b128 touches ({0-3,12-15,20-27} ...) land on 16 different 4-bank groups.  B: the 1 KB
+// chunks of the fragment-order weight copy as they are (lane-linear: conflict-free).
 template <int DT, int TM, int TN>
 __device__ __forceinline__ void hs_mma_stage(const typename HT<DT>::T* __restrict__ As,
                                              const typename HT<DT>::T* __restrict__ Bs, f32x16 (&acc)[TM][TN],
@@ -56,8 +58,8 @@ __device__ __forceinline__ void hs_mma_stage(const typename HT<DT>::T* __restric
     const int ch_ = ((2 * (s_) + hi) ^ swz) * 8;                                                                \
     _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                              \
       a[set_][t] = *reinterpret_cast<const V8*>(&As[(a_off + t * 32 + l31) * HS_BK + ch_]);                     \
-    _Pragma("unroll") for (int t = 0; t < TN; ++t)                                                              \
-      b[set_][t] = *reinterpret_cast<const V8*>(&Bs[(b_off + t * 32 + l31) * HS_BK + ch_]);                     \
+    _Pragma("unroll") for (int t = 0; t < TN; ++t)     /* B: 1 KB chunks in fragment order, (column group, k-step) */ \
+      b[set_][t] = *reinterpret_cast<const V8*>(&Bs[(((b_off >> 5) + t) * (HS_BK / 16) + (s_)) * 512 + lane * 8]); \
   } while (0)
   HS_FRAG(0, 0);
 #pragma unroll
@@ -74,35 +76,76 @@ __device__ __forceinline__ void hs_mma_stage(const typename HT<DT>::T* __restric
 #undef HS_FRAG
 }
 
-template <int BM, int BN, int NBUF>
+// The same stage with the B fragments already in registers (BG kernels: B straight from global memory, below): only the A
+// fragments come out of LDS.
+template <int DT, int TM, int TN>
+__device__ __forceinline__ void hs_mma_stage_rb(const typename HT<DT>::T* __restrict__ As, f32x16 (&acc)[TM][TN], int a_off,
+                                                int lane, const typename HT<DT>::V8 (&b)[HS_BK / 16][TN]) {
+  typedef typename HT<DT>::V8 V8;
+  const int l31 = lane & 31, hi = lane >> 5, swz = (l31 >> 1) & 7;
+  V8 a[2][TM];
+#define HS_FRAG_A(set_, s_)                                                                                     \
+  do {                                                                                                          \
+    const int ch_ = ((2 * (s_) + hi) ^ swz) * 8;                                                                \
+    _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                              \
+      a[set_][t] = *reinterpret_cast<const V8*>(&As[(a_off + t * 32 + l31) * HS_BK + ch_]);                     \
+  } while (0)
+  HS_FRAG_A(0, 0);
+#pragma unroll
+  for (int s = 0; s < HS_BK / 16; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < HS_BK / 16) HS_FRAG_A(cur ^ 1, s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[cur][tm], b[s][tn], acc[tm][tn]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef HS_FRAG_A
+}
+
+template <int BM, int BN, int NBUF, bool BG>
 struct hs_smem {
-  static constexpr int ring = NBUF * (BM + BN) * HS_BK / 2, epi = BM * (BN + 4);      // floats
+  static constexpr int ring = NBUF * (BM + (BG ? 0 : BN)) * HS_BK / 2, epi = BM * (BN + 4);      // floats
   static constexpr int floats = ring > epi ? ring : epi;
 };
-// ring depth by tile: 64 KB (two blocks per CU) for the small tiles, 96 KB (one block) at 128 x 128
-template <int BM, int BN> struct hs_nbuf { static constexpr int value = (BM + BN == 128) ? 4 : 3; };
+// ring depth by tile: 64 KB (two blocks per CU) for the small tiles, 96 KB (one block) at 128 x 128; BG kernels (A only in
+// LDS): three stages — their B loads are awaited one stage after they are issued, and with loads returning in order nothing
+// issued before them can stay in flight longer than that
+template <int BM, int BN, bool BG> struct hs_nbuf { static constexpr int value = BG ? 3 : ((BM + BN == 128) ? 4 : 3); };
 
-// BWD = false: forward (A = x, rows of B = output channels of w_fwd);  BWD = true: backward data (A = g, rows of B = input
-// channels of w_bwd).  Needs (reduction channels) % 64 == 0 and (output channels) % 8 == 0.
-// Operand rows go from global memory straight into LDS (global_load_lds_dwordx4: one wave instruction = 8 rows of 128
+template <int N> __device__ __forceinline__ void hs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BWD = false: forward (A = x, B = w_fwd);  BWD = true: backward data (A = g, B = w_bwd).
+// Needs (reduction channels) % 64 == 0 and (output channels) % 64 == 0.
+// A rows go from global memory straight into LDS (global_load_lds_dwordx4: one wave instruction = 8 rows of 128
 // bytes, lane-linear in LDS; the k-chunk a lane FETCHES is permuted so that the image is the swizzled one above), through
 // an NBUF-deep ring with NBUF - 1 stages in flight, one raw s_barrier per stage and counted vmcnt waits
 // (conv_wgrad1x1.h has the same pipeline): at 64 x 64 a stage is only 4 MFMAs per wave, so the kernel lives on how many
 // loads it keeps in the air, not on bandwidth.
-template <int DT, int BM, int BN, bool BWD>
-__global__ void __launch_bounds__(256, (BM + BN == 256) ? 1 : 2)
+// BG = false: the B chunks of a stage ride in the same ring (BN / 8 more LDS-DMA instructions per block and stage).
+// BG = true (round 6, third session): a wave loads the B fragments of its own column groups straight into registers, one
+// stage ahead (two register sets).  What bounded the LDS variant was the rate of the LDS-DMA instructions themselves
+// (scripts/r6_hs_decomp.py: the main loop without MFMAs and with every load served from one cached line still took 94 of the
+// RPN convolution's 180 us; a wave gets one 1 KB global_load_lds through every ~100 cycles, a plain global_load_dwordx4 of a
+// contiguous 1 KB takes the same path in ~16): B is a third (128 x 64) to a half (128 x 128) of a stage's LDS-DMA
+// instructions, it is the same for every row tile of a launch (L2-resident), and in fragment order it needs no LDS at all.
+template <int DT, int BM, int BN, bool BWD, bool BG>
+__global__ void __launch_bounds__(256, (BM * BN > 128 * 128 || (!BG && BM * BN == 128 * 128)) ? 1 : 2)
 k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typename HT<DT>::T* __restrict__ B,
           hs_epilogue e) {
   typedef typename HT<DT>::T HTT;
   typedef typename HT<DT>::V8 V8;
-  constexpr int NBUF = hs_nbuf<BM, BN>::value, D = NBUF - 1;
+  constexpr int NBUF = hs_nbuf<BM, BN, BG>::value, D = NBUF - 1;
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AJ = BM / 32, BJ = BN / 32;           // wave instructions per wave and stage (8 rows each, 4 waves)
+  constexpr int AJ = BM / 32, BJ = BG ? 0 : BN / 32;  // LDS-DMA instructions per wave and stage (1 KB each, 4 waves)
   constexpr int NLD = AJ + BJ;
-  constexpr int A_SZ = BM * HS_BK, STAGE = (BM + BN) * HS_BK;
+  constexpr int A_SZ = BM * HS_BK, STAGE = (BM + (BG ? 0 : BN)) * HS_BK;
   constexpr int LDC = BN + 4;
-  __shared__ __attribute__((aligned(16))) float smem[hs_smem<BM, BN, NBUF>::floats];
-  HTT* const ring = reinterpret_cast<HTT*>(smem);     // [NBUF][BM + BN][HS_BK]
+  constexpr int KS = HS_BK / 16;                      // k-steps per stage
+  __shared__ __attribute__((aligned(16))) float smem[hs_smem<BM, BN, NBUF, BG>::floats];
+  HTT* const ring = reinterpret_cast<HTT*>(smem);     // [NBUF][BM (+ BN)][HS_BK]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int M = BWD ? d.N * d.H * d.W : d.N * d.OH * d.OW;
@@ -114,7 +157,7 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int KC = KR / HS_BK, KT = RS * KC;
   // lane -> (row within the instruction's 8 rows, LDS chunk slot); instruction j of this wave covers tile rows
-  // (wave * AJ + j) * 8 .. + 7 (A set) / (wave * BJ + j) * 8 .. + 7 (B set)
+  // (wave * AJ + j) * 8 .. + 7
   const int lrow = lane >> 3, slot = lane & 7;
   // ---- A rows: output pixels (forward) / input pixels (backward)
   const int PW = BWD ? d.W : d.OW, PH = BWD ? d.H : d.OH;
@@ -160,19 +203,47 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
       inca[j] = ok ? HS_BK : 0;
     }
   };
-  // ---- B rows: forward w_fwd[k][tap][c] (taps follow each other inside a row); backward w_bwd[tap][c][k]
-  const HTT* pb[BJ];
-  int incb[BJ];
-  size_t tapb[BJ];
+  // ---- B: fragment-order chunks of 1 KB, [column group][stage][k-step] (halfstore.hip); stages follow each other across the
+  // taps.  Column groups past NC (a forced tile wider than the layer) read the last group: their columns are never stored.
+  const int NG = NC >> 5;
+  // BG = false: instruction j of this wave moves chunk c = wave * BJ + j of the block's BN / 32 * 4 chunks into LDS
+  const HTT* pb[BJ > 0 ? BJ : 1];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
-    const int r = (wave * BJ + j) * 8 + lrow;
-    const int row = n0 + r;
-    const bool ok = row < NC;
-    pb[j] = ok ? B + (size_t)row * (BWD ? (size_t)KR : (size_t)RS * KR) + 8 * (slot ^ ((r >> 1) & 7)) : zero;
-    incb[j] = ok ? HS_BK : 0;
-    tapb[j] = ok ? (BWD ? (size_t)NC * KR - KR + HS_BK : (size_t)HS_BK) : 0;
+    const int c = wave * BJ + j, g_ = min((n0 >> 5) + c / KS, NG - 1);
+    pb[j] = B + ((size_t)g_ * KT * KS + (c % KS)) * 512 + lane * 8;
   }
+  // BG = true: this wave's TN column groups, straight into registers
+  const HTT* bp[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+    bp[t] = B + (size_t)min((n0 >> 5) + wn * TN + t, NG - 1) * KT * KS * 512 + lane * 8;
+  // The loads are inline asm: the compiler's own wait for a tracked load of the PREVIOUS loop iteration is a vmcnt(0) in front
+  // of the stage's first MFMA (ISA check), which also drains the A stages just issued — the ring would never be more than one
+  // stage deep.  Here the waits are the counted ones at the top of a stage, and tie_b makes the registers a stage multiplies
+  // depend on that wait (the compiler neither knows that they are still in flight before it nor may move a use above it).
+  static_assert(KS == 4, "load_b issues the four k-steps of a stage");
+  V8 bq[2][KS][TN];
+  // (macros, not lambdas: an asm operand cannot name a captured array element)
+#define HS_LOAD_B(set_, t_)                                                                                \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int tb_ = 0; tb_ < TN; ++tb_) {                                                 \
+      const HTT* p_ = bp[tb_] + (size_t)(t_) * (KS * 512);                                                 \
+      asm volatile("global_load_dwordx4 %0, %4, off\n\t"                                                  \
+                   "global_load_dwordx4 %1, %4, off offset:1024\n\t"                                      \
+                   "global_load_dwordx4 %2, %4, off offset:2048\n\t"                                      \
+                   "global_load_dwordx4 %3, %4, off offset:3072"                                           \
+                   : "=&v"(bq[set_][0][tb_]), "=&v"(bq[set_][1][tb_]), "=&v"(bq[set_][2][tb_]),            \
+                     "=&v"(bq[set_][3][tb_])                                                               \
+                   : "v"(p_)                                                                               \
+                   : "memory");                                                                            \
+    }                                                                                                      \
+  } while (0)
+#define HS_TIE_B(set_)                                                                                     \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int sb_ = 0; sb_ < KS; ++sb_)                                                   \
+      _Pragma("unroll") for (int tb_ = 0; tb_ < TN; ++tb_) asm volatile("" : "+v"(bq[set_][sb_][tb_]));    \
+  } while (0)
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
   int rs = 0, kc = 0;
@@ -182,49 +253,72 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
   const int dbg = conv_probe_bits() >> 8;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
-  // issue the loads of the stage the pointers stand on into ring slot `buf`, then advance the pointers by one stage
+  // issue the LDS-DMA loads of the stage the pointers stand on into ring slot `buf`, then advance the pointers by one stage
 #define HS_ISSUE(buf_)                                                                                     \
   do {                                                                                                     \
     HTT* As_ = ring + (buf_) * STAGE;                                                                      \
     HTT* Bs_ = As_ + A_SZ;                                                                                 \
     _Pragma("unroll") for (int j = 0; j < AJ; ++j)                                                         \
       __builtin_amdgcn_global_load_lds((glb_ptr)((dbg & 8) ? zero : pa[j]), (lds_ptr)(As_ + (wave * AJ + j) * 8 * HS_BK), 16, 0, 0); \
-    _Pragma("unroll") for (int j = 0; j < BJ; ++j)                                                         \
-      __builtin_amdgcn_global_load_lds((glb_ptr)((dbg & 8) ? zero : pb[j]), (lds_ptr)(Bs_ + (wave * BJ + j) * 8 * HS_BK), 16, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < BJ; ++j) {                                                       \
+      __builtin_amdgcn_global_load_lds((glb_ptr)((dbg & 8) ? zero : pb[j]), (lds_ptr)(Bs_ + (wave * BJ + j) * 512), 16, 0, 0); \
+      pb[j] += KS * 512;                                                                                   \
+    }                                                                                                      \
     if (++kc == KC) {                                                                                      \
       kc = 0; ++rs;                                                                                        \
       if (rs < RS) setup_tap(rs);                                                                          \
-      _Pragma("unroll") for (int j = 0; j < BJ; ++j) pb[j] += tapb[j];                                     \
     } else {                                                                                               \
       _Pragma("unroll") for (int j = 0; j < AJ; ++j) pa[j] += inca[j];                                     \
-      _Pragma("unroll") for (int j = 0; j < BJ; ++j) pb[j] += incb[j];                                     \
     }                                                                                                      \
   } while (0)
+  if (BG) {
+    HS_LOAD_B(0, 0);                       // (the oldest loads in flight: awaited together with stage 0)
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int s = 0; s < D; ++s)
     if (s < KT) HS_ISSUE(s);
   int cur = 0;
-  for (int t = 0; t < ((dbg & 4) ? 0 : KT); ++t) {
-    // stage t has landed once at most min(D - 1, KT - 1 - t) younger stages are still in flight
-    if (KT - 1 - t >= D - 1) {
-      if (D - 1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (NLD * (D - 1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (NLD * (D - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (NLD * (D - 1) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (NLD * (D - 1) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (NLD * (D - 1) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    // raw barrier (no vmcnt drain): every wave's rows of stage t are in LDS and every wave is done reading the slot of
-    // stage t - 1, which the issue below overwrites
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (t + D < KT) HS_ISSUE(cur == 0 ? NBUF - 1 : cur - 1);
-    const HTT* As = ring + cur * STAGE;
-    if (!(dbg & 16)) hs_mma_stage<DT, TM, TN>(As, As + A_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);
-    cur = (cur + 1 == NBUF) ? 0 : cur + 1;
+  // one stage (set_: the B register set it multiplies, literal): stage t has landed once at most `allowed` younger LDS-DMA
+  // instructions are still in flight
+#define HS_STAGE(set_, t_)                                                                                 \
+  do {                                                                                                     \
+    const int t = (t_);                                                                                    \
+    if (!BG) {                                                                                             \
+      if (KT - 1 - t >= D - 1) hs_wait_vm<NLD * (D - 1)>(); else hs_wait_vm<0>();                          \
+    } else if (t == 0) {                                                                                   \
+      /* issued so far: B(0), A(0) .. A(min(D, KT) - 1) */                                                 \
+      if (KT >= D) hs_wait_vm<AJ * (D - 1)>(); else hs_wait_vm<0>();                                       \
+    } else {                                                                                               \
+      /* iteration t - 1 issued B(t), then A(t - 1 + D): everything but that last stage has to be in — B(t) with it */ \
+      /* (loads return in order) */                                                                        \
+      if (t - 1 + D < KT) hs_wait_vm<AJ>(); else hs_wait_vm<0>();                                          \
+    }                                                                                                      \
+    if (BG) HS_TIE_B(set_);                                                                                \
+    /* raw barrier (no vmcnt drain): every wave's rows of stage t are in LDS and every wave is done reading the slot of */ \
+    /* stage t - 1, which the issue below overwrites */                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                        \
+    if (BG) {                                                                                              \
+      if (t + 1 < KT) HS_LOAD_B((set_) ^ 1, t + 1);                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }                                                                                                      \
+    if (t + D < KT) HS_ISSUE(cur == 0 ? NBUF - 1 : cur - 1);                                               \
+    const HTT* As = ring + cur * STAGE;                                                                    \
+    if (!(dbg & 16)) {                                                                                     \
+      if (BG) hs_mma_stage_rb<DT, TM, TN>(As, acc, wm * (BM / 2), lane, bq[set_]);                         \
+      else hs_mma_stage<DT, TM, TN>(As, As + A_SZ, acc, wm * (BM / 2), wn * (BN / 2), lane);               \
+    }                                                                                                      \
+    cur = (cur + 1 == NBUF) ? 0 : cur + 1;                                                                 \
+  } while (0)
+  {
+    const int kt_run = (dbg & 4) ? 0 : KT;
+    int t2 = 0;
+    for (; t2 + 1 < kt_run; t2 += 2) { HS_STAGE(0, t2); HS_STAGE(1, t2 + 1); }
+    if (t2 < kt_run) HS_STAGE(0, t2);
   }
+#undef HS_STAGE
+#undef HS_TIE_B
+#undef HS_LOAD_B
 #undef HS_ISSUE
   __syncthreads();      // the epilogue tile overlays the ring
   // ---- epilogue through LDS: a thread owns 8 consecutive output channels of a row (one 16-byte half store).

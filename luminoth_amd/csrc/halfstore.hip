@@ -18,6 +18,17 @@ template <int DT> __device__ __forceinline__ typename HS<DT>::T hs_sat(float v) 
   return (typename HS<DT>::T)(DT == 1 ? fminf(fmaxf(v, -65504.f), 65504.f) : v);
 }
 
+// q(v * ks) for the backward weight copy: ONE rounding of the exact product for f16 (v_fma_mixlo_f16: fp32 sources, the
+// fused result rounded straight to f16 — what the compiler picks for (T)(v * ks) in some contexts and not in others; tests
+// pin the single rounding); bf16: the fp32 product, then round-to-nearest-even.
+template <int DT> __device__ __forceinline__ typename HS<DT>::T hs_mul_round(float v, float ks);
+template <> __device__ __forceinline__ _Float16 hs_mul_round<1>(float v, float ks) {
+  uint32_t r = 0;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(r) : "v"(v), "v"(ks));
+  return __builtin_bit_cast(_Float16, (uint16_t)r);
+}
+template <> __device__ __forceinline__ __bf16 hs_mul_round<2>(float v, float ks) { return (__bf16)(v * ks); }
+
 #define HS_DISPATCH(dtype, CALL)                                  \
   do {                                                            \
     if ((dtype) == 1) { CALL(1); } else { CALL(2); }              \
@@ -83,8 +94,18 @@ extern "C" int lmh_cast_to_f32(const void* x, int64_t n, float mul, float* y, in
   return LMH_OK;
 }
 
-// ---- working copies of the weights (conv_hs.h): w (RS, C, K) fp32 ->  w_fwd [K][RS*C] = q(w),  w_bwd [RS*C][K] = q(w * kscale[k])
-// One launch for many layers: 64 x 64 tiles of the (RS*C) x K matrix, transposed through LDS for the forward copy.
+// ---- working copies of the weights (conv_hs.h): w (RS, C, K) fp32 ->  w_fwd = q(w),  w_bwd = q(w * kscale[k])
+// One launch for many layers: 64 x 64 tiles of the (RS*C) x K matrix through LDS.
+//
+// Layout (round 6, third session).  Both copies are the B operand of a gather-GEMM  out[p][n] = sum_q A[p][q] * B[n][q]:
+//     forward    n = output channel k,  q = tap * C + c      (B[n][q] = q(w[tap][c][k]))
+//     backward   n = input channel c,   q = tap * K + k      (B[n][q] = q(w[tap][c][k] * kscale[k]))
+// When C % 64 == 0 and K % 64 == 0 (every layer conv_hs.h accepts) a copy is stored in the FRAGMENT ORDER of
+// v_mfma_f32_32x32x16_{f16,bf16}:  [n / 32][q / 64 (stage)][(q % 64) / 16 (k-step)][lane = 32 * ((q % 16) / 8) + n % 32][q % 8]
+// — the 16 bytes lane `lane` holds as the B operand of k-step (q % 64) / 16, so that one wave instruction moves one
+// contiguous 1 KB whether it goes to LDS (global_load_lds, lane-linear) or straight into the operand registers.
+// (Rounds 3-5 kept row-major copies, [K][RS*C] and [RS*C][K]: a B row of a stage was 128 contiguous bytes and always went
+// through LDS.)  Other shapes keep the row-major copies (no kernel reads them).
 #define HW_BATCH_MAX 48
 struct half_weight_batch {
   lmh_half_weight_job job[HW_BATCH_MAX];
@@ -96,7 +117,9 @@ template <int DT>
 __global__ void __launch_bounds__(256)
 k_half_weights(half_weight_batch b) {
   typedef typename HS<DT>::T T;
+  typedef typename HS<DT>::V8 V8;
   __shared__ float tile[64][65];
+  __shared__ float sks[64];
   int j = 0;
   while (j + 1 < b.n && (int)blockIdx.x >= b.first_block[j + 1]) ++j;
   const lmh_half_weight_job jb = b.job[j];
@@ -107,21 +130,48 @@ k_half_weights(half_weight_batch b) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   T* wf = reinterpret_cast<T*>(jb.w_fwd);
   T* wb = reinterpret_cast<T*>(jb.w_bwd);
+  const bool frag = (jb.C % 64) == 0 && (K % 64) == 0;
   const float ks = (jb.kscale && k0 + tx < K) ? jb.kscale[k0 + tx] : 1.f;
+  if (ty == 0) sks[tx] = ks;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, k = k0 + tx;
     float v = 0.f;
     if (r < rows && k < K) {
       v = jb.w[(size_t)r * K + k];
-      if (wb) wb[(size_t)r * K + k] = (T)(v * ks);     // weights: no saturation (one rounding of the exact product, v_fma_mixlo_f16)
+      if (wb && !frag) wb[(size_t)r * K + k] = hs_mul_round<DT>(v, ks);     // weights: no saturation
     }
     tile[i][tx] = v;
   }
   __syncthreads();
-  if (wf) {
-    for (int i = ty; i < 64; i += 4) {
-      const int k = k0 + i, r = r0 + tx;
-      if (k < K && r < rows) wf[(size_t)k * rows + r] = (T)tile[tx][i];
+  if (!frag) {
+    if (wf) {
+      for (int i = ty; i < 64; i += 4) {
+        const int k = k0 + i, r = r0 + tx;
+        if (k < K && r < rows) wf[(size_t)k * rows + r] = (T)tile[tx][i];
+      }
+    }
+    return;
+  }
+  // fragment order: the tile is one stage of the forward copy (q = r0 .. r0 + 63) for two 32-column groups (k0 / 32 + {0, 1}),
+  // and one stage of the backward copy (tap r0 / C, q = tap * K + k0 ..) for the two groups c0 / 32 + {0, 1}
+  const int tap = r0 / jb.C, c0 = r0 - tap * jb.C;
+  const int KTf = rows >> 6, KTb = (jb.RS * K) >> 6;
+  const int tf = r0 >> 6, tb = tap * (K >> 6) + (k0 >> 6);
+#pragma unroll
+  for (int e = threadIdx.x; e < 512; e += 256) {
+    const int ntl = e >> 8, s = (e >> 6) & 3, lane = e & 63;
+    const int hi = lane >> 5, l31 = lane & 31, q0 = 16 * s + 8 * hi;
+    if (wf) {
+      V8 h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h[i] = (T)tile[q0 + i][32 * ntl + l31];
+      *reinterpret_cast<V8*>(wf + ((((size_t)((k0 >> 5) + ntl) * KTf + tf) * 4 + s) * 64 + lane) * 8) = h;
+    }
+    if (wb) {
+      V8 h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h[i] = hs_mul_round<DT>(tile[32 * ntl + l31][q0 + i], sks[q0 + i]);
+      *reinterpret_cast<V8*>(wb + ((((size_t)((c0 >> 5) + ntl) * KTb + tb) * 4 + s) * 64 + lane) * 8) = h;
     }
   }
 }

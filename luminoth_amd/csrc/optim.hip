@@ -181,16 +181,37 @@ k_l2_reg(const float* __restrict__ w, int64_t n, const int64_t* __restrict__ seg
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, (sh[0] + sh[1]) + (sh[2] + sh[3]));
+  // one partial per block, added up by k_l2_reg_finish in block order: the reported scalar is the same bits every step
+  // (round 6: the blocks used to add into `out` atomically, in arrival order — 1e-7 of run-to-run noise on a reported value)
+  if (threadIdx.x == 0) out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+#define L2_MAX_BLOCKS 1024
+__global__ void __launch_bounds__(256)
+k_l2_reg_finish(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+  __shared__ float sh[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) a += partial[i];      // (fixed assignment, fixed order)
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+extern "C" size_t lmh_l2_reg_workspace_bytes(void) { return L2_MAX_BLOCKS * sizeof(float); }
+
 extern "C" int lmh_l2_reg_loss(const float* w, int64_t n, const int64_t* seg_offset, const float* seg_wd,
-                               int nseg, float* out, lmh_stream_t stream) {
+                               int nseg, float* out, void* ws, size_t ws_bytes, lmh_stream_t stream) {
   LMH_CHECK_ARG(w && seg_offset && seg_wd && out && n > 0 && nseg > 0 && nseg <= OPT_MAX_SEG);
+  if (!ws || ws_bytes < lmh_l2_reg_workspace_bytes()) { lmh_set_error("lmh_l2_reg_loss: workspace too small"); return LMH_ERR_WORKSPACE; }
   const int64_t n4 = n >> 2;
-  const int blocks = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 + 1 : 1024);
-  lmh_launch(k_l2_reg, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, n, seg_offset,
-                     seg_wd, nseg, out);
+  const int blocks = (int)((n4 + 255) / 256 < L2_MAX_BLOCKS ? (n4 + 255) / 256 + 1 : L2_MAX_BLOCKS);
+  float* partial = reinterpret_cast<float*>(ws);
+  lmh_launch(k_l2_reg, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, n, seg_offset, seg_wd, nseg, partial);
+  lmh_launch(k_l2_reg_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, blocks, out);
   LMH_CHECK_LAUNCH();
   return LMH_OK;
 }

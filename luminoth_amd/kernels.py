@@ -787,9 +787,19 @@ def conv_hs_ok(d):
     return bool(_lib.load().lmh_conv2d_hs_supported(ctypes.byref(d)))
 
 
+def hs_fragment_order(b_nq):
+    """The layout lmh_half_weights_batch gives a working copy when C % 64 == 0 and K % 64 == 0 (include/luminoth_hip.h,
+    lmh_half_weight_job): B (N, Q) -> flat [N/32][Q/64][4 k-steps][lane = 32 * (q % 16 // 8) + n % 32][q % 8] — the B operand
+    fragments of v_mfma_f32_32x32x16_*.  Host-side restatement for tests and tools (the product never needs it)."""
+    N, Q = b_nq.shape
+    assert N % 32 == 0 and Q % 64 == 0, (N, Q)
+    return b_nq.reshape(N // 32, 32, Q // 64, 4, 2, 8).permute(0, 2, 3, 4, 1, 5).contiguous().reshape(-1)
+
+
 def half_weights_batch(jobs, storage):
-    """jobs: [(w (R,S,C,K) fp32, kscale (K,) or None, w_fwd half (K,R,S,C) or None, w_bwd half (R,S,C,K) or None)]: the
-    working copies of every layer in one launch (per 48 layers)."""
+    """jobs: [(w (R,S,C,K) fp32, kscale (K,) or None, w_fwd half (K*R*S*C elements) or None, w_bwd half or None)]: the
+    working copies of every layer in one launch (per 48 layers).  The copies are opaque operands of conv2d_fwd_hs /
+    conv2d_bwd_data_hs (fragment order, hs_fragment_order, for the shapes those accept)."""
     if not jobs:
         return
     code, tdt = half_type(storage)
@@ -1247,9 +1257,11 @@ def dropout(x, keep_prob, seed):
 
 def l2_reg_loss(w, seg_offset, seg_wd, out=None):
     lib = _lib.load()
-    out = zero_(out if out is not None else torch.empty((1,), dtype=torch.float32, device=w.device))
-    check(lib.lmh_l2_reg_loss(_p(w), w.numel(), _p(seg_offset), _p(seg_wd), seg_wd.numel(), _p(out),
-                              _stream()), 'lmh_l2_reg_loss')
+    out = out if out is not None else torch.empty((1,), dtype=torch.float32, device=w.device)
+    nbytes = lib.lmh_l2_reg_workspace_bytes()
+    ws = _workspace(nbytes, w.device, 'l2reg')
+    check(lib.lmh_l2_reg_loss(_p(w), w.numel(), _p(seg_offset), _p(seg_wd), seg_wd.numel(), _p(out), _p(ws),
+                              ctypes.c_size_t(ws.numel()), _stream()), 'lmh_l2_reg_loss')
     return out
 
 

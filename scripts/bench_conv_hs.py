@@ -14,6 +14,7 @@ storage = sys.argv[1] if len(sys.argv) > 1 else 'f16'
 flt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('--') else ''
 sweep = '--sweep' in sys.argv
 only = [a[7:] for a in sys.argv if a.startswith('--only=')]
+bgs = [int(a[5:]) for a in sys.argv if a.startswith('--bg=')]      # hs_bg: B fragments from global memory (1) / through LDS (0)
 B = 2
 S4, S8, S16 = (200, 334), (100, 167), (50, 84)
 LAYERS = [
@@ -28,6 +29,8 @@ LAYERS = [
     ('b3 1x1 1024->256', S16, 1024, 256, 1, 1, 'SAME'), ('rpn 3x3 1024->512', S16, 1024, 512, 3, 1, 'SAME'),
 ]
 dev = torch.device('cuda:0')
+if bgs:
+    K.set_option('hs_bg', bgs[0])
 _, tdt = K.half_type(storage)
 lib = K._lib.load()
 
@@ -70,7 +73,7 @@ def main():
             tot[i] += t
             row += ' %s %6.1f us %5.0f TF %4.2f TB/s %-14s|' % (op, t, fl / t / 1e6, by / t / 1e6, kn[kn.index('<') + 4:-1] if '<' in kn else kn)
             if sweep:
-                cfgs = ((64, 64, 0), (128, 64, 0), (128, 128, 0)) if op != 'wgr' else \
+                cfgs = ((64, 64, 0), (64, 128, 0), (64, 256, 0), (128, 64, 0), (128, 128, 0), (256, 128, 0)) if op != 'wgr' else \
                     ((64, 64, 0), (64, 64, 2), (64, 64, 4), (64, 64, 8), (64, 64, 16), (128, 128, 0), (128, 128, 4), (128, 128, 8), (128, 128, 16))
                 for bm, bn, sp in cfgs:
                     lib.lmh_conv2d_force_config(bm, bn, sp)

@@ -20,7 +20,8 @@ def run(storage, tdt, N, H, W, C, Kc, R, gs):
     K.half_weights_batch([(w.to(dev), scale.to(dev), wf, wb)], storage)
     # forward fp32-out vs fp64 reference and vs the fp32 MFMA kernel on the same rounded operands
     y = K.conv2d_fwd_hs(d, x.to(dev), wf, out_f32=True).cpu().double()
-    wq = wf.permute(1, 2, 3, 0).contiguous()      # HWIO rounded
+    wq = w.to(tdt).to(dev)      # HWIO rounded (wf / wb themselves are in MFMA fragment order: opaque)
+    wbq = (torch.tensor((w.double().numpy() * scale.double().numpy()).astype(np.float16)) if storage == 'f16' else (w * scale).to(tdt)).to(dev)
     K.WINOGRAD = False
     y32 = K.conv2d_fwd(d32, x.to(dev).float(), wq.float()).cpu().double()
     ref = ot.conv2d_nhwc(x.double(), wq.cpu().double(), 1, 1, 'SAME')
@@ -30,9 +31,9 @@ def run(storage, tdt, N, H, W, C, Kc, R, gs):
         float((y32 - ref).abs().max()) / sc, float((y32 - ref).pow(2).mean().sqrt()) / sc))
     g = torch.tensor((rs.randn(N, H, W, Kc) * gs).astype(F)).to(tdt)
     dx = K.conv2d_bwd_data_hs(d, g.to(dev), wb).cpu()
-    dx32 = K.conv2d_bwd_data(d32, g.to(dev).float(), wb.float()).cpu().double()
+    dx32 = K.conv2d_bwd_data(d32, g.to(dev).float(), wbq.float()).cpu().double()
     xt = x.double().clone().requires_grad_(True)
-    ot.conv2d_nhwc(xt, wb.cpu().double(), 1, 1, 'SAME').backward(g.double())
+    ot.conv2d_nhwc(xt, wbq.cpu().double(), 1, 1, 'SAME').backward(g.double())
     r = xt.grad
     sc = float(r.abs().max())
     rq = r.float().to(tdt)

@@ -114,7 +114,13 @@ def test_half_weight_copies_are_exact(K, storage):
             rb = T((w.double().cpu().numpy() * ks.double().cpu().numpy()).astype(np.float16))
         else:
             rb = (w * ks).to(tdt)
-        refs.append((w.to(tdt).permute(3, 0, 1, 2).contiguous(), rb))
+        rf = w.to(tdt).permute(3, 0, 1, 2).contiguous()
+        if C % 64 == 0 and Kc % 64 == 0:
+            # the shapes the half-storage kernels accept: both copies in the MFMA's B-fragment order (include/luminoth_hip.h),
+            # forward B[n = k][q = (tap, c)], backward B[n = c][q = (tap, k)]
+            rf = K.hs_fragment_order(rf.reshape(Kc, R * R * C)).reshape(rf.shape)
+            rb = K.hs_fragment_order(rb.reshape(R * R, C, Kc).permute(1, 0, 2).reshape(C, R * R * Kc)).reshape(rb.shape)
+        refs.append((rf, rb))
     K.half_weights_batch(jobs * 12, storage)          # 60 jobs: more than one launch
     for (w, ks, wf, wb), (rf, rb) in zip(jobs, refs):
         assert torch.equal(wf, rf) and torch.equal(wb, rb)
@@ -161,7 +167,10 @@ def test_hs_convolution_kernels(K, case, storage):
     xm = rs.rand(N * H * W, C) > 0.4
     xbits = T(np.packbits(xm.reshape(-1, C // 32, 32), axis=-1, bitorder='little').view(np.int32).reshape(-1, C // 32))
     xt = x.double().clone().requires_grad_(True)
-    ot.conv2d_nhwc(xt, wb.cpu().double(), stride, dil, padding).backward(g.double())      # the copy test pins wb itself
+    # q(w * scale) as the copy test pins it (one rounding of the exact product for f16; wb itself is in fragment order)
+    wbq = (torch.tensor((w.double().numpy() * scale.double().numpy()).astype(np.float16)) if storage == 'f16'
+           else (w * scale).to(tdt))
+    ot.conv2d_nhwc(xt, wbq.double(), stride, dil, padding).backward(g.double())
     dx_ref = xt.grad
     dx = K.conv2d_bwd_data_hs(d, g.to(dev()), wb)
     assert_half_close(dx, dx_ref, storage, 'bwd_data')
@@ -183,6 +192,54 @@ def test_hs_convolution_kernels(K, case, storage):
     np.testing.assert_allclose(cs.cpu().numpy(), cs_ref, rtol=1e-4, atol=2e-5 * float(np.abs(cs_ref).max()))
     dw2 = K.conv2d_bwd_weight_hs(d, x.to(dev()), g.to(dev()), inv)
     assert torch.equal(dw2, dw)
+
+
+@pytest.mark.parametrize('storage', ['f16', 'bf16'])
+@pytest.mark.parametrize('case', [HS_CASES[1], HS_CASES[2], HS_CASES[5], HS_CASES[6], (2, 9, 11, 64, 64, 1, 1, 1, 'SAME', 'relu')])
+def test_hs_tiles_and_b_paths_agree_bit_for_bit(K, case, storage):
+    """Every tile (64 x 64 / 128 / 256, 128 x 64 / 128, 256 x 128) and both routes of the B operand (hs_bg = 1: fragments straight from
+    global memory into registers; 0: through the LDS ring) multiply the same fragments in the same order: the 16-bit results,
+    the fp32 results and the activation masks are the same bits.  (A single-stage reduction, odd row counts, tiles wider than
+    the layer and the 16-stage block3 shape are among the cases.)"""
+    N, H, W, C, Kc, R, stride, dil, padding, act = case
+    tdt = TORCH_DT[storage]
+    rs = np.random.RandomState(7)
+    x = T(rs.randn(N, H, W, C).astype(F)).to(tdt)
+    w = T((rs.randn(R, R, C, Kc) * np.sqrt(2.0 / (R * R * C))).astype(F))
+    scale, shift = T((1 + 0.1 * rs.randn(Kc)).astype(F)), T((0.1 * rs.randn(Kc)).astype(F))
+    d = K.conv_desc(x.shape, w.shape, stride, dil, padding, act, storage)
+    res = T(rs.randn(N, d.OH, d.OW, Kc).astype(F)).to(tdt)
+    g = T((rs.randn(N, d.OH, d.OW, Kc) * 0.05).astype(F)).to(tdt)
+    add = T((rs.randn(N, H, W, C) * 0.05).astype(F)).to(tdt)
+    xbits = T(np.packbits(rs.rand(N * H * W, C // 32, 32) > 0.4, axis=-1, bitorder='little').view(np.int32).reshape(-1, C // 32))
+    wf = torch.empty((Kc, R, R, C), dtype=tdt, device=dev())
+    wb = torch.empty((R, R, C, Kc), dtype=tdt, device=dev())
+    K.half_weights_batch([(w, scale, wf, wb)], storage)
+    lib = K._lib.load()
+
+    def run():
+        bits = K.new_act_bits(N * d.OH * d.OW, Kc, dev()) if act else None
+        y = K.conv2d_fwd_hs(d, x, wf, scale, shift, res, act_bits=bits)
+        y32 = K.conv2d_fwd_hs(d, x, wf, None, None, None, out_f32=True)
+        dx = K.conv2d_bwd_data_hs(d, g, wb, addend=add, xbits=xbits)
+        dx32 = K.conv2d_bwd_data_hs(d, g, wb, out_f32=True, mul=0.5)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (y, y32, dx, dx32)] + ([bits.clone()] if act else [])
+    old = K.get_option('hs_bg')
+    try:
+        ref = None
+        for bg in (1, 0):
+            K.set_option('hs_bg', bg)
+            for bm, bn in ((0, 0), (64, 64), (64, 128), (64, 256), (128, 64), (128, 128), (256, 128)):      # (64-row wide tiles: hs_bg = 1 only, else 64 x 64)
+                lib.lmh_conv2d_force_config(bm, bn, 0)
+                out = run()
+                if ref is None:
+                    ref = out
+                for name, a, b in zip(('y', 'y32', 'dx', 'dx32', 'bits'), out, ref):
+                    assert torch.equal(a, b), (name, bg, bm, bn)
+    finally:
+        lib.lmh_conv2d_force_config(0, 0, 0)
+        K.set_option('hs_bg', old)
 
 
 @pytest.mark.parametrize('storage', ['f16', 'bf16'])

@@ -923,6 +923,14 @@ def test_sgd_momentum_and_l2(K):
     reg = K.l2_reg_loss(wt, T(off), T(wd))
     wde = np.repeat(wd, sizes)
     np.testing.assert_allclose(float(reg), float((wde * w.astype(np.float64) ** 2 / 2).sum()), rtol=1e-5)
+    # the reported regulariser is the same bits every call (per-block partials added in block order; it used to be an atomic
+    # sum in arrival order): a tensor large enough for the 1024-block grid, twenty calls
+    big = T(rs.randn(3_000_001).astype(F))
+    boff, bwd = T(np.array([0, 1_000_000, 3_000_001], np.int64)), T(np.array([5e-4, 1e-4], F))
+    vals = set(float(K.l2_reg_loss(big, boff, bwd)) for _ in range(20))
+    assert len(vals) == 1, vals
+    bw = big.double().cpu().numpy()
+    np.testing.assert_allclose(vals.pop(), 5e-4 * (bw[:1_000_000] ** 2).sum() / 2 + 1e-4 * (bw[1_000_000:] ** 2).sum() / 2, rtol=1e-5)
     K.sgd_momentum(wt, gt_, vt, T(off), T(wd), lr=3e-4, momentum=0.9, gscale=0.5)
     gg = g * F(0.5) + wde * w
     vv = F(0.9) * v + gg
