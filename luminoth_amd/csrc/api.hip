@@ -43,6 +43,7 @@ static const lmh_option g_option_defaults[] = {
                               // of the split-K slab bytes, f16 step 3.60 -> 3.67 ms: profiles/r06_ab.md)
     {"hs_bg", 1},             // half-storage forward / backward data: B fragments straight from global memory into registers (conv_hs.h, BG); 0: through
                               // the LDS ring like A
+    {"hs_wg_rs", 1},          // half-storage weight gradient: tiles through registers + ds_write_b128 (k_wgrad_hs_tr RS = 4); 0: LDS-DMA instructions
     {"nms_stage_mult", 0},    // > 0: NMS in two stages, A = this many x max_out candidates (mask + scan), the rest only if needed; 0: one stage
     {"head_gemm", 1},         // Linear heads on <= 4096 rows: the split-reduction 32x32 kernel (conv_generic.h k_head_fwd); 0: the tiled / skinny kernels
     {"roi_cs", 0},            // ROI backward slab width (0: automatic, 4: force the 4-channel slab)

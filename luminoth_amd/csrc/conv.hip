@@ -899,7 +899,7 @@ static int hs_launch(const lmh_conv_desc* d, const void* A, const void* B, const
   else { bm = 64; bn = 64; }
   if (bm == 256) bn = 128;
   if (bm == 64 && bn > 64 && !bg) bn = 64;            // the wide 64-row tiles exist for the register-B kernels only
-  if (bm == 64 && bn > 128) bn = 256;
+  if (bm == 64 && bn > 128) bn = 128;
   const int grid = (int)(((M + bm - 1) / bm) * ((NC + bn - 1) / bn));
 #define LAUNCH_HS(DT_, BM_, BN_, BG_)                                                                        \
   lmh_launch((k_conv_hs<DT_, BM_, BN_, BWD, BG_>), dim3(grid), dim3(256), 0, st, *d,                    \
@@ -914,7 +914,6 @@ static int hs_launch(const lmh_conv_desc* d, const void* A, const void* B, const
   if (bm == 256) LAUNCH_HS_T(256, 128);
   else if (bm == 128 && bn == 128) LAUNCH_HS_T(128, 128);
   else if (bm == 128) { bn = 64; LAUNCH_HS_T(128, 64); }
-  else if (bn == 256) LAUNCH_HS_BG(64, 256);
   else if (bn == 128) LAUNCH_HS_BG(64, 128);
   else { bn = 64; LAUNCH_HS_T(64, 64); }
 #undef LAUNCH_HS_BG
@@ -1010,19 +1009,22 @@ extern "C" int lmh_conv2d_bwd_weight_hs(const lmh_conv_desc* d, const void* x, c
   // 1x1 / stride 1: source pixel == output pixel, no decode in the loader
   const bool gather = !(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->OH == d->H &&
                         d->OW == d->W);
-#define LAUNCH_BW_TR(DT_, BM_, G_)                                                                           \
-  lmh_launch((k_wgrad_hs_tr<DT_, BM_, BM_, G_>), dim3(tx * ty * splits), dim3(256), 0, st, *d,            \
+  const bool rs = lmh_opt("hs_wg_rs") != 0;      // tiles through registers (k_wgrad_hs_tr RS = 4) / LDS-DMA instructions
+#define LAUNCH_BW_TR(DT_, BM_, G_, RS_)                                                                      \
+  lmh_launch((k_wgrad_hs_tr<DT_, BM_, BM_, G_, RS_>), dim3(tx * ty * splits), dim3(256), 0, st, *d,       \
                      reinterpret_cast<const HT<DT_>::T*>(x), reinterpret_cast<const HT<DT_>::T*>(g), out, kps, dvw, dvh, \
                      inv_scale, tx, ty, splits, cpart)
+#define LAUNCH_BW_TR_G(DT_, BM_, G_) do { if (rs) LAUNCH_BW_TR(DT_, BM_, G_, 4); else LAUNCH_BW_TR(DT_, BM_, G_, 0); } while (0)
 #define LAUNCH_BW_TR_T(BM_)                                                                                  \
   do {                                                                                                       \
-    if (d->compute == 1) { if (gather) LAUNCH_BW_TR(1, BM_, true); else LAUNCH_BW_TR(1, BM_, false); }        \
-    else { if (gather) LAUNCH_BW_TR(2, BM_, true); else LAUNCH_BW_TR(2, BM_, false); }                        \
+    if (d->compute == 1) { if (gather) LAUNCH_BW_TR_G(1, BM_, true); else LAUNCH_BW_TR_G(1, BM_, false); }    \
+    else { if (gather) LAUNCH_BW_TR_G(2, BM_, true); else LAUNCH_BW_TR_G(2, BM_, false); }                    \
   } while (0)
   prof_begin(st);
   if (bm == 128) LAUNCH_BW_TR_T(128); else LAUNCH_BW_TR_T(64);
-  prof_end(st, desc_flops(d), "k_wgrad_hs_tr<%d, %d, %d, %s>", d->compute, bm, bn, gather ? "true" : "false");
+  prof_end(st, desc_flops(d), "k_wgrad_hs_tr<%d, %d, %d, %s, %d>", d->compute, bm, bn, gather ? "true" : "false", rs ? 4 : 0);
 #undef LAUNCH_BW_TR_T
+#undef LAUNCH_BW_TR_G
 #undef LAUNCH_BW_TR
   if (g_lmh_defer_tail) {
     g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;

@@ -249,7 +249,8 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
   int rs = 0, kc = 0;
   setup_tap(0);
   // timing decomposition (probe builds only; scripts/r6_hs_decomp.py): bits 8.. of the probe word — 1 no residual / addend /
-  // mask reads, 2 no output stores, 4 no main loop, 8 loads from the zero page, 16 no MFMA phase.  Wrong results.
+  // mask reads, 2 no output stores, 4 no main loop, 8 A rows from the zero page, 16 no MFMA phase, 32 no B loads past stage 0.
+  // Wrong results.
   const int dbg = conv_probe_bits() >> 8;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -299,7 +300,7 @@ k_conv_hs(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ A, const typen
     /* stage t - 1, which the issue below overwrites */                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                        \
     if (BG) {                                                                                              \
-      if (t + 1 < KT) HS_LOAD_B((set_) ^ 1, t + 1);                                                        \
+      if (t + 1 < KT && !(dbg & 32)) HS_LOAD_B((set_) ^ 1, t + 1);                                         \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
     }                                                                                                      \
     if (t + D < KT) HS_ISSUE(cur == 0 ? NBUF - 1 : cur - 1);                                               \
@@ -452,14 +453,20 @@ __device__ __forceinline__ hs_s16x4 hs_tr_read(const void* p) {      // 16-bit e
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)p);
 }
 
-template <int DT, int BM, int BN, bool GATHER>
+// RS = 0: the tiles go from global memory into the LDS ring with LDS-DMA instructions (rounds 3-5).  RS = 4 (round 6, third
+// session): through registers — global_load_dwordx4 into one of four register sets, three stages ahead, ds_write_b128 into
+// the same lane-linear image (two LDS slots) one stage ahead.  An unsplit 256-tile launch of the LDS-DMA kernel takes 1.16 us per
+// 32 KB stage and CU = 28 GB/s per CU (scripts/probes/r6_wgrad_group_potential.py), the rate MI355X_MICROARCH.md measures for
+// the LDS-DMA path itself (~25 GB/s per CU, 6.4 TB/s over the chip) — a fifth of what the vector caches deliver to registers.
+template <int DT, int BM, int BN, bool GATHER, int RS = 0>
 __global__ void __launch_bounds__(256, (BM + BN == 256) ? 1 : 2)
 k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const typename HT<DT>::T* __restrict__ g,
               float* __restrict__ out, int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh, float inv_scale,
               int tiles_x, int tiles_y, int splits, float* __restrict__ colpart) {
   typedef typename HT<DT>::T HTT;
   typedef typename HT<DT>::V8 V8;
-  constexpr int NBUF = (BM + BN == 128) ? 4 : 3, D = NBUF - 1;
+  constexpr int NBUF = RS ? 2 : ((BM + BN == 128) ? 4 : 3), D = NBUF - 1;
+  static_assert(RS == 0 || RS == 4, "register sets: four (unrolled by hand)");
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A_LPR = BM / 8, B_LPR = BN / 8;              // lanes (16-byte chunks) per tile row
   constexpr int A_RPI = 64 / A_LPR, B_RPI = 64 / B_LPR;      // tile rows per wave instruction
@@ -500,11 +507,8 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
   int pst = kt_begin * HSW_BK;           // first pixel of the next stage to issue
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
-#define HSW_ISSUE(buf_)                                                                                     \
-  do {                                                                                                      \
-    HTT* As_ = ring + (buf_) * STAGE;                                                                       \
-    HTT* Bs_ = As_ + A_SZ;                                                                                  \
-    _Pragma("unroll") for (int j = 0; j < A_NI; ++j) {                                                      \
+  // source of instruction j of this wave for the stage at `pst` (the zero page for rows / channels outside)
+#define HSW_SRC_A(j, src)                                                                                   \
       const unsigned p = (unsigned)(pst + a_row[j]);                                                        \
       const HTT* src = zero;                                                                                \
       if (GATHER) {                                                                                         \
@@ -515,15 +519,52 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
           src = x + ((size_t)((int)n * d.H + ih) * d.W + iw) * C + a_col[j];                                \
       } else if (a_cok[j] && (int)p < P) {                                                                  \
         src = x + (size_t)p * C + a_col[j];                                                                 \
-      }                                                                                                     \
+      }
+#define HSW_SRC_B(j, src)                                                                                   \
+      const int p = pst + b_row[j];                                                                         \
+      const HTT* src = (b_cok[j] && p < P) ? g + (size_t)p * K + b_col[j] : zero;
+#define HSW_ISSUE(buf_)                                                                                     \
+  do {                                                                                                      \
+    HTT* As_ = ring + (buf_) * STAGE;                                                                       \
+    HTT* Bs_ = As_ + A_SZ;                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < A_NI; ++j) {                                                      \
+      HSW_SRC_A(j, src)                                                                                     \
       __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(As_ + (wave * A_NI + j) * A_RPI * BM), 16, 0, 0); \
     }                                                                                                       \
     _Pragma("unroll") for (int j = 0; j < B_NI; ++j) {                                                      \
-      const int p = pst + b_row[j];                                                                         \
-      const HTT* src = (b_cok[j] && p < P) ? g + (size_t)p * K + b_col[j] : zero;                           \
+      HSW_SRC_B(j, src)                                                                                     \
       __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(Bs_ + (wave * B_NI + j) * B_RPI * BN), 16, 0, 0); \
     }                                                                                                       \
     pst += HSW_BK;                                                                                          \
+  } while (0)
+  // RS: the same 16 bytes per lane into register set set_ (literal) / from that set into LDS slot buf_ (the lane-linear image the
+  // LDS-DMA instruction writes).  Inline asm loads: the waits are counted by hand (vector-memory loads return in order), and the
+  // empty asm in front of a store makes the registers depend on the wait that precedes it.
+  V8 rg[RS ? RS : 1][NLD];
+#define HSW_LOAD(set_)                                                                                      \
+  do {                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < A_NI; ++j) {                                                      \
+      HSW_SRC_A(j, src)                                                                                     \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rg[set_][j]) : "v"(src) : "memory");           \
+    }                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < B_NI; ++j) {                                                      \
+      HSW_SRC_B(j, src)                                                                                     \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rg[set_][A_NI + j]) : "v"(src) : "memory");    \
+    }                                                                                                       \
+    pst += HSW_BK;                                                                                          \
+  } while (0)
+#define HSW_STORE(set_, buf_)                                                                               \
+  do {                                                                                                      \
+    HTT* As_ = ring + (buf_) * STAGE;                                                                       \
+    HTT* Bs_ = As_ + A_SZ;                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < A_NI; ++j) {                                                      \
+      asm volatile("" : "+v"(rg[set_][j]));                                                                 \
+      *reinterpret_cast<V8*>(As_ + (wave * A_NI + j) * A_RPI * BM + lane * 8) = rg[set_][j];                \
+    }                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < B_NI; ++j) {                                                      \
+      asm volatile("" : "+v"(rg[set_][A_NI + j]));                                                          \
+      *reinterpret_cast<V8*>(Bs_ + (wave * B_NI + j) * B_RPI * BN + lane * 8) = rg[set_][A_NI + j];         \
+    }                                                                                                       \
   } while (0)
 
   // ---- fragment addressing (bytes inside a tile): group gq = lane >> 4 reads rows 8 (gq >> 1) + 4 half + (i >> 2) of the
@@ -547,27 +588,9 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (HTT)1.0f;
 
-#pragma unroll
-  for (int s = 0; s < D; ++s)
-    if (s < n_st) HSW_ISSUE(s);
-  int cur = 0;
-  for (int t = 0; t < n_st; ++t) {
-    if (n_st - 1 - t >= D - 1) {
-      if (NLD * (D - 1) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (NLD * (D - 1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (NLD * (D - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (NLD * (D - 1) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (t + D < n_st) HSW_ISSUE(cur == 0 ? NBUF - 1 : cur - 1);
-    const char* As = reinterpret_cast<const char*>(ring + cur * STAGE);
-    const char* Bs = As + A_SZ * 2;
-    // fragments of k-step s + 1 are read (transposing LDS reads) while the MFMAs of k-step s issue: two register sets,
-    // regions pinned with sched_barrier (round 4; before, every MFMA pair sat behind an s_waitcnt lgkmcnt(0))
-    hs_s16x8 ar[2][TM], br[2][TN];
+  // the MFMA phase of one stage out of LDS slot slot_: fragments of k-step s + 1 are read (transposing LDS reads) while the MFMAs
+  // of k-step s issue: two register sets, regions pinned with sched_barrier (round 4; before, every MFMA pair sat behind an
+  // s_waitcnt lgkmcnt(0))
 #define HSW_FRAG(set_, s_)                                                                                      \
     _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                             \
       const int row = 16 * (s_) + 4 * h + frow;                                                                 \
@@ -582,30 +605,78 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
         _Pragma("unroll") for (int e = 0; e < 4; ++e) br[set_][tn][4 * h + e] = v[e];                            \
       }                                                                                                         \
     }
-    HSW_FRAG(0, 0)
-#pragma unroll
-    for (int s = 0; s < HSW_BK / 16; ++s) {
-      const int fc = s & 1;
-      if (s + 1 < HSW_BK / 16) { HSW_FRAG(fc ^ 1, s + 1) }
-      __builtin_amdgcn_sched_barrier(0);
-      V8 a[TM], b[TN];
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) a[tm] = __builtin_bit_cast(V8, ar[fc][tm]);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) b[tn] = __builtin_bit_cast(V8, br[fc][tn]);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[tm], b[tn], acc[tm][tn]);
-      if (do_col) {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) hs_mfma_vgpr<DT>(cacc[tn], ones, b[tn]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+#define HSW_MMA(slot_)                                                                                          \
+  do {                                                                                                          \
+    const char* As = reinterpret_cast<const char*>(ring + (slot_) * STAGE);                                     \
+    const char* Bs = As + A_SZ * 2;                                                                             \
+    hs_s16x8 ar[2][TM], br[2][TN];                                                                              \
+    HSW_FRAG(0, 0)                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < HSW_BK / 16; ++s) {                                                   \
+      const int fc = s & 1;                                                                                     \
+      if (s + 1 < HSW_BK / 16) { HSW_FRAG(fc ^ 1, s + 1) }                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      V8 a[TM], b[TN];                                                                                          \
+      _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) a[tm] = __builtin_bit_cast(V8, ar[fc][tm]);             \
+      _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) b[tn] = __builtin_bit_cast(V8, br[fc][tn]);             \
+      _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                         \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = HT<DT>::mfma(a[tm], b[tn], acc[tm][tn]); \
+      if (do_col) {                                                                                             \
+        _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) hs_mfma_vgpr<DT>(cacc[tn], ones, b[tn]);              \
+      }                                                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }                                                                                                           \
+  } while (0)
+  if constexpr (RS == 4) {
+    // stage s lives in register set s % 4 and LDS slot s % 2.  Prologue: four stages requested, stage 0 stored.
+    if (n_st > 0) HSW_LOAD(0);
+    if (n_st > 1) HSW_LOAD(1);
+    if (n_st > 2) HSW_LOAD(2);
+    if (n_st > 3) HSW_LOAD(3);
+    if (n_st > 0) {
+      if (n_st > 3) hs_wait_vm<3 * NLD>(); else if (n_st == 3) hs_wait_vm<2 * NLD>(); else if (n_st == 2) hs_wait_vm<NLD>(); else hs_wait_vm<0>();
+      HSW_STORE(0, 0);
     }
-#undef HSW_FRAG
+    // iteration t (set_ = t % 4, literal): [barrier] request stage t + 4 into the set stage t left, multiply stage t, then await
+    // stage t + 1 (requested three iterations ago; up to three younger stages stay in flight) and store it into the other slot
+#define HSW_STAGE_R(set_, t_)                                                                               \
+  do {                                                                                                      \
+    const int t = (t_);                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                         \
+    if (t + 4 < n_st) HSW_LOAD(set_);                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    HSW_MMA((set_) & 1);                                                                                    \
+    if (t + 1 < n_st) {                                                                                     \
+      const int younger = n_st - t - 2;                                                                     \
+      if (younger >= 3) hs_wait_vm<3 * NLD>(); else if (younger == 2) hs_wait_vm<2 * NLD>();                \
+      else if (younger == 1) hs_wait_vm<NLD>(); else hs_wait_vm<0>();                                       \
+      HSW_STORE(((set_) + 1) & 3, ((set_) + 1) & 1);                                                        \
+    }                                                                                                       \
+  } while (0)
+    int t4 = 0;
+    for (; t4 + 4 <= n_st; t4 += 4) { HSW_STAGE_R(0, t4); HSW_STAGE_R(1, t4 + 1); HSW_STAGE_R(2, t4 + 2); HSW_STAGE_R(3, t4 + 3); }
+    if (t4 < n_st) HSW_STAGE_R(0, t4);
+    if (t4 + 1 < n_st) HSW_STAGE_R(1, t4 + 1);
+    if (t4 + 2 < n_st) HSW_STAGE_R(2, t4 + 2);
+#undef HSW_STAGE_R
+  } else {
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < n_st) HSW_ISSUE(s);
+  int cur = 0;
+  for (int t = 0; t < n_st; ++t) {
+    if (n_st - 1 - t >= D - 1) hs_wait_vm<NLD * (D - 1)>(); else hs_wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t + D < n_st) HSW_ISSUE(cur == 0 ? NBUF - 1 : cur - 1);
+    HSW_MMA(cur);
     cur = (cur + 1 == NBUF) ? 0 : cur + 1;
   }
+  }
+#undef HSW_MMA
+#undef HSW_FRAG
+#undef HSW_STORE
+#undef HSW_LOAD
+#undef HSW_SRC_B
+#undef HSW_SRC_A
 #undef HSW_ISSUE
   const int l31 = lane & 31, rbase = 4 * (lane >> 5);
   if (do_col) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last column-sum MFMA (inline asm: no hazard tracking) has written back

@@ -31,6 +31,9 @@ LAYERS = [
 dev = torch.device('cuda:0')
 if bgs:
     K.set_option('hs_bg', bgs[0])
+for a in sys.argv:
+    if a.startswith('--rs='):      # hs_wg_rs: weight-gradient tiles through registers (1) / LDS-DMA (0)
+        K.set_option('hs_wg_rs', int(a[5:]))
 _, tdt = K.half_type(storage)
 lib = K._lib.load()
 
@@ -73,7 +76,7 @@ def main():
             tot[i] += t
             row += ' %s %6.1f us %5.0f TF %4.2f TB/s %-14s|' % (op, t, fl / t / 1e6, by / t / 1e6, kn[kn.index('<') + 4:-1] if '<' in kn else kn)
             if sweep:
-                cfgs = ((64, 64, 0), (64, 128, 0), (64, 256, 0), (128, 64, 0), (128, 128, 0), (256, 128, 0)) if op != 'wgr' else \
+                cfgs = ((64, 64, 0), (64, 128, 0), (128, 64, 0), (128, 128, 0), (256, 128, 0)) if op != 'wgr' else \
                     ((64, 64, 0), (64, 64, 2), (64, 64, 4), (64, 64, 8), (64, 64, 16), (128, 128, 0), (128, 128, 4), (128, 128, 8), (128, 128, 16))
                 for bm, bn, sp in cfgs:
                     lib.lmh_conv2d_force_config(bm, bn, sp)

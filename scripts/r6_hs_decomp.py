@@ -16,8 +16,8 @@ LAYERS = [('b3 1x1 1024->256', 50, 84, 1024, 256, 1, False), ('b3 3x3 256->256',
           ('b3 1x1 256->1024 (+res)', 50, 84, 256, 1024, 1, True), ('b2 1x1 512->128', 100, 167, 512, 128, 1, False),
           ('b2 3x3 128->128', 100, 167, 128, 128, 3, False), ('b2 1x1 128->512 (+res)', 100, 167, 128, 512, 1, True),
           ('rpn 3x3 1024->512', 50, 84, 1024, 512, 3, False)]
-PARTS = [('full', 0), ('-residual read', 1), ('-stores', 2), ('-epilogue mem', 3), ('-loads', 8), ('-MFMA', 16), ('-loads -MFMA', 24),
-         ('-main loop', 4), ('nothing', 7)]
+PARTS = [('full', 0), ('-residual read', 1), ('-stores', 2), ('-epilogue mem', 3), ('-A loads', 8), ('-B loads', 32), ('-A -B loads', 40),
+         ('-MFMA', 16), ('-loads -MFMA', 56), ('-main loop', 4), ('nothing', 7)]
 
 
 def timeit(fn):

@@ -197,7 +197,7 @@ def test_hs_convolution_kernels(K, case, storage):
 @pytest.mark.parametrize('storage', ['f16', 'bf16'])
 @pytest.mark.parametrize('case', [HS_CASES[1], HS_CASES[2], HS_CASES[5], HS_CASES[6], (2, 9, 11, 64, 64, 1, 1, 1, 'SAME', 'relu')])
 def test_hs_tiles_and_b_paths_agree_bit_for_bit(K, case, storage):
-    """Every tile (64 x 64 / 128 / 256, 128 x 64 / 128, 256 x 128) and both routes of the B operand (hs_bg = 1: fragments straight from
+    """Every tile (64 x 64 / 128, 128 x 64 / 128, 256 x 128) and both routes of the B operand (hs_bg = 1: fragments straight from
     global memory into registers; 0: through the LDS ring) multiply the same fragments in the same order: the 16-bit results,
     the fp32 results and the activation masks are the same bits.  (A single-stage reduction, odd row counts, tiles wider than
     the layer and the 16-stage block3 shape are among the cases.)"""
@@ -230,7 +230,7 @@ def test_hs_tiles_and_b_paths_agree_bit_for_bit(K, case, storage):
         ref = None
         for bg in (1, 0):
             K.set_option('hs_bg', bg)
-            for bm, bn in ((0, 0), (64, 64), (64, 128), (64, 256), (128, 64), (128, 128), (256, 128)):      # (64-row wide tiles: hs_bg = 1 only, else 64 x 64)
+            for bm, bn in ((0, 0), (64, 64), (64, 128), (128, 64), (128, 128), (256, 128)):      # (64-row wide tiles: hs_bg = 1 only, else 64 x 64)
                 lib.lmh_conv2d_force_config(bm, bn, 0)
                 out = run()
                 if ref is None:
