@@ -39,8 +39,8 @@ static const lmh_option g_option_defaults[] = {
     {"wg_slots", 512},        // ... its block count target
     {"wino_m", 4},            // Winograd output tile: 4 = F(4x4,3x3) (round 3 default), 2 = F(2x2,3x3)
     {"hs_slab_cap", 2},       // half-storage weight gradient: split-K slabs stay within this multiple of the operand bytes (0: no cap)
-    {"hs_wg_tile", 0},        // half-storage 1x1 weight gradient tile: 0 = 128 x 128 when both channel counts reach it, 64 / 128 = forced (64: a quarter
-                              // of the split-K slab bytes, f16 step 3.60 -> 3.67 ms: profiles/r06_ab.md)
+    {"hs_wg_tile", 0},        // half-storage weight gradient tile of the 1x1 layers: 0 / 64 = 64 x 64 (round 6, with hs_wg_rs: a quarter of the split-K slab bytes and
+                              // faster, profiles/r06_ab.md); 128 = 128 x 128 when both channel counts reach it (rounds 3-5)
     {"hs_bg", 1},             // half-storage forward / backward data: B fragments straight from global memory into registers (conv_hs.h, BG); 0: through
                               // the LDS ring like A
     {"hs_wg_rs", 1},          // half-storage weight gradient: tiles through registers + ds_write_b128 (k_wgrad_hs_tr RS = 4); 0: LDS-DMA instructions

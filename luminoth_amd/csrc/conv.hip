@@ -949,17 +949,20 @@ extern "C" int lmh_conv2d_bwd_data_hs(const lmh_conv_desc* d, const void* g, con
   return hs_launch<true>(d, g, w_bwd, e, (hipStream_t)stream);
 }
 
-// Plan of k_wgrad_hs_tr (stages of 64 pixels): square tiles, 128 x 128 when both channel counts reach it (half the L2
-// traffic per FLOP of 64 x 64), as many pixel splits as fill the resident-block slots once with >= 4 stages per block.
+// Plan of k_wgrad_hs_tr (stages of 64 pixels): 64 x 64 tiles, as many pixel splits as fill the resident-block slots once with
+// >= 4 stages per block.  Rounds 3-5 took 128 x 128 tiles when both channel counts reach it (half the L2 traffic per FLOP): with
+// the tiles going through registers (RS = 4) the small tiles are as fast or faster on every layer alone (RPN 3x3 240 -> 173 us, block2
+// 3x3/2 18 -> 11 us, the 1x1 layers within 1 us; scripts/bench_conv_hs.py --sweep); for the 1x1 layers a block carries a quarter of the split-K slab
+// bytes (the slabs are splits x |dW| fp32 bytes written here and read again by the tail — for a fixed number
+// of blocks that is blocks x tile area), and the f16 step gains 1 % (3.20 -> 3.17 ms).  hs_wg_tile = 128: the old rule.
 static bool wgrad_hs_plan(const lmh_conv_desc* d, int* bm, int* bn, int* splits, int* kt_per_split) {
   if (!((d->compute == 1 || d->compute == 2) && (d->C % 64) == 0 && (d->K % 64) == 0)) return false;
-  *bm = *bn = (d->C >= 128 && d->K >= 128) ? 128 : 64;
   const bool gather = d->R * d->S > 1 || d->stride > 1;
-  // round 6: the split-K slabs are splits x |dW| fp32 bytes written here and read again by the tail; for a
-  // fixed number of blocks that is blocks x tile area, so 64 x 64 tiles carry a quarter of the slab bytes of 128 x 128 ones
-  // (and twice the operand traffic, which L2 absorbs).  hs_wg_tile: 0 = the rule above, 64 / 128 = that tile for the 1x1 layers
   const int wt = lmh_opt("hs_wg_tile");
-  if (!gather && (wt == 64 || (wt == 128 && d->C >= 128 && d->K >= 128))) *bm = *bn = wt;
+  // (the gathered layers keep 128 x 128: alone the RPN 3x3 is faster in 64 x 64 blocks, 173 against 240 us, but its 2304 blocks at
+  // three per CU then sit on every CU beside the proposal chain — the chain ends 0.2 ms later and the f16 step is 3.28 instead
+  // of 3.17 ms, scripts/ab.sh on one box)
+  *bm = *bn = ((wt == 128 || gather) && d->C >= 128 && d->K >= 128) ? 128 : 64;
   if (g_force_bm && g_force_bn) *bm = *bn = (g_force_bm >= 128 && g_force_bn >= 128) ? 128 : 64;
   const int64_t tiles = (int64_t)d->R * d->S * ((d->C + *bm - 1) / *bm) * ((d->K + *bn - 1) / *bn);
   const int64_t P = (int64_t)d->N * d->OH * d->OW;

@@ -244,31 +244,42 @@ def test_hs_tiles_and_b_paths_agree_bit_for_bit(K, case, storage):
 
 @pytest.mark.parametrize('storage', ['f16', 'bf16'])
 @pytest.mark.parametrize('case', [(2, 50, 84, 512, 256), (2, 17, 23, 128, 64)])
-def test_hs_small_wgrad_tile_option(K, case, storage):
-    """hs_wg_tile = 64: 64 x 64 tiles for the 1x1 weight gradient (a quarter of the split-K slab bytes for the same block
-    count; another split count, so the fp32 summation order differs: 1e-5 of the scale)."""
+def test_hs_wgrad_tile_and_route_options(K, case, storage):
+    """The weight gradient under its options: 64 x 64 tiles (default since round 6: a quarter of the split-K slab bytes for the
+    same block count) against hs_wg_tile = 128 (rounds 3-5: another split count, so the fp32 summation order differs: 1e-5 of the
+    scale), and the tiles through registers (hs_wg_rs = 1, default) against LDS-DMA instructions (0): the same LDS image, the
+    same MFMAs — the same bits."""
     N, H, W, C, Kc = case
     tdt = TORCH_DT[storage]
     rs = np.random.RandomState(77)
     x = T(rs.randn(N, H, W, C).astype(F)).to(tdt)
     g = T((rs.randn(N, H, W, Kc) * 0.05).astype(F)).to(tdt)
     d = K.conv_desc(x.shape, (1, 1, C, Kc), 1, 1, 'SAME', 'relu', storage)
+    d3 = K.conv_desc(x.shape, (3, 3, C, Kc), 1, 1, 'SAME', 'relu', storage)
 
-    def run():
+    def run(dd):
         cs = torch.zeros((Kc,), device=dev())
-        dw = K.conv2d_bwd_weight_hs(d, x, g, 1.0 / 256, colsum=cs)
+        dw = K.conv2d_bwd_weight_hs(dd, x, g, 1.0 / 256, colsum=cs)
         torch.cuda.synchronize()
         return dw.clone(), cs.clone()
-    old = K.get_option('hs_wg_tile')
+    old, old_rs = K.get_option('hs_wg_tile'), K.get_option('hs_wg_rs')
     try:
-        K.set_option('hs_wg_tile', 0)
-        dw0, cs0 = run()
-        K.set_option('hs_wg_tile', 64)
-        dw2, cs2 = run()
-        assert float((dw2 - dw0).abs().max()) <= 1e-5 * float(dw0.abs().max())
-        assert float((cs2 - cs0).abs().max()) <= 1e-5 * float(cs0.abs().max())
+        for dd in (d, d3):
+            K.set_option('hs_wg_tile', 0)
+            K.set_option('hs_wg_rs', 1)
+            dw0, cs0 = run(dd)
+            K.set_option('hs_wg_rs', 0)
+            dw1, cs1 = run(dd)
+            assert torch.equal(dw1, dw0) and torch.equal(cs1, cs0)
+            for rs_ in (1, 0):
+                K.set_option('hs_wg_rs', rs_)
+                K.set_option('hs_wg_tile', 128)
+                dw2, cs2 = run(dd)
+                assert float((dw2 - dw0).abs().max()) <= 1e-5 * float(dw0.abs().max())
+                assert float((cs2 - cs0).abs().max()) <= 1e-5 * float(cs0.abs().max())
     finally:
         K.set_option('hs_wg_tile', old)
+        K.set_option('hs_wg_rs', old_rs)
 
 
 def test_hs_entry_points_refuse_what_they_do_not_take(K):
