@@ -39,7 +39,7 @@ static const lmh_option g_option_defaults[] = {
     {"wg_slots", 512},        // ... its block count target
     {"wino_m", 4},            // Winograd output tile: 4 = F(4x4,3x3) (round 3 default), 2 = F(2x2,3x3)
     {"hs_slab_cap", 2},       // half-storage weight gradient: split-K slabs stay within this multiple of the operand bytes (0: no cap)
-    {"hs_wg_tile", 0},        // half-storage weight gradient tile of the 1x1 layers: 0 / 64 = 64 x 64 (round 6, with hs_wg_rs: a quarter of the split-K slab bytes and
+    {"hs_wg_tile", 0},        // half-storage weight gradient tile of the 1x1 layers: 0 / 64 = 64 x 64 (round 6, with hs_wg_rs: half the split-K slab bytes of a layer and
                               // faster, profiles/r06_ab.md); 128 = 128 x 128 when both channel counts reach it (rounds 3-5)
     {"hs_bg", 1},             // half-storage forward / backward data: B fragments straight from global memory into registers (conv_hs.h, BG); 0: through
                               // the LDS ring like A

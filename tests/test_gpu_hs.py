@@ -245,8 +245,8 @@ def test_hs_tiles_and_b_paths_agree_bit_for_bit(K, case, storage):
 @pytest.mark.parametrize('storage', ['f16', 'bf16'])
 @pytest.mark.parametrize('case', [(2, 50, 84, 512, 256), (2, 17, 23, 128, 64)])
 def test_hs_wgrad_tile_and_route_options(K, case, storage):
-    """The weight gradient under its options: 64 x 64 tiles (default since round 6: a quarter of the split-K slab bytes for the
-    same block count) against hs_wg_tile = 128 (rounds 3-5: another split count, so the fp32 summation order differs: 1e-5 of the
+    """The weight gradient under its options: 64 x 64 tiles (default since round 6: a quarter of the split-K slab bytes per
+    block) against hs_wg_tile = 128 (rounds 3-5: another split count, so the fp32 summation order differs: 1e-5 of the
     scale), and the tiles through registers (hs_wg_rs = 1, default) against LDS-DMA instructions (0): the same LDS image, the
     same MFMAs — the same bits."""
     N, H, W, C, Kc = case
