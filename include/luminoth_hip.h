@@ -43,7 +43,7 @@ extern "C" {
 typedef void* lmh_stream_t; /* hipStream_t */
 
 /* Tuning options (defaults are the measured best on MI355X).  Names: bd_parity_small, half_pf, x3_tile_slots, x3_pf,
- * x3_pf_fwd, x3_pf_gb, x3_pf_bd, x3_pf_bw, x3_new, x3_pipe, x3_stagger, x3_bw_slots, bd_slots, bw_slots, wgrad_glds, wg_slots, wino_m,
+ * x3_pf_fwd, x3_pf_gb, x3_pf_bd, x3_pf_bw, x3_new, x3_wg_plain, x3_pipe, x3_stagger, x3_bw_slots, bd_slots, bw_slots, wgrad_glds, wg_slots, wino_m,
  * hs_slab_cap, hs_wg_tile, hs_wg_rs, hs_bg, nms_stage_mult, head_gemm, conv_pp, roi_cs, roi_mean_cs (csrc/api.hip documents each).  Unknown name:
  * LMH_ERR_INVALID.
  * Re-entrancy (round 6): lmh_set_option sets the value for the CALLING THREAD only — two threads that drive two models

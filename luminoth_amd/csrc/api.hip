@@ -32,6 +32,7 @@ static const lmh_option g_option_defaults[] = {
                               // against 6.60 — the pipelined blocks need a whole CU and shut the other streams' kernels out);
                               // 1 = software-pipelined, one block per CU
     {"x3_stagger", 0},        // phase-by-phase schedule: the block in a CU's second LDS slot starts this many x 64 cycles late (no effect measured)
+    {"x3_wg_plain", 1},       // bf16x3 weight gradient of 1x1 / stride-1 layers and stacked Winograd GEMMs: no pixel decode in the loader
     {"x3_new", 1},            // bf16x3: the kernels of round 6 (conv_x3.h: fused mask epilogues); 0: the round-2 kernels (conv_half.h)
     {"bd_slots", 256},        // resident-block slots the backward-data tile choice fills
     {"bw_slots", 512},        // ... the split-K weight gradient

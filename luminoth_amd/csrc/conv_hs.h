@@ -505,6 +505,12 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
     b_cok[j] = b_col[j] < K;
   }
   int pst = kt_begin * HSW_BK;           // first pixel of the next stage to issue
+  const HTT* xrow[A_NI];
+  const HTT* grow[B_NI];
+#pragma unroll
+  for (int j = 0; j < A_NI; ++j) xrow[j] = x + (size_t)(pst + a_row[j]) * C + a_col[j];
+#pragma unroll
+  for (int j = 0; j < B_NI; ++j) grow[j] = g + (size_t)(pst + b_row[j]) * K + b_col[j];
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* glb_ptr;
   // source of instruction j of this wave for the stage at `pst` (the zero page for rows / channels outside)
@@ -518,11 +524,19 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
         if (a_cok[j] && n < (unsigned)d.N && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W)  \
           src = x + ((size_t)((int)n * d.H + ih) * d.W + iw) * C + a_col[j];                                \
       } else if (a_cok[j] && (int)p < P) {                                                                  \
-        src = x + (size_t)p * C + a_col[j];                                                                 \
+        src = xrow[j];                                                                                      \
       }
 #define HSW_SRC_B(j, src)                                                                                   \
       const int p = pst + b_row[j];                                                                         \
-      const HTT* src = (b_cok[j] && p < P) ? g + (size_t)p * K + b_col[j] : zero;
+      const HTT* src = (b_cok[j] && p < P) ? grow[j] : zero;
+  // running row pointers of the un-gathered operands (advanced with pst: a 64-bit add per instruction and stage instead of a
+  // quarter-rate 64-bit multiply-add)
+#define HSW_ADVANCE()                                                                                       \
+  do {                                                                                                      \
+    pst += HSW_BK;                                                                                          \
+    if (!GATHER) { _Pragma("unroll") for (int j = 0; j < A_NI; ++j) xrow[j] += (size_t)HSW_BK * C; }        \
+    _Pragma("unroll") for (int j = 0; j < B_NI; ++j) grow[j] += (size_t)HSW_BK * K;                         \
+  } while (0)
 #define HSW_ISSUE(buf_)                                                                                     \
   do {                                                                                                      \
     HTT* As_ = ring + (buf_) * STAGE;                                                                       \
@@ -535,7 +549,7 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
       HSW_SRC_B(j, src)                                                                                     \
       __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(Bs_ + (wave * B_NI + j) * B_RPI * BN), 16, 0, 0); \
     }                                                                                                       \
-    pst += HSW_BK;                                                                                          \
+    HSW_ADVANCE();                                                                                          \
   } while (0)
   // RS: the same 16 bytes per lane into register set set_ (literal) / from that set into LDS slot buf_ (the lane-linear image the
   // LDS-DMA instruction writes).  Inline asm loads: the waits are counted by hand (vector-memory loads return in order), and the
@@ -551,7 +565,7 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
       HSW_SRC_B(j, src)                                                                                     \
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rg[set_][A_NI + j]) : "v"(src) : "memory");    \
     }                                                                                                       \
-    pst += HSW_BK;                                                                                          \
+    HSW_ADVANCE();                                                                                          \
   } while (0)
 #define HSW_STORE(set_, buf_)                                                                               \
   do {                                                                                                      \
@@ -675,6 +689,7 @@ k_wgrad_hs_tr(lmh_conv_desc d, const typename HT<DT>::T* __restrict__ x, const t
 #undef HSW_FRAG
 #undef HSW_STORE
 #undef HSW_LOAD
+#undef HSW_ADVANCE
 #undef HSW_SRC_B
 #undef HSW_SRC_A
 #undef HSW_ISSUE

@@ -951,7 +951,8 @@ k_x3_bwd_data_ws(lmh_conv_desc d, const float* __restrict__ dy, const uint4* __r
 //   GB: the R*S "taps" are independent GEMMs stacked in x / g (Winograd weight gradient).
 //   colpart (not GB): [splits][K] per-channel sums of g by the blocks of tile column bx == 0, off the matrix pipe.
 // ============================================================================
-template <int BM, int BN, bool GB, int PIPE>
+//   PLAIN (host-checked: stride 1, no padding, OH x OW == H x W, one tap or GB): see `load` below.
+template <int BM, int BN, bool GB, int PIPE, bool PLAIN = false>
 __global__ void __launch_bounds__(256, (PIPE && (BM + BN) > 128) ? 1 : 2)
 k_x3_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ out,
                 int kt_per_split, lmh_fastdiv div_ow, lmh_fastdiv div_oh, int tiles_x, int tiles_y, int splits,
@@ -1000,8 +1001,26 @@ k_x3_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __res
   constexpr int dbg = 0;
 #endif
   f32x4 ra[2][4], rb[2][4];
+  // PLAIN: the source pixel of x IS the output pixel (1x1 / stride-1 layers, the stacked GEMMs of a Winograd weight gradient) —
+  // no decode, and both operands are walked with pointers that advance by one stage.  The decode below is two magic-number
+  // divisions, the bounds and a 64-bit address product per pixel: 46 quarter-rate integer instructions per thread and stage
+  // (v_mul_lo / v_mul_hi / v_mad_u64: ISA check, round 6), as many issue cycles as the split itself — and for 23 + 10 of the
+  // 33 weight-gradient launches of the ResNet-50 step it is the identity.  Same addresses, same bits.
+  const float* xpp = xb + (size_t)p0 * C;
+  const float* gpp = gb + (size_t)p0 * K;
   auto load = [&](auto S) {
     constexpr int s_ = decltype(S)::value;
+    if constexpr (PLAIN) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool inp = (unsigned)(p0 + i) < p_end;
+        const float* pa_ = (a_ok && inp && !(dbg & 4)) ? xpp + (size_t)i * C : lmh_zero_page;
+        if (A_ALL || a_act) ra[s_][i] = *reinterpret_cast<const f32x4*>(pa_);
+        const float* pb_ = (b_ok && inp && !(dbg & 4)) ? gpp + (size_t)i * K : lmh_zero_page;
+        if (B_ALL || b_act) rb[s_][i] = *reinterpret_cast<const f32x4*>(pb_);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned p = (unsigned)(p0 + i);
@@ -1012,11 +1031,11 @@ k_x3_bwd_weight(lmh_conv_desc d, const float* __restrict__ x, const float* __res
       const float* pa_ = (oka && !(dbg & 4)) ? xb + ((size_t)((int)n * d.H + ih) * d.W + iw) * C : lmh_zero_page;
       if (A_ALL || a_act) ra[s_][i] = *reinterpret_cast<const f32x4*>(pa_);
       const bool okb = b_ok && p < p_end;
-      const float* pb_ = (okb && !(dbg & 4)) ? gb + (size_t)p * K : lmh_zero_page;
+      const float* pb_ = (okb && !(dbg & 4)) ? gpp + (size_t)i * K : lmh_zero_page;
       if (B_ALL || b_act) rb[s_][i] = *reinterpret_cast<const f32x4*>(pb_);
     }
   };
-  auto advance = [&]() { p0 += BK; };   // past the split's end (p_end): the zero page
+  auto advance = [&]() { p0 += BK; xpp += (size_t)BK * C; gpp += (size_t)BK * K; };   // past the split's end (p_end): the zero page
   auto store_a = [&](int buf, auto S) {
     constexpr int s_ = decltype(S)::value;
     if ((A_ALL || a_act) && !(dbg & 2)) st_km<3>(As + buf * A_BUF, A_SZ, 4 * cq, kq, ra[s_]);

@@ -60,14 +60,21 @@ int lmh_x3_bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
   const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
   const int nblk = tiles_x * tiles_y * splits;
   const int sg = lmh_opt("x3_stagger");
+  // source pixel == output pixel for every tap of the launch (k_x3_bwd_weight PLAIN; x3_wg_plain = 0: the general decode)
+  const bool plain = lmh_opt("x3_wg_plain") != 0 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->OH == d->H &&
+                     d->OW == d->W && (gb || d->R * d->S == 1);
 #define X3_BW(BM_, BN_)                                                                                               \
   do {                                                                                                                \
     if (gb && pipe) lmh_launch((k_x3_bwd_weight<BM_, BN_, true, 1>), dim3(nblk), dim3(256), 0, st, *d, x, g, out,     \
                                kt_per_split, dvw, dvh, tiles_x, tiles_y, splits, (float*)nullptr, sg);                    \
+    else if (gb && plain) lmh_launch((k_x3_bwd_weight<BM_, BN_, true, 0, true>), dim3(nblk), dim3(256), 0, st, *d, x, \
+                                     g, out, kt_per_split, dvw, dvh, tiles_x, tiles_y, splits, (float*)nullptr, sg);      \
     else if (gb) lmh_launch((k_x3_bwd_weight<BM_, BN_, true, 0>), dim3(nblk), dim3(256), 0, st, *d, x, g, out,        \
                             kt_per_split, dvw, dvh, tiles_x, tiles_y, splits, (float*)nullptr, sg);                       \
     else if (pipe) lmh_launch((k_x3_bwd_weight<BM_, BN_, false, 1>), dim3(nblk), dim3(256), 0, st, *d, x, g, out,     \
                               kt_per_split, dvw, dvh, tiles_x, tiles_y, splits, colpart, sg);                             \
+    else if (plain) lmh_launch((k_x3_bwd_weight<BM_, BN_, false, 0, true>), dim3(nblk), dim3(256), 0, st, *d, x, g,   \
+                               out, kt_per_split, dvw, dvh, tiles_x, tiles_y, splits, colpart, sg);                       \
     else lmh_launch((k_x3_bwd_weight<BM_, BN_, false, 0>), dim3(nblk), dim3(256), 0, st, *d, x, g, out, kt_per_split, \
                     dvw, dvh, tiles_x, tiles_y, splits, colpart, sg);                                                     \
   } while (0)
