@@ -731,7 +731,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     if (lmh_opt("x3_new")) {
       prof_begin(st);
       const int rc3 = lmh_x3_bwd_weight_launch(d, x, dy, out, kps, (int)grid.x, (int)grid.y, (int)grid.z, nullptr, true, bm, bn, x3_pipe(2), st);
-      prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, true, %d>", bm, bn, x3_pipe(2));
+      prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, true, %d, %s>", bm, bn, x3_pipe(2), lmh_x3_bwd_weight_plain(d, true, x3_pipe(2)) ? "true" : "false");
       if (rc3) return rc3;
       if (splits > 1 && g_gb_slabs.want) {
         g_gb_slabs.slabs = reinterpret_cast<const float*>(ws);
@@ -800,7 +800,7 @@ static int bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float
     else LAUNCH_BW_HT(64, 64);
 #undef LAUNCH_BW_HT
 #undef LAUNCH_BW_H
-    if (d->compute == 3 && lmh_opt("x3_new")) prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, false, %d>", bm, bn, x3_pipe(2));
+    if (d->compute == 3 && lmh_opt("x3_new")) prof_end(st, desc_flops(d), "k_x3_bwd_weight<%d, %d, false, %d, %s>", bm, bn, x3_pipe(2), lmh_x3_bwd_weight_plain(d, false, x3_pipe(2)) ? "true" : "false");
     else prof_end(st, desc_flops(d), "k_conv_bwd_weight_h<%d, %d, %d>", d->compute, bm, bn);
     if (g_lmh_defer_tail) {
       g_lmh_last_plan.slabs = splits > 1 ? reinterpret_cast<const float*>(ws) : nullptr;

@@ -54,15 +54,20 @@ int lmh_x3_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const float*
   return LMH_OK;
 }
 
+// source pixel == output pixel for every tap of the launch: the PLAIN instantiation of k_x3_bwd_weight (x3_wg_plain = 0: the general
+// decode); also what the profile name of the launch says (conv.hip)
+bool lmh_x3_bwd_weight_plain(const lmh_conv_desc* d, bool gb, int pipe) {
+  return !pipe && lmh_opt("x3_wg_plain") != 0 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->OH == d->H &&
+         d->OW == d->W && (gb || d->R * d->S == 1);
+}
+
 int lmh_x3_bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float* g, float* out, int kt_per_split,
                              int tiles_x, int tiles_y, int splits, float* colpart, bool gb, int bm, int bn,
                              int pipe, hipStream_t st) {
   const lmh_fastdiv dvw = lmh_make_fastdiv((uint32_t)d->OW), dvh = lmh_make_fastdiv((uint32_t)d->OH);
   const int nblk = tiles_x * tiles_y * splits;
   const int sg = lmh_opt("x3_stagger");
-  // source pixel == output pixel for every tap of the launch (k_x3_bwd_weight PLAIN; x3_wg_plain = 0: the general decode)
-  const bool plain = lmh_opt("x3_wg_plain") != 0 && d->stride == 1 && d->pad_top == 0 && d->pad_left == 0 && d->OH == d->H &&
-                     d->OW == d->W && (gb || d->R * d->S == 1);
+  const bool plain = lmh_x3_bwd_weight_plain(d, gb, pipe);
 #define X3_BW(BM_, BN_)                                                                                               \
   do {                                                                                                                \
     if (gb && pipe) lmh_launch((k_x3_bwd_weight<BM_, BN_, true, 1>), dim3(nblk), dim3(256), 0, st, *d, x, g, out,     \

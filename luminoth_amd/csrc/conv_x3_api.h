@@ -8,6 +8,7 @@ int lmh_x3_bwd_data_launch(const lmh_conv_desc* d, const float* dy, const float*
 int lmh_x3_bwd_weight_launch(const lmh_conv_desc* d, const float* x, const float* g, float* out, int kt_per_split,
                              int tiles_x, int tiles_y, int splits, float* colpart, bool gb, int bm, int bn,
                              int pipe, hipStream_t st);
+bool lmh_x3_bwd_weight_plain(const lmh_conv_desc* d, bool gb, int pipe);   // the PLAIN instantiation is what the launch above takes
 // pipe: 0 = the round-2 schedule (one LDS buffer, two blocks per CU), 1 = software-pipelined (conv_x3.h)
 // pre-split weights (round 6): bytes of a layer's W3 planes; one launch that splits n layers; forward with them
 size_t lmh_x3_w3_bytes(int rs, int c, int k, int fwd);

@@ -28,8 +28,8 @@ STEP = ['k_conv_fwd<128, 128, false>', 'k_conv_fwd<128, 64, false>', 'k_conv_fwd
         'k_rcnn_loss_grad', 'k_rcnn_loss', 'k_skinny_bwd_data', 'k_skinny_fwd', 'k_conv_bwd_weight_gen<64, 64>',
         'k_conv_bwd_data_gen<64, 64>', 'k_roi_sample_table', 'k_roi_pool_bwd_slab<4, true>', 'k_rpn_target_rowmax',
         'k_rpn_target_labels', 'k_rpn_target_subsample', 'k_rpn_loss', 'k_rpn_loss_grad', 'k_loss_mean', 'k_l2_reg',
-        'k_sgd_momentum', 'k_conv_hs<1, 128, 64, false>', 'k_conv_hs<1, 128, 64, true>', 'k_wgrad_hs_tr<1, 128, 128, false>',
-        'k_wgrad_hs_tr<1, 128, 128, true>', 'k_maxpool_fwd_hs<1, true>', 'k_half_weights<1>', 'k_cast_to_half<1>']
+        'k_sgd_momentum', 'k_conv_hs<1, 64, 64, false, true>', 'k_conv_hs<1, 64, 64, true, true>', 'k_conv_hs<1, 128, 64, false, true>',
+        'k_wgrad_hs_tr<1, 64, 64, false, 4>', 'k_wgrad_hs_tr<1, 128, 128, true, 4>', 'k_maxpool_fwd_hs<1, true>', 'k_half_weights<1>', 'k_cast_to_half<1>']
 
 
 def demangle(names):
